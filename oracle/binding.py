@@ -1,0 +1,152 @@
+"""ctypes binding of oracle/libpalace_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never from the
+product package (palace_amd/).  Build with `make -C oracle libpalace_oracle.so`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libpalace_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("eref_oracle.c", "graph_oracle.cpp", "match_oracle.cpp")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run(["make", "-C", _HERE, "libpalace_oracle.so"], check=True, stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.orc_table_new.restype = C.c_void_p
+        L.orc_table_free.argtypes = [C.c_void_p]
+        L.orc_count_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_index_ref.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.orc_scan_ref.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_format_line.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_build_index_file.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_char_p]
+        L.orc_scan_index_file.argtypes = [C.c_char_p, C.c_void_p, C.c_float, C.c_float, C.c_char_p, C.c_size_t]
+        L.orc_scan_index_file.restype = C.c_long
+        L.orc_sample_ratio.argtypes = [C.c_int64]
+        L.orc_rand_new.restype = C.c_void_p
+        L.orc_rand_new.argtypes = [C.c_uint]
+        L.orc_rand_next.argtypes = [C.c_void_p]
+        L.orc_rand_free.argtypes = [C.c_void_p]
+        L.orc_header_to_cc.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_cc_to_header.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_cc_from_picks.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_eref_reference_dead_cost.restype = C.c_uint64
+    return _LIB
+
+
+def _p(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+def header_to_cc(header: np.ndarray) -> np.ndarray:
+    cc = np.zeros(96, dtype=np.int16)
+    h = np.ascontiguousarray(header, dtype=np.uint8)
+    lib().orc_header_to_cc(_p(h), _p(cc))
+    return cc
+
+
+def header_from_picks(picks) -> np.ndarray:
+    """400-byte index header for a choice of one of the 6 projection orders per k-mer offset."""
+    p = np.ascontiguousarray(picks, dtype=np.uint8)
+    assert p.shape == (32,) and p.max() < 6
+    cc = np.zeros(96, dtype=np.int16)
+    hdr = np.zeros(400, dtype=np.uint8)
+    lib().orc_cc_from_picks(_p(p), _p(cc))
+    lib().orc_cc_to_header(_p(cc), _p(hdr))
+    return hdr
+
+
+class CountTable:
+    """The reference's 2^32-entry byte table (extract_ref.cpp:25-26), lazily paged."""
+
+    def __init__(self):
+        self.ptr = lib().orc_table_new()
+        if not self.ptr:
+            raise MemoryError("oracle count table (4 GiB virtual)")
+        self.view = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint8)), shape=(1 << 32,))
+
+    def count(self, bases: np.ndarray, offsets: np.ndarray, cc: np.ndarray, keep: np.ndarray | None = None):
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        k = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+        lib().orc_count_reads(_p(b), _p(o), len(o) - 1, None if k is None else _p(k), _p(cc), self.ptr)
+
+    def lookup(self, keys: np.ndarray) -> np.ndarray:
+        return self.view[np.asarray(keys, dtype=np.int64)]
+
+    def free(self):
+        if self.ptr:
+            lib().orc_table_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.free()
+
+
+def index_ref(seq: np.ndarray, cc: np.ndarray) -> np.ndarray:
+    s = np.ascontiguousarray(seq, dtype=np.uint8)
+    n = max(0, len(s) - 31)
+    out = np.zeros(3 * n, dtype=np.uint32)
+    if n:
+        lib().orc_index_ref(_p(s), len(s), _p(cc), _p(out))
+    return out
+
+
+def scan_ref(idx: np.ndarray, ref_len: int, table: CountTable, hit_ratio: float, perfect_ratio: float):
+    """-> (printed, n_intervals, el, intervals[n,2])"""
+    n_int, el = C.c_int(0), C.c_int(0)
+    cap = max(4, 2 * ref_len // 500 + 4)
+    iv = np.zeros(2 * cap, dtype=np.int32)
+    i = np.ascontiguousarray(idx, dtype=np.uint32)
+    printed = lib().orc_scan_ref(_p(i), ref_len, table.ptr, hit_ratio, perfect_ratio, C.byref(n_int),
+                                 C.byref(el), _p(iv), cap)
+    return bool(printed), n_int.value, el.value, iv[: 2 * n_int.value].reshape(-1, 2).copy()
+
+
+def format_line(ref_index: int, n_int: int, el: int, ref_len: int) -> bytes:
+    buf = C.create_string_buffer(256)
+    n = lib().orc_format_line(buf, 256, ref_index, n_int, el, ref_len)
+    return buf.raw[:n]
+
+
+def build_index_file(fasta: str, header: np.ndarray, index_path: str, len_path: str) -> None:
+    h = np.ascontiguousarray(header, dtype=np.uint8)
+    rc = lib().orc_build_index_file(fasta.encode(), _p(h), index_path.encode(), len_path.encode())
+    if rc:
+        raise OSError("orc_build_index_file failed")
+
+
+def scan_index_file(index_path: str, table: CountTable, hit_ratio: float, perfect_ratio: float) -> bytes:
+    cap = 1 << 24
+    buf = C.create_string_buffer(cap)
+    n = lib().orc_scan_index_file(index_path.encode(), table.ptr, hit_ratio, perfect_ratio, buf, cap)
+    if n < 0:
+        raise OSError("orc_scan_index_file failed")
+    return buf.raw[:n]
+
+
+def sample_ratio(fq1_bases: int) -> int:
+    return lib().orc_sample_ratio(fq1_bases)
+
+
+def glibc_rand_stream(seed: int, n: int) -> np.ndarray:
+    st = lib().orc_rand_new(seed)
+    out = np.array([lib().orc_rand_next(st) for _ in range(n)], dtype=np.int64)
+    lib().orc_rand_free(st)
+    return out

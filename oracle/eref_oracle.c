@@ -1,0 +1,341 @@
+/*
+ * oracle/eref_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reference's `eref` algorithm (bin/extract_ref.cpp), written
+ * from the behaviour of that file, used as the checker in tests/, __graft_entry__.smoke() and
+ * as bench.py's cpu_baseline leg.  The product path (palace_amd/csrc, palace_amd/host) never
+ * links, loads or calls anything in this directory.
+ *
+ * Parity status: PINNED.  tests/test_oracle_eref.py checks this file against
+ * tests/golden/eref_toy.npz, which holds outputs of the compiled, unmodified reference
+ * (oracle/_ref/eref_ref; recipe oracle/Makefile, generator tests/golden/make_eref_golden.py).
+ *
+ * The restatement deliberately keeps the reference's cost structure (a 32-step inner loop per
+ * (position, channel) and a 4 GiB byte table) so that timing it is timing the reference's
+ * algorithm; only the dead 16.3 GiB `Peaks` arrays (extract_ref.cpp:1296-1299, never read) are
+ * left out unless orc_eref_reference_dead_cost() is called explicitly.
+ */
+#define _GNU_SOURCE
+#include <stdint.h>
+#include <sys/types.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define K 32
+#define NCH 3
+#define TABLE_ENTRIES (1ULL << 32)
+
+/* extract_ref.cpp:1010-1054 (generate_coder): three binary projections of a base, 5 = invalid.
+ * projection 0: A,T -> 1  C,G -> 0;  projection 1: A,C -> 1  T,G -> 0;  projection 2: A,G -> 1
+ * T,C -> 0; case-insensitive; every other byte is invalid. */
+int orc_base_code(int projection, unsigned char ch)
+{
+    int a = (ch == 'A' || ch == 'a'), c = (ch == 'C' || ch == 'c');
+    int g = (ch == 'G' || ch == 'g'), t = (ch == 'T' || ch == 't');
+    if (!(a || c || g || t)) return 5;
+    switch (projection) {
+    case 0: return a || t;
+    case 1: return a || c;
+    default: return a || g;
+    }
+}
+
+/* extract_ref.cpp:1065-1080 (generate_complement): upper-case complement, 0 for anything else. */
+unsigned char orc_complement(unsigned char ch)
+{
+    switch (ch) {
+    case 'A': case 'a': return 'T';
+    case 'T': case 't': return 'A';
+    case 'C': case 'c': return 'G';
+    case 'G': case 'g': return 'C';
+    default: return 0;
+    }
+}
+
+/* extract_ref.cpp:1104-1122 (saved_random_coder): entry j of the 100-word header, truncated to
+ * 16 bits, is choose_coder[j]; only j < 96 is ever used (32 positions x 3 channels). */
+void orc_header_to_cc(const uint8_t *hdr400, int16_t cc[96])
+{
+    for (int j = 0; j < 96; j++)
+        cc[j] = (int16_t)(hdr400[4 * j] | (hdr400[4 * j + 1] << 8));
+}
+
+/* extract_ref.cpp:680-682: each header word is a 4-byte write starting at a 2-byte element, so
+ * word j = cc[j] | cc[j+1] << 16.  Words 96..99 come from the zero-initialised static tail. */
+void orc_cc_to_header(const int16_t cc[96], uint8_t *hdr400)
+{
+    memset(hdr400, 0, 400);
+    for (int j = 0; j < 96; j++) {
+        uint32_t lo = (uint16_t)cc[j], hi = (j + 1 < 96) ? (uint16_t)cc[j + 1] : 0;
+        uint32_t w = lo | (hi << 16);
+        memcpy(hdr400 + 4 * j, &w, 4);
+    }
+}
+
+/* extract_ref.cpp:1082-1102 (random_coder): one of the six orders of (0,1,2) per k-mer position.
+ * `picks[z]` in 0..5 selects the order; the reference draws it from rand() seeded with time(0). */
+void orc_cc_from_picks(const uint8_t picks[32], int16_t cc[96])
+{
+    static const int16_t orders[18] = {0, 1, 2, 0, 2, 1, 1, 2, 0, 1, 0, 2, 2, 0, 1, 2, 1, 0};
+    for (int z = 0; z < 32; z++)
+        for (int i = 0; i < 3; i++) cc[3 * z + i] = orders[3 * picks[z] + i];
+}
+
+/* The inner loop shared by extract_ref.cpp:717-735 (reference side) and :971-994 (read side):
+ * forward index with weight 2^(31-z) at offset z, reverse-complement index built in the same
+ * pass, canonical = the smaller.  Returns 0 and *valid=0 at the first invalid base. */
+uint32_t orc_canonical_index(const unsigned char *s, const int16_t cc[96], int channel, int *valid)
+{
+    uint32_t fwd = 0, rc = 0;
+    for (int z = 0; z < K; z++) {
+        int m = orc_base_code(cc[3 * z + channel], s[z]);
+        if (m == 5) { *valid = 0; return 0; }
+        int n = orc_base_code(cc[3 * (K - 1 - z) + channel], orc_complement(s[z]));
+        fwd += (uint32_t)m << (K - 1 - z);
+        rc += (uint32_t)n << z;
+    }
+    *valid = 1;
+    return fwd < rc ? fwd : rc;
+}
+
+/* extract_ref.cpp:25-26, 1257: the 2^32-entry byte table, zeroed. */
+uint8_t *orc_table_new(void) { return (uint8_t *)calloc(TABLE_ENTRIES, 1); }
+void orc_table_free(uint8_t *t) { free(t); }
+
+/* extract_ref.cpp:961-1000 (read_fastq body for one sequence line): every position, every
+ * channel, saturating increment at least_depth = 3 (extract_ref.cpp:23, 995-996). */
+void orc_count_read(const unsigned char *s, int64_t len, const int16_t cc[96], uint8_t *table)
+{
+    for (int64_t j = 0; j + K <= len; j++)
+        for (int i = 0; i < NCH; i++) {
+            int ok;
+            uint32_t idx = orc_canonical_index(s + j, cc, i, &ok);
+            if (ok && table[idx] < 3) table[idx]++;
+        }
+}
+
+/* Phase A over a packed read set; keep[r] == 0 drops read r (the E3 subsampling decision,
+ * extract_ref.cpp:955-960), keep == NULL keeps all. */
+void orc_count_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,
+                     const uint8_t *keep, const int16_t cc[96], uint8_t *table)
+{
+    for (int64_t r = 0; r < n_reads; r++)
+        if (!keep || keep[r])
+            orc_count_read(bases + offsets[r], offsets[r + 1] - offsets[r], cc, table);
+}
+
+/* extract_ref.cpp:711-738 (read_ref, one record): 3 canonical indices per position, 0 when the
+ * k-mer holds an invalid base.  out has 3*(len-31) entries. */
+void orc_index_ref(const unsigned char *seq, int64_t len, const int16_t cc[96], uint32_t *out)
+{
+    for (int64_t j = 0; j + K <= len; j++)
+        for (int i = 0; i < NCH; i++) {
+            int ok;
+            uint32_t idx = orc_canonical_index(seq + j, cc, i, &ok);
+            out[3 * j + i] = ok ? idx : 0;
+        }
+}
+
+/* extract_ref.cpp:858-870 (read_index): hit[3j+i] = table[idx] for idx != 0 else 0; the tail
+ * (positions >= len-31) is never written by the reference -- defined as 0 here (see header of
+ * tests/golden/make_eref_golden.py).  Then extract_ref.cpp:504-617 (slide_window).
+ * Returns 1 when the reference would print the ref; fills n_intervals / el either way. */
+int orc_scan_ref(const uint32_t *idx, int64_t ref_len, const uint8_t *table, float hit_ratio,
+                 float perfect_ratio, int *n_intervals, int *el_out, int *intervals, int max_intervals)
+{
+    const int window = 500;
+    int one_min = window * hit_ratio;          /* int * float -> float -> int, as :513-514 */
+    int three_min = window * perfect_ratio;
+    int64_t npos = ref_len - K + 1;
+    uint8_t *single = (uint8_t *)calloc((size_t)ref_len + 1, 1);
+    uint8_t *trio = (uint8_t *)calloc((size_t)ref_len + 1, 1);
+    for (int64_t j = 0; j < npos; j++) {
+        int h = 0;
+        for (int i = 0; i < NCH; i++) {
+            uint32_t x = idx[3 * j + i];
+            if (x != 0 && table[x] == 3) h++;
+        }
+        single[j] = h > 0;
+        trio[j] = h == 3;
+    }
+    int one = 0, three = 0, open = 0, good = 0, frag = 0, start = 0, end = 0, prev_end = 0, el = 0;
+    int cur_start = 0;
+    for (int64_t j = 0; j < ref_len; j++) {
+        if (j < window) { one += single[j]; three += trio[j]; }
+        else { one += single[j] - single[j - window]; three += trio[j] - trio[j - window]; }
+        good = (one >= one_min) && (three >= three_min);
+        if (!open && good) {
+            start = (int)j - 2 * window;
+            if (start < 1) start = 1;
+            open = 1;
+        }
+        if (open && !good) {
+            end = (int)j + 2 * window;
+            if (end > ref_len) end = (int)ref_len;
+            if (frag > 0 && start - prev_end < window) { el += end - prev_end; prev_end = end; }
+            else { frag++; cur_start = start; el += end - start; prev_end = end; }
+            if (intervals && frag <= max_intervals) { intervals[2 * (frag - 1)] = cur_start; intervals[2 * (frag - 1) + 1] = prev_end; }
+            open = 0;
+        }
+    }
+    if (open && good) {
+        end = (int)ref_len;
+        if (frag > 0 && start - prev_end < window) { el += end - prev_end; prev_end = end; }
+        else { frag++; cur_start = start; el += end - start; prev_end = end; }
+        if (intervals && frag <= max_intervals) { intervals[2 * (frag - 1)] = cur_start; intervals[2 * (frag - 1) + 1] = prev_end; }
+    }
+    free(single);
+    free(trio);
+    *n_intervals = frag;
+    *el_out = el;
+    float ratio = (float)el / (float)ref_len;
+    return el > 0 && ratio > 0.75;
+}
+
+/* extract_ref.cpp:611-617: the stdout line.  ostream<<float at default precision == "%g". */
+int orc_format_line(char *buf, size_t cap, int ref_index, int n_intervals, int el, int ref_len)
+{
+    float ratio = (float)el / (float)ref_len;
+    return snprintf(buf, cap, "ref_index\t%d\t%d\t%d\t%d\t%g\n", ref_index, n_intervals, el, ref_len, (double)ratio);
+}
+
+/* extract_ref.cpp:1124-1148 (cal_sam_ratio): percent of reads kept; 2e9 bases target, x2 for the
+ * pair, long arithmetic then truncation to int. */
+int orc_sample_ratio(int64_t fq1_seq_bases)
+{
+    long total = (long)fq1_seq_bases * 2;
+    return (int)(100L * 2000000000L / total);
+}
+
+/* glibc srand(seed)/rand() TYPE_3 generator (the additive feedback generator documented in
+ * random_r.c: r[i] = r[i-3] + r[i-31], 310 outputs discarded, result >> 1).  Needed only when
+ * orc_sample_ratio() < 100 (extract_ref.cpp:955-960 draws rand()%100 per sequence line). */
+typedef struct { uint32_t r[34]; int f, b; } orc_rand_t;
+void orc_srand(orc_rand_t *st, unsigned seed)
+{
+    int32_t word = seed ? (int32_t)seed : 1;
+    st->r[0] = (uint32_t)word;
+    for (int i = 1; i < 31; i++) {
+        long hi = word / 127773, lo = word % 127773;
+        word = (int32_t)(16807 * lo - 2836 * hi);
+        if (word < 0) word += 2147483647;
+        st->r[i] = (uint32_t)word;
+    }
+    st->f = 3; st->b = 0;
+    for (int i = 0; i < 310; i++) {
+        st->r[st->f] += st->r[st->b];
+        st->f = (st->f + 1) % 31; st->b = (st->b + 1) % 31;
+    }
+}
+int orc_rand(orc_rand_t *st)
+{
+    st->r[st->f] += st->r[st->b];
+    int out = (int)(st->r[st->f] >> 1);
+    st->f = (st->f + 1) % 31; st->b = (st->b + 1) % 31;
+    return out;
+}
+/* flat wrappers for ctypes */
+void *orc_rand_new(unsigned seed) { orc_rand_t *s = (orc_rand_t *)malloc(sizeof *s); orc_srand(s, seed); return s; }
+int orc_rand_next(void *s) { return orc_rand((orc_rand_t *)s); }
+void orc_rand_free(void *s) { free(s); }
+
+/* extract_ref.cpp:1296-1299: the allocation + memset of the never-read Peaks arrays (16 GiB +
+ * 300 MB).  Only for an "as-shipped cost" CPU figure; returns bytes touched. */
+uint64_t orc_eref_reference_dead_cost(void)
+{
+    uint64_t a = TABLE_ENTRIES * 4ULL, b = 300000000ULL;
+    char *p = (char *)malloc(a), *q = (char *)malloc(b);
+    if (!p || !q) { free(p); free(q); return 0; }
+    memset(q, 0, b);
+    memset(p, 0, a);
+    uint64_t touched = a + b + (uint64_t)(p[a / 2] + q[b / 2]);
+    free(p); free(q);
+    return touched;
+}
+
+/* ---- file-level restatement (index build + whole program), used to pin E2/E5/E7 ---------- */
+
+/* extract_ref.cpp:246-254 (get_read_ID): cut at the first '/', then ' ', then '\t'. */
+static void header_to_name(const char *line, char *out, size_t cap)
+{
+    size_t n = strlen(line);
+    const char *stops = "/ \t";
+    for (int s = 0; s < 3; s++)
+        for (size_t i = 0; i < n; i++)
+            if (line[i] == stops[s]) { n = i; break; }
+    if (n >= cap) n = cap - 1;
+    memcpy(out, line, n);
+    out[n] = 0;
+}
+
+static void emit_ref(FILE *fi, FILE *fl, const char *name, int ordinal, const unsigned char *seq,
+                     int64_t len, int64_t cum, const int16_t cc[96])
+{
+    if (len <= K) return;                                   /* extract_ref.cpp:697, 761 */
+    fprintf(fl, "%s\t%d\t%lld\t%lld\n", name, ordinal, (long long)len, (long long)cum);
+    uint32_t l32 = (uint32_t)len;
+    fwrite(&l32, 4, 1, fi);
+    uint32_t *buf = (uint32_t *)malloc(12 * (size_t)(len - K + 1));
+    orc_index_ref(seq, len, cc, buf);
+    fwrite(buf, 12, (size_t)(len - K + 1), fi);
+    free(buf);
+}
+
+/* extract_ref.cpp:652-811 (read_ref): multi-line FASTA -> <db>.k32.index.dat + genome.len.txt.
+ * The len-file ordinal counts every '>' record (1-based), cumlen counts every record's length. */
+int orc_build_index_file(const char *fasta, const uint8_t *hdr400, const char *index_path, const char *len_path)
+{
+    FILE *fa = fopen(fasta, "rb"), *fi = fopen(index_path, "wb"), *fl = fopen(len_path, "w");
+    if (!fa || !fi || !fl) return -1;
+    int16_t cc[96];
+    orc_header_to_cc(hdr400, cc);
+    fwrite(hdr400, 1, 400, fi);
+    char *line = NULL; size_t cap = 0; ssize_t n;
+    unsigned char *seq = NULL; int64_t len = 0, scap = 0, cum = 0;
+    char name[4096] = "start", next[4096];
+    int ordinal = 0;
+    while ((n = getline(&line, &cap, fa)) >= 0) {
+        if (n > 0 && line[n - 1] == '\n') line[--n] = 0;
+        if (line[0] == '>') {
+            header_to_name(line, next, sizeof next);
+            cum += len;
+            emit_ref(fi, fl, name, ordinal, seq, len, cum, cc);
+            strcpy(name, next + 1);
+            ordinal++;
+            len = 0;
+        } else {
+            if (len + n > scap) { scap = (len + n) * 2 + 1024; seq = (unsigned char *)realloc(seq, (size_t)scap); }
+            memcpy(seq + len, line, (size_t)n);
+            len += n;
+        }
+    }
+    cum += len;
+    emit_ref(fi, fl, name, ordinal, seq, len, cum, cc);
+    free(seq); free(line);
+    fclose(fa); fclose(fi); fclose(fl);
+    return 0;
+}
+
+/* extract_ref.cpp:813-903 + 504-617 for a whole index file against a count table; writes the
+ * stdout text into out (returns bytes written, or -1). Ordinals are 1-based index-file order. */
+long orc_scan_index_file(const char *index_path, const uint8_t *table, float hit_ratio,
+                         float perfect_ratio, char *out, size_t cap)
+{
+    FILE *fi = fopen(index_path, "rb");
+    if (!fi) return -1;
+    fseek(fi, 400, SEEK_SET);
+    uint32_t len32; long used = 0; int ordinal = 1;
+    while (fread(&len32, 4, 1, fi) == 1) {
+        int64_t npos = (int64_t)len32 - K + 1;
+        uint32_t *idx = (uint32_t *)malloc(12 * (size_t)npos);
+        if (fread(idx, 12, (size_t)npos, fi) != (size_t)npos) { free(idx); break; }
+        int nint, el;
+        if (orc_scan_ref(idx, len32, table, hit_ratio, perfect_ratio, &nint, &el, NULL, 0))
+            used += orc_format_line(out + used, cap - (size_t)used, ordinal, nint, el, (int)len32);
+        free(idx);
+        ordinal++;
+    }
+    fclose(fi);
+    return used;
+}

@@ -1,0 +1,67 @@
+// Shared internals of libpalace_hip.so (gfx950 only; no other back end exists or is planned).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/palace_hip.h"
+
+namespace palace {
+
+void set_error(const char *fmt, ...);
+
+#define PALACE_HIP_TRY(expr)                                                                    \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            palace::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                              __LINE__);                                                        \
+            return PALACE_EHIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+#define PALACE_REQUIRE(cond, msg)                                  \
+    do {                                                           \
+        if (!(cond)) {                                             \
+            palace::set_error("%s: %s", __func__, msg);            \
+            return PALACE_EINVAL;                                  \
+        }                                                          \
+    } while (0)
+
+constexpr int kWave = 64;               // CDNA wavefront
+constexpr int kCUs = 256;               // MI355X
+constexpr size_t kPlaneBytes = 1ull << 29;   // 2^32 bits
+constexpr size_t kPlaneWords = 1ull << 27;   // u32 words per plane
+
+// E1: the nine 32-bit masks of the position-wise coder.  mask[i][q] has bit t set iff channel i
+// reads projection q at k-mer offset 31-t (see eref.hip for the derivation).
+struct CoderMasks {
+    uint32_t m[3][3];
+};
+
+struct Workspace {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace palace
+
+struct palace_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // eref
+    bool coder_set = false;
+    palace::CoderMasks masks{};
+    uint32_t *plane[3] = {nullptr, nullptr, nullptr};
+    palace::Workspace ws;      // grow-only scratch
+    uint64_t *d_small = nullptr;   // 64 x u64 scratch for reductions
+};
+
+namespace palace {
+int ensure_workspace(palace_ctx *ctx, size_t bytes);
+int ensure_table(palace_ctx *ctx);
+}  // namespace palace

@@ -1,0 +1,168 @@
+// Context, memory and timing plumbing of the C ABI (include/palace_hip.h).
+#include "common.hpp"
+
+namespace palace {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int ensure_workspace(palace_ctx *ctx, size_t bytes)
+{
+    if (ctx->ws.bytes >= bytes) return PALACE_OK;
+    if (ctx->ws.ptr) {
+        PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        PALACE_HIP_TRY(hipFree(ctx->ws.ptr));
+        ctx->ws.ptr = nullptr;
+        ctx->ws.bytes = 0;
+    }
+    size_t want = bytes + bytes / 4 + (1 << 20);
+    hipError_t e = hipMalloc(&ctx->ws.ptr, want);
+    if (e != hipSuccess) {
+        set_error("workspace hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return PALACE_ENOMEM;
+    }
+    ctx->ws.bytes = want;
+    return PALACE_OK;
+}
+
+int ensure_table(palace_ctx *ctx)
+{
+    for (int p = 0; p < 3; p++) {
+        if (ctx->plane[p]) continue;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->plane[p]), kPlaneBytes);
+        if (e != hipSuccess) {
+            set_error("count-table plane hipMalloc failed: %s", hipGetErrorString(e));
+            return PALACE_ENOMEM;
+        }
+        PALACE_HIP_TRY(hipMemsetAsync(ctx->plane[p], 0, kPlaneBytes, ctx->stream));
+    }
+    return PALACE_OK;
+}
+
+}  // namespace palace
+
+using namespace palace;
+
+extern "C" {
+
+const char *palace_last_error(void) { return g_err; }
+const char *palace_version(void) { return "palace_hip 0.1 (gfx950)"; }
+
+int palace_ctx_create(int device, palace_ctx **out)
+{
+    PALACE_REQUIRE(out != nullptr, "out is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+        return PALACE_EHIP;
+    }
+    PALACE_REQUIRE(device >= 0 && device < n, "device ordinal out of range");
+    PALACE_HIP_TRY(hipSetDevice(device));
+    palace_ctx *ctx = new palace_ctx();
+    ctx->device = device;
+    PALACE_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    PALACE_HIP_TRY(hipEventCreate(&ctx->ev0));
+    PALACE_HIP_TRY(hipEventCreate(&ctx->ev1));
+    PALACE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_small), 64 * sizeof(uint64_t)));
+    *out = ctx;
+    return PALACE_OK;
+}
+
+int palace_ctx_destroy(palace_ctx *ctx)
+{
+    if (!ctx) return PALACE_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int p = 0; p < 3; p++)
+        if (ctx->plane[p]) (void)hipFree(ctx->plane[p]);
+    if (ctx->ws.ptr) (void)hipFree(ctx->ws.ptr);
+    if (ctx->d_small) (void)hipFree(ctx->d_small);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PALACE_OK;
+}
+
+int palace_sync(palace_ctx *ctx)
+{
+    PALACE_REQUIRE(ctx, "ctx is null");
+    PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PALACE_OK;
+}
+
+void *palace_stream(palace_ctx *ctx) { return ctx ? ctx->stream : nullptr; }
+
+int palace_malloc(palace_ctx *ctx, size_t bytes, void **d_out)
+{
+    PALACE_REQUIRE(ctx && d_out, "null argument");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(d_out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return PALACE_ENOMEM;
+    }
+    return PALACE_OK;
+}
+
+int palace_free(palace_ctx *ctx, void *d_ptr)
+{
+    PALACE_REQUIRE(ctx, "ctx is null");
+    if (!d_ptr) return PALACE_OK;
+    PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    PALACE_HIP_TRY(hipFree(d_ptr));
+    return PALACE_OK;
+}
+
+int palace_memset(palace_ctx *ctx, void *d_ptr, int value, size_t bytes)
+{
+    PALACE_REQUIRE(ctx && (d_ptr || !bytes), "null argument");
+    if (bytes) PALACE_HIP_TRY(hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
+    return PALACE_OK;
+}
+
+int palace_h2d(palace_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    PALACE_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), "null argument");
+    if (bytes) {
+        PALACE_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));   // h_src may be pageable
+    }
+    return PALACE_OK;
+}
+
+int palace_d2h(palace_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    PALACE_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "null argument");
+    if (bytes) {
+        PALACE_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return PALACE_OK;
+}
+
+int palace_timer_begin(palace_ctx *ctx)
+{
+    PALACE_REQUIRE(ctx, "ctx is null");
+    PALACE_HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    return PALACE_OK;
+}
+
+int palace_timer_end(palace_ctx *ctx, float *ms_out)
+{
+    PALACE_REQUIRE(ctx && ms_out, "null argument");
+    PALACE_HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    PALACE_HIP_TRY(hipEventSynchronize(ctx->ev1));
+    PALACE_HIP_TRY(hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+    return PALACE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,606 @@
+// eref on gfx950: k-mer screening of reads against the phage DB.
+// Functional spec: bin/extract_ref.cpp of the reference (rows E1-E6 of SURVEY.md section 8).
+//
+// Design (MI355X-first, not a translation):
+//  * A sequence is turned into three projection bit-streams + one validity stream with wave-wide
+//    ballots: lane l of a 64-lane wave classifies base l, __ballot() delivers 64 bases of one
+//    projection as one 64-bit scalar.  A 32-mer at offset j is then the 32-bit window
+//    w_q = stream_q >> j (bit t = base j+t), obtained with one 64-bit funnel shift per stream.
+//  * The reference's 32-step loop per (position, channel) collapses to mask algebra.  Channel i
+//    reads projection cc[3z+i] at k-mer offset z with weight 2^(31-z) (extract_ref.cpp:717-725).
+//    With M[i][q] = { bit t : cc[3(31-t)+i] == q } the forward index is
+//        fwd_i = OR_q ( brev(w_q) & M[i][q] )
+//    and, because the complement leaves projection 0 unchanged and inverts projections 1 and 2
+//    (A<->T, C<->G; extract_ref.cpp:1012-1051, 1071-1078), the reverse-complement index is
+//        rc_i  = (w_0 & M[i][0]) | (~w_1 & M[i][1]) | (~w_2 & M[i][2]).
+//    canonical = min(fwd, rc) (extract_ref.cpp:727-732, 989-994).
+//  * The 4 GiB saturating byte table (extract_ref.cpp:25-26, 995-996) becomes three 512 MiB bit
+//    planes "count>=1", ">=2", ">=3".  An occurrence does atomicOr on plane 1 and climbs to the
+//    next plane only if the bit was already set, so n occurrences set exactly min(n,3) planes in
+//    any interleaving: the result equals the reference's threads=1 table, with no CAS loop.
+//    Phase B only ever asks "count == 3" (extract_ref.cpp:531), i.e. it reads plane 3 alone.
+//  * Phase B recomputes the ref-side indices from the ref bases (1 B/base) instead of streaming
+//    the 12 B/position index file, writes 2 bits per position (any-channel / all-channel hit),
+//    and does the 500-base window test with prefix population counts.
+#include "common.hpp"
+
+namespace palace {
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+struct BaseBits {
+    bool p0, p1, p2, ok;
+};
+
+__device__ __forceinline__ BaseBits classify(uint32_t ch)
+{
+    uint32_t c = ch | 0x20u;                   // fold case; only letters map onto a/c/g/t
+    bool a = c == 'a', cc = c == 'c', g = c == 'g', t = c == 't';
+    return BaseBits{a || t, a || cc, a || g, a || cc || g || t};
+}
+
+struct Streams {
+    uint64_t p0, p1, p2, ok;
+};
+
+__device__ __forceinline__ Streams ballot_streams(const uint8_t *__restrict__ s, int64_t idx, int64_t len)
+{
+    uint32_t ch = (idx < len) ? s[idx] : 0u;
+    BaseBits b = classify(ch);
+    return Streams{__ballot(b.p0), __ballot(b.p1), __ballot(b.p2), __ballot(b.ok)};
+}
+
+__device__ __forceinline__ uint32_t window32(uint64_t lo, uint64_t hi, int lane)
+{
+    uint64_t v = lo >> lane;
+    if (lane) v |= hi << (64 - lane);
+    return static_cast<uint32_t>(v);
+}
+
+__device__ __forceinline__ uint32_t canonical(const CoderMasks &m, int i, uint32_t w0, uint32_t w1,
+                                              uint32_t w2, uint32_t f0, uint32_t f1, uint32_t f2)
+{
+    uint32_t fwd = (f0 & m.m[i][0]) | (f1 & m.m[i][1]) | (f2 & m.m[i][2]);
+    uint32_t rc = (w0 & m.m[i][0]) | (~w1 & m.m[i][1]) | (~w2 & m.m[i][2]);
+    return fwd < rc ? fwd : rc;
+}
+
+// Three canonical indices of the 32-mer whose projection windows are w0..w2.
+__device__ __forceinline__ void kmer_keys(const CoderMasks &m, uint32_t w0, uint32_t w1, uint32_t w2,
+                                          uint32_t key[3])
+{
+    uint32_t f0 = __brev(w0), f1 = __brev(w1), f2 = __brev(w2);
+#pragma unroll
+    for (int i = 0; i < 3; i++) key[i] = canonical(m, i, w0, w1, w2, f0, f1, f2);
+}
+
+// ------------------------------------------------------------------------------------------
+// E4: count reads -- one wave per read, grid-stride over reads
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void count_key(uint32_t key, uint32_t *__restrict__ p1,
+                                          uint32_t *__restrict__ p2, uint32_t *__restrict__ p3)
+{
+    uint32_t word = key >> 5, bit = 1u << (key & 31);
+    if (atomicOr(&p1[word], bit) & bit)
+        if (atomicOr(&p2[word], bit) & bit) atomicOr(&p3[word], bit);
+}
+
+__global__ __launch_bounds__(256) void eref_count_kernel(const uint8_t *__restrict__ bases,
+                                                         const int64_t *__restrict__ offsets,
+                                                         int64_t n_reads,
+                                                         const uint8_t *__restrict__ keep,
+                                                         CoderMasks masks, uint32_t *__restrict__ p1,
+                                                         uint32_t *__restrict__ p2,
+                                                         uint32_t *__restrict__ p3)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_reads; r += n_waves) {
+        if (keep && !keep[r]) continue;
+        const int64_t beg = offsets[r];
+        const int64_t len = offsets[r + 1] - beg;
+        const int64_t npos = len - 31;
+        if (npos <= 0) continue;
+        const uint8_t *s = bases + beg;
+        Streams lo = ballot_streams(s, lane, len);
+        for (int64_t base = 0; base < npos; base += 64) {
+            Streams hi = ballot_streams(s, base + 64 + lane, len);
+            const int64_t j = base + lane;
+            uint32_t wv = window32(lo.ok, hi.ok, lane);
+            if (j < npos && wv == 0xffffffffu) {
+                uint32_t key[3];
+                kmer_keys(masks, window32(lo.p0, hi.p0, lane), window32(lo.p1, hi.p1, lane),
+                          window32(lo.p2, hi.p2, lane), key);
+#pragma unroll
+                for (int i = 0; i < 3; i++) count_key(key[i], p1, p2, p3);
+            }
+            lo = hi;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// tiling of a set of sequences: tile = kTileChunks x 64 positions of one sequence
+// ------------------------------------------------------------------------------------------
+constexpr int kTileChunks = 32;                 // 2048 positions per 256-thread block
+constexpr int kTilePos = kTileChunks * 64;
+
+// prefix sums of ceil(len/kTilePos) and ceil(len/64) over the sequences (single block).
+__global__ __launch_bounds__(1024) void seq_prefix_kernel(const int64_t *__restrict__ offsets,
+                                                          int64_t n, int64_t *__restrict__ tile_pre,
+                                                          int64_t *__restrict__ word_pre)
+{
+    __shared__ int64_t s_t[1024], s_w[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t a = min(n, t * per), b = min(n, a + per);
+    int64_t st = 0, sw = 0;
+    for (int64_t r = a; r < b; r++) {
+        int64_t len = offsets[r + 1] - offsets[r];
+        st += (len + kTilePos - 1) / kTilePos;
+        sw += (len + 63) / 64;
+    }
+    s_t[t] = st;
+    s_w[t] = sw;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        int64_t vt = (t >= d) ? s_t[t - d] : 0, vw = (t >= d) ? s_w[t - d] : 0;
+        __syncthreads();
+        s_t[t] += vt;
+        s_w[t] += vw;
+        __syncthreads();
+    }
+    int64_t rt = s_t[t] - st, rw = s_w[t] - sw;      // exclusive
+    for (int64_t r = a; r < b; r++) {
+        int64_t len = offsets[r + 1] - offsets[r];
+        tile_pre[r] = rt;
+        word_pre[r] = rw;
+        rt += (len + kTilePos - 1) / kTilePos;
+        rw += (len + 63) / 64;
+    }
+    if (t == 1023) {
+        tile_pre[n] = s_t[1023];
+        word_pre[n] = s_w[1023];
+    }
+}
+
+__device__ __forceinline__ int64_t find_seq(const int64_t *__restrict__ pre, int64_t n, int64_t tile)
+{
+    int64_t lo = 0, hi = n;            // largest r with pre[r] <= tile
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (pre[mid] <= tile) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// E5: per-position hit bits of every ref (lookup in plane 3)
+// MODE 0: write any/all hit words;  MODE 1: write the three indices (E2 index build)
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void eref_ref_kernel(const uint8_t *__restrict__ bases,
+                                                       const int64_t *__restrict__ offsets,
+                                                       int64_t n_refs,
+                                                       const int64_t *__restrict__ tile_pre,
+                                                       const int64_t *__restrict__ word_pre,
+                                                       CoderMasks masks,
+                                                       const uint32_t *__restrict__ p3,
+                                                       uint64_t *__restrict__ any_words,
+                                                       uint64_t *__restrict__ all_words,
+                                                       uint32_t *__restrict__ idx_out,
+                                                       const int64_t *__restrict__ idx_offsets)
+{
+    const int64_t tile = blockIdx.x;
+    if (tile >= tile_pre[n_refs]) return;
+    const int64_t r = find_seq(tile_pre, n_refs, tile);
+    const int64_t beg = offsets[r], len = offsets[r + 1] - beg;
+    const int64_t npos = len - 31;                       // may be <= 0
+    const int64_t n_chunks = (len + 63) / 64;
+    const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
+    constexpr int per_wave = kTileChunks / 4;
+    const int64_t c0 = (tile - tile_pre[r]) * kTileChunks + static_cast<int64_t>(wv_id) * per_wave;
+    if (c0 >= n_chunks) return;
+    const int64_t c1 = min(n_chunks, c0 + per_wave);
+    const uint8_t *s = bases + beg;
+    Streams lo = ballot_streams(s, c0 * 64 + lane, len);
+    for (int64_t c = c0; c < c1; c++) {
+        Streams hi = ballot_streams(s, (c + 1) * 64 + lane, len);
+        const int64_t j = c * 64 + lane;
+        uint32_t ok = window32(lo.ok, hi.ok, lane);
+        bool valid = (j < npos) && ok == 0xffffffffu;
+        uint32_t key[3] = {0, 0, 0};
+        if (valid)
+            kmer_keys(masks, window32(lo.p0, hi.p0, lane), window32(lo.p1, hi.p1, lane),
+                      window32(lo.p2, hi.p2, lane), key);
+        if (MODE == 0) {
+            int h = 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++)           // index 0 means "none" (extract_ref.cpp:861)
+                if (valid && key[i] != 0) h += (p3[key[i] >> 5] >> (key[i] & 31)) & 1u;
+            uint64_t any = __ballot(h > 0), all = __ballot(h == 3);
+            if (lane == 0) {
+                any_words[word_pre[r] + c] = any;
+                all_words[word_pre[r] + c] = all;
+            }
+        } else {
+            if (j < npos) {
+                uint32_t *o = idx_out + idx_offsets[r] + 3 * j;
+                o[0] = key[0]; o[1] = key[1]; o[2] = key[2];
+            }
+        }
+        lo = hi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// E6: window scan + interval merge, one block per ref (slide_window, extract_ref.cpp:504-617)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t prefix_count(const uint64_t *__restrict__ words,
+                                                 const uint32_t *__restrict__ pre, int64_t j)
+{
+    int64_t w = j >> 6;
+    int b = static_cast<int>(j & 63);
+    uint64_t mask = (b == 63) ? ~0ull : ((2ull << b) - 1);
+    return pre[w] + __popcll(words[w] & mask);           // hits at positions <= j
+}
+
+__global__ __launch_bounds__(256) void eref_window_kernel(const int64_t *__restrict__ offsets,
+                                                          int64_t n_refs,
+                                                          const int64_t *__restrict__ word_pre,
+                                                          const uint64_t *__restrict__ any_words,
+                                                          const uint64_t *__restrict__ all_words,
+                                                          uint32_t *__restrict__ any_pre,
+                                                          uint32_t *__restrict__ all_pre,
+                                                          uint64_t *__restrict__ good_words,
+                                                          int one_min, int three_min,
+                                                          int32_t *__restrict__ rows)
+{
+    const int64_t r = blockIdx.x;
+    if (r >= n_refs) return;
+    const int64_t len = offsets[r + 1] - offsets[r];
+    const int64_t n_words = (len + 63) / 64, w0 = word_pre[r];
+    const uint64_t *A = any_words + w0, *T = all_words + w0;
+    uint32_t *PA = any_pre + w0, *PT = all_pre + w0;
+    uint64_t *G = good_words + w0;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+
+    // (a) exclusive prefix population counts per 64-position word, 256 words per sweep
+    __shared__ uint32_t s_a[4], s_t[4];
+    __shared__ uint32_t carry_a, carry_t;
+    if (t == 0) { carry_a = 0; carry_t = 0; }
+    __syncthreads();
+    for (int64_t base = 0; base < n_words; base += 256) {
+        int64_t w = base + t;
+        uint32_t ca = (w < n_words) ? __popcll(A[w]) : 0, ct = (w < n_words) ? __popcll(T[w]) : 0;
+        uint32_t ia = ca, it = ct;                     // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t ua = __shfl_up(ia, d), ut = __shfl_up(it, d);
+            if (lane >= d) { ia += ua; it += ut; }
+        }
+        if (lane == 63) { s_a[wv] = ia; s_t[wv] = it; }
+        __syncthreads();
+        uint32_t oa = carry_a, ot = carry_t;
+        for (int k = 0; k < wv; k++) { oa += s_a[k]; ot += s_t[k]; }
+        if (w < n_words) { PA[w] = oa + ia - ca; PT[w] = ot + it - ct; }
+        __syncthreads();
+        if (t == 255) { carry_a = oa + ia; carry_t = ot + it; }
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // (b) good[j]: >= one_min any-hits and >= three_min all-hits among positions (j-500, j]
+    for (int64_t w = wv; w < n_words; w += 4) {
+        int64_t j = w * 64 + lane;
+        bool good = false;
+        if (j < len) {
+            uint32_t one = prefix_count(A, PA, j), three = prefix_count(T, PT, j);
+            if (j >= 500) { one -= prefix_count(A, PA, j - 500); three -= prefix_count(T, PT, j - 500); }
+            good = static_cast<int>(one) >= one_min && static_cast<int>(three) >= three_min;
+        }
+        uint64_t g = __ballot(good);
+        if (lane == 0) G[w] = g;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // (c) rising edge -> start = max(1, j-1000); falling edge (or end of ref) -> end =
+    //     min(len, j+1000); merge into the previous interval when start - prev_end < 500.
+    if (t == 0) {
+        int frag = 0, el = 0, start = 0, prev_end = 0;
+        uint64_t prev_bit = 0;
+        const int ilen = static_cast<int>(len);
+        for (int64_t w = 0; w <= n_words; w++) {
+            uint64_t g = (w < n_words) ? G[w] : 0;     // one virtual zero word closes an open run
+            uint64_t x = g ^ ((g << 1) | prev_bit);
+            while (x) {
+                int b = __ffsll(static_cast<long long>(x)) - 1;
+                x &= x - 1;
+                int j = static_cast<int>(w * 64 + b);
+                if ((g >> b) & 1) {
+                    start = max(1, j - 1000);
+                } else {
+                    int end = min(ilen, j + 1000);
+                    if (frag > 0 && start - prev_end < 500) { el += end - prev_end; }
+                    else { frag++; el += end - start; }
+                    prev_end = end;
+                }
+            }
+            prev_bit = g >> 63;
+        }
+        rows[4 * r + 0] = frag;
+        rows[4 * r + 1] = el;
+        rows[4 * r + 2] = ilen;
+        rows[4 * r + 3] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// table utilities
+// ------------------------------------------------------------------------------------------
+__global__ void table_lookup_kernel(const uint32_t *__restrict__ keys, int64_t n,
+                                    const uint32_t *__restrict__ p1, const uint32_t *__restrict__ p2,
+                                    const uint32_t *__restrict__ p3, uint8_t *__restrict__ out)
+{
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k = keys[i], w = k >> 5, b = k & 31;
+    out[i] = ((p1[w] >> b) & 1) + ((p2[w] >> b) & 1) + ((p3[w] >> b) & 1);
+}
+
+__global__ __launch_bounds__(256) void plane_popcount_kernel(const uint4 *__restrict__ plane, size_t n16,
+                                                             unsigned long long *__restrict__ out)
+{
+    unsigned long long acc = 0;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        uint4 v = plane[i];
+        acc += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    for (int d = 32; d; d >>= 1) acc += __shfl_down(acc, d);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+// saturating unary add of n_parts partial tables into the context's planes (16 B per lane)
+__global__ __launch_bounds__(256) void merge_slices_kernel(const uint4 *__restrict__ parts, int n_parts,
+                                                           size_t slice16, uint4 *__restrict__ d1,
+                                                           uint4 *__restrict__ d2, uint4 *__restrict__ d3)
+{
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < slice16;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        uint32_t a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, a3[4] = {0, 0, 0, 0};
+        for (int p = 0; p < n_parts; p++) {
+            const uint4 *base = parts + static_cast<size_t>(p) * 3 * slice16;
+            uint4 v1 = base[i], v2 = base[slice16 + i], v3 = base[2 * slice16 + i];
+            uint32_t b1[4] = {v1.x, v1.y, v1.z, v1.w}, b2[4] = {v2.x, v2.y, v2.z, v2.w},
+                     b3[4] = {v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t r3 = a3[k] | b3[k] | (a2[k] & b1[k]) | (a1[k] & b2[k]);
+                uint32_t r2 = a2[k] | b2[k] | (a1[k] & b1[k]);
+                uint32_t r1 = a1[k] | b1[k];
+                a1[k] = r1; a2[k] = r2; a3[k] = r3;
+            }
+        }
+        d1[i] = make_uint4(a1[0], a1[1], a1[2], a1[3]);
+        d2[i] = make_uint4(a2[0], a2[1], a2[2], a2[3]);
+        d3[i] = make_uint4(a3[0], a3[1], a3[2], a3[3]);
+    }
+}
+
+// host: E1 masks from the header (extract_ref.cpp:1104-1122 for the header layout)
+static int masks_from_header(const uint8_t *hdr, CoderMasks *out)
+{
+    std::memset(out, 0, sizeof *out);
+    for (int z = 0; z < 32; z++) {
+        int seen = 0;
+        for (int i = 0; i < 3; i++) {
+            int q = static_cast<int16_t>(hdr[4 * (3 * z + i)] | (hdr[4 * (3 * z + i) + 1] << 8));
+            if (q < 0 || q > 2) return -1;
+            seen |= 1 << q;
+            out->m[i][q] |= 1u << (31 - z);
+        }
+        if (seen != 7) return -1;                  // each position must hold a permutation of 0,1,2
+    }
+    return 0;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace palace
+
+using namespace palace;
+
+extern "C" {
+
+int palace_eref_set_coder(palace_ctx *ctx, const uint8_t header400[400])
+{
+    PALACE_REQUIRE(ctx && header400, "null argument");
+    CoderMasks m;
+    PALACE_REQUIRE(masks_from_header(header400, &m) == 0,
+                   "index header does not hold a permutation of (0,1,2) at every k-mer position");
+    ctx->masks = m;
+    ctx->coder_set = true;
+    return PALACE_OK;
+}
+
+int palace_eref_table_reset(palace_ctx *ctx)
+{
+    PALACE_REQUIRE(ctx, "ctx is null");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    bool fresh = ctx->plane[0] == nullptr;
+    int rc = ensure_table(ctx);
+    if (rc) return rc;
+    if (!fresh)
+        for (int p = 0; p < 3; p++) PALACE_HIP_TRY(hipMemsetAsync(ctx->plane[p], 0, kPlaneBytes, ctx->stream));
+    return PALACE_OK;
+}
+
+int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets,
+                            int64_t n_reads, const uint8_t *d_keep)
+{
+    PALACE_REQUIRE(ctx && n_reads >= 0, "bad argument");
+    if (!ctx->coder_set) { set_error("palace_eref_count_reads: coder not set"); return PALACE_ESTATE; }
+    if (n_reads == 0) return PALACE_OK;
+    PALACE_REQUIRE(d_bases && d_offsets, "null device pointer");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_table(ctx);
+    if (rc) return rc;
+    int64_t blocks = (n_reads + 3) / 4;                 // 4 waves (reads) per 256-thread block
+    int64_t cap = static_cast<int64_t>(kCUs) * 8 * 8;   // grid-stride beyond 16 Ki blocks
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(eref_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream,
+                       d_bases, d_offsets, n_reads, d_keep, ctx->masks, ctx->plane[0], ctx->plane[1],
+                       ctx->plane[2]);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+static int launch_prefix(palace_ctx *ctx, const int64_t *d_offsets, int64_t n, int64_t *tile_pre, int64_t *word_pre)
+{
+    hipLaunchKernelGGL(seq_prefix_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_offsets, n, tile_pre, word_pre);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+int palace_eref_index_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets,
+                           int64_t n_refs, uint32_t *d_out, const int64_t *d_out_offsets)
+{
+    PALACE_REQUIRE(ctx && n_refs >= 0, "bad argument");
+    if (!ctx->coder_set) { set_error("palace_eref_index_refs: coder not set"); return PALACE_ESTATE; }
+    if (n_refs == 0) return PALACE_OK;
+    PALACE_REQUIRE(d_bases && d_offsets && d_out && d_out_offsets, "null device pointer");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    int64_t h_off[2];
+    PALACE_HIP_TRY(hipMemcpyAsync(&h_off[0], d_offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PALACE_HIP_TRY(hipMemcpyAsync(&h_off[1], d_offsets + n_refs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int64_t total = h_off[1] - h_off[0];
+    PALACE_REQUIRE(total >= 0, "offsets not ascending");
+    size_t pre_bytes = align_up((n_refs + 1) * 8, 256);
+    int rc = ensure_workspace(ctx, 2 * pre_bytes);
+    if (rc) return rc;
+    char *ws = static_cast<char *>(ctx->ws.ptr);
+    int64_t *tile_pre = reinterpret_cast<int64_t *>(ws), *word_pre = reinterpret_cast<int64_t *>(ws + pre_bytes);
+    rc = launch_prefix(ctx, d_offsets, n_refs, tile_pre, word_pre);
+    if (rc) return rc;
+    int64_t max_tiles = total / kTilePos + n_refs;
+    PALACE_REQUIRE(max_tiles < (1ll << 31), "too many tiles for one launch");
+    hipLaunchKernelGGL(eref_ref_kernel<1>, dim3(static_cast<unsigned>(max_tiles)), dim3(256), 0, ctx->stream,
+                       d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks,
+                       static_cast<const uint32_t *>(nullptr), static_cast<uint64_t *>(nullptr),
+                       static_cast<uint64_t *>(nullptr), d_out, d_out_offsets);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets,
+                          int64_t n_refs, int64_t total_bases, int one_min, int three_min,
+                          int32_t *d_rows)
+{
+    PALACE_REQUIRE(ctx && n_refs >= 0 && total_bases >= 0, "bad argument");
+    if (!ctx->coder_set) { set_error("palace_eref_scan_refs: coder not set"); return PALACE_ESTATE; }
+    if (n_refs == 0) return PALACE_OK;
+    PALACE_REQUIRE(d_bases && d_offsets && d_rows, "null device pointer");
+    PALACE_REQUIRE(n_refs < (1ll << 31), "too many refs for one launch");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_table(ctx);
+    if (rc) return rc;
+    const int64_t max_tiles = total_bases / kTilePos + n_refs;
+    const int64_t max_words = total_bases / 64 + n_refs + 1;
+    PALACE_REQUIRE(max_tiles < (1ll << 31), "too many tiles for one launch");
+    const size_t pre_bytes = align_up((n_refs + 1) * 8, 256);
+    const size_t w64 = align_up(max_words * 8, 256), w32 = align_up(max_words * 4, 256);
+    rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32);
+    if (rc) return rc;
+    char *ws = static_cast<char *>(ctx->ws.ptr);
+    int64_t *tile_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
+    int64_t *word_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
+    uint64_t *any_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
+    uint64_t *all_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
+    uint64_t *good_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
+    uint32_t *any_p = reinterpret_cast<uint32_t *>(ws); ws += w32;
+    uint32_t *all_p = reinterpret_cast<uint32_t *>(ws);
+    rc = launch_prefix(ctx, d_offsets, n_refs, tile_pre, word_pre);
+    if (rc) return rc;
+    hipLaunchKernelGGL(eref_ref_kernel<0>, dim3(static_cast<unsigned>(max_tiles)), dim3(256), 0, ctx->stream,
+                       d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks, ctx->plane[2], any_w,
+                       all_w, static_cast<uint32_t *>(nullptr), static_cast<const int64_t *>(nullptr));
+    PALACE_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(eref_window_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(256), 0, ctx->stream,
+                       d_offsets, n_refs, word_pre, any_w, all_w, any_p, all_p, good_w, one_min, three_min,
+                       d_rows);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+int palace_eref_table_planes(palace_ctx *ctx, void **d_planes3, size_t *bytes_per_plane)
+{
+    PALACE_REQUIRE(ctx && d_planes3 && bytes_per_plane, "null argument");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_table(ctx);
+    if (rc) return rc;
+    for (int p = 0; p < 3; p++) d_planes3[p] = ctx->plane[p];
+    *bytes_per_plane = kPlaneBytes;
+    return PALACE_OK;
+}
+
+int palace_eref_table_merge_slices(palace_ctx *ctx, const void *d_parts, int n_parts, size_t slice_off,
+                                   size_t slice_bytes)
+{
+    PALACE_REQUIRE(ctx && d_parts && n_parts > 0, "bad argument");
+    PALACE_REQUIRE(slice_off % 16 == 0 && slice_bytes % 16 == 0 && slice_off + slice_bytes <= kPlaneBytes,
+                   "slice must be 16-byte aligned and inside the plane");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_table(ctx);
+    if (rc) return rc;
+    size_t n16 = slice_bytes / 16;
+    if (n16 == 0) return PALACE_OK;
+    char *b1 = reinterpret_cast<char *>(ctx->plane[0]) + slice_off;
+    char *b2 = reinterpret_cast<char *>(ctx->plane[1]) + slice_off;
+    char *b3 = reinterpret_cast<char *>(ctx->plane[2]) + slice_off;
+    unsigned blocks = static_cast<unsigned>(std::min<size_t>((n16 + 255) / 256, kCUs * 8));
+    hipLaunchKernelGGL(merge_slices_kernel, dim3(blocks), dim3(256), 0, ctx->stream,
+                       static_cast<const uint4 *>(d_parts), n_parts, n16, reinterpret_cast<uint4 *>(b1),
+                       reinterpret_cast<uint4 *>(b2), reinterpret_cast<uint4 *>(b3));
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+int palace_eref_table_lookup(palace_ctx *ctx, const uint32_t *d_keys, int64_t n, uint8_t *d_counts)
+{
+    PALACE_REQUIRE(ctx && n >= 0, "bad argument");
+    if (n == 0) return PALACE_OK;
+    PALACE_REQUIRE(d_keys && d_counts, "null device pointer");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_table(ctx);
+    if (rc) return rc;
+    hipLaunchKernelGGL(table_lookup_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, d_keys, n, ctx->plane[0], ctx->plane[1], ctx->plane[2], d_counts);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+int palace_eref_table_popcounts(palace_ctx *ctx, uint64_t out3[3])
+{
+    PALACE_REQUIRE(ctx && out3, "null argument");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_table(ctx);
+    if (rc) return rc;
+    PALACE_HIP_TRY(hipMemsetAsync(ctx->d_small, 0, 3 * sizeof(uint64_t), ctx->stream));
+    for (int p = 0; p < 3; p++) {
+        hipLaunchKernelGGL(plane_popcount_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const uint4 *>(ctx->plane[p]), kPlaneBytes / 16,
+                           reinterpret_cast<unsigned long long *>(ctx->d_small) + p);
+        PALACE_HIP_TRY(hipGetLastError());
+    }
+    PALACE_HIP_TRY(hipMemcpyAsync(out3, ctx->d_small, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PALACE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+"""Seeded synthetic inputs for the conjugate-graph hot path.
+
+Build code, not reference code: nothing here is derived from /root/reference.  The generator
+produces every file the three executables consume:
+
+  phage DB FASTA                      -> eref argv[3]          (extract_ref.cpp:1221)
+  paired 4-line FASTQ                 -> eref argv[1], argv[2] (extract_ref.cpp:1222-1223)
+  BAM (BGZF, coordinate sorted)       -> generateGraph <BAM>   (generate_graph.cpp:600)
+  assembly_graph.fastg.fai            -> generateGraph <FASTG_FAI> (generate_graph.cpp:601)
+  assembly_graph.fasta.fai, .blast, hit_seqs.out, node_scores.out, contigs.paths
+                                      -> filter_graph.py argv  (filter_graph.py:8-20)
+
+Everything is driven by numpy's PCG64 so a (seed, sizes) pair names a workload exactly.
+"""
+from __future__ import annotations
+
+import struct
+import zlib
+from dataclasses import dataclass, field
+
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTacgtNn", b"TGCAtgcaNn"):
+    _COMP[_a] = _b
+
+
+def rng_for(seed: int) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def random_dna(rng: np.random.Generator, n: int) -> np.ndarray:
+    return ACGT[rng.integers(0, 4, size=n, dtype=np.uint8)]
+
+
+def revcomp(seq: np.ndarray) -> np.ndarray:
+    return _COMP[seq[::-1]]
+
+
+def mutate(rng: np.random.Generator, seq: np.ndarray, rate: float) -> np.ndarray:
+    """Substitute each base with probability `rate` by a different base."""
+    out = seq.copy()
+    if rate <= 0 or len(seq) == 0:
+        return out
+    hit = np.nonzero(rng.random(len(seq)) < rate)[0]
+    for p in hit:
+        cur = out[p]
+        alt = ACGT[rng.integers(0, 4)]
+        while alt == cur:
+            alt = ACGT[rng.integers(0, 4)]
+        out[p] = alt
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# phage DB + reads (eref inputs)
+# --------------------------------------------------------------------------------------
+@dataclass
+class PhageDB:
+    names: list            # FASTA header text after '>' (may contain spaces / '/')
+    seqs: list             # list of np.uint8 ASCII arrays
+
+    def write_fasta(self, path: str, width: int = 80) -> None:
+        with open(path, "wb") as f:
+            for name, seq in zip(self.names, self.seqs):
+                f.write(b">" + name.encode() + b"\n")
+                b = seq.tobytes()
+                for i in range(0, len(b), width):
+                    f.write(b[i:i + width] + b"\n")
+
+
+def make_phage_db(rng, n_refs: int, len_lo: int, len_hi: int, name_prefix: str = "phage") -> PhageDB:
+    names, seqs = [], []
+    for i in range(n_refs):
+        L = int(rng.integers(len_lo, len_hi + 1))
+        names.append(f"{name_prefix}_{i + 1}|len{L} synthetic")
+        seqs.append(random_dna(rng, L))
+    return PhageDB(names, seqs)
+
+
+@dataclass
+class ReadSet:
+    """Concatenated read bases (ASCII) with offsets; reads[i] = bases[off[i]:off[i+1]]."""
+    bases: np.ndarray
+    offsets: np.ndarray
+    names: list = field(default_factory=list)
+
+    @property
+    def n(self) -> int:
+        return len(self.offsets) - 1
+
+    def read(self, i: int) -> np.ndarray:
+        return self.bases[self.offsets[i]:self.offsets[i + 1]]
+
+    def write_fastq(self, path: str, tag: str) -> None:
+        with open(path, "wb") as f:
+            for i in range(self.n):
+                s = self.read(i).tobytes()
+                nm = self.names[i] if self.names else f"r{i}"
+                f.write(b"@" + nm.encode() + b"/" + tag.encode() + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
+
+
+def reads_from_list(seqs: list, names: list | None = None) -> ReadSet:
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    bases = np.concatenate(seqs) if seqs else np.zeros(0, dtype=np.uint8)
+    return ReadSet(bases.astype(np.uint8), off, names or [])
+
+
+def sample_pairs(rng, template: np.ndarray, n_pairs: int, read_len: int, insert_mu: float,
+                 insert_sd: float, err: float, lo: int = 0, hi: int | None = None):
+    """Sample FR read pairs whose fragment lies inside template[lo:hi]."""
+    hi = len(template) if hi is None else hi
+    r1, r2 = [], []
+    for _ in range(n_pairs):
+        ins = int(max(read_len, min(hi - lo, rng.normal(insert_mu, insert_sd))))
+        st = int(rng.integers(lo, max(lo + 1, hi - ins + 1)))
+        frag = template[st:st + ins]
+        a = frag[:read_len]
+        b = revcomp(frag[-read_len:])
+        if rng.random() < 0.5:                       # fragment from the other strand
+            a, b = b, a
+        r1.append(mutate(rng, a, err))
+        r2.append(mutate(rng, b, err))
+    return r1, r2
+
+
+def vector_reads(rng, pool: np.ndarray, n: int, read_len: int) -> ReadSet:
+    """Fast path for big workloads: n fixed-length reads cut from a random pool (vectorised)."""
+    starts = rng.integers(0, len(pool) - read_len, size=n)
+    idx = starts[:, None] + np.arange(read_len)[None, :]
+    bases = pool[idx].reshape(-1)
+    off = np.arange(n + 1, dtype=np.int64) * read_len
+    return ReadSet(bases, off)
+
+
+# --------------------------------------------------------------------------------------
+# BAM writer (BGZF over zlib) -- SAM spec v1 section 4; test/bench infrastructure only
+# --------------------------------------------------------------------------------------
+_CIGAR_OPS = "MIDNSHP=X"
+
+
+def parse_cigar(text: str):
+    ops, n = [], 0
+    for ch in text:
+        if ch.isdigit():
+            n = n * 10 + ord(ch) - 48
+        else:
+            ops.append((n, _CIGAR_OPS.index(ch)))
+            n = 0
+    return ops
+
+
+def _reg2bin(beg: int, end: int) -> int:
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+@dataclass
+class BamRecord:
+    qname: str
+    flag: int
+    tid: int
+    pos: int            # 0-based
+    mapq: int
+    cigar: str
+    mtid: int = -1
+    mpos: int = -1
+    tlen: int = 0
+    nm: int | None = 0
+    sa: str | None = None
+    nm_type: str = "C"  # aux integer type used for NM: c C s S i I
+
+    def encode(self) -> bytes:
+        ops = parse_cigar(self.cigar)
+        qlen = sum(n for n, op in ops if op in (0, 1, 4, 7, 8))
+        rlen = sum(n for n, op in ops if op in (0, 2, 3, 7, 8))
+        name = self.qname.encode() + b"\0"
+        bin_ = _reg2bin(max(self.pos, 0), max(self.pos, 0) + max(rlen, 1))
+        body = struct.pack("<iiBBHHHiiii", self.tid, self.pos, len(name), self.mapq, bin_, len(ops),
+                           self.flag, qlen, self.mtid, self.mpos, self.tlen)
+        body += name
+        body += b"".join(struct.pack("<I", (n << 4) | op) for n, op in ops)
+        body += b"\x11" * ((qlen + 1) // 2)          # sequence: all 'A' (=1) nibbles
+        body += b"\xff" * qlen                        # qualities absent
+        # an unrelated tag first, so aux scanning has to skip something
+        body += b"ASC" + struct.pack("<B", 30)
+        if self.nm is not None:
+            fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I"}[self.nm_type]
+            body += b"NM" + self.nm_type.encode() + struct.pack(fmt, self.nm)
+        body += b"XSi" + struct.pack("<i", -7)
+        if self.sa is not None:
+            body += b"SAZ" + self.sa.encode() + b"\0"
+        return struct.pack("<i", len(body)) + body
+
+
+def _bgzf_block(data: bytes, level: int = 1) -> bytes:
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    comp = co.compress(data) + co.flush()
+    bsize = len(comp) + 25
+    hdr = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize)
+    return hdr + comp + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+
+
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def write_bam(path: str, targets: list, records: list, block: int = 0xFF00, level: int = 1) -> None:
+    """targets: [(name, length)], records: iterable of BamRecord (caller sorts)."""
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in targets)
+    raw = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(targets)))
+    for n, l in targets:
+        nb = n.encode() + b"\0"
+        raw += struct.pack("<i", len(nb)) + nb + struct.pack("<i", l)
+    for r in records:
+        raw += r.encode()
+    with open(path, "wb") as f:
+        for i in range(0, len(raw), block):
+            f.write(_bgzf_block(bytes(raw[i:i + block]), level))
+        f.write(_BGZF_EOF)
+
+
+# --------------------------------------------------------------------------------------
+# contigs / graph-side inputs
+# --------------------------------------------------------------------------------------
+def contig_names(rng, n: int, median: float = 800.0, sigma: float = 1.0, min_len: int = 56,
+                 long_mode: bool = False):
+    """EDGE_<id>_length_<len>_cov_<cov> names (the naming split_fastg.py:55-66 produces)."""
+    if long_mode:      # N50 ~ 50 kb with a tail > 120 kb (exercises the G5 underflow gate)
+        lens = np.maximum(min_len, rng.lognormal(np.log(30000.0), 0.9, size=n)).astype(np.int64)
+    else:
+        lens = np.maximum(min_len, rng.lognormal(np.log(median), sigma, size=n)).astype(np.int64)
+    ids = rng.permutation(np.arange(1, 4 * n + 1))[:n]           # non-contiguous ids, random order
+    covs = rng.gamma(2.0, 8.0, size=n)
+    names = [f"EDGE_{int(i)}_length_{int(l)}_cov_{c:.6f}" for i, l, c in zip(ids, lens, covs)]
+    return names, lens
+
+
+def fastg_fai_lines(rng, names: list, lens, links_per_contig: float = 1.3):
+    """Lines of assembly_graph.fastg.fai: both strands of every edge with their successors."""
+    n = len(names)
+    lines = []
+    for strand in ("", "'"):
+        for i, nm in enumerate(names):
+            k = int(rng.poisson(links_per_contig))
+            succ = []
+            for _ in range(k):
+                j = int(rng.integers(0, n))
+                succ.append(names[j] + ("'" if rng.random() < 0.5 else ""))
+            head = nm + strand
+            col0 = head + (":" + ",".join(succ) if succ else "") + ";"
+            lines.append(f"{col0}\t{int(lens[i])}\t0\t60\t61\n")
+    return lines
