@@ -43,6 +43,7 @@ int palace_free(palace_ctx *ctx, void *d_ptr);
 int palace_memset(palace_ctx *ctx, void *d_ptr, int value, size_t bytes);
 int palace_h2d(palace_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int palace_d2h(palace_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int palace_d2d(palace_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 /* HIP-event timing on the context's stream: begin/end bracket, elapsed in milliseconds. */
 int palace_timer_begin(palace_ctx *ctx);
 int palace_timer_end(palace_ctx *ctx, float *ms_out);

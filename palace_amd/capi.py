@@ -1,0 +1,209 @@
+"""ctypes view of libpalace_hip.so (the C ABI declared in include/palace_hip.h).
+
+This is plumbing for tests/ and bench.py: it adds no compute of its own and has no CPU
+fallback -- if the HIP library is missing or a call fails, it raises.  The product's host side
+is the C++ under palace_amd/host/, which links the same library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libpalace_hip.so")
+_LIB = None
+
+
+class PalaceError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc")]
+    if force:
+        subprocess.run(args + ["clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(args, check=True, stdout=subprocess.DEVNULL)
+    return SO_PATH
+
+
+_SIGS = {
+    "palace_ctx_create": [C.c_int, C.POINTER(C.c_void_p)],
+    "palace_ctx_destroy": [C.c_void_p],
+    "palace_sync": [C.c_void_p],
+    "palace_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
+    "palace_free": [C.c_void_p, C.c_void_p],
+    "palace_memset": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t],
+    "palace_h2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "palace_d2h": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "palace_d2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "palace_timer_begin": [C.c_void_p],
+    "palace_timer_end": [C.c_void_p, C.POINTER(C.c_float)],
+    "palace_eref_set_coder": [C.c_void_p, C.c_void_p],
+    "palace_eref_index_refs": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
+    "palace_eref_table_reset": [C.c_void_p],
+    "palace_eref_count_reads": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "palace_eref_scan_refs": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                              C.c_void_p],
+    "palace_eref_table_planes": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+    "palace_eref_table_merge_slices": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t],
+    "palace_eref_table_lookup": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "palace_eref_table_popcounts": [C.c_void_p, C.POINTER(C.c_uint64)],
+}
+
+
+def declared_symbols():
+    """Every function include/palace_hip.h declares (parsed from the header itself)."""
+    import re
+    text = open(os.path.join(_HERE, "..", "include", "palace_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(palace_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise PalaceError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _LIB = C.CDLL(SO_PATH)
+        _LIB.palace_last_error.restype = C.c_char_p
+        _LIB.palace_version.restype = C.c_char_p
+        _LIB.palace_stream.restype = C.c_void_p
+        _LIB.palace_stream.argtypes = [C.c_void_p]
+        for name, sig in _SIGS.items():
+            fn = getattr(_LIB, name)
+            fn.argtypes = sig
+            fn.restype = C.c_int
+    return _LIB
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise PalaceError(f"{what} -> {rc}: {lib().palace_last_error().decode()}")
+
+
+class DevBuf:
+    """A device allocation owned through palace_malloc/palace_free."""
+
+    def __init__(self, ctx: "Ctx", nbytes: int, dtype=np.uint8, shape=None):
+        self.ctx, self.nbytes, self.dtype, self.shape = ctx, int(nbytes), np.dtype(dtype), shape
+        p = C.c_void_p()
+        _check(lib().palace_malloc(ctx.h, self.nbytes, C.byref(p)), "palace_malloc")
+        self.ptr = p.value
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.nbytes // self.dtype.itemsize, dtype=self.dtype)
+        _check(lib().palace_d2h(self.ctx.h, out.ctypes.data, self.ptr, self.nbytes), "palace_d2h")
+        return out.reshape(self.shape) if self.shape is not None else out
+
+    def free(self):
+        if self.ptr:
+            lib().palace_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Ctx:
+    """One device context (one HIP stream).  `calls` go straight to the C ABI."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        _check(lib().palace_ctx_create(device, C.byref(h)), "palace_ctx_create")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib().palace_ctx_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- memory ---------------------------------------------------------------------------
+    def upload(self, arr: np.ndarray) -> DevBuf:
+        a = np.ascontiguousarray(arr)
+        b = DevBuf(self, max(a.nbytes, 1), a.dtype, a.shape)
+        if a.nbytes:
+            _check(lib().palace_h2d(self.h, b.ptr, a.ctypes.data, a.nbytes), "palace_h2d")
+        return b
+
+    def empty(self, shape, dtype) -> DevBuf:
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return DevBuf(self, max(n, 1), dtype, tuple(np.atleast_1d(shape)))
+
+    def d2d(self, dst_ptr: int, src_ptr: int, nbytes: int):
+        _check(lib().palace_d2d(self.h, dst_ptr, src_ptr, nbytes), "palace_d2d")
+
+    def sync(self):
+        _check(lib().palace_sync(self.h), "palace_sync")
+
+    def timer_begin(self):
+        _check(lib().palace_timer_begin(self.h), "palace_timer_begin")
+
+    def timer_end(self) -> float:
+        ms = C.c_float()
+        _check(lib().palace_timer_end(self.h, C.byref(ms)), "palace_timer_end")
+        return ms.value
+
+    @property
+    def stream(self) -> int:
+        return lib().palace_stream(self.h)
+
+    # -- eref -----------------------------------------------------------------------------
+    def eref_set_coder(self, header400: np.ndarray):
+        h = np.ascontiguousarray(header400, dtype=np.uint8)
+        assert h.size == 400
+        _check(lib().palace_eref_set_coder(self.h, h.ctypes.data), "palace_eref_set_coder")
+
+    def eref_table_reset(self):
+        _check(lib().palace_eref_table_reset(self.h), "palace_eref_table_reset")
+
+    def eref_count_reads(self, d_bases: DevBuf, d_offsets: DevBuf, n_reads: int, d_keep: DevBuf | None = None):
+        _check(lib().palace_eref_count_reads(self.h, d_bases.ptr, d_offsets.ptr, n_reads,
+                                             d_keep.ptr if d_keep else None), "palace_eref_count_reads")
+
+    def eref_scan_refs(self, d_bases: DevBuf, d_offsets: DevBuf, n_refs: int, total_bases: int,
+                       one_min: int, three_min: int, d_rows: DevBuf):
+        _check(lib().palace_eref_scan_refs(self.h, d_bases.ptr, d_offsets.ptr, n_refs, total_bases,
+                                           one_min, three_min, d_rows.ptr), "palace_eref_scan_refs")
+
+    def eref_index_refs(self, d_bases: DevBuf, d_offsets: DevBuf, n_refs: int, d_out: DevBuf, d_out_offsets: DevBuf):
+        _check(lib().palace_eref_index_refs(self.h, d_bases.ptr, d_offsets.ptr, n_refs, d_out.ptr,
+                                            d_out_offsets.ptr), "palace_eref_index_refs")
+
+    def eref_table_lookup(self, keys: np.ndarray) -> np.ndarray:
+        k = self.upload(np.ascontiguousarray(keys, dtype=np.uint32))
+        out = self.empty(len(keys), np.uint8)
+        _check(lib().palace_eref_table_lookup(self.h, k.ptr, len(keys), out.ptr), "palace_eref_table_lookup")
+        res = out.to_host()
+        k.free()
+        out.free()
+        return res
+
+    def eref_table_popcounts(self):
+        out = (C.c_uint64 * 3)()
+        _check(lib().palace_eref_table_popcounts(self.h, out), "palace_eref_table_popcounts")
+        return [int(v) for v in out]
+
+    def eref_table_planes(self):
+        ptrs = (C.c_void_p * 3)()
+        nbytes = C.c_size_t()
+        _check(lib().palace_eref_table_planes(self.h, ptrs, C.byref(nbytes)), "palace_eref_table_planes")
+        return [int(p) for p in ptrs], int(nbytes.value)
+
+    def eref_table_merge_slices(self, parts_ptr: int, n_parts: int, slice_off: int, slice_bytes: int):
+        _check(lib().palace_eref_table_merge_slices(self.h, parts_ptr, n_parts, slice_off, slice_bytes),
+               "palace_eref_table_merge_slices")
+
+
+def window_minimums(hit_ratio: float, perfect_ratio: float):
+    """int(500 * float32(ratio)) -- the expression of extract_ref.cpp:513-514."""
+    w = np.float32(500)
+    return int(w * np.float32(hit_ratio)), int(w * np.float32(perfect_ratio))

@@ -149,6 +149,13 @@ int palace_d2h(palace_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
     return PALACE_OK;
 }
 
+int palace_d2d(palace_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
+{
+    PALACE_REQUIRE(ctx && (bytes == 0 || (d_dst && d_src)), "null argument");
+    if (bytes) PALACE_HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return PALACE_OK;
+}
+
 int palace_timer_begin(palace_ctx *ctx)
 {
     PALACE_REQUIRE(ctx, "ctx is null");

@@ -1,0 +1,31 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and
+exports every symbol include/palace_hip.h declares.  No compute calls (no GPU here)."""
+import ctypes
+
+from palace_amd import capi
+
+
+def test_library_exports_every_declared_symbol():
+    capi.build()
+    lib = capi.lib()
+    names = capi.declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    assert b"gfx950" in lib.palace_version()
+
+
+def test_every_declared_symbol_has_a_python_signature():
+    have = set(capi._SIGS) | {"palace_last_error", "palace_version", "palace_stream"}
+    assert set(capi.declared_symbols()) <= have
+
+
+def test_ctx_create_without_gpu_fails_loudly_or_works():
+    import torch
+    h = ctypes.c_void_p()
+    rc = capi.lib().palace_ctx_create(0, ctypes.byref(h))
+    if torch.cuda.is_available():
+        assert rc == 0
+        capi.lib().palace_ctx_destroy(h)
+    else:
+        assert rc < 0 and capi.lib().palace_last_error()

@@ -1,0 +1,250 @@
+"""GPU parity of the eref HIP path (through the C ABI) against the oracle and the golden vectors
+the compiled reference produced.  Bit-exact: this is integer/index work."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+from palace_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def parse_fasta(buf: bytes):
+    """-> list of sequences (np.uint8) in file order (test helper; '\n'-stripped concatenation)."""
+    seqs, cur = [], None
+    for line in buf.split(b"\n"):
+        if line.startswith(b">"):
+            if cur is not None:
+                seqs.append(np.frombuffer(b"".join(cur), dtype=np.uint8))
+            cur = []
+        elif cur is not None:
+            cur.append(line)
+    if cur is not None:
+        seqs.append(np.frombuffer(b"".join(cur), dtype=np.uint8))
+    return seqs
+
+
+def oracle_key_counts(bases, offsets, cc):
+    """unique canonical indices of a read set with min(3, multiplicity), via the oracle."""
+    keys = []
+    for r in range(len(offsets) - 1):
+        s = bases[offsets[r]:offsets[r + 1]]
+        if len(s) >= 32:
+            k = orc.index_ref(s, cc)
+            keys.append(k[k != 0])
+    if not keys:
+        return np.zeros(0, np.uint32), np.zeros(0, np.int64)
+    u, c = np.unique(np.concatenate(keys), return_counts=True)
+    return u, np.minimum(c, 3)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Ctx(0)
+    yield c
+    c.close()
+
+
+def count_on_gpu(ctx, readsets, header, keep=None):
+    ctx.eref_set_coder(header)
+    ctx.eref_table_reset()
+    for i, (b, o) in enumerate(readsets):
+        db, do = ctx.upload(b), ctx.upload(np.asarray(o, dtype=np.int64))
+        dk = ctx.upload(keep[i]) if keep is not None else None
+        ctx.eref_count_reads(db, do, len(o) - 1, dk)
+        ctx.sync()
+        db.free(); do.free()
+        if dk: dk.free()
+
+
+def assert_table_equals(ctx, u, c):
+    got = ctx.eref_table_lookup(u) if len(u) else np.zeros(0, np.uint8)
+    assert np.array_equal(got, c.astype(np.uint8))
+    pops = ctx.eref_table_popcounts()
+    assert pops == [int((c >= 1).sum()), int((c >= 2).sum()), int((c >= 3).sum())]   # nothing else is set
+
+
+def test_count_table_golden_reads(ctx, golden_eref):
+    g = golden_eref
+    cc = orc.header_to_cc(g["index_header"])
+    sets = [(g["r1_bases"], g["r1_offsets"]), (g["r2_bases"], g["r2_offsets"])]
+    count_on_gpu(ctx, sets, g["index_header"])
+    u, c = oracle_key_counts(np.concatenate([g["r1_bases"], g["r2_bases"]]),
+                             np.concatenate([g["r1_offsets"], g["r2_offsets"][1:] + g["r1_offsets"][-1]]), cc)
+    assert_table_equals(ctx, u, c)
+    # and against the reference-shaped byte table of the oracle
+    t = orc.CountTable()
+    for b, o in sets:
+        t.count(b, o, cc)
+    assert np.array_equal(t.lookup(u), c.astype(np.uint8))
+    t.free()
+
+
+@pytest.mark.parametrize("key,hr,pr", [("stdout_090_085", 0.9, 0.85), ("stdout_080_050", 0.8, 0.5),
+                                       ("stdout_095_090", 0.95, 0.9)])
+def test_stdout_equals_reference(ctx, golden_eref, key, hr, pr):
+    g = golden_eref
+    count_on_gpu(ctx, [(g["r1_bases"], g["r1_offsets"]), (g["r2_bases"], g["r2_offsets"])], g["index_header"])
+    refs = [s for s in parse_fasta(g["db_fasta"].tobytes()) if len(s) > 32]     # extract_ref.cpp:697
+    rs = synth.reads_from_list(refs)
+    db, do = ctx.upload(rs.bases), ctx.upload(rs.offsets)
+    rows = ctx.empty((rs.n, 4), np.int32)
+    one_min, three_min = capi.window_minimums(hr, pr)
+    ctx.eref_scan_refs(db, do, rs.n, len(rs.bases), one_min, three_min, rows)
+    r = rows.to_host()
+    out = b""
+    for i in range(rs.n):
+        n_int, el, L, _ = (int(v) for v in r[i])
+        assert L == len(refs[i])
+        if el > 0 and np.float32(el) / np.float32(L) > 0.75:
+            out += orc.format_line(i + 1, n_int, el, L)
+    assert out == g[key].tobytes()
+    for b in (db, do, rows):
+        b.free()
+
+
+def test_index_build_equals_reference(ctx, golden_eref):
+    g = golden_eref
+    ctx.eref_set_coder(g["index_header"])
+    refs = [s for s in parse_fasta(g["db_fasta"].tobytes()) if len(s) > 32]
+    rs = synth.reads_from_list(refs)
+    npos = np.array([len(s) - 31 for s in refs], dtype=np.int64)
+    out_off = np.zeros(len(refs) + 1, dtype=np.int64)
+    np.cumsum(3 * npos, out=out_off[1:])
+    db, do, doo = ctx.upload(rs.bases), ctx.upload(rs.offsets), ctx.upload(out_off)
+    out = ctx.empty(int(out_off[-1]), np.uint32)
+    ctx.eref_index_refs(db, do, rs.n, out, doo)
+    idx = out.to_host()
+    body = b"".join(np.uint32(len(s)).tobytes() + idx[out_off[i]:out_off[i + 1]].tobytes()
+                    for i, s in enumerate(refs))
+    assert hashlib.sha256(body).digest() == g["index_body_sha256"].tobytes()
+    for b in (db, do, doo, out):
+        b.free()
+
+
+def test_edge_cases(ctx):
+    rng = synth.rng_for(7)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    cc = orc.header_to_cc(hdr)
+    base = synth.random_dna(rng, 5000)
+    reads = [base[:0], base[:1], base[:31], base[:32], base[10:43], base[100:1100].copy(), base[200:264],
+             base[300:395], base[300:396], base[300:397], np.frombuffer(b"A" * 200, dtype=np.uint8),
+             np.frombuffer(base[500:700].tobytes().lower(), dtype=np.uint8)]
+    withn = base[1000:1300].copy(); withn[[0, 31, 32, 150, 299]] = ord("N"); reads.append(withn)
+    weird = base[2000:2100].copy(); weird[50] = 0xC3; weird[51] = ord("\r"); reads.append(weird)
+    rs = synth.reads_from_list(reads)
+    count_on_gpu(ctx, [(rs.bases, rs.offsets)], hdr)
+    u, c = oracle_key_counts(rs.bases, rs.offsets, cc)
+    assert_table_equals(ctx, u, c)
+    # empty read set is a no-op
+    ctx.eref_table_reset()
+    ctx.eref_count_reads(ctx.upload(np.zeros(1, np.uint8)), ctx.upload(np.zeros(1, np.int64)), 0)
+    assert ctx.eref_table_popcounts() == [0, 0, 0]
+
+
+def test_keep_mask(ctx):
+    rng = synth.rng_for(11)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    cc = orc.header_to_cc(hdr)
+    rs = synth.vector_reads(rng, synth.random_dna(rng, 50000), 3000, 100)
+    keep = (rng.random(rs.n) < 0.5).astype(np.uint8)
+    count_on_gpu(ctx, [(rs.bases, rs.offsets)], hdr, keep=[keep])
+    kept = [rs.read(i) for i in range(rs.n) if keep[i]]
+    ks = synth.reads_from_list(kept)
+    u, c = oracle_key_counts(ks.bases, ks.offsets, cc)
+    assert_table_equals(ctx, u, c)
+
+
+def test_random_reads_medium(ctx):
+    """60k x 150 bp with heavy duplication (small pool) so counts 1, 2 and >=3 all occur."""
+    rng = synth.rng_for(3)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    cc = orc.header_to_cc(hdr)
+    rs = synth.vector_reads(rng, synth.random_dna(rng, 3_000_000), 60000, 150)
+    count_on_gpu(ctx, [(rs.bases, rs.offsets)], hdr)
+    t = orc.CountTable()
+    t.count(rs.bases, rs.offsets, cc)
+    u, c = oracle_key_counts(rs.bases, rs.offsets, cc)
+    assert np.array_equal(t.lookup(u), c.astype(np.uint8))
+    assert_table_equals(ctx, u, c)
+    assert (c == 1).any() and (c == 2).any() and (c == 3).any()
+    t.free()
+
+
+def test_scan_matches_oracle_on_random_coverage(ctx):
+    """Refs with patchy coverage, several ratio pairs: rows equal the oracle's (n_intervals, el)."""
+    rng = synth.rng_for(5)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    cc = orc.header_to_cc(hdr)
+    refs, reads = [], []
+    for L in (500, 501, 999, 1000, 2048, 4096, 4097, 12345, 33, 64, 65, 40000):
+        s = synth.random_dna(rng, L)
+        refs.append(s)
+        n_seg = int(rng.integers(0, 4))
+        for _ in range(n_seg):
+            a = int(rng.integers(0, max(1, L - 200)))
+            b = int(min(L, a + rng.integers(200, 9000)))
+            if b - a < 120:
+                continue
+            for _ in range(int(6 * (b - a) / 100)):
+                st = int(rng.integers(a, b - 100))
+                reads.append(synth.mutate(rng, s[st:st + 100], 0.01))
+    rr = synth.reads_from_list(reads)
+    count_on_gpu(ctx, [(rr.bases, rr.offsets)], hdr)
+    t = orc.CountTable()
+    t.count(rr.bases, rr.offsets, cc)
+    rs = synth.reads_from_list(refs)
+    db, do = ctx.upload(rs.bases), ctx.upload(rs.offsets)
+    rows = ctx.empty((rs.n, 4), np.int32)
+    for hr, pr in ((0.9, 0.85), (0.5, 0.2), (0.99, 0.97), (0.7, 0.7)):
+        one_min, three_min = capi.window_minimums(hr, pr)
+        ctx.eref_scan_refs(db, do, rs.n, len(rs.bases), one_min, three_min, rows)
+        got = rows.to_host()
+        for i, s in enumerate(refs):
+            _, n_int, el, _ = orc.scan_ref(orc.index_ref(s, cc), len(s), t, hr, pr)
+            assert (int(got[i, 0]), int(got[i, 1]), int(got[i, 2])) == (n_int, el, len(s)), (i, len(s), hr, pr)
+    t.free()
+
+
+def test_properties_full_size(ctx):
+    """Size-independent properties at bench scale (2M reads): order independence, idempotence at
+    saturation (x3 == x4), and the saturating merge of partial tables equals one-shot counting."""
+    rng = synth.rng_for(9)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    pool = synth.random_dna(rng, 20_000_000)
+    a = synth.vector_reads(rng, pool, 1_000_000, 150)
+    b = synth.vector_reads(rng, pool, 1_000_000, 150)
+    da, dao = ctx.upload(a.bases), ctx.upload(a.offsets)
+    dbb, dbo = ctx.upload(b.bases), ctx.upload(b.offsets)
+    ctx.eref_set_coder(hdr)
+    probe = np.unique(rng.integers(0, 2**32, size=200000, dtype=np.uint64).astype(np.uint32))
+
+    def run(seq):
+        ctx.eref_table_reset()
+        for (x, xo, n) in seq:
+            ctx.eref_count_reads(x, xo, n)
+        ctx.sync()
+        return ctx.eref_table_popcounts(), ctx.eref_table_lookup(probe)
+
+    A, B = (da, dao, a.n), (dbb, dbo, b.n)
+    p_ab, l_ab = run([A, B])
+    p_ba, l_ba = run([B, A])
+    assert p_ab == p_ba and np.array_equal(l_ab, l_ba)
+    p3, l3 = run([A, A, A])
+    p4, l4 = run([A, A, A, A])
+    assert p3 == p4 and np.array_equal(l3, l4) and p3[0] == p3[1] == p3[2]
+    # merge: parts = [table(A), table(B)] -> planes == table(A then B)
+    planes, nbytes = ctx.eref_table_planes()
+    parts = ctx.empty(2 * 3 * nbytes, np.uint8)
+    for k, S in enumerate((A, B)):
+        run([S])
+        for p in range(3):
+            ctx.d2d(parts.ptr + (k * 3 + p) * nbytes, planes[p], nbytes)
+    ctx.eref_table_reset()
+    ctx.eref_table_merge_slices(parts.ptr, 2, 0, nbytes)
+    ctx.sync()
+    assert ctx.eref_table_popcounts() == p_ab and np.array_equal(ctx.eref_table_lookup(probe), l_ab)
+    for buf in (da, dao, dbb, dbo, parts):
+        buf.free()
