@@ -47,6 +47,10 @@ int palace_d2d(palace_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 /* HIP-event timing on the context's stream: begin/end bracket, elapsed in milliseconds. */
 int palace_timer_begin(palace_ctx *ctx);
 int palace_timer_end(palace_ctx *ctx, float *ms_out);
+/* Non-blocking variant for timing kernels inside a longer timed region: mark(i) records event i
+ * (0 <= i < 4096) on the stream; mark_elapsed(a, b) waits for event b and returns b - a in ms. */
+int palace_mark(palace_ctx *ctx, int i);
+int palace_mark_elapsed(palace_ctx *ctx, int a, int b, float *ms_out);
 
 /* ---- eref: k-mer screening of reads against the phage DB (bin/extract_ref.cpp) ---------- */
 

@@ -30,6 +30,7 @@ def lib() -> C.CDLL:
         L = _LIB
         L.orc_table_new.restype = C.c_void_p
         L.orc_table_free.argtypes = [C.c_void_p]
+        L.orc_table_clear.argtypes = [C.c_void_p]
         L.orc_count_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_index_ref.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.orc_scan_ref.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
@@ -86,6 +87,9 @@ class CountTable:
         o = np.ascontiguousarray(offsets, dtype=np.int64)
         k = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
         lib().orc_count_reads(_p(b), _p(o), len(o) - 1, None if k is None else _p(k), _p(cc), self.ptr)
+
+    def clear(self):
+        lib().orc_table_clear(self.ptr)
 
     def lookup(self, keys: np.ndarray) -> np.ndarray:
         return self.view[np.asarray(keys, dtype=np.int64)]

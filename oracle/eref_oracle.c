@@ -82,16 +82,29 @@ void orc_cc_from_picks(const uint8_t picks[32], int16_t cc[96])
         for (int i = 0; i < 3; i++) cc[3 * z + i] = orders[3 * picks[z] + i];
 }
 
+/* Lookup-table form of orc_base_code / orc_complement, as the reference holds them
+ * (static char coder[1000] with stride 300, static char comple[256]; extract_ref.cpp:1013, 1067). */
+static uint8_t g_code[3][256], g_comp[256];
+static int g_tables_ready = 0;
+static void init_tables(void)
+{
+    for (int p = 0; p < 3; p++)
+        for (int ch = 0; ch < 256; ch++) g_code[p][ch] = (uint8_t)orc_base_code(p, (unsigned char)ch);
+    for (int ch = 0; ch < 256; ch++) g_comp[ch] = orc_complement((unsigned char)ch);
+    g_tables_ready = 1;
+}
+
 /* The inner loop shared by extract_ref.cpp:717-735 (reference side) and :971-994 (read side):
  * forward index with weight 2^(31-z) at offset z, reverse-complement index built in the same
  * pass, canonical = the smaller.  Returns 0 and *valid=0 at the first invalid base. */
 uint32_t orc_canonical_index(const unsigned char *s, const int16_t cc[96], int channel, int *valid)
 {
+    if (!g_tables_ready) init_tables();
     uint32_t fwd = 0, rc = 0;
     for (int z = 0; z < K; z++) {
-        int m = orc_base_code(cc[3 * z + channel], s[z]);
+        int m = g_code[cc[3 * z + channel]][s[z]];
         if (m == 5) { *valid = 0; return 0; }
-        int n = orc_base_code(cc[3 * (K - 1 - z) + channel], orc_complement(s[z]));
+        int n = g_code[cc[3 * (K - 1 - z) + channel]][g_comp[s[z]]];
         fwd += (uint32_t)m << (K - 1 - z);
         rc += (uint32_t)n << z;
     }
@@ -102,6 +115,8 @@ uint32_t orc_canonical_index(const unsigned char *s, const int16_t cc[96], int c
 /* extract_ref.cpp:25-26, 1257: the 2^32-entry byte table, zeroed. */
 uint8_t *orc_table_new(void) { return (uint8_t *)calloc(TABLE_ENTRIES, 1); }
 void orc_table_free(uint8_t *t) { free(t); }
+/* extract_ref.cpp:1257: memset of the whole table (also faults every page in). */
+void orc_table_clear(uint8_t *t) { memset(t, 0, TABLE_ENTRIES); }
 
 /* extract_ref.cpp:961-1000 (read_fastq body for one sequence line): every position, every
  * channel, saturating increment at least_depth = 3 (extract_ref.cpp:23, 995-996). */

@@ -42,6 +42,8 @@ _SIGS = {
     "palace_d2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "palace_timer_begin": [C.c_void_p],
     "palace_timer_end": [C.c_void_p, C.POINTER(C.c_float)],
+    "palace_mark": [C.c_void_p, C.c_int],
+    "palace_mark_elapsed": [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)],
     "palace_eref_set_coder": [C.c_void_p, C.c_void_p],
     "palace_eref_index_refs": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     "palace_eref_table_reset": [C.c_void_p],
@@ -150,6 +152,14 @@ class Ctx:
     def timer_end(self) -> float:
         ms = C.c_float()
         _check(lib().palace_timer_end(self.h, C.byref(ms)), "palace_timer_end")
+        return ms.value
+
+    def mark(self, i: int):
+        _check(lib().palace_mark(self.h, i), "palace_mark")
+
+    def mark_elapsed(self, a: int, b: int) -> float:
+        ms = C.c_float()
+        _check(lib().palace_mark_elapsed(self.h, a, b, C.byref(ms)), "palace_mark_elapsed")
         return ms.value
 
     @property

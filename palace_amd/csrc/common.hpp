@@ -53,6 +53,7 @@ struct palace_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> marks;   // lazily created
     // eref
     bool coder_set = false;
     palace::CoderMasks masks{};

@@ -85,6 +85,8 @@ int palace_ctx_destroy(palace_ctx *ctx)
         if (ctx->plane[p]) (void)hipFree(ctx->plane[p]);
     if (ctx->ws.ptr) (void)hipFree(ctx->ws.ptr);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
+    for (hipEvent_t e : ctx->marks)
+        if (e) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
@@ -169,6 +171,25 @@ int palace_timer_end(palace_ctx *ctx, float *ms_out)
     PALACE_HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     PALACE_HIP_TRY(hipEventSynchronize(ctx->ev1));
     PALACE_HIP_TRY(hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+    return PALACE_OK;
+}
+
+int palace_mark(palace_ctx *ctx, int i)
+{
+    PALACE_REQUIRE(ctx && i >= 0 && i < 4096, "mark index out of range");
+    if (ctx->marks.size() <= static_cast<size_t>(i)) ctx->marks.resize(i + 1, nullptr);
+    if (!ctx->marks[i]) PALACE_HIP_TRY(hipEventCreate(&ctx->marks[i]));
+    PALACE_HIP_TRY(hipEventRecord(ctx->marks[i], ctx->stream));
+    return PALACE_OK;
+}
+
+int palace_mark_elapsed(palace_ctx *ctx, int a, int b, float *ms_out)
+{
+    PALACE_REQUIRE(ctx && ms_out && a >= 0 && b >= 0 && static_cast<size_t>(a) < ctx->marks.size() &&
+                       static_cast<size_t>(b) < ctx->marks.size() && ctx->marks[a] && ctx->marks[b],
+                   "marks not recorded");
+    PALACE_HIP_TRY(hipEventSynchronize(ctx->marks[b]));
+    PALACE_HIP_TRY(hipEventElapsedTime(ms_out, ctx->marks[a], ctx->marks[b]));
     return PALACE_OK;
 }
 
