@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (gpurun_out/...) into a small text summary for profiles/.
+usage: rocprof_summary.py <out.md> --stats <kernel_stats.csv> [--pmc NAME=<counter_collection.csv> ...] [--note TEXT]"""
+import collections
+import csv
+import sys
+
+
+def main():
+    out, args = sys.argv[1], sys.argv[2:]
+    lines = []
+    i = 0
+    while i < len(args):
+        if args[i] == "--note":
+            lines.append(args[i + 1] + "\n")
+        elif args[i] == "--stats":
+            lines.append("## rocprofv3 --kernel-trace --stats (palace kernels + top others)\n")
+            lines.append("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|")
+            rows = list(csv.DictReader(open(args[i + 1])))
+            keep = [r for r in rows if "palace::" in r["Name"]] + [r for r in rows if "palace::" not in r["Name"]][:4]
+            for r in keep:
+                nm = r["Name"].split("(")[0].replace("void ", "")[:70]
+                lines.append(f"| {nm} | {r['Calls']} | {float(r['AverageNs'])/1e6:.4f} | "
+                             f"{float(r['TotalDurationNs'])/1e6:.3f} | {float(r['Percentage']):.2f} |")
+            lines.append("")
+        elif args[i] == "--pmc":
+            name, path = args[i + 1].split("=", 1)
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(path)):
+                if r["Counter_Name"] == name and "palace::" in r["Kernel_Name"]:
+                    agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+            lines.append(f"## rocprofv3 --pmc {name} (own pass; per-dispatch mean, counter unit = KiB)\n")
+            lines.append("| kernel | dispatches | mean value (KiB) | mean GB |\n|---|---|---|---|")
+            for k, v in agg.items():
+                m = sum(v) / len(v)
+                lines.append(f"| {k[:70]} | {len(v)} | {m:.1f} | {m*1024/1e9:.3f} |")
+            lines.append("")
+        i += 2
+    open(out, "w").write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()
