@@ -154,3 +154,68 @@ def glibc_rand_stream(seed: int, n: int) -> np.ndarray:
     out = np.array([lib().orc_rand_next(st) for _ in range(n)], dtype=np.int64)
     lib().orc_rand_free(st)
     return out
+
+
+# ---- generateGraph restatement (oracle/graph_oracle.cpp) -------------------------------------
+class _OrcRecords(C.Structure):
+    _fields_ = [("n", C.c_int64), ("flag", C.c_void_p), ("tid", C.c_void_p), ("pos", C.c_void_p),
+                ("mtid", C.c_void_p), ("mpos", C.c_void_p), ("mapq", C.c_void_p), ("nm", C.c_void_p),
+                ("cigar_off", C.c_void_p), ("cigar", C.c_void_p), ("qname_off", C.c_void_p), ("qname", C.c_void_p),
+                ("sa_off", C.c_void_p), ("sa", C.c_void_p), ("has_sa", C.c_void_p)]
+
+
+class GraphOpts(C.Structure):
+    _fields_ = [("max_end", C.c_int), ("min_mapq", C.c_int), ("max_nm", C.c_int), ("enable_paired", C.c_int),
+                ("both_order", C.c_int), ("min_count", C.c_int), ("max_span_frac", C.c_double)]
+
+
+def graph_default_opts() -> GraphOpts:
+    o = GraphOpts()
+    lib().orc_graph_default_opts(C.byref(o))
+    return o
+
+
+def _concat(strings):
+    bs = [s.encode() if isinstance(s, str) else s for s in strings]
+    off = np.zeros(len(bs) + 1, dtype=np.int64)
+    np.cumsum([len(b) for b in bs], out=off[1:])
+    return np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8).copy(), off
+
+
+def graph_run(records, targets, fastg_fai: str, avg_depth: float, opts: GraphOpts | None = None) -> bytes:
+    """records: list of palace_amd.synth.BamRecord (file order); targets: [(name, len)]."""
+    from palace_amd.synth import parse_cigar
+    n = len(records)
+    keep = []
+    flag = np.array([r.flag for r in records], dtype=np.uint16)
+    tid = np.array([r.tid for r in records], dtype=np.int32)
+    pos = np.array([r.pos for r in records], dtype=np.int32)
+    mtid = np.array([r.mtid for r in records], dtype=np.int32)
+    mpos = np.array([r.mpos for r in records], dtype=np.int32)
+    mapq = np.array([r.mapq for r in records], dtype=np.uint8)
+    nm = np.array([0 if r.nm is None else r.nm for r in records], dtype=np.int32)
+    cig = [np.array([(ln << 4) | op for ln, op in parse_cigar(r.cigar)], dtype=np.uint32) for r in records]
+    cigar_off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(c) for c in cig], out=cigar_off[1:])
+    cigar = np.concatenate(cig) if n else np.zeros(0, np.uint32)
+    cigar = np.ascontiguousarray(np.append(cigar, np.uint32(0)))
+    qn, qoff = _concat([r.qname for r in records])
+    sa, saoff = _concat([r.sa or "" for r in records])
+    has_sa = np.array([r.sa is not None for r in records], dtype=np.uint8)
+    tn, toff = _concat([t[0] for t in targets])
+    tlen = np.array([t[1] for t in targets], dtype=np.int32)
+    keep += [flag, tid, pos, mtid, mpos, mapq, nm, cigar_off, cigar, qn, qoff, sa, saoff, has_sa, tn, toff, tlen]
+    R = _OrcRecords(n, *(a.ctypes.data for a in (flag, tid, pos, mtid, mpos, mapq, nm, cigar_off, cigar, qoff, qn,
+                                                 saoff, sa, has_sa)))
+    o = opts or graph_default_opts()
+    cap = 64 * 1024 * 1024 + 200 * len(targets)
+    buf = C.create_string_buffer(cap)
+    L = lib()
+    L.orc_graph_run.restype = C.c_long
+    L.orc_graph_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_double,
+                                C.c_void_p, C.c_char_p, C.c_size_t]
+    got = L.orc_graph_run(C.byref(R), len(targets), tn.ctypes.data, toff.ctypes.data, tlen.ctypes.data,
+                          fastg_fai.encode(), avg_depth, C.byref(o), buf, cap)
+    if got < 0:
+        raise OSError("orc_graph_run: output buffer too small")
+    return buf.raw[:got]

@@ -1,0 +1,47 @@
+"""oracle/graph_oracle.cpp against hand-derived expectations (no reference-run golden exists for
+generateGraph: htslib is absent, see the oracle's header)."""
+import dataclasses
+
+from oracle import binding as orc
+from tests import graph_cases as gc
+
+
+def run(records, tmp_path, targets=gc.TARGETS, fai=gc.FASTG_FAI, avg=gc.AVG_DEPTH, **opt):
+    p = tmp_path / "g.fastg.fai"
+    p.write_text(fai)
+    o = orc.graph_default_opts()
+    for k, v in opt.items():
+        setattr(o, k, v)
+    return orc.graph_run(records, targets, str(p), avg, o)
+
+
+def test_hand_case(tmp_path):
+    assert run(gc.records(), tmp_path) == gc.EXPECTED
+
+
+def test_min_count_and_flags(tmp_path):
+    recs = gc.records()
+    out = run(recs, tmp_path, min_count=6)
+    assert b"JUNC ctgA + ctgC" not in out and b"JUNC ctgA + ctgB + 7 0" in out
+    # secondary / supplementary / unmapped records contribute nothing, not even depth
+    extra = [dataclasses.replace(recs[0], flag=f, qname=f"x{f}") for f in (0x100, 0x800, 0x4)]
+    assert run(extra + recs, tmp_path) == gc.EXPECTED
+
+
+def test_mapq_zero_kills_score_but_still_marks_pair(tmp_path):
+    recs = [dataclasses.replace(r, mapq=0) if r.qname.startswith("p") and r.tid == 0 else r for r in gc.records()]
+    out = run(recs, tmp_path)
+    assert b"JUNC ctgA + ctgC" not in out
+    assert b"SEG ctgA 1.36 3" in out          # the mates still hit the processed-pairs quirk
+
+
+def test_long_contig_underflow_gate(tmp_path):
+    """'-' orientation measures distance to the far end: on a 120 kb contig exp() underflows to 0."""
+    targets = [("ctgA", 120000), ("ctgB", 2000)]
+    fai = "ctgA;\t1\n"
+    from palace_amd.synth import BamRecord
+    mk = lambda i, L: BamRecord(f"t{i}", 0x10, 1, 4, 60, "40S60M", nm=0, sa=f"ctgA,{L - 100},-,60S40M,60,0;")
+    out_long = run([mk(i, 120000) for i in range(6)], tmp_path, targets, fai)
+    assert b"JUNC" not in out_long
+    out_short = run([mk(i, 50000) for i in range(6)], tmp_path, [("ctgA", 50000), ("ctgB", 2000)], fai)
+    assert b"JUNC ctgA + ctgB + 6 0" in out_short
