@@ -95,6 +95,88 @@ int palace_eref_table_merge_slices(palace_ctx *ctx, const void *d_parts, int n_p
 int palace_eref_table_lookup(palace_ctx *ctx, const uint32_t *d_keys, int64_t n, uint8_t *d_counts);
 int palace_eref_table_popcounts(palace_ctx *ctx, uint64_t out3[3]);
 
+/* ---- generateGraph: BAM evidence -> conjugate graph (bin/generate_graph.cpp) ------------ */
+
+/* Options of generate_graph.cpp:20-44 (defaults there; set by its getopt loop :573-593). */
+typedef struct {
+    int32_t max_end;        /* MAX_END        300 */
+    int32_t min_mapq;       /* MIN_MAPQ         0 */
+    int32_t max_nm;         /* MAX_NM           5 */
+    int32_t enable_paired;  /* ENABLE_PAIRED    1 */
+    int32_t both_order;     /* OUTPUT_BOTH_ORDER 0 */
+    int32_t reserved;
+    double max_span_frac;   /* MAX_SPAN_FRAC 0.80 */
+} palace_graph_params;
+
+/* Decoded primary-alignment columns, one entry per BAM record in file order (device pointers).
+ * What htslib's bam1_t hands the reference at generate_graph.cpp:644-698, as structure of arrays:
+ * ref_len = bam_cigar2rlen; read_len = getReadLength (:385-397); clip_s / clip_e = the soft clips
+ * parseCigarReadInterval (:330-383) finds on the record's own CIGAR; nm = NM tag or 0; qkey = a
+ * (clip_s = -1 marks a record without CIGAR ops, whose read interval is [0,0], :332); qkey = a
+ * 64-bit key of the read name (equal names <=> equal keys, guaranteed by the caller);
+ * sa_off[i]..sa_off[i+1] = the record's parsed SA items (empty when the tag is absent). */
+typedef struct {
+    int64_t n;
+    const int32_t *tid, *pos, *mtid, *mpos, *nm, *ref_len, *read_len, *clip_s, *clip_e;
+    const uint16_t *flag;
+    const uint8_t *mapq;
+    const uint64_t *qkey;
+    const int32_t *sa_off;
+} palace_bam_cols;
+
+/* One parsed SA item (parseSAItem + parseCigarReadInterval on its CIGAR, :185-206, :744;
+ * clip_s2 = -1 when the item's CIGAR text is empty).
+ * tid2 < 0 when the item must be skipped (name equals the primary's contig :731, or is not in the
+ * header :733-734); items that fail to parse are not listed at all. */
+typedef struct {
+    int32_t tid2, pos2, mapq2, nm2, clip_s2, clip_e2, len2, rev2;
+} palace_sa_item;
+
+/* One piece of candidate evidence (classify output / resolve input).  kind 0 = split read,
+ * 1 = cross-contig pair.  cls: 0 score is 0 (a mapq is 0), 1 score > 0, 2 decided on the host by
+ * libm (exp underflow region of computeLayoutScore, :432-461).  found: a layout exists (:916-938).
+ * left/right/oL/oR are already canonical (:855-861); in_fastg is the :863 lookup. */
+typedef struct {
+    int64_t ord;
+    uint64_t qkey;
+    int32_t left, right;
+    int32_t mtid, ref_len;
+    int32_t dL, dR;
+    int32_t nmL, nmR;
+    int16_t mapqL, mapqR;
+    uint8_t kind, cls, found, in_fastg, oL, oR, pad0, pad1;
+    int32_t pad2;
+} palace_graph_cand;
+
+/* Aggregated edge (AggStats, :300-306): counts[0..3] = supplementCount, supplementCountNoFastg,
+ * spanCount, spanCountNoFastg.  oL/oR: 0 = '+', 1 = '-'. */
+typedef struct {
+    int32_t left, right;
+    uint32_t counts[4];
+    uint8_t oL, oR, pad[6];
+} palace_graph_edge;
+
+/* G2-G5 + first half of G6.  Per record: filters (:647-649, :679), depth accumulation into
+ * d_consumed[tid] (:654-662), split-read (:684-879) and read-pair (:887-1011) layout search.
+ * Appends candidates to d_cands (capacity cand_cap) and returns their number in *n_cands_out.
+ * d_tlen / d_trank: target lengths and the dense rank of each target name in byte order (used for
+ * the `cR < cL` test :856 and for output order).  d_fastg: sorted keys
+ * (tidA << 33 | tidB << 2 | (o1=='-') << 1 | (o2=='-')) of parseFastgFile's set (:119-169).
+ * ord_base is the file ordinal of record 0 of this shard. */
+int palace_graph_classify(palace_ctx *ctx, const palace_bam_cols *cols, const palace_sa_item *d_sa,
+                          int32_t n_targets, const int32_t *d_tlen, const int32_t *d_trank,
+                          const uint64_t *d_fastg, int64_t n_fastg, const palace_graph_params *prm,
+                          int64_t ord_base, uint64_t *d_consumed, palace_graph_cand *d_cands,
+                          int64_t cand_cap, int64_t *n_cands_out);
+
+/* Second half: decide host-side borderline scores, apply the order-dependent rules
+ * (hasSupplementEvidence gating :881-888, processedPairedReads "first in file order wins" and its
+ * mate-contig depth quirk :890-893, :938), aggregate per canonical edge (:866-872, :1002-1008).
+ * n_records_total bounds candidate ordinals.  Writes up to edge_cap edges (unsorted). */
+int palace_graph_resolve(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_cands,
+                         int64_t n_records_total, const palace_graph_params *prm, uint64_t *d_consumed,
+                         palace_graph_edge *d_edges, int64_t edge_cap, int64_t *n_edges_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,308 @@
+#include "bam.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include <thread>
+
+namespace palace_host {
+
+namespace {
+
+uint32_t le32(const uint8_t *p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+uint16_t le16(const uint8_t *p) { uint16_t v; std::memcpy(&v, p, 2); return v; }
+
+std::vector<uint8_t> slurp(const std::string &path)
+{
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) throw std::runtime_error("Failed to open BAM " + path);
+    std::streamsize n = f.tellg();
+    f.seekg(0);
+    std::vector<uint8_t> buf(static_cast<size_t>(n));
+    if (n && !f.read(reinterpret_cast<char *>(buf.data()), n)) throw std::runtime_error("Failed to read BAM " + path);
+    return buf;
+}
+
+template <class F>
+void parallel_for(size_t n, int threads, F f)
+{
+    threads = std::max(1, std::min<int>(threads, static_cast<int>(n ? n : 1)));
+    if (threads == 1) { f(0, n, 0); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++) {
+        size_t a = n * t / threads, b = n * (t + 1) / threads;
+        pool.emplace_back([=] { f(a, b, t); });
+    }
+    for (auto &th : pool) th.join();
+}
+
+// BGZF: gzip members with a BC extra subfield carrying the member size (SAM spec 4.1).
+void inflate_bgzf(const std::vector<uint8_t> &file, int threads, std::vector<uint8_t> &out)
+{
+    struct Block { size_t in_off, in_len, out_off, out_len; };
+    std::vector<Block> blocks;
+    size_t p = 0, total = 0;
+    while (p + 18 <= file.size()) {
+        const uint8_t *h = file.data() + p;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) throw std::runtime_error("Failed to read BAM header");
+        size_t xlen = le16(h + 10), q = 12, bsize = 0;
+        while (q + 4 <= 12 + xlen) {
+            size_t slen = le16(h + q + 2);
+            if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2) bsize = static_cast<size_t>(le16(h + q + 4)) + 1;
+            q += 4 + slen;
+        }
+        if (!bsize || p + bsize > file.size()) throw std::runtime_error("truncated BGZF block");
+        size_t isize = le32(h + bsize - 4);
+        blocks.push_back({p + 12 + xlen, bsize - xlen - 20, total, isize});
+        total += isize;
+        p += bsize;
+    }
+    out.resize(total);
+    bool bad = false;
+    parallel_for(blocks.size(), threads, [&](size_t a, size_t b, int) {
+        for (size_t i = a; i < b; i++) {
+            const Block &k = blocks[i];
+            if (!k.out_len) continue;
+            z_stream zs{};
+            if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
+            zs.next_in = const_cast<Bytef *>(file.data() + k.in_off);
+            zs.avail_in = static_cast<uInt>(k.in_len);
+            zs.next_out = out.data() + k.out_off;
+            zs.avail_out = static_cast<uInt>(k.out_len);
+            int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = true; return; }
+        }
+    });
+    if (bad) throw std::runtime_error("BGZF inflate failed");
+}
+
+// One CIGAR as parseCigarReadInterval sees it (generate_graph.cpp:330-366): zero-length ops are
+// dropped; clip_s = leading S, clip_e = trailing S when more than one op remains; len = query span.
+struct ClipInfo { int32_t clip_s, clip_e, len; };
+
+struct OpScan {
+    int n_ops = 0; int first_len = 0, last_len = 0; char first = 0, last = 0; int32_t len = 0;
+    void add(int n, char c)
+    {
+        if (n <= 0) return;
+        if (!n_ops) { first = c; first_len = n; }
+        last = c; last_len = n; n_ops++;
+        if (c == 'M' || c == 'I' || c == 'S' || c == '=' || c == 'X') len += n;
+    }
+    ClipInfo done() const
+    {
+        ClipInfo r{0, 0, len};
+        if (n_ops && first == 'S') r.clip_s = first_len;
+        if (n_ops > 1 && last == 'S') r.clip_e = last_len;
+        return r;
+    }
+};
+
+ClipInfo clip_from_text(const char *s, size_t n)
+{
+    if (n == 0) return ClipInfo{-1, 0, 0};                 // empty text: interval stays [0,0] (:332)
+    OpScan sc;
+    int acc = 0;
+    for (size_t i = 0; i < n; i++) {
+        unsigned char ch = static_cast<unsigned char>(s[i]);
+        if (std::isdigit(ch)) acc = acc * 10 + (ch - '0');
+        else { sc.add(acc, static_cast<char>(ch)); acc = 0; }
+    }
+    return sc.done();
+}
+
+void trim_ws(const char *&b, const char *&e)
+{
+    while (b < e && std::isspace(static_cast<unsigned char>(*b))) ++b;
+    while (e > b && std::isspace(static_cast<unsigned char>(e[-1]))) --e;
+}
+
+// parseSAItem (generate_graph.cpp:185-206): six comma fields must be extractable in getline's
+// sense (a field exists iff at least one byte -- possibly just its delimiter -- is left).
+bool parse_sa(const char *b, const char *e, const BamColumns &cols, int32_t own_tid, palace_sa_item &out)
+{
+    const char *fb[6], *fe[6];
+    const char *p = b;
+    for (int k = 0; k < 6; k++) {
+        if (p >= e) return false;                          // nothing left: getline fails
+        const char *c = static_cast<const char *>(std::memchr(p, ',', static_cast<size_t>(e - p)));
+        fb[k] = p;
+        fe[k] = c ? c : e;
+        p = c ? c + 1 : e;
+    }
+    for (int k = 0; k < 6; k++) trim_ws(fb[k], fe[k]);
+    if (fb[0] == fe[0] || fb[1] == fe[1]) return false;
+    std::string rname(fb[0], fe[0]);
+    out.pos2 = std::atoi(std::string(fb[1], fe[1]).c_str());
+    out.rev2 = (fe[2] - fb[2] == 1 && *fb[2] == '-') ? 1 : 0;
+    ClipInfo ci = clip_from_text(fb[3], static_cast<size_t>(fe[3] - fb[3]));
+    out.clip_s2 = ci.clip_s; out.clip_e2 = ci.clip_e; out.len2 = ci.len;
+    out.mapq2 = std::atoi(std::string(fb[4], fe[4]).c_str());
+    out.nm2 = std::atoi(std::string(fb[5], fe[5]).c_str());
+    out.tid2 = -1;
+    if (own_tid >= 0 && rname != cols.target_name[own_tid]) {       // r1 == r2 -> skip (:731)
+        auto it = cols.name_to_tid.find(rname);
+        if (it != cols.name_to_tid.end()) out.tid2 = it->second;     // unknown name -> skip (:733-734)
+    }
+    return true;
+}
+
+// size of one aux value at p (type byte already consumed); 0 on malformed input
+size_t aux_size(uint8_t type, const uint8_t *p, const uint8_t *end)
+{
+    switch (type) {
+    case 'A': case 'c': case 'C': return 1;
+    case 's': case 'S': return 2;
+    case 'i': case 'I': case 'f': return 4;
+    case 'Z': case 'H': { const void *z = std::memchr(p, 0, static_cast<size_t>(end - p)); return z ? static_cast<const uint8_t *>(z) - p + 1 : 0; }
+    case 'B': {
+        if (end - p < 5) return 0;
+        size_t es = (p[0] == 'c' || p[0] == 'C') ? 1 : (p[0] == 's' || p[0] == 'S') ? 2 : 4;
+        return 5 + es * le32(p + 1);
+    }
+    default: return 0;
+    }
+}
+
+}  // namespace
+
+uint64_t name_key(const char *s, size_t n, uint64_t seed)
+{
+    uint64_t h = 0xcbf29ce484222325ull ^ (seed * 0x9e3779b97f4a7c15ull);
+    for (size_t i = 0; i < n; i++) { h ^= static_cast<unsigned char>(s[i]); h *= 0x100000001b3ull; }
+    h ^= h >> 32; h *= 0xd6e8feb86659fd93ull; h ^= h >> 32;
+    return h;
+}
+
+void rekey(BamColumns &c, uint64_t seed)
+{
+    for (int64_t i = 0; i < c.n(); i++)
+        c.qkey[i] = name_key(reinterpret_cast<const char *>(c.raw.data()) + c.qname_at[i], c.qname_len[i], seed);
+}
+
+void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumns &c)
+{
+    {
+        std::vector<uint8_t> file = slurp(path);
+        inflate_bgzf(file, threads, c.raw);
+    }
+    const uint8_t *d = c.raw.data();
+    const size_t N = c.raw.size();
+    if (N < 12 || std::memcmp(d, "BAM\1", 4) != 0) throw std::runtime_error("Failed to read BAM header");
+    size_t p = 8 + le32(d + 4);
+    if (p + 4 > N) throw std::runtime_error("Failed to read BAM header");
+    int32_t n_ref = static_cast<int32_t>(le32(d + p));
+    p += 4;
+    for (int32_t i = 0; i < n_ref; i++) {
+        if (p + 4 > N) throw std::runtime_error("Failed to read BAM header");
+        uint32_t l = le32(d + p);
+        if (p + 4 + l + 4 > N) throw std::runtime_error("Failed to read BAM header");
+        std::string nm(reinterpret_cast<const char *>(d + p + 4), l ? l - 1 : 0);
+        c.target_name.push_back(nm);
+        c.target_len.push_back(static_cast<int32_t>(le32(d + p + 4 + l)));
+        c.name_to_tid[nm] = i;
+        p += 8 + l;
+    }
+    std::vector<uint64_t> rec_at;
+    while (p + 4 <= N) {
+        uint32_t bs = le32(d + p);
+        if (bs < 32 || p + 4 + bs > N) break;                   // truncated tail: stop like a failed sam_read1
+        rec_at.push_back(p + 4);
+        p += 4 + bs;
+    }
+    const size_t n = rec_at.size();
+    for (auto *v : {&c.tid, &c.pos, &c.mtid, &c.mpos, &c.nm, &c.ref_len, &c.read_len, &c.clip_s, &c.clip_e})
+        v->assign(n, 0);
+    c.sa_off.assign(n + 1, 0);
+    c.flag.assign(n, 0); c.mapq.assign(n, 0); c.qkey.assign(n, 0);
+    c.qname_at.assign(n, 0); c.qname_len.assign(n, 0);
+    threads = std::max(1, threads);
+    std::vector<std::vector<palace_sa_item>> sa_part(static_cast<size_t>(threads));
+    std::vector<int32_t> sa_cnt(n, 0);
+    parallel_for(n, threads, [&](size_t a, size_t b, int t) {
+        static const char opchr[] = "MIDNSHP=XB??????";
+        for (size_t i = a; i < b; i++) {
+            const uint8_t *r = d + rec_at[i];
+            const uint8_t *end = r + le32(r - 4);
+            const int32_t tid = static_cast<int32_t>(le32(r));
+            c.tid[i] = tid;
+            c.pos[i] = static_cast<int32_t>(le32(r + 4));
+            const size_t l_name = r[8];
+            c.mapq[i] = r[9];
+            const size_t n_cig = le16(r + 12);
+            c.flag[i] = le16(r + 14);
+            const size_t l_seq = le32(r + 16);
+            c.mtid[i] = static_cast<int32_t>(le32(r + 20));
+            c.mpos[i] = static_cast<int32_t>(le32(r + 24));
+            const uint8_t *name = r + 32;
+            size_t nlen = l_name ? l_name - 1 : 0;
+            if (const void *z = std::memchr(name, 0, l_name)) nlen = static_cast<const uint8_t *>(z) - name;   // C-string view (:651)
+            c.qname_at[i] = static_cast<uint64_t>(name - d);
+            c.qname_len[i] = static_cast<uint8_t>(nlen);
+            c.qkey[i] = name_key(reinterpret_cast<const char *>(name), nlen, key_seed);
+            const uint8_t *cg = name + l_name;
+            int32_t rl = 0, ql = 0;
+            OpScan sc;
+            for (size_t k = 0; k < n_cig; k++) {
+                uint32_t v = le32(cg + 4 * k);
+                int op = v & 15, len = static_cast<int>(v >> 4);
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += len;   // bam_cigar2rlen
+                if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) ql += len;   // getReadLength (:385-397)
+                sc.add(len, opchr[op]);
+            }
+            ClipInfo ci = sc.done();
+            c.ref_len[i] = rl;
+            c.read_len[i] = ql;
+            c.clip_s[i] = n_cig ? ci.clip_s : -1;
+            c.clip_e[i] = ci.clip_e;
+            // aux: first NM (integer types only, like bam_aux2i) and first SA (Z)
+            const uint8_t *x = cg + 4 * n_cig + (l_seq + 1) / 2 + l_seq;
+            bool have_nm = false, have_sa = false;
+            while (x + 3 <= end && !(have_nm && have_sa)) {
+                uint8_t ty = x[2];
+                const uint8_t *v = x + 3;
+                size_t sz = aux_size(ty, v, end);
+                if (!sz || v + sz > end) break;
+                if (!have_nm && x[0] == 'N' && x[1] == 'M') {
+                    have_nm = true;
+                    int64_t val = 0;
+                    switch (ty) {
+                    case 'c': val = static_cast<int8_t>(v[0]); break;
+                    case 'C': val = v[0]; break;
+                    case 's': val = static_cast<int16_t>(le16(v)); break;
+                    case 'S': val = le16(v); break;
+                    case 'i': val = static_cast<int32_t>(le32(v)); break;
+                    case 'I': val = le32(v); break;
+                    default: val = 0;
+                    }
+                    c.nm[i] = static_cast<int32_t>(val);
+                } else if (!have_sa && x[0] == 'S' && x[1] == 'A' && ty == 'Z') {
+                    have_sa = true;
+                    if (tid >= 0 && tid < n_ref) {                         // :687
+                        const char *s = reinterpret_cast<const char *>(v), *se = s + sz - 1;
+                        while (s < se) {                                   // items split at ';' (:719-720)
+                            const char *semi = static_cast<const char *>(std::memchr(s, ';', static_cast<size_t>(se - s)));
+                            const char *ie = semi ? semi : se;
+                            palace_sa_item it{};
+                            if (ie > s && parse_sa(s, ie, c, tid, it)) { sa_part[t].push_back(it); sa_cnt[i]++; }
+                            s = semi ? semi + 1 : se;
+                        }
+                    }
+                }
+                x = v + sz;
+            }
+        }
+    });
+    for (size_t i = 0; i < n; i++) c.sa_off[i + 1] = c.sa_off[i] + sa_cnt[i];
+    c.sa.clear();
+    c.sa.reserve(static_cast<size_t>(c.sa_off[n]) + 1);
+    for (auto &part : sa_part) c.sa.insert(c.sa.end(), part.begin(), part.end());   // thread ranges are in record order
+}
+
+}  // namespace palace_host

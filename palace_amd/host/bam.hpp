@@ -1,0 +1,46 @@
+// BGZF inflate + BAM record decode into the structure-of-arrays columns the HIP classify kernel
+// consumes (include/palace_hip.h: palace_bam_cols / palace_sa_item).  Stands in for what htslib
+// does inside sam_open / sam_hdr_read / sam_read1 / bam_aux_get for the reference
+// (generate_graph.cpp:611-698); written against the SAM/BAM specification, not against htslib.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/palace_hip.h"
+
+namespace palace_host {
+
+struct BamColumns {
+    // header
+    std::vector<std::string> target_name;
+    std::vector<int32_t> target_len;
+    std::unordered_map<std::string, int32_t> name_to_tid;      // last duplicate wins (:624-627)
+    // one entry per record, file order
+    std::vector<int32_t> tid, pos, mtid, mpos, nm, ref_len, read_len, clip_s, clip_e, sa_off;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq;
+    std::vector<uint64_t> qkey;
+    std::vector<palace_sa_item> sa;
+    // read names stay in the inflated stream; (offset, length) per record for the exactness guard
+    std::vector<uint8_t> raw;
+    std::vector<uint64_t> qname_at;
+    std::vector<uint8_t> qname_len;
+    int64_t n() const { return static_cast<int64_t>(flag.size()); }
+    std::string qname(int64_t i) const
+    {
+        return std::string(reinterpret_cast<const char *>(raw.data()) + qname_at[i], qname_len[i]);
+    }
+};
+
+// 64-bit key of a read name (seeded so a collision can be escaped by re-keying).
+uint64_t name_key(const char *s, size_t n, uint64_t seed);
+
+// Reads, inflates (threads) and decodes a whole BAM file.  Throws std::runtime_error.
+void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumns &out);
+
+// Re-key every read name with another seed (collision escape hatch).
+void rekey(BamColumns &cols, uint64_t key_seed);
+
+}  // namespace palace_host

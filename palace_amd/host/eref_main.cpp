@@ -1,0 +1,224 @@
+// eref -- drop-in for the reference executable (bin/extract_ref.cpp; call site palace:475-477):
+//     eref <fq1> <fq2> <phagedb.fa> <tmp.txt> <hit_ratio> <perfect_ratio> <threads>  > ref_names.txt
+// Host side: text parsing, the index file contract, stdout formatting.  The k-mer work (index
+// build, read counting, reference scan) runs in HIP through libpalace_hip.so; no CPU path exists.
+//
+// Defined behaviour where the reference has none: results are those of the
+// reference at threads=1 with a pre-existing index, for every <threads> value; lines are printed
+// in index order.  <threads> only sizes the host-side text parsing.
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+
+#include "../../include/palace_hip.h"
+#include "fastx.hpp"
+
+using namespace palace_host;
+
+namespace {
+
+#define CK(call)                                                                   \
+    do {                                                                           \
+        int rc__ = (call);                                                         \
+        if (rc__ != 0) {                                                           \
+            std::cerr << "eref: " #call " failed: " << palace_last_error() << "\n"; \
+            return 1;                                                              \
+        }                                                                          \
+    } while (0)
+
+// glibc srand()/rand() (TYPE_3 additive feedback generator, as documented in random_r.c), so the
+// E3 subsampling decisions (extract_ref.cpp:955-960) match the reference's seed-1 stream.
+struct GlibcRand {
+    uint32_t r[34];
+    int f = 3, b = 0;
+    explicit GlibcRand(unsigned seed)
+    {
+        int32_t w = seed ? static_cast<int32_t>(seed) : 1;
+        r[0] = static_cast<uint32_t>(w);
+        for (int i = 1; i < 31; i++) {
+            long hi = w / 127773, lo = w % 127773;
+            w = static_cast<int32_t>(16807 * lo - 2836 * hi);
+            if (w < 0) w += 2147483647;
+            r[i] = static_cast<uint32_t>(w);
+        }
+        for (int i = 0; i < 310; i++) next();
+    }
+    int next()
+    {
+        r[f] += r[b];
+        int out = static_cast<int>(r[f] >> 1);
+        f = (f + 1) % 31;
+        b = (b + 1) % 31;
+        return out;
+    }
+};
+
+bool file_exists(const std::string &p)
+{
+    struct stat st;
+    return stat(p.c_str(), &st) == 0;
+}
+
+// random_coder (extract_ref.cpp:1082-1102): one of six orders of (0,1,2) per k-mer offset.  The
+// reference seeds this with time(0); any choice is valid, so a fixed default keeps runs
+// reproducible (override with PALACE_CODER_SEED).
+void make_header(uint8_t hdr[400])
+{
+    static const int16_t orders[18] = {0, 1, 2, 0, 2, 1, 1, 2, 0, 1, 0, 2, 2, 0, 1, 2, 1, 0};
+    const char *env = std::getenv("PALACE_CODER_SEED");
+    GlibcRand g(env ? static_cast<unsigned>(std::strtoul(env, nullptr, 10)) : 20261003u);
+    int16_t cc[97] = {0};
+    for (int z = 0; z < 32; z++) {
+        int pick = g.next() % 6;
+        for (int i = 0; i < 3; i++) cc[3 * z + i] = orders[3 * pick + i];
+    }
+    std::memset(hdr, 0, 400);
+    for (int j = 0; j < 96; j++) {                        // 4-byte writes from a 2-byte array (:680-682)
+        uint32_t w = static_cast<uint16_t>(cc[j]) | (static_cast<uint32_t>(static_cast<uint16_t>(cc[j + 1])) << 16);
+        std::memcpy(hdr + 4 * j, &w, 4);
+    }
+}
+
+template <class T>
+int upload(palace_ctx *ctx, const T *src, size_t n, T **d)
+{
+    void *p = nullptr;
+    int rc = palace_malloc(ctx, (n ? n : 1) * sizeof(T), &p);
+    if (rc) return rc;
+    *d = static_cast<T *>(p);
+    return palace_h2d(ctx, p, src, n * sizeof(T));
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc < 8) {
+        std::cerr << "Usage: " << argv[0] << " <fq1> <fq2> <phagedb.fa> <tmp.txt> <hit_ratio> <perfect_ratio> <threads>\n";
+        return 1;
+    }
+    const std::string fq1 = argv[1], fq2 = argv[2], fasta = argv[3], interval_name = argv[4];
+    const float hit_ratio = static_cast<float>(std::stod(argv[5]));            // :1228-1229
+    const float perfect_ratio = static_cast<float>(std::stod(argv[6]));
+    const int threads = std::max(1, std::min(64, static_cast<int>(std::stod(argv[7]))));
+    const int window = 500;
+    const int one_min = window * hit_ratio, three_min = window * perfect_ratio;   // :513-514
+
+    palace_ctx *ctx = nullptr;
+    CK(palace_ctx_create(0, &ctx));
+
+    // ---- references: FASTA -> records longer than k=32 (:697), index-file contract ----
+    SeqSet db_all, db;
+    try {
+        parse_fasta(read_file(fasta), db_all);
+    } catch (const std::exception &e) { std::cerr << "eref: " << e.what() << "\n"; return 1; }
+    std::vector<int64_t> cum(db_all.n() + 1, 0);
+    for (int64_t i = 0; i < db_all.n(); i++) {
+        cum[i + 1] = cum[i] + db_all.len(i);
+        if (db_all.len(i) > 32) {
+            db.bases.insert(db.bases.end(), db_all.bases.begin() + db_all.offsets[i], db_all.bases.begin() + db_all.offsets[i + 1]);
+            db.offsets.push_back(static_cast<int64_t>(db.bases.size()));
+            db.names.push_back(db_all.names[i]);
+            db.ordinal.push_back(i);                     // position in db_all
+        }
+    }
+    const int64_t n_refs = db.n();
+    std::vector<int64_t> idx_off(n_refs + 1, 0);
+    for (int64_t r = 0; r < n_refs; r++) idx_off[r + 1] = idx_off[r] + 3 * (db.len(r) - 31);
+    const uint64_t index_bytes = 400 + 4ull * n_refs + 4ull * static_cast<uint64_t>(idx_off[n_refs]);
+
+    uint8_t *d_ref = nullptr; int64_t *d_ref_off = nullptr;
+    CK(upload(ctx, db.bases.data(), db.bases.size(), &d_ref));
+    CK(upload(ctx, db.offsets.data(), db.offsets.size(), &d_ref_off));
+
+    const std::string index_name = fasta + ".k32.index.dat";                   // :1245
+    uint8_t hdr[400];
+    if (!file_exists(index_name)) {                                            // :1246-1251 -> read_ref
+        make_header(hdr);
+        CK(palace_eref_set_coder(ctx, hdr));
+        uint32_t *d_idx = nullptr; int64_t *d_idx_off = nullptr;
+        void *p = nullptr;
+        CK(palace_malloc(ctx, static_cast<size_t>(idx_off[n_refs] + 1) * 4, &p));
+        d_idx = static_cast<uint32_t *>(p);
+        CK(upload(ctx, idx_off.data(), idx_off.size(), &d_idx_off));
+        CK(palace_eref_index_refs(ctx, d_ref, d_ref_off, n_refs, d_idx, d_idx_off));
+        std::vector<uint32_t> idx(static_cast<size_t>(idx_off[n_refs]));
+        CK(palace_d2h(ctx, idx.data(), d_idx, idx.size() * 4));
+        CK(palace_free(ctx, d_idx)); CK(palace_free(ctx, d_idx_off));
+        std::ofstream fi(index_name, std::ios::binary), fl(fasta + ".genome.len.txt");
+        if (!fi || !fl) { std::cerr << "eref: cannot write index beside " << fasta << "\n"; return 1; }
+        fi.write(reinterpret_cast<const char *>(hdr), 400);
+        for (int64_t r = 0; r < n_refs; r++) {
+            uint32_t l32 = static_cast<uint32_t>(db.len(r));
+            fi.write(reinterpret_cast<const char *>(&l32), 4);                  // :710
+            fi.write(reinterpret_cast<const char *>(idx.data() + idx_off[r]), 4 * (idx_off[r + 1] - idx_off[r]));
+            const int64_t a = db.ordinal[r];                                    // :698, :803
+            fl << db.names[r] << "\t" << db_all.ordinal[a] << "\t" << db.len(r) << "\t" << cum[a + 1] << "\n";
+        }
+    } else {                                                                   // saved_random_coder (:1104-1122)
+        std::ifstream fi(index_name, std::ios::binary);
+        if (!fi.read(reinterpret_cast<char *>(hdr), 400)) { std::cerr << "eref: short index " << index_name << "\n"; return 1; }
+        fi.seekg(0, std::ios::end);
+        if (static_cast<uint64_t>(fi.tellg()) != index_bytes) {
+            std::cerr << "eref: " << index_name << " does not belong to " << fasta << " (size " << fi.tellg()
+                      << ", expected " << index_bytes << "); delete it to rebuild\n";
+            return 1;
+        }
+        CK(palace_eref_set_coder(ctx, hdr));
+    }
+
+    // ---- reads: Phase A ----
+    CK(palace_eref_table_reset(ctx));
+    GlibcRand rng(1);                                                           // :1239-1240
+    int down_sam_ratio = 100;
+    for (int side = 0; side < 2; side++) {
+        SeqSet rs;
+        try {
+            parse_fastq(read_file(side == 0 ? fq1 : fq2), threads, rs);
+        } catch (const std::exception &e) { std::cerr << "eref: " << e.what() << "\n"; return 1; }
+        if (side == 0) {                                                        // cal_sam_ratio (:1124-1148)
+            long sample = static_cast<long>(rs.bases.size()) * 2;
+            down_sam_ratio = sample > 0 ? static_cast<int>(100L * 2000000000L / sample) : 100;
+        }
+        std::vector<uint8_t> keep;
+        if (down_sam_ratio < 100) {                                             // one draw per sequence line (:955-960)
+            keep.resize(static_cast<size_t>(rs.n()));
+            for (int64_t i = 0; i < rs.n(); i++) keep[i] = (rng.next() % 100) < down_sam_ratio;
+        }
+        uint8_t *d_b = nullptr, *d_k = nullptr; int64_t *d_o = nullptr;
+        CK(upload(ctx, rs.bases.data(), rs.bases.size(), &d_b));
+        CK(upload(ctx, rs.offsets.data(), rs.offsets.size(), &d_o));
+        if (!keep.empty()) CK(upload(ctx, keep.data(), keep.size(), &d_k));
+        CK(palace_eref_count_reads(ctx, d_b, d_o, rs.n(), d_k));
+        CK(palace_free(ctx, d_b)); CK(palace_free(ctx, d_o)); CK(palace_free(ctx, d_k));
+    }
+
+    // ---- references: Phase B ----
+    std::vector<int32_t> rows(static_cast<size_t>(4 * n_refs));
+    if (n_refs) {
+        void *p = nullptr;
+        CK(palace_malloc(ctx, rows.size() * 4, &p));
+        CK(palace_eref_scan_refs(ctx, d_ref, d_ref_off, n_refs, static_cast<int64_t>(db.bases.size()), one_min, three_min,
+                                 static_cast<int32_t *>(p)));
+        CK(palace_d2h(ctx, rows.data(), p, rows.size() * 4));
+    }
+    palace_ctx_destroy(ctx);
+
+    { std::ofstream trunc(interval_name, std::ios::out | std::ios::trunc); }   // :825, :899 (left empty)
+    std::string out;
+    char line[160];
+    for (int64_t r = 0; r < n_refs; r++) {
+        const int n_int = rows[4 * r], el = rows[4 * r + 1], len = rows[4 * r + 2];
+        const float ratio = static_cast<float>(el) / static_cast<float>(len);   // :615
+        if (el > 0 && ratio > 0.75)
+            out.append(line, std::snprintf(line, sizeof line, "ref_index\t%d\t%d\t%d\t%d\t%g\n", static_cast<int>(r + 1), n_int, el, len,
+                                           static_cast<double>(ratio)));
+    }
+    std::fwrite(out.data(), 1, out.size(), stdout);
+    return 0;
+}

@@ -1,0 +1,249 @@
+// generateGraph -- drop-in for the reference executable of the same name
+// (bin/generate_graph.cpp; call site palace:557-560):
+//     generateGraph [options] <BAM> <FASTG_FAI> <OUT> <AverageDepth>
+// Host side: BGZF/BAM decode to columns, name tables, text output.  All per-record and
+// per-evidence work runs in HIP through libpalace_hip.so (palace_graph_classify / _resolve);
+// there is no CPU path for it.
+#include <getopt.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "bam.hpp"
+
+using namespace palace_host;
+
+namespace {
+
+void usage(const char *prog)            // same option surface as generate_graph.cpp:542-556
+{
+    std::cerr << "Usage: " << prog << " [options] <BAM> <FASTG_FAI> <OUT> <AverageDepth>\n"
+              << "Options:\n"
+              << "  -e <int>      MAX_END (default: 300)\n"
+              << "  -q <int>      MIN_MAPQ (default: 0)\n"
+              << "  -n <int>      MAX_NM (default: 5)\n"
+              << "  -p <double>   MIN_MATCH_FRAC (accepted, unused as in the reference)\n"
+              << "  -P <0/1>      Enable paired-end evidence (default: 1)\n"
+              << "  --max-span-frac <double>  (default: 0.80)\n"
+              << "  --both-order <0/1>        Output both orders (default: 0)\n"
+              << "  --lib <FR|RF|FF>          Library type (accepted, unused as in the reference)\n"
+              << "  --min-count <int>         Minimum supporting reads (default: 5)\n"
+              << "  --min-score <double>      (accepted, unused as in the reference)\n"
+              << "  --debug                   (accepted; per-read traces are not produced)\n";
+}
+
+#define CK(call)                                                                        \
+    do {                                                                                \
+        int rc__ = (call);                                                              \
+        if (rc__ != 0) {                                                                \
+            std::cerr << "generateGraph: " #call " failed: " << palace_last_error() << "\n"; \
+            return 1;                                                                   \
+        }                                                                               \
+    } while (0)
+
+template <class T>
+int upload(palace_ctx *ctx, const std::vector<T> &v, T **d)
+{
+    void *p = nullptr;
+    int rc = palace_malloc(ctx, std::max<size_t>(1, v.size()) * sizeof(T), &p);
+    if (rc) return rc;
+    *d = static_cast<T *>(p);
+    return palace_h2d(ctx, p, v.data(), v.size() * sizeof(T));
+}
+
+// parseFastgFile (generate_graph.cpp:119-169) reduced to the pairs whose two names are BAM targets
+std::vector<uint64_t> fastg_keys(const std::string &path, const BamColumns &c)
+{
+    std::vector<uint64_t> keys;
+    std::ifstream in(path);
+    std::string line;
+    auto tid_of = [&](const std::string &n) -> int64_t {
+        auto it = c.name_to_tid.find(n);
+        return it == c.name_to_tid.end() ? -1 : it->second;
+    };
+    while (std::getline(in, line)) {
+        size_t semi = line.find(';');
+        std::string head = line.substr(0, semi);
+        size_t colon = head.find(':');
+        if (colon == std::string::npos) continue;
+        std::string name = head.substr(0, colon);
+        bool rev = !name.empty() && name.back() == '\'';
+        if (rev) name.pop_back();
+        int64_t a = tid_of(name);
+        size_t p = colon + 1;
+        while (p < head.size()) {
+            size_t comma = head.find(',', p);
+            std::string lk = head.substr(p, comma == std::string::npos ? std::string::npos : comma - p);
+            p = comma == std::string::npos ? head.size() : comma + 1;
+            if (lk.empty()) continue;
+            bool lrev = lk.back() == '\'';
+            if (lrev) lk.pop_back();
+            int64_t b = tid_of(lk);
+            if (a < 0 || b < 0) continue;
+            uint64_t o1 = rev ? 1 : 0, o2 = (rev != lrev) ? 1 : 0;       // :151-157
+            keys.push_back((static_cast<uint64_t>(a) << 33) | (static_cast<uint64_t>(b) << 2) | (o1 << 1) | o2);
+            keys.push_back((static_cast<uint64_t>(b) << 33) | (static_cast<uint64_t>(a) << 2) | ((o1 ^ 1) << 1) | (o2 ^ 1));
+        }
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    return keys;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    palace_graph_params prm{300, 0, 5, 1, 0, 0, 0.80};
+    int min_count = 5;
+    static struct option long_opts[] = {{"max-span-frac", required_argument, 0, 1000},
+                                        {"both-order", required_argument, 0, 1001},
+                                        {"lib", required_argument, 0, 1002},
+                                        {"min-count", required_argument, 0, 1003},
+                                        {"min-score", required_argument, 0, 1004},
+                                        {"debug", no_argument, 0, 1005},
+                                        {0, 0, 0, 0}};
+    int opt, li = 0;
+    while ((opt = getopt_long(argc, argv, "e:q:n:p:P:", long_opts, &li)) != -1) {
+        switch (opt) {                                       // clamps as generate_graph.cpp:575-590
+        case 'e': prm.max_end = std::max(1, std::atoi(optarg)); break;
+        case 'q': prm.min_mapq = std::max(0, std::atoi(optarg)); break;
+        case 'n': prm.max_nm = std::max(0, std::atoi(optarg)); break;
+        case 'p': break;
+        case 'P': prm.enable_paired = std::atoi(optarg) != 0; break;
+        case 1000: prm.max_span_frac = std::min(0.99, std::max(0.1, std::atof(optarg))); break;
+        case 1001: prm.both_order = std::atoi(optarg) != 0; break;
+        case 1002: {
+            std::string v = optarg;
+            if (!(v == "FR" || v == "RF" || v == "FF")) std::cerr << "Unknown --lib " << v << ", fallback FR\n";
+            break;
+        }
+        case 1003: min_count = std::max(1, std::atoi(optarg)); break;
+        case 1004: break;
+        case 1005: break;
+        default: usage(argv[0]); return 1;
+        }
+    }
+    if (argc - optind < 4) { usage(argv[0]); return 1; }
+    const std::string bam_path = argv[optind], fai_path = argv[optind + 1], out_path = argv[optind + 2];
+    const double avg_depth = std::atof(argv[optind + 3]);
+
+    BamColumns c;
+    const int threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    uint64_t seed = 1;
+    try {
+        load_bam(bam_path, threads, seed, c);
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << "\n";
+        return 1;
+    }
+    const int32_t nt = static_cast<int32_t>(c.target_name.size());
+    // dense rank of every target name in byte order: the `cR < cL` test and the output order
+    std::vector<int32_t> by_name(nt), rank(nt, 0);
+    std::iota(by_name.begin(), by_name.end(), 0);
+    std::sort(by_name.begin(), by_name.end(), [&](int32_t a, int32_t b) { return c.target_name[a] < c.target_name[b]; });
+    for (int32_t k = 0, r = -1; k < nt; k++) {
+        if (k == 0 || c.target_name[by_name[k]] != c.target_name[by_name[k - 1]]) r++;
+        rank[by_name[k]] = r;
+    }
+    std::vector<uint64_t> fkeys = fastg_keys(fai_path, c);
+
+    palace_ctx *ctx = nullptr;
+    CK(palace_ctx_create(0, &ctx));
+    palace_bam_cols cols{};
+    cols.n = c.n();
+    int32_t *d_tid, *d_pos, *d_mtid, *d_mpos, *d_nm, *d_rl, *d_ql, *d_cs, *d_ce, *d_sao, *d_tlen, *d_rank;
+    uint16_t *d_flag; uint8_t *d_mapq; uint64_t *d_qkey, *d_fk, *d_consumed; palace_sa_item *d_sa;
+    CK(upload(ctx, c.tid, &d_tid)); CK(upload(ctx, c.pos, &d_pos)); CK(upload(ctx, c.mtid, &d_mtid));
+    CK(upload(ctx, c.mpos, &d_mpos)); CK(upload(ctx, c.nm, &d_nm)); CK(upload(ctx, c.ref_len, &d_rl));
+    CK(upload(ctx, c.read_len, &d_ql)); CK(upload(ctx, c.clip_s, &d_cs)); CK(upload(ctx, c.clip_e, &d_ce));
+    CK(upload(ctx, c.sa_off, &d_sao)); CK(upload(ctx, c.flag, &d_flag)); CK(upload(ctx, c.mapq, &d_mapq));
+    CK(upload(ctx, c.qkey, &d_qkey)); CK(upload(ctx, c.sa, &d_sa)); CK(upload(ctx, c.target_len, &d_tlen));
+    CK(upload(ctx, rank, &d_rank)); CK(upload(ctx, fkeys, &d_fk));
+    cols.tid = d_tid; cols.pos = d_pos; cols.mtid = d_mtid; cols.mpos = d_mpos; cols.nm = d_nm;
+    cols.ref_len = d_rl; cols.read_len = d_ql; cols.clip_s = d_cs; cols.clip_e = d_ce; cols.sa_off = d_sao;
+    cols.flag = d_flag; cols.mapq = d_mapq; cols.qkey = d_qkey;
+    void *p = nullptr;
+    CK(palace_malloc(ctx, std::max<size_t>(1, nt) * 8, &p));
+    d_consumed = static_cast<uint64_t *>(p);
+    const int64_t cand_cap = c.n() + static_cast<int64_t>(c.sa.size()) + 1;      // worst case: every record, every item
+    CK(palace_malloc(ctx, static_cast<size_t>(cand_cap) * sizeof(palace_graph_cand), &p));
+    palace_graph_cand *d_cands = static_cast<palace_graph_cand *>(p);
+
+    std::vector<palace_graph_cand> cands;
+    int64_t n_cands = 0;
+    for (int attempt = 0;; attempt++) {
+        CK(palace_memset(ctx, d_consumed, 0, std::max<size_t>(1, nt) * 8));
+        CK(palace_graph_classify(ctx, &cols, d_sa, nt, d_tlen, d_rank, d_fk, static_cast<int64_t>(fkeys.size()), &prm,
+                                 0, d_consumed, d_cands, cand_cap, &n_cands));
+        // exactness guard: among pair candidates equal keys must mean equal read names
+        cands.resize(static_cast<size_t>(n_cands));
+        CK(palace_d2h(ctx, cands.data(), d_cands, cands.size() * sizeof(palace_graph_cand)));
+        std::unordered_map<uint64_t, int64_t> first;
+        bool collision = false;
+        for (const auto &k : cands) {
+            if (k.kind != 1) continue;
+            auto ins = first.emplace(k.qkey, k.ord);
+            if (!ins.second && ins.first->second != k.ord && c.qname(ins.first->second) != c.qname(k.ord)) { collision = true; break; }
+        }
+        if (!collision) break;
+        if (attempt == 8) { std::cerr << "generateGraph: read-name key collisions persist\n"; return 1; }
+        rekey(c, ++seed);
+        CK(palace_h2d(ctx, d_qkey, c.qkey.data(), c.qkey.size() * 8));
+    }
+    CK(palace_malloc(ctx, static_cast<size_t>(std::max<int64_t>(1, n_cands)) * sizeof(palace_graph_edge), &p));
+    palace_graph_edge *d_edges = static_cast<palace_graph_edge *>(p);
+    int64_t n_edges = 0;
+    CK(palace_graph_resolve(ctx, d_cands, n_cands, c.n(), &prm, d_consumed, d_edges, std::max<int64_t>(1, n_cands), &n_edges));
+    std::vector<uint64_t> consumed(static_cast<size_t>(nt));
+    std::vector<palace_graph_edge> edges(static_cast<size_t>(n_edges));
+    CK(palace_d2h(ctx, consumed.data(), d_consumed, consumed.size() * 8));
+    CK(palace_d2h(ctx, edges.data(), d_edges, edges.size() * sizeof(palace_graph_edge)));
+    palace_ctx_destroy(ctx);
+
+    // ---- text output (generate_graph.cpp:1019-1076) ----
+    FILE *out = std::fopen(out_path.c_str(), "w");
+    if (!out) { std::cerr << "Failed to open output " << out_path << "\n"; return 1; }
+    std::vector<char> big(1 << 22);
+    std::setvbuf(out, big.data(), _IOFBF, big.size());
+    for (int32_t k = 0; k < nt; k++) {
+        // std::map keeps one entry per distinct name; a later duplicate overwrites an earlier one (:1033)
+        if (k + 1 < nt && rank[by_name[k + 1]] == rank[by_name[k]]) continue;
+        int32_t best = -1;
+        for (int32_t j = k; j >= 0 && rank[by_name[j]] == rank[by_name[k]]; j--)
+            if (c.target_len[by_name[j]] > 0) best = std::max(best, by_name[j]);
+        if (best < 0) continue;                                       // L <= 0 targets are skipped (:1023)
+        // refConsumed is keyed by NAME (:631, :659): duplicates share one sum
+        double sum = 0.0;
+        for (int32_t j = k; j >= 0 && rank[by_name[j]] == rank[by_name[k]]; j--) sum += static_cast<double>(consumed[by_name[j]]);
+        const int32_t L = c.target_len[best];
+        const double depth = sum / std::max(1, L);
+        const double cnf = avg_depth > 0.0 ? depth / avg_depth : 0.0;
+        std::fprintf(out, "SEG %s %g %d\n", c.target_name[best].c_str(), depth, static_cast<int>(std::floor(cnf + 0.5)));
+    }
+    std::sort(edges.begin(), edges.end(), [&](const palace_graph_edge &a, const palace_graph_edge &b) {
+        if (rank[a.left] != rank[b.left]) return rank[a.left] < rank[b.left];
+        if (rank[a.right] != rank[b.right]) return rank[a.right] < rank[b.right];
+        if (a.oL != b.oL) return a.oL < b.oL;                          // '+' (43) < '-' (45)
+        return a.oR < b.oR;
+    });
+    for (const auto &e : edges) {
+        const uint32_t supp = e.counts[0], supp_nf = e.counts[1], span = e.counts[2], span_nf = e.counts[3];
+        const uint32_t total = supp + supp_nf + span + span_nf;
+        if (total == 0 || total < static_cast<uint32_t>(min_count)) continue;   // :1056-1061
+        std::fprintf(out, "JUNC %s %c %s %c %u %u\n", c.target_name[e.left].c_str(), e.oL ? '-' : '+',
+                     c.target_name[e.right].c_str(), e.oR ? '-' : '+', supp + span + supp_nf, span_nf);
+    }
+    std::fclose(out);
+    return 0;
+}

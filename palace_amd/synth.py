@@ -263,3 +263,116 @@ def fastg_fai_lines(rng, names: list, lens, links_per_contig: float = 1.3):
             col0 = head + (":" + ",".join(succ) if succ else "") + ";"
             lines.append(f"{col0}\t{int(lens[i])}\t0\t60\t61\n")
     return lines
+
+
+# --------------------------------------------------------------------------------------
+# random generateGraph scenario (records + targets + fastg.fai) for parity tests
+# --------------------------------------------------------------------------------------
+def random_graph_case(rng, n_contigs: int = 60, n_events: int = 3000, long_mode: bool = False,
+                      read_len: int = 100):
+    names, lens = contig_names(rng, n_contigs, median=1500.0, sigma=0.9, min_len=90, long_mode=long_mode)
+    lens = [int(x) for x in lens]
+    targets = list(zip(names, lens))
+    fai = fastg_fai_lines(rng, names, lens, 1.3)
+    recs = []
+    mapqs = [0, 20, 40, 60, 60, 60]
+
+    def end_pos(L):     # 0-based pos whose 1-based value lies in the END region (default MAX_END)
+        lo = max(L - 300, L // 2)
+        return int(rng.integers(lo, max(lo + 1, L - 1)))
+
+    def start_pos(L):
+        hi = min(300, L // 2)
+        return int(rng.integers(0, max(1, hi)))
+
+    def any_pos(L):
+        return int(rng.integers(0, max(1, L - 1)))
+
+    hot = [(int(rng.integers(0, n_contigs)), int(rng.integers(0, n_contigs)), int(rng.integers(0, 8)))
+           for _ in range(max(4, n_contigs // 3))]
+    nm_types = "cCsSiI"
+    for ev in range(n_events):
+        q = f"q{ev}"
+        kind = rng.random()
+        mq = int(mapqs[int(rng.integers(0, len(mapqs)))])
+        nm = int(rng.choice([0, 0, 0, 1, 2, 5, 6, 9]))
+        nmt = nm_types[int(rng.integers(0, 6))]
+        if kind < 0.45:                                    # ordinary intra-contig pair
+            a = int(rng.integers(0, n_contigs)); L = lens[a]
+            p1 = any_pos(L); p2 = min(L - 1, p1 + int(rng.integers(0, 300)))
+            cg = str(rng.choice(["100M", "50M2I48M", "50M3D50M", "30S70M", "70M30S", "10H90M", "100M"]))
+            recs.append(BamRecord(q, 0x63, a, p1, mq, cg, a, p2, nm=nm, nm_type=nmt))
+            recs.append(BamRecord(q, 0x93, a, p2, mq, "100M", a, p1, nm=None if rng.random() < 0.2 else nm))
+        elif kind < 0.75:                                  # cross-contig pair
+            if rng.random() < 0.7:
+                a, b, t = hot[int(rng.integers(0, len(hot)))]
+            else:
+                a, b, t = int(rng.integers(0, n_contigs)), int(rng.integers(0, n_contigs)), int(rng.integers(0, 8))
+            if a == b:
+                b = (a + 1) % n_contigs
+            rev1, rev2 = bool(t & 1), bool(t & 2)
+            p1 = (start_pos if rev1 else end_pos)(lens[a]) if rng.random() < 0.85 else any_pos(lens[a])
+            if t & 4:
+                p2 = (end_pos if not rev2 else start_pos)(lens[b])
+            else:
+                p2 = (start_pos if rev2 else end_pos)(lens[b])
+            if rng.random() < 0.1:
+                p2 = any_pos(lens[b])
+            f1 = 0x41 | (0x10 if rev1 else 0) | (0x20 if rev2 else 0)
+            f2 = 0x81 | (0x10 if rev2 else 0) | (0x20 if rev1 else 0)
+            mq2 = int(mapqs[int(rng.integers(0, len(mapqs)))])
+            recs.append(BamRecord(q, f1, a, p1, mq, "100M", b, p2, nm=nm, nm_type=nmt))
+            if rng.random() < 0.9:                         # sometimes the mate record is absent
+                recs.append(BamRecord(q, f2, b, p2, mq2, "90M10S", a, p1, nm=int(rng.choice([0, 1, 7]))))
+        elif kind < 0.95:                                  # split read with SA tag(s)
+            if rng.random() < 0.7:
+                a, b, t = hot[int(rng.integers(0, len(hot)))]
+            else:
+                a, b, t = int(rng.integers(0, n_contigs)), int(rng.integers(0, n_contigs)), int(rng.integers(0, 8))
+            k = int(rng.integers(25, 76)); m = read_len - k
+            rev1, rev2 = bool(t & 1), bool(t & 2)
+            # primary covers read bases [1,k] (left part), SA covers [k+1, read_len]
+            cg1 = f"{m}S{k}M" if rev1 else f"{k}M{m}S"
+            cg2 = f"{m}M{k}S" if rev2 else f"{k}S{m}M"
+            if t & 4:                                      # swap roles: primary is the right part
+                cg1 = f"{k}M{m}S" if rev1 else f"{m}S{k}M"
+                cg2 = f"{k}S{m}M" if rev2 else f"{m}M{k}S"
+            left_a = not (t & 4)
+            pa = ((start_pos if rev1 else end_pos) if left_a else (end_pos if rev1 else start_pos))(lens[a])
+            pb = ((end_pos if rev2 else start_pos) if left_a else (start_pos if rev2 else end_pos))(lens[b])
+            if rng.random() < 0.1:
+                pa = any_pos(lens[a])
+            items = [f"{names[b]},{pb + 1},{'-' if rev2 else '+'},{cg2},{int(mapqs[int(rng.integers(0, 6))])},{int(rng.choice([0, 1, 6]))}"]
+            r = rng.random()
+            if r < 0.08:
+                items.insert(0, f"{names[a]},5,+,{cg2},60,0")                 # same contig as primary
+            elif r < 0.16:
+                items.insert(0, "nosuchcontig,5,+,50S50M,60,0")               # unknown name
+            elif r < 0.22:
+                items.insert(0, f"{names[b]},7,+,50S50M,60")                  # 5 fields only
+            elif r < 0.28:
+                items.insert(0, f" {names[b]} , {pb + 1} ,{'-' if rev2 else '+'}, {cg2} , 60 , 0 ")   # blanks
+            elif r < 0.32:
+                items.append(f"{names[(b + 1) % n_contigs]},{start_pos(lens[(b + 1) % n_contigs]) + 1},+,{k}S{m}M,60,0")
+            elif r < 0.35:
+                items.insert(0, "")
+            sa = ";".join(items) + (";" if rng.random() < 0.9 else "")
+            flag = (0x10 if rev1 else 0)
+            paired = rng.random() < 0.5
+            if paired:                                     # split read that is also a cross-contig pair
+                c = int(rng.integers(0, n_contigs))
+                flag |= 0x41 | (0x20 if rng.random() < 0.5 else 0)
+                pc = start_pos(lens[c]) if rng.random() < 0.5 else end_pos(lens[c])
+                recs.append(BamRecord(q, flag, a, pa, mq, cg1, c, pc, nm=nm, sa=sa, nm_type=nmt))
+                recs.append(BamRecord(q, 0x81 | (0x10 if flag & 0x20 else 0) | (0x20 if rev1 else 0), c, pc, 60, "100M", a, pa, nm=0))
+            else:
+                recs.append(BamRecord(q, flag, a, pa, mq, cg1, nm=nm, sa=sa, nm_type=nmt))
+        else:                                              # records the reference skips outright
+            a = int(rng.integers(0, n_contigs))
+            f = int(rng.choice([0x4, 0x100, 0x800, 0x904]))
+            recs.append(BamRecord(q, f, a if f != 0x4 else -1, any_pos(lens[a]) if f != 0x4 else -1, mq, "100M" if f != 0x4 else "", nm=nm))
+    order = sorted(range(len(recs)), key=lambda i: (recs[i].tid if recs[i].tid >= 0 else 1 << 30, recs[i].pos, i))
+    recs = [recs[i] for i in order]
+    total = sum(sum(n for n, op in parse_cigar(r.cigar) if op in (0, 2, 3, 7, 8)) for r in recs)
+    avg_depth = float(f"{total / max(1, sum(lens)):.6g}")
+    return targets, "".join(fai), recs, avg_depth

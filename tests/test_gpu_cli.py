@@ -1,0 +1,141 @@
+"""End-to-end parity of the drop-in executables (palace_amd/bin/{eref,generateGraph}) on a GPU:
+same argv, same files, byte-identical outputs vs the golden reference outputs / the oracle."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+from palace_amd import synth
+from tests import graph_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "palace_amd", "bin")
+
+
+def run(cmd, **kw):
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# eref
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def eref_files(golden_eref, tmp_path_factory):
+    g = golden_eref
+    d = tmp_path_factory.mktemp("eref_cli")
+    fa = str(d / "db.fa")
+    open(fa, "wb").write(g["db_fasta"].tobytes())
+    synth.ReadSet(g["r1_bases"], g["r1_offsets"]).write_fastq(str(d / "r_1.fq"), "1")
+    synth.ReadSet(g["r2_bases"], g["r2_offsets"]).write_fastq(str(d / "r_2.fq"), "2")
+    return d, fa
+
+
+@pytest.mark.parametrize("key,hr,pr", [("stdout_090_085", "0.9", "0.85"), ("stdout_080_050", "0.8", "0.5"),
+                                       ("stdout_095_090", "0.95", "0.9")])
+def test_eref_cached_index_equals_reference_stdout(eref_files, golden_eref, key, hr, pr):
+    d, fa = eref_files
+    # index as the reference left it beside the DB (same coder permutation as the golden run)
+    orc.build_index_file(fa, golden_eref["index_header"], fa + ".k32.index.dat", fa + ".genome.len.txt")
+    tmp = str(d / "tmp.txt")
+    open(tmp, "w").write("stale")
+    for threads in ("1", "8"):
+        p = run([os.path.join(BIN, "eref"), str(d / "r_1.fq"), str(d / "r_2.fq"), fa, tmp, hr, pr, threads])
+        assert p.returncode == 0, p.stderr
+        assert p.stdout == golden_eref[key].tobytes()
+        assert os.path.getsize(tmp) == 0                      # extract_ref.cpp:825, 899
+
+
+def test_eref_builds_index_like_reference(eref_files, golden_eref, tmp_path):
+    d, fa0 = eref_files
+    fa = str(tmp_path / "db2.fa")
+    open(fa, "wb").write(open(fa0, "rb").read())
+    p = run([os.path.join(BIN, "eref"), str(d / "r_1.fq"), str(d / "r_2.fq"), fa, str(tmp_path / "t.txt"), "0.9", "0.85", "4"],
+            env=dict(os.environ, PALACE_CODER_SEED="77"))
+    assert p.returncode == 0, p.stderr
+    idx = open(fa + ".k32.index.dat", "rb").read()
+    hdr = np.frombuffer(idx[:400], dtype=np.uint8)
+    ofa = str(tmp_path / "oracle.fa")
+    open(ofa, "wb").write(open(fa0, "rb").read())
+    orc.build_index_file(ofa, hdr, ofa + ".k32.index.dat", ofa + ".genome.len.txt")
+    assert hashlib.sha256(idx).digest() == hashlib.sha256(open(ofa + ".k32.index.dat", "rb").read()).digest()
+    assert open(fa + ".genome.len.txt", "rb").read() == golden_eref["genome_len_txt"].tobytes()
+    # stdout under that permutation == oracle under the same permutation
+    cc = orc.header_to_cc(hdr)
+    t = orc.CountTable()
+    t.count(golden_eref["r1_bases"], golden_eref["r1_offsets"], cc)
+    t.count(golden_eref["r2_bases"], golden_eref["r2_offsets"], cc)
+    assert p.stdout == orc.scan_index_file(ofa + ".k32.index.dat", t, 0.9, 0.85)
+    t.free()
+    # second run finds the index it wrote and gives the same answer
+    p2 = run([os.path.join(BIN, "eref"), str(d / "r_1.fq"), str(d / "r_2.fq"), fa, str(tmp_path / "t.txt"), "0.9", "0.85", "1"])
+    assert p2.returncode == 0 and p2.stdout == p.stdout
+
+
+def test_eref_rejects_foreign_index(eref_files, tmp_path):
+    d, fa0 = eref_files
+    fa = str(tmp_path / "db3.fa")
+    open(fa, "wb").write(open(fa0, "rb").read())
+    open(fa + ".k32.index.dat", "wb").write(b"\0" * 1000)
+    p = run([os.path.join(BIN, "eref"), str(d / "r_1.fq"), str(d / "r_2.fq"), fa, str(tmp_path / "t.txt"), "0.9", "0.85", "1"])
+    assert p.returncode != 0 and b"does not belong" in p.stderr
+
+
+# ------------------------------------------------------------------------------------------------
+# generateGraph
+# ------------------------------------------------------------------------------------------------
+def graph_cli(tmp_path, targets, fai_text, recs, avg, extra=()):
+    bam, fai, out = str(tmp_path / "t.bam"), str(tmp_path / "g.fastg.fai"), str(tmp_path / "graph.txt")
+    synth.write_bam(bam, targets, recs, block=4000)            # small blocks: records straddle BGZF blocks
+    open(fai, "w").write(fai_text)
+    p = run([os.path.join(BIN, "generateGraph"), *extra, bam, fai, out, f"{avg:.6g}"])
+    assert p.returncode == 0, p.stderr
+    return open(out, "rb").read(), fai
+
+
+def test_graph_hand_case(tmp_path):
+    got, _ = graph_cli(tmp_path, gc.TARGETS, gc.FASTG_FAI, gc.records(), gc.AVG_DEPTH)
+    assert got == gc.EXPECTED
+
+
+@pytest.mark.parametrize("seed,n_contigs,n_events", [(1, 40, 3000), (2, 12, 2000), (3, 300, 20000)])
+def test_graph_random_equals_oracle(tmp_path, seed, n_contigs, n_events):
+    targets, fai_text, recs, avg = synth.random_graph_case(synth.rng_for(seed), n_contigs, n_events)
+    got, fai = graph_cli(tmp_path, targets, fai_text, recs, avg)
+    want = orc.graph_run(recs, targets, fai, float(f"{avg:.6g}"))
+    assert got == want
+    assert got.count(b"JUNC") > 3
+
+
+@pytest.mark.parametrize("extra,opt", [
+    (["-e", "150", "-n", "2", "--min-count", "2"], dict(max_end=150, max_nm=2, min_count=2)),
+    (["-P", "0", "--min-count", "1"], dict(enable_paired=0, min_count=1)),
+    (["--max-span-frac", "0.1", "-q", "30", "--min-count", "3"], dict(max_span_frac=0.1, min_mapq=30, min_count=3)),
+    (["--both-order", "1", "--min-count", "2", "--lib", "FR", "-p", "0.5", "--min-score", "0.1"], dict(both_order=1, min_count=2)),
+])
+def test_graph_options(tmp_path, extra, opt):
+    targets, fai_text, recs, avg = synth.random_graph_case(synth.rng_for(11), 30, 4000)
+    got, fai = graph_cli(tmp_path, targets, fai_text, recs, avg, extra)
+    o = orc.graph_default_opts()
+    for k, v in opt.items():
+        setattr(o, k, v)
+    assert got == orc.graph_run(recs, targets, fai, float(f"{avg:.6g}"), o)
+
+
+def test_graph_long_contigs_underflow_gate(tmp_path):
+    """N50 ~ 50 kb with a >120 kb tail: '-' orientations on long contigs underflow exp() to 0."""
+    targets, fai_text, recs, avg = synth.random_graph_case(synth.rng_for(21), 25, 6000, long_mode=True)
+    assert max(l for _, l in targets) > 120000
+    got, fai = graph_cli(tmp_path, targets, fai_text, recs, avg)
+    assert got == orc.graph_run(recs, targets, fai, float(f"{avg:.6g}"))
+
+
+def test_graph_usage_and_errors(tmp_path):
+    p = run([os.path.join(BIN, "generateGraph"), "only", "three", "args"])
+    assert p.returncode == 1 and b"Usage:" in p.stderr
+    p = run([os.path.join(BIN, "generateGraph"), str(tmp_path / "missing.bam"), "x", str(tmp_path / "o"), "1"])
+    assert p.returncode == 1 and b"Failed to open BAM" in p.stderr
