@@ -30,6 +30,32 @@ def build(force: bool = False) -> str:
     return SO_PATH
 
 
+class GraphParams(C.Structure):
+    """palace_graph_params (defaults = generate_graph.cpp:20-44)."""
+    _fields_ = [("max_end", C.c_int32), ("min_mapq", C.c_int32), ("max_nm", C.c_int32), ("enable_paired", C.c_int32),
+                ("both_order", C.c_int32), ("reserved", C.c_int32), ("max_span_frac", C.c_double)]
+
+    @classmethod
+    def default(cls):
+        return cls(300, 0, 5, 1, 0, 0, 0.80)
+
+
+class BamCols(C.Structure):
+    _fields_ = [("n", C.c_int64)] + [(k, C.c_void_p) for k in
+                                     ("tid", "pos", "mtid", "mpos", "nm", "ref_len", "read_len", "clip_s", "clip_e",
+                                      "flag", "mapq", "qkey", "sa_off")]
+
+
+SA_ITEM_DTYPE = np.dtype([(k, np.int32) for k in ("tid2", "pos2", "mapq2", "nm2", "clip_s2", "clip_e2", "len2", "rev2")])
+CAND_DTYPE = np.dtype([("ord", np.int64), ("qkey", np.uint64), ("left", np.int32), ("right", np.int32),
+                       ("mtid", np.int32), ("ref_len", np.int32), ("dL", np.int32), ("dR", np.int32),
+                       ("nmL", np.int32), ("nmR", np.int32), ("mapqL", np.int16), ("mapqR", np.int16),
+                       ("kind", np.uint8), ("cls", np.uint8), ("found", np.uint8), ("in_fastg", np.uint8),
+                       ("oL", np.uint8), ("oR", np.uint8), ("pad0", np.uint8), ("pad1", np.uint8), ("pad2", np.int32)])
+EDGE_DTYPE = np.dtype([("left", np.int32), ("right", np.int32), ("counts", np.uint32, 4), ("oL", np.uint8),
+                       ("oR", np.uint8), ("pad", np.uint8, 6)])
+assert CAND_DTYPE.itemsize == 64 and EDGE_DTYPE.itemsize == 32 and SA_ITEM_DTYPE.itemsize == 32
+
 _SIGS = {
     "palace_ctx_create": [C.c_int, C.POINTER(C.c_void_p)],
     "palace_ctx_destroy": [C.c_void_p],
@@ -54,6 +80,11 @@ _SIGS = {
     "palace_eref_table_merge_slices": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t],
     "palace_eref_table_lookup": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "palace_eref_table_popcounts": [C.c_void_p, C.POINTER(C.c_uint64)],
+    "palace_graph_classify": [C.c_void_p, C.POINTER(BamCols), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_int64, C.POINTER(GraphParams), C.c_int64, C.c_void_p, C.c_void_p,
+                              C.c_int64, C.POINTER(C.c_int64)],
+    "palace_graph_resolve": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(GraphParams), C.c_void_p,
+                             C.c_void_p, C.c_int64, C.POINTER(C.c_int64)],
 }
 
 

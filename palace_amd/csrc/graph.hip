@@ -438,3 +438,8 @@ int palace_graph_resolve(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_
 }
 
 }  // extern "C"
+
+static_assert(sizeof(palace_graph_cand) == 64, "candidate layout is part of the ABI");
+static_assert(sizeof(palace_graph_edge) == 32, "edge layout is part of the ABI");
+static_assert(sizeof(palace_sa_item) == 32, "SA item layout is part of the ABI");
+static_assert(sizeof(palace_graph_params) == 32, "params layout is part of the ABI");

@@ -29,3 +29,9 @@ def test_ctx_create_without_gpu_fails_loudly_or_works():
         capi.lib().palace_ctx_destroy(h)
     else:
         assert rc < 0 and capi.lib().palace_last_error()
+
+
+def test_struct_layouts_match_header():
+    """sizes the C side static-asserts too (csrc/graph.hip)"""
+    assert ctypes.sizeof(capi.GraphParams) == 32
+    assert ctypes.sizeof(capi.BamCols) == 8 + 13 * 8
