@@ -376,3 +376,48 @@ def random_graph_case(rng, n_contigs: int = 60, n_events: int = 3000, long_mode:
     total = sum(sum(n for n, op in parse_cigar(r.cigar) if op in (0, 2, 3, 7, 8)) for r in recs)
     avg_depth = float(f"{total / max(1, sum(lens)):.6g}")
     return targets, "".join(fai), recs, avg_depth
+
+
+# --------------------------------------------------------------------------------------
+# side inputs of the graph filter (filter_graph.py argv) for a set of contigs
+# --------------------------------------------------------------------------------------
+def filter_side_files(rng, names, lens, ref_names=("phageA", "phageB", "phageC")):
+    """-> dict of file texts: fasta_fai, blast, hit_seqs, node_scores, contigs_paths."""
+    n = len(names)
+    fasta_fai = "".join(f"{nm}\t{int(L)}\t{7 + i * 100}\t60\t61\n" for i, (nm, L) in enumerate(zip(names, lens)))
+    # blastn outfmt 6 (palace:524-528): qseqid sseqid pident length mismatch gapopen qstart qend sstart send evalue bitscore qlen slen
+    blast = []
+    for i in rng.permutation(n)[: max(1, n // 8)]:
+        L = int(lens[i])
+        for ref in rng.permutation(len(ref_names))[: int(rng.integers(1, 3))]:
+            for _ in range(int(rng.integers(1, 4))):
+                ident = float(rng.choice([99.5, 85.0, 70.0, 69.9, 55.0]))
+                al = int(max(30, L * rng.choice([0.1, 0.3, 0.5, 0.8])))
+                blast.append(f"{names[i]}\t{ref_names[ref]}\t{ident:.3f}\t{al}\t3\t0\t1\t{al}\t100\t{100 + al}\t1e-50\t200\t{L}\t40000\n")
+    hit = "".join(f"{names[i]}\t{int(rng.integers(1, 9))}\n" for i in rng.permutation(n)[: max(1, n // 12)])
+    scores = []
+    for i in range(n):
+        r = rng.random()
+        if r < 0.1:
+            s = f"{rng.random() * 9:.4f}e-05"
+        elif r < 0.15:
+            s = "1.0"
+        else:
+            s = f"{rng.random():.6f}"
+        scores.append(f"{names[i]}\t{s}\n")
+    ids = [nm.split("_")[1] for nm in names]
+    paths = []
+    for k in range(max(1, n // 3)):
+        m = int(rng.integers(1, 6))
+        members = [int(x) for x in rng.integers(0, n, size=m)]
+        fwd = [ids[j] + ("+" if rng.random() < 0.5 else "-") for j in members]
+        rc = [t[:-1] + ("-" if t[-1] == "+" else "+") for t in reversed(fwd)]
+        sep = ";\n" if (m > 2 and rng.random() < 0.3) else None
+        for tag, toks in (("", fwd), ("'", rc)):
+            paths.append(f"NODE_{k + 1}_length_{sum(int(lens[j]) for j in members)}_cov_9.5{tag}\n")
+            if sep:
+                paths.append(",".join(toks[:2]) + sep + ",".join(toks[2:]) + "\n")
+            else:
+                paths.append(",".join(toks) + "\n")
+    return dict(fasta_fai=fasta_fai, blast="".join(blast), hit_seqs=hit, node_scores="".join(scores),
+                contigs_paths="".join(paths))
