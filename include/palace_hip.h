@@ -177,6 +177,22 @@ int palace_graph_resolve(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_
                          int64_t n_records_total, const palace_graph_params *prm, uint64_t *d_consumed,
                          palace_graph_edge *d_edges, int64_t edge_cap, int64_t *n_edges_out);
 
+/* ---- matching: path / cycle decomposition of the conjugate graph ------------------------- */
+
+/* M1. One greedy matching over the arcs of the conjugate graph, computed as rounds of locally
+ * dominant arcs (an arc is taken when it is the best remaining arc of both its tail's out-slot
+ * and its head's in-slot), which yields exactly the sequential greedy matching in rank order.
+ * The reference's `matching` binary is absent; the call it serves is
+ * palace:587-590 / 684-688 and the algorithm is this repository's own.
+ * Vertices are oriented segments (2*seg + (orient=='-')); arcs are given in rank order
+ * (arc id == rank, lower is better; an arc and its conjugate are adjacent), with CSR lists of
+ * arc ids per tail (out_off/out_arcs) and per head (in_off/in_arcs).  d_alive: 1 B per vertex.
+ * Outputs per vertex: d_next / d_prev (-1 = none) and d_next_arc (id of the arc leaving it). */
+int palace_match_greedy(palace_ctx *ctx, int32_t n_vertices, int64_t n_arcs, const int32_t *d_src,
+                        const int32_t *d_dst, const int64_t *d_out_off, const int32_t *d_out_arcs,
+                        const int64_t *d_in_off, const int32_t *d_in_arcs, const uint8_t *d_alive,
+                        int32_t *d_next, int32_t *d_prev, int32_t *d_next_arc, int32_t *rounds_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,3 +219,21 @@ def graph_run(records, targets, fastg_fai: str, avg_depth: float, opts: GraphOpt
     if got < 0:
         raise OSError("orc_graph_run: output buffer too small")
     return buf.raw[:got]
+
+
+# ---- matching (oracle/match_oracle.cpp: this repository's own algorithm, reference absent) ------
+def match_run(graph_path: str, paths_path: str | None, iterations: int = 10, self_loops: bool = False,
+              break_cycles: bool = False, aggressive: bool = False):
+    """-> (linear_bytes, cycle_bytes)"""
+    L = lib()
+    L.orc_match_run.restype = C.c_long
+    L.orc_match_run.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t,
+                                C.c_char_p, C.c_size_t, C.POINTER(C.c_long)]
+    cap = 32 * 1024 * 1024
+    lin, cyc = C.create_string_buffer(cap), C.create_string_buffer(cap)
+    n_cyc = C.c_long(0)
+    n = L.orc_match_run(graph_path.encode(), (paths_path or "").encode(), iterations, int(self_loops),
+                        int(break_cycles), int(aggressive), lin, cap, cyc, cap, C.byref(n_cyc))
+    if n < 0:
+        raise OSError("orc_match_run: output too large")
+    return lin.raw[:n], cyc.raw[:n_cyc.value]

@@ -139,3 +139,73 @@ def test_graph_usage_and_errors(tmp_path):
     assert p.returncode == 1 and b"Usage:" in p.stderr
     p = run([os.path.join(BIN, "generateGraph"), str(tmp_path / "missing.bam"), "x", str(tmp_path / "o"), "1"])
     assert p.returncode == 1 and b"Failed to open BAM" in p.stderr
+
+
+# ------------------------------------------------------------------------------------------------
+# matching (own algorithm; checked against oracle/match_oracle.cpp -- the reference binary is absent)
+# ------------------------------------------------------------------------------------------------
+FILTER_G = np.load(os.path.join(ROOT, "tests", "golden", "filter_cases.npz"))
+
+
+def ring_graph():
+    """three rings (one with a repeat segment of copy number 2), a self loop and a chain"""
+    n = lambda i, L=1000: f"EDGE_{i}_length_{L}_cov_5.0"
+    seg = [f"SEG {n(i)} 10 {2 if i == 3 else 1} 0 0.500 0\n" for i in range(1, 15)]
+    j = []
+    ring = lambda ids, w: [f"JUNC {n(a)} + {n(b)} + {w} 0\n" for a, b in zip(ids, ids[1:] + ids[:1])]
+    j += ring([1, 2, 3], 9) + ring([3, 4, 5, 6], 7)          # two rings sharing segment 3 (cn 2)
+    j += [f"JUNC {n(7)} + {n(7)} + 8 0\n"]                    # self loop
+    j += [f"JUNC {n(8)} + {n(9)} - 6 1\n", f"JUNC {n(9)} - {n(10)} + 5 0\n"]
+    j += ring([11, 12], 5) + [f"JUNC {n(12)} + {n(13)} + 5 0\n", f"JUNC {n(13)} + {n(14)} - 2 0\n"]
+    paths = "NODE_1_length_3000_cov_5\n13+,14+\nNODE_1_length_3000_cov_5'\n14-,13-\n"
+    return "".join(seg + j), paths
+
+
+def match_cli(tmp_path, graph_text, paths_text, flags):
+    g, p = str(tmp_path / "g.txt"), str(tmp_path / "contigs.paths")
+    open(g, "w").write(graph_text)
+    open(p, "w").write(paths_text)
+    lin, cyc = str(tmp_path / "lin.txt"), str(tmp_path / "cyc.txt")
+    r = run([os.path.join(BIN, "matching"), "-g", g, "-r", lin, "-c", cyc, *flags, "-l", p])
+    assert r.returncode == 0, r.stderr
+    it = int(flags[flags.index("-i") + 1]) if "-i" in flags else 10
+    want = orc.match_run(g, p, it, "-s" in flags, "-b" in flags, "--aggressive" in flags)
+    return (open(lin, "rb").read(), open(cyc, "rb").read()), want
+
+
+@pytest.mark.parametrize("flags", [["-s", "-i", "10"], ["-i", "10", "-b", "--aggressive"], ["-i", "2"], ["-s", "-b", "-i", "1"]])
+def test_matching_rings(tmp_path, flags):
+    g, p = ring_graph()
+    got, want = match_cli(tmp_path, g, p, flags)
+    assert got == want
+    assert b"iter 0\n" in got[1]
+    if "-s" in flags:
+        assert b"self\nEDGE_7_length_1000_cov_5.0+\n" in got[1]
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+@pytest.mark.parametrize("flags", [["-s", "-i", "10"], ["-i", "10", "-b", "--aggressive"]])
+def test_matching_filtered_graphs(tmp_path, case, flags):
+    got, want = match_cli(tmp_path, FILTER_G[f"case{case}_pre"].tobytes().decode(),
+                          FILTER_G[f"case{case}_contigs_paths"].tobytes().decode(), flags)
+    assert got == want and got[0]
+
+
+def test_matching_large_random(tmp_path):
+    rng = synth.rng_for(5)
+    names, lens = synth.contig_names(rng, 20000)
+    seg = "".join(f"SEG {nm} {rng.random() * 30:.4g} {int(rng.integers(0, 4))} 0 0.100 0\n" for nm in names)
+    junc = []
+    for _ in range(30000):
+        a, b = int(rng.integers(0, 20000)), int(rng.integers(0, 20000))
+        junc.append(f"JUNC {names[a]} {'+-'[int(rng.integers(0, 2))]} {names[b]} {'+-'[int(rng.integers(0, 2))]} "
+                    f"{int(rng.integers(1, 40))} {int(rng.integers(0, 5))}\n")
+    side = synth.filter_side_files(rng, names, lens)
+    got, want = match_cli(tmp_path, seg + "".join(junc), side["contigs_paths"], ["-s", "-i", "10", "-b"])
+    assert got == want
+    assert got[1].count(b"iter") > 0
+
+
+def test_matching_usage():
+    p = run([os.path.join(BIN, "matching"), "-g", "x"])
+    assert p.returncode == 1 and b"Usage" in p.stderr
