@@ -14,6 +14,7 @@ kernel (live HIP-event timing on the kernel's own stream) and `cpu_baseline` (th
 the CPU restatement of the reference algorithm, timed on a bounded sample on this host).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -38,6 +39,7 @@ def parse_args():
     ap.add_argument("--refs", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=40000)
+    ap.add_argument("--cpu-sample-records", type=int, default=300000)
     return ap.parse_args()
 
 
@@ -118,11 +120,145 @@ def make_sample(torch, dev, n_contigs, n_refs, rank=0, world=1):
 
 
 # ----------------------------------------------------------------------------------------------
-def cpu_baseline(torch, sample, header, n_reads):
-    """The oracle (CPU restatement of the reference algorithm, 1 thread) on a bounded sample,
-    extrapolated linearly to the whole workload.  Returns contigs/s and a description."""
+# BAM-side sample: one primary record per read, coordinate sorted, as decoded columns in HBM
+# ----------------------------------------------------------------------------------------------
+def make_graph_sample(torch, dev, n_contigs, n_pairs, rank=0, world=1):
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED + 1)
+    rng = np.random.Generator(np.random.PCG64(SEED + 1))
+    c_lens = np.maximum(56, np.random.Generator(np.random.PCG64(SEED)).lognormal(np.log(800.0), 1.0, size=n_contigs)).astype(np.int64)
+    ids = rng.permutation(np.arange(1, 4 * n_contigs + 1))[:n_contigs]
+    covs = rng.gamma(2.0, 8.0, size=n_contigs)
+    names = [f"EDGE_{i}_length_{l}_cov_{c:.6f}" for i, l, c in zip(ids.tolist(), c_lens.tolist(), covs.tolist())]
+    order = np.argsort(np.array(names, dtype="S"))
+    trank = np.empty(n_contigs, dtype=np.int32)
+    trank[order] = np.arange(n_contigs, dtype=np.int32)
+    link = rng.integers(0, n_contigs, size=n_contigs)
+    link = np.where(link == np.arange(n_contigs), (link + 1) % n_contigs, link)
+    # FASTG links: one random successor per contig plus, for half of them, the evidence-bearing one
+    a = np.concatenate([np.arange(n_contigs), np.arange(n_contigs)[::2]])
+    b = np.concatenate([rng.integers(0, n_contigs, size=n_contigs), link[::2]])
+    o1 = rng.integers(0, 2, size=len(a)).astype(np.uint64)
+    o2 = np.concatenate([rng.integers(0, 2, size=n_contigs), np.zeros(len(a) - n_contigs, dtype=np.int64)]).astype(np.uint64)
+    o1[n_contigs:] = 0
+    k1 = (a.astype(np.uint64) << np.uint64(33)) | (b.astype(np.uint64) << np.uint64(2)) | (o1 << np.uint64(1)) | o2
+    k2 = (b.astype(np.uint64) << np.uint64(33)) | (a.astype(np.uint64) << np.uint64(2)) | ((o1 ^ np.uint64(1)) << np.uint64(1)) | (o2 ^ np.uint64(1))
+    fastg = np.unique(np.concatenate([k1, k2]))
+
+    T = lambda x, dt=None: torch.as_tensor(x, device=dev) if dt is None else torch.as_tensor(x, device=dev).to(dt)
+    lens_t, link_t = T(c_lens), T(link)
+    cum = torch.cumsum(lens_t, 0)
+    start = cum - lens_t
+    # read 1 of every pair
+    u = (torch.rand(n_pairs, generator=g, device=dev, dtype=torch.float64) * float(cum[-1].item())).long()
+    ta = torch.searchsorted(cum, u, right=True).clamp_(max=n_contigs - 1)
+    la = lens_t[ta]
+    p1 = torch.minimum(u - start[ta], torch.clamp(la - 2, min=0))
+    ins = torch.clamp(torch.normal(400.0, 40.0, (n_pairs,), generator=g, device=dev), 150, 800).long()
+    rev1 = torch.rand(n_pairs, generator=g, device=dev) < 0.5
+    tb = ta.clone()
+    p2 = torch.where(rev1, torch.clamp(p1 - ins + 150, min=0), torch.minimum(p1 + ins - 150, torch.clamp(la - 2, min=0)))
+    rev2 = ~rev1
+    kind = torch.rand(n_pairs, generator=g, device=dev)
+    hot_x = T(rng.choice(n_contigs, size=max(8, n_contigs // 50), replace=False))      # junctions seen by pairs
+    hot_s = T(rng.choice(n_contigs, size=max(8, n_contigs // 33), replace=False))      # junctions seen by split reads
+    cross = kind < 0.04
+    split = (kind >= 0.04) & (kind < 0.10)                                            # 6 % of pairs = 3 % of reads
+    nx, ns = int(cross.sum().item()), int(split.sum().item())
+
+    def end_pos(L, n):      # 0-based position whose 1-based value is in the END region
+        lo = torch.maximum(L - 300, L // 2)
+        return lo + (torch.rand(n, generator=g, device=dev) * torch.clamp(L - 1 - lo, min=1).float()).long()
+
+    def start_pos(L, n):
+        hi = torch.minimum(torch.full_like(L, 300), L // 2)
+        return (torch.rand(n, generator=g, device=dev) * torch.clamp(hi, min=1).float()).long().clamp_(max=299)
+
+    xa = hot_x[torch.randint(0, len(hot_x), (nx,), generator=g, device=dev)]
+    ta[cross] = xa; tb[cross] = link_t[xa]
+    p1[cross] = end_pos(lens_t[xa], nx); p2[cross] = start_pos(lens_t[link_t[xa]], nx)
+    rev1[cross] = False; rev2[cross] = True
+    sa_a = hot_s[torch.randint(0, len(hot_s), (ns,), generator=g, device=dev)]
+    ta[split] = sa_a; tb[split] = sa_a
+    p1[split] = end_pos(lens_t[sa_a], ns); p2[split] = torch.clamp(p1[split] - 250, min=0)
+    rev1[split] = False; rev2[split] = True
+
+    def mapq_nm(n):
+        r = torch.rand(n, generator=g, device=dev)
+        mq = torch.where(r < 0.7, 60, torch.where(r < 0.85, 40, torch.where(r < 0.95, 20, 0))).to(torch.uint8)
+        nm = (torch.rand(n, generator=g, device=dev) ** 2 * 7).to(torch.int32)
+        return mq, nm
+
+    mq1, nm1 = mapq_nm(n_pairs)
+    mq2, nm2 = mapq_nm(n_pairs)
+    i32 = torch.int32
+    f1 = (0x41 + 0x10 * rev1.long() + 0x20 * rev2.long()).to(torch.int16)
+    f2 = (0x81 + 0x10 * rev2.long() + 0x20 * rev1.long()).to(torch.int16)
+    pair_id = torch.arange(n_pairs, device=dev, dtype=torch.int64)
+    qk = (pair_id * -7046029254386353131) ^ (pair_id >> 7)                            # distinct per pair
+    rl1 = torch.where(split, 90, 150).to(i32)
+    ce1 = torch.where(split, 60, 0).to(i32)
+    col = dict(
+        tid=torch.cat([ta, tb]).to(i32), pos=torch.cat([p1, p2]).to(i32), mtid=torch.cat([tb, ta]).to(i32),
+        mpos=torch.cat([p2, p1]).to(i32), flag=torch.cat([f1, f2]), mapq=torch.cat([mq1, mq2]), nm=torch.cat([nm1, nm2]),
+        ref_len=torch.cat([rl1, torch.full((n_pairs,), 150, device=dev, dtype=i32)]),
+        read_len=torch.full((2 * n_pairs,), 150, device=dev, dtype=i32),
+        clip_s=torch.zeros(2 * n_pairs, device=dev, dtype=i32), clip_e=torch.cat([ce1, torch.zeros(n_pairs, device=dev, dtype=i32)]),
+        qkey=torch.cat([qk, qk]), has_sa=torch.cat([split, torch.zeros(n_pairs, device=dev, dtype=torch.bool)]))
+    sa_tid = torch.cat([link_t[ta], torch.zeros(n_pairs, device=dev, dtype=torch.int64)])
+    sa_pos = torch.cat([start_pos(lens_t[link_t[ta]], n_pairs) + 1, torch.zeros(n_pairs, device=dev, dtype=torch.int64)])
+    sa_mq, sa_nm = mapq_nm(2 * n_pairs)
+    key = col["tid"].long() * (1 << 32) + col["pos"].long()
+    perm = torch.argsort(key, stable=True)
+    col = {k: v[perm].contiguous() for k, v in col.items()}
+    sa_tid, sa_pos, sa_mq, sa_nm = sa_tid[perm], sa_pos[perm], sa_mq[perm], sa_nm[perm]
+    n_rec = 2 * n_pairs
+    if world > 1:                                   # records shard by ordinal range across ranks
+        lo, hi = n_rec * rank // world, n_rec * (rank + 1) // world
+        col = {k: v[lo:hi].contiguous() for k, v in col.items()}
+        sa_tid, sa_pos, sa_mq, sa_nm = sa_tid[lo:hi], sa_pos[lo:hi], sa_mq[lo:hi], sa_nm[lo:hi]
+    else:
+        lo, hi = 0, n_rec
+    hs = col.pop("has_sa")
+    sa_off = torch.zeros(hi - lo + 1, device=dev, dtype=i32)
+    sa_off[1:] = torch.cumsum(hs.to(i32), 0)
+    n_sa = int(sa_off[-1].item())
+    sa = torch.zeros((max(1, n_sa), 8), device=dev, dtype=i32)             # palace_sa_item rows
+    sa[:n_sa, 0] = sa_tid[hs].to(i32); sa[:n_sa, 1] = sa_pos[hs].to(i32); sa[:n_sa, 2] = sa_mq[hs].to(i32)
+    sa[:n_sa, 3] = sa_nm[hs]; sa[:n_sa, 4] = 90; sa[:n_sa, 5] = 0; sa[:n_sa, 6] = 150; sa[:n_sa, 7] = 0
+    total_ref = float(col["ref_len"].sum().item()) if world == 1 else None
+    return dict(col=col, sa_off=sa_off, sa=sa, n_sa=n_sa, n=hi - lo, ord_base=lo, n_total=n_rec,
+                tlen=T(c_lens, i32), trank=T(trank), fastg=T(fastg.view(np.int64)), n_fastg=len(fastg),
+                names=names, lens=c_lens, link=link, avg_depth=None if total_ref is None else float(f"{total_ref / c_lens.sum():.6g}"))
+
+
+def graph_to_arcs(consumed, lens, avg_depth, edges, min_count=5):
+    """host glue between generateGraph's numbers and matching's input (SEG cn :1029-1031, JUNC filter
+    :1056-1061; arc ranking as palace_amd/host/matching_main.cpp)."""
+    depth = consumed.astype(np.float64) / np.maximum(1, lens)
+    copies = np.maximum(1, np.floor(depth / avg_depth + 0.5).astype(np.int64))
+    tot = edges["counts"].sum(axis=1).astype(np.int64)
+    e = edges[tot >= min_count]
+    w = tot[tot >= min_count]
+    u = 2 * e["left"].astype(np.int64) + e["oL"]
+    v = 2 * e["right"].astype(np.int64) + e["oR"]
+    selfc = (v ^ 1) == u
+    uu = np.concatenate([u, (v ^ 1)[~selfc]]); vv = np.concatenate([v, (u ^ 1)[~selfc]]); ww = np.concatenate([w, w[~selfc]])
+    V = 2 * len(lens)
+    cls = np.minimum(uu * V + vv, (vv ^ 1) * V + (uu ^ 1))
+    order = np.lexsort((vv, uu, cls, -ww))
+    return copies, uu[order].astype(np.int32), vv[order].astype(np.int32), ww[order]
+
+
+# ----------------------------------------------------------------------------------------------
+def cpu_baseline(torch, sample, gs, header, n_reads, n_records, graph_out):
+    """The oracle (CPU restatement of the reference algorithm, 1 thread) on a bounded sample of every
+    stage, extrapolated linearly to the whole workload.  Returns contigs/s and a description."""
+    import tempfile
     from oracle import binding as orc
+    from palace_amd.synth import BamRecord
     cc = orc.header_to_cc(header)
+    # ---- eref ----
     n_side = min(n_reads // 2, sample["n_reads_side"])
     b1 = sample["r1"][: n_side * READ_LEN].cpu().numpy()
     b2 = sample["r2"][: n_side * READ_LEN].cpu().numpy()
@@ -145,13 +281,51 @@ def cpu_baseline(torch, sample, header, n_reads):
     t_refs = time.perf_counter() - t0
     table.free()
     total_reads = 2 * sample["n_pairs_total"]
-    t_full = t_clear + t_reads * total_reads / (2 * n_side) + t_refs * sample["n_refs"] / n_ref_s
+    t_eref = t_clear + t_reads * total_reads / (2 * n_side) + t_refs * sample["n_refs"] / n_ref_s
+    # ---- generateGraph: first n_records records of the sorted stream, rebuilt as BAM-level records ----
+    m = min(n_records, gs["n"])
+    c = {k: v[:m].cpu().numpy() for k, v in gs["col"].items()}
+    so = gs["sa_off"][: m + 1].cpu().numpy()
+    sa = gs["sa"][: max(1, int(so[-1]))].cpu().numpy()
+    names = gs["names"]
+    recs = []
+    for i in range(m):
+        s_txt = None
+        if so[i + 1] > so[i]:
+            it = sa[so[i]]
+            s_txt = f"{names[it[0]]},{it[1]},{'-' if it[7] else '+'},{it[4]}S{it[6] - it[4]}M,{it[2]},{it[3]};"
+        cig = f"{c['ref_len'][i]}M{c['clip_e'][i]}S" if c["clip_e"][i] else "150M"
+        recs.append(BamRecord(f"q{c['qkey'][i] & 0xffffffffffff:x}", int(c["flag"][i]) & 0xffff, int(c["tid"][i]), int(c["pos"][i]),
+                              int(c["mapq"][i]), cig, int(c["mtid"][i]), int(c["mpos"][i]), nm=int(c["nm"][i]), sa=s_txt))
+    tmp = tempfile.mkdtemp(prefix="palace_bench_")
+    hot = sorted(set(c["tid"].tolist()) | set(gs["link"][c["tid"]].tolist()))
+    with open(os.path.join(tmp, "g.fastg.fai"), "w") as f:       # reduced .fai: only contigs the sample can touch
+        for a in hot:
+            f.write(f"{names[a]}:{names[gs['link'][a]]};\t{gs['lens'][a]}\t0\t60\t61\n")
+    targets = list(zip(names, gs["lens"].tolist()))
+    t0 = time.perf_counter()
+    orc.graph_run(recs, targets, os.path.join(tmp, "g.fastg.fai"), gs["avg_depth"])
+    t_graph_s = time.perf_counter() - t0
+    t_graph = t_graph_s * gs["n_total"] / m
+    # ---- matching: the whole graph this run produced, through the oracle's own text parser ----
+    copies, src, dst, w = graph_out
+    gpath = os.path.join(tmp, "graph.txt")
+    with open(gpath, "w") as f:
+        f.write("".join(f"SEG {n} 1 {k} 0 0.000 0\n" for n, k in zip(names, copies.tolist())))
+        keep = src <= (dst ^ 1)                      # one line per conjugate pair
+        f.write("".join(f"JUNC {names[u >> 1]} {'+-'[u & 1]} {names[v >> 1]} {'+-'[v & 1]} {x} 0\n"
+                        for u, v, x in zip(src[keep].tolist(), dst[keep].tolist(), w[keep].tolist())))
+    t0 = time.perf_counter()
+    orc.match_run(gpath, None, 10)
+    t_match = time.perf_counter() - t0
+    t_full = t_eref + t_graph + t_match
     return dict(value=sample["n_contigs"] / t_full, unit="contigs/s", cores=1, kind="port",
-                sample=(f"oracle/eref_oracle.c, 1 thread: {2 * n_side} of {total_reads} reads x{READ_LEN} bp "
-                        f"({t_reads:.1f} s) + 4 GiB table memset ({t_clear:.1f} s, fixed) + scan of {n_ref_s} of {sample['n_refs']} refs ({t_refs:.2f} s), "
-                        f"extrapolated linearly; stages: eref only (4 GiB byte table as the reference, "
-                        f"dead 16 GiB Peaks memset excluded)"),
-                reads_per_s=2 * n_side / t_reads)
+                sample=(f"oracle/ (1 thread). eref: {2 * n_side} of {total_reads} reads x{READ_LEN} bp ({t_reads:.1f} s) + 4 GiB "
+                        f"table memset ({t_clear:.1f} s, fixed) + scan of {n_ref_s} of {sample['n_refs']} refs ({t_refs:.2f} s) "
+                        f"-> {t_eref:.0f} s extrapolated; generateGraph: first {m} of {gs['n_total']} decoded records "
+                        f"({t_graph_s:.1f} s, BGZF/BAM decode and full .fai parse excluded) -> {t_graph:.0f} s; matching: whole "
+                        f"graph ({t_match:.1f} s, own algorithm, reference absent). Dead 16 GiB Peaks memset excluded."),
+                stage_s=dict(eref=t_eref, generateGraph=t_graph, matching=t_match))
 
 
 def main():
@@ -160,40 +334,109 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-    from palace_amd import capi
+    from palace_amd import capi, multigpu
     from oracle import binding as orc       # header helper + cpu_baseline leg only
 
     hdr = orc.header_from_picks(np.random.Generator(np.random.PCG64(SEED)).integers(0, 6, size=32))
     ctx = capi.Ctx(local)
     ctx.eref_set_coder(hdr)
     sample = make_sample(torch, dev, args.contigs, args.refs, rank, world)
+    gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world)
+    if world > 1:                                   # avgDepth is a pipeline input: computed once from all shards
+        tot = torch.tensor([float(gs["col"]["ref_len"].sum().item())], device=dev, dtype=torch.float64)
+        dist.all_reduce(tot)
+        gs["avg_depth"] = float(f"{tot.item() / gs['lens'].sum():.6g}")
     torch.cuda.synchronize()
     one_min, three_min = capi.window_minimums(0.9, 0.85)
-    rows = torch.zeros((sample["n_refs"], 4), dtype=torch.int32, device=dev)
-    rows_host = torch.zeros((sample["n_refs"], 4), dtype=torch.int32).pin_memory()
     L = capi.lib()
     P = lambda t: t.data_ptr()
-    n_side = sample["n_reads_side"]
+    n_side, n_refs, nt = sample["n_reads_side"], sample["n_refs"], args.contigs
+    # refs shard by cumulative length across ranks (eref Phase B); every rank holds the whole (small) DB
+    r_lo, r_hi = multigpu.split_by_weight(sample["ref_lens"], rank, world)
+    rows = torch.zeros((n_refs, 4), dtype=torch.int32, device=dev)
+    rows_host = torch.zeros((n_refs, 4), dtype=torch.int32).pin_memory()
+    consumed = torch.zeros(nt, dtype=torch.int64, device=dev)
+    cand_cap = gs["n"] + gs["n_sa"] + 1
+    cands = torch.zeros((cand_cap, 64), dtype=torch.uint8, device=dev)
+    edges = torch.zeros((cand_cap, 32), dtype=torch.uint8, device=dev)
+    cols = capi.BamCols(gs["n"], *(P(gs["col"][k]) for k in ("tid", "pos", "mtid", "mpos", "nm", "ref_len", "read_len",
+                                                           "clip_s", "clip_e", "flag", "mapq", "qkey")), P(gs["sa_off"]))
+    prm = capi.GraphParams.default()
+    exch = multigpu.Exchange(torch, dist, rank, world) if world > 1 else None
+    if exch:
+        ptrs, nbytes = ctx.eref_table_planes()
+        planes = [multigpu.wrap_device(torch, q, nbytes, dev) for q in ptrs]
+        ref_ranges = [multigpu.split_by_weight(sample["ref_lens"], r, world) for r in range(world)]
+        scratch_consumed = torch.zeros(nt, dtype=torch.int64, device=dev)
+
+        def merge_fn(parts, n_parts, slice_off, slice_bytes):
+            torch.cuda.synchronize()
+            ctx.eref_table_merge_slices(parts.data_ptr(), n_parts, slice_off, slice_bytes)
+            ctx.sync()
+    last = {}
+    ref_off_local = sample["ref_off"][r_lo:r_hi + 1].contiguous()
 
     def step(i, timed):
-        m = 4 * i
+        m = 8 * i
+        # ---------------- eref ----------------
         capi._check(L.palace_eref_table_reset(ctx.h), "reset")
         if timed: ctx.mark(m)
         capi._check(L.palace_eref_count_reads(ctx.h, P(sample["r1"]), P(sample["read_off"]), n_side, None), "count")
         capi._check(L.palace_eref_count_reads(ctx.h, P(sample["r2"]), P(sample["read_off"]), n_side, None), "count")
         if timed: ctx.mark(m + 1)
-        capi._check(L.palace_eref_scan_refs(ctx.h, P(sample["ref_bases"]), P(sample["ref_off"]), sample["n_refs"],
-                                            sample["ref_total"], one_min, three_min, P(rows)), "scan")
+        if exch:
+            ctx.sync()
+            exch.merge_planes(planes, merge_fn)
+            torch.cuda.synchronize()
         if timed: ctx.mark(m + 2)
+        capi._check(L.palace_eref_scan_refs(ctx.h, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
+                                            sample["ref_total"], one_min, three_min, P(rows) + 16 * r_lo), "scan")
+        if exch:
+            ctx.sync()
+            exch.gather_ranges(rows, ref_ranges)
+            torch.cuda.synchronize()
+        if timed: ctx.mark(m + 3)
         capi._check(L.palace_d2h(ctx.h, rows_host.data_ptr(), P(rows), rows.numel() * 4), "d2h")
+        # ---------------- generateGraph ----------------
+        capi._check(L.palace_memset(ctx.h, P(consumed), 0, nt * 8), "memset")
+        n_c = ctypes.c_int64()
+        capi._check(L.palace_graph_classify(ctx.h, ctypes.byref(cols), P(gs["sa"]), nt, P(gs["tlen"]), P(gs["trank"]),
+                                            P(gs["fastg"]), gs["n_fastg"], ctypes.byref(prm), gs["ord_base"], P(consumed),
+                                            P(cands), cand_cap, ctypes.byref(n_c)), "classify")
+        if timed: ctx.mark(m + 4)
+        all_c, n_cands, e_buf, cons_for_quirk = cands, n_c.value, edges, consumed
+        if exch:                                   # every rank resolves the same gathered candidates;
+            all_c, n_cands = exch.gather_varlen(cands, n_cands)          # only rank 0's quirk sums join the reduce
+            e_buf = edges if n_cands <= cand_cap else torch.zeros((n_cands, 32), dtype=torch.uint8, device=dev)
+            if rank != 0:
+                scratch_consumed.zero_()
+                cons_for_quirk = scratch_consumed
+            torch.cuda.synchronize()
+        n_e = ctypes.c_int64()
+        capi._check(L.palace_graph_resolve(ctx.h, P(all_c), n_cands, gs["n_total"], ctypes.byref(prm), P(cons_for_quirk),
+                                           P(e_buf), max(1, n_cands), ctypes.byref(n_e)), "resolve")
+        if exch:
+            ctx.sync()
+            exch.reduce_sum(consumed)
+            torch.cuda.synchronize()
+        if timed: ctx.mark(m + 5)
+        ctx.sync()
+        h_cons = consumed.cpu().numpy()
+        h_edges = e_buf[: n_e.value].cpu().numpy().view(capi.EDGE_DTYPE).reshape(-1)
+        # ---------------- matching (small; rank 0 owns it, components are independent) ----------------
+        copies, src, dst, w = graph_to_arcs(h_cons, gs["lens"], gs["avg_depth"], h_edges)
+        if rank == 0:
+            off, verts, kind, it, open_at = capi.match_decompose(ctx, copies, src, dst, 10, False)
+            last.update(n_comp=len(kind), n_cycles=int(kind.sum()), n_multi=int(((off[1:] - off[:-1]) > 1).sum()))
+        last.update(graph=(copies, src, dst, w), n_edges=int(n_e.value), n_cands=int(n_cands), n_arcs=len(src))
 
     def barrier():
         ctx.sync()
@@ -202,7 +445,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for w in range(args.warmup):
+    for _ in range(args.warmup):
         step(0, False)
     barrier()
     t0 = time.perf_counter()
@@ -215,30 +458,41 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_step = 1e3 * dt / args.steps
-    count_ms = np.mean([ctx.mark_elapsed(4 * i, 4 * i + 1) for i in range(args.steps)]) / 2    # two launches
-    scan_ms = np.mean([ctx.mark_elapsed(4 * i + 1, 4 * i + 2) for i in range(args.steps)])
+    K = range(args.steps)
+    count_ms = np.mean([ctx.mark_elapsed(8 * i, 8 * i + 1) for i in K]) / 2        # two launches per step
+    merge_ms = np.mean([ctx.mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
+    scan_ms = np.mean([ctx.mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
+    classify_ms = np.mean([ctx.mark_elapsed(8 * i + 3, 8 * i + 4) for i in K])
+    resolve_ms = np.mean([ctx.mark_elapsed(8 * i + 4, 8 * i + 5) for i in K])
     r = rows_host.numpy()
     reported = int(((r[:, 1] > 0) & (r[:, 1].astype(np.float32) / r[:, 2].astype(np.float32) > 0.75)).sum())
 
     if rank == 0:
-        alg_bytes = (READ_LEN + 6 * (READ_LEN - 31)) * n_side            # per launch (one FASTQ side)
+        alg_bytes = (READ_LEN + 6 * (READ_LEN - 31)) * n_side            # per launch (one FASTQ side of this rank)
         achieved = alg_bytes / (count_ms * 1e-3) / 1e9
+        gpu_ms = 2 * count_ms + merge_ms + scan_ms + classify_ms + resolve_ms
         out = {
             "metric": "contigs/sec eref+generate_graph+matching, 1M-contig synth",
             "value": args.contigs / (ms_step * 1e-3), "unit": "contigs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{args.contigs}-contig synthetic sample: {sample['n_refs']} phage refs "
-                                   f"({sample['ref_total']} bp), {2 * sample['n_pairs_total']} reads x {READ_LEN} bp",
-                       "stages": ["eref"], "seed": SEED, "refs_reported": reported,
-                       "refs_present": int(len(sample["present"]))},
+            "config": {"workload": f"{args.contigs}-contig synthetic sample: {n_refs} phage refs ({sample['ref_total']} bp), "
+                                   f"{2 * sample['n_pairs_total']} reads x {READ_LEN} bp, {gs['n_total']} primary BAM records, "
+                                   f"{gs['n_fastg']} FASTG links",
+                       "stages": ["eref", "generateGraph", "matching"], "seed": SEED,
+                       "parallelism": "1 GPU" if world == 1 else f"reads/records/refs sharded over {world} GPUs (RCCL)",
+                       "refs_reported": reported, "refs_present": int(len(sample["present"])),
+                       "graph": {k: last[k] for k in ("n_cands", "n_edges", "n_arcs", "n_comp", "n_cycles", "n_multi")}},
             "roofline": {"bound": "hbm", "kernel": "eref_count_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": count_ms, "algorithmic_bytes_per_launch": alg_bytes},
-            "stage_ms": {"eref_count_both_sides": 2 * count_ms, "eref_scan_refs": scan_ms},
+            "stage_ms": {"eref_count_both_sides": 2 * count_ms, "eref_table_merge": merge_ms, "eref_scan_refs": scan_ms,
+                         "graph_classify": classify_ms, "graph_resolve": resolve_ms,
+                         "matching_and_host_glue": ms_step - gpu_ms},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(torch, sample, hdr, args.cpu_sample_reads)
+            out["cpu_baseline"] = cpu_baseline(torch, sample, gs, hdr, args.cpu_sample_reads, args.cpu_sample_records,
+                                               last["graph"])
         print(json.dumps(out))
     ctx.close()
     if world > 1:

@@ -193,6 +193,26 @@ int palace_match_greedy(palace_ctx *ctx, int32_t n_vertices, int64_t n_arcs, con
                         const int64_t *d_in_off, const int32_t *d_in_arcs, const uint8_t *d_alive,
                         int32_t *d_next, int32_t *d_prev, int32_t *d_next_arc, int32_t *rounds_out);
 
+/* M1, whole decomposition: `iterations` rounds of {greedy matching on the GPU, read the paths and
+ * cycles off the successor links, charge copy numbers, drop exhausted segments} (+ one copy-number
+ * blind round when `aggressive`).  Host arrays in: copies[n_segs] (>= 1), arcs in rank order
+ * (src/dst oriented-vertex ids, an arc and its conjugate adjacent).  Result: components in emission
+ * order; component c holds verts[off[c] .. off[c+1]) in path order (cycles rotated to their
+ * smallest vertex, conjugate representative chosen), kind[c] = 0 path / 1 cycle, iter[c] = round,
+ * open_at[c] = position after the cycle's weakest arc (where -b opens it; 0 for paths).
+ * Duplicate and later-round singleton components are NOT filtered here (the caller formats). */
+typedef struct palace_match_result palace_match_result;
+int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
+                           const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
+                           palace_match_result **out);
+int64_t palace_match_result_count(const palace_match_result *r);
+const int64_t *palace_match_result_offsets(const palace_match_result *r);
+const int32_t *palace_match_result_verts(const palace_match_result *r);
+const uint8_t *palace_match_result_kind(const palace_match_result *r);
+const int32_t *palace_match_result_iter(const palace_match_result *r);
+const int32_t *palace_match_result_open_at(const palace_match_result *r);
+void palace_match_result_free(palace_match_result *r);
+
 #ifdef __cplusplus
 }
 #endif

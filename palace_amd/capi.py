@@ -83,6 +83,9 @@ _SIGS = {
     "palace_graph_classify": [C.c_void_p, C.POINTER(BamCols), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_int64, C.POINTER(GraphParams), C.c_int64, C.c_void_p, C.c_void_p,
                               C.c_int64, C.POINTER(C.c_int64)],
+    "palace_match_greedy": [C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 10 + [C.POINTER(C.c_int32)],
+    "palace_match_decompose": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                               C.c_int32, C.POINTER(C.c_void_p)],
     "palace_graph_resolve": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(GraphParams), C.c_void_p,
                              C.c_void_p, C.c_int64, C.POINTER(C.c_int64)],
 }
@@ -107,6 +110,13 @@ def lib() -> C.CDLL:
         _LIB.palace_version.restype = C.c_char_p
         _LIB.palace_stream.restype = C.c_void_p
         _LIB.palace_stream.argtypes = [C.c_void_p]
+        for nm, rt in (("count", C.c_int64), ("offsets", C.POINTER(C.c_int64)), ("verts", C.POINTER(C.c_int32)),
+                       ("kind", C.POINTER(C.c_uint8)), ("iter", C.POINTER(C.c_int32)), ("open_at", C.POINTER(C.c_int32))):
+            fn = getattr(_LIB, "palace_match_result_" + nm)
+            fn.argtypes = [C.c_void_p]
+            fn.restype = rt
+        _LIB.palace_match_result_free.argtypes = [C.c_void_p]
+        _LIB.palace_match_result_free.restype = None
         for name, sig in _SIGS.items():
             fn = getattr(_LIB, name)
             fn.argtypes = sig
@@ -242,6 +252,27 @@ class Ctx:
     def eref_table_merge_slices(self, parts_ptr: int, n_parts: int, slice_off: int, slice_bytes: int):
         _check(lib().palace_eref_table_merge_slices(self.h, parts_ptr, n_parts, slice_off, slice_bytes),
                "palace_eref_table_merge_slices")
+
+
+def match_decompose(ctx: "Ctx", copies: np.ndarray, src: np.ndarray, dst: np.ndarray, iterations: int = 10,
+                    aggressive: bool = False):
+    """palace_match_decompose -> (offsets, verts, kind, iter, open_at) as numpy copies."""
+    cp = np.ascontiguousarray(copies, dtype=np.int64)
+    s = np.ascontiguousarray(src, dtype=np.int32)
+    d = np.ascontiguousarray(dst, dtype=np.int32)
+    res = C.c_void_p()
+    _check(lib().palace_match_decompose(ctx.h, len(cp), cp.ctypes.data, len(s), s.ctypes.data, d.ctypes.data,
+                                        iterations, int(aggressive), C.byref(res)), "palace_match_decompose")
+    L = lib()
+    n = L.palace_match_result_count(res)
+    off = np.ctypeslib.as_array(L.palace_match_result_offsets(res), shape=(n + 1,)).copy()
+    nv = int(off[-1])
+    verts = np.ctypeslib.as_array(L.palace_match_result_verts(res), shape=(max(nv, 1),))[:nv].copy()
+    mk = lambda f, dt: (np.ctypeslib.as_array(f(res), shape=(max(n, 1),))[:n].copy() if n else np.zeros(0, dt))
+    out = (off, verts, mk(L.palace_match_result_kind, np.uint8), mk(L.palace_match_result_iter, np.int32),
+           mk(L.palace_match_result_open_at, np.int32))
+    L.palace_match_result_free(res)
+    return out
 
 
 def window_minimums(hit_ratio: float, perfect_ratio: float):

@@ -111,3 +111,154 @@ extern "C" int palace_match_greedy(palace_ctx *ctx, int32_t n_vertices, int64_t 
     if (rounds_out) *rounds_out = rounds;
     return PALACE_OK;
 }
+
+// ---- whole decomposition: GPU matching per round + host read-off ------------------------------
+struct palace_match_result {
+    std::vector<int64_t> off{0};
+    std::vector<int32_t> verts, iter, open_at;
+    std::vector<uint8_t> kind;
+};
+
+namespace palace {
+template <class T>
+static int dev_copy(palace_ctx *ctx, const T *h, size_t n, T **d)
+{
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(d), std::max<size_t>(1, n) * sizeof(T));
+    if (e != hipSuccess) { set_error("hipMalloc failed: %s", hipGetErrorString(e)); return PALACE_ENOMEM; }
+    if (n) PALACE_HIP_TRY(hipMemcpyAsync(*d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return PALACE_OK;
+}
+}  // namespace palace
+
+extern "C" {
+
+int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
+                           const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
+                           palace_match_result **out)
+{
+    PALACE_REQUIRE(ctx && out && n_segs >= 0 && n_arcs >= 0 && iterations >= 1, "bad argument");
+    PALACE_REQUIRE(n_segs == 0 || copies, "null copies");
+    PALACE_REQUIRE(n_arcs == 0 || (src && dst), "null arc arrays");
+    PALACE_REQUIRE(n_segs < (1 << 30) && n_arcs < (1ll << 31), "graph too large for int32 ids");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    const int32_t V = 2 * n_segs;
+    const int64_t E = n_arcs;
+    for (int64_t e = 0; e < E; e++)
+        PALACE_REQUIRE(src[e] >= 0 && src[e] < V && dst[e] >= 0 && dst[e] < V, "arc endpoint out of range");
+    // CSR by tail and by head; arc ids ascend inside every list because arcs arrive in rank order
+    std::vector<int64_t> out_off(V + 1, 0), in_off(V + 1, 0);
+    std::vector<int32_t> out_arcs(E), in_arcs(E);
+    for (int64_t e = 0; e < E; e++) { out_off[src[e] + 1]++; in_off[dst[e] + 1]++; }
+    for (int32_t v = 0; v < V; v++) { out_off[v + 1] += out_off[v]; in_off[v + 1] += in_off[v]; }
+    {
+        std::vector<int64_t> po(out_off.begin(), out_off.end() - 1), pi(in_off.begin(), in_off.end() - 1);
+        for (int64_t e = 0; e < E; e++) { out_arcs[po[src[e]]++] = static_cast<int32_t>(e); in_arcs[pi[dst[e]]++] = static_cast<int32_t>(e); }
+    }
+    int32_t *d_src = nullptr, *d_dst = nullptr, *d_oa = nullptr, *d_ia = nullptr, *d_next = nullptr, *d_prev = nullptr, *d_narc = nullptr;
+    int64_t *d_oo = nullptr, *d_io = nullptr;
+    uint8_t *d_alive = nullptr;
+    std::vector<int32_t> next(V), prev(V), narc(V);
+    std::vector<uint8_t> alive(V);
+    auto cleanup = [&] {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void *p : {(void *)d_src, (void *)d_dst, (void *)d_oa, (void *)d_ia, (void *)d_next, (void *)d_prev, (void *)d_narc,
+                        (void *)d_oo, (void *)d_io, (void *)d_alive})
+            if (p) (void)hipFree(p);
+    };
+#define TRY_OR_CLEAN(expr) do { int rc__ = (expr); if (rc__) { cleanup(); return rc__; } } while (0)
+    TRY_OR_CLEAN(dev_copy(ctx, src, E, &d_src)); TRY_OR_CLEAN(dev_copy(ctx, dst, E, &d_dst));
+    TRY_OR_CLEAN(dev_copy(ctx, out_arcs.data(), E, &d_oa)); TRY_OR_CLEAN(dev_copy(ctx, in_arcs.data(), E, &d_ia));
+    TRY_OR_CLEAN(dev_copy(ctx, out_off.data(), V + 1, &d_oo)); TRY_OR_CLEAN(dev_copy(ctx, in_off.data(), V + 1, &d_io));
+    TRY_OR_CLEAN(dev_copy(ctx, next.data(), V, &d_next)); TRY_OR_CLEAN(dev_copy(ctx, prev.data(), V, &d_prev));
+    TRY_OR_CLEAN(dev_copy(ctx, narc.data(), V, &d_narc)); TRY_OR_CLEAN(dev_copy(ctx, alive.data(), V, &d_alive));
+
+    palace_match_result *res = new palace_match_result();
+    std::vector<int64_t> left(copies, copies + n_segs);
+    for (auto &c : left) c = std::max<int64_t>(1, c);
+    std::vector<uint8_t> seen(V);
+    std::vector<int32_t> owner(V);
+    struct Head { int32_t first; int64_t begin, end; uint8_t cycle; int32_t open; };
+    std::vector<Head> heads;
+    std::vector<int32_t> pool;
+    const int rounds = iterations + (aggressive ? 1 : 0);
+    for (int t = 0; t < rounds; t++) {
+        if (aggressive && t == rounds - 1) std::fill(left.begin(), left.end(), 1);
+        bool any = false;
+        for (int32_t s = 0; s < n_segs; s++) { alive[2 * s] = alive[2 * s + 1] = left[s] > 0; any |= left[s] > 0; }
+        if (!any) break;
+        int rc = palace_h2d(ctx, d_alive, alive.data(), alive.size());
+        if (!rc) rc = palace_match_greedy(ctx, V, E, d_src, d_dst, d_oo, d_oa, d_io, d_ia, d_alive, d_next, d_prev, d_narc, nullptr);
+        if (!rc) rc = palace_d2h(ctx, next.data(), d_next, next.size() * 4);
+        if (!rc) rc = palace_d2h(ctx, prev.data(), d_prev, prev.size() * 4);
+        if (!rc) rc = palace_d2h(ctx, narc.data(), d_narc, narc.size() * 4);
+        if (rc) { delete res; cleanup(); return rc; }
+        std::fill(seen.begin(), seen.end(), 0);
+        heads.clear();
+        pool.clear();
+        for (int32_t v = 0; v < V; v++) {                     // open paths, one representative per conjugate pair
+            if (!alive[v] || seen[v] || prev[v] >= 0) continue;
+            const int64_t b = static_cast<int64_t>(pool.size());
+            for (int32_t x = v; x >= 0; x = next[x]) { pool.push_back(x); seen[x] = 1; }
+            const int64_t e = static_cast<int64_t>(pool.size());
+            for (int64_t k = b; k < e; k++) seen[pool[k] ^ 1] = 1;
+            if ((pool[e - 1] ^ 1) < pool[b]) {
+                std::reverse(pool.begin() + b, pool.begin() + e);
+                for (int64_t k = b; k < e; k++) pool[k] ^= 1;
+            }
+            heads.push_back({pool[b], b, e, 0, 0});
+        }
+        for (int32_t v = 0; v < V; v++) {                     // closed walks
+            if (!alive[v] || seen[v]) continue;
+            const int64_t b = static_cast<int64_t>(pool.size());
+            for (int32_t x = v; !seen[x]; x = next[x]) { pool.push_back(x); seen[x] = 1; }
+            const int64_t e = static_cast<int64_t>(pool.size());
+            int32_t lo = pool[b], lo_conj = pool[b] ^ 1;
+            for (int64_t k = b; k < e; k++) { seen[pool[k] ^ 1] = 1; lo = std::min(lo, pool[k]); lo_conj = std::min(lo_conj, pool[k] ^ 1); }
+            if (lo_conj < lo) {
+                std::reverse(pool.begin() + b, pool.begin() + e);
+                for (int64_t k = b; k < e; k++) pool[k] ^= 1;
+            }
+            std::rotate(pool.begin() + b, std::min_element(pool.begin() + b, pool.begin() + e), pool.begin() + e);
+            int64_t worst = b;
+            for (int64_t k = b + 1; k < e; k++)
+                if (narc[pool[k]] > narc[pool[worst]]) worst = k;
+            heads.push_back({pool[b], b, e, 1, static_cast<int32_t>((worst + 1 - b) % (e - b))});
+        }
+        std::sort(heads.begin(), heads.end(), [](const Head &a, const Head &b) { return a.first < b.first; });
+        std::fill(owner.begin(), owner.end(), -1);
+        for (size_t c = 0; c < heads.size(); c++)
+            for (int64_t k = heads[c].begin; k < heads[c].end; k++) owner[pool[k]] = static_cast<int32_t>(c);
+        for (const Head &h : heads) {
+            // copies paid = min over segments of floor(left / uses); a segment is used twice when both
+            // of its orientations lie on this component
+            const int32_t me = static_cast<int32_t>(&h - heads.data());
+            int64_t pay = -1;
+            for (int64_t k = h.begin; k < h.end; k++) {
+                const int64_t uses = 1 + (owner[pool[k] ^ 1] == me);
+                const int64_t q = left[pool[k] >> 1] / uses;
+                pay = pay < 0 ? q : std::min(pay, q);
+            }
+            pay = std::max<int64_t>(1, pay);
+            for (int64_t k = h.begin; k < h.end; k++) { int64_t &l = left[pool[k] >> 1]; l = std::max<int64_t>(0, l - pay); }
+            res->verts.insert(res->verts.end(), pool.begin() + h.begin, pool.begin() + h.end);
+            res->off.push_back(static_cast<int64_t>(res->verts.size()));
+            res->kind.push_back(h.cycle);
+            res->iter.push_back(t);
+            res->open_at.push_back(h.open);
+        }
+    }
+    cleanup();
+#undef TRY_OR_CLEAN
+    *out = res;
+    return PALACE_OK;
+}
+
+int64_t palace_match_result_count(const palace_match_result *r) { return r ? static_cast<int64_t>(r->kind.size()) : 0; }
+const int64_t *palace_match_result_offsets(const palace_match_result *r) { return r->off.data(); }
+const int32_t *palace_match_result_verts(const palace_match_result *r) { return r->verts.data(); }
+const uint8_t *palace_match_result_kind(const palace_match_result *r) { return r->kind.data(); }
+const int32_t *palace_match_result_iter(const palace_match_result *r) { return r->iter.data(); }
+const int32_t *palace_match_result_open_at(const palace_match_result *r) { return r->open_at.data(); }
+void palace_match_result_free(palace_match_result *r) { delete r; }
+
+}  // extern "C"

@@ -143,16 +143,6 @@ void load_graph(ConjGraph &g, const Options &o)
     }
 }
 
-template <class T>
-int to_device(palace_ctx *ctx, const std::vector<T> &v, T **d)
-{
-    void *p = nullptr;
-    int rc = palace_malloc(ctx, std::max<size_t>(1, v.size()) * sizeof(T), &p);
-    if (rc) return rc;
-    *d = static_cast<T *>(p);
-    return palace_h2d(ctx, p, v.data(), v.size() * sizeof(T));
-}
-
 }  // namespace
 
 int main(int argc, char **argv)
@@ -179,103 +169,52 @@ int main(int argc, char **argv)
         return x.u != y.u ? x.u < y.u : x.v < y.v;
     });
     const int64_t E = static_cast<int64_t>(g.arcs.size());
-    std::vector<int32_t> src(E), dst(E), out_arcs(E), in_arcs(E);
-    std::vector<int64_t> out_off(V + 1, 0), in_off(V + 1, 0);
-    for (int64_t e = 0; e < E; e++) { src[e] = g.arcs[e].u; dst[e] = g.arcs[e].v; out_off[src[e] + 1]++; in_off[dst[e] + 1]++; }
-    for (int32_t v = 0; v < V; v++) { out_off[v + 1] += out_off[v]; in_off[v + 1] += in_off[v]; }
-    {
-        std::vector<int64_t> po(out_off.begin(), out_off.end() - 1), pi(in_off.begin(), in_off.end() - 1);
-        for (int64_t e = 0; e < E; e++) { out_arcs[po[src[e]]++] = static_cast<int32_t>(e); in_arcs[pi[dst[e]]++] = static_cast<int32_t>(e); }
-    }
+    std::vector<int32_t> src(E), dst(E);
+    for (int64_t e = 0; e < E; e++) { src[e] = g.arcs[e].u; dst[e] = g.arcs[e].v; }
 
     palace_ctx *ctx = nullptr;
     CK(palace_ctx_create(0, &ctx));
-    int32_t *d_src, *d_dst, *d_oa, *d_ia, *d_next, *d_prev, *d_narc; int64_t *d_oo, *d_io; uint8_t *d_alive;
-    CK(to_device(ctx, src, &d_src)); CK(to_device(ctx, dst, &d_dst)); CK(to_device(ctx, out_arcs, &d_oa));
-    CK(to_device(ctx, in_arcs, &d_ia)); CK(to_device(ctx, out_off, &d_oo)); CK(to_device(ctx, in_off, &d_io));
-    std::vector<int32_t> next(V), prev(V), narc(V);
-    std::vector<uint8_t> alive(V);
-    CK(to_device(ctx, next, &d_next)); CK(to_device(ctx, prev, &d_prev)); CK(to_device(ctx, narc, &d_narc));
-    CK(to_device(ctx, alive, &d_alive));
+    palace_match_result *res = nullptr;
+    CK(palace_match_decompose(ctx, S, g.copies.data(), E, src.data(), dst.data(), opt.iterations, opt.aggressive, &res));
+    palace_ctx_destroy(ctx);
 
-    auto tok = [&](int32_t v) { return g.name[v >> 1] + ((v & 1) ? "-" : "+"); };
-    auto line_of = [&](const std::vector<int32_t> &vs, size_t first) {
+    const int64_t n_comp = palace_match_result_count(res);
+    const int64_t *off = palace_match_result_offsets(res);
+    const int32_t *verts = palace_match_result_verts(res), *iter = palace_match_result_iter(res),
+                  *open_at = palace_match_result_open_at(res);
+    const uint8_t *kind = palace_match_result_kind(res);
+    auto line_of = [&](int64_t c, int64_t first) {
+        const int64_t n = off[c + 1] - off[c];
         std::string s;
-        for (size_t i = 0; i < vs.size(); i++) { if (i) s += '\t'; s += tok(vs[(first + i) % vs.size()]); }
+        for (int64_t i = 0; i < n; i++) {
+            const int32_t v = verts[off[c] + (first + i) % n];
+            if (i) s += '\t';
+            s += g.name[v >> 1];
+            s += (v & 1) ? '-' : '+';
+        }
         s += '\n';
         return s;
     };
-    std::vector<int64_t> left(g.copies);
     std::string lin, cyc, selfs;
     std::unordered_set<std::string> lin_seen, cyc_seen;
-    const int rounds = opt.iterations + (opt.aggressive ? 1 : 0);
-    for (int t = 0; t < rounds; t++) {
-        if (opt.aggressive && t == rounds - 1) std::fill(left.begin(), left.end(), 1);
-        bool any = false;
-        for (int32_t s = 0; s < S; s++) { alive[2 * s] = alive[2 * s + 1] = left[s] > 0; any |= left[s] > 0; }
-        if (!any) break;
-        CK(palace_h2d(ctx, d_alive, alive.data(), alive.size()));
-        CK(palace_match_greedy(ctx, V, E, d_src, d_dst, d_oo, d_oa, d_io, d_ia, d_alive, d_next, d_prev, d_narc, nullptr));
-        CK(palace_d2h(ctx, next.data(), d_next, next.size() * 4));
-        CK(palace_d2h(ctx, prev.data(), d_prev, prev.size() * 4));
-        CK(palace_d2h(ctx, narc.data(), d_narc, narc.size() * 4));
-
-        struct Comp { std::vector<int32_t> v; bool cycle; };
-        std::vector<Comp> comps;
-        std::vector<uint8_t> seen(V, 0);
-        for (int32_t v = 0; v < V; v++) {                     // open paths, one representative per conjugate pair
-            if (!alive[v] || seen[v] || prev[v] >= 0) continue;
-            std::vector<int32_t> p;
-            for (int32_t x = v; x >= 0; x = next[x]) { p.push_back(x); seen[x] = 1; }
-            const int32_t conj_head = p.back() ^ 1;
-            for (int32_t x : p) seen[x ^ 1] = 1;
-            if (conj_head < p.front()) {
-                std::reverse(p.begin(), p.end());
-                for (int32_t &x : p) x ^= 1;
-            }
-            comps.push_back({std::move(p), false});
+    for (int64_t c = 0; c < n_comp; c++) {
+        const int64_t n = off[c + 1] - off[c];
+        if (!kind[c]) {
+            if (n == 1 && iter[c] > 0) continue;               // a bare segment is reported once, in round 0
+            std::string s = line_of(c, 0);
+            if (lin_seen.insert(s).second) lin += s;
+            continue;
         }
-        for (int32_t v = 0; v < V; v++) {                     // closed walks
-            if (!alive[v] || seen[v]) continue;
-            std::vector<int32_t> c;
-            for (int32_t x = v; !seen[x]; x = next[x]) { c.push_back(x); seen[x] = 1; }
-            int32_t lo = *std::min_element(c.begin(), c.end()), lo_conj = c[0] ^ 1;
-            for (int32_t x : c) { seen[x ^ 1] = 1; lo_conj = std::min(lo_conj, x ^ 1); }
-            if (lo_conj < lo) {
-                std::reverse(c.begin(), c.end());
-                for (int32_t &x : c) x ^= 1;
-            }
-            std::rotate(c.begin(), std::min_element(c.begin(), c.end()), c.end());
-            comps.push_back({std::move(c), true});
-        }
-        std::sort(comps.begin(), comps.end(), [](const Comp &a, const Comp &b) { return a.v.front() < b.v.front(); });
-        for (const Comp &c : comps) {
-            std::unordered_map<int32_t, int64_t> uses;
-            for (int32_t x : c.v) uses[x >> 1]++;
-            int64_t pay = -1;
-            for (auto &kv : uses) { int64_t q = left[kv.first] / kv.second; pay = pay < 0 ? q : std::min(pay, q); }
-            pay = std::max<int64_t>(1, pay);
-            for (auto &kv : uses) left[kv.first] = std::max<int64_t>(0, left[kv.first] - pay * kv.second);
-            if (!c.cycle) {
-                if (c.v.size() == 1 && t > 0) continue;        // a bare segment is reported once, in round 0
-                std::string s = line_of(c.v, 0);
-                if (lin_seen.insert(s).second) lin += s;
-                continue;
-            }
-            std::string s = line_of(c.v, 0);
-            if (!cyc_seen.insert(s).second) continue;
-            if (c.v.size() == 1 && opt.self_loops) selfs += "self\n" + s;
-            else cyc += "iter " + std::to_string(t) + "\n" + s;
-            if (opt.break_cycles) {                             // also report it opened at its weakest arc
-                size_t worst = 0;
-                for (size_t i = 1; i < c.v.size(); i++)
-                    if (narc[c.v[i]] > narc[c.v[worst]]) worst = i;
-                std::string open = line_of(c.v, worst + 1);
-                if (lin_seen.insert(open).second) lin += open;
-            }
+        std::string s = line_of(c, 0);
+        if (!cyc_seen.insert(s).second) continue;
+        if (n == 1 && opt.self_loops) selfs += "self\n" + s;
+        else cyc += "iter " + std::to_string(iter[c]) + "\n" + s;
+        if (opt.break_cycles) {                                 // also report it opened at its weakest arc
+            std::string open = line_of(c, open_at[c]);
+            if (lin_seen.insert(open).second) lin += open;
         }
     }
-    palace_ctx_destroy(ctx);
+    palace_match_result_free(res);
     cyc += selfs;
     std::ofstream fl(opt.linear, std::ios::binary), fc(opt.cycle, std::ios::binary);
     if (!fl || !fc) { std::cerr << "matching: cannot write outputs\n"; return 1; }

@@ -1,0 +1,104 @@
+"""Exchange steps of the hot path when one sample is sharded over the GPUs of a node
+(one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the
+CPU tests).  SURVEY.md section 8(e):
+
+  eref Phase A   reads sharded by record range, private count table per rank; merge = every rank
+                 owns 1/world of the key space: all_to_all of plane slices (each rank sends slice j of
+                 its three planes straight to rank j -- all 7 xGMI links busy at once, 3 * 512/world
+                 MiB per link), saturating bit-plane add of the world parts on the owner, then
+                 all_gather of the merged ">= 3" plane (the only one Phase B reads).
+  eref Phase B   refs sharded by cumulative length; all_gather of the per-ref rows (16 B each).
+  generateGraph  records sharded by file ordinal; candidates (a few % of records) all_gathered with
+                 a size pre-exchange, resolved identically on every rank; per-contig depth sums
+                 all_reduced.
+  matching       small after filtering: rank 0 (components are independent; no collective).
+
+This module only moves bytes; the arithmetic on them is the HIP library's (merge_slices, resolve).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def split_by_weight(weights, rank: int, world: int):
+    """Contiguous range [lo, hi) of items for `rank` with ~equal total weight per rank."""
+    w = np.asarray(weights, dtype=np.float64)
+    if world <= 1 or len(w) == 0:
+        return 0, len(w)
+    cum = np.cumsum(w)
+    cuts = [int(np.searchsorted(cum, cum[-1] * r / world, side="left")) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, len(w)
+    for r in range(1, world + 1):
+        cuts[r] = max(cuts[r], cuts[r - 1])
+    return cuts[rank], cuts[rank + 1]
+
+
+class DevicePtr:
+    """Zero-copy torch view of memory owned by the HIP library (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def wrap_device(torch, ptr: int, nbytes: int, device):
+    return torch.as_tensor(DevicePtr(ptr, nbytes), device=device)
+
+
+class Exchange:
+    def __init__(self, torch, dist, rank: int, world: int):
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self._send = self._recv = None
+
+    # ---- eref count table ------------------------------------------------------------------------
+    def merge_planes(self, planes, merge_fn):
+        """planes: three 1-D uint8 tensors (this rank's partial planes, equal length B with
+        B % (16 * world) == 0).  merge_fn(parts, n_parts, slice_off, slice_bytes) must fold
+        parts[part][plane][slice] into the planes at slice_off (the HIP library in production).
+        On return planes[2] is the global '>= 3' plane on every rank."""
+        torch, dist, W = self.torch, self.dist, self.world
+        B = planes[0].numel()
+        assert B % (16 * W) == 0 and all(p.numel() == B for p in planes)
+        S = B // W
+        if self._send is None or self._send.numel() != 3 * B:
+            self._send = torch.empty((W, 3, S), dtype=torch.uint8, device=planes[0].device)
+            self._recv = torch.empty((W, 3, S), dtype=torch.uint8, device=planes[0].device)
+        for p in range(3):
+            self._send[:, p, :] = planes[p].view(W, S)
+        dist.all_to_all_single(self._recv.view(-1), self._send.view(-1))
+        merge_fn(self._recv, W, self.rank * S, S)
+        mine = planes[2][self.rank * S:(self.rank + 1) * S].clone()
+        dist.all_gather_into_tensor(planes[2], mine)
+
+    # ---- small tables ------------------------------------------------------------------------------
+    def gather_ranges(self, table, ranges):
+        """table: (n, k) tensor, rank r filled rows ranges[r] = (lo, hi); afterwards all rows everywhere."""
+        torch, dist, W = self.torch, self.dist, self.world
+        width = max(hi - lo for lo, hi in ranges)
+        lo, hi = ranges[self.rank]
+        part = torch.zeros((width,) + tuple(table.shape[1:]), dtype=table.dtype, device=table.device)
+        part[: hi - lo] = table[lo:hi]
+        out = torch.empty((W, width) + tuple(table.shape[1:]), dtype=table.dtype, device=table.device)
+        dist.all_gather_into_tensor(out.view(-1), part.view(-1))
+        for r, (a, b) in enumerate(ranges):
+            table[a:b] = out[r, : b - a]
+
+    def gather_varlen(self, rows, n: int):
+        """rows: (cap, width) tensor of which the first n rows are valid on this rank.  Returns a
+        contiguous (total, width) tensor holding every rank's rows in rank order, and `total`."""
+        torch, dist, W = self.torch, self.dist, self.world
+        counts = torch.zeros(W, dtype=torch.int64, device=rows.device)
+        mine = torch.tensor([n], dtype=torch.int64, device=rows.device)
+        dist.all_gather_into_tensor(counts, mine)
+        counts = [int(x) for x in counts.tolist()]
+        width = max(1, max(counts))
+        part = torch.zeros((width, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        part[:n] = rows[:n]
+        out = torch.empty((W, width, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        dist.all_gather_into_tensor(out.view(-1), part.view(-1))
+        allrows = torch.cat([out[r, :c] for r, c in enumerate(counts)], dim=0).contiguous()
+        return allrows, sum(counts)
+
+    def reduce_sum(self, t):
+        self.dist.all_reduce(t)
+        return t
