@@ -182,54 +182,62 @@ def _concat(strings):
     return np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8).copy(), off
 
 
+class GraphInput:
+    """BAM-level records marshalled into the arrays orc_graph_run reads (done once, outside any timing)."""
+
+    def __init__(self, records, targets):
+        from palace_amd.synth import parse_cigar
+        n = len(records)
+        self.n, self.n_targets = n, len(targets)
+        flag = np.array([r.flag for r in records], dtype=np.uint16)
+        tid = np.array([r.tid for r in records], dtype=np.int32)
+        pos = np.array([r.pos for r in records], dtype=np.int32)
+        mtid = np.array([r.mtid for r in records], dtype=np.int32)
+        mpos = np.array([r.mpos for r in records], dtype=np.int32)
+        mapq = np.array([r.mapq for r in records], dtype=np.uint8)
+        nm = np.array([0 if r.nm is None else r.nm for r in records], dtype=np.int32)
+        cig = [np.array([(ln << 4) | op for ln, op in parse_cigar(r.cigar)], dtype=np.uint32) for r in records]
+        cigar_off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(c) for c in cig], out=cigar_off[1:])
+        cigar = np.concatenate(cig) if n else np.zeros(0, np.uint32)
+        cigar = np.ascontiguousarray(np.append(cigar, np.uint32(0)))
+        qn, qoff = _concat([r.qname for r in records])
+        sa, saoff = _concat([r.sa or "" for r in records])
+        has_sa = np.array([r.sa is not None for r in records], dtype=np.uint8)
+        self.tn, self.toff = _concat([t[0] for t in targets])
+        self.tlen = np.array([t[1] for t in targets], dtype=np.int32)
+        self._keep = [flag, tid, pos, mtid, mpos, mapq, nm, cigar_off, cigar, qn, qoff, sa, saoff, has_sa]
+        self.R = _OrcRecords(n, *(a.ctypes.data for a in (flag, tid, pos, mtid, mpos, mapq, nm, cigar_off, cigar, qoff,
+                                                          qn, saoff, sa, has_sa)))
+
+    def run(self, fastg_fai: str, avg_depth: float, opts: GraphOpts | None = None) -> bytes:
+        o = opts or graph_default_opts()
+        cap = 64 * 1024 * 1024 + 200 * self.n_targets
+        buf = C.create_string_buffer(cap)
+        L = lib()
+        L.orc_graph_run.restype = C.c_long
+        L.orc_graph_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_double,
+                                    C.c_void_p, C.c_char_p, C.c_size_t]
+        got = L.orc_graph_run(C.byref(self.R), self.n_targets, self.tn.ctypes.data, self.toff.ctypes.data,
+                              self.tlen.ctypes.data, fastg_fai.encode(), avg_depth, C.byref(o), buf, cap)
+        if got < 0:
+            raise OSError("orc_graph_run: output buffer too small")
+        return buf.raw[:got]
+
+
 def graph_run(records, targets, fastg_fai: str, avg_depth: float, opts: GraphOpts | None = None) -> bytes:
     """records: list of palace_amd.synth.BamRecord (file order); targets: [(name, len)]."""
-    from palace_amd.synth import parse_cigar
-    n = len(records)
-    keep = []
-    flag = np.array([r.flag for r in records], dtype=np.uint16)
-    tid = np.array([r.tid for r in records], dtype=np.int32)
-    pos = np.array([r.pos for r in records], dtype=np.int32)
-    mtid = np.array([r.mtid for r in records], dtype=np.int32)
-    mpos = np.array([r.mpos for r in records], dtype=np.int32)
-    mapq = np.array([r.mapq for r in records], dtype=np.uint8)
-    nm = np.array([0 if r.nm is None else r.nm for r in records], dtype=np.int32)
-    cig = [np.array([(ln << 4) | op for ln, op in parse_cigar(r.cigar)], dtype=np.uint32) for r in records]
-    cigar_off = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum([len(c) for c in cig], out=cigar_off[1:])
-    cigar = np.concatenate(cig) if n else np.zeros(0, np.uint32)
-    cigar = np.ascontiguousarray(np.append(cigar, np.uint32(0)))
-    qn, qoff = _concat([r.qname for r in records])
-    sa, saoff = _concat([r.sa or "" for r in records])
-    has_sa = np.array([r.sa is not None for r in records], dtype=np.uint8)
-    tn, toff = _concat([t[0] for t in targets])
-    tlen = np.array([t[1] for t in targets], dtype=np.int32)
-    keep += [flag, tid, pos, mtid, mpos, mapq, nm, cigar_off, cigar, qn, qoff, sa, saoff, has_sa, tn, toff, tlen]
-    R = _OrcRecords(n, *(a.ctypes.data for a in (flag, tid, pos, mtid, mpos, mapq, nm, cigar_off, cigar, qoff, qn,
-                                                 saoff, sa, has_sa)))
-    o = opts or graph_default_opts()
-    cap = 64 * 1024 * 1024 + 200 * len(targets)
-    buf = C.create_string_buffer(cap)
-    L = lib()
-    L.orc_graph_run.restype = C.c_long
-    L.orc_graph_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_double,
-                                C.c_void_p, C.c_char_p, C.c_size_t]
-    got = L.orc_graph_run(C.byref(R), len(targets), tn.ctypes.data, toff.ctypes.data, tlen.ctypes.data,
-                          fastg_fai.encode(), avg_depth, C.byref(o), buf, cap)
-    if got < 0:
-        raise OSError("orc_graph_run: output buffer too small")
-    return buf.raw[:got]
+    return GraphInput(records, targets).run(fastg_fai, avg_depth, opts)
 
 
 # ---- matching (oracle/match_oracle.cpp: this repository's own algorithm, reference absent) ------
 def match_run(graph_path: str, paths_path: str | None, iterations: int = 10, self_loops: bool = False,
-              break_cycles: bool = False, aggressive: bool = False):
+              break_cycles: bool = False, aggressive: bool = False, cap: int = 32 * 1024 * 1024):
     """-> (linear_bytes, cycle_bytes)"""
     L = lib()
     L.orc_match_run.restype = C.c_long
     L.orc_match_run.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t,
                                 C.c_char_p, C.c_size_t, C.POINTER(C.c_long)]
-    cap = 32 * 1024 * 1024
     lin, cyc = C.create_string_buffer(cap), C.create_string_buffer(cap)
     n_cyc = C.c_long(0)
     n = L.orc_match_run(graph_path.encode(), (paths_path or "").encode(), iterations, int(self_loops),
