@@ -342,9 +342,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    force_exchange = os.environ.get("PALACE_FORCE_EXCHANGE") == "1"      # rehearse the N>1 code path on one GPU
+    if world > 1 or force_exchange:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     from palace_amd import capi, multigpu
     from oracle import binding as orc       # header helper + cpu_baseline leg only
 
@@ -353,7 +357,7 @@ def main():
     ctx.eref_set_coder(hdr)
     sample = make_sample(torch, dev, args.contigs, args.refs, rank, world)
     gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world)
-    if world > 1:                                   # avgDepth is a pipeline input: computed once from all shards
+    if world > 1 or force_exchange:                 # avgDepth is a pipeline input: computed once from all shards
         tot = torch.tensor([float(gs["col"]["ref_len"].sum().item())], device=dev, dtype=torch.float64)
         dist.all_reduce(tot)
         gs["avg_depth"] = float(f"{tot.item() / gs['lens'].sum():.6g}")
@@ -373,7 +377,7 @@ def main():
     cols = capi.BamCols(gs["n"], *(P(gs["col"][k]) for k in ("tid", "pos", "mtid", "mpos", "nm", "ref_len", "read_len",
                                                            "clip_s", "clip_e", "flag", "mapq", "qkey")), P(gs["sa_off"]))
     prm = capi.GraphParams.default()
-    exch = multigpu.Exchange(torch, dist, rank, world) if world > 1 else None
+    exch = multigpu.Exchange(torch, dist, rank, world) if (world > 1 or force_exchange) else None
     if exch:
         ptrs, nbytes = ctx.eref_table_planes()
         planes = [multigpu.wrap_device(torch, q, nbytes, dev) for q in ptrs]
@@ -444,7 +448,7 @@ def main():
     def barrier():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -498,7 +502,7 @@ def main():
                                                last["graph"])
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

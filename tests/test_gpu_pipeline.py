@@ -1,0 +1,63 @@
+"""Whole 04-match stage through the drop-in tools on a GPU (palace:555-600), checked against the
+oracle chain; plus bench.py's multi-rank exchange code path rehearsed on one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from oracle import binding as orc
+from palace_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "palace_amd", "bin")
+SCRIPTS = os.path.join(ROOT, "palace_amd", "scripts")
+
+
+def sh(cmd, **kw):
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return p.stdout
+
+
+def test_stage4_chain_equals_oracle_chain(tmp_path):
+    rng = synth.rng_for(77)
+    targets, fai_text, recs, avg = synth.random_graph_case(rng, 80, 9000)
+    names, lens = [t[0] for t in targets], [t[1] for t in targets]
+    side = synth.filter_side_files(rng, names, lens)
+    P = lambda n: str(tmp_path / n)
+    synth.write_bam(P("s.bam"), targets, recs)
+    for k, v in dict(fastg_fai=fai_text, **side).items():
+        open(P(k), "w").write(v)
+    depth = f"{avg:.6g}"
+    # 4.3 generateGraph (min-count 3 so the toy keeps a few dozen junctions)
+    sh([os.path.join(BIN, "generateGraph"), "--min-count", "3", P("s.bam"), P("fastg_fai"), P("graph.txt"), depth])
+    o = orc.graph_default_opts(); o.min_count = 3
+    want_graph = orc.graph_run(recs, targets, P("fastg_fai"), float(depth), o)
+    assert open(P("graph.txt"), "rb").read() == want_graph
+    # 4.4 filter + uniq
+    sh([sys.executable, os.path.join(SCRIPTS, "filter_graph.py"), P("fastg_fai"), P("graph.txt"), P("pre.txt"), depth, "0",
+        P("hit_seqs"), P("node_scores"), P("blast"), "0.7", P("fasta_fai"), P("all_hit_segs.txt"), P("contigs_paths"), "0.7"])
+    open(P("filtered.txt"), "wb").write(sh(["uniq", P("pre.txt")]))
+    assert open(P("filtered.txt")).read().count("JUNC") > 5
+    # 4.5 matching + remove_cycle_dup + cat
+    sh([os.path.join(BIN, "matching"), "-g", P("filtered.txt"), "-r", P("linear.txt"), "-c", P("cycle.txt"), "-s", "-i", "10",
+        "-l", P("contigs_paths")])
+    sh([sys.executable, os.path.join(SCRIPTS, "remove_cycle_dup.py"), P("cycle.txt"), P("cycle_nodup.txt")])
+    all_result = open(P("linear.txt"), "rb").read() + open(P("cycle_nodup.txt"), "rb").read()
+    lin, cyc = orc.match_run(P("filtered.txt"), P("contigs_paths"), 10, self_loops=True)
+    assert open(P("linear.txt"), "rb").read() == lin and open(P("cycle.txt"), "rb").read() == cyc
+    assert all_result.startswith(lin) and len(lin) > 0
+
+
+def test_bench_exchange_path_rehearsal():
+    """world_size 1 over RCCL: same results as the plain single-GPU run."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--contigs", "20000", "--refs", "200", "--steps", "1",
+            "--warmup", "0", "--no-cpu-baseline"]
+    a = json.loads(sh(base).decode().strip().splitlines()[-1])
+    b = json.loads(sh(base, env=dict(os.environ, PALACE_FORCE_EXCHANGE="1")).decode().strip().splitlines()[-1])
+    assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
+    assert a["config"]["graph"] == b["config"]["graph"]
+    assert a["config"]["graph"]["n_edges"] > 0

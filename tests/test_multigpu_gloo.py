@@ -1,0 +1,104 @@
+"""world_size-2 gloo run of palace_amd/multigpu.Exchange on CPU tensors: the byte movement of the
+N>1 path (plane-slice all_to_all + owner merge + all_gather, padded row gathers, var-length candidate
+gather, depth reduce).  The merge arithmetic is the HIP library's in production; here a torch
+statement of the same bit-plane algebra stands in so the exchange can be checked end to end."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from palace_amd import multigpu
+
+
+def planes_from_counts(c):
+    """unary planes (count>=1, >=2, >=3) packed 8 keys per byte"""
+    return [torch.from_numpy(np.packbits((c >= t).astype(np.uint8), bitorder="little")) for t in (1, 2, 3)]
+
+
+def torch_merge(planes):
+    def fn(parts, n_parts, slice_off, slice_bytes):
+        a1 = torch.zeros(slice_bytes, dtype=torch.uint8); a2 = a1.clone(); a3 = a1.clone()
+        for p in range(n_parts):
+            b1, b2, b3 = parts[p, 0], parts[p, 1], parts[p, 2]
+            a3 = a3 | b3 | (a2 & b1) | (a1 & b2)
+            a2 = a2 | b2 | (a1 & b1)
+            a1 = a1 | b1
+        for pl, v in zip(planes, (a1, a2, a3)):
+            pl[slice_off:slice_off + slice_bytes] = v
+    return fn
+
+
+def worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ex = multigpu.Exchange(torch, dist, rank, world)
+        rng = np.random.Generator(np.random.PCG64(5))
+        n_keys = 1 << 16
+        counts = [rng.integers(0, 4, size=n_keys) * (rng.random(n_keys) < 0.3) for _ in range(world)]
+        planes = planes_from_counts(counts[rank])
+        ex.merge_planes(planes, torch_merge(planes))
+        want = planes_from_counts(np.minimum(3, sum(counts)))
+        ok_planes = bool(torch.equal(planes[2], want[2]))
+        S = planes[0].numel() // world
+        own = slice(rank * S, (rank + 1) * S)
+        ok_planes &= bool(torch.equal(planes[0][own], want[0][own]) and torch.equal(planes[1][own], want[1][own]))
+        # rows by ranges
+        lens = rng.integers(100, 1000, size=37)
+        ranges = [multigpu.split_by_weight(lens, r, world) for r in range(world)]
+        full = torch.from_numpy(rng.integers(0, 1000, size=(37, 4)).astype(np.int32))
+        table = torch.zeros_like(full)
+        lo, hi = ranges[rank]
+        table[lo:hi] = full[lo:hi]
+        ex.gather_ranges(table, ranges)
+        ok_rows = bool(torch.equal(table, full)) and ranges[0][0] == 0 and ranges[-1][1] == 37
+        # var-length candidates
+        n_mine = [5, 0, 11, 3][rank % 4] if world > 1 else 5
+        allc = [torch.full((n, 64), r + 1, dtype=torch.uint8) for r, n in enumerate([[5, 0, 11, 3][r % 4] for r in range(world)])]
+        buf = torch.zeros((16, 64), dtype=torch.uint8)
+        buf[:n_mine] = allc[rank]
+        got, total = ex.gather_varlen(buf, n_mine)
+        ok_var = total == sum(len(x) for x in allc) and bool(torch.equal(got, torch.cat(allc)))
+        t = torch.full((9,), rank + 1, dtype=torch.int64)
+        ex.reduce_sum(t)
+        ok_sum = bool((t == sum(range(1, world + 1))).all())
+        q.put((rank, ok_planes, ok_rows, ok_var, ok_sum))
+    finally:
+        dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2])
+def test_exchange_world2(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:]), r
+
+
+def test_split_by_weight_properties():
+    rng = np.random.Generator(np.random.PCG64(1))
+    w = rng.integers(1, 100, size=1000)
+    for world in (1, 2, 3, 8):
+        cuts = [multigpu.split_by_weight(w, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == len(w)
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        sums = [w[a:b].sum() for a, b in cuts]
+        assert max(sums) - min(sums) <= 2 * w.max()
+    assert multigpu.split_by_weight([], 0, 4) == (0, 0)
