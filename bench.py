@@ -379,8 +379,8 @@ def main():
     prm = capi.GraphParams.default()
     exch = multigpu.Exchange(torch, dist, rank, world) if (world > 1 or force_exchange) else None
     if exch:
-        ptrs, nbytes = ctx.eref_table_planes()
-        planes = [multigpu.wrap_device(torch, q, nbytes, dev) for q in ptrs]
+        planes = [torch.zeros(1 << 29, dtype=torch.uint8, device=dev) for _ in range(3)]   # torch-owned so RCCL
+        ctx.eref_table_attach([t.data_ptr() for t in planes])                                # can address them
         ref_ranges = [multigpu.split_by_weight(sample["ref_lens"], r, world) for r in range(world)]
         scratch_consumed = torch.zeros(nt, dtype=torch.int64, device=dev)
 

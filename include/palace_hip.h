@@ -88,6 +88,9 @@ int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t
  * [part][plane][slice_bytes] into the caller's planes at byte offset `slice_off`, with the
  * saturating add  (a + b >= t  for t = 1, 2, 3)  done bit-parallel on the planes. */
 int palace_eref_table_planes(palace_ctx *ctx, void **d_planes3, size_t *bytes_per_plane);
+/* Use three caller-owned device buffers (each 2^29 bytes, 16-byte aligned) as the table from now on
+ * (so a collective library can address them directly); the context no longer frees table memory. */
+int palace_eref_table_attach(palace_ctx *ctx, void *const d_planes3[3]);
 int palace_eref_table_merge_slices(palace_ctx *ctx, const void *d_parts, int n_parts,
                                    size_t slice_off, size_t slice_bytes);
 

@@ -77,6 +77,7 @@ _SIGS = {
     "palace_eref_scan_refs": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
                               C.c_void_p],
     "palace_eref_table_planes": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+    "palace_eref_table_attach": [C.c_void_p, C.POINTER(C.c_void_p)],
     "palace_eref_table_merge_slices": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t],
     "palace_eref_table_lookup": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "palace_eref_table_popcounts": [C.c_void_p, C.POINTER(C.c_uint64)],
@@ -248,6 +249,10 @@ class Ctx:
         nbytes = C.c_size_t()
         _check(lib().palace_eref_table_planes(self.h, ptrs, C.byref(nbytes)), "palace_eref_table_planes")
         return [int(p) for p in ptrs], int(nbytes.value)
+
+    def eref_table_attach(self, ptrs):
+        arr = (C.c_void_p * 3)(*[int(p) for p in ptrs])
+        _check(lib().palace_eref_table_attach(self.h, arr), "palace_eref_table_attach")
 
     def eref_table_merge_slices(self, parts_ptr: int, n_parts: int, slice_off: int, slice_bytes: int):
         _check(lib().palace_eref_table_merge_slices(self.h, parts_ptr, n_parts, slice_off, slice_bytes),

@@ -58,6 +58,7 @@ struct palace_ctx {
     bool coder_set = false;
     palace::CoderMasks masks{};
     uint32_t *plane[3] = {nullptr, nullptr, nullptr};
+    bool planes_external = false;
     palace::Workspace ws;      // grow-only scratch
     uint64_t *d_small = nullptr;   // 64 x u64 scratch for reductions
 };

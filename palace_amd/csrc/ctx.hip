@@ -82,7 +82,7 @@ int palace_ctx_destroy(palace_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (int p = 0; p < 3; p++)
-        if (ctx->plane[p]) (void)hipFree(ctx->plane[p]);
+        if (ctx->plane[p] && !ctx->planes_external) (void)hipFree(ctx->plane[p]);
     if (ctx->ws.ptr) (void)hipFree(ctx->ws.ptr);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     for (hipEvent_t e : ctx->marks)

@@ -549,6 +549,21 @@ int palace_eref_table_planes(palace_ctx *ctx, void **d_planes3, size_t *bytes_pe
     return PALACE_OK;
 }
 
+int palace_eref_table_attach(palace_ctx *ctx, void *const d_planes3[3])
+{
+    PALACE_REQUIRE(ctx && d_planes3 && d_planes3[0] && d_planes3[1] && d_planes3[2], "null argument");
+    for (int p = 0; p < 3; p++)
+        PALACE_REQUIRE(reinterpret_cast<uintptr_t>(d_planes3[p]) % 16 == 0, "planes must be 16-byte aligned");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < 3; p++) {
+        if (ctx->plane[p] && !ctx->planes_external) PALACE_HIP_TRY(hipFree(ctx->plane[p]));
+        ctx->plane[p] = static_cast<uint32_t *>(d_planes3[p]);
+    }
+    ctx->planes_external = true;
+    return PALACE_OK;
+}
+
 int palace_eref_table_merge_slices(palace_ctx *ctx, const void *d_parts, int n_parts, size_t slice_off,
                                    size_t slice_bytes)
 {

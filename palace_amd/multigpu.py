@@ -33,18 +33,6 @@ def split_by_weight(weights, rank: int, world: int):
     return cuts[rank], cuts[rank + 1]
 
 
-class DevicePtr:
-    """Zero-copy torch view of memory owned by the HIP library (via __cuda_array_interface__)."""
-
-    def __init__(self, ptr: int, nbytes: int):
-        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
-                                         "version": 2}
-
-
-def wrap_device(torch, ptr: int, nbytes: int, device):
-    return torch.as_tensor(DevicePtr(ptr, nbytes), device=device)
-
-
 class Exchange:
     def __init__(self, torch, dist, rank: int, world: int):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
