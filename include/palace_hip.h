@@ -85,7 +85,7 @@ int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t
 /* Multi-GPU exchange of the count table (no reference counterpart: the reference shares one
  * table between std::threads, extract_ref.cpp:1269-1291).  planes() exposes the three device
  * buffers (each 2^29 bytes); merge_slices() folds `n_parts` partial tables laid out as
- * [part][plane][slice_bytes] into the caller's planes at byte offset `slice_off`, with the
+ * [plane][part][slice_bytes] into the caller's planes at byte offset `slice_off`, with the
  * saturating add  (a + b >= t  for t = 1, 2, 3)  done bit-parallel on the planes. */
 int palace_eref_table_planes(palace_ctx *ctx, void **d_planes3, size_t *bytes_per_plane);
 /* Use three caller-owned device buffers (each 2^29 bytes, 16-byte aligned) as the table from now on

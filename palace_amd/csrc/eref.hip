@@ -373,9 +373,10 @@ __global__ __launch_bounds__(256) void merge_slices_kernel(const uint4 *__restri
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < slice16;
          i += static_cast<size_t>(gridDim.x) * blockDim.x) {
         uint32_t a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, a3[4] = {0, 0, 0, 0};
-        for (int p = 0; p < n_parts; p++) {
-            const uint4 *base = parts + static_cast<size_t>(p) * 3 * slice16;
-            uint4 v1 = base[i], v2 = base[slice16 + i], v3 = base[2 * slice16 + i];
+        for (int p = 0; p < n_parts; p++) {           // layout [plane][part][slice]
+            const size_t np = static_cast<size_t>(n_parts);
+            uint4 v1 = parts[(0 * np + p) * slice16 + i], v2 = parts[(1 * np + p) * slice16 + i],
+                  v3 = parts[(2 * np + p) * slice16 + i];
             uint32_t b1[4] = {v1.x, v1.y, v1.z, v1.w}, b2[4] = {v2.x, v2.y, v2.z, v2.w},
                      b3[4] = {v3.x, v3.y, v3.z, v3.w};
 #pragma unroll

@@ -36,24 +36,24 @@ def split_by_weight(weights, rank: int, world: int):
 class Exchange:
     def __init__(self, torch, dist, rank: int, world: int):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
-        self._send = self._recv = None
+        self._recv = None
 
     # ---- eref count table ------------------------------------------------------------------------
     def merge_planes(self, planes, merge_fn):
         """planes: three 1-D uint8 tensors (this rank's partial planes, equal length B with
         B % (16 * world) == 0).  merge_fn(parts, n_parts, slice_off, slice_bytes) must fold
-        parts[part][plane][slice] into the planes at slice_off (the HIP library in production).
+        parts[plane][part][slice] into the planes at slice_off (the HIP library in production).
         On return planes[2] is the global '>= 3' plane on every rank."""
         torch, dist, W = self.torch, self.dist, self.world
         B = planes[0].numel()
         assert B % (16 * W) == 0 and all(p.numel() == B for p in planes)
         S = B // W
-        if self._send is None or self._send.numel() != 3 * B:
-            self._send = torch.empty((W, 3, S), dtype=torch.uint8, device=planes[0].device)
-            self._recv = torch.empty((W, 3, S), dtype=torch.uint8, device=planes[0].device)
+        if self._recv is None or self._recv.numel() != 3 * B:
+            self._recv = torch.empty((3, W, S), dtype=torch.uint8, device=planes[0].device)
+        # one all_to_all per plane: a plane already is [peer][slice], so it is its own send buffer, and a
+        # message stays <= 512/W MiB (RCCL 2.26 corrupts single all_to_all calls above 1 GiB per rank)
         for p in range(3):
-            self._send[:, p, :] = planes[p].view(W, S)
-        dist.all_to_all_single(self._recv.view(-1), self._send.view(-1))
+            dist.all_to_all_single(self._recv[p].view(-1), planes[p])
         merge_fn(self._recv, W, self.rank * S, S)
         mine = planes[2][self.rank * S:(self.rank + 1) * S].clone()
         dist.all_gather_into_tensor(planes[2], mine)

@@ -241,7 +241,7 @@ def test_properties_full_size(ctx):
     for k, S in enumerate((A, B)):
         run([S])
         for p in range(3):
-            ctx.d2d(parts.ptr + (k * 3 + p) * nbytes, planes[p], nbytes)
+            ctx.d2d(parts.ptr + (p * 2 + k) * nbytes, planes[p], nbytes)      # [plane][part][slice]
     ctx.eref_table_reset()
     ctx.eref_table_merge_slices(parts.ptr, 2, 0, nbytes)
     ctx.sync()

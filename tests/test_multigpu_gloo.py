@@ -23,7 +23,7 @@ def torch_merge(planes):
     def fn(parts, n_parts, slice_off, slice_bytes):
         a1 = torch.zeros(slice_bytes, dtype=torch.uint8); a2 = a1.clone(); a3 = a1.clone()
         for p in range(n_parts):
-            b1, b2, b3 = parts[p, 0], parts[p, 1], parts[p, 2]
+            b1, b2, b3 = parts[0, p], parts[1, p], parts[2, p]
             a3 = a3 | b3 | (a2 & b1) | (a1 & b2)
             a2 = a2 | b2 | (a1 & b1)
             a1 = a1 | b1
