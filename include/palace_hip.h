@@ -74,6 +74,11 @@ int palace_eref_table_reset(palace_ctx *ctx);
 int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets,
                             int64_t n_reads, const uint8_t *d_keep);
 
+/* Tuning / test hook for count_reads: mode 0 = automatic (binned LDS counting for large inputs,
+ * direct global atomics for tiny ones), 1 = always direct, 2 = always binned; bucket_cap > 0
+ * overrides the per-bucket capacity of the binned path (keys beyond it take the direct path). */
+int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap);
+
 /* E5 + E6. For each ref: look the three indices of every position up in the table and run the
  * 500-base window scan (read_index + slide_window, extract_ref.cpp:813-903, 504-617).
  * one_min / three_min are int(500 * float(ratio)) as computed by the caller (extract_ref.cpp:

@@ -59,6 +59,8 @@ struct palace_ctx {
     palace::CoderMasks masks{};
     uint32_t *plane[3] = {nullptr, nullptr, nullptr};
     bool planes_external = false;
+    int count_mode = 0;             // 0 auto, 1 direct atomics, 2 binned
+    int64_t bin_cap_override = 0;
     palace::Workspace ws;      // grow-only scratch
     uint64_t *d_small = nullptr;   // 64 x u64 scratch for reductions
 };

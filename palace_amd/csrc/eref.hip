@@ -121,6 +121,128 @@ __global__ __launch_bounds__(256) void eref_count_kernel(const uint8_t *__restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// E4, binned path: no global atomics on the table.
+//   bin kernel    every 32-mer key goes to one of 2^14 fine buckets (key >> 18).  A workgroup owns a
+//                 tile of reads: pass 1 histograms its keys into LDS counters, one thread per bucket
+//                 then reserves the tile's run in the bucket with ONE global atomicAdd, pass 2
+//                 recomputes the keys and stores each at run_start + (LDS counter++).  A run is
+//                 written by one workgroup within microseconds, so its 4-byte stores combine in that
+//                 XCD's L2 and leave as whole lines.  Keys that do not fit the bucket's capacity
+//                 (heavily skewed inputs) fall back to the global atomicOr path -- still exact.
+//   count kernel  one workgroup per bucket: its 2^18-key slice of the three planes (3 x 32 KiB)
+//                 lives in LDS, is seeded from the global planes, takes the bucket's keys with LDS
+//                 atomicOr climbing 1 -> 2 -> 3, and is written back with 16-byte stores.
+// Traffic per key: 4 B written + 4 B read, instead of ~52 B of memory-side atomic requests.
+// ------------------------------------------------------------------------------------------
+constexpr int kBucketBits = 14;
+constexpr int kBuckets = 1 << kBucketBits;            // 16384
+constexpr int kBucketShift = 32 - kBucketBits;        // 18: keys per bucket = 2^18
+constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 per plane per bucket
+constexpr int kBinThreads = 1024;
+constexpr int kBinTileReads = 2048;
+
+template <class F>
+__device__ __forceinline__ void for_each_key(const uint8_t *__restrict__ s, int64_t len, int lane,
+                                             const CoderMasks &masks, F f)
+{
+    const int64_t npos = len - 31;
+    if (npos <= 0) return;
+    Streams lo = ballot_streams(s, lane, len);
+    for (int64_t base = 0; base < npos; base += 64) {
+        Streams hi = ballot_streams(s, base + 64 + lane, len);
+        const int64_t j = base + lane;
+        uint32_t wv = window32(lo.ok, hi.ok, lane);
+        if (j < npos && wv == 0xffffffffu) {
+            uint32_t key[3];
+            kmer_keys(masks, window32(lo.p0, hi.p0, lane), window32(lo.p1, hi.p1, lane),
+                      window32(lo.p2, hi.p2, lane), key);
+#pragma unroll
+            for (int i = 0; i < 3; i++) f(key[i]);
+        }
+        lo = hi;
+    }
+}
+
+__global__ __launch_bounds__(kBinThreads) void eref_bin_kernel(const uint8_t *__restrict__ bases,
+                                                               const int64_t *__restrict__ offsets,
+                                                               int64_t n_reads,
+                                                               const uint8_t *__restrict__ keep,
+                                                               CoderMasks masks,
+                                                               unsigned int *__restrict__ cursor,
+                                                               uint32_t *__restrict__ binned, uint32_t cap,
+                                                               uint32_t *__restrict__ p1,
+                                                               uint32_t *__restrict__ p2,
+                                                               uint32_t *__restrict__ p3)
+{
+    __shared__ unsigned int slot[kBuckets];            // pass 1: tile histogram; pass 2: next free offset
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int n_waves = kBinThreads / 64;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * kBinTileReads;
+    const int64_t r1 = min(n_reads, r0 + kBinTileReads);
+    for (int b = threadIdx.x; b < kBuckets; b += kBinThreads) slot[b] = 0;
+    __syncthreads();
+    for (int64_t r = r0 + wave; r < r1; r += n_waves) {
+        if (keep && !keep[r]) continue;
+        const int64_t beg = offsets[r];
+        for_each_key(bases + beg, offsets[r + 1] - beg, lane, masks,
+                     [&](uint32_t k) { atomicAdd(&slot[k >> kBucketShift], 1u); });
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < kBuckets; b += kBinThreads) {
+        unsigned int c = slot[b];
+        slot[b] = c ? atomicAdd(&cursor[b], c) : 0u;     // start of this tile's run inside bucket b
+    }
+    __syncthreads();
+    for (int64_t r = r0 + wave; r < r1; r += n_waves) {
+        if (keep && !keep[r]) continue;
+        const int64_t beg = offsets[r];
+        for_each_key(bases + beg, offsets[r + 1] - beg, lane, masks, [&](uint32_t k) {
+            const uint32_t b = k >> kBucketShift;
+            const unsigned int pos = atomicAdd(&slot[b], 1u);
+            if (pos < cap) binned[static_cast<size_t>(b) * cap + pos] = k;
+            else count_key(k, p1, p2, p3);                 // bucket full: exact slow path
+        });
+    }
+}
+
+__global__ __launch_bounds__(1024) void eref_lds_count_kernel(const unsigned int *__restrict__ cursor,
+                                                              const uint32_t *__restrict__ binned,
+                                                              uint32_t cap, uint32_t *__restrict__ p1,
+                                                              uint32_t *__restrict__ p2,
+                                                              uint32_t *__restrict__ p3)
+{
+    __shared__ uint32_t l1[kSliceWords], l2[kSliceWords], l3[kSliceWords];      // 3 x 32 KiB
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = min(cursor[b], cap);
+    if (n == 0) return;                                    // uniform for the whole workgroup
+    const size_t w0 = static_cast<size_t>(b) * kSliceWords;
+    const uint4 *g1 = reinterpret_cast<const uint4 *>(p1 + w0), *g2 = reinterpret_cast<const uint4 *>(p2 + w0),
+                *g3 = reinterpret_cast<const uint4 *>(p3 + w0);
+    for (int i = threadIdx.x; i < kSliceWords / 4; i += blockDim.x) {
+        reinterpret_cast<uint4 *>(l1)[i] = g1[i];
+        reinterpret_cast<uint4 *>(l2)[i] = g2[i];
+        reinterpret_cast<uint4 *>(l3)[i] = g3[i];
+    }
+    __syncthreads();
+    const uint32_t *keys = binned + static_cast<size_t>(b) * cap;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t k = keys[i];
+        const uint32_t w = (k & ((1u << kBucketShift) - 1)) >> 5, bit = 1u << (k & 31);
+        if (atomicOr(&l1[w], bit) & bit)
+            if (atomicOr(&l2[w], bit) & bit) atomicOr(&l3[w], bit);
+    }
+    __syncthreads();
+    uint4 *o1 = reinterpret_cast<uint4 *>(p1 + w0), *o2 = reinterpret_cast<uint4 *>(p2 + w0),
+          *o3 = reinterpret_cast<uint4 *>(p3 + w0);
+    for (int i = threadIdx.x; i < kSliceWords / 4; i += blockDim.x) {
+        o1[i] = reinterpret_cast<const uint4 *>(l1)[i];
+        o2[i] = reinterpret_cast<const uint4 *>(l2)[i];
+        o3[i] = reinterpret_cast<const uint4 *>(l3)[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // tiling of a set of sequences: tile = kTileChunks x 64 positions of one sequence
 // ------------------------------------------------------------------------------------------
@@ -451,13 +573,56 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
-    int64_t blocks = (n_reads + 3) / 4;                 // 4 waves (reads) per 256-thread block
-    int64_t cap = static_cast<int64_t>(kCUs) * 8 * 8;   // grid-stride beyond 16 Ki blocks
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(eref_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream,
-                       d_bases, d_offsets, n_reads, d_keep, ctx->masks, ctx->plane[0], ctx->plane[1],
-                       ctx->plane[2]);
+    // total bases bound the number of keys; tiny inputs keep the direct path (a 16 Ki-workgroup launch
+    // per call would dominate them), everything else is binned
+    int64_t h_off[2];
+    PALACE_HIP_TRY(hipMemcpyAsync(&h_off[0], d_offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PALACE_HIP_TRY(hipMemcpyAsync(&h_off[1], d_offsets + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const int64_t total_bases = h_off[1] - h_off[0];
+    PALACE_REQUIRE(total_bases >= 0, "offsets not ascending");
+    const bool binned = ctx->count_mode == 2 || (ctx->count_mode == 0 && total_bases >= (1ll << 22));
+    if (!binned) {
+        int64_t blocks = (n_reads + 3) / 4;                 // 4 waves (reads) per 256-thread block
+        int64_t cap = static_cast<int64_t>(kCUs) * 8 * 8;   // grid-stride beyond 16 Ki blocks
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(eref_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream,
+                           d_bases, d_offsets, n_reads, d_keep, ctx->masks, ctx->plane[0], ctx->plane[1],
+                           ctx->plane[2]);
+        PALACE_HIP_TRY(hipGetLastError());
+        return PALACE_OK;
+    }
+    // capacity per bucket: 1.25 x the uniform expectation of the key upper bound, plus slack
+    const int64_t max_keys = 3 * total_bases;
+    int64_t cap64 = max_keys / kBuckets + max_keys / (4 * kBuckets) + 2048;
+    if (ctx->bin_cap_override > 0) cap64 = ctx->bin_cap_override;
+    PALACE_REQUIRE(cap64 < (1ll << 31), "read set too large for one call; split it");
+    const uint32_t cap = static_cast<uint32_t>(cap64);
+    const size_t cur_bytes = align_up(kBuckets * sizeof(unsigned int), 256);
+    rc = ensure_workspace(ctx, cur_bytes + static_cast<size_t>(kBuckets) * cap * 4);
+    if (rc) return rc;
+    unsigned int *cursor = static_cast<unsigned int *>(ctx->ws.ptr);
+    uint32_t *binned_keys = reinterpret_cast<uint32_t *>(static_cast<char *>(ctx->ws.ptr) + cur_bytes);
+    PALACE_HIP_TRY(hipMemsetAsync(cursor, 0, cur_bytes, ctx->stream));
+    const int64_t tiles = (n_reads + kBinTileReads - 1) / kBinTileReads;
+    PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
+    hipLaunchKernelGGL(eref_bin_kernel, dim3(static_cast<unsigned>(tiles)), dim3(kBinThreads), 0, ctx->stream,
+                       d_bases, d_offsets, n_reads, d_keep, ctx->masks, cursor, binned_keys, cap, ctx->plane[0],
+                       ctx->plane[1], ctx->plane[2]);
     PALACE_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, cursor, binned_keys, cap,
+                       ctx->plane[0], ctx->plane[1], ctx->plane[2]);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+/* Test / tuning hook: 0 = automatic, 1 = always direct global atomics, 2 = always binned;
+ * bucket_cap > 0 overrides the per-bucket capacity (to exercise the overflow path). */
+int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap)
+{
+    PALACE_REQUIRE(ctx && mode >= 0 && mode <= 2 && bucket_cap >= 0 && bucket_cap < (1ll << 31), "bad argument");
+    ctx->count_mode = mode;
+    ctx->bin_cap_override = bucket_cap;
     return PALACE_OK;
 }
 

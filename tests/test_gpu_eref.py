@@ -248,3 +248,50 @@ def test_properties_full_size(ctx):
     assert ctx.eref_table_popcounts() == p_ab and np.array_equal(ctx.eref_table_lookup(probe), l_ab)
     for buf in (da, dao, dbb, dbo, parts):
         buf.free()
+
+
+@pytest.mark.parametrize("mode,cap", [(2, 0), (2, 64), (2, 1)])
+def test_binned_path_equals_oracle(ctx, golden_eref, mode, cap):
+    """LDS-binned counting (forced on small inputs), incl. bucket overflow into the direct path."""
+    g = golden_eref
+    cc = orc.header_to_cc(g["index_header"])
+    rng = synth.rng_for(13)
+    dup = synth.reads_from_list([synth.random_dna(rng, 120)] * 300 + [np.frombuffer(b"ACGT" * 50, dtype=np.uint8)] * 50)
+    sets = [(g["r1_bases"], g["r1_offsets"]), (g["r2_bases"], g["r2_offsets"]), (dup.bases, dup.offsets)]
+    try:
+        ctx.eref_set_count_mode(mode, cap)
+        count_on_gpu(ctx, sets, g["index_header"])
+    finally:
+        ctx.eref_set_count_mode(0, 0)
+    allb = np.concatenate([s[0] for s in sets])
+    offs, base = [np.zeros(1, np.int64)], 0
+    for b, o in sets:
+        offs.append(np.asarray(o[1:], dtype=np.int64) + base)
+        base += int(o[-1])
+    u, c = oracle_key_counts(allb, np.concatenate(offs), cc)
+    assert_table_equals(ctx, u, c)
+
+
+def test_binned_equals_direct_at_scale(ctx):
+    rng = synth.rng_for(17)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    a = synth.vector_reads(rng, synth.random_dna(rng, 30_000_000), 1_500_000, 150)
+    keep = (rng.random(a.n) < 0.9).astype(np.uint8)
+    da, dao, dk = ctx.upload(a.bases), ctx.upload(a.offsets), ctx.upload(keep)
+    ctx.eref_set_coder(hdr)
+    probe = np.unique(rng.integers(0, 2**32, size=300000, dtype=np.uint64).astype(np.uint32))
+    res = []
+    try:
+        for mode in (1, 2):
+            ctx.eref_set_count_mode(mode, 0)
+            ctx.eref_table_reset()
+            ctx.eref_count_reads(da, dao, a.n, dk)
+            ctx.eref_count_reads(da, dao, a.n)                 # second pass over the same reads: counts reach 2..3
+            ctx.sync()
+            res.append((ctx.eref_table_popcounts(), ctx.eref_table_lookup(probe)))
+    finally:
+        ctx.eref_set_count_mode(0, 0)
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    assert res[0][0][2] > 0
+    for b in (da, dao, dk):
+        b.free()
