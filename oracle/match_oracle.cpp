@@ -133,7 +133,7 @@ extern "C" long orc_match_run(const char *graph_path, const char *paths_path, in
         std::vector<char> alive(S);
         bool any = false;
         for (int s = 0; s < S; s++) { alive[s] = left[s] > 0; any |= alive[s]; }
-        if (!any) break;
+        if (!any) continue;
         std::vector<int> nxt(V, -1), prv(V, -1);
         std::vector<long> wt(V, 0);                              // weight rank of the arc leaving v
         for (size_t r = 0; r < arcs.size(); r++) {

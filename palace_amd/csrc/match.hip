@@ -130,21 +130,14 @@ static int dev_copy(palace_ctx *ctx, const T *h, size_t n, T **d)
 }
 }  // namespace palace
 
-extern "C" {
+using palace::dev_copy;
 
-int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
-                           const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
-                           palace_match_result **out)
+static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
+                          const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
+                          palace_match_result *res)
 {
-    PALACE_REQUIRE(ctx && out && n_segs >= 0 && n_arcs >= 0 && iterations >= 1, "bad argument");
-    PALACE_REQUIRE(n_segs == 0 || copies, "null copies");
-    PALACE_REQUIRE(n_arcs == 0 || (src && dst), "null arc arrays");
-    PALACE_REQUIRE(n_segs < (1 << 30) && n_arcs < (1ll << 31), "graph too large for int32 ids");
-    PALACE_HIP_TRY(hipSetDevice(ctx->device));
     const int32_t V = 2 * n_segs;
     const int64_t E = n_arcs;
-    for (int64_t e = 0; e < E; e++)
-        PALACE_REQUIRE(src[e] >= 0 && src[e] < V && dst[e] >= 0 && dst[e] < V, "arc endpoint out of range");
     // CSR by tail and by head; arc ids ascend inside every list because arcs arrive in rank order
     std::vector<int64_t> out_off(V + 1, 0), in_off(V + 1, 0);
     std::vector<int32_t> out_arcs(E), in_arcs(E);
@@ -172,7 +165,6 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
     TRY_OR_CLEAN(dev_copy(ctx, next.data(), V, &d_next)); TRY_OR_CLEAN(dev_copy(ctx, prev.data(), V, &d_prev));
     TRY_OR_CLEAN(dev_copy(ctx, narc.data(), V, &d_narc)); TRY_OR_CLEAN(dev_copy(ctx, alive.data(), V, &d_alive));
 
-    palace_match_result *res = new palace_match_result();
     std::vector<int64_t> left(copies, copies + n_segs);
     for (auto &c : left) c = std::max<int64_t>(1, c);
     std::vector<uint8_t> seen(V);
@@ -185,13 +177,13 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
         if (aggressive && t == rounds - 1) std::fill(left.begin(), left.end(), 1);
         bool any = false;
         for (int32_t s = 0; s < n_segs; s++) { alive[2 * s] = alive[2 * s + 1] = left[s] > 0; any |= left[s] > 0; }
-        if (!any) break;
+        if (!any) continue;                                   // nothing left this round (an `aggressive` round may follow)
         int rc = palace_h2d(ctx, d_alive, alive.data(), alive.size());
         if (!rc) rc = palace_match_greedy(ctx, V, E, d_src, d_dst, d_oo, d_oa, d_io, d_ia, d_alive, d_next, d_prev, d_narc, nullptr);
         if (!rc) rc = palace_d2h(ctx, next.data(), d_next, next.size() * 4);
         if (!rc) rc = palace_d2h(ctx, prev.data(), d_prev, prev.size() * 4);
         if (!rc) rc = palace_d2h(ctx, narc.data(), d_narc, narc.size() * 4);
-        if (rc) { delete res; cleanup(); return rc; }
+        if (rc) { cleanup(); return rc; }
         std::fill(seen.begin(), seen.end(), 0);
         heads.clear();
         pool.clear();
@@ -249,6 +241,71 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
     }
     cleanup();
 #undef TRY_OR_CLEAN
+    return PALACE_OK;
+}
+
+extern "C" {
+
+int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
+                           const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
+                           palace_match_result **out)
+{
+    PALACE_REQUIRE(ctx && out && n_segs >= 0 && n_arcs >= 0 && iterations >= 1, "bad argument");
+    PALACE_REQUIRE(n_segs == 0 || copies, "null copies");
+    PALACE_REQUIRE(n_arcs == 0 || (src && dst), "null arc arrays");
+    PALACE_REQUIRE(n_segs < (1 << 30) && n_arcs < (1ll << 31), "graph too large for int32 ids");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    const int32_t V = 2 * n_segs;
+    for (int64_t e = 0; e < n_arcs; e++)
+        PALACE_REQUIRE(src[e] >= 0 && src[e] < V && dst[e] >= 0 && dst[e] < V, "arc endpoint out of range");
+    // Segments without any arc can only ever be bare one-vertex paths of round 0 (and, when
+    // `aggressive`, of the extra round).  The matching runs on the sub-graph of segments that have
+    // arcs, relabelled monotonically so every "smaller vertex id" decision is unchanged; the bare
+    // segments are merged back in by first-vertex order.
+    std::vector<int32_t> new_id(n_segs, -1), old_id;
+    for (int64_t e = 0; e < n_arcs; e++) { new_id[src[e] >> 1] = 0; new_id[dst[e] >> 1] = 0; }
+    for (int32_t s = 0; s < n_segs; s++)
+        if (new_id[s] == 0) { new_id[s] = static_cast<int32_t>(old_id.size()); old_id.push_back(s); }
+    const int32_t n_sub = static_cast<int32_t>(old_id.size());
+    std::vector<int64_t> sub_copies(n_sub);
+    for (int32_t k = 0; k < n_sub; k++) sub_copies[k] = copies[old_id[k]];
+    std::vector<int32_t> ssrc(n_arcs), sdst(n_arcs);
+    for (int64_t e = 0; e < n_arcs; e++) {
+        ssrc[e] = 2 * new_id[src[e] >> 1] + (src[e] & 1);
+        sdst[e] = 2 * new_id[dst[e] >> 1] + (dst[e] & 1);
+    }
+    palace_match_result sub;
+    int rc = n_sub ? decompose_core(ctx, n_sub, sub_copies.data(), n_arcs, ssrc.data(), sdst.data(), iterations, aggressive, &sub)
+                   : PALACE_OK;
+    if (rc) return rc;
+    for (int32_t &v : sub.verts) v = 2 * old_id[v >> 1] + (v & 1);
+    palace_match_result *res = new palace_match_result();
+    const int64_t n_sub_comp = static_cast<int64_t>(sub.kind.size());
+    const int last_round = iterations + (aggressive ? 1 : 0) - 1;
+    auto emit_sub = [&](int64_t c) {
+        res->verts.insert(res->verts.end(), sub.verts.begin() + sub.off[c], sub.verts.begin() + sub.off[c + 1]);
+        res->off.push_back(static_cast<int64_t>(res->verts.size()));
+        res->kind.push_back(sub.kind[c]); res->iter.push_back(sub.iter[c]); res->open_at.push_back(sub.open_at[c]);
+    };
+    auto emit_bare = [&](int32_t s, int round) {
+        res->verts.push_back(2 * s);
+        res->off.push_back(static_cast<int64_t>(res->verts.size()));
+        res->kind.push_back(0); res->iter.push_back(round); res->open_at.push_back(0);
+    };
+    int64_t c = 0;
+    for (int round = 0; round <= last_round; round++) {
+        const bool bare_round = round == 0 || (aggressive && round == last_round);
+        int32_t s = 0;
+        auto next_bare = [&] { while (s < n_segs && new_id[s] >= 0) s++; };
+        next_bare();
+        while (c < n_sub_comp && sub.iter[c] == round) {
+            if (bare_round)
+                while (s < n_segs && 2 * s < sub.verts[sub.off[c]]) { emit_bare(s, round); s++; next_bare(); }
+            emit_sub(c++);
+        }
+        if (bare_round)
+            while (s < n_segs) { emit_bare(s, round); s++; next_bare(); }
+    }
     *out = res;
     return PALACE_OK;
 }
