@@ -123,25 +123,31 @@ __global__ __launch_bounds__(256) void eref_count_kernel(const uint8_t *__restri
 
 
 // ------------------------------------------------------------------------------------------
-// E4, binned path: no global atomics on the table.
-//   bin kernel    every 32-mer key goes to one of 2^14 fine buckets (key >> 18).  A workgroup owns a
-//                 tile of reads: pass 1 histograms its keys into LDS counters, one thread per bucket
-//                 then reserves the tile's run in the bucket with ONE global atomicAdd, pass 2
-//                 recomputes the keys and stores each at run_start + (LDS counter++).  A run is
-//                 written by one workgroup within microseconds, so its 4-byte stores combine in that
-//                 XCD's L2 and leave as whole lines.  Keys that do not fit the bucket's capacity
-//                 (heavily skewed inputs) fall back to the global atomicOr path -- still exact.
-//   count kernel  one workgroup per bucket: its 2^18-key slice of the three planes (3 x 32 KiB)
-//                 lives in LDS, is seeded from the global planes, takes the bucket's keys with LDS
-//                 atomicOr climbing 1 -> 2 -> 3, and is written back with 16-byte stores.
-// Traffic per key: 4 B written + 4 B read, instead of ~52 B of memory-side atomic requests.
+// E4, binned path: no global atomics on the table.  Two radix-partition levels of 7 bits each
+// bring every key into one of 2^14 fine buckets (key >> 18), then one workgroup per bucket counts
+// in LDS.
+//   bin1 kernel   a workgroup owns a tile of reads (~22 K keys).  Each key is appended to its
+//                 level-1 bucket's 256-slot staging row in LDS (LDS atomicAdd on 128 counters).
+//                 At the end one thread per bucket reserves the row's run in the bucket's global
+//                 region with ONE global atomicAdd and the rows are copied out -- contiguous, so the
+//                 stores coalesce into whole lines (the point of staging: 4-byte stores scattered
+//                 over 16 Ki destinations do not combine in L2, measured 21 ms vs 3 ms).
+//   bin2 kernel   the same step over a level-1 bucket's keys, on key bits 24..18.
+//   count kernel  one workgroup per fine bucket: its 2^18-key slice of the three planes
+//                 (3 x 32 KiB) lives in LDS, is seeded from the global planes, takes the bucket's keys
+//                 with LDS atomicOr climbing 1 -> 2 -> 3, and is written back with 16-byte stores.
+// A key that finds its staging row or its bucket region full takes the global atomicOr path, so
+// the result stays exact for any input; with hash-like keys that never happens (row mean 178 of 256).
+// Traffic per key: 4 B x (write, read, write, read) instead of ~52 B of memory-side atomic requests.
 // ------------------------------------------------------------------------------------------
 constexpr int kBucketBits = 14;
-constexpr int kBuckets = 1 << kBucketBits;            // 16384
-constexpr int kBucketShift = 32 - kBucketBits;        // 18: keys per bucket = 2^18
+constexpr int kBuckets = 1 << kBucketBits;            // 16384 fine buckets
+constexpr int kBucketShift = 32 - kBucketBits;        // 18: keys per fine bucket = 2^18
 constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 per plane per bucket
+constexpr int kL1Buckets = 128, kL1Shift = 25;        // level 1: key >> 25
+constexpr int kRowSlots = 256;                        // staging row per bucket
 constexpr int kBinThreads = 1024;
-constexpr int kBinTileReads = 2048;
+constexpr int kTileKeys = 22528;                      // keys per tile (22 per thread at level 2)
 
 template <class F>
 __device__ __forceinline__ void for_each_key(const uint8_t *__restrict__ s, int64_t len, int lane,
@@ -165,46 +171,84 @@ __device__ __forceinline__ void for_each_key(const uint8_t *__restrict__ s, int6
     }
 }
 
-__global__ __launch_bounds__(kBinThreads) void eref_bin_kernel(const uint8_t *__restrict__ bases,
-                                                               const int64_t *__restrict__ offsets,
-                                                               int64_t n_reads,
-                                                               const uint8_t *__restrict__ keep,
-                                                               CoderMasks masks,
-                                                               unsigned int *__restrict__ cursor,
-                                                               uint32_t *__restrict__ binned, uint32_t cap,
-                                                               uint32_t *__restrict__ p1,
-                                                               uint32_t *__restrict__ p2,
-                                                               uint32_t *__restrict__ p3)
+struct BinOut {
+    unsigned int *cursor;          // per destination bucket: keys reserved so far
+    uint32_t *buf;                 // bucket b owns buf[b * cap .. b * cap + cap)
+    uint32_t cap;
+    uint32_t *p1, *p2, *p3;        // overflow path
+};
+
+// stage -> reserve -> copy out; `bucket0` is the first destination bucket of this workgroup's 128
+__device__ __forceinline__ void flush_rows(uint32_t *stage, unsigned int *cnt, unsigned int *gbase,
+                                           uint32_t bucket0, const BinOut &o)
 {
-    __shared__ unsigned int slot[kBuckets];            // pass 1: tile histogram; pass 2: next free offset
+    __syncthreads();
+    if (threadIdx.x < kL1Buckets) {
+        const unsigned int c = min(cnt[threadIdx.x], static_cast<unsigned int>(kRowSlots));
+        cnt[threadIdx.x] = c;
+        gbase[threadIdx.x] = c ? atomicAdd(&o.cursor[bucket0 + threadIdx.x], c) : 0u;
+    }
+    __syncthreads();
+    for (int sidx = threadIdx.x; sidx < kL1Buckets * kRowSlots; sidx += kBinThreads) {
+        const int b = sidx / kRowSlots, p = sidx % kRowSlots;
+        if (p < static_cast<int>(cnt[b])) {
+            const uint32_t k = stage[sidx];
+            const unsigned int g = gbase[b] + p;
+            if (g < o.cap) o.buf[static_cast<size_t>(bucket0 + b) * o.cap + g] = k;
+            else count_key(k, o.p1, o.p2, o.p3);           // bucket region full: exact slow path
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBinThreads) void eref_bin1_kernel(const uint8_t *__restrict__ bases,
+                                                                const int64_t *__restrict__ offsets,
+                                                                int64_t n_reads,
+                                                                const uint8_t *__restrict__ keep,
+                                                                CoderMasks masks, int reads_per_tile, BinOut o)
+{
+    __shared__ uint32_t stage[kL1Buckets * kRowSlots];     // 128 KiB
+    __shared__ unsigned int cnt[kL1Buckets], gbase[kL1Buckets];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int n_waves = kBinThreads / 64;
-    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * kBinTileReads;
-    const int64_t r1 = min(n_reads, r0 + kBinTileReads);
-    for (int b = threadIdx.x; b < kBuckets; b += kBinThreads) slot[b] = 0;
+    if (threadIdx.x < kL1Buckets) cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (int64_t r = r0 + wave; r < r1; r += n_waves) {
-        if (keep && !keep[r]) continue;
-        const int64_t beg = offsets[r];
-        for_each_key(bases + beg, offsets[r + 1] - beg, lane, masks,
-                     [&](uint32_t k) { atomicAdd(&slot[k >> kBucketShift], 1u); });
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < kBuckets; b += kBinThreads) {
-        unsigned int c = slot[b];
-        slot[b] = c ? atomicAdd(&cursor[b], c) : 0u;     // start of this tile's run inside bucket b
-    }
-    __syncthreads();
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * reads_per_tile;
+    const int64_t r1 = min(n_reads, r0 + reads_per_tile);
     for (int64_t r = r0 + wave; r < r1; r += n_waves) {
         if (keep && !keep[r]) continue;
         const int64_t beg = offsets[r];
         for_each_key(bases + beg, offsets[r + 1] - beg, lane, masks, [&](uint32_t k) {
-            const uint32_t b = k >> kBucketShift;
-            const unsigned int pos = atomicAdd(&slot[b], 1u);
-            if (pos < cap) binned[static_cast<size_t>(b) * cap + pos] = k;
-            else count_key(k, p1, p2, p3);                 // bucket full: exact slow path
+            const uint32_t b = k >> kL1Shift;
+            const unsigned int pos = atomicAdd(&cnt[b], 1u);
+            if (pos < kRowSlots) stage[b * kRowSlots + pos] = k;
+            else count_key(k, o.p1, o.p2, o.p3);           // row full: exact slow path
         });
     }
+    flush_rows(stage, cnt, gbase, 0u, o);
+}
+
+__global__ __launch_bounds__(kBinThreads) void eref_bin2_kernel(const unsigned int *__restrict__ cursor1,
+                                                                const uint32_t *__restrict__ buf1, uint32_t cap1,
+                                                                BinOut o)
+{
+    __shared__ uint32_t stage[kL1Buckets * kRowSlots];
+    __shared__ unsigned int cnt[kL1Buckets], gbase[kL1Buckets];
+    const uint32_t b1 = blockIdx.y;
+    const uint32_t n1 = min(cursor1[b1], cap1);
+    const uint32_t start = blockIdx.x * kTileKeys;
+    if (start >= n1) return;                               // uniform for the workgroup
+    const uint32_t end = min(n1, start + kTileKeys);
+    if (threadIdx.x < kL1Buckets) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t *src = buf1 + static_cast<size_t>(b1) * cap1;
+    for (uint32_t i = start + threadIdx.x; i < end; i += kBinThreads) {
+        const uint32_t k = src[i];
+        const uint32_t b = (k >> kBucketShift) & (kL1Buckets - 1);
+        const unsigned int pos = atomicAdd(&cnt[b], 1u);
+        if (pos < kRowSlots) stage[b * kRowSlots + pos] = k;
+        else count_key(k, o.p1, o.p2, o.p3);
+    }
+    flush_rows(stage, cnt, gbase, b1 * kL1Buckets, o);
 }
 
 __global__ __launch_bounds__(1024) void eref_lds_count_kernel(const unsigned int *__restrict__ cursor,
@@ -592,25 +636,41 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         PALACE_HIP_TRY(hipGetLastError());
         return PALACE_OK;
     }
-    // capacity per bucket: 1.25 x the uniform expectation of the key upper bound, plus slack
+    // capacities: 1.25 x the uniform expectation of the key upper bound, plus slack
     const int64_t max_keys = 3 * total_bases;
-    int64_t cap64 = max_keys / kBuckets + max_keys / (4 * kBuckets) + 2048;
-    if (ctx->bin_cap_override > 0) cap64 = ctx->bin_cap_override;
-    PALACE_REQUIRE(cap64 < (1ll << 31), "read set too large for one call; split it");
-    const uint32_t cap = static_cast<uint32_t>(cap64);
-    const size_t cur_bytes = align_up(kBuckets * sizeof(unsigned int), 256);
-    rc = ensure_workspace(ctx, cur_bytes + static_cast<size_t>(kBuckets) * cap * 4);
+    int64_t cap2_64 = max_keys / kBuckets + max_keys / (4 * kBuckets) + 2048;
+    int64_t cap1_64 = max_keys / kL1Buckets + max_keys / (4 * kL1Buckets) + 4096;
+    if (ctx->bin_cap_override > 0) { cap2_64 = ctx->bin_cap_override; cap1_64 = ctx->bin_cap_override * kL1Buckets; }
+    PALACE_REQUIRE(cap1_64 < (1ll << 31), "read set too large for one call; split it");
+    const uint32_t cap1 = static_cast<uint32_t>(cap1_64), cap2 = static_cast<uint32_t>(cap2_64);
+    const size_t cur1_bytes = align_up(kL1Buckets * sizeof(unsigned int), 256);
+    const size_t cur2_bytes = align_up(kBuckets * sizeof(unsigned int), 256);
+    const size_t buf1_bytes = align_up(static_cast<size_t>(kL1Buckets) * cap1 * 4, 256);
+    rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + buf1_bytes + static_cast<size_t>(kBuckets) * cap2 * 4);
     if (rc) return rc;
-    unsigned int *cursor = static_cast<unsigned int *>(ctx->ws.ptr);
-    uint32_t *binned_keys = reinterpret_cast<uint32_t *>(static_cast<char *>(ctx->ws.ptr) + cur_bytes);
-    PALACE_HIP_TRY(hipMemsetAsync(cursor, 0, cur_bytes, ctx->stream));
-    const int64_t tiles = (n_reads + kBinTileReads - 1) / kBinTileReads;
+    char *ws = static_cast<char *>(ctx->ws.ptr);
+    unsigned int *cursor1 = reinterpret_cast<unsigned int *>(ws); ws += cur1_bytes;
+    unsigned int *cursor2 = reinterpret_cast<unsigned int *>(ws); ws += cur2_bytes;
+    uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
+    uint32_t *buf2 = reinterpret_cast<uint32_t *>(ws);
+    PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes, ctx->stream));
+    // reads per tile so that a tile holds about kTileKeys keys
+    const int64_t keys_per_read = std::max<int64_t>(1, 3 * (total_bases / n_reads - 31));
+    int64_t rpt = std::max<int64_t>(1, kTileKeys / keys_per_read);
+    if (rpt >= 16) rpt -= rpt % 16;
+    rpt = std::min<int64_t>(rpt, 1 << 20);
+    const int64_t tiles = (n_reads + rpt - 1) / rpt;
     PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
-    hipLaunchKernelGGL(eref_bin_kernel, dim3(static_cast<unsigned>(tiles)), dim3(kBinThreads), 0, ctx->stream,
-                       d_bases, d_offsets, n_reads, d_keep, ctx->masks, cursor, binned_keys, cap, ctx->plane[0],
-                       ctx->plane[1], ctx->plane[2]);
+    BinOut o1{cursor1, buf1, cap1, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
+    BinOut o2{cursor2, buf2, cap2, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
+    hipLaunchKernelGGL(eref_bin1_kernel, dim3(static_cast<unsigned>(tiles)), dim3(kBinThreads), 0, ctx->stream,
+                       d_bases, d_offsets, n_reads, d_keep, ctx->masks, static_cast<int>(rpt), o1);
     PALACE_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, cursor, binned_keys, cap,
+    const unsigned tiles2 = static_cast<unsigned>((static_cast<int64_t>(cap1) + kTileKeys - 1) / kTileKeys);
+    hipLaunchKernelGGL(eref_bin2_kernel, dim3(tiles2, kL1Buckets), dim3(kBinThreads), 0, ctx->stream, cursor1, buf1,
+                       cap1, o2);
+    PALACE_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, cursor2, buf2, cap2,
                        ctx->plane[0], ctx->plane[1], ctx->plane[2]);
     PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
