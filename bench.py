@@ -232,11 +232,10 @@ def make_graph_sample(torch, dev, n_contigs, n_pairs, rank=0, world=1):
                 names=names, lens=c_lens, link=link, avg_depth=None if total_ref is None else float(f"{total_ref / c_lens.sum():.6g}"))
 
 
-def graph_to_arcs(consumed, lens, avg_depth, edges, min_count=5):
-    """host glue between generateGraph's numbers and matching's input (SEG cn :1029-1031, JUNC filter
-    :1056-1061; arc ranking as palace_amd/host/matching_main.cpp)."""
-    depth = consumed.astype(np.float64) / np.maximum(1, lens)
-    copies = np.maximum(1, np.floor(depth / avg_depth + 0.5).astype(np.int64))
+def graph_to_arcs(cn, n_segs, edges, min_count=5):
+    """host glue between generateGraph's numbers and matching's input (JUNC filter :1056-1061; arc
+    ranking as palace_amd/host/matching_main.cpp).  cn comes from palace_graph_copy_numbers."""
+    copies = np.maximum(1, cn).astype(np.int64)
     tot = edges["counts"].sum(axis=1).astype(np.int64)
     e = edges[tot >= min_count]
     w = tot[tot >= min_count]
@@ -244,7 +243,7 @@ def graph_to_arcs(consumed, lens, avg_depth, edges, min_count=5):
     v = 2 * e["right"].astype(np.int64) + e["oR"]
     selfc = (v ^ 1) == u
     uu = np.concatenate([u, (v ^ 1)[~selfc]]); vv = np.concatenate([v, (u ^ 1)[~selfc]]); ww = np.concatenate([w, w[~selfc]])
-    V = 2 * len(lens)
+    V = 2 * n_segs
     cls = np.minimum(uu * V + vv, (vv ^ 1) * V + (uu ^ 1))
     order = np.lexsort((vv, uu, cls, -ww))
     return copies, uu[order].astype(np.int32), vv[order].astype(np.int32), ww[order]
@@ -371,6 +370,7 @@ def main():
     rows = torch.zeros((n_refs, 4), dtype=torch.int32, device=dev)
     rows_host = torch.zeros((n_refs, 4), dtype=torch.int32).pin_memory()
     consumed = torch.zeros(nt, dtype=torch.int64, device=dev)
+    cn_dev = torch.zeros(nt, dtype=torch.int32, device=dev)
     cand_cap = gs["n"] + gs["n_sa"] + 1
     cands = torch.zeros((cand_cap, 64), dtype=torch.uint8, device=dev)
     edges = torch.zeros((cand_cap, 32), dtype=torch.uint8, device=dev)
@@ -389,6 +389,7 @@ def main():
             ctx.eref_table_merge_slices(parts.data_ptr(), n_parts, slice_off, slice_bytes)
             ctx.sync()
     last = {}
+    host_ms = {}
     ref_off_local = sample["ref_off"][r_lo:r_hi + 1].contiguous()
 
     def step(i, timed):
@@ -436,12 +437,21 @@ def main():
             torch.cuda.synchronize()
         if timed: ctx.mark(m + 5)
         ctx.sync()
-        h_cons = consumed.cpu().numpy()
+        capi._check(L.palace_graph_copy_numbers(ctx.h, P(consumed), P(gs["tlen"]), nt, gs["avg_depth"], P(cn_dev)), "cn")
+        ctx.sync()
+        th0 = time.perf_counter()
+        h_cn = cn_dev.cpu().numpy()
         h_edges = e_buf[: n_e.value].cpu().numpy().view(capi.EDGE_DTYPE).reshape(-1)
+        th1 = time.perf_counter()
         # ---------------- matching (small; rank 0 owns it, components are independent) ----------------
-        copies, src, dst, w = graph_to_arcs(h_cons, gs["lens"], gs["avg_depth"], h_edges)
+        copies, src, dst, w = graph_to_arcs(h_cn, nt, h_edges)
+        th2 = time.perf_counter()
         if rank == 0:
             off, verts, kind, it, open_at = capi.match_decompose(ctx, copies, src, dst, 10, False)
+            th3 = time.perf_counter()
+            if timed:
+                for k_, v_ in (("d2h_graph", th1 - th0), ("glue_numpy", th2 - th1), ("match_decompose", th3 - th2)):
+                    host_ms[k_] = host_ms.get(k_, 0.0) + 1e3 * v_ / args.steps
             last.update(n_comp=len(kind), n_cycles=int(kind.sum()), n_multi=int(((off[1:] - off[:-1]) > 1).sum()))
         last.update(graph=(copies, src, dst, w), n_edges=int(n_e.value), n_cands=int(n_cands), n_arcs=len(src))
 
@@ -490,12 +500,12 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"reads/records/refs sharded over {world} GPUs (RCCL)",
                        "refs_reported": reported, "refs_present": int(len(sample["present"])),
                        "graph": {k: last[k] for k in ("n_cands", "n_edges", "n_arcs", "n_comp", "n_cycles", "n_multi")}},
-            "roofline": {"bound": "hbm", "kernel": "eref_count_kernel", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "eref count_reads (bin1 + bin2 + lds_count kernels of one launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": count_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "stage_ms": {"eref_count_both_sides": 2 * count_ms, "eref_table_merge": merge_ms, "eref_scan_refs": scan_ms,
                          "graph_classify": classify_ms, "graph_resolve": resolve_ms,
-                         "matching_and_host_glue": ms_step - gpu_ms},
+                         "matching_and_host_glue": ms_step - gpu_ms, **{"host_" + k: v for k, v in host_ms.items()}},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, sample, gs, hdr, args.cpu_sample_reads, args.cpu_sample_records,

@@ -185,6 +185,11 @@ int palace_graph_resolve(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_
                          int64_t n_records_total, const palace_graph_params *prm, uint64_t *d_consumed,
                          palace_graph_edge *d_edges, int64_t edge_cap, int64_t *n_edges_out);
 
+/* G6 epilogue numbers (generate_graph.cpp:1029-1031): depth = consumed / max(1, len) and
+ * cn = (int)floor(depth / avg_depth + 0.5) (0 when avg_depth <= 0), per target, in IEEE double. */
+int palace_graph_copy_numbers(palace_ctx *ctx, const uint64_t *d_consumed, const int32_t *d_tlen,
+                              int32_t n_targets, double avg_depth, int32_t *d_cn);
+
 /* ---- matching: path / cycle decomposition of the conjugate graph ------------------------- */
 
 /* M1. One greedy matching over the arcs of the conjugate graph, computed as rounds of locally

@@ -85,6 +85,7 @@ _SIGS = {
     "palace_graph_classify": [C.c_void_p, C.POINTER(BamCols), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_int64, C.POINTER(GraphParams), C.c_int64, C.c_void_p, C.c_void_p,
                               C.c_int64, C.POINTER(C.c_int64)],
+    "palace_graph_copy_numbers": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p],
     "palace_match_greedy": [C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 10 + [C.POINTER(C.c_int32)],
     "palace_match_decompose": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                C.c_int32, C.POINTER(C.c_void_p)],

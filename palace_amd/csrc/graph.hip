@@ -316,6 +316,16 @@ __global__ void compact_edges_kernel(ResolveArgs a)
     a.edges[i] = e;
 }
 
+__global__ void copy_number_kernel(const unsigned long long *__restrict__ consumed, const int32_t *__restrict__ tlen,
+                                   int32_t n, double avg, int32_t *__restrict__ cn)
+{
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double depth = static_cast<double>(consumed[i]) / static_cast<double>(max(1, tlen[i]));   // :1029
+    double cnf = avg > 0.0 ? depth / avg : 0.0;                                                // :1030
+    cn[i] = static_cast<int32_t>(floor(cnf + 0.5));                                            // :1031
+}
+
 static uint64_t pow2_at_least(uint64_t v) { uint64_t p = 64; while (p < v) p <<= 1; return p; }
 static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -374,6 +384,19 @@ int palace_graph_classify(palace_ctx *ctx, const palace_bam_cols *cols, const pa
         set_error("palace_graph_classify: %llu candidates exceed capacity %lld", n, (long long)cand_cap);
         return PALACE_EINVAL;
     }
+    return PALACE_OK;
+}
+
+int palace_graph_copy_numbers(palace_ctx *ctx, const uint64_t *d_consumed, const int32_t *d_tlen,
+                              int32_t n_targets, double avg_depth, int32_t *d_cn)
+{
+    PALACE_REQUIRE(ctx && n_targets >= 0, "bad argument");
+    if (n_targets == 0) return PALACE_OK;
+    PALACE_REQUIRE(d_consumed && d_tlen && d_cn, "null device pointer");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(copy_number_kernel, dim3((n_targets + 255) / 256), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const unsigned long long *>(d_consumed), d_tlen, n_targets, avg_depth, d_cn);
+    PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
 }
 

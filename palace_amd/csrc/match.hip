@@ -282,15 +282,26 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
     palace_match_result *res = new palace_match_result();
     const int64_t n_sub_comp = static_cast<int64_t>(sub.kind.size());
     const int last_round = iterations + (aggressive ? 1 : 0) - 1;
+    const int64_t n_bare = static_cast<int64_t>(n_segs) - n_sub;
+    const int64_t n_out = n_sub_comp + n_bare * (aggressive && last_round > 0 ? 2 : 1);
+    res->off.resize(static_cast<size_t>(n_out) + 1);
+    res->kind.resize(static_cast<size_t>(n_out));
+    res->iter.resize(static_cast<size_t>(n_out));
+    res->open_at.resize(static_cast<size_t>(n_out));
+    res->verts.resize(sub.verts.size() + static_cast<size_t>(n_out - n_sub_comp));
+    int64_t oc = 0, ov = 0;                               // next component / vertex slot
+    res->off[0] = 0;
     auto emit_sub = [&](int64_t c) {
-        res->verts.insert(res->verts.end(), sub.verts.begin() + sub.off[c], sub.verts.begin() + sub.off[c + 1]);
-        res->off.push_back(static_cast<int64_t>(res->verts.size()));
-        res->kind.push_back(sub.kind[c]); res->iter.push_back(sub.iter[c]); res->open_at.push_back(sub.open_at[c]);
+        const int64_t len = sub.off[c + 1] - sub.off[c];
+        std::copy(sub.verts.begin() + sub.off[c], sub.verts.begin() + sub.off[c + 1], res->verts.begin() + ov);
+        ov += len;
+        res->kind[oc] = sub.kind[c]; res->iter[oc] = sub.iter[c]; res->open_at[oc] = sub.open_at[c];
+        res->off[++oc] = ov;
     };
     auto emit_bare = [&](int32_t s, int round) {
-        res->verts.push_back(2 * s);
-        res->off.push_back(static_cast<int64_t>(res->verts.size()));
-        res->kind.push_back(0); res->iter.push_back(round); res->open_at.push_back(0);
+        res->verts[ov++] = 2 * s;
+        res->kind[oc] = 0; res->iter[oc] = round; res->open_at[oc] = 0;
+        res->off[++oc] = ov;
     };
     int64_t c = 0;
     for (int round = 0; round <= last_round; round++) {
@@ -306,6 +317,9 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
         if (bare_round)
             while (s < n_segs) { emit_bare(s, round); s++; next_bare(); }
     }
+    res->off.resize(static_cast<size_t>(oc) + 1);
+    res->kind.resize(static_cast<size_t>(oc)); res->iter.resize(static_cast<size_t>(oc)); res->open_at.resize(static_cast<size_t>(oc));
+    res->verts.resize(static_cast<size_t>(ov));
     *out = res;
     return PALACE_OK;
 }

@@ -207,6 +207,10 @@ int main(int argc, char **argv)
     CK(palace_graph_resolve(ctx, d_cands, n_cands, c.n(), &prm, d_consumed, d_edges, std::max<int64_t>(1, n_cands), &n_edges));
     std::vector<uint64_t> consumed(static_cast<size_t>(nt));
     std::vector<palace_graph_edge> edges(static_cast<size_t>(n_edges));
+    std::vector<int32_t> cn_dev(static_cast<size_t>(nt));
+    CK(palace_malloc(ctx, std::max<size_t>(1, nt) * 4, &p));
+    CK(palace_graph_copy_numbers(ctx, d_consumed, d_tlen, nt, avg_depth, static_cast<int32_t *>(p)));
+    CK(palace_d2h(ctx, cn_dev.data(), p, cn_dev.size() * 4));
     CK(palace_d2h(ctx, consumed.data(), d_consumed, consumed.size() * 8));
     CK(palace_d2h(ctx, edges.data(), d_edges, edges.size() * sizeof(palace_graph_edge)));
     palace_ctx_destroy(ctx);
@@ -228,8 +232,10 @@ int main(int argc, char **argv)
         for (int32_t j = k; j >= 0 && rank[by_name[j]] == rank[by_name[k]]; j--) sum += static_cast<double>(consumed[by_name[j]]);
         const int32_t L = c.target_len[best];
         const double depth = sum / std::max(1, L);
+        const bool unique_name = (k == 0 || rank[by_name[k - 1]] != rank[by_name[k]]);
         const double cnf = avg_depth > 0.0 ? depth / avg_depth : 0.0;
-        std::fprintf(out, "SEG %s %g %d\n", c.target_name[best].c_str(), depth, static_cast<int>(std::floor(cnf + 0.5)));
+        const int cn = unique_name ? cn_dev[best] : static_cast<int>(std::floor(cnf + 0.5));   // device value; host only for duplicate names
+        std::fprintf(out, "SEG %s %g %d\n", c.target_name[best].c_str(), depth, cn);
     }
     std::sort(edges.begin(), edges.end(), [&](const palace_graph_edge &a, const palace_graph_edge &b) {
         if (rank[a.left] != rank[b.left]) return rank[a.left] < rank[b.left];
