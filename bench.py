@@ -244,8 +244,13 @@ def graph_to_arcs(cn, n_segs, edges, min_count=5):
     selfc = (v ^ 1) == u
     uu = np.concatenate([u, (v ^ 1)[~selfc]]); vv = np.concatenate([v, (u ^ 1)[~selfc]]); ww = np.concatenate([w, w[~selfc]])
     V = 2 * n_segs
-    cls = np.minimum(uu * V + vv, (vv ^ 1) * V + (uu ^ 1))
-    order = np.lexsort((vv, uu, cls, -ww))
+    own = uu * V + vv
+    cls = np.minimum(own, (vv ^ 1) * V + (uu ^ 1))
+    if V <= (1 << 21) and (len(ww) == 0 or ww.max() < (1 << 20)):      # one packed 64-bit key: weight desc, class asc, pair order
+        key = ((np.int64((1 << 20) - 1) - ww) << np.int64(43)) | (cls << np.int64(1)) | (own != cls)
+        order = np.argsort(key, kind="stable")
+    else:
+        order = np.lexsort((vv, uu, cls, -ww))
     return copies, uu[order].astype(np.int32), vv[order].astype(np.int32), ww[order]
 
 
