@@ -69,14 +69,17 @@ int palace_eref_index_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_
 /* E4. Count table.  reset zeroes it (extract_ref.cpp:1257); count_reads adds every 32-mer of
  * every read, all three channels, saturating at 3 (read_fastq, extract_ref.cpp:961-1000).
  * d_keep (optional, 1 B/read) carries the E3 subsampling decision (extract_ref.cpp:955-960).
+ * total_bases = d_offsets[n_reads] - d_offsets[0] when the caller knows it (keeps the call
+ * asynchronous), or -1 to have it read back.
  * The table is held as three 2^32-bit planes "count >= 1 / >= 2 / >= 3". */
 int palace_eref_table_reset(palace_ctx *ctx);
 int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets,
-                            int64_t n_reads, const uint8_t *d_keep);
+                            int64_t n_reads, const uint8_t *d_keep, int64_t total_bases);
 
 /* Tuning / test hook for count_reads: mode 0 = automatic (binned LDS counting for large inputs,
  * direct global atomics for tiny ones), 1 = always direct, 2 = always binned; bucket_cap > 0
- * overrides the per-bucket capacity of the binned path (keys beyond it take the direct path). */
+ * overrides the per-bucket capacity of the binned path (keys beyond it take the direct path);
+ * modes 10..12 select the binning tile shape (tuning). */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap);
 
 /* E5 + E6. For each ref: look the three indices of every position up in the table and run the

@@ -73,7 +73,7 @@ _SIGS = {
     "palace_eref_set_coder": [C.c_void_p, C.c_void_p],
     "palace_eref_index_refs": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     "palace_eref_table_reset": [C.c_void_p],
-    "palace_eref_count_reads": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "palace_eref_count_reads": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64],
     "palace_eref_set_count_mode": [C.c_void_p, C.c_int, C.c_int64],
     "palace_eref_scan_refs": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
                               C.c_void_p],
@@ -219,9 +219,10 @@ class Ctx:
     def eref_table_reset(self):
         _check(lib().palace_eref_table_reset(self.h), "palace_eref_table_reset")
 
-    def eref_count_reads(self, d_bases: DevBuf, d_offsets: DevBuf, n_reads: int, d_keep: DevBuf | None = None):
+    def eref_count_reads(self, d_bases: DevBuf, d_offsets: DevBuf, n_reads: int, d_keep: DevBuf | None = None,
+                         total_bases: int = -1):
         _check(lib().palace_eref_count_reads(self.h, d_bases.ptr, d_offsets.ptr, n_reads,
-                                             d_keep.ptr if d_keep else None), "palace_eref_count_reads")
+                                             d_keep.ptr if d_keep else None, total_bases), "palace_eref_count_reads")
 
     def eref_set_count_mode(self, mode: int, bucket_cap: int = 0):
         _check(lib().palace_eref_set_count_mode(self.h, mode, bucket_cap), "palace_eref_set_count_mode")

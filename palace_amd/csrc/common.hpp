@@ -61,6 +61,7 @@ struct palace_ctx {
     bool planes_external = false;
     int count_mode = 0;             // 0 auto, 1 direct atomics, 2 binned
     int64_t bin_cap_override = 0;
+    int bin_variant = 0;            // 0: 512 threads x 128-slot rows, 1: 1024 x 256, 2: 256 x 64
     palace::Workspace ws;      // grow-only scratch
     uint64_t *d_small = nullptr;   // 64 x u64 scratch for reductions
 };

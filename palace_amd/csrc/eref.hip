@@ -145,9 +145,7 @@ constexpr int kBuckets = 1 << kBucketBits;            // 16384 fine buckets
 constexpr int kBucketShift = 32 - kBucketBits;        // 18: keys per fine bucket = 2^18
 constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 per plane per bucket
 constexpr int kL1Buckets = 128, kL1Shift = 25;        // level 1: key >> 25
-constexpr int kRowSlots = 256;                        // staging row per bucket
-constexpr int kBinThreads = 1024;
-constexpr int kTileKeys = 22528;                      // keys per tile (22 per thread at level 2)
+constexpr int kKeysPerThread = 22;                    // tile = THREADS * 22 keys: staging rows fill to ~70 %
 
 template <class F>
 __device__ __forceinline__ void for_each_key(const uint8_t *__restrict__ s, int64_t len, int lane,
@@ -171,6 +169,11 @@ __device__ __forceinline__ void for_each_key(const uint8_t *__restrict__ s, int6
     }
 }
 
+template <int T, int S>
+struct BinVariant {
+    static constexpr int threads = T, slots = S;
+};
+
 struct BinOut {
     unsigned int *cursor;          // per destination bucket: keys reserved so far
     uint32_t *buf;                 // bucket b owns buf[b * cap .. b * cap + cap)
@@ -179,18 +182,19 @@ struct BinOut {
 };
 
 // stage -> reserve -> copy out; `bucket0` is the first destination bucket of this workgroup's 128
+template <int THREADS, int SLOTS>
 __device__ __forceinline__ void flush_rows(uint32_t *stage, unsigned int *cnt, unsigned int *gbase,
                                            uint32_t bucket0, const BinOut &o)
 {
     __syncthreads();
     if (threadIdx.x < kL1Buckets) {
-        const unsigned int c = min(cnt[threadIdx.x], static_cast<unsigned int>(kRowSlots));
+        const unsigned int c = min(cnt[threadIdx.x], static_cast<unsigned int>(SLOTS));
         cnt[threadIdx.x] = c;
         gbase[threadIdx.x] = c ? atomicAdd(&o.cursor[bucket0 + threadIdx.x], c) : 0u;
     }
     __syncthreads();
-    for (int sidx = threadIdx.x; sidx < kL1Buckets * kRowSlots; sidx += kBinThreads) {
-        const int b = sidx / kRowSlots, p = sidx % kRowSlots;
+    for (int sidx = threadIdx.x; sidx < kL1Buckets * SLOTS; sidx += THREADS) {
+        const int b = sidx / SLOTS, p = sidx % SLOTS;
         if (p < static_cast<int>(cnt[b])) {
             const uint32_t k = stage[sidx];
             const unsigned int g = gbase[b] + p;
@@ -200,16 +204,17 @@ __device__ __forceinline__ void flush_rows(uint32_t *stage, unsigned int *cnt, u
     }
 }
 
-__global__ __launch_bounds__(kBinThreads) void eref_bin1_kernel(const uint8_t *__restrict__ bases,
+template <int THREADS, int SLOTS>
+__global__ __launch_bounds__(THREADS) void eref_bin1_kernel(const uint8_t *__restrict__ bases,
                                                                 const int64_t *__restrict__ offsets,
                                                                 int64_t n_reads,
                                                                 const uint8_t *__restrict__ keep,
                                                                 CoderMasks masks, int reads_per_tile, BinOut o)
 {
-    __shared__ uint32_t stage[kL1Buckets * kRowSlots];     // 128 KiB
+    __shared__ uint32_t stage[kL1Buckets * SLOTS];
     __shared__ unsigned int cnt[kL1Buckets], gbase[kL1Buckets];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int n_waves = kBinThreads / 64;
+    constexpr int n_waves = THREADS / 64;
     if (threadIdx.x < kL1Buckets) cnt[threadIdx.x] = 0;
     __syncthreads();
     const int64_t r0 = static_cast<int64_t>(blockIdx.x) * reads_per_tile;
@@ -220,35 +225,37 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin1_kernel(const uint8_t *_
         for_each_key(bases + beg, offsets[r + 1] - beg, lane, masks, [&](uint32_t k) {
             const uint32_t b = k >> kL1Shift;
             const unsigned int pos = atomicAdd(&cnt[b], 1u);
-            if (pos < kRowSlots) stage[b * kRowSlots + pos] = k;
+            if (pos < SLOTS) stage[b * SLOTS + pos] = k;
             else count_key(k, o.p1, o.p2, o.p3);           // row full: exact slow path
         });
     }
-    flush_rows(stage, cnt, gbase, 0u, o);
+    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, 0u, o);
 }
 
-__global__ __launch_bounds__(kBinThreads) void eref_bin2_kernel(const unsigned int *__restrict__ cursor1,
+template <int THREADS, int SLOTS>
+__global__ __launch_bounds__(THREADS) void eref_bin2_kernel(const unsigned int *__restrict__ cursor1,
                                                                 const uint32_t *__restrict__ buf1, uint32_t cap1,
                                                                 BinOut o)
 {
-    __shared__ uint32_t stage[kL1Buckets * kRowSlots];
+    __shared__ uint32_t stage[kL1Buckets * SLOTS];
     __shared__ unsigned int cnt[kL1Buckets], gbase[kL1Buckets];
     const uint32_t b1 = blockIdx.y;
     const uint32_t n1 = min(cursor1[b1], cap1);
+    constexpr uint32_t kTileKeys = THREADS * kKeysPerThread;
     const uint32_t start = blockIdx.x * kTileKeys;
     if (start >= n1) return;                               // uniform for the workgroup
     const uint32_t end = min(n1, start + kTileKeys);
     if (threadIdx.x < kL1Buckets) cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t *src = buf1 + static_cast<size_t>(b1) * cap1;
-    for (uint32_t i = start + threadIdx.x; i < end; i += kBinThreads) {
+    for (uint32_t i = start + threadIdx.x; i < end; i += THREADS) {
         const uint32_t k = src[i];
         const uint32_t b = (k >> kBucketShift) & (kL1Buckets - 1);
         const unsigned int pos = atomicAdd(&cnt[b], 1u);
-        if (pos < kRowSlots) stage[b * kRowSlots + pos] = k;
+        if (pos < SLOTS) stage[b * SLOTS + pos] = k;
         else count_key(k, o.p1, o.p2, o.p3);
     }
-    flush_rows(stage, cnt, gbase, b1 * kL1Buckets, o);
+    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, b1 * kL1Buckets, o);
 }
 
 __global__ __launch_bounds__(1024) void eref_lds_count_kernel(const unsigned int *__restrict__ cursor,
@@ -608,7 +615,7 @@ int palace_eref_table_reset(palace_ctx *ctx)
 }
 
 int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets,
-                            int64_t n_reads, const uint8_t *d_keep)
+                            int64_t n_reads, const uint8_t *d_keep, int64_t total_bases)
 {
     PALACE_REQUIRE(ctx && n_reads >= 0, "bad argument");
     if (!ctx->coder_set) { set_error("palace_eref_count_reads: coder not set"); return PALACE_ESTATE; }
@@ -619,12 +626,14 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     if (rc) return rc;
     // total bases bound the number of keys; tiny inputs keep the direct path (a 16 Ki-workgroup launch
     // per call would dominate them), everything else is binned
-    int64_t h_off[2];
-    PALACE_HIP_TRY(hipMemcpyAsync(&h_off[0], d_offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PALACE_HIP_TRY(hipMemcpyAsync(&h_off[1], d_offsets + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    const int64_t total_bases = h_off[1] - h_off[0];
-    PALACE_REQUIRE(total_bases >= 0, "offsets not ascending");
+    if (total_bases < 0) {                                  // caller does not know: read the two end offsets back
+        int64_t h_off[2];
+        PALACE_HIP_TRY(hipMemcpyAsync(&h_off[0], d_offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
+        PALACE_HIP_TRY(hipMemcpyAsync(&h_off[1], d_offsets + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
+        PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        total_bases = h_off[1] - h_off[0];
+        PALACE_REQUIRE(total_bases >= 0, "offsets not ascending");
+    }
     const bool binned = ctx->count_mode == 2 || (ctx->count_mode == 0 && total_bases >= (1ll << 22));
     if (!binned) {
         int64_t blocks = (n_reads + 3) / 4;                 // 4 waves (reads) per 256-thread block
@@ -654,22 +663,34 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
     uint32_t *buf2 = reinterpret_cast<uint32_t *>(ws);
     PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes, ctx->stream));
-    // reads per tile so that a tile holds about kTileKeys keys
-    const int64_t keys_per_read = std::max<int64_t>(1, 3 * (total_bases / n_reads - 31));
-    int64_t rpt = std::max<int64_t>(1, kTileKeys / keys_per_read);
-    if (rpt >= 16) rpt -= rpt % 16;
-    rpt = std::min<int64_t>(rpt, 1 << 20);
-    const int64_t tiles = (n_reads + rpt - 1) / rpt;
-    PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
     BinOut o1{cursor1, buf1, cap1, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
     BinOut o2{cursor2, buf2, cap2, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
-    hipLaunchKernelGGL(eref_bin1_kernel, dim3(static_cast<unsigned>(tiles)), dim3(kBinThreads), 0, ctx->stream,
-                       d_bases, d_offsets, n_reads, d_keep, ctx->masks, static_cast<int>(rpt), o1);
-    PALACE_HIP_TRY(hipGetLastError());
-    const unsigned tiles2 = static_cast<unsigned>((static_cast<int64_t>(cap1) + kTileKeys - 1) / kTileKeys);
-    hipLaunchKernelGGL(eref_bin2_kernel, dim3(tiles2, kL1Buckets), dim3(kBinThreads), 0, ctx->stream, cursor1, buf1,
-                       cap1, o2);
-    PALACE_HIP_TRY(hipGetLastError());
+    auto launch_bins = [&](auto variant) -> int {
+        constexpr int THREADS = decltype(variant)::threads, SLOTS = decltype(variant)::slots;
+        constexpr int64_t tile_keys = static_cast<int64_t>(THREADS) * kKeysPerThread;
+        // reads per tile so that a tile holds about tile_keys keys; whole waves' worth when possible
+        const int64_t keys_per_read = std::max<int64_t>(1, 3 * (total_bases / n_reads - 31));
+        int64_t rpt = std::max<int64_t>(1, tile_keys / keys_per_read);
+        constexpr int waves = THREADS / 64;
+        if (rpt >= waves) rpt -= rpt % waves;
+        rpt = std::min<int64_t>(rpt, 1 << 20);
+        const int64_t tiles = (n_reads + rpt - 1) / rpt;
+        PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
+        hipLaunchKernelGGL((eref_bin1_kernel<THREADS, SLOTS>), dim3(static_cast<unsigned>(tiles)), dim3(THREADS), 0,
+                           ctx->stream, d_bases, d_offsets, n_reads, d_keep, ctx->masks, static_cast<int>(rpt), o1);
+        PALACE_HIP_TRY(hipGetLastError());
+        const unsigned tiles2 = static_cast<unsigned>((static_cast<int64_t>(cap1) + tile_keys - 1) / tile_keys);
+        hipLaunchKernelGGL((eref_bin2_kernel<THREADS, SLOTS>), dim3(tiles2, kL1Buckets), dim3(THREADS), 0, ctx->stream,
+                           cursor1, buf1, cap1, o2);
+        PALACE_HIP_TRY(hipGetLastError());
+        return PALACE_OK;
+    };
+    switch (ctx->bin_variant) {
+    case 1: rc = launch_bins(BinVariant<1024, 256>{}); break;
+    case 2: rc = launch_bins(BinVariant<256, 64>{}); break;
+    default: rc = launch_bins(BinVariant<512, 128>{}); break;
+    }
+    if (rc) return rc;
     hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, cursor2, buf2, cap2,
                        ctx->plane[0], ctx->plane[1], ctx->plane[2]);
     PALACE_HIP_TRY(hipGetLastError());
@@ -680,6 +701,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
  * bucket_cap > 0 overrides the per-bucket capacity (to exercise the overflow path). */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap)
 {
+    if (ctx && mode >= 10 && mode <= 12) { ctx->bin_variant = mode - 10; return PALACE_OK; }   // tuning: tile shape
     PALACE_REQUIRE(ctx && mode >= 0 && mode <= 2 && bucket_cap >= 0 && bucket_cap < (1ll << 31), "bad argument");
     ctx->count_mode = mode;
     ctx->bin_cap_override = bucket_cap;

@@ -194,7 +194,7 @@ int main(int argc, char **argv)
         CK(upload(ctx, rs.bases.data(), rs.bases.size(), &d_b));
         CK(upload(ctx, rs.offsets.data(), rs.offsets.size(), &d_o));
         if (!keep.empty()) CK(upload(ctx, keep.data(), keep.size(), &d_k));
-        CK(palace_eref_count_reads(ctx, d_b, d_o, rs.n(), d_k));
+        CK(palace_eref_count_reads(ctx, d_b, d_o, rs.n(), d_k, static_cast<int64_t>(rs.bases.size())));
         CK(palace_free(ctx, d_b)); CK(palace_free(ctx, d_o)); CK(palace_free(ctx, d_k));
     }
 
