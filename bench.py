@@ -359,7 +359,7 @@ def main():
 
     hdr = orc.header_from_picks(np.random.Generator(np.random.PCG64(SEED)).integers(0, 6, size=32))
     ctx = capi.Ctx(local)                      # eref stream
-    ctx_g = capi.Ctx(local)                    # generateGraph + matching stream (independent of eref until the end)
+    ctx_g = capi.Ctx(local, high_priority=True)   # generateGraph + matching stream (independent of eref until the end)
     ctx.eref_set_coder(hdr)
     if args.bin_variant:
         ctx.eref_set_count_mode(10 + args.bin_variant)

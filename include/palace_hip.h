@@ -34,6 +34,9 @@ const char *palace_version(void);
 
 /* ---- context, memory, stream plumbing --------------------------------------------------- */
 int palace_ctx_create(int device, palace_ctx **out);
+/* same, with the context's stream at the device's highest priority when high_priority != 0 (for
+ * small latency-bound work that runs beside bulk kernels of another context) */
+int palace_ctx_create_prio(int device, int high_priority, palace_ctx **out);
 int palace_ctx_destroy(palace_ctx *ctx);
 int palace_sync(palace_ctx *ctx);
 /* raw hipStream_t of the context (for callers that want to order their own work / events) */

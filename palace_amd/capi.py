@@ -58,6 +58,7 @@ assert CAND_DTYPE.itemsize == 64 and EDGE_DTYPE.itemsize == 32 and SA_ITEM_DTYPE
 
 _SIGS = {
     "palace_ctx_create": [C.c_int, C.POINTER(C.c_void_p)],
+    "palace_ctx_create_prio": [C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "palace_ctx_destroy": [C.c_void_p],
     "palace_sync": [C.c_void_p],
     "palace_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
@@ -155,9 +156,9 @@ class DevBuf:
 class Ctx:
     """One device context (one HIP stream).  `calls` go straight to the C ABI."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, high_priority: bool = False):
         h = C.c_void_p()
-        _check(lib().palace_ctx_create(device, C.byref(h)), "palace_ctx_create")
+        _check(lib().palace_ctx_create_prio(device, int(high_priority), C.byref(h)), "palace_ctx_create_prio")
         self.h = h
         self.device = device
 

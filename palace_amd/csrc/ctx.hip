@@ -55,7 +55,9 @@ extern "C" {
 const char *palace_last_error(void) { return g_err; }
 const char *palace_version(void) { return "palace_hip 0.1 (gfx950)"; }
 
-int palace_ctx_create(int device, palace_ctx **out)
+int palace_ctx_create(int device, palace_ctx **out) { return palace_ctx_create_prio(device, 0, out); }
+
+int palace_ctx_create_prio(int device, int high_priority, palace_ctx **out)
 {
     PALACE_REQUIRE(out != nullptr, "out is null");
     int n = 0;
@@ -68,7 +70,13 @@ int palace_ctx_create(int device, palace_ctx **out)
     PALACE_HIP_TRY(hipSetDevice(device));
     palace_ctx *ctx = new palace_ctx();
     ctx->device = device;
-    PALACE_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    if (high_priority) {
+        int least = 0, greatest = 0;                       // numerically lower = more urgent
+        PALACE_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        PALACE_HIP_TRY(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest));
+    } else {
+        PALACE_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    }
     PALACE_HIP_TRY(hipEventCreate(&ctx->ev0));
     PALACE_HIP_TRY(hipEventCreate(&ctx->ev1));
     PALACE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_small), 64 * sizeof(uint64_t)));

@@ -145,6 +145,8 @@ constexpr int kBuckets = 1 << kBucketBits;            // 16384 fine buckets
 constexpr int kBucketShift = 32 - kBucketBits;        // 18: keys per fine bucket = 2^18
 constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 per plane per bucket
 constexpr int kL1Buckets = 128, kL1Shift = 25;        // level 1: key >> 25
+constexpr int kL1Replicas = 32;                        // level-1 bucket regions are split 32 ways so that the
+                                                      // per-tile reservations do not pile onto 128 addresses
 constexpr int kKeysPerThread = 22;                    // tile = THREADS * 22 keys: staging rows fill to ~70 %
 
 template <class F>
@@ -184,13 +186,13 @@ struct BinOut {
 // stage -> reserve -> copy out; `bucket0` is the first destination bucket of this workgroup's 128
 template <int THREADS, int SLOTS>
 __device__ __forceinline__ void flush_rows(uint32_t *stage, unsigned int *cnt, unsigned int *gbase,
-                                           uint32_t bucket0, const BinOut &o)
+                                           uint32_t bucket0, uint32_t stride, const BinOut &o)
 {
     __syncthreads();
     if (threadIdx.x < kL1Buckets) {
         const unsigned int c = min(cnt[threadIdx.x], static_cast<unsigned int>(SLOTS));
         cnt[threadIdx.x] = c;
-        gbase[threadIdx.x] = c ? atomicAdd(&o.cursor[bucket0 + threadIdx.x], c) : 0u;
+        gbase[threadIdx.x] = c ? atomicAdd(&o.cursor[bucket0 + threadIdx.x * stride], c) : 0u;
     }
     __syncthreads();
     for (int sidx = threadIdx.x; sidx < kL1Buckets * SLOTS; sidx += THREADS) {
@@ -198,7 +200,7 @@ __device__ __forceinline__ void flush_rows(uint32_t *stage, unsigned int *cnt, u
         if (p < static_cast<int>(cnt[b])) {
             const uint32_t k = stage[sidx];
             const unsigned int g = gbase[b] + p;
-            if (g < o.cap) o.buf[static_cast<size_t>(bucket0 + b) * o.cap + g] = k;
+            if (g < o.cap) o.buf[static_cast<size_t>(bucket0 + b * stride) * o.cap + g] = k;
             else count_key(k, o.p1, o.p2, o.p3);           // bucket region full: exact slow path
         }
     }
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_kernel(const uint8_t *__res
             else count_key(k, o.p1, o.p2, o.p3);           // row full: exact slow path
         });
     }
-    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, 0u, o);
+    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, blockIdx.x % kL1Replicas, kL1Replicas, o);   // region = bucket * 32 + replica
 }
 
 template <int THREADS, int SLOTS>
@@ -239,15 +241,15 @@ __global__ __launch_bounds__(THREADS) void eref_bin2_kernel(const unsigned int *
 {
     __shared__ uint32_t stage[kL1Buckets * SLOTS];
     __shared__ unsigned int cnt[kL1Buckets], gbase[kL1Buckets];
-    const uint32_t b1 = blockIdx.y;
-    const uint32_t n1 = min(cursor1[b1], cap1);
+    const uint32_t region = blockIdx.y, b1 = region / kL1Replicas;
+    const uint32_t n1 = min(cursor1[region], cap1);
     constexpr uint32_t kTileKeys = THREADS * kKeysPerThread;
     const uint32_t start = blockIdx.x * kTileKeys;
     if (start >= n1) return;                               // uniform for the workgroup
     const uint32_t end = min(n1, start + kTileKeys);
     if (threadIdx.x < kL1Buckets) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t *src = buf1 + static_cast<size_t>(b1) * cap1;
+    const uint32_t *src = buf1 + static_cast<size_t>(region) * cap1;
     for (uint32_t i = start + threadIdx.x; i < end; i += THREADS) {
         const uint32_t k = src[i];
         const uint32_t b = (k >> kBucketShift) & (kL1Buckets - 1);
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin2_kernel(const unsigned int *
         if (pos < SLOTS) stage[b * SLOTS + pos] = k;
         else count_key(k, o.p1, o.p2, o.p3);
     }
-    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, b1 * kL1Buckets, o);
+    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, b1 * kL1Buckets, 1u, o);
 }
 
 __global__ __launch_bounds__(1024) void eref_lds_count_kernel(const unsigned int *__restrict__ cursor,
@@ -648,13 +650,14 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     // capacities: 1.25 x the uniform expectation of the key upper bound, plus slack
     const int64_t max_keys = 3 * total_bases;
     int64_t cap2_64 = max_keys / kBuckets + max_keys / (4 * kBuckets) + 2048;
-    int64_t cap1_64 = max_keys / kL1Buckets + max_keys / (4 * kL1Buckets) + 4096;
-    if (ctx->bin_cap_override > 0) { cap2_64 = ctx->bin_cap_override; cap1_64 = ctx->bin_cap_override * kL1Buckets; }
+    constexpr int64_t kRegions = static_cast<int64_t>(kL1Buckets) * kL1Replicas;
+    int64_t cap1_64 = max_keys / kRegions + max_keys / (4 * kRegions) + 4096;      // per level-1 region
+    if (ctx->bin_cap_override > 0) { cap2_64 = ctx->bin_cap_override; cap1_64 = ctx->bin_cap_override * 4; }
     PALACE_REQUIRE(cap1_64 < (1ll << 31), "read set too large for one call; split it");
     const uint32_t cap1 = static_cast<uint32_t>(cap1_64), cap2 = static_cast<uint32_t>(cap2_64);
-    const size_t cur1_bytes = align_up(kL1Buckets * sizeof(unsigned int), 256);
+    const size_t cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
     const size_t cur2_bytes = align_up(kBuckets * sizeof(unsigned int), 256);
-    const size_t buf1_bytes = align_up(static_cast<size_t>(kL1Buckets) * cap1 * 4, 256);
+    const size_t buf1_bytes = align_up(static_cast<size_t>(kRegions) * cap1 * 4, 256);
     rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + buf1_bytes + static_cast<size_t>(kBuckets) * cap2 * 4);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
@@ -680,7 +683,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
                            ctx->stream, d_bases, d_offsets, n_reads, d_keep, ctx->masks, static_cast<int>(rpt), o1);
         PALACE_HIP_TRY(hipGetLastError());
         const unsigned tiles2 = static_cast<unsigned>((static_cast<int64_t>(cap1) + tile_keys - 1) / tile_keys);
-        hipLaunchKernelGGL((eref_bin2_kernel<THREADS, SLOTS>), dim3(tiles2, kL1Buckets), dim3(THREADS), 0, ctx->stream,
+        hipLaunchKernelGGL((eref_bin2_kernel<THREADS, SLOTS>), dim3(tiles2, static_cast<unsigned>(kRegions)), dim3(THREADS), 0, ctx->stream,
                            cursor1, buf1, cap1, o2);
         PALACE_HIP_TRY(hipGetLastError());
         return PALACE_OK;
