@@ -234,6 +234,64 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_kernel(const uint8_t *__res
     flush_rows<THREADS, SLOTS>(stage, cnt, gbase, blockIdx.x % kL1Replicas, kL1Replicas, o);   // region = bucket * 32 + replica
 }
 
+// Read ends as a bit per base position (bit p set <=> position p is the last base of a read), so
+// the flat kernel below needs no per-read offset lookups: a 32-mer starting at p is inside one read
+// iff no end bit lies in [p, p+30].
+__global__ void mark_read_ends_kernel(const int64_t *__restrict__ offsets, int64_t n_reads,
+                                      unsigned long long *__restrict__ ends)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const int64_t a = offsets[r] - offsets[0], b = offsets[r + 1] - offsets[0];
+    if (b > a) atomicOr(&ends[(b - 1) >> 6], 1ull << ((b - 1) & 63));
+}
+
+// bin1 without per-read work: the concatenated bases are one stream; a wave walks consecutive
+// 64-position chunks (one coalesced byte load per chunk, no dependent loads), windows that would
+// cross a read end are masked with the end bits.  Used when no keep mask is given.
+template <int THREADS, int SLOTS>
+__global__ __launch_bounds__(THREADS) void eref_bin1_flat_kernel(const uint8_t *__restrict__ all_bases,
+                                                                 const int64_t *__restrict__ offsets, int64_t total,
+                                                                 const unsigned long long *__restrict__ ends,
+                                                                 CoderMasks masks, int chunks_per_wave, BinOut o)
+{
+    __shared__ uint32_t stage[kL1Buckets * SLOTS];
+    __shared__ unsigned int cnt[kL1Buckets], gbase[kL1Buckets];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int n_waves = THREADS / 64;
+    if (threadIdx.x < kL1Buckets) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint8_t *bases = all_bases + offsets[0];      // the read set starts at its first offset
+    const int64_t n_chunks = (total + 63) >> 6;
+    const int64_t c0 = (static_cast<int64_t>(blockIdx.x) * n_waves + wave) * chunks_per_wave;
+    const int64_t c1 = min(n_chunks, c0 + chunks_per_wave);
+    if (c0 < c1) {
+        Streams lo = ballot_streams(bases, c0 * 64 + lane, total);
+        unsigned long long elo = ends[c0];
+        for (int64_t c = c0; c < c1; c++) {
+            Streams hi = ballot_streams(bases, (c + 1) * 64 + lane, total);
+            const unsigned long long ehi = (c + 1 < n_chunks) ? ends[c + 1] : 0ull;
+            const uint32_t ok = window32(lo.ok, hi.ok, lane);
+            const uint32_t cross = window32(elo, ehi, lane) & 0x7fffffffu;     // an end inside [p, p+30]
+            if (ok == 0xffffffffu && cross == 0u) {
+                uint32_t key[3];
+                kmer_keys(masks, window32(lo.p0, hi.p0, lane), window32(lo.p1, hi.p1, lane),
+                          window32(lo.p2, hi.p2, lane), key);
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const uint32_t b = key[i] >> kL1Shift;
+                    const unsigned int pos = atomicAdd(&cnt[b], 1u);
+                    if (pos < SLOTS) stage[b * SLOTS + pos] = key[i];
+                    else count_key(key[i], o.p1, o.p2, o.p3);
+                }
+            }
+            lo = hi;
+            elo = ehi;
+        }
+    }
+    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, blockIdx.x % kL1Replicas, kL1Replicas, o);
+}
+
 template <int THREADS, int SLOTS>
 __global__ __launch_bounds__(THREADS) void eref_bin2_kernel(const unsigned int *__restrict__ cursor1,
                                                                 const uint32_t *__restrict__ buf1, uint32_t cap1,
@@ -658,11 +716,13 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     const size_t cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
     const size_t cur2_bytes = align_up(kBuckets * sizeof(unsigned int), 256);
     const size_t buf1_bytes = align_up(static_cast<size_t>(kRegions) * cap1 * 4, 256);
-    rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + buf1_bytes + static_cast<size_t>(kBuckets) * cap2 * 4);
+    const size_t ends_bytes = align_up(static_cast<size_t>((total_bases + 63) / 64 + 2) * 8, 256);
+    rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + ends_bytes + buf1_bytes + static_cast<size_t>(kBuckets) * cap2 * 4);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
     unsigned int *cursor1 = reinterpret_cast<unsigned int *>(ws); ws += cur1_bytes;
     unsigned int *cursor2 = reinterpret_cast<unsigned int *>(ws); ws += cur2_bytes;
+    unsigned long long *ends = reinterpret_cast<unsigned long long *>(ws); ws += ends_bytes;
     uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
     uint32_t *buf2 = reinterpret_cast<uint32_t *>(ws);
     PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes, ctx->stream));
@@ -679,8 +739,25 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         rpt = std::min<int64_t>(rpt, 1 << 20);
         const int64_t tiles = (n_reads + rpt - 1) / rpt;
         PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
-        hipLaunchKernelGGL((eref_bin1_kernel<THREADS, SLOTS>), dim3(static_cast<unsigned>(tiles)), dim3(THREADS), 0,
-                           ctx->stream, d_bases, d_offsets, n_reads, d_keep, ctx->masks, static_cast<int>(rpt), o1);
+        if (d_keep) {
+            hipLaunchKernelGGL((eref_bin1_kernel<THREADS, SLOTS>), dim3(static_cast<unsigned>(tiles)), dim3(THREADS), 0,
+                               ctx->stream, d_bases, d_offsets, n_reads, d_keep, ctx->masks, static_cast<int>(rpt), o1);
+        } else {
+            // flat stream: end bits first, then tiles of (waves x chunks_per_wave) 64-position chunks sized so
+            // that a tile yields about tile_keys keys
+            const int64_t n_chunks = (total_bases + 63) / 64;
+            PALACE_HIP_TRY(hipMemsetAsync(ends, 0, static_cast<size_t>(n_chunks + 1) * 8, ctx->stream));
+            hipLaunchKernelGGL(mark_read_ends_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
+                               ctx->stream, d_offsets, n_reads, ends);
+            const double keys_per_pos = std::max(0.05, static_cast<double>(keys_per_read) /
+                                                           std::max<double>(1.0, static_cast<double>(total_bases) / n_reads));
+            int cpw = static_cast<int>(static_cast<double>(tile_keys) / (keys_per_pos * 64.0 * waves));
+            cpw = std::max(1, std::min(cpw, 4096));
+            const int64_t flat_tiles = (n_chunks + static_cast<int64_t>(waves) * cpw - 1) / (static_cast<int64_t>(waves) * cpw);
+            PALACE_REQUIRE(flat_tiles < (1ll << 31), "too many tiles for one launch");
+            hipLaunchKernelGGL((eref_bin1_flat_kernel<THREADS, SLOTS>), dim3(static_cast<unsigned>(flat_tiles)), dim3(THREADS),
+                               0, ctx->stream, d_bases, d_offsets, total_bases, ends, ctx->masks, cpw, o1);
+        }
         PALACE_HIP_TRY(hipGetLastError());
         const unsigned tiles2 = static_cast<unsigned>((static_cast<int64_t>(cap1) + tile_keys - 1) / tile_keys);
         hipLaunchKernelGGL((eref_bin2_kernel<THREADS, SLOTS>), dim3(tiles2, static_cast<unsigned>(kRegions)), dim3(THREADS), 0, ctx->stream,

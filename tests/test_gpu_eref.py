@@ -295,3 +295,34 @@ def test_binned_equals_direct_at_scale(ctx):
     assert res[0][0][2] > 0
     for b in (da, dao, dk):
         b.free()
+
+
+def test_binned_flat_stream_with_offset_base_and_ragged_reads(ctx):
+    """flat streaming bin kernel: read set that does not start at offset 0, reads of every length
+    class (0, <32, ==32, long), N inside reads, read ends adjacent to chunk boundaries"""
+    rng = synth.rng_for(23)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    cc = orc.header_to_cc(hdr)
+    pool = synth.random_dna(rng, 400000)
+    lens = [0, 1, 31, 32, 33, 63, 64, 65, 95, 96, 127, 128, 129, 150, 150, 1000, 0, 40] * 200
+    reads, p = [], 0
+    for L in lens:
+        r = pool[p:p + L].copy(); p = (p + L + 7) % 300000
+        if L > 50 and rng.random() < 0.1:
+            r[int(rng.integers(0, L))] = ord("N")
+        reads.append(r)
+    rs = synth.reads_from_list(reads)
+    junk = synth.random_dna(rng, 777)
+    bases = np.concatenate([junk, rs.bases])
+    offsets = rs.offsets + 777
+    try:
+        ctx.eref_set_count_mode(2, 0)
+        ctx.eref_set_coder(hdr)
+        ctx.eref_table_reset()
+        db, do = ctx.upload(bases), ctx.upload(offsets)
+        ctx.eref_count_reads(db, do, rs.n, None, int(offsets[-1] - offsets[0]))
+        ctx.sync()
+    finally:
+        ctx.eref_set_count_mode(0, 0)
+    u, c = oracle_key_counts(rs.bases, rs.offsets, cc)
+    assert_table_equals(ctx, u, c)
