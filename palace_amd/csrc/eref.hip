@@ -147,7 +147,6 @@ constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 per plane per 
 constexpr int kL1Buckets = 128, kL1Shift = 25;        // level 1: key >> 25
 constexpr int kL1Replicas = 32;                        // level-1 bucket regions are split 32 ways so that the
                                                       // per-tile reservations do not pile onto 128 addresses
-constexpr int kFlatMaxChunks = 12;                    // 64-position chunks one wave walks in the flat bin1 kernel
 constexpr int kKeysPerThread = 22;                    // tile = THREADS * 22 keys: staging rows fill to ~70 %
 
 template <class F>
@@ -267,23 +266,10 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_flat_kernel(const uint8_t *
     const int64_t c0 = (static_cast<int64_t>(blockIdx.x) * n_waves + wave) * chunks_per_wave;
     const int64_t c1 = min(n_chunks, c0 + chunks_per_wave);
     if (c0 < c1) {
-        // all byte loads of this wave's chunk range are issued before the first use (kFlatMaxChunks + 1
-        // loads in flight per lane instead of one): the kernel is latency-bound otherwise
-        uint32_t ch[kFlatMaxChunks + 1];
-#pragma unroll
-        for (int q = 0; q <= kFlatMaxChunks; q++) {
-            const int64_t idx = (c0 + q) * 64 + lane;
-            ch[q] = (q <= c1 - c0 && idx < total) ? bases[idx] : 0u;
-        }
+        Streams lo = ballot_streams(bases, c0 * 64 + lane, total);
         unsigned long long elo = ends[c0];
-        BaseBits b0 = classify(ch[0]);
-        Streams lo{__ballot(b0.p0), __ballot(b0.p1), __ballot(b0.p2), __ballot(b0.ok)};
-#pragma unroll
-        for (int q = 0; q < kFlatMaxChunks; q++) {
-            const int64_t c = c0 + q;
-            if (c >= c1) break;                                  // wave-uniform
-            BaseBits bn = classify(ch[q + 1]);
-            Streams hi{__ballot(bn.p0), __ballot(bn.p1), __ballot(bn.p2), __ballot(bn.ok)};
+        for (int64_t c = c0; c < c1; c++) {
+            Streams hi = ballot_streams(bases, (c + 1) * 64 + lane, total);
             const unsigned long long ehi = (c + 1 < n_chunks) ? ends[c + 1] : 0ull;
             const uint32_t ok = window32(lo.ok, hi.ok, lane);
             const uint32_t cross = window32(elo, ehi, lane) & 0x7fffffffu;     // an end inside [p, p+30]
@@ -766,7 +752,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
             const double keys_per_pos = std::max(0.05, static_cast<double>(keys_per_read) /
                                                            std::max<double>(1.0, static_cast<double>(total_bases) / n_reads));
             int cpw = static_cast<int>(static_cast<double>(tile_keys) / (keys_per_pos * 64.0 * waves));
-            cpw = std::max(1, std::min(cpw, kFlatMaxChunks));
+            cpw = std::max(1, std::min(cpw, 4096));
             const int64_t flat_tiles = (n_chunks + static_cast<int64_t>(waves) * cpw - 1) / (static_cast<int64_t>(waves) * cpw);
             PALACE_REQUIRE(flat_tiles < (1ll << 31), "too many tiles for one launch");
             hipLaunchKernelGGL((eref_bin1_flat_kernel<THREADS, SLOTS>), dim3(static_cast<unsigned>(flat_tiles)), dim3(THREADS),
