@@ -186,30 +186,22 @@ struct BinOut {
 // stage -> reserve -> copy out; `bucket0` is the first destination bucket of this workgroup's 128
 template <int THREADS, int SLOTS>
 __device__ __forceinline__ void flush_rows(uint32_t *stage, unsigned int *cnt, unsigned int *gbase,
-                                           uint32_t bucket0, uint32_t stride, uint32_t dest_shift, const BinOut &o)
+                                           uint32_t bucket0, uint32_t stride, const BinOut &o)
 {
-    // Runs are reserved and written in whole 128-byte lines (32 keys): a run that starts or ends inside
-    // a line shares it with another workgroup's run, usually on another XCD, and such half-written
-    // lines cost a read-modify-write at the memory side.  The tail of the last line is padded with a
-    // key of a DIFFERENT destination bucket, which the consumer recognises and skips.
     __syncthreads();
     if (threadIdx.x < kL1Buckets) {
         const unsigned int c = min(cnt[threadIdx.x], static_cast<unsigned int>(SLOTS));
         cnt[threadIdx.x] = c;
-        gbase[threadIdx.x] = c ? atomicAdd(&o.cursor[bucket0 + threadIdx.x * stride], (c + 31u) & ~31u) : 0u;
+        gbase[threadIdx.x] = c ? atomicAdd(&o.cursor[bucket0 + threadIdx.x * stride], c) : 0u;
     }
     __syncthreads();
     for (int sidx = threadIdx.x; sidx < kL1Buckets * SLOTS; sidx += THREADS) {
         const int b = sidx / SLOTS, p = sidx % SLOTS;
-        const unsigned int c = cnt[b];
-        if (p < static_cast<int>((c + 31u) & ~31u)) {
-            const bool real = p < static_cast<int>(c);
-            const uint32_t dest = bucket0 + b * stride;
-            const uint32_t own = (stride == 1u) ? dest : static_cast<uint32_t>(b);     // bucket id the consumer checks
-            const uint32_t k = real ? stage[sidx] : ((own ^ 1u) << dest_shift);
+        if (p < static_cast<int>(cnt[b])) {
+            const uint32_t k = stage[sidx];
             const unsigned int g = gbase[b] + p;
-            if (g < o.cap) o.buf[static_cast<size_t>(dest) * o.cap + g] = k;
-            else if (real) count_key(k, o.p1, o.p2, o.p3);  // bucket region full: exact slow path
+            if (g < o.cap) o.buf[static_cast<size_t>(bucket0 + b * stride) * o.cap + g] = k;
+            else count_key(k, o.p1, o.p2, o.p3);           // bucket region full: exact slow path
         }
     }
 }
@@ -239,7 +231,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_kernel(const uint8_t *__res
             else count_key(k, o.p1, o.p2, o.p3);           // row full: exact slow path
         });
     }
-    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, blockIdx.x % kL1Replicas, kL1Replicas, kL1Shift, o);   // region = bucket * 32 + replica
+    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, blockIdx.x % kL1Replicas, kL1Replicas, o);   // region = bucket * 32 + replica
 }
 
 // Read ends as a bit per base position (bit p set <=> position p is the last base of a read), so
@@ -297,7 +289,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_flat_kernel(const uint8_t *
             elo = ehi;
         }
     }
-    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, blockIdx.x % kL1Replicas, kL1Replicas, kL1Shift, o);
+    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, blockIdx.x % kL1Replicas, kL1Replicas, o);
 }
 
 template <int THREADS, int SLOTS>
@@ -318,13 +310,12 @@ __global__ __launch_bounds__(THREADS) void eref_bin2_kernel(const unsigned int *
     const uint32_t *src = buf1 + static_cast<size_t>(region) * cap1;
     for (uint32_t i = start + threadIdx.x; i < end; i += THREADS) {
         const uint32_t k = src[i];
-        if ((k >> kL1Shift) != b1) continue;               // line padding written by bin1
         const uint32_t b = (k >> kBucketShift) & (kL1Buckets - 1);
         const unsigned int pos = atomicAdd(&cnt[b], 1u);
         if (pos < SLOTS) stage[b * SLOTS + pos] = k;
         else count_key(k, o.p1, o.p2, o.p3);
     }
-    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, b1 * kL1Buckets, 1u, kBucketShift, o);
+    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, b1 * kL1Buckets, 1u, o);
 }
 
 __global__ __launch_bounds__(1024) void eref_lds_count_kernel(const unsigned int *__restrict__ cursor,
@@ -349,7 +340,6 @@ __global__ __launch_bounds__(1024) void eref_lds_count_kernel(const unsigned int
     const uint32_t *keys = binned + static_cast<size_t>(b) * cap;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         const uint32_t k = keys[i];
-        if ((k >> kBucketShift) != b) continue;            // line padding written by bin2
         const uint32_t w = (k & ((1u << kBucketShift) - 1)) >> 5, bit = 1u << (k & 31);
         if (atomicOr(&l1[w], bit) & bit)
             if (atomicOr(&l2[w], bit) & bit) atomicOr(&l3[w], bit);
@@ -722,7 +712,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     int64_t cap1_64 = max_keys / kRegions + max_keys / (4 * kRegions) + 4096;      // per level-1 region
     if (ctx->bin_cap_override > 0) { cap2_64 = ctx->bin_cap_override; cap1_64 = ctx->bin_cap_override * 4; }
     PALACE_REQUIRE(cap1_64 < (1ll << 31), "read set too large for one call; split it");
-    const uint32_t cap1 = static_cast<uint32_t>((cap1_64 + 31) & ~31ll), cap2 = static_cast<uint32_t>((cap2_64 + 31) & ~31ll);
+    const uint32_t cap1 = static_cast<uint32_t>(cap1_64), cap2 = static_cast<uint32_t>(cap2_64);
     const size_t cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
     const size_t cur2_bytes = align_up(kBuckets * sizeof(unsigned int), 256);
     const size_t buf1_bytes = align_up(static_cast<size_t>(kRegions) * cap1 * 4, 256);
