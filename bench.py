@@ -361,7 +361,9 @@ def main():
     ctx = capi.Ctx(local)                      # eref stream
     ctx_g = capi.Ctx(local, high_priority=True)   # generateGraph + matching stream (independent of eref until the end)
     ctx.eref_set_coder(hdr)
-    if args.bin_variant:
+    if args.bin_variant >= 20:
+        ctx.eref_set_count_mode(args.bin_variant)
+    elif args.bin_variant:
         ctx.eref_set_count_mode(10 + args.bin_variant)
     sample = make_sample(torch, dev, args.contigs, args.refs, rank, world)
     gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world)

@@ -147,7 +147,6 @@ constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 per plane per 
 constexpr int kL1Buckets = 128, kL1Shift = 25;        // level 1: key >> 25
 constexpr int kL1Replicas = 32;                        // level-1 bucket regions are split 32 ways so that the
                                                       // per-tile reservations do not pile onto 128 addresses
-constexpr int kKeysPerThread = 22;                    // tile = THREADS * 22 keys: staging rows fill to ~70 %
 
 template <class F>
 __device__ __forceinline__ void for_each_key(const uint8_t *__restrict__ s, int64_t len, int lane,
@@ -174,6 +173,8 @@ __device__ __forceinline__ void for_each_key(const uint8_t *__restrict__ s, int6
 template <int T, int S>
 struct BinVariant {
     static constexpr int threads = T, slots = S;
+    // tile = about 70 % of the staging capacity (128 rows x S slots)
+    static constexpr int keys_per_thread = (kL1Buckets * S * 7 / 10) / T;
 };
 
 struct BinOut {
@@ -181,6 +182,7 @@ struct BinOut {
     uint32_t *buf;                 // bucket b owns buf[b * cap .. b * cap + cap)
     uint32_t cap;
     uint32_t *p1, *p2, *p3;        // overflow path
+    int dbg;                       // timing experiments only: 1 skip stores, 2 skip reservations, 4 skip staging
 };
 
 // stage -> reserve -> copy out; `bucket0` is the first destination bucket of this workgroup's 128
@@ -192,7 +194,7 @@ __device__ __forceinline__ void flush_rows(uint32_t *stage, unsigned int *cnt, u
     if (threadIdx.x < kL1Buckets) {
         const unsigned int c = min(cnt[threadIdx.x], static_cast<unsigned int>(SLOTS));
         cnt[threadIdx.x] = c;
-        gbase[threadIdx.x] = c ? atomicAdd(&o.cursor[bucket0 + threadIdx.x * stride], c) : 0u;
+        gbase[threadIdx.x] = (c && !(o.dbg & 2)) ? atomicAdd(&o.cursor[bucket0 + threadIdx.x * stride], c) : (blockIdx.x % 1024u) * SLOTS;
     }
     __syncthreads();
     for (int sidx = threadIdx.x; sidx < kL1Buckets * SLOTS; sidx += THREADS) {
@@ -200,6 +202,7 @@ __device__ __forceinline__ void flush_rows(uint32_t *stage, unsigned int *cnt, u
         if (p < static_cast<int>(cnt[b])) {
             const uint32_t k = stage[sidx];
             const unsigned int g = gbase[b] + p;
+            if (o.dbg & 1) continue;
             if (g < o.cap) o.buf[static_cast<size_t>(bucket0 + b * stride) * o.cap + g] = k;
             else count_key(k, o.p1, o.p2, o.p3);           // bucket region full: exact slow path
         }
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_flat_kernel(const uint8_t *
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
                     const uint32_t b = key[i] >> kL1Shift;
+                    if (o.dbg & 4) { if (key[i] == 0x12345u) cnt[b] = 1; continue; }
                     const unsigned int pos = atomicAdd(&cnt[b], 1u);
                     if (pos < SLOTS) stage[b * SLOTS + pos] = key[i];
                     else count_key(key[i], o.p1, o.p2, o.p3);
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin2_kernel(const unsigned int *
     __shared__ unsigned int cnt[kL1Buckets], gbase[kL1Buckets];
     const uint32_t region = blockIdx.y, b1 = region / kL1Replicas;
     const uint32_t n1 = min(cursor1[region], cap1);
-    constexpr uint32_t kTileKeys = THREADS * kKeysPerThread;
+    constexpr uint32_t kTileKeys = BinVariant<THREADS, SLOTS>::keys_per_thread * THREADS;
     const uint32_t start = blockIdx.x * kTileKeys;
     if (start >= n1) return;                               // uniform for the workgroup
     const uint32_t end = min(n1, start + kTileKeys);
@@ -410,6 +414,30 @@ __device__ __forceinline__ int64_t find_seq(const int64_t *__restrict__ pre, int
 }
 
 // ------------------------------------------------------------------------------------------
+// Plane 3 is sparse (only k-mers seen >= 3 times), and Phase B probes it 3 times per reference
+// position at random: 6e8 probes of a 512 MiB table are HBM sector reads.  Folding the plane 8:1 by
+// OR (64 MiB, resident in the Infinity Cache) gives an exact pre-filter: a clear filter bit proves
+// the plane bit clear; only probes that pass go on to the full plane.
+// ------------------------------------------------------------------------------------------
+constexpr int kFoldLog2 = 3;
+constexpr size_t kFoldWords = kPlaneWords >> kFoldLog2;           // u32 words of the folded plane
+
+__global__ __launch_bounds__(256) void fold_plane_kernel(const uint4 *__restrict__ plane, uint4 *__restrict__ folded)
+{
+    const size_t n16 = kFoldWords / 4;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        uint4 acc = plane[i];
+#pragma unroll
+        for (int sl = 1; sl < (1 << kFoldLog2); sl++) {
+            const uint4 v = plane[i + sl * n16];
+            acc.x |= v.x; acc.y |= v.y; acc.z |= v.z; acc.w |= v.w;
+        }
+        folded[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // E5: per-position hit bits of every ref (lookup in plane 3)
 // MODE 0: write any/all hit words;  MODE 1: write the three indices (E2 index build)
 // ------------------------------------------------------------------------------------------
@@ -421,6 +449,7 @@ __global__ __launch_bounds__(256) void eref_ref_kernel(const uint8_t *__restrict
                                                        const int64_t *__restrict__ word_pre,
                                                        CoderMasks masks,
                                                        const uint32_t *__restrict__ p3,
+                                                       const uint32_t *__restrict__ p3_folded,
                                                        uint64_t *__restrict__ any_words,
                                                        uint64_t *__restrict__ all_words,
                                                        uint32_t *__restrict__ idx_out,
@@ -451,8 +480,11 @@ __global__ __launch_bounds__(256) void eref_ref_kernel(const uint8_t *__restrict
         if (MODE == 0) {
             int h = 0;
 #pragma unroll
-            for (int i = 0; i < 3; i++)           // index 0 means "none" (extract_ref.cpp:861)
-                if (valid && key[i] != 0) h += (p3[key[i] >> 5] >> (key[i] & 31)) & 1u;
+            for (int i = 0; i < 3; i++) {         // index 0 means "none" (extract_ref.cpp:861)
+                if (!(valid && key[i] != 0)) continue;
+                const uint32_t fk = key[i] & ((1u << (32 - kFoldLog2)) - 1);
+                if ((p3_folded[fk >> 5] >> (fk & 31)) & 1u) h += (p3[key[i] >> 5] >> (key[i] & 31)) & 1u;
+            }
             uint64_t any = __ballot(h > 0), all = __ballot(h == 3);
             if (lane == 0) {
                 any_words[word_pre[r] + c] = any;
@@ -726,11 +758,11 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
     uint32_t *buf2 = reinterpret_cast<uint32_t *>(ws);
     PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes, ctx->stream));
-    BinOut o1{cursor1, buf1, cap1, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
-    BinOut o2{cursor2, buf2, cap2, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
+    BinOut o1{cursor1, buf1, cap1, ctx->plane[0], ctx->plane[1], ctx->plane[2], ctx->bin_dbg};
+    BinOut o2{cursor2, buf2, cap2, ctx->plane[0], ctx->plane[1], ctx->plane[2], 0};
     auto launch_bins = [&](auto variant) -> int {
         constexpr int THREADS = decltype(variant)::threads, SLOTS = decltype(variant)::slots;
-        constexpr int64_t tile_keys = static_cast<int64_t>(THREADS) * kKeysPerThread;
+        constexpr int64_t tile_keys = static_cast<int64_t>(THREADS) * decltype(variant)::keys_per_thread;
         // reads per tile so that a tile holds about tile_keys keys; whole waves' worth when possible
         const int64_t keys_per_read = std::max<int64_t>(1, 3 * (total_bases / n_reads - 31));
         int64_t rpt = std::max<int64_t>(1, tile_keys / keys_per_read);
@@ -765,10 +797,10 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         PALACE_HIP_TRY(hipGetLastError());
         return PALACE_OK;
     };
-    switch (ctx->bin_variant) {
+    switch (ctx->bin_variant) {                 // measured at the 1M-contig size: 512x64 (4 workgroups per CU) fastest
     case 1: rc = launch_bins(BinVariant<1024, 256>{}); break;
-    case 2: rc = launch_bins(BinVariant<256, 64>{}); break;
-    default: rc = launch_bins(BinVariant<512, 128>{}); break;
+    case 2: rc = launch_bins(BinVariant<512, 128>{}); break;
+    default: rc = launch_bins(BinVariant<512, 64>{}); break;
     }
     if (rc) return rc;
     hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, cursor2, buf2, cap2,
@@ -782,6 +814,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap)
 {
     if (ctx && mode >= 10 && mode <= 12) { ctx->bin_variant = mode - 10; return PALACE_OK; }   // tuning: tile shape
+    if (ctx && mode >= 20 && mode < 28) { ctx->bin_dbg = mode - 20; return PALACE_OK; }          // timing experiments (wrong results)
     PALACE_REQUIRE(ctx && mode >= 0 && mode <= 2 && bucket_cap >= 0 && bucket_cap < (1ll << 31), "bad argument");
     ctx->count_mode = mode;
     ctx->bin_cap_override = bucket_cap;
@@ -820,7 +853,8 @@ int palace_eref_index_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_
     PALACE_REQUIRE(max_tiles < (1ll << 31), "too many tiles for one launch");
     hipLaunchKernelGGL(eref_ref_kernel<1>, dim3(static_cast<unsigned>(max_tiles)), dim3(256), 0, ctx->stream,
                        d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks,
-                       static_cast<const uint32_t *>(nullptr), static_cast<uint64_t *>(nullptr),
+                       static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr),
+                       static_cast<uint64_t *>(nullptr),
                        static_cast<uint64_t *>(nullptr), d_out, d_out_offsets);
     PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
@@ -843,9 +877,11 @@ int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t
     PALACE_REQUIRE(max_tiles < (1ll << 31), "too many tiles for one launch");
     const size_t pre_bytes = align_up((n_refs + 1) * 8, 256);
     const size_t w64 = align_up(max_words * 8, 256), w32 = align_up(max_words * 4, 256);
-    rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32);
+    const size_t fold_bytes = kFoldWords * 4;
+    rc = ensure_workspace(ctx, fold_bytes + 2 * pre_bytes + 3 * w64 + 2 * w32);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
+    uint32_t *folded = reinterpret_cast<uint32_t *>(ws); ws += fold_bytes;
     int64_t *tile_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
     int64_t *word_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
     uint64_t *any_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
@@ -855,8 +891,11 @@ int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t
     uint32_t *all_p = reinterpret_cast<uint32_t *>(ws);
     rc = launch_prefix(ctx, d_offsets, n_refs, tile_pre, word_pre);
     if (rc) return rc;
+    hipLaunchKernelGGL(fold_plane_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const uint4 *>(ctx->plane[2]), reinterpret_cast<uint4 *>(folded));
+    PALACE_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(eref_ref_kernel<0>, dim3(static_cast<unsigned>(max_tiles)), dim3(256), 0, ctx->stream,
-                       d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks, ctx->plane[2], any_w,
+                       d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks, ctx->plane[2], folded, any_w,
                        all_w, static_cast<uint32_t *>(nullptr), static_cast<const int64_t *>(nullptr));
     PALACE_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(eref_window_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(256), 0, ctx->stream,
