@@ -414,30 +414,6 @@ __device__ __forceinline__ int64_t find_seq(const int64_t *__restrict__ pre, int
 }
 
 // ------------------------------------------------------------------------------------------
-// Plane 3 is sparse (only k-mers seen >= 3 times), and Phase B probes it 3 times per reference
-// position at random: 6e8 probes of a 512 MiB table are HBM sector reads.  Folding the plane 8:1 by
-// OR (64 MiB, resident in the Infinity Cache) gives an exact pre-filter: a clear filter bit proves
-// the plane bit clear; only probes that pass go on to the full plane.
-// ------------------------------------------------------------------------------------------
-constexpr int kFoldLog2 = 3;
-constexpr size_t kFoldWords = kPlaneWords >> kFoldLog2;           // u32 words of the folded plane
-
-__global__ __launch_bounds__(256) void fold_plane_kernel(const uint4 *__restrict__ plane, uint4 *__restrict__ folded)
-{
-    const size_t n16 = kFoldWords / 4;
-    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16;
-         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
-        uint4 acc = plane[i];
-#pragma unroll
-        for (int sl = 1; sl < (1 << kFoldLog2); sl++) {
-            const uint4 v = plane[i + sl * n16];
-            acc.x |= v.x; acc.y |= v.y; acc.z |= v.z; acc.w |= v.w;
-        }
-        folded[i] = acc;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // E5: per-position hit bits of every ref (lookup in plane 3)
 // MODE 0: write any/all hit words;  MODE 1: write the three indices (E2 index build)
 // ------------------------------------------------------------------------------------------
@@ -449,7 +425,6 @@ __global__ __launch_bounds__(256) void eref_ref_kernel(const uint8_t *__restrict
                                                        const int64_t *__restrict__ word_pre,
                                                        CoderMasks masks,
                                                        const uint32_t *__restrict__ p3,
-                                                       const uint32_t *__restrict__ p3_folded,
                                                        uint64_t *__restrict__ any_words,
                                                        uint64_t *__restrict__ all_words,
                                                        uint32_t *__restrict__ idx_out,
@@ -480,11 +455,8 @@ __global__ __launch_bounds__(256) void eref_ref_kernel(const uint8_t *__restrict
         if (MODE == 0) {
             int h = 0;
 #pragma unroll
-            for (int i = 0; i < 3; i++) {         // index 0 means "none" (extract_ref.cpp:861)
-                if (!(valid && key[i] != 0)) continue;
-                const uint32_t fk = key[i] & ((1u << (32 - kFoldLog2)) - 1);
-                if ((p3_folded[fk >> 5] >> (fk & 31)) & 1u) h += (p3[key[i] >> 5] >> (key[i] & 31)) & 1u;
-            }
+            for (int i = 0; i < 3; i++)           // index 0 means "none" (extract_ref.cpp:861)
+                if (valid && key[i] != 0) h += (p3[key[i] >> 5] >> (key[i] & 31)) & 1u;
             uint64_t any = __ballot(h > 0), all = __ballot(h == 3);
             if (lane == 0) {
                 any_words[word_pre[r] + c] = any;
@@ -853,8 +825,7 @@ int palace_eref_index_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_
     PALACE_REQUIRE(max_tiles < (1ll << 31), "too many tiles for one launch");
     hipLaunchKernelGGL(eref_ref_kernel<1>, dim3(static_cast<unsigned>(max_tiles)), dim3(256), 0, ctx->stream,
                        d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks,
-                       static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr),
-                       static_cast<uint64_t *>(nullptr),
+                       static_cast<const uint32_t *>(nullptr), static_cast<uint64_t *>(nullptr),
                        static_cast<uint64_t *>(nullptr), d_out, d_out_offsets);
     PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
@@ -877,11 +848,9 @@ int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t
     PALACE_REQUIRE(max_tiles < (1ll << 31), "too many tiles for one launch");
     const size_t pre_bytes = align_up((n_refs + 1) * 8, 256);
     const size_t w64 = align_up(max_words * 8, 256), w32 = align_up(max_words * 4, 256);
-    const size_t fold_bytes = kFoldWords * 4;
-    rc = ensure_workspace(ctx, fold_bytes + 2 * pre_bytes + 3 * w64 + 2 * w32);
+    rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
-    uint32_t *folded = reinterpret_cast<uint32_t *>(ws); ws += fold_bytes;
     int64_t *tile_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
     int64_t *word_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
     uint64_t *any_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
@@ -891,11 +860,8 @@ int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t
     uint32_t *all_p = reinterpret_cast<uint32_t *>(ws);
     rc = launch_prefix(ctx, d_offsets, n_refs, tile_pre, word_pre);
     if (rc) return rc;
-    hipLaunchKernelGGL(fold_plane_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<const uint4 *>(ctx->plane[2]), reinterpret_cast<uint4 *>(folded));
-    PALACE_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(eref_ref_kernel<0>, dim3(static_cast<unsigned>(max_tiles)), dim3(256), 0, ctx->stream,
-                       d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks, ctx->plane[2], folded, any_w,
+                       d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks, ctx->plane[2], any_w,
                        all_w, static_cast<uint32_t *>(nullptr), static_cast<const int64_t *>(nullptr));
     PALACE_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(eref_window_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(256), 0, ctx->stream,
