@@ -414,18 +414,23 @@ def main():
         capi._check(L.palace_eref_count_reads(ctx.h, P(sample["r1"]), P(sample["read_off"]), n_side, None, tot_b), "count")
         capi._check(L.palace_eref_count_reads(ctx.h, P(sample["r2"]), P(sample["read_off"]), n_side, None, tot_b), "count")
         if timed: ctx.mark(m + 1)
-        if exch:
-            ctx.sync()
-            exch.merge_planes(planes, merge_fn)
-            torch.cuda.synchronize()
-        if timed: ctx.mark(m + 2)
-        capi._check(L.palace_eref_scan_refs(ctx.h, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
-                                            sample["ref_total"], one_min, three_min, P(rows) + 16 * r_lo), "scan")
-        if timed: ctx.mark(m + 3)
-        if exch:
-            ctx.sync()
-            exch.gather_ranges(rows, ref_ranges)
-            torch.cuda.synchronize()
+
+        def eref_tail():
+            if exch:                                   # count-table exchange (RCCL), then Phase B on this rank's refs
+                ctx.sync()
+                exch.merge_planes(planes, merge_fn)
+                torch.cuda.synchronize()
+            if timed: ctx.mark(m + 2)
+            capi._check(L.palace_eref_scan_refs(ctx.h, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
+                                                sample["ref_total"], one_min, three_min, P(rows) + 16 * r_lo), "scan")
+            if timed: ctx.mark(m + 3)
+            if exch:
+                ctx.sync()
+                exch.gather_ranges(rows, ref_ranges)
+                torch.cuda.synchronize()
+
+        if not exch:
+            eref_tail()                                # one GPU: queue Phase B right behind the counting kernels
         # ---------------- generateGraph (second stream; overlaps the eref kernels) ----------------
         g = ctx_g
         if timed: g.mark(m)
@@ -474,6 +479,8 @@ def main():
             last.update(n_comp=len(kind), n_cycles=int(kind.sum()), n_multi=int(((off[1:] - off[:-1]) > 1).sum()))
         last.update(graph=(copies, src, dst, w), n_edges=int(n_e.value), n_cands=int(n_cands), n_arcs=len(src))
         # ---------------- join: eref results to the host ----------------
+        if exch:
+            eref_tail()                                # N GPUs: the exchange waits for the counts; graph + matching ran meanwhile
         capi._check(L.palace_d2h(ctx.h, rows_host.data_ptr(), P(rows), rows.numel() * 4), "d2h")
 
     def barrier():
