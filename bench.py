@@ -338,6 +338,11 @@ def cpu_baseline(torch, sample, gs, header, n_reads, n_records, graph_out):
 
 def main():
     args = parse_args()
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 when a process group
+    # initialises, so everything written to fd 1 before the final line is routed to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -539,7 +544,8 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, sample, gs, hdr, args.cpu_sample_reads, args.cpu_sample_records,
                                                last["graph"])
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     ctx_g.close()
     if dist is not None:
