@@ -442,6 +442,49 @@ __global__ __launch_bounds__(256) void eref_ref_kernel(const uint8_t *__restrict
     if (c0 >= n_chunks) return;
     const int64_t c1 = min(n_chunks, c0 + per_wave);
     const uint8_t *s = bases + beg;
+    if (MODE == 0) {
+        // Latency-bound by construction (three dependent random probes per position), so the wave keeps
+        // everything in flight at once: all 9 byte loads of its 8 chunks first, then the 24 probes of all
+        // chunks, and only then the first use of a probe result.
+        uint32_t ch[per_wave + 1];
+#pragma unroll
+        for (int q = 0; q <= per_wave; q++) {
+            const int64_t idx = (c0 + q) * 64 + lane;
+            ch[q] = (idx < len) ? s[idx] : 0u;
+        }
+        uint32_t word[per_wave][3], sh[per_wave];
+        BaseBits b0 = classify(ch[0]);
+        Streams lo{__ballot(b0.p0), __ballot(b0.p1), __ballot(b0.p2), __ballot(b0.ok)};
+#pragma unroll
+        for (int q = 0; q < per_wave; q++) {
+            BaseBits bn = classify(ch[q + 1]);
+            Streams hi{__ballot(bn.p0), __ballot(bn.p1), __ballot(bn.p2), __ballot(bn.ok)};
+            const int64_t j = (c0 + q) * 64 + lane;
+            const uint32_t ok = window32(lo.ok, hi.ok, lane);
+            const bool valid = (c0 + q < c1) && (j < npos) && ok == 0xffffffffu;
+            uint32_t key[3] = {0, 0, 0};
+            if (valid)
+                kmer_keys(masks, window32(lo.p0, hi.p0, lane), window32(lo.p1, hi.p1, lane),
+                          window32(lo.p2, hi.p2, lane), key);
+            sh[q] = (key[0] & 31) | ((key[1] & 31) << 8) | ((key[2] & 31) << 16);
+#pragma unroll
+            for (int i = 0; i < 3; i++)           // index 0 means "none" (extract_ref.cpp:861): probe word 0 bit 0 ...
+                word[q][i] = (valid && key[i] != 0) ? p3[key[i] >> 5] : 0u;     // ... is never counted: word forced to 0
+            lo = hi;
+        }
+#pragma unroll
+        for (int q = 0; q < per_wave; q++) {
+            if (c0 + q >= c1) break;                                   // wave-uniform
+            const int h = ((word[q][0] >> (sh[q] & 31)) & 1u) + ((word[q][1] >> ((sh[q] >> 8) & 31)) & 1u) +
+                          ((word[q][2] >> ((sh[q] >> 16) & 31)) & 1u);
+            const uint64_t any = __ballot(h > 0), all = __ballot(h == 3);
+            if (lane == 0) {
+                any_words[word_pre[r] + c0 + q] = any;
+                all_words[word_pre[r] + c0 + q] = all;
+            }
+        }
+        return;
+    }
     Streams lo = ballot_streams(s, c0 * 64 + lane, len);
     for (int64_t c = c0; c < c1; c++) {
         Streams hi = ballot_streams(s, (c + 1) * 64 + lane, len);
@@ -452,21 +495,9 @@ __global__ __launch_bounds__(256) void eref_ref_kernel(const uint8_t *__restrict
         if (valid)
             kmer_keys(masks, window32(lo.p0, hi.p0, lane), window32(lo.p1, hi.p1, lane),
                       window32(lo.p2, hi.p2, lane), key);
-        if (MODE == 0) {
-            int h = 0;
-#pragma unroll
-            for (int i = 0; i < 3; i++)           // index 0 means "none" (extract_ref.cpp:861)
-                if (valid && key[i] != 0) h += (p3[key[i] >> 5] >> (key[i] & 31)) & 1u;
-            uint64_t any = __ballot(h > 0), all = __ballot(h == 3);
-            if (lane == 0) {
-                any_words[word_pre[r] + c] = any;
-                all_words[word_pre[r] + c] = all;
-            }
-        } else {
-            if (j < npos) {
-                uint32_t *o = idx_out + idx_offsets[r] + 3 * j;
-                o[0] = key[0]; o[1] = key[1]; o[2] = key[2];
-            }
+        if (j < npos) {
+            uint32_t *o = idx_out + idx_offsets[r] + 3 * j;
+            o[0] = key[0]; o[1] = key[1]; o[2] = key[2];
         }
         lo = hi;
     }
