@@ -428,7 +428,8 @@ __global__ __launch_bounds__(256) void eref_ref_kernel(const uint8_t *__restrict
                                                        uint64_t *__restrict__ any_words,
                                                        uint64_t *__restrict__ all_words,
                                                        uint32_t *__restrict__ idx_out,
-                                                       const int64_t *__restrict__ idx_offsets)
+                                                       const int64_t *__restrict__ idx_offsets,
+                                                       const uint8_t *__restrict__ need)
 {
     const int64_t tile = blockIdx.x;
     if (tile >= tile_pre[n_refs]) return;
@@ -442,17 +443,33 @@ __global__ __launch_bounds__(256) void eref_ref_kernel(const uint8_t *__restrict
     if (c0 >= n_chunks) return;
     const int64_t c1 = min(n_chunks, c0 + per_wave);
     const uint8_t *s = bases + beg;
-    if (MODE == 0) {
-        // Latency-bound by construction (three dependent random probes per position), so the wave keeps
-        // everything in flight at once: all 9 byte loads of its 8 chunks first, then the 24 probes of all
-        // chunks, and only then the first use of a probe result.
+    if (MODE == 0 || MODE == 2) {
+        // MODE 2: probe channel 0 only (writes the channel-0 hit bits into any_words).
+        // MODE 0: full three-channel probe; with `need`, chunks whose flag is clear keep their channel-0
+        //         bits as `any` and get all = 0 (they cannot lie in a window that passes, see scan_refs).
+        // All byte loads of the wave's 8 chunks, then all probes, are issued before the first use.
+        constexpr int NCH = MODE == 2 ? 1 : 3;
+        const int64_t wbase = word_pre[r];
+        bool todo[per_wave];
+        bool any_todo = false;
+#pragma unroll
+        for (int q = 0; q < per_wave; q++) {
+            todo[q] = (c0 + q < c1) && (MODE == 2 || !need || need[wbase + c0 + q]);
+            any_todo |= todo[q];
+        }
+        if (MODE == 0 && need) {
+#pragma unroll
+            for (int q = 0; q < per_wave; q++)
+                if (c0 + q < c1 && !todo[q] && lane == 0) all_words[wbase + c0 + q] = 0;
+            if (!any_todo) return;                                         // wave-uniform
+        }
         uint32_t ch[per_wave + 1];
 #pragma unroll
         for (int q = 0; q <= per_wave; q++) {
             const int64_t idx = (c0 + q) * 64 + lane;
             ch[q] = (idx < len) ? s[idx] : 0u;
         }
-        uint32_t word[per_wave][3], sh[per_wave];
+        uint32_t word[per_wave][NCH], sh[per_wave];
         BaseBits b0 = classify(ch[0]);
         Streams lo{__ballot(b0.p0), __ballot(b0.p1), __ballot(b0.p2), __ballot(b0.ok)};
 #pragma unroll
@@ -461,26 +478,30 @@ __global__ __launch_bounds__(256) void eref_ref_kernel(const uint8_t *__restrict
             Streams hi{__ballot(bn.p0), __ballot(bn.p1), __ballot(bn.p2), __ballot(bn.ok)};
             const int64_t j = (c0 + q) * 64 + lane;
             const uint32_t ok = window32(lo.ok, hi.ok, lane);
-            const bool valid = (c0 + q < c1) && (j < npos) && ok == 0xffffffffu;
+            const bool valid = todo[q] && (j < npos) && ok == 0xffffffffu;
             uint32_t key[3] = {0, 0, 0};
-            if (valid)
-                kmer_keys(masks, window32(lo.p0, hi.p0, lane), window32(lo.p1, hi.p1, lane),
-                          window32(lo.p2, hi.p2, lane), key);
+            if (valid) {
+                const uint32_t w0 = window32(lo.p0, hi.p0, lane), w1 = window32(lo.p1, hi.p1, lane),
+                               w2 = window32(lo.p2, hi.p2, lane);
+                if (MODE == 2) key[0] = canonical(masks, 0, w0, w1, w2, __brev(w0), __brev(w1), __brev(w2));
+                else kmer_keys(masks, w0, w1, w2, key);
+            }
             sh[q] = (key[0] & 31) | ((key[1] & 31) << 8) | ((key[2] & 31) << 16);
 #pragma unroll
-            for (int i = 0; i < 3; i++)           // index 0 means "none" (extract_ref.cpp:861): probe word 0 bit 0 ...
-                word[q][i] = (valid && key[i] != 0) ? p3[key[i] >> 5] : 0u;     // ... is never counted: word forced to 0
+            for (int i = 0; i < NCH; i++)         // index 0 means "none" (extract_ref.cpp:861)
+                word[q][i] = (valid && key[i] != 0) ? p3[key[i] >> 5] : 0u;
             lo = hi;
         }
 #pragma unroll
         for (int q = 0; q < per_wave; q++) {
-            if (c0 + q >= c1) break;                                   // wave-uniform
-            const int h = ((word[q][0] >> (sh[q] & 31)) & 1u) + ((word[q][1] >> ((sh[q] >> 8) & 31)) & 1u) +
-                          ((word[q][2] >> ((sh[q] >> 16) & 31)) & 1u);
+            if (!todo[q]) continue;                                    // wave-uniform
+            int h = (word[q][0] >> (sh[q] & 31)) & 1u;
+            if (MODE == 0)
+                h += ((word[q][1] >> ((sh[q] >> 8) & 31)) & 1u) + ((word[q][2] >> ((sh[q] >> 16) & 31)) & 1u);
             const uint64_t any = __ballot(h > 0), all = __ballot(h == 3);
             if (lane == 0) {
-                any_words[word_pre[r] + c0 + q] = any;
-                all_words[word_pre[r] + c0 + q] = all;
+                any_words[wbase + c0 + q] = any;
+                if (MODE == 0) all_words[wbase + c0 + q] = all;
             }
         }
         return;
@@ -513,6 +534,78 @@ __device__ __forceinline__ uint32_t prefix_count(const uint64_t *__restrict__ wo
     int b = static_cast<int>(j & 63);
     uint64_t mask = (b == 63) ? ~0ull : ((2ull << b) - 1);
     return pre[w] + __popcll(words[w] & mask);           // hits at positions <= j
+}
+
+// Phase B probe pruning (exact).  A window can only pass if it holds >= three_min positions where ALL
+// three channels hit (extract_ref.cpp:561), hence >= three_min channel-0 hits.  So channel 0 is probed
+// everywhere first; this kernel marks the 64-position chunks that overlap at least one window with
+// enough channel-0 hits, and only those chunks get the other two probes.  Everywhere else `all` is 0
+// and `any` keeps the channel-0 bits: every window touching such a chunk fails the three_min test
+// with the true bits already, so the substitution cannot change any good[j].
+__global__ __launch_bounds__(256) void eref_need_kernel(const int64_t *__restrict__ offsets, int64_t n_refs,
+                                                        const int64_t *__restrict__ word_pre,
+                                                        const uint64_t *__restrict__ c0_words,
+                                                        uint32_t *__restrict__ c0_pre, uint64_t *__restrict__ cand_words,
+                                                        uint32_t *__restrict__ cand_pre, int three_min,
+                                                        uint8_t *__restrict__ need)
+{
+    const int64_t r = blockIdx.x;
+    if (r >= n_refs) return;
+    const int64_t len = offsets[r + 1] - offsets[r];
+    const int64_t n_words = (len + 63) / 64, w0 = word_pre[r];
+    const uint64_t *A = c0_words + w0;
+    uint32_t *PA = c0_pre + w0, *PC = cand_pre + w0;
+    uint64_t *C = cand_words + w0;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    __shared__ uint32_t s_part[4];
+    __shared__ uint32_t carry;
+    auto block_prefix = [&](const uint64_t *W, uint32_t *P) {     // exclusive prefix popcount per word
+        if (t == 0) carry = 0;
+        __syncthreads();
+        for (int64_t base = 0; base < n_words; base += 256) {
+            const int64_t w = base + t;
+            const uint32_t c = (w < n_words) ? __popcll(W[w]) : 0;
+            uint32_t inc = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t u = __shfl_up(inc, d);
+                if (lane >= d) inc += u;
+            }
+            if (lane == 63) s_part[wv] = inc;
+            __syncthreads();
+            uint32_t o = carry;
+            for (int k = 0; k < wv; k++) o += s_part[k];
+            if (w < n_words) P[w] = o + inc - c;
+            __syncthreads();
+            if (t == 255) carry = o + inc;
+            __syncthreads();
+        }
+    };
+    block_prefix(A, PA);
+    __threadfence_block();
+    __syncthreads();
+    for (int64_t w = wv; w < n_words; w += 4) {                    // cand[j]: channel-0 hits in (j-500, j] >= three_min
+        const int64_t j = w * 64 + lane;
+        bool cand = false;
+        if (j < len) {
+            uint32_t c = prefix_count(A, PA, j);
+            if (j >= 500) c -= prefix_count(A, PA, j - 500);
+            cand = static_cast<int>(c) >= three_min;
+        }
+        const uint64_t g = __ballot(cand);
+        if (lane == 0) C[w] = g;
+    }
+    __threadfence_block();
+    __syncthreads();
+    block_prefix(C, PC);
+    __threadfence_block();
+    __syncthreads();
+    for (int64_t w = t; w < n_words; w += 256) {                   // chunk w is needed iff a cand j lies in [64w, 64w+562]
+        const int64_t hi = min(len - 1, w * 64 + 63 + 499);
+        uint32_t upto = prefix_count(C, PC, hi);
+        uint32_t before = w ? prefix_count(C, PC, w * 64 - 1) : 0u;
+        need[w0 + w] = upto > before;
+    }
 }
 
 __global__ __launch_bounds__(256) void eref_window_kernel(const int64_t *__restrict__ offsets,
@@ -857,7 +950,7 @@ int palace_eref_index_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_
     hipLaunchKernelGGL(eref_ref_kernel<1>, dim3(static_cast<unsigned>(max_tiles)), dim3(256), 0, ctx->stream,
                        d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks,
                        static_cast<const uint32_t *>(nullptr), static_cast<uint64_t *>(nullptr),
-                       static_cast<uint64_t *>(nullptr), d_out, d_out_offsets);
+                       static_cast<uint64_t *>(nullptr), d_out, d_out_offsets, static_cast<const uint8_t *>(nullptr));
     PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
 }
@@ -879,7 +972,8 @@ int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t
     PALACE_REQUIRE(max_tiles < (1ll << 31), "too many tiles for one launch");
     const size_t pre_bytes = align_up((n_refs + 1) * 8, 256);
     const size_t w64 = align_up(max_words * 8, 256), w32 = align_up(max_words * 4, 256);
-    rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32);
+    const size_t w8 = align_up(max_words, 256);
+    rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32 + w8);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
     int64_t *tile_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
@@ -888,12 +982,23 @@ int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t
     uint64_t *all_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
     uint64_t *good_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
     uint32_t *any_p = reinterpret_cast<uint32_t *>(ws); ws += w32;
-    uint32_t *all_p = reinterpret_cast<uint32_t *>(ws);
+    uint32_t *all_p = reinterpret_cast<uint32_t *>(ws); ws += w32;
+    uint8_t *need = reinterpret_cast<uint8_t *>(ws);
     rc = launch_prefix(ctx, d_offsets, n_refs, tile_pre, word_pre);
     if (rc) return rc;
+    // channel 0 everywhere -> chunks that can matter -> channels 1 and 2 only there (exact; see eref_need_kernel)
+    hipLaunchKernelGGL(eref_ref_kernel<2>, dim3(static_cast<unsigned>(max_tiles)), dim3(256), 0, ctx->stream,
+                       d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks, ctx->plane[2], any_w,
+                       all_w, static_cast<uint32_t *>(nullptr), static_cast<const int64_t *>(nullptr),
+                       static_cast<const uint8_t *>(nullptr));
+    PALACE_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(eref_need_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(256), 0, ctx->stream, d_offsets,
+                       n_refs, word_pre, any_w, any_p, good_w, all_p, three_min, need);
+    PALACE_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(eref_ref_kernel<0>, dim3(static_cast<unsigned>(max_tiles)), dim3(256), 0, ctx->stream,
                        d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks, ctx->plane[2], any_w,
-                       all_w, static_cast<uint32_t *>(nullptr), static_cast<const int64_t *>(nullptr));
+                       all_w, static_cast<uint32_t *>(nullptr), static_cast<const int64_t *>(nullptr),
+                       static_cast<const uint8_t *>(need));
     PALACE_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(eref_window_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(256), 0, ctx->stream,
                        d_offsets, n_refs, word_pre, any_w, all_w, any_p, all_p, good_w, one_min, three_min,
