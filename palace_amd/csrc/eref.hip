@@ -342,11 +342,21 @@ __global__ __launch_bounds__(1024) void eref_lds_count_kernel(const unsigned int
     }
     __syncthreads();
     const uint32_t *keys = binned + static_cast<size_t>(b) * cap;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t k = keys[i];
-        const uint32_t w = (k & ((1u << kBucketShift) - 1)) >> 5, bit = 1u << (k & 31);
-        if (atomicOr(&l1[w], bit) & bit)
-            if (atomicOr(&l2[w], bit) & bit) atomicOr(&l3[w], bit);
+    constexpr int kBatch = 8;                              // key loads in flight per thread
+    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kBatch * blockDim.x) {
+        uint32_t k[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            const uint32_t i = i0 + u * blockDim.x;
+            k[u] = (i < n) ? keys[i] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            if (i0 + u * blockDim.x >= n) break;
+            const uint32_t w = (k[u] & ((1u << kBucketShift) - 1)) >> 5, bit = 1u << (k[u] & 31);
+            if (atomicOr(&l1[w], bit) & bit)
+                if (atomicOr(&l2[w], bit) & bit) atomicOr(&l3[w], bit);
+        }
     }
     __syncthreads();
     uint4 *o1 = reinterpret_cast<uint4 *>(p1 + w0), *o2 = reinterpret_cast<uint4 *>(p2 + w0),
