@@ -24,6 +24,12 @@
 //    and does the 500-base window test with prefix population counts.
 #include "common.hpp"
 
+// Diagnostic build switch: -DPALACE_STAMPS=1 compiles the in-kernel phase stamps of the bin kernel in
+// (read back by palace_ctx_destroy); the shipped library carries none of them.
+#ifndef PALACE_STAMPS
+#define PALACE_STAMPS 0
+#endif
+
 namespace palace {
 
 // ------------------------------------------------------------------------------------------
@@ -33,11 +39,15 @@ struct BaseBits {
     bool p0, p1, p2, ok;
 };
 
+// One base -> its three projection bits and validity.  Upper-cased ASCII: A 0x41, C 0x43, G 0x47,
+// T 0x54; (x >> 1) & 3 maps A,C,T,G to 0,1,2,3, so {A,T} = !(c & 1), {A,C} = !(c & 2), {A,G} = bits equal.
 __device__ __forceinline__ BaseBits classify(uint32_t ch)
 {
-    uint32_t c = ch | 0x20u;                   // fold case; only letters map onto a/c/g/t
-    bool a = c == 'a', cc = c == 'c', g = c == 'g', t = c == 't';
-    return BaseBits{a || t, a || cc, a || g, a || cc || g || t};
+    const uint32_t x = ch & 0xDFu;                 // fold case (only letters can land on A/C/G/T)
+    const uint32_t d = x - 0x41u;                  // A,C,G,T -> 0,2,6,19
+    const bool ok = d < 20u && ((0x80045u >> d) & 1u);
+    const uint32_t c = x >> 1;
+    return BaseBits{!(c & 1u), !(c & 2u), !((c ^ (c >> 1)) & 1u), ok};
 }
 
 struct Streams {
@@ -48,14 +58,16 @@ __device__ __forceinline__ Streams ballot_streams(const uint8_t *__restrict__ s,
 {
     uint32_t ch = (idx < len) ? s[idx] : 0u;
     BaseBits b = classify(ch);
-    return Streams{__ballot(b.p0), __ballot(b.p1), __ballot(b.p2), __ballot(b.ok)};
+    return Streams{__ballot(b.p0), __ballot(b.p1), __ballot(b.p2), __ballot(b.ok)};   // p* of invalid bases are never used
 }
 
+// bits [lane, lane+31] of the 128-bit value hi:lo, for lane in 0..63: pick the two 32-bit words that
+// hold them and funnel-shift (v_alignbit_b32) -- no 64-bit shifts.
 __device__ __forceinline__ uint32_t window32(uint64_t lo, uint64_t hi, int lane)
 {
-    uint64_t v = lo >> lane;
-    if (lane) v |= hi << (64 - lane);
-    return static_cast<uint32_t>(v);
+    const uint32_t w0 = static_cast<uint32_t>(lo), w1 = static_cast<uint32_t>(lo >> 32), w2 = static_cast<uint32_t>(hi);
+    const bool upper = lane >= 32;
+    return __builtin_amdgcn_alignbit(upper ? w2 : w1, upper ? w1 : w0, static_cast<uint32_t>(lane) & 31u);
 }
 
 __device__ __forceinline__ uint32_t canonical(const CoderMasks &m, int i, uint32_t w0, uint32_t w1,
@@ -145,6 +157,7 @@ constexpr int kBuckets = 1 << kBucketBits;            // 16384 fine buckets
 constexpr int kBucketShift = 32 - kBucketBits;        // 18: keys per fine bucket = 2^18
 constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 per plane per bucket
 constexpr int kL1Buckets = 128, kL1Shift = 25;        // level 1: key >> 25
+constexpr int kFlatMaxChunks = 6;                     // 64-position chunks one wave walks in the flat bin1 kernel
 constexpr int kL1Replicas = 32;                        // level-1 bucket regions are split 32 ways so that the
                                                       // per-tile reservations do not pile onto 128 addresses
 
@@ -183,6 +196,7 @@ struct BinOut {
     uint32_t cap;
     uint32_t *p1, *p2, *p3;        // overflow path
     int dbg;                       // timing experiments only: 1 skip stores, 2 skip reservations, 4 skip staging
+    unsigned long long *stamps;    // diagnostic: per-phase cycle sums (null in production)
 };
 
 // stage -> reserve -> copy out; `bucket0` is the first destination bucket of this workgroup's 128
@@ -191,22 +205,26 @@ __device__ __forceinline__ void flush_rows(uint32_t *stage, unsigned int *cnt, u
                                            uint32_t bucket0, uint32_t stride, const BinOut &o)
 {
     __syncthreads();
+    const unsigned long long f0 = (PALACE_STAMPS && o.stamps) ? wall_clock64() : 0ull;
     if (threadIdx.x < kL1Buckets) {
         const unsigned int c = min(cnt[threadIdx.x], static_cast<unsigned int>(SLOTS));
         cnt[threadIdx.x] = c;
-        gbase[threadIdx.x] = (c && !(o.dbg & 2)) ? atomicAdd(&o.cursor[bucket0 + threadIdx.x * stride], c) : (blockIdx.x % 1024u) * SLOTS;
+        gbase[threadIdx.x] = (c && !(PALACE_STAMPS && (o.dbg & 2))) ? atomicAdd(&o.cursor[bucket0 + threadIdx.x * stride], c) : (blockIdx.x % 1024u) * SLOTS;
     }
     __syncthreads();
+    const unsigned long long f1 = (PALACE_STAMPS && o.stamps) ? wall_clock64() : 0ull;
+    if (PALACE_STAMPS && o.stamps && threadIdx.x == 0) atomicAdd(&o.stamps[3], f1 - f0);   // reservation phase (atomic + barrier)
     for (int sidx = threadIdx.x; sidx < kL1Buckets * SLOTS; sidx += THREADS) {
         const int b = sidx / SLOTS, p = sidx % SLOTS;
         if (p < static_cast<int>(cnt[b])) {
             const uint32_t k = stage[sidx];
             const unsigned int g = gbase[b] + p;
-            if (o.dbg & 1) continue;
+            if (PALACE_STAMPS && (o.dbg & 1)) continue;
             if (g < o.cap) o.buf[static_cast<size_t>(bucket0 + b * stride) * o.cap + g] = k;
             else count_key(k, o.p1, o.p2, o.p3);           // bucket region full: exact slow path
         }
     }
+    if (PALACE_STAMPS && o.stamps && threadIdx.x == 0) atomicAdd(&o.stamps[4], wall_clock64() - f1);   // store loop (issue only)
 }
 
 template <int THREADS, int SLOTS>
@@ -260,8 +278,11 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_flat_kernel(const uint8_t *
 {
     __shared__ uint32_t stage[kL1Buckets * SLOTS];
     __shared__ unsigned int cnt[kL1Buckets], gbase[kL1Buckets];
+    __shared__ unsigned long long dbg_first_start, dbg_last_start, dbg_last_end;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int n_waves = THREADS / 64;
+    const unsigned long long t_begin = (PALACE_STAMPS && o.stamps) ? wall_clock64() : 0ull;
+    if (PALACE_STAMPS && o.stamps && threadIdx.x == 0) { dbg_first_start = ~0ull; dbg_last_start = 0; dbg_last_end = 0; }
     if (threadIdx.x < kL1Buckets) cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint8_t *bases = all_bases + offsets[0];      // the read set starts at its first offset
@@ -269,31 +290,60 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_flat_kernel(const uint8_t *
     const int64_t c0 = (static_cast<int64_t>(blockIdx.x) * n_waves + wave) * chunks_per_wave;
     const int64_t c1 = min(n_chunks, c0 + chunks_per_wave);
     if (c0 < c1) {
-        Streams lo = ballot_streams(bases, c0 * 64 + lane, total);
-        unsigned long long elo = ends[c0];
-        for (int64_t c = c0; c < c1; c++) {
-            Streams hi = ballot_streams(bases, (c + 1) * 64 + lane, total);
-            const unsigned long long ehi = (c + 1 < n_chunks) ? ends[c + 1] : 0ull;
+        // Every load of this wave's chunk range -- base bytes AND read-end words -- is issued before the
+        // first use (the loop used to pay two dependent memory round trips per 64 positions), and the
+        // three LDS row appends of a position are issued together before their results are used.
+        uint32_t ch[kFlatMaxChunks + 1];
+        unsigned long long en[kFlatMaxChunks + 1];
+#pragma unroll
+        for (int q = 0; q <= kFlatMaxChunks; q++) {
+            const int64_t c = c0 + q;
+            const int64_t idx = c * 64 + lane;
+            const bool in = c <= c1;
+            ch[q] = (in && idx < total) ? bases[idx] : 0u;
+            en[q] = (in && c < n_chunks) ? ends[c] : 0ull;
+        }
+        BaseBits b0 = classify(ch[0]);
+        Streams lo{__ballot(b0.p0), __ballot(b0.p1), __ballot(b0.p2), __ballot(b0.ok)};
+#pragma unroll
+        for (int q = 0; q < kFlatMaxChunks; q++) {
+            if (c0 + q >= c1) break;                             // wave-uniform
+            BaseBits bn = classify(ch[q + 1]);
+            Streams hi{__ballot(bn.p0), __ballot(bn.p1), __ballot(bn.p2), __ballot(bn.ok)};
             const uint32_t ok = window32(lo.ok, hi.ok, lane);
-            const uint32_t cross = window32(elo, ehi, lane) & 0x7fffffffu;     // an end inside [p, p+30]
+            const uint32_t cross = window32(en[q], en[q + 1], lane) & 0x7fffffffu;     // an end inside [p, p+30]
             if (ok == 0xffffffffu && cross == 0u) {
                 uint32_t key[3];
                 kmer_keys(masks, window32(lo.p0, hi.p0, lane), window32(lo.p1, hi.p1, lane),
                           window32(lo.p2, hi.p2, lane), key);
+                if (!(PALACE_STAMPS && (o.dbg & 4))) {
+                    unsigned int pos[3];
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    const uint32_t b = key[i] >> kL1Shift;
-                    if (o.dbg & 4) { if (key[i] == 0x12345u) cnt[b] = 1; continue; }
-                    const unsigned int pos = atomicAdd(&cnt[b], 1u);
-                    if (pos < SLOTS) stage[b * SLOTS + pos] = key[i];
-                    else count_key(key[i], o.p1, o.p2, o.p3);
+                    for (int i = 0; i < 3; i++) pos[i] = atomicAdd(&cnt[key[i] >> kL1Shift], 1u);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        if (pos[i] < SLOTS) stage[(key[i] >> kL1Shift) * SLOTS + pos[i]] = key[i];
+                        else count_key(key[i], o.p1, o.p2, o.p3);
+                    }
                 }
             }
             lo = hi;
-            elo = ehi;
         }
     }
+    const unsigned long long t_mid = (PALACE_STAMPS && o.stamps) ? wall_clock64() : 0ull;
+    if (PALACE_STAMPS && o.stamps && lane == 0) {
+        atomicMin(&dbg_first_start, t_begin); atomicMax(&dbg_last_start, t_begin); atomicMax(&dbg_last_end, t_mid);
+        atomicAdd(&o.stamps[8 + wave], t_mid - t_begin);
+    }
     flush_rows<THREADS, SLOTS>(stage, cnt, gbase, blockIdx.x % kL1Replicas, kL1Replicas, o);
+    if (PALACE_STAMPS && o.stamps && threadIdx.x == 0) {
+        atomicAdd(&o.stamps[5], dbg_last_start - dbg_first_start);   // start skew between the workgroup's waves
+        atomicAdd(&o.stamps[6], dbg_last_end - dbg_first_start);     // slowest wave's staging end since first start
+        const unsigned long long t_end = wall_clock64();
+        atomicAdd(&o.stamps[0], t_mid - t_begin);      // staging phase of thread 0's wave
+        atomicAdd(&o.stamps[1], t_end - t_mid);        // flush phase
+        atomicAdd(&o.stamps[2], 1ull);
+    }
 }
 
 template <int THREADS, int SLOTS>
@@ -507,7 +557,8 @@ __global__ __launch_bounds__(256) void eref_ref_kernel(const uint8_t *__restrict
             if (!todo[q]) continue;                                    // wave-uniform
             int h = (word[q][0] >> (sh[q] & 31)) & 1u;
             if (MODE == 0)
-                h += ((word[q][1] >> ((sh[q] >> 8) & 31)) & 1u) + ((word[q][2] >> ((sh[q] >> 16) & 31)) & 1u);
+                h += ((word[q][NCH > 1 ? 1 : 0] >> ((sh[q] >> 8) & 31)) & 1u) +
+                     ((word[q][NCH > 2 ? 2 : 0] >> ((sh[q] >> 16) & 31)) & 1u);
             const uint64_t any = __ballot(h > 0), all = __ballot(h == 3);
             if (lane == 0) {
                 any_words[wbase + c0 + q] = any;
@@ -864,8 +915,9 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
     uint32_t *buf2 = reinterpret_cast<uint32_t *>(ws);
     PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes, ctx->stream));
-    BinOut o1{cursor1, buf1, cap1, ctx->plane[0], ctx->plane[1], ctx->plane[2], ctx->bin_dbg};
-    BinOut o2{cursor2, buf2, cap2, ctx->plane[0], ctx->plane[1], ctx->plane[2], 0};
+    unsigned long long *stamps = (PALACE_STAMPS && (ctx->bin_dbg & 8)) ? reinterpret_cast<unsigned long long *>(ctx->d_small) + 8 : nullptr;
+    BinOut o1{cursor1, buf1, cap1, ctx->plane[0], ctx->plane[1], ctx->plane[2], ctx->bin_dbg & 7, stamps};
+    BinOut o2{cursor2, buf2, cap2, ctx->plane[0], ctx->plane[1], ctx->plane[2], 0, nullptr};
     auto launch_bins = [&](auto variant) -> int {
         constexpr int THREADS = decltype(variant)::threads, SLOTS = decltype(variant)::slots;
         constexpr int64_t tile_keys = static_cast<int64_t>(THREADS) * decltype(variant)::keys_per_thread;
@@ -890,7 +942,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
             const double keys_per_pos = std::max(0.05, static_cast<double>(keys_per_read) /
                                                            std::max<double>(1.0, static_cast<double>(total_bases) / n_reads));
             int cpw = static_cast<int>(static_cast<double>(tile_keys) / (keys_per_pos * 64.0 * waves));
-            cpw = std::max(1, std::min(cpw, 4096));
+            cpw = std::max(1, std::min(cpw, kFlatMaxChunks));
             const int64_t flat_tiles = (n_chunks + static_cast<int64_t>(waves) * cpw - 1) / (static_cast<int64_t>(waves) * cpw);
             PALACE_REQUIRE(flat_tiles < (1ll << 31), "too many tiles for one launch");
             hipLaunchKernelGGL((eref_bin1_flat_kernel<THREADS, SLOTS>), dim3(static_cast<unsigned>(flat_tiles)), dim3(THREADS),
@@ -906,6 +958,8 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     switch (ctx->bin_variant) {                 // measured at the 1M-contig size: 512x64 (4 workgroups per CU) fastest
     case 1: rc = launch_bins(BinVariant<1024, 256>{}); break;
     case 2: rc = launch_bins(BinVariant<512, 128>{}); break;
+    case 3: rc = launch_bins(BinVariant<256, 64>{}); break;
+    case 4: rc = launch_bins(BinVariant<256, 32>{}); break;
     default: rc = launch_bins(BinVariant<512, 64>{}); break;
     }
     if (rc) return rc;
@@ -919,8 +973,8 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
  * bucket_cap > 0 overrides the per-bucket capacity (to exercise the overflow path). */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap)
 {
-    if (ctx && mode >= 10 && mode <= 12) { ctx->bin_variant = mode - 10; return PALACE_OK; }   // tuning: tile shape
-    if (ctx && mode >= 20 && mode < 28) { ctx->bin_dbg = mode - 20; return PALACE_OK; }          // timing experiments (wrong results)
+    if (ctx && mode >= 10 && mode <= 14) { ctx->bin_variant = mode - 10; return PALACE_OK; }   // tuning: tile shape
+    if (PALACE_STAMPS && ctx && mode >= 20 && mode < 36) { ctx->bin_dbg = mode - 20; return PALACE_OK; }   // diagnostic builds only
     PALACE_REQUIRE(ctx && mode >= 0 && mode <= 2 && bucket_cap >= 0 && bucket_cap < (1ll << 31), "bad argument");
     ctx->count_mode = mode;
     ctx->bin_cap_override = bucket_cap;
