@@ -209,7 +209,8 @@ __device__ __forceinline__ void flush_rows(uint32_t *stage, unsigned int *cnt, u
     if (threadIdx.x < kL1Buckets) {
         const unsigned int c = min(cnt[threadIdx.x], static_cast<unsigned int>(SLOTS));
         cnt[threadIdx.x] = c;
-        gbase[threadIdx.x] = (c && !(PALACE_STAMPS && (o.dbg & 2))) ? atomicAdd(&o.cursor[bucket0 + threadIdx.x * stride], c) : (blockIdx.x % 1024u) * SLOTS;
+        if (PALACE_STAMPS && (o.dbg & 2)) gbase[threadIdx.x] = (blockIdx.x % 1024u) * SLOTS;    // ablation: no reservation
+        else gbase[threadIdx.x] = c ? atomicAdd(&o.cursor[bucket0 + threadIdx.x * stride], c) : 0u;
     }
     __syncthreads();
     const unsigned long long f1 = (PALACE_STAMPS && o.stamps) ? wall_clock64() : 0ull;
