@@ -536,9 +536,9 @@ def main():
                        "graph": {k: last[k] for k in ("n_cands", "n_edges", "n_arcs", "n_comp", "n_cycles", "n_multi")}},
             "roofline": {"bound": "hbm", "kernel": "eref count_reads (bin1 + bin2 + lds_count kernels of one launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         # PMC (separate rocprofv3 passes, profiles/r01p_end_state.md): FETCH_SIZE x2 + WRITE_SIZE of
+                         # PMC (separate rocprofv3 passes, profiles/r01q_end_state_fused_launch.md): FETCH_SIZE x2 + WRITE_SIZE of
                          # bin1 + bin2 + lds_count per launch; only valid for the default workload on one GPU
-                         "traffic": None if True else 26.3e9 if (args.contigs == 1_000_000 and world == 1) else None,
+                         "traffic": 48.2e9 if (args.contigs == 1_000_000 and world == 1) else None,
                          "traffic_unit": "bytes per launch",
                          "avg_launch_ms": count_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "stage_ms": {"eref_count_both_sides": count_ms, "eref_table_merge": merge_ms, "eref_scan_refs": scan_ms,
