@@ -274,6 +274,7 @@ __global__ void mark_read_ends_kernel(const int64_t *__restrict__ offsets, int64
 template <int THREADS, int SLOTS>
 __global__ __launch_bounds__(THREADS) void eref_bin1_flat_kernel(const uint8_t *__restrict__ all_bases,
                                                                  const int64_t *__restrict__ offsets, int64_t total,
+                                                                 int64_t chunk_lo, int64_t chunk_hi,
                                                                  const unsigned long long *__restrict__ ends,
                                                                  CoderMasks masks, int chunks_per_wave, BinOut o)
 {
@@ -288,8 +289,8 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_flat_kernel(const uint8_t *
     __syncthreads();
     const uint8_t *bases = all_bases + offsets[0];      // the read set starts at its first offset
     const int64_t n_chunks = (total + 63) >> 6;
-    const int64_t c0 = (static_cast<int64_t>(blockIdx.x) * n_waves + wave) * chunks_per_wave;
-    const int64_t c1 = min(n_chunks, c0 + chunks_per_wave);
+    const int64_t c0 = chunk_lo + (static_cast<int64_t>(blockIdx.x) * n_waves + wave) * chunks_per_wave;
+    const int64_t c1 = min(chunk_hi, c0 + chunks_per_wave);       // windows starting in [chunk_lo, chunk_hi) chunks
     if (c0 < c1) {
         // Every load of this wave's chunk range -- base bytes AND read-end words -- is issued before the
         // first use (the loop used to pay two dependent memory round trips per 64 positions), and the
@@ -895,18 +896,24 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         PALACE_HIP_TRY(hipGetLastError());
         return PALACE_OK;
     }
-    // capacities: 1.25 x the uniform expectation of the key upper bound, plus slack
-    const int64_t max_keys = 3 * total_bases;
+    // Large read sets are processed in slabs of at most kSlabBases positions (the planes accumulate across
+    // slabs), which bounds the workspace at ~30 GB whatever the input size.
+    const int64_t kSlabBases = ctx->slab_override > 0 ? ctx->slab_override : (1ll << 30);   // multiple of 64
+    const int64_t n_slabs = (total_bases + kSlabBases - 1) / kSlabBases;
+    const int64_t slab_bases = std::min(total_bases, kSlabBases);
+    // capacities: 1.25 x the uniform expectation of the key upper bound of one slab, plus slack
+    // (with a keep mask slabs are read ranges of equal count, so allow them to be 1.5 x the mean)
+    const int64_t max_keys = 3 * (d_keep && n_slabs > 1 ? slab_bases + slab_bases / 2 : slab_bases);
     int64_t cap2_64 = max_keys / kBuckets + max_keys / (4 * kBuckets) + 2048;
     constexpr int64_t kRegions = static_cast<int64_t>(kL1Buckets) * kL1Replicas;
     int64_t cap1_64 = max_keys / kRegions + max_keys / (4 * kRegions) + 4096;      // per level-1 region
     if (ctx->bin_cap_override > 0) { cap2_64 = ctx->bin_cap_override; cap1_64 = ctx->bin_cap_override * 4; }
-    PALACE_REQUIRE(cap1_64 < (1ll << 31), "read set too large for one call; split it");
     const uint32_t cap1 = static_cast<uint32_t>(cap1_64), cap2 = static_cast<uint32_t>(cap2_64);
     const size_t cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
     const size_t cur2_bytes = align_up(kBuckets * sizeof(unsigned int), 256);
     const size_t buf1_bytes = align_up(static_cast<size_t>(kRegions) * cap1 * 4, 256);
-    const size_t ends_bytes = align_up(static_cast<size_t>((total_bases + 63) / 64 + 2) * 8, 256);
+    const int64_t n_chunks = (total_bases + 63) / 64;
+    const size_t ends_bytes = align_up(static_cast<size_t>(n_chunks + 2) * 8, 256);
     rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + ends_bytes + buf1_bytes + static_cast<size_t>(kBuckets) * cap2 * 4);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
@@ -915,58 +922,63 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     unsigned long long *ends = reinterpret_cast<unsigned long long *>(ws); ws += ends_bytes;
     uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
     uint32_t *buf2 = reinterpret_cast<uint32_t *>(ws);
-    PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes, ctx->stream));
     unsigned long long *stamps = (PALACE_STAMPS && (ctx->bin_dbg & 8)) ? reinterpret_cast<unsigned long long *>(ctx->d_small) + 8 : nullptr;
     BinOut o1{cursor1, buf1, cap1, ctx->plane[0], ctx->plane[1], ctx->plane[2], ctx->bin_dbg & 7, stamps};
     BinOut o2{cursor2, buf2, cap2, ctx->plane[0], ctx->plane[1], ctx->plane[2], 0, nullptr};
-    auto launch_bins = [&](auto variant) -> int {
+    if (!d_keep) {                                   // read ends as a bit per position, once for the whole set
+        PALACE_HIP_TRY(hipMemsetAsync(ends, 0, static_cast<size_t>(n_chunks + 1) * 8, ctx->stream));
+        hipLaunchKernelGGL(mark_read_ends_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
+                           ctx->stream, d_offsets, n_reads, ends);
+        PALACE_HIP_TRY(hipGetLastError());
+    }
+    const int64_t keys_per_read = std::max<int64_t>(1, 3 * (total_bases / n_reads - 31));
+    auto launch_slab = [&](auto variant, int64_t slab) -> int {
         constexpr int THREADS = decltype(variant)::threads, SLOTS = decltype(variant)::slots;
         constexpr int64_t tile_keys = static_cast<int64_t>(THREADS) * decltype(variant)::keys_per_thread;
-        // reads per tile so that a tile holds about tile_keys keys; whole waves' worth when possible
-        const int64_t keys_per_read = std::max<int64_t>(1, 3 * (total_bases / n_reads - 31));
-        int64_t rpt = std::max<int64_t>(1, tile_keys / keys_per_read);
         constexpr int waves = THREADS / 64;
-        if (rpt >= waves) rpt -= rpt % waves;
-        rpt = std::min<int64_t>(rpt, 1 << 20);
-        const int64_t tiles = (n_reads + rpt - 1) / rpt;
-        PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
+        PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes, ctx->stream));
         if (d_keep) {
-            hipLaunchKernelGGL((eref_bin1_kernel<THREADS, SLOTS>), dim3(static_cast<unsigned>(tiles)), dim3(THREADS), 0,
-                               ctx->stream, d_bases, d_offsets, n_reads, d_keep, ctx->masks, static_cast<int>(rpt), o1);
+            // per-read kernel over this slab's share of the reads; a tile holds about tile_keys keys
+            const int64_t r_lo = n_reads * slab / n_slabs, r_hi = n_reads * (slab + 1) / n_slabs;
+            int64_t rpt = std::max<int64_t>(1, tile_keys / keys_per_read);
+            if (rpt >= waves) rpt -= rpt % waves;
+            rpt = std::min<int64_t>(rpt, 1 << 20);
+            const int64_t tiles = (r_hi - r_lo + rpt - 1) / rpt;
+            PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
+            if (tiles > 0)
+                hipLaunchKernelGGL((eref_bin1_kernel<THREADS, SLOTS>), dim3(static_cast<unsigned>(tiles)), dim3(THREADS), 0,
+                                   ctx->stream, d_bases, d_offsets + r_lo, r_hi - r_lo, d_keep + r_lo, ctx->masks,
+                                   static_cast<int>(rpt), o1);
         } else {
-            // flat stream: end bits first, then tiles of (waves x chunks_per_wave) 64-position chunks sized so
-            // that a tile yields about tile_keys keys
-            const int64_t n_chunks = (total_bases + 63) / 64;
-            PALACE_HIP_TRY(hipMemsetAsync(ends, 0, static_cast<size_t>(n_chunks + 1) * 8, ctx->stream));
-            hipLaunchKernelGGL(mark_read_ends_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
-                               ctx->stream, d_offsets, n_reads, ends);
+            // flat stream: tiles of (waves x chunks_per_wave) 64-position chunks sized to about tile_keys keys
+            const int64_t c_lo = slab * (kSlabBases / 64), c_hi = std::min(n_chunks, (slab + 1) * (kSlabBases / 64));
             const double keys_per_pos = std::max(0.05, static_cast<double>(keys_per_read) /
                                                            std::max<double>(1.0, static_cast<double>(total_bases) / n_reads));
             int cpw = static_cast<int>(static_cast<double>(tile_keys) / (keys_per_pos * 64.0 * waves));
             cpw = std::max(1, std::min(cpw, kFlatMaxChunks));
-            const int64_t flat_tiles = (n_chunks + static_cast<int64_t>(waves) * cpw - 1) / (static_cast<int64_t>(waves) * cpw);
+            const int64_t flat_tiles = (c_hi - c_lo + static_cast<int64_t>(waves) * cpw - 1) / (static_cast<int64_t>(waves) * cpw);
             PALACE_REQUIRE(flat_tiles < (1ll << 31), "too many tiles for one launch");
             hipLaunchKernelGGL((eref_bin1_flat_kernel<THREADS, SLOTS>), dim3(static_cast<unsigned>(flat_tiles)), dim3(THREADS),
-                               0, ctx->stream, d_bases, d_offsets, total_bases, ends, ctx->masks, cpw, o1);
+                               0, ctx->stream, d_bases, d_offsets, total_bases, c_lo, c_hi, ends, ctx->masks, cpw, o1);
         }
         PALACE_HIP_TRY(hipGetLastError());
         const unsigned tiles2 = static_cast<unsigned>((static_cast<int64_t>(cap1) + tile_keys - 1) / tile_keys);
         hipLaunchKernelGGL((eref_bin2_kernel<THREADS, SLOTS>), dim3(tiles2, static_cast<unsigned>(kRegions)), dim3(THREADS), 0, ctx->stream,
                            cursor1, buf1, cap1, o2);
         PALACE_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, cursor2, buf2, cap2,
+                           ctx->plane[0], ctx->plane[1], ctx->plane[2]);
+        PALACE_HIP_TRY(hipGetLastError());
         return PALACE_OK;
     };
-    switch (ctx->bin_variant) {                 // measured at the 1M-contig size: 512x64 (4 workgroups per CU) fastest
-    case 1: rc = launch_bins(BinVariant<1024, 256>{}); break;
-    case 2: rc = launch_bins(BinVariant<512, 128>{}); break;
-    case 3: rc = launch_bins(BinVariant<256, 64>{}); break;
-    case 4: rc = launch_bins(BinVariant<256, 32>{}); break;
-    default: rc = launch_bins(BinVariant<512, 64>{}); break;
+    for (int64_t slab = 0; slab < n_slabs; slab++) {
+        switch (ctx->bin_variant) {             // measured at the 1M-contig size: 512x64 (4 workgroups per CU) fastest
+        case 1: rc = launch_slab(BinVariant<1024, 256>{}, slab); break;
+        case 2: rc = launch_slab(BinVariant<512, 128>{}, slab); break;
+        default: rc = launch_slab(BinVariant<512, 64>{}, slab); break;
+        }
+        if (rc) return rc;
     }
-    if (rc) return rc;
-    hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, cursor2, buf2, cap2,
-                       ctx->plane[0], ctx->plane[1], ctx->plane[2]);
-    PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
 }
 
@@ -974,7 +986,12 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
  * bucket_cap > 0 overrides the per-bucket capacity (to exercise the overflow path). */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap)
 {
-    if (ctx && mode >= 10 && mode <= 14) { ctx->bin_variant = mode - 10; return PALACE_OK; }   // tuning: tile shape
+    if (ctx && mode >= 10 && mode <= 12) { ctx->bin_variant = mode - 10; return PALACE_OK; }
+    if (ctx && mode == 13) {                      // test hook: slab size in bases (0 = default 2^30), multiple of 64
+        PALACE_REQUIRE(bucket_cap >= 0 && bucket_cap % 64 == 0, "slab size must be a multiple of 64");
+        ctx->slab_override = bucket_cap;
+        return PALACE_OK;
+    }   // tuning: tile shape
     if (PALACE_STAMPS && ctx && mode >= 20 && mode < 36) { ctx->bin_dbg = mode - 20; return PALACE_OK; }   // diagnostic builds only
     PALACE_REQUIRE(ctx && mode >= 0 && mode <= 2 && bucket_cap >= 0 && bucket_cap < (1ll << 31), "bad argument");
     ctx->count_mode = mode;

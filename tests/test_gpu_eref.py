@@ -326,3 +326,23 @@ def test_binned_flat_stream_with_offset_base_and_ragged_reads(ctx):
         ctx.eref_set_count_mode(0, 0)
     u, c = oracle_key_counts(rs.bases, rs.offsets, cc)
     assert_table_equals(ctx, u, c)
+
+
+@pytest.mark.parametrize("with_keep", [False, True])
+def test_binned_slabs(ctx, with_keep):
+    """large read sets are processed in slabs; force tiny slabs and compare with the oracle"""
+    rng = synth.rng_for(29)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    cc = orc.header_to_cc(hdr)
+    rs = synth.vector_reads(rng, synth.random_dna(rng, 200000), 5000, 123)     # 615 kbases, reads straddle slab edges
+    keep = (rng.random(rs.n) < 0.7).astype(np.uint8) if with_keep else None
+    try:
+        ctx.eref_set_count_mode(2, 0)
+        ctx.eref_set_count_mode(13, 64 * 1024)                                 # 64 Ki-base slabs -> 10 slabs
+        count_on_gpu(ctx, [(rs.bases, rs.offsets)], hdr, keep=[keep] if with_keep else None)
+    finally:
+        ctx.eref_set_count_mode(13, 0)
+        ctx.eref_set_count_mode(0, 0)
+    kept = synth.reads_from_list([rs.read(i) for i in range(rs.n) if keep is None or keep[i]])
+    u, c = oracle_key_counts(kept.bases, kept.offsets, cc)
+    assert_table_equals(ctx, u, c)
