@@ -183,7 +183,9 @@ int main(int argc, char **argv)
         } catch (const std::exception &e) { std::cerr << "eref: " << e.what() << "\n"; return 1; }
         if (side == 0) {                                                        // cal_sam_ratio (:1124-1148)
             long sample = static_cast<long>(rs.bases.size()) * 2;
-            down_sam_ratio = sample > 0 ? static_cast<int>(100L * 2000000000L / sample) : 100;
+            long target = 2000000000L;                                          // down_sampling_size (:1230)
+            if (const char *t = std::getenv("PALACE_EREF_SAMPLE_TARGET")) target = std::atol(t);   // test hook
+            down_sam_ratio = sample > 0 ? static_cast<int>(100L * target / sample) : 100;
         }
         std::vector<uint8_t> keep;
         if (down_sam_ratio < 100) {                                             // one draw per sequence line (:955-960)

@@ -209,3 +209,29 @@ def test_matching_large_random(tmp_path):
 def test_matching_usage():
     p = run([os.path.join(BIN, "matching"), "-g", "x"])
     assert p.returncode == 1 and b"Usage" in p.stderr
+
+
+def test_eref_subsampling_follows_glibc_rand_stream(eref_files, golden_eref):
+    """E3: when 2 * sum(fq1 bases) exceeds the sampling target, one rand() % 100 draw per sequence line
+    (fq1 then fq2, seed 1) decides which reads count (extract_ref.cpp:955-960, 1124-1148, 1239-1240)."""
+    d, fa = eref_files
+    g = golden_eref
+    orc.build_index_file(fa, g["index_header"], fa + ".k32.index.dat", fa + ".genome.len.txt")
+    n1, n2 = len(g["r1_offsets"]) - 1, len(g["r2_offsets"]) - 1
+    fq1_bases = int(g["r1_offsets"][-1])
+    target = fq1_bases                                        # ratio = 100 * target / (2 * fq1_bases) = 50
+    ratio = 100 * target // (2 * fq1_bases)
+    assert ratio == 50
+    draws = orc.glibc_rand_stream(1, n1 + n2) % 100
+    keep1, keep2 = (draws[:n1] < ratio).astype(np.uint8), (draws[n1:] < ratio).astype(np.uint8)
+    cc = orc.header_to_cc(g["index_header"])
+    t = orc.CountTable()
+    t.count(g["r1_bases"], g["r1_offsets"], cc, keep1)
+    t.count(g["r2_bases"], g["r2_offsets"], cc, keep2)
+    want = orc.scan_index_file(fa + ".k32.index.dat", t, 0.8, 0.5)
+    t.free()
+    p = run([os.path.join(BIN, "eref"), str(d / "r_1.fq"), str(d / "r_2.fq"), fa, str(d / "tmp.txt"), "0.8", "0.5", "2"],
+            env=dict(os.environ, PALACE_EREF_SAMPLE_TARGET=str(target)))
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == want
+    assert want != g["stdout_080_050"].tobytes()              # sampling really changed the answer

@@ -1,0 +1,142 @@
+"""Host-side text/BAM parsing of the drop-in executables (palace_amd/host), checked on CPU through
+the `hostdump` tool: what the parsers hand to the GPU must follow the reference's getline / htslib
+view of the files (extract_ref.cpp:686-756, 940-1004; generate_graph.cpp:185-206, 330-397, 644-698)."""
+import os
+import subprocess
+
+import pytest
+
+from palace_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOSTDUMP = os.path.join(ROOT, "palace_amd", "bin", "hostdump")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "palace_amd", "host"), os.path.join("..", "bin", "hostdump")], check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+def dump(*args):
+    p = subprocess.run([HOSTDUMP, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    return p.stdout
+
+
+# ---- expectations restated in test code (independent of the C++) ---------------------------------
+def clip_info(cigar_text):
+    """parseCigarReadInterval's view (generate_graph.cpp:330-366): zero-length ops dropped."""
+    if cigar_text == "":
+        return -1, 0, 0
+    ops, n = [], 0
+    for ch in cigar_text:
+        if ch.isdigit():
+            n = n * 10 + int(ch)
+        else:
+            if n > 0:
+                ops.append((n, ch))
+            n = 0
+    cs = ops[0][0] if ops and ops[0][1] == "S" else 0
+    ce = ops[-1][0] if len(ops) > 1 and ops[-1][1] == "S" else 0
+    ln = sum(k for k, c in ops if c in "MIS=X")
+    return cs, ce, ln
+
+
+def atoi(s):
+    s = s.lstrip(" \t\n\v\f\r")
+    sign, i = 1, 0
+    if s[:1] in "+-":
+        sign, i = (-1 if s[0] == "-" else 1), 1
+    j = i
+    while j < len(s) and s[j].isdigit():
+        j += 1
+    return sign * int(s[i:j]) if j > i else 0
+
+
+def expected_sa(sa_text, names, own_tid):
+    if sa_text is None or own_tid < 0:
+        return []
+    out = []
+    for item in sa_text.split(";"):
+        if item == "":
+            continue
+        f = item.split(",")
+        if item.endswith(","):                      # a trailing empty field is not extractable by getline
+            f = f[:-1]
+        if len(f) < 6:
+            continue
+        f = [x.strip(" \t\n\v\f\r") for x in f[:6]]
+        if f[0] == "" or f[1] == "":
+            continue
+        tid2 = -1
+        if f[0] != names[own_tid] and f[0] in names:
+            tid2 = len(names) - 1 - names[::-1].index(f[0])          # last duplicate wins
+        cs, ce, ln = clip_info(f[3])
+        out.append((tid2, atoi(f[1]), 1 if f[2] == "-" else 0, atoi(f[4]), atoi(f[5]), cs, ce, ln))
+    return out
+
+
+def test_bam_decode_matches_expectations(tmp_path):
+    rng = synth.rng_for(314)
+    targets, _, recs, _ = synth.random_graph_case(rng, 30, 2500)
+    names = [t[0] for t in targets]
+    # a few hand-made oddities
+    B = synth.BamRecord
+    recs += [B("odd1", 0, 0, 5, 60, "5H20S30M2D10M0M7S", nm=3, sa=f"{names[1]},10,-,20S40M,60,1;;{names[2]},7,+,,50,0;bad,1,+;"),
+             B("odd2", 16, 1, 9, 0, "0S50M", nm=None, sa=f" {names[0]} ,12, - ,10M40S, 7x ,-3"),
+             B("odd3", 0, 2, 1, 255, "10S", nm=300, nm_type="S"),
+             B("odd4", 0, 2, 1, 20, "30M", nm=-5, nm_type="c", sa=f"{names[2]},5,+,30M,60,0,extra;{names[3]},5,+,30M,60,")]
+    bam = str(tmp_path / "t.bam")
+    synth.write_bam(bam, targets, recs, block=3000)
+    for threads in ("1", "5"):
+        lines = dump("bam", bam, threads).decode().split("\n")
+        hdr = [l for l in lines if l.startswith("@SQ")]
+        assert [tuple(l.split("\t")[1:]) for l in hdr] == [(n, str(L)) for n, L in targets]
+        body = [l for l in lines if l and not l.startswith("@SQ")]
+        assert len(body) == len(recs)
+        for l, r in zip(body, recs):
+            f = l.split("\t")
+            ops = synth.parse_cigar(r.cigar)
+            ref_len = sum(n for n, op in ops if op in (0, 2, 3, 7, 8))
+            read_len = sum(n for n, op in ops if op in (0, 1, 4, 7, 8))
+            cs, ce, _ = clip_info(r.cigar)
+            want = [r.qname, r.flag, r.tid, r.pos, r.mapq, r.mtid, r.mpos, 0 if r.nm is None else r.nm, ref_len, read_len, cs, ce]
+            assert f[:12] == [str(x) for x in want], (l, r)
+            got_sa = [tuple(int(x) for x in s[3:].split(",")) for s in f[12:]]
+            assert got_sa == expected_sa(r.sa, names, r.tid), (l, r.sa)
+
+
+def test_fastq_line_semantics(tmp_path):
+    txt = (b"@r0\nACGT\n+\nIIII\n"
+           b"@r1\r\nACGTN\r\n+\r\nIIIII\r\n"          # CR stays in the sequence line
+           b"@r2\n\n+\n\n"                              # empty read
+           b"@r3\nacgtACGTacgtACGTacgtACGTacgtACGT\n+\nx\n"
+           b"@r4\nTTTT")                                # no trailing newline, truncated record
+    p = str(tmp_path / "a.fq")
+    open(p, "wb").write(txt)
+    lines = txt.split(b"\n")
+    if lines[-1] == b"":
+        lines = lines[:-1]
+    want = b"".join(l + b"\n" for i, l in enumerate(lines) if i % 4 == 1)
+    for threads in ("1", "3", "16"):
+        assert dump("fastq", p, threads) == want
+    # a bigger file: chunking over threads must not change anything
+    rng = synth.rng_for(2)
+    rs = synth.vector_reads(rng, synth.random_dna(rng, 50000), 2000, 77)
+    rs.write_fastq(str(tmp_path / "b.fq"), "1")
+    one = dump("fastq", str(tmp_path / "b.fq"), "1")
+    assert one == dump("fastq", str(tmp_path / "b.fq"), "7") and one.count(b"\n") == 2000
+
+
+def test_fasta_record_semantics(tmp_path):
+    txt = (b"ACGTACGT\n"                                 # text before the first header: implicit record 'start', ordinal 0
+           b">one/1 desc\tmore\nACGT\nAC\n\nGT\n"
+           b">two three\nNNNN\r\n"
+           b">\n"
+           b">four\tx/y\nacgt")
+    p = str(tmp_path / "d.fa")
+    open(p, "wb").write(txt)
+    got = [l.split(b"\t") for l in dump("fasta", p).split(b"\n") if l]
+    assert got == [[b"0", b"start", b"8", b"ACGTACGT"], [b"1", b"one", b"8", b"ACGTACGT"], [b"2", b"two", b"5", b"NNNN\r"],
+                   [b"3", b"", b"0", b""], [b"4", b"four", b"4", b"acgt"]]
