@@ -18,6 +18,7 @@ import ctypes
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -474,19 +475,28 @@ def main():
             h_edges = e_buf[: n_e.value].cpu().numpy().view(capi.EDGE_DTYPE).reshape(-1)
         th1 = time.perf_counter()
         # ---------------- matching (small; rank 0 owns it, components are independent) ----------------
-        copies, src, dst, w = graph_to_arcs(h_cn, nt, h_edges)
-        th2 = time.perf_counter()
-        if rank == 0:
-            off, verts, kind, it, open_at = capi.match_decompose(g, copies, src, dst, 10, False)
-            th3 = time.perf_counter()
-            if timed:
-                for k_, v_ in (("d2h_graph", th1 - th0), ("glue_numpy", th2 - th1), ("match_decompose", th3 - th2)):
-                    host_ms[k_] = host_ms.get(k_, 0.0) + 1e3 * v_ / args.steps
-            last.update(n_comp=len(kind), n_cycles=int(kind.sum()), n_multi=int(((off[1:] - off[:-1]) > 1).sum()))
-        last.update(graph=(copies, src, dst, w), n_edges=int(n_e.value), n_cands=int(n_cands), n_arcs=len(src))
-        # ---------------- join: eref results to the host ----------------
+        def matching():
+            copies, src, dst, w = graph_to_arcs(h_cn, nt, h_edges)
+            th2 = time.perf_counter()
+            if rank == 0:
+                off, verts, kind, it, open_at = capi.match_decompose(g, copies, src, dst, 10, False)
+                th3 = time.perf_counter()
+                if timed:
+                    for k_, v_ in (("d2h_graph", th1 - th0), ("glue_numpy", th2 - th1), ("match_decompose", th3 - th2)):
+                        host_ms[k_] = host_ms.get(k_, 0.0) + 1e3 * v_ / args.steps
+                last.update(n_comp=len(kind), n_cycles=int(kind.sum()), n_multi=int(((off[1:] - off[:-1]) > 1).sum()))
+            last.update(graph=(copies, src, dst, w), n_edges=int(n_e.value), n_cands=int(n_cands), n_arcs=len(src))
+
         if exch:
-            eref_tail()                                # N GPUs: the exchange waits for the counts; graph + matching ran meanwhile
+            # N GPUs: the count-table exchange and Phase B need every rank's host thread for the collectives, so
+            # the host-side matching runs beside them in a second thread (ctypes and numpy release the GIL)
+            worker = threading.Thread(target=matching)
+            worker.start()
+            eref_tail()
+            worker.join()
+        else:
+            matching()
+        # ---------------- join: eref results to the host ----------------
         capi._check(L.palace_d2h(ctx.h, rows_host.data_ptr(), P(rows), rows.numel() * 4), "d2h")
 
     def barrier():
