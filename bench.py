@@ -258,6 +258,42 @@ def graph_to_arcs(cn, n_segs, edges, min_count=5):
 
 
 # ----------------------------------------------------------------------------------------------
+def reference_eref_check(b1, b2, off, rb, ro, n_ref_s, tmp):
+    """When the compiled reference travels with the repo (oracle/_ref/eref_ref, built from the unmodified
+    extract_ref.cpp), time IT on the same read sample at two sizes: marginal reads/s next to the port's."""
+    import subprocess
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "eref_ref")
+    if not os.path.exists(ref_bin):
+        return None
+    try:
+        fa = os.path.join(tmp, "db.fa")
+        with open(fa, "wb") as f:
+            for i in range(n_ref_s):
+                f.write(b">ref%d\n" % i + rb[ro[i]:ro[i + 1]].tobytes() + b"\n")
+        n = len(off) - 1
+        times = {}
+        for frac in (2, 1):                          # half the sample, then all of it (first run also builds the index)
+            m = n // frac
+            for tag, b in (("1", b1), ("2", b2)):
+                with open(os.path.join(tmp, f"s_{tag}.fq"), "wb") as f:
+                    f.write(b"".join(b"@r%d\n" % i + b[off[i]:off[i + 1]].tobytes() + b"\n+\n" + b"I" * READ_LEN + b"\n"
+                                     for i in range(m)))
+            if frac == 2:                            # untimed run that leaves the index beside the DB
+                subprocess.run([ref_bin, os.path.join(tmp, "s_1.fq"), os.path.join(tmp, "s_2.fq"), fa, os.path.join(tmp, "t.txt"),
+                                "0.9", "0.85", "1"], stdout=subprocess.DEVNULL, check=True, timeout=300)
+            t0 = time.perf_counter()
+            subprocess.run([ref_bin, os.path.join(tmp, "s_1.fq"), os.path.join(tmp, "s_2.fq"), fa, os.path.join(tmp, "t.txt"),
+                            "0.9", "0.85", "1"], stdout=subprocess.DEVNULL, check=True, timeout=300)
+            times[2 * m] = time.perf_counter() - t0
+        (ra, ta), (rbn, tb) = sorted(times.items())
+        marginal = (rbn - ra) / max(1e-9, tb - ta)
+        return dict(binary="oracle/_ref/eref_ref (unmodified extract_ref.cpp, -O2, threads=1, cached index)",
+                    runs_s={str(k): round(v, 2) for k, v in times.items()}, marginal_reads_per_s=marginal,
+                    fixed_s=ta - ra / marginal)
+    except Exception as e:                           # never let the cross-check break the bench line
+        return dict(error=str(e)[:200])
+
+
 def cpu_baseline(torch, sample, gs, header, n_reads, n_records, graph_out):
     """The oracle (CPU restatement of the reference algorithm, 1 thread) on a bounded sample of every
     stage, extrapolated linearly to the whole workload.  Returns contigs/s and a description."""
@@ -329,13 +365,14 @@ def cpu_baseline(torch, sample, gs, header, n_reads, n_records, graph_out):
     orc.match_run(gpath, None, 10, cap=cap)
     t_match = time.perf_counter() - t0
     t_full = t_eref + t_graph + t_match
-    return dict(value=sample["n_contigs"] / t_full, unit="contigs/s", cores=1, kind="port",
+    ref_check = reference_eref_check(b1, b2, off, rb, ro, n_ref_s, tmp)
+    return dict(reference_eref=ref_check, value=sample["n_contigs"] / t_full, unit="contigs/s", cores=1, kind="port",
                 sample=(f"oracle/ (1 thread). eref: {2 * n_side} of {total_reads} reads x{READ_LEN} bp ({t_reads:.1f} s) + 4 GiB "
                         f"table memset ({t_clear:.1f} s, fixed) + scan of {n_ref_s} of {sample['n_refs']} refs ({t_refs:.2f} s) "
                         f"-> {t_eref:.0f} s extrapolated; generateGraph: first {m} of {gs['n_total']} decoded records "
                         f"({t_graph_s:.1f} s, BGZF/BAM decode and full .fai parse excluded) -> {t_graph:.0f} s; matching: whole "
                         f"graph ({t_match:.1f} s, own algorithm, reference absent). Dead 16 GiB Peaks memset excluded."),
-                stage_s=dict(eref=t_eref, generateGraph=t_graph, matching=t_match))
+                stage_s=dict(eref=t_eref, generateGraph=t_graph, matching=t_match), port_reads_per_s=2 * n_side / t_reads)
 
 
 def main():
