@@ -1,0 +1,81 @@
+"""generateGraph through the C ABI directly (palace_graph_classify / _resolve / _copy_numbers) on the
+structure-of-arrays sample bench.py generates, against the oracle run on the same records rebuilt as
+BAM-level records.  Checks the bench's own data path, not only the CLI's."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_shaped_sample_equals_oracle(tmp_path):
+    import torch
+
+    import bench
+    from oracle import binding as orc
+    from palace_amd import capi
+    from palace_amd.synth import BamRecord
+
+    dev = torch.device("cuda", 0)
+    n_contigs, n_pairs = 20000, 66666
+    gs = bench.make_graph_sample(torch, dev, n_contigs, n_pairs)
+    torch.cuda.synchronize()
+    names, lens = gs["names"], gs["lens"]
+    P = lambda t: t.data_ptr()
+    L = capi.lib()
+    with capi.Ctx(0) as ctx:
+        cols = capi.BamCols(gs["n"], *(P(gs["col"][k]) for k in ("tid", "pos", "mtid", "mpos", "nm", "ref_len", "read_len",
+                                                               "clip_s", "clip_e", "flag", "mapq", "qkey")), P(gs["sa_off"]))
+        prm = capi.GraphParams.default()
+        consumed = torch.zeros(n_contigs, dtype=torch.int64, device=dev)
+        cap = gs["n"] + gs["n_sa"] + 1
+        cands = torch.zeros((cap, 64), dtype=torch.uint8, device=dev)
+        edges = torch.zeros((cap, 32), dtype=torch.uint8, device=dev)
+        cn = torch.zeros(n_contigs, dtype=torch.int32, device=dev)
+        n_c, n_e = ctypes.c_int64(), ctypes.c_int64()
+        capi._check(L.palace_graph_classify(ctx.h, ctypes.byref(cols), P(gs["sa"]), n_contigs, P(gs["tlen"]), P(gs["trank"]),
+                                            P(gs["fastg"]), gs["n_fastg"], ctypes.byref(prm), 0, P(consumed), P(cands), cap,
+                                            ctypes.byref(n_c)), "classify")
+        capi._check(L.palace_graph_resolve(ctx.h, P(cands), n_c.value, gs["n_total"], ctypes.byref(prm), P(consumed), P(edges),
+                                           cap, ctypes.byref(n_e)), "resolve")
+        capi._check(L.palace_graph_copy_numbers(ctx.h, P(consumed), P(gs["tlen"]), n_contigs, gs["avg_depth"], P(cn)), "cn")
+        ctx.sync()
+        h_cons = consumed.cpu().numpy()
+        h_cn = cn.cpu().numpy()
+        h_edges = edges[: n_e.value].cpu().numpy().view(capi.EDGE_DTYPE).reshape(-1)
+    # ---- GPU numbers -> the text generateGraph writes (generate_graph.cpp:1048-1076) ----
+    order = np.argsort(np.array(names, dtype="S"))
+    rank = np.empty(n_contigs, dtype=np.int64)
+    rank[order] = np.arange(n_contigs)
+    got = []
+    for i in order:
+        got.append("SEG %s %s %d\n" % (names[i], "%g" % (h_cons[i] / max(1, lens[i])), h_cn[i]))
+    es = sorted(h_edges.tolist(), key=lambda e: (rank[e[0]], rank[e[1]], e[3], e[4]))
+    for left, right, counts, oL, oR, _ in es:
+        supp, supp_nf, span, span_nf = counts
+        if supp + supp_nf + span + span_nf >= 5:
+            got.append("JUNC %s %s %s %s %d %d\n" % (names[left], "+-"[oL], names[right], "+-"[oR], supp + span + supp_nf, span_nf))
+    # ---- the same records for the oracle ----
+    c = {k: v.cpu().numpy() for k, v in gs["col"].items()}
+    so = gs["sa_off"].cpu().numpy()
+    sa = gs["sa"].cpu().numpy()
+    recs = []
+    for i in range(gs["n"]):
+        s_txt = None
+        if so[i + 1] > so[i]:
+            it = sa[so[i]]
+            s_txt = f"{names[it[0]]},{it[1]},{'-' if it[7] else '+'},{it[4]}S{it[6] - it[4]}M,{it[2]},{it[3]};"
+        cig = f"{c['ref_len'][i]}M{c['clip_e'][i]}S" if c["clip_e"][i] else "150M"
+        recs.append(BamRecord(f"q{c['qkey'][i] & 0xffffffffffff:x}", int(c["flag"][i]) & 0xffff, int(c["tid"][i]), int(c["pos"][i]),
+                              int(c["mapq"][i]), cig, int(c["mtid"][i]), int(c["mpos"][i]), nm=int(c["nm"][i]), sa=s_txt))
+    fk = gs["fastg"].cpu().numpy().view(np.uint64)
+    fai = str(tmp_path / "g.fastg.fai")
+    with open(fai, "w") as f:
+        for k in fk.tolist():
+            a, b, o1, o2 = k >> 33, (k >> 2) & 0x7fffffff, (k >> 1) & 1, k & 1
+            f.write(f"{names[a]}{chr(39) if o1 else ''}:{names[b]}{chr(39) if (o1 ^ o2) else ''};\t{lens[a]}\t0\t60\t61\n")
+    want = orc.graph_run(recs, list(zip(names, lens.tolist())), fai, gs["avg_depth"]).decode()
+    assert "".join(got) == want
+    assert want.count("JUNC") > 50
