@@ -79,3 +79,49 @@ def test_bench_shaped_sample_equals_oracle(tmp_path):
     want = orc.graph_run(recs, list(zip(names, lens.tolist())), fai, gs["avg_depth"]).decode()
     assert "".join(got) == want
     assert want.count("JUNC") > 50
+
+
+def test_bench_matching_stage_equals_oracle(tmp_path):
+    """bench.py's glue (graph_to_arcs) + palace_match_decompose, formatted the way matching_main.cpp formats,
+    equal the oracle's linear/cycle files for the same SEG/JUNC text."""
+    import bench
+    from oracle import binding as orc
+    from palace_amd import capi
+
+    rng = np.random.Generator(np.random.PCG64(4))
+    n = 30000
+    names = [f"EDGE_{i + 1}_length_{int(rng.integers(60, 5000))}_cov_{rng.random() * 20:.4f}" for i in range(n)]
+    cn = rng.integers(0, 4, size=n).astype(np.int32)
+    e = np.zeros(40000, dtype=capi.EDGE_DTYPE)
+    e["left"] = rng.integers(0, n, len(e)); e["right"] = rng.integers(0, n, len(e))
+    e["oL"] = rng.integers(0, 2, len(e)); e["oR"] = rng.integers(0, 2, len(e))
+    e["counts"] = rng.integers(0, 6, size=(len(e), 4))
+    # canonical, unique edge keys as generateGraph would hand them over
+    key = (e["left"].astype(np.int64) << 34) | (e["right"].astype(np.int64) << 2) | (e["oL"] << 1) | e["oR"]
+    e = e[np.unique(key, return_index=True)[1]]
+    copies, src, dst, w = bench.graph_to_arcs(cn, n, e)
+    with capi.Ctx(0) as ctx:
+        off, verts, kind, it, open_at = capi.match_decompose(ctx, copies, src, dst, 10, False)
+    tok = lambda v: names[v >> 1] + "+-"[v & 1]
+    lin, cyc, seen_l, seen_c = [], [], set(), set()
+    for c in range(len(kind)):
+        vs = verts[off[c]:off[c + 1]]
+        body = "\t".join(tok(int(v)) for v in vs) + "\n"
+        if not kind[c]:
+            if len(vs) == 1 and it[c] > 0:
+                continue
+            if body not in seen_l:
+                seen_l.add(body); lin.append(body)
+        elif body not in seen_c:
+            seen_c.add(body); cyc.append(f"iter {it[c]}\n" + body)
+    g = str(tmp_path / "g.txt")
+    tot = e["counts"].sum(axis=1)
+    with open(g, "w") as f:
+        f.write("".join(f"SEG {nm} 1 {k} 0 0.000 0\n" for nm, k in zip(names, cn.tolist())))
+        f.write("".join(f"JUNC {names[l]} {'+-'[a]} {names[r]} {'+-'[b]} {t} 0\n"
+                        for l, r, a, b, t in zip(e["left"].tolist(), e["right"].tolist(), e["oL"].tolist(), e["oR"].tolist(), tot.tolist())
+                        if t >= 5))
+    want_lin, want_cyc = orc.match_run(g, None, 10)
+    assert "".join(lin).encode() == want_lin
+    assert "".join(cyc).encode() == want_cyc
+    assert want_cyc.count(b"iter") > 0
