@@ -96,6 +96,9 @@ def test_bench_matching_stage_equals_oracle(tmp_path):
     e["left"] = rng.integers(0, n, len(e)); e["right"] = rng.integers(0, n, len(e))
     e["oL"] = rng.integers(0, 2, len(e)); e["oR"] = rng.integers(0, 2, len(e))
     e["counts"] = rng.integers(0, 6, size=(len(e), 4))
+    ring = np.arange(3000)                                    # planted heavy 10-rings so that cycles are certain
+    e["left"][:3000] = ring; e["right"][:3000] = (ring // 10) * 10 + (ring + 1) % 10
+    e["oL"][:3000] = 0; e["oR"][:3000] = 0; e["counts"][:3000] = 50
     # canonical, unique edge keys as generateGraph would hand them over
     key = (e["left"].astype(np.int64) << 34) | (e["right"].astype(np.int64) << 2) | (e["oL"] << 1) | e["oR"]
     e = e[np.unique(key, return_index=True)[1]]
