@@ -95,18 +95,23 @@ extern "C" int palace_match_greedy(palace_ctx *ctx, int32_t n_vertices, int64_t 
     a.changed = reinterpret_cast<unsigned int *>(ctx->d_small);
     const unsigned blocks = static_cast<unsigned>((n_vertices + 255) / 256);
     hipLaunchKernelGGL(match_init_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+    // A round that changes nothing is a no-op, so rounds are enqueued in batches of kBatch between
+    // host checks of the `changed` word (one stream round trip per batch, not per round).
+    constexpr int kBatch = 4;
     int rounds = 0;
     for (;;) {
         PALACE_HIP_TRY(hipMemsetAsync(ctx->d_small, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(match_propose_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL(match_commit_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+        for (int k = 0; k < kBatch; k++) {
+            hipLaunchKernelGGL(match_propose_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(match_commit_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+        }
         PALACE_HIP_TRY(hipGetLastError());
         unsigned int changed = 0;
         PALACE_HIP_TRY(hipMemcpyAsync(&changed, ctx->d_small, 4, hipMemcpyDeviceToHost, ctx->stream));
         PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        rounds++;
+        rounds += kBatch;
         if (!changed) break;
-        if (rounds > n_vertices + 2) { set_error("palace_match_greedy: no fixed point"); return PALACE_ESTATE; }
+        if (rounds > n_vertices + 2 + kBatch) { set_error("palace_match_greedy: no fixed point"); return PALACE_ESTATE; }
     }
     if (rounds_out) *rounds_out = rounds;
     return PALACE_OK;
@@ -120,11 +125,24 @@ struct palace_match_result {
 };
 
 namespace palace {
+// Device arrays of one decomposition live in the context's grow-only workspace, behind the two
+// want arrays palace_match_greedy keeps at its start: hipMalloc/hipFree per call would wait for every
+// stream of the device (the eref stream runs beside this one).
+struct Arena {
+    char *base;
+    size_t used;
+    template <class T>
+    T *take(size_t n)
+    {
+        T *p = reinterpret_cast<T *>(base + used);
+        used += (std::max<size_t>(1, n) * sizeof(T) + 255) / 256 * 256;
+        return p;
+    }
+};
 template <class T>
-static int dev_copy(palace_ctx *ctx, const T *h, size_t n, T **d)
+static int dev_copy(palace_ctx *ctx, Arena &ar, const T *h, size_t n, T **d)
 {
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(d), std::max<size_t>(1, n) * sizeof(T));
-    if (e != hipSuccess) { set_error("hipMalloc failed: %s", hipGetErrorString(e)); return PALACE_ENOMEM; }
+    *d = ar.take<T>(n);
     if (n) PALACE_HIP_TRY(hipMemcpyAsync(*d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     return PALACE_OK;
 }
@@ -152,18 +170,22 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
     uint8_t *d_alive = nullptr;
     std::vector<int32_t> next(V), prev(V), narc(V);
     std::vector<uint8_t> alive(V);
-    auto cleanup = [&] {
-        (void)hipStreamSynchronize(ctx->stream);
-        for (void *p : {(void *)d_src, (void *)d_dst, (void *)d_oa, (void *)d_ia, (void *)d_next, (void *)d_prev, (void *)d_narc,
-                        (void *)d_oo, (void *)d_io, (void *)d_alive})
-            if (p) (void)hipFree(p);
-    };
+    const size_t greedy_bytes = (static_cast<size_t>(V) * 8 + 256 + 255) / 256 * 256;
+    const size_t arena_bytes = greedy_bytes + 4 * (static_cast<size_t>(E) * 4 + 256) + 2 * (static_cast<size_t>(V + 1) * 8 + 256) +
+                               3 * (static_cast<size_t>(V) * 4 + 256) + static_cast<size_t>(V) + 256;
+    {
+        int rc = palace::ensure_workspace(ctx, arena_bytes);
+        if (rc) return rc;
+    }
+    palace::Arena ar{static_cast<char *>(ctx->ws.ptr), greedy_bytes};
+    auto cleanup = [&] { (void)hipStreamSynchronize(ctx->stream); };   // host vectors must outlive the copies
 #define TRY_OR_CLEAN(expr) do { int rc__ = (expr); if (rc__) { cleanup(); return rc__; } } while (0)
-    TRY_OR_CLEAN(dev_copy(ctx, src, E, &d_src)); TRY_OR_CLEAN(dev_copy(ctx, dst, E, &d_dst));
-    TRY_OR_CLEAN(dev_copy(ctx, out_arcs.data(), E, &d_oa)); TRY_OR_CLEAN(dev_copy(ctx, in_arcs.data(), E, &d_ia));
-    TRY_OR_CLEAN(dev_copy(ctx, out_off.data(), V + 1, &d_oo)); TRY_OR_CLEAN(dev_copy(ctx, in_off.data(), V + 1, &d_io));
-    TRY_OR_CLEAN(dev_copy(ctx, next.data(), V, &d_next)); TRY_OR_CLEAN(dev_copy(ctx, prev.data(), V, &d_prev));
-    TRY_OR_CLEAN(dev_copy(ctx, narc.data(), V, &d_narc)); TRY_OR_CLEAN(dev_copy(ctx, alive.data(), V, &d_alive));
+    TRY_OR_CLEAN(dev_copy(ctx, ar, src, E, &d_src)); TRY_OR_CLEAN(dev_copy(ctx, ar, dst, E, &d_dst));
+    TRY_OR_CLEAN(dev_copy(ctx, ar, out_arcs.data(), E, &d_oa)); TRY_OR_CLEAN(dev_copy(ctx, ar, in_arcs.data(), E, &d_ia));
+    TRY_OR_CLEAN(dev_copy(ctx, ar, out_off.data(), V + 1, &d_oo)); TRY_OR_CLEAN(dev_copy(ctx, ar, in_off.data(), V + 1, &d_io));
+    d_next = ar.take<int32_t>(V); d_prev = ar.take<int32_t>(V); d_narc = ar.take<int32_t>(V);   // written by match_init_kernel
+    d_alive = ar.take<uint8_t>(V);
+    if (ar.used > arena_bytes) { palace::set_error("decompose: arena accounting"); cleanup(); return PALACE_ESTATE; }
 
     std::vector<int64_t> left(copies, copies + n_segs);
     for (auto &c : left) c = std::max<int64_t>(1, c);
