@@ -82,7 +82,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
 /* Tuning / test hook for count_reads: mode 0 = automatic (binned LDS counting for large inputs,
  * direct global atomics for tiny ones), 1 = always direct, 2 = always binned; bucket_cap > 0
  * overrides the per-bucket capacity of the binned path (keys beyond it take the direct path);
- * modes 10..12 select the binning tile shape (tuning); mode 13 sets the slab size in bases
+ * mode 13 sets the slab size in bases
  * (bucket_cap = bases, multiple of 64; 0 = default 2^30) that large read sets are processed in. */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap);
 

@@ -63,7 +63,6 @@ struct palace_ctx {
     int64_t bin_cap_override = 0;
     int bin_dbg = 0;
     int64_t slab_override = 0;
-    int bin_variant = 0;            // 0: 512 threads x 64-slot rows (4 workgroups per CU), 1: 1024 x 256, 2: 512 x 128
     palace::Workspace ws;      // grow-only scratch
     uint64_t *d_small = nullptr;   // 64 x u64 scratch for reductions
 };

@@ -138,18 +138,22 @@ __global__ __launch_bounds__(256) void eref_count_kernel(const uint8_t *__restri
 // E4, binned path: no global atomics on the table.  Two radix-partition levels of 7 bits each
 // bring every key into one of 2^14 fine buckets (key >> 18), then one workgroup per bucket counts
 // in LDS.
-//   bin1 kernel   a workgroup owns a tile of reads (~22 K keys).  Each key is appended to its
-//                 level-1 bucket's 256-slot staging row in LDS (LDS atomicAdd on 128 counters).
-//                 At the end one thread per bucket reserves the row's run in the bucket's global
-//                 region with ONE global atomicAdd and the rows are copied out -- contiguous, so the
-//                 stores coalesce into whole lines (the point of staging: 4-byte stores scattered
-//                 over 16 Ki destinations do not combine in L2, measured 21 ms vs 3 ms).
-//   bin2 kernel   the same step over a level-1 bucket's keys, on key bits 24..18.
+//   bin1 kernel   a workgroup owns a tile of the base stream (~5 K keys).  Each key is appended to its
+//                 level-1 bucket's staging row in LDS (one 64-bit LDS atomic returns slot and row end).
+//                 At the end a lane per row reserves the row's run in the bucket's global region with
+//                 ONE global atomicAdd and the rows are copied out -- contiguous, so the stores
+//                 coalesce into whole lines (4-byte stores scattered over 16 Ki destinations do not
+//                 combine in L2: measured 21 ms vs 3 ms).
+//   bin2 kernel   the same step over a level-1 region's keys, on key bits 24..18.
 //   count kernel  one workgroup per fine bucket: its 2^18-key slice of the three planes
 //                 (3 x 32 KiB) lives in LDS, is seeded from the global planes, takes the bucket's keys
 //                 with LDS atomicOr climbing 1 -> 2 -> 3, and is written back with 16-byte stores.
-// A key that finds its staging row or its bucket region full takes the global atomicOr path, so
-// the result stays exact for any input; with hash-like keys that never happens (row mean 178 of 256).
+// The canonical index is min(forward, reverse complement) of two hash-like 32-bit words, so for ANY
+// input its density over the key space is 2(1-x): level-1 bucket 0 receives twice the mean, bucket
+// 127 almost nothing.  Staging rows, level-1 regions and fine-bucket regions are therefore sized
+// by that density (a constant pad plus a share proportional to 255-2b), not uniformly.
+// A key that finds its staging row or its region full takes the global atomicOr path, so the
+// result stays exact for any input.
 // Traffic per key: 4 B x (write, read, write, read) instead of ~52 B of memory-side atomic requests.
 // ------------------------------------------------------------------------------------------
 constexpr int kBucketBits = 14;
@@ -158,8 +162,31 @@ constexpr int kBucketShift = 32 - kBucketBits;        // 18: keys per fine bucke
 constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 per plane per bucket
 constexpr int kL1Buckets = 128, kL1Shift = 25;        // level 1: key >> 25
 constexpr int kFlatMaxChunks = 6;                     // 64-position chunks one wave walks in the flat bin1 kernel
-constexpr int kL1Replicas = 32;                        // level-1 bucket regions are split 32 ways so that the
+constexpr int kL1Replicas = 32;                       // level-1 bucket regions are split 32 ways so that the
                                                       // per-tile reservations do not pile onto 128 addresses
+constexpr int kBinThreads = 512;                      // 8 waves; 33 KiB of LDS -> 4 workgroups per CU
+constexpr int kRowSlots = 64;                         // mean staging row
+constexpr int kStageSlots = kL1Buckets * kRowSlots;   // 8192 keys staged per workgroup
+constexpr int kRowPad = 8;                            // density-independent part of a level-1 row
+constexpr int kTileKeys = kStageSlots * 7 / 10;       // a tile fills about 70 % of the staging area
+
+// Capacity of the slot range that belongs to level-1 bucket b when a total is shared out by the key
+// density: prefix(b) = pad*b + share*b*(256-b)/128, capacity(b) = prefix(b+1) - prefix(b)
+//        = pad + share*(255-2b)/128 (up to rounding); prefix(128) = 128*(pad + share).
+struct DensityCaps {
+    uint64_t share;      // mean capacity handed out by density
+    uint32_t pad;        // flat capacity every bucket gets
+    __host__ __device__ uint64_t prefix(uint32_t b) const { return static_cast<uint64_t>(pad) * b + ((share * (b * (256u - b))) >> 7); }
+    __host__ __device__ uint32_t cap(uint32_t b) const { return static_cast<uint32_t>(prefix(b + 1) - prefix(b)); }
+};
+
+// first staging slot of level-1 row b (b = 128: total), rows sized by density
+__host__ __device__ constexpr uint32_t l1_row_start(uint32_t b)
+{
+    return kRowPad * b + (((kRowSlots - kRowPad) * b * (256u - b)) >> 7);
+}
+static_assert(l1_row_start(kL1Buckets) == kStageSlots, "rows tile the staging area");
+static_assert(l1_row_start(1) <= 128, "a row is copied out in at most two 64-lane passes");
 
 template <class F>
 __device__ __forceinline__ void for_each_key(const uint8_t *__restrict__ s, int64_t len, int lane,
@@ -183,77 +210,122 @@ __device__ __forceinline__ void for_each_key(const uint8_t *__restrict__ s, int6
     }
 }
 
-template <int T, int S>
-struct BinVariant {
-    static constexpr int threads = T, slots = S;
-    // tile = about 70 % of the staging capacity (128 rows x S slots)
-    static constexpr int keys_per_thread = (kL1Buckets * S * 7 / 10) / T;
-};
-
 struct BinOut {
-    unsigned int *cursor;          // per destination bucket: keys reserved so far
-    uint32_t *buf;                 // bucket b owns buf[b * cap .. b * cap + cap)
-    uint32_t cap;
+    unsigned int *cursor;          // per destination region: keys reserved so far
+    uint32_t *buf;                 // destination regions, laid out by `caps`
+    DensityCaps caps;              // capacity of a destination region of level-1 bucket b
     uint32_t *p1, *p2, *p3;        // overflow path
     int dbg;                       // timing experiments only: 1 skip stores, 2 skip reservations, 4 skip staging
     unsigned long long *stamps;    // diagnostic: per-phase cycle sums (null in production)
 };
 
-// stage -> reserve -> copy out; `bucket0` is the first destination bucket of this workgroup's 128
-template <int THREADS, int SLOTS>
-__device__ __forceinline__ void flush_rows(uint32_t *stage, unsigned int *cnt, unsigned int *gbase,
-                                           uint32_t bucket0, uint32_t stride, const BinOut &o)
+// Level-1 regions: the kL1Replicas regions of bucket b lie side by side, buckets in order.
+__device__ __forceinline__ uint64_t l1_region_base(const DensityCaps &c, uint32_t b, uint32_t replica)
 {
+    return c.prefix(b) * kL1Replicas + static_cast<uint64_t>(replica) * c.cap(b);
+}
+// Fine-bucket regions: the 128 fine buckets of level-1 bucket b1 lie side by side, equal capacity.
+__device__ __forceinline__ uint64_t fine_region_base(const DensityCaps &c, uint32_t b1, uint32_t sub)
+{
+    return c.prefix(b1) * kL1Buckets + static_cast<uint64_t>(sub) * c.cap(b1);
+}
+
+// The staging area: rows[b] = (row end << 32) | next free slot, so ONE 64-bit LDS atomic hands a key
+// its slot and tells it whether the row is full.
+struct Stage {
+    uint32_t slot[kStageSlots];
+    unsigned long long rows[kL1Buckets];
+    uint32_t start[kL1Buckets + 1];
+};
+
+__device__ __forceinline__ void stage_append(Stage &st, uint32_t row, uint32_t key, const BinOut &o)
+{
+    const unsigned long long r = atomicAdd(&st.rows[row], 1ull);
+    const uint32_t at = static_cast<uint32_t>(r), end = static_cast<uint32_t>(r >> 32);
+    if (at < end) st.slot[at] = key;
+    else count_key(key, o.p1, o.p2, o.p3);                    // row full: exact slow path
+}
+
+// stage -> reserve -> copy out.  `dest(row)` names the row's destination: region index (cursor slot),
+// first key of the region in o.buf, region capacity.
+struct Dest { uint32_t region; uint64_t base; uint32_t cap; };
+
+template <class D>
+__device__ __forceinline__ void flush_rows(Stage &st, const BinOut &o, D dest)
+{
+    constexpr int rows_per_wave = kL1Buckets / (kBinThreads / 64);
     __syncthreads();
     const unsigned long long f0 = (PALACE_STAMPS && o.stamps) ? wall_clock64() : 0ull;
-    if (threadIdx.x < kL1Buckets) {
-        const unsigned int c = min(cnt[threadIdx.x], static_cast<unsigned int>(SLOTS));
-        cnt[threadIdx.x] = c;
-        if (PALACE_STAMPS && (o.dbg & 2)) gbase[threadIdx.x] = (blockIdx.x % 1024u) * SLOTS;    // ablation: no reservation
-        else gbase[threadIdx.x] = c ? atomicAdd(&o.cursor[bucket0 + threadIdx.x * stride], c) : 0u;
+    // The first lanes of a wave reserve the runs of the wave's 16 rows (all atomics in flight together);
+    // the wave then walks its rows with count, source, destination and capacity in SGPRs (v_readlane).
+    const int lane = threadIdx.x & 63;
+    const int row0 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) * rows_per_wave;
+    uint32_t c = 0, s0 = 0, g = 0, cap = 0, base_lo = 0, base_hi = 0;
+    if (lane < rows_per_wave) {
+        const uint32_t row = row0 + lane;
+        const unsigned long long r = st.rows[row];
+        s0 = st.start[row];
+        c = min(static_cast<uint32_t>(r), static_cast<uint32_t>(r >> 32)) - s0;
+        const Dest d = dest(row);
+        cap = d.cap; base_lo = static_cast<uint32_t>(d.base); base_hi = static_cast<uint32_t>(d.base >> 32);
+        if (PALACE_STAMPS && (o.dbg & 2)) g = (blockIdx.x % 64u) * kRowSlots;                  // ablation: no reservation
+        else if (c) g = atomicAdd(&o.cursor[d.region], c);
     }
-    __syncthreads();
     const unsigned long long f1 = (PALACE_STAMPS && o.stamps) ? wall_clock64() : 0ull;
-    if (PALACE_STAMPS && o.stamps && threadIdx.x == 0) atomicAdd(&o.stamps[3], f1 - f0);   // reservation phase (atomic + barrier)
-    for (int sidx = threadIdx.x; sidx < kL1Buckets * SLOTS; sidx += THREADS) {
-        const int b = sidx / SLOTS, p = sidx % SLOTS;
-        if (p < static_cast<int>(cnt[b])) {
-            const uint32_t k = stage[sidx];
-            const unsigned int g = gbase[b] + p;
+    if (PALACE_STAMPS && o.stamps && threadIdx.x == 0) atomicAdd(&o.stamps[3], f1 - f0);   // reservation issue
+#pragma unroll
+    for (int j = 0; j < rows_per_wave; j++) {
+        const uint32_t cj = __builtin_amdgcn_readlane(c, j), sj = __builtin_amdgcn_readlane(s0, j),
+                       gj = __builtin_amdgcn_readlane(g, j), capj = __builtin_amdgcn_readlane(cap, j);
+        const uint32_t bl = __builtin_amdgcn_readlane(base_lo, j), bh = __builtin_amdgcn_readlane(base_hi, j);   // (the builtin returns int)
+        uint32_t *dst = o.buf + ((static_cast<uint64_t>(bh) << 32) | bl) + gj;
+        for (uint32_t p = lane; p < cj; p += 64) {             // a row is at most 128 slots: two passes
+            const uint32_t k = st.slot[sj + p];
             if (PALACE_STAMPS && (o.dbg & 1)) continue;
-            if (g < o.cap) o.buf[static_cast<size_t>(bucket0 + b * stride) * o.cap + g] = k;
-            else count_key(k, o.p1, o.p2, o.p3);           // bucket region full: exact slow path
+            if (gj + p < capj) dst[p] = k;
+            else count_key(k, o.p1, o.p2, o.p3);               // region full: exact slow path
         }
     }
     if (PALACE_STAMPS && o.stamps && threadIdx.x == 0) atomicAdd(&o.stamps[4], wall_clock64() - f1);   // store loop (issue only)
 }
 
-template <int THREADS, int SLOTS>
-__global__ __launch_bounds__(THREADS) void eref_bin1_kernel(const uint8_t *__restrict__ bases,
+// rows sized by density (level 1) or all equal (level 2)
+__device__ __forceinline__ void stage_init(Stage &st, bool by_density)
+{
+    if (threadIdx.x <= kL1Buckets) {
+        const uint32_t b = threadIdx.x;
+        const uint32_t s0 = by_density ? l1_row_start(b) : b * kRowSlots;
+        st.start[b] = s0;
+        if (b < kL1Buckets) {
+            const uint32_t s1 = by_density ? l1_row_start(b + 1) : (b + 1) * kRowSlots;
+            st.rows[b] = (static_cast<unsigned long long>(s1) << 32) | s0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBinThreads) void eref_bin1_kernel(const uint8_t *__restrict__ bases,
                                                                 const int64_t *__restrict__ offsets,
                                                                 int64_t n_reads,
                                                                 const uint8_t *__restrict__ keep,
                                                                 CoderMasks masks, int reads_per_tile, BinOut o)
 {
-    __shared__ uint32_t stage[kL1Buckets * SLOTS];
-    __shared__ unsigned int cnt[kL1Buckets], gbase[kL1Buckets];
+    __shared__ Stage st;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int n_waves = THREADS / 64;
-    if (threadIdx.x < kL1Buckets) cnt[threadIdx.x] = 0;
+    constexpr int n_waves = kBinThreads / 64;
+    stage_init(st, true);
     __syncthreads();
     const int64_t r0 = static_cast<int64_t>(blockIdx.x) * reads_per_tile;
     const int64_t r1 = min(n_reads, r0 + reads_per_tile);
     for (int64_t r = r0 + wave; r < r1; r += n_waves) {
         if (keep && !keep[r]) continue;
         const int64_t beg = offsets[r];
-        for_each_key(bases + beg, offsets[r + 1] - beg, lane, masks, [&](uint32_t k) {
-            const uint32_t b = k >> kL1Shift;
-            const unsigned int pos = atomicAdd(&cnt[b], 1u);
-            if (pos < SLOTS) stage[b * SLOTS + pos] = k;
-            else count_key(k, o.p1, o.p2, o.p3);           // row full: exact slow path
-        });
+        for_each_key(bases + beg, offsets[r + 1] - beg, lane, masks,
+                     [&](uint32_t k) { stage_append(st, k >> kL1Shift, k, o); });
     }
-    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, blockIdx.x % kL1Replicas, kL1Replicas, o);   // region = bucket * 32 + replica
+    const uint32_t replica = blockIdx.x % kL1Replicas;
+    flush_rows(st, o, [&](uint32_t row) {
+        return Dest{row * kL1Replicas + replica, l1_region_base(o.caps, row, replica), o.caps.cap(row)};
+    });
 }
 
 // Read ends as a bit per base position (bit p set <=> position p is the last base of a read), so
@@ -271,21 +343,19 @@ __global__ void mark_read_ends_kernel(const int64_t *__restrict__ offsets, int64
 // bin1 without per-read work: the concatenated bases are one stream; a wave walks consecutive
 // 64-position chunks (one coalesced byte load per chunk, no dependent loads), windows that would
 // cross a read end are masked with the end bits.  Used when no keep mask is given.
-template <int THREADS, int SLOTS>
-__global__ __launch_bounds__(THREADS) void eref_bin1_flat_kernel(const uint8_t *__restrict__ all_bases,
-                                                                 const int64_t *__restrict__ offsets, int64_t total,
-                                                                 int64_t chunk_lo, int64_t chunk_hi,
-                                                                 const unsigned long long *__restrict__ ends,
-                                                                 CoderMasks masks, int chunks_per_wave, BinOut o)
+__global__ __launch_bounds__(kBinThreads) void eref_bin1_flat_kernel(const uint8_t *__restrict__ all_bases,
+                                                                     const int64_t *__restrict__ offsets, int64_t total,
+                                                                     int64_t chunk_lo, int64_t chunk_hi,
+                                                                     const unsigned long long *__restrict__ ends,
+                                                                     CoderMasks masks, int chunks_per_wave, BinOut o)
 {
-    __shared__ uint32_t stage[kL1Buckets * SLOTS];
-    __shared__ unsigned int cnt[kL1Buckets], gbase[kL1Buckets];
+    __shared__ Stage st;
     __shared__ unsigned long long dbg_first_start, dbg_last_start, dbg_last_end;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int n_waves = THREADS / 64;
+    constexpr int n_waves = kBinThreads / 64;
     const unsigned long long t_begin = (PALACE_STAMPS && o.stamps) ? wall_clock64() : 0ull;
     if (PALACE_STAMPS && o.stamps && threadIdx.x == 0) { dbg_first_start = ~0ull; dbg_last_start = 0; dbg_last_end = 0; }
-    if (threadIdx.x < kL1Buckets) cnt[threadIdx.x] = 0;
+    stage_init(st, true);
     __syncthreads();
     const uint8_t *bases = all_bases + offsets[0];      // the read set starts at its first offset
     const int64_t n_chunks = (total + 63) >> 6;
@@ -293,8 +363,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_flat_kernel(const uint8_t *
     const int64_t c1 = min(chunk_hi, c0 + chunks_per_wave);       // windows starting in [chunk_lo, chunk_hi) chunks
     if (c0 < c1) {
         // Every load of this wave's chunk range -- base bytes AND read-end words -- is issued before the
-        // first use (the loop used to pay two dependent memory round trips per 64 positions), and the
-        // three LDS row appends of a position are issued together before their results are used.
+        // first use (the loop used to pay two dependent memory round trips per 64 positions).
         uint32_t ch[kFlatMaxChunks + 1];
         unsigned long long en[kFlatMaxChunks + 1];
 #pragma unroll
@@ -319,12 +388,14 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_flat_kernel(const uint8_t *
                 kmer_keys(masks, window32(lo.p0, hi.p0, lane), window32(lo.p1, hi.p1, lane),
                           window32(lo.p2, hi.p2, lane), key);
                 if (!(PALACE_STAMPS && (o.dbg & 4))) {
-                    unsigned int pos[3];
+                    // the three row appends of a position are issued together before their results are used
+                    unsigned long long r[3];
 #pragma unroll
-                    for (int i = 0; i < 3; i++) pos[i] = atomicAdd(&cnt[key[i] >> kL1Shift], 1u);
+                    for (int i = 0; i < 3; i++) r[i] = atomicAdd(&st.rows[key[i] >> kL1Shift], 1ull);
 #pragma unroll
                     for (int i = 0; i < 3; i++) {
-                        if (pos[i] < SLOTS) stage[(key[i] >> kL1Shift) * SLOTS + pos[i]] = key[i];
+                        const uint32_t at = static_cast<uint32_t>(r[i]);
+                        if (at < static_cast<uint32_t>(r[i] >> 32)) st.slot[at] = key[i];
                         else count_key(key[i], o.p1, o.p2, o.p3);
                     }
                 }
@@ -337,7 +408,10 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_flat_kernel(const uint8_t *
         atomicMin(&dbg_first_start, t_begin); atomicMax(&dbg_last_start, t_begin); atomicMax(&dbg_last_end, t_mid);
         atomicAdd(&o.stamps[8 + wave], t_mid - t_begin);
     }
-    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, blockIdx.x % kL1Replicas, kL1Replicas, o);
+    const uint32_t replica = blockIdx.x % kL1Replicas;
+    flush_rows(st, o, [&](uint32_t row) {
+        return Dest{row * kL1Replicas + replica, l1_region_base(o.caps, row, replica), o.caps.cap(row)};
+    });
     if (PALACE_STAMPS && o.stamps && threadIdx.x == 0) {
         atomicAdd(&o.stamps[5], dbg_last_start - dbg_first_start);   // start skew between the workgroup's waves
         atomicAdd(&o.stamps[6], dbg_last_end - dbg_first_start);     // slowest wave's staging end since first start
@@ -348,41 +422,38 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_flat_kernel(const uint8_t *
     }
 }
 
-template <int THREADS, int SLOTS>
-__global__ __launch_bounds__(THREADS) void eref_bin2_kernel(const unsigned int *__restrict__ cursor1,
-                                                                const uint32_t *__restrict__ buf1, uint32_t cap1,
+// level 2: blockIdx.y = level-1 region (bucket b1, replica), blockIdx.x = tile of its keys
+__global__ __launch_bounds__(kBinThreads) void eref_bin2_kernel(const unsigned int *__restrict__ cursor1,
+                                                                const uint32_t *__restrict__ buf1, DensityCaps caps1,
                                                                 BinOut o)
 {
-    __shared__ uint32_t stage[kL1Buckets * SLOTS];
-    __shared__ unsigned int cnt[kL1Buckets], gbase[kL1Buckets];
-    const uint32_t region = blockIdx.y, b1 = region / kL1Replicas;
-    const uint32_t n1 = min(cursor1[region], cap1);
-    constexpr uint32_t kTileKeys = BinVariant<THREADS, SLOTS>::keys_per_thread * THREADS;
+    __shared__ Stage st;
+    const uint32_t region = blockIdx.y, b1 = region / kL1Replicas, replica = region % kL1Replicas;
+    const uint32_t n1 = min(cursor1[region], caps1.cap(b1));
     const uint32_t start = blockIdx.x * kTileKeys;
     if (start >= n1) return;                               // uniform for the workgroup
     const uint32_t end = min(n1, start + kTileKeys);
-    if (threadIdx.x < kL1Buckets) cnt[threadIdx.x] = 0;
+    stage_init(st, false);
     __syncthreads();
-    const uint32_t *src = buf1 + static_cast<size_t>(region) * cap1;
-    for (uint32_t i = start + threadIdx.x; i < end; i += THREADS) {
+    const uint32_t *src = buf1 + l1_region_base(caps1, b1, replica);
+    for (uint32_t i = start + threadIdx.x; i < end; i += kBinThreads) {
         const uint32_t k = src[i];
-        const uint32_t b = (k >> kBucketShift) & (kL1Buckets - 1);
-        const unsigned int pos = atomicAdd(&cnt[b], 1u);
-        if (pos < SLOTS) stage[b * SLOTS + pos] = k;
-        else count_key(k, o.p1, o.p2, o.p3);
+        stage_append(st, (k >> kBucketShift) & (kL1Buckets - 1), k, o);
     }
-    flush_rows<THREADS, SLOTS>(stage, cnt, gbase, b1 * kL1Buckets, 1u, o);
+    flush_rows(st, o, [&](uint32_t row) {
+        return Dest{b1 * kL1Buckets + row, fine_region_base(o.caps, b1, row), o.caps.cap(b1)};
+    });
 }
 
 __global__ __launch_bounds__(1024) void eref_lds_count_kernel(const unsigned int *__restrict__ cursor,
                                                               const uint32_t *__restrict__ binned,
-                                                              uint32_t cap, uint32_t *__restrict__ p1,
+                                                              DensityCaps caps, uint32_t *__restrict__ p1,
                                                               uint32_t *__restrict__ p2,
                                                               uint32_t *__restrict__ p3)
 {
     __shared__ uint32_t l1[kSliceWords], l2[kSliceWords], l3[kSliceWords];      // 3 x 32 KiB
     const uint32_t b = blockIdx.x;
-    const uint32_t n = min(cursor[b], cap);
+    const uint32_t n = min(cursor[b], caps.cap(b >> 7));
     if (n == 0) return;                                    // uniform for the whole workgroup
     const size_t w0 = static_cast<size_t>(b) * kSliceWords;
     const uint4 *g1 = reinterpret_cast<const uint4 *>(p1 + w0), *g2 = reinterpret_cast<const uint4 *>(p2 + w0),
@@ -393,7 +464,7 @@ __global__ __launch_bounds__(1024) void eref_lds_count_kernel(const unsigned int
         reinterpret_cast<uint4 *>(l3)[i] = g3[i];
     }
     __syncthreads();
-    const uint32_t *keys = binned + static_cast<size_t>(b) * cap;
+    const uint32_t *keys = binned + fine_region_base(caps, b >> 7, b & 127);
     constexpr int kBatch = 8;                              // key loads in flight per thread
     for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kBatch * blockDim.x) {
         uint32_t k[kBatch];
@@ -901,20 +972,26 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     const int64_t kSlabBases = ctx->slab_override > 0 ? ctx->slab_override : (1ll << 30);   // multiple of 64
     const int64_t n_slabs = (total_bases + kSlabBases - 1) / kSlabBases;
     const int64_t slab_bases = std::min(total_bases, kSlabBases);
-    // capacities: 1.25 x the uniform expectation of the key upper bound of one slab, plus slack
-    // (with a keep mask slabs are read ranges of equal count, so allow them to be 1.5 x the mean)
+    // capacities: the key upper bound of one slab shared out by the key density with 20 % head room, plus a
+    // flat pad of 1/8 of the mean and a constant (with a keep mask slabs are read ranges of equal count, so
+    // allow them to be 1.5 x the mean)
     const int64_t max_keys = 3 * (d_keep && n_slabs > 1 ? slab_bases + slab_bases / 2 : slab_bases);
-    int64_t cap2_64 = max_keys / kBuckets + max_keys / (4 * kBuckets) + 2048;
     constexpr int64_t kRegions = static_cast<int64_t>(kL1Buckets) * kL1Replicas;
-    int64_t cap1_64 = max_keys / kRegions + max_keys / (4 * kRegions) + 4096;      // per level-1 region
-    if (ctx->bin_cap_override > 0) { cap2_64 = ctx->bin_cap_override; cap1_64 = ctx->bin_cap_override * 4; }
-    const uint32_t cap1 = static_cast<uint32_t>(cap1_64), cap2 = static_cast<uint32_t>(cap2_64);
+    const int64_t mean1 = max_keys / kRegions, mean2 = max_keys / kBuckets;
+    DensityCaps caps1{static_cast<uint64_t>(mean1 + mean1 / 5), static_cast<uint32_t>(mean1 / 8 + 4096)};   // per level-1 region
+    DensityCaps caps2{static_cast<uint64_t>(mean2 + mean2 / 5), static_cast<uint32_t>(mean2 / 8 + 2048)};   // per fine bucket
+    if (ctx->bin_cap_override > 0) {                       // test hook: uniform, deliberately small regions
+        caps2 = DensityCaps{0, static_cast<uint32_t>(ctx->bin_cap_override)};
+        caps1 = DensityCaps{0, static_cast<uint32_t>(ctx->bin_cap_override * 4)};
+    }
+    PALACE_REQUIRE(caps1.cap(0) < (1u << 31) && caps2.cap(0) < (1u << 31), "slab too large for 32-bit region cursors");
     const size_t cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
     const size_t cur2_bytes = align_up(kBuckets * sizeof(unsigned int), 256);
-    const size_t buf1_bytes = align_up(static_cast<size_t>(kRegions) * cap1 * 4, 256);
+    const size_t buf1_bytes = align_up(static_cast<size_t>(caps1.prefix(kL1Buckets)) * kL1Replicas * 4, 256);
+    const size_t buf2_bytes = align_up(static_cast<size_t>(caps2.prefix(kL1Buckets)) * kL1Buckets * 4, 256);
     const int64_t n_chunks = (total_bases + 63) / 64;
     const size_t ends_bytes = align_up(static_cast<size_t>(n_chunks + 2) * 8, 256);
-    rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + ends_bytes + buf1_bytes + static_cast<size_t>(kBuckets) * cap2 * 4);
+    rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + ends_bytes + buf1_bytes + buf2_bytes);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
     unsigned int *cursor1 = reinterpret_cast<unsigned int *>(ws); ws += cur1_bytes;
@@ -923,8 +1000,8 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
     uint32_t *buf2 = reinterpret_cast<uint32_t *>(ws);
     unsigned long long *stamps = (PALACE_STAMPS && (ctx->bin_dbg & 8)) ? reinterpret_cast<unsigned long long *>(ctx->d_small) + 8 : nullptr;
-    BinOut o1{cursor1, buf1, cap1, ctx->plane[0], ctx->plane[1], ctx->plane[2], ctx->bin_dbg & 7, stamps};
-    BinOut o2{cursor2, buf2, cap2, ctx->plane[0], ctx->plane[1], ctx->plane[2], 0, nullptr};
+    BinOut o1{cursor1, buf1, caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], ctx->bin_dbg & 7, stamps};
+    BinOut o2{cursor2, buf2, caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2], 0, nullptr};
     if (!d_keep) {                                   // read ends as a bit per position, once for the whole set
         PALACE_HIP_TRY(hipMemsetAsync(ends, 0, static_cast<size_t>(n_chunks + 1) * 8, ctx->stream));
         hipLaunchKernelGGL(mark_read_ends_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
@@ -932,52 +1009,41 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         PALACE_HIP_TRY(hipGetLastError());
     }
     const int64_t keys_per_read = std::max<int64_t>(1, 3 * (total_bases / n_reads - 31));
-    auto launch_slab = [&](auto variant, int64_t slab) -> int {
-        constexpr int THREADS = decltype(variant)::threads, SLOTS = decltype(variant)::slots;
-        constexpr int64_t tile_keys = static_cast<int64_t>(THREADS) * decltype(variant)::keys_per_thread;
-        constexpr int waves = THREADS / 64;
+    constexpr int waves = kBinThreads / 64;
+    for (int64_t slab = 0; slab < n_slabs; slab++) {
         PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes, ctx->stream));
         if (d_keep) {
-            // per-read kernel over this slab's share of the reads; a tile holds about tile_keys keys
+            // per-read kernel over this slab's share of the reads; a tile holds about kTileKeys keys
             const int64_t r_lo = n_reads * slab / n_slabs, r_hi = n_reads * (slab + 1) / n_slabs;
-            int64_t rpt = std::max<int64_t>(1, tile_keys / keys_per_read);
+            int64_t rpt = std::max<int64_t>(1, kTileKeys / keys_per_read);
             if (rpt >= waves) rpt -= rpt % waves;
             rpt = std::min<int64_t>(rpt, 1 << 20);
             const int64_t tiles = (r_hi - r_lo + rpt - 1) / rpt;
             PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
             if (tiles > 0)
-                hipLaunchKernelGGL((eref_bin1_kernel<THREADS, SLOTS>), dim3(static_cast<unsigned>(tiles)), dim3(THREADS), 0,
+                hipLaunchKernelGGL(eref_bin1_kernel, dim3(static_cast<unsigned>(tiles)), dim3(kBinThreads), 0,
                                    ctx->stream, d_bases, d_offsets + r_lo, r_hi - r_lo, d_keep + r_lo, ctx->masks,
                                    static_cast<int>(rpt), o1);
         } else {
-            // flat stream: tiles of (waves x chunks_per_wave) 64-position chunks sized to about tile_keys keys
+            // flat stream: tiles of (waves x chunks_per_wave) 64-position chunks sized to about kTileKeys keys
             const int64_t c_lo = slab * (kSlabBases / 64), c_hi = std::min(n_chunks, (slab + 1) * (kSlabBases / 64));
             const double keys_per_pos = std::max(0.05, static_cast<double>(keys_per_read) /
                                                            std::max<double>(1.0, static_cast<double>(total_bases) / n_reads));
-            int cpw = static_cast<int>(static_cast<double>(tile_keys) / (keys_per_pos * 64.0 * waves));
+            int cpw = static_cast<int>(static_cast<double>(kTileKeys) / (keys_per_pos * 64.0 * waves));
             cpw = std::max(1, std::min(cpw, kFlatMaxChunks));
             const int64_t flat_tiles = (c_hi - c_lo + static_cast<int64_t>(waves) * cpw - 1) / (static_cast<int64_t>(waves) * cpw);
             PALACE_REQUIRE(flat_tiles < (1ll << 31), "too many tiles for one launch");
-            hipLaunchKernelGGL((eref_bin1_flat_kernel<THREADS, SLOTS>), dim3(static_cast<unsigned>(flat_tiles)), dim3(THREADS),
+            hipLaunchKernelGGL(eref_bin1_flat_kernel, dim3(static_cast<unsigned>(flat_tiles)), dim3(kBinThreads),
                                0, ctx->stream, d_bases, d_offsets, total_bases, c_lo, c_hi, ends, ctx->masks, cpw, o1);
         }
         PALACE_HIP_TRY(hipGetLastError());
-        const unsigned tiles2 = static_cast<unsigned>((static_cast<int64_t>(cap1) + tile_keys - 1) / tile_keys);
-        hipLaunchKernelGGL((eref_bin2_kernel<THREADS, SLOTS>), dim3(tiles2, static_cast<unsigned>(kRegions)), dim3(THREADS), 0, ctx->stream,
-                           cursor1, buf1, cap1, o2);
+        const unsigned tiles2 = static_cast<unsigned>((static_cast<int64_t>(caps1.cap(0)) + kTileKeys - 1) / kTileKeys);
+        hipLaunchKernelGGL(eref_bin2_kernel, dim3(tiles2, static_cast<unsigned>(kRegions)), dim3(kBinThreads), 0, ctx->stream,
+                           cursor1, buf1, caps1, o2);
         PALACE_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, cursor2, buf2, cap2,
+        hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, cursor2, buf2, caps2,
                            ctx->plane[0], ctx->plane[1], ctx->plane[2]);
         PALACE_HIP_TRY(hipGetLastError());
-        return PALACE_OK;
-    };
-    for (int64_t slab = 0; slab < n_slabs; slab++) {
-        switch (ctx->bin_variant) {             // measured at the 1M-contig size: 512x64 (4 workgroups per CU) fastest
-        case 1: rc = launch_slab(BinVariant<1024, 256>{}, slab); break;
-        case 2: rc = launch_slab(BinVariant<512, 128>{}, slab); break;
-        default: rc = launch_slab(BinVariant<512, 64>{}, slab); break;
-        }
-        if (rc) return rc;
     }
     return PALACE_OK;
 }
@@ -986,12 +1052,11 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
  * bucket_cap > 0 overrides the per-bucket capacity (to exercise the overflow path). */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap)
 {
-    if (ctx && mode >= 10 && mode <= 12) { ctx->bin_variant = mode - 10; return PALACE_OK; }
     if (ctx && mode == 13) {                      // test hook: slab size in bases (0 = default 2^30), multiple of 64
         PALACE_REQUIRE(bucket_cap >= 0 && bucket_cap % 64 == 0, "slab size must be a multiple of 64");
         ctx->slab_override = bucket_cap;
         return PALACE_OK;
-    }   // tuning: tile shape
+    }
     if (PALACE_STAMPS && ctx && mode >= 20 && mode < 36) { ctx->bin_dbg = mode - 20; return PALACE_OK; }   // diagnostic builds only
     PALACE_REQUIRE(ctx && mode >= 0 && mode <= 2 && bucket_cap >= 0 && bucket_cap < (1ll << 31), "bad argument");
     ctx->count_mode = mode;

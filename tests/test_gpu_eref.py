@@ -250,9 +250,10 @@ def test_properties_full_size(ctx):
         buf.free()
 
 
-@pytest.mark.parametrize("mode,cap", [(2, 0), (2, 64), (2, 1)])
+@pytest.mark.parametrize("mode,cap", [(2, 0), (2, 64), (2, 1), (2, 140000)])
 def test_binned_path_equals_oracle(ctx, golden_eref, mode, cap):
-    """LDS-binned counting (forced on small inputs), incl. bucket overflow into the direct path."""
+    """LDS-binned counting (forced on small inputs), incl. bucket overflow into the direct path; cap 140000 puts
+    the upper regions beyond 2^31 keys / 2^33 bytes of the workspace (64-bit region addressing)."""
     g = golden_eref
     cc = orc.header_to_cc(g["index_header"])
     rng = synth.rng_for(13)
