@@ -168,15 +168,16 @@ constexpr int kBinThreads = 512;                      // 8 waves; 33 KiB of LDS 
 constexpr int kRowSlots = 64;                         // mean staging row
 constexpr int kStageSlots = kL1Buckets * kRowSlots;   // 8192 keys staged per workgroup
 constexpr int kRowPad = 8;                            // density-independent part of a level-1 row
-constexpr int kTileKeys = kStageSlots * 7 / 10;       // a tile fills about 70 % of the staging area
+constexpr int kTileKeys = kBinThreads * 11;           // a tile fills about 70 % of the staging area; multiple of 4
 
 // Capacity of the slot range that belongs to level-1 bucket b when a total is shared out by the key
 // density: prefix(b) = pad*b + share*b*(256-b)/128, capacity(b) = prefix(b+1) - prefix(b)
 //        = pad + share*(255-2b)/128 (up to rounding); prefix(128) = 128*(pad + share).
 struct DensityCaps {
-    uint64_t share;      // mean capacity handed out by density
-    uint32_t pad;        // flat capacity every bucket gets
-    __host__ __device__ uint64_t prefix(uint32_t b) const { return static_cast<uint64_t>(pad) * b + ((share * (b * (256u - b))) >> 7); }
+    uint64_t share;      // mean capacity handed out by density, in units of 4 keys
+    uint32_t pad;        // flat capacity every bucket gets, in units of 4 keys
+    // multiples of 4 keys, so that regions start on 16-byte boundaries
+    __host__ __device__ uint64_t prefix(uint32_t b) const { return 4 * (static_cast<uint64_t>(pad) * b + ((share * (b * (256u - b))) >> 7)); }
     __host__ __device__ uint32_t cap(uint32_t b) const { return static_cast<uint32_t>(prefix(b + 1) - prefix(b)); }
 };
 
@@ -422,23 +423,86 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin1_flat_kernel(const uint8
     }
 }
 
-// level 2: blockIdx.y = level-1 region (bucket b1, replica), blockIdx.x = tile of its keys
+// Work list of level 2: one entry (tile << 12 | region) per kTileKeys keys that level 1 actually left in a
+// region, so that bin2 launches no empty workgroups (capacities are ~1.6 x the contents, and uneven).
+// One workgroup; thread t owns regions 4t .. 4t+3.
+__global__ __launch_bounds__(1024) void eref_tile_map_kernel(const unsigned int *__restrict__ cursor1, DensityCaps caps1,
+                                                             uint32_t *__restrict__ tile_map, uint32_t map_cap,
+                                                             unsigned int *__restrict__ n_tiles)
+{
+    static_assert(kL1Buckets * kL1Replicas == 4096, "region id is packed into 12 bits; 4 regions per thread");
+    __shared__ uint32_t wave_sum[16];
+    uint32_t t[4], mine = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t region = threadIdx.x * 4 + i;
+        const uint32_t n = min(cursor1[region], caps1.cap(region / kL1Replicas));
+        t[i] = (n + kTileKeys - 1) / kTileKeys;
+        mine += t[i];
+    }
+    uint32_t incl = mine;                                   // inclusive scan inside the wave, then over the 16 waves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < 16; w++) {
+        if (w < wave) before += wave_sum[w];
+        total += wave_sum[w];
+    }
+    uint32_t at = before + incl - mine;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        for (uint32_t k = 0; k < t[i]; k++, at++)
+            if (at < map_cap) tile_map[at] = (k << 12) | (threadIdx.x * 4 + i);
+    if (threadIdx.x == 0) *n_tiles = min(total, map_cap);
+}
+
+// level 2: one workgroup per work-list entry = kTileKeys keys of one level-1 region (bucket b1, replica)
 __global__ __launch_bounds__(kBinThreads) void eref_bin2_kernel(const unsigned int *__restrict__ cursor1,
                                                                 const uint32_t *__restrict__ buf1, DensityCaps caps1,
-                                                                BinOut o)
+                                                                const uint32_t *__restrict__ tile_map,
+                                                                const unsigned int *__restrict__ n_tiles, BinOut o)
 {
     __shared__ Stage st;
-    const uint32_t region = blockIdx.y, b1 = region / kL1Replicas, replica = region % kL1Replicas;
+    if (blockIdx.x >= *n_tiles) return;                    // uniform for the workgroup
+    const uint32_t entry = tile_map[blockIdx.x];
+    const uint32_t region = entry & 4095u, b1 = region / kL1Replicas, replica = region % kL1Replicas;
     const uint32_t n1 = min(cursor1[region], caps1.cap(b1));
-    const uint32_t start = blockIdx.x * kTileKeys;
-    if (start >= n1) return;                               // uniform for the workgroup
+    const uint32_t start = (entry >> 12) * kTileKeys;
     const uint32_t end = min(n1, start + kTileKeys);
     stage_init(st, false);
     __syncthreads();
-    const uint32_t *src = buf1 + l1_region_base(caps1, b1, replica);
-    for (uint32_t i = start + threadIdx.x; i < end; i += kBinThreads) {
-        const uint32_t k = src[i];
-        stage_append(st, (k >> kBucketShift) & (kL1Buckets - 1), k, o);
+    // all of a thread's keys are loaded (16 bytes at a time: regions and tiles start on 16-byte boundaries and
+    // capacities are multiples of 4 keys, so a vector may run past n1 but not past the region) before the first
+    // append: the kernel is latency-bound with one load in flight per wave
+    const uint4 *src = reinterpret_cast<const uint4 *>(buf1 + l1_region_base(caps1, b1, replica));
+    constexpr int kVecs = (kTileKeys + 4 * kBinThreads - 1) / (4 * kBinThreads);
+    uint4 v[kVecs];
+#pragma unroll
+    for (int it = 0; it < kVecs; it++) {
+        const uint32_t i = start + (it * kBinThreads + threadIdx.x) * 4;
+        v[it] = i < end ? src[i >> 2] : uint4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int it = 0; it < kVecs; it++) {
+        const uint32_t i = start + (it * kBinThreads + threadIdx.x) * 4;
+        const uint32_t k[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+        unsigned long long r[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (i + e < end) r[e] = atomicAdd(&st.rows[(k[e] >> kBucketShift) & (kL1Buckets - 1)], 1ull);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (i + e < end) {
+                const uint32_t at = static_cast<uint32_t>(r[e]);
+                if (at < static_cast<uint32_t>(r[e] >> 32)) st.slot[at] = k[e];
+                else count_key(k[e], o.p1, o.p2, o.p3);
+            }
     }
     flush_rows(st, o, [&](uint32_t row) {
         return Dest{b1 * kL1Buckets + row, fine_region_base(o.caps, b1, row), o.caps.cap(b1)};
@@ -978,11 +1042,11 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     const int64_t max_keys = 3 * (d_keep && n_slabs > 1 ? slab_bases + slab_bases / 2 : slab_bases);
     constexpr int64_t kRegions = static_cast<int64_t>(kL1Buckets) * kL1Replicas;
     const int64_t mean1 = max_keys / kRegions, mean2 = max_keys / kBuckets;
-    DensityCaps caps1{static_cast<uint64_t>(mean1 + mean1 / 5), static_cast<uint32_t>(mean1 / 8 + 4096)};   // per level-1 region
-    DensityCaps caps2{static_cast<uint64_t>(mean2 + mean2 / 5), static_cast<uint32_t>(mean2 / 8 + 2048)};   // per fine bucket
+    DensityCaps caps1{static_cast<uint64_t>(mean1 + mean1 / 5) / 4, static_cast<uint32_t>(mean1 / 8 + 4096) / 4};   // per level-1 region
+    DensityCaps caps2{static_cast<uint64_t>(mean2 + mean2 / 5) / 4, static_cast<uint32_t>(mean2 / 8 + 2048) / 4};   // per fine bucket
     if (ctx->bin_cap_override > 0) {                       // test hook: uniform, deliberately small regions
-        caps2 = DensityCaps{0, static_cast<uint32_t>(ctx->bin_cap_override)};
-        caps1 = DensityCaps{0, static_cast<uint32_t>(ctx->bin_cap_override * 4)};
+        caps2 = DensityCaps{0, static_cast<uint32_t>((ctx->bin_cap_override + 3) / 4)};
+        caps1 = DensityCaps{0, static_cast<uint32_t>(ctx->bin_cap_override)};
     }
     PALACE_REQUIRE(caps1.cap(0) < (1u << 31) && caps2.cap(0) < (1u << 31), "slab too large for 32-bit region cursors");
     const size_t cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
@@ -991,12 +1055,20 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     const size_t buf2_bytes = align_up(static_cast<size_t>(caps2.prefix(kL1Buckets)) * kL1Buckets * 4, 256);
     const int64_t n_chunks = (total_bases + 63) / 64;
     const size_t ends_bytes = align_up(static_cast<size_t>(n_chunks + 2) * 8, 256);
-    rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + ends_bytes + buf1_bytes + buf2_bytes);
+    // level-2 work list: the regions cannot hold more than their capacity, so (sum of capacities) / kTileKeys
+    // full tiles plus one partial tile per region bound it for any input
+    const uint64_t map_cap64 = caps1.prefix(kL1Buckets) * kL1Replicas / kTileKeys + kRegions;
+    PALACE_REQUIRE(map_cap64 < (1ull << 31), "slab too large for one level-2 launch");
+    const uint32_t map_cap = static_cast<uint32_t>(map_cap64);
+    const size_t map_bytes = align_up((static_cast<size_t>(map_cap) + 1) * 4, 256);
+    rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + ends_bytes + map_bytes + buf1_bytes + buf2_bytes);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
     unsigned int *cursor1 = reinterpret_cast<unsigned int *>(ws); ws += cur1_bytes;
     unsigned int *cursor2 = reinterpret_cast<unsigned int *>(ws); ws += cur2_bytes;
     unsigned long long *ends = reinterpret_cast<unsigned long long *>(ws); ws += ends_bytes;
+    uint32_t *tile_map = reinterpret_cast<uint32_t *>(ws); ws += map_bytes;       // [map_cap] entries, then the count
+    unsigned int *n_tiles = tile_map + map_cap;
     uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
     uint32_t *buf2 = reinterpret_cast<uint32_t *>(ws);
     unsigned long long *stamps = (PALACE_STAMPS && (ctx->bin_dbg & 8)) ? reinterpret_cast<unsigned long long *>(ctx->d_small) + 8 : nullptr;
@@ -1037,9 +1109,9 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
                                0, ctx->stream, d_bases, d_offsets, total_bases, c_lo, c_hi, ends, ctx->masks, cpw, o1);
         }
         PALACE_HIP_TRY(hipGetLastError());
-        const unsigned tiles2 = static_cast<unsigned>((static_cast<int64_t>(caps1.cap(0)) + kTileKeys - 1) / kTileKeys);
-        hipLaunchKernelGGL(eref_bin2_kernel, dim3(tiles2, static_cast<unsigned>(kRegions)), dim3(kBinThreads), 0, ctx->stream,
-                           cursor1, buf1, caps1, o2);
+        hipLaunchKernelGGL(eref_tile_map_kernel, dim3(1), dim3(1024), 0, ctx->stream, cursor1, caps1, tile_map, map_cap, n_tiles);
+        hipLaunchKernelGGL(eref_bin2_kernel, dim3(map_cap), dim3(kBinThreads), 0, ctx->stream, cursor1, buf1, caps1, tile_map,
+                           n_tiles, o2);
         PALACE_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, cursor2, buf2, caps2,
                            ctx->plane[0], ctx->plane[1], ctx->plane[2]);
