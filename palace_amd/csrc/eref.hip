@@ -164,11 +164,12 @@ constexpr int kL1Buckets = 128, kL1Shift = 25;        // level 1: key >> 25
 constexpr int kFlatMaxChunks = 6;                     // 64-position chunks one wave walks in the flat bin1 kernel
 constexpr int kL1Replicas = 32;                       // level-1 bucket regions are split 32 ways so that the
                                                       // per-tile reservations do not pile onto 128 addresses
-constexpr int kBinThreads = 512;                      // 8 waves; 33 KiB of LDS -> 4 workgroups per CU
-constexpr int kRowSlots = 64;                         // mean staging row
-constexpr int kStageSlots = kL1Buckets * kRowSlots;   // 8192 keys staged per workgroup
+constexpr int kBinThreads = 512;                      // 8 waves; 37.5 KiB of LDS -> 4 workgroups per CU
+constexpr int kRowSlots = 72;                         // mean staging row
+constexpr int kStageSlots = kL1Buckets * kRowSlots;   // 9216 keys staged per workgroup
 constexpr int kRowPad = 8;                            // density-independent part of a level-1 row
-constexpr int kTileKeys = kBinThreads * 11;           // a tile fills about 70 % of the staging area; multiple of 4
+constexpr int kTileKeys = kBinThreads * 12;           // level-2 tile: 2/3 of the staging area (row mean 48 of 72: +3.5 sigma)
+constexpr int kTile1Keys = 6200;                      // level-1 tile target (rows sized by density: +3.6 sigma or more)
 
 // Capacity of the slot range that belongs to level-1 bucket b when a total is shared out by the key
 // density: prefix(b) = pad*b + share*b*(256-b)/128, capacity(b) = prefix(b+1) - prefix(b)
@@ -187,7 +188,6 @@ __host__ __device__ constexpr uint32_t l1_row_start(uint32_t b)
     return kRowPad * b + (((kRowSlots - kRowPad) * b * (256u - b)) >> 7);
 }
 static_assert(l1_row_start(kL1Buckets) == kStageSlots, "rows tile the staging area");
-static_assert(l1_row_start(1) <= 128, "a row is copied out in at most two 64-lane passes");
 
 template <class F>
 __device__ __forceinline__ void for_each_key(const uint8_t *__restrict__ s, int64_t len, int lane,
@@ -280,7 +280,7 @@ __device__ __forceinline__ void flush_rows(Stage &st, const BinOut &o, D dest)
                        gj = __builtin_amdgcn_readlane(g, j), capj = __builtin_amdgcn_readlane(cap, j);
         const uint32_t bl = __builtin_amdgcn_readlane(base_lo, j), bh = __builtin_amdgcn_readlane(base_hi, j);   // (the builtin returns int)
         uint32_t *dst = o.buf + ((static_cast<uint64_t>(bh) << 32) | bl) + gj;
-        for (uint32_t p = lane; p < cj; p += 64) {             // a row is at most 128 slots: two passes
+        for (uint32_t p = lane; p < cj; p += 64) {             // the longest row is 135 slots: up to three passes
             const uint32_t k = st.slot[sj + p];
             if (PALACE_STAMPS && (o.dbg & 1)) continue;
             if (gj + p < capj) dst[p] = k;
@@ -1085,9 +1085,9 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     for (int64_t slab = 0; slab < n_slabs; slab++) {
         PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes, ctx->stream));
         if (d_keep) {
-            // per-read kernel over this slab's share of the reads; a tile holds about kTileKeys keys
+            // per-read kernel over this slab's share of the reads; a tile holds about kTile1Keys keys
             const int64_t r_lo = n_reads * slab / n_slabs, r_hi = n_reads * (slab + 1) / n_slabs;
-            int64_t rpt = std::max<int64_t>(1, kTileKeys / keys_per_read);
+            int64_t rpt = std::max<int64_t>(1, kTile1Keys / keys_per_read);
             if (rpt >= waves) rpt -= rpt % waves;
             rpt = std::min<int64_t>(rpt, 1 << 20);
             const int64_t tiles = (r_hi - r_lo + rpt - 1) / rpt;
@@ -1097,11 +1097,11 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
                                    ctx->stream, d_bases, d_offsets + r_lo, r_hi - r_lo, d_keep + r_lo, ctx->masks,
                                    static_cast<int>(rpt), o1);
         } else {
-            // flat stream: tiles of (waves x chunks_per_wave) 64-position chunks sized to about kTileKeys keys
+            // flat stream: tiles of (waves x chunks_per_wave) 64-position chunks sized to about kTile1Keys keys
             const int64_t c_lo = slab * (kSlabBases / 64), c_hi = std::min(n_chunks, (slab + 1) * (kSlabBases / 64));
             const double keys_per_pos = std::max(0.05, static_cast<double>(keys_per_read) /
                                                            std::max<double>(1.0, static_cast<double>(total_bases) / n_reads));
-            int cpw = static_cast<int>(static_cast<double>(kTileKeys) / (keys_per_pos * 64.0 * waves));
+            int cpw = static_cast<int>(static_cast<double>(kTile1Keys) / (keys_per_pos * 64.0 * waves));
             cpw = std::max(1, std::min(cpw, kFlatMaxChunks));
             const int64_t flat_tiles = (c_hi - c_lo + static_cast<int64_t>(waves) * cpw - 1) / (static_cast<int64_t>(waves) * cpw);
             PALACE_REQUIRE(flat_tiles < (1ll << 31), "too many tiles for one launch");
