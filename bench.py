@@ -39,7 +39,6 @@ def parse_args():
     ap.add_argument("--contigs", type=int, default=1_000_000)
     ap.add_argument("--refs", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bin-variant", type=int, default=0, help="diagnostic builds only: 20+ selects in-kernel stamps / ablations")
     ap.add_argument("--cpu-sample-reads", type=int, default=40000)
     ap.add_argument("--cpu-sample-records", type=int, default=300000)
     return ap.parse_args()
@@ -405,8 +404,6 @@ def main():
     ctx = capi.Ctx(local)                      # eref stream
     ctx_g = capi.Ctx(local, high_priority=True)   # generateGraph + matching stream (independent of eref until the end)
     ctx.eref_set_coder(hdr)
-    if args.bin_variant >= 20:                     # diagnostic builds (-DPALACE_STAMPS=1) only
-        ctx.eref_set_count_mode(args.bin_variant)
     sample = make_sample(torch, dev, args.contigs, args.refs, rank, world)
     gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world)
     if world > 1 or force_exchange:                 # avgDepth is a pipeline input: computed once from all shards

@@ -61,7 +61,6 @@ struct palace_ctx {
     bool planes_external = false;
     int count_mode = 0;             // 0 auto, 1 direct atomics, 2 binned
     int64_t bin_cap_override = 0;
-    int bin_dbg = 0;
     int64_t slab_override = 0;
     palace::Workspace ws;      // grow-only scratch
     uint64_t *d_small = nullptr;   // 64 x u64 scratch for reductions

@@ -89,17 +89,6 @@ int palace_ctx_destroy(palace_ctx *ctx)
     if (!ctx) return PALACE_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-#if defined(PALACE_STAMPS) && PALACE_STAMPS
-    if (ctx->bin_dbg & 8) {                               // diagnostic build of the bin kernel: print phase sums
-        unsigned long long st[24] = {0};
-        (void)hipMemcpy(st, ctx->d_small + 8, sizeof st, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[palace stamps] tiles=%llu staging=%.3f flush=%.3f (reservation %.3f, store issue %.3f) start-skew=%.3f slowest-wave-staging=%.3f us/tile @100MHz\n", st[2],
-                st[2] ? st[0] / 100.0 / st[2] : 0.0, st[2] ? st[1] / 100.0 / st[2] : 0.0, st[2] ? st[3] / 100.0 / st[2] : 0.0,
-                st[2] ? st[4] / 100.0 / st[2] : 0.0, st[2] ? st[5] / 100.0 / st[2] : 0.0, st[2] ? st[6] / 100.0 / st[2] : 0.0);
-        for (int w = 0; w < 16; w++) fprintf(stderr, " w%d=%.1f", w, st[2] ? st[8 + w] / 100.0 / st[2] : 0.0);
-        fprintf(stderr, "\n");
-    }
-#endif
     for (int p = 0; p < 3; p++)
         if (ctx->plane[p] && !ctx->planes_external) (void)hipFree(ctx->plane[p]);
     if (ctx->ws.ptr) (void)hipFree(ctx->ws.ptr);

@@ -24,11 +24,6 @@
 //    and does the 500-base window test with prefix population counts.
 #include "common.hpp"
 
-// Diagnostic build switch: -DPALACE_STAMPS=1 compiles the in-kernel phase stamps of the bin kernel in
-// (read back by palace_ctx_destroy); the shipped library carries none of them.
-#ifndef PALACE_STAMPS
-#define PALACE_STAMPS 0
-#endif
 
 namespace palace {
 
@@ -221,8 +216,6 @@ struct BinOut {
     uint32_t *buf;                 // destination regions, laid out by `caps`
     DensityCaps caps;              // capacity of a destination region of level-1 bucket b
     uint32_t *p1, *p2, *p3;        // overflow path
-    int dbg;                       // timing experiments only: 1 skip stores, 2 skip reservations, 4 skip staging
-    unsigned long long *stamps;    // diagnostic: per-phase cycle sums (null in production)
 };
 
 // Level-1 regions: the kL1Replicas regions of bucket b lie side by side, buckets in order.
@@ -261,7 +254,6 @@ __device__ __forceinline__ void flush_rows(Stage &st, const BinOut &o, D dest)
 {
     constexpr int rows_per_wave = kL1Buckets / (kBinThreads / 64);
     __syncthreads();
-    const unsigned long long f0 = (PALACE_STAMPS && o.stamps) ? wall_clock64() : 0ull;
     // The first lanes of a wave reserve the runs of the wave's 16 rows (all atomics in flight together);
     // the wave then walks its rows with count, source, destination and capacity in SGPRs (v_readlane).
     const int lane = threadIdx.x & 63;
@@ -274,11 +266,8 @@ __device__ __forceinline__ void flush_rows(Stage &st, const BinOut &o, D dest)
         c = min(static_cast<uint32_t>(r), static_cast<uint32_t>(r >> 32)) - s0;
         const Dest d = dest(row);
         cap = d.cap; base_lo = static_cast<uint32_t>(d.base); base_hi = static_cast<uint32_t>(d.base >> 32);
-        if (PALACE_STAMPS && (o.dbg & 2)) g = (blockIdx.x % 64u) * kRowSlots;                  // ablation: no reservation
-        else if (c) g = atomicAdd(&o.cursor[d.region], c);
+        if (c) g = atomicAdd(&o.cursor[d.region], c);
     }
-    const unsigned long long f1 = (PALACE_STAMPS && o.stamps) ? wall_clock64() : 0ull;
-    if (PALACE_STAMPS && o.stamps && threadIdx.x == 0) atomicAdd(&o.stamps[3], f1 - f0);   // reservation issue
 #pragma unroll
     for (int j = 0; j < rows_per_wave; j++) {
         const uint32_t cj = __builtin_amdgcn_readlane(c, j), sj = __builtin_amdgcn_readlane(s0, j),
@@ -287,12 +276,10 @@ __device__ __forceinline__ void flush_rows(Stage &st, const BinOut &o, D dest)
         uint32_t *dst = o.buf + ((static_cast<uint64_t>(bh) << 32) | bl) + gj;
         for (uint32_t p = lane; p < cj; p += 64) {             // the longest row is 135 slots: up to three passes
             const uint32_t k = st.slot[sj + p];
-            if (PALACE_STAMPS && (o.dbg & 1)) continue;
             if (gj + p < capj) dst[p] = k;
             else count_key(k, o.p1, o.p2, o.p3);               // region full: exact slow path
         }
     }
-    if (PALACE_STAMPS && o.stamps && threadIdx.x == 0) atomicAdd(&o.stamps[4], wall_clock64() - f1);   // store loop (issue only)
 }
 
 // rows sized by density (level 1) or all equal (level 2)
@@ -349,6 +336,9 @@ __global__ void mark_read_ends_kernel(const int64_t *__restrict__ offsets, int64
 // bin1 without per-read work: the concatenated bases are one stream; a wave walks consecutive
 // 64-position chunks (one coalesced byte load per chunk, no dependent loads), windows that would
 // cross a read end are masked with the end bits.  Used when no keep mask is given.
+// (Measured and dropped: several tiles per workgroup with the next tile's loads issued before the
+// current tile's appends -- 11 % slower than one tile per workgroup; the hardware's own overlap of
+// four resident workgroups per CU does better than the longer-lived, larger-register variant.)
 __global__ __launch_bounds__(kBinThreads) void eref_bin1_flat_kernel(const uint8_t *__restrict__ all_bases,
                                                                      const int64_t *__restrict__ offsets, int64_t total,
                                                                      int64_t chunk_lo, int64_t chunk_hi,
@@ -356,11 +346,8 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin1_flat_kernel(const uint8
                                                                      CoderMasks masks, int chunks_per_wave, BinOut o)
 {
     __shared__ Stage st;
-    __shared__ unsigned long long dbg_first_start, dbg_last_start, dbg_last_end;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int n_waves = kBinThreads / 64;
-    const unsigned long long t_begin = (PALACE_STAMPS && o.stamps) ? wall_clock64() : 0ull;
-    if (PALACE_STAMPS && o.stamps && threadIdx.x == 0) { dbg_first_start = ~0ull; dbg_last_start = 0; dbg_last_end = 0; }
     stage_init(st, true);
     __syncthreads();
     const uint8_t *bases = all_bases + offsets[0];      // the read set starts at its first offset
@@ -393,39 +380,24 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin1_flat_kernel(const uint8
                 uint32_t key[3];
                 kmer_keys(masks, window32(lo.p0, hi.p0, lane), window32(lo.p1, hi.p1, lane),
                           window32(lo.p2, hi.p2, lane), key);
-                if (!(PALACE_STAMPS && (o.dbg & 4))) {
-                    // the three row appends of a position are issued together before their results are used
-                    unsigned long long r[3];
+                // the three row appends of a position are issued together before their results are used
+                unsigned long long r[3];
 #pragma unroll
-                    for (int i = 0; i < 3; i++) r[i] = atomicAdd(&st.rows[key[i] >> kL1Shift], 1ull);
+                for (int i = 0; i < 3; i++) r[i] = atomicAdd(&st.rows[key[i] >> kL1Shift], 1ull);
 #pragma unroll
-                    for (int i = 0; i < 3; i++) {
-                        const uint32_t at = static_cast<uint32_t>(r[i]);
-                        if (at < static_cast<uint32_t>(r[i] >> 32)) st.slot[at] = key[i];
-                        else count_key(key[i], o.p1, o.p2, o.p3);
-                    }
+                for (int i = 0; i < 3; i++) {
+                    const uint32_t at = static_cast<uint32_t>(r[i]);
+                    if (at < static_cast<uint32_t>(r[i] >> 32)) st.slot[at] = key[i];
+                    else count_key(key[i], o.p1, o.p2, o.p3);
                 }
             }
             lo = hi;
         }
     }
-    const unsigned long long t_mid = (PALACE_STAMPS && o.stamps) ? wall_clock64() : 0ull;
-    if (PALACE_STAMPS && o.stamps && lane == 0) {
-        atomicMin(&dbg_first_start, t_begin); atomicMax(&dbg_last_start, t_begin); atomicMax(&dbg_last_end, t_mid);
-        atomicAdd(&o.stamps[8 + wave], t_mid - t_begin);
-    }
     const uint32_t replica = blockIdx.x % kL1Replicas;
     flush_rows(st, o, [&](uint32_t row) {
         return Dest{row * kL1Replicas + replica, l1_region_base(o.caps, row, replica), o.caps.cap(row)};
     });
-    if (PALACE_STAMPS && o.stamps && threadIdx.x == 0) {
-        atomicAdd(&o.stamps[5], dbg_last_start - dbg_first_start);   // start skew between the workgroup's waves
-        atomicAdd(&o.stamps[6], dbg_last_end - dbg_first_start);     // slowest wave's staging end since first start
-        const unsigned long long t_end = wall_clock64();
-        atomicAdd(&o.stamps[0], t_mid - t_begin);      // staging phase of thread 0's wave
-        atomicAdd(&o.stamps[1], t_end - t_mid);        // flush phase
-        atomicAdd(&o.stamps[2], 1ull);
-    }
 }
 
 // Work list of level 2: one entry (tile << 12 | region) per kTileKeys keys that level 1 actually left in a
@@ -1076,9 +1048,8 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     unsigned int *n_tiles = tile_map + map_cap;
     uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
     uint32_t *buf2 = reinterpret_cast<uint32_t *>(ws);
-    unsigned long long *stamps = (PALACE_STAMPS && (ctx->bin_dbg & 8)) ? reinterpret_cast<unsigned long long *>(ctx->d_small) + 8 : nullptr;
-    BinOut o1{cursor1, buf1, caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], ctx->bin_dbg & 7, stamps};
-    BinOut o2{cursor2, buf2, caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2], 0, nullptr};
+    BinOut o1{cursor1, buf1, caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
+    BinOut o2{cursor2, buf2, caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
     if (!d_keep) {                                   // read ends as a bit per position, once for the whole set
         PALACE_HIP_TRY(hipMemsetAsync(ends, 0, static_cast<size_t>(n_chunks + 1) * 8, ctx->stream));
         hipLaunchKernelGGL(mark_read_ends_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
@@ -1134,7 +1105,6 @@ int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap)
         ctx->slab_override = bucket_cap;
         return PALACE_OK;
     }
-    if (PALACE_STAMPS && ctx && mode >= 20 && mode < 36) { ctx->bin_dbg = mode - 20; return PALACE_OK; }   // diagnostic builds only
     PALACE_REQUIRE(ctx && mode >= 0 && mode <= 2 && bucket_cap >= 0 && bucket_cap < (1ll << 31), "bad argument");
     ctx->count_mode = mode;
     ctx->bin_cap_override = bucket_cap;
