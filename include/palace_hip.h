@@ -94,6 +94,21 @@ int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t
                           int64_t n_refs, int64_t total_bases, int one_min, int three_min,
                           int32_t *d_rows);
 
+/* E5 with a per-DB probe index -- the analogue of the index file the reference builds once per DB
+ * and then only reads (<fasta>.k32.index.dat, extract_ref.cpp:676-712, 1245-1251).  The index holds
+ * the channel-0 index of every valid ref position grouped by table slice (8 B/position, device
+ * memory) and depends on the ref set and the coder only, not on the reads.
+ * palace_eref_scan_refs_indexed gives exactly the rows of palace_eref_scan_refs for the same table;
+ * it replaces the per-position random probe of channel 0 by a sequential pass over the index.
+ * Meant for a resident DB scanned against many samples; a one-shot run gains nothing from it. */
+typedef struct palace_eref_probe_index palace_eref_probe_index;
+int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_refs,
+                                  int64_t total_bases, palace_eref_probe_index **out);
+int palace_eref_probe_index_free(palace_ctx *ctx, palace_eref_probe_index *ix);
+int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index *ix, const uint8_t *d_bases,
+                                  const int64_t *d_offsets, int64_t n_refs, int64_t total_bases, int one_min,
+                                  int three_min, int32_t *d_rows);
+
 /* Multi-GPU exchange of the count table (no reference counterpart: the reference shares one
  * table between std::threads, extract_ref.cpp:1269-1291).  planes() exposes the three device
  * buffers (each 2^29 bytes); merge_slices() folds `n_parts` partial tables laid out as

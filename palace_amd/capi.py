@@ -78,6 +78,10 @@ _SIGS = {
     "palace_eref_set_count_mode": [C.c_void_p, C.c_int, C.c_int64],
     "palace_eref_scan_refs": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
                               C.c_void_p],
+    "palace_eref_probe_index_build": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)],
+    "palace_eref_probe_index_free": [C.c_void_p, C.c_void_p],
+    "palace_eref_scan_refs_indexed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                      C.c_void_p],
     "palace_eref_table_planes": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
     "palace_eref_table_attach": [C.c_void_p, C.POINTER(C.c_void_p)],
     "palace_eref_table_merge_slices": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t],
@@ -232,6 +236,21 @@ class Ctx:
                        one_min: int, three_min: int, d_rows: DevBuf):
         _check(lib().palace_eref_scan_refs(self.h, d_bases.ptr, d_offsets.ptr, n_refs, total_bases,
                                            one_min, three_min, d_rows.ptr), "palace_eref_scan_refs")
+
+    def eref_probe_index_build(self, d_bases: DevBuf, d_offsets: DevBuf, n_refs: int, total_bases: int) -> C.c_void_p:
+        """Per-DB probe index (device resident); free with eref_probe_index_free."""
+        h = C.c_void_p()
+        _check(lib().palace_eref_probe_index_build(self.h, d_bases.ptr, d_offsets.ptr, n_refs, total_bases, C.byref(h)),
+               "palace_eref_probe_index_build")
+        return h
+
+    def eref_probe_index_free(self, index: C.c_void_p):
+        _check(lib().palace_eref_probe_index_free(self.h, index), "palace_eref_probe_index_free")
+
+    def eref_scan_refs_indexed(self, index: C.c_void_p, d_bases: DevBuf, d_offsets: DevBuf, n_refs: int, total_bases: int,
+                               one_min: int, three_min: int, d_rows: DevBuf):
+        _check(lib().palace_eref_scan_refs_indexed(self.h, index, d_bases.ptr, d_offsets.ptr, n_refs, total_bases,
+                                                   one_min, three_min, d_rows.ptr), "palace_eref_scan_refs_indexed")
 
     def eref_index_refs(self, d_bases: DevBuf, d_offsets: DevBuf, n_refs: int, d_out: DevBuf, d_out_offsets: DevBuf):
         _check(lib().palace_eref_index_refs(self.h, d_bases.ptr, d_offsets.ptr, n_refs, d_out.ptr,

@@ -711,6 +711,115 @@ __device__ __forceinline__ uint32_t prefix_count(const uint64_t *__restrict__ wo
     return pre[w] + __popcll(words[w] & mask);           // hits at positions <= j
 }
 
+// ------------------------------------------------------------------------------------------
+// E5 with a probe index: the reference reads the three indices of every ref position from a file it
+// built once per DB (<fasta>.k32.index.dat, 12 B/position, extract_ref.cpp:676-712) instead of
+// recomputing them.  The analogue here is built once per DB and kept in HBM: the channel-0 index of
+// every valid ref position, grouped by fine bucket (index >> 18), 8 B per position =
+// (position id << 18) | (index & 0x3ffff), position id = 64 * (word of the ref's hit bitmap) + bit.
+// A scan then tests each group against its 32 KiB slice of plane 3 in LDS -- sequential reads of
+// 8 B/position instead of one random 64-byte sector per position -- and sets the hit bit of the few
+// positions that hit.  Channels 1 and 2 keep the pruned recompute-and-probe path.
+// ------------------------------------------------------------------------------------------
+template <int PASS>   // 0: count positions per fine bucket, 1: place them
+__global__ __launch_bounds__(256) void eref_probe_index_kernel(const uint8_t *__restrict__ bases,
+                                                               const int64_t *__restrict__ offsets, int64_t n_refs,
+                                                               const int64_t *__restrict__ tile_pre,
+                                                               const int64_t *__restrict__ word_pre, CoderMasks masks,
+                                                               unsigned long long *__restrict__ count,
+                                                               const unsigned long long *__restrict__ first,
+                                                               unsigned long long *__restrict__ entries)
+{
+    const int64_t tile = blockIdx.x;
+    if (tile >= tile_pre[n_refs]) return;
+    const int64_t r = find_seq(tile_pre, n_refs, tile);
+    const int64_t beg = offsets[r], len = offsets[r + 1] - beg;
+    const int64_t npos = len - 31;
+    const int64_t n_chunks = (len + 63) / 64;
+    const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
+    constexpr int per_wave = kTileChunks / 4;
+    const int64_t c0 = (tile - tile_pre[r]) * kTileChunks + static_cast<int64_t>(wv_id) * per_wave;
+    if (c0 >= n_chunks) return;
+    const int64_t c1 = min(n_chunks, c0 + per_wave);
+    const uint8_t *s = bases + beg;
+    const int64_t wbase = word_pre[r];
+    Streams lo = ballot_streams(s, c0 * 64 + lane, len);
+    for (int64_t c = c0; c < c1; c++) {
+        Streams hi = ballot_streams(s, (c + 1) * 64 + lane, len);
+        const int64_t j = c * 64 + lane;
+        const uint32_t ok = window32(lo.ok, hi.ok, lane);
+        if (j < npos && ok == 0xffffffffu) {
+            const uint32_t w0 = window32(lo.p0, hi.p0, lane), w1 = window32(lo.p1, hi.p1, lane),
+                           w2 = window32(lo.p2, hi.p2, lane);
+            const uint32_t key = canonical(masks, 0, w0, w1, w2, __brev(w0), __brev(w1), __brev(w2));
+            if (key != 0) {                                   // index 0 means "none" (extract_ref.cpp:861)
+                const uint32_t b = key >> kBucketShift;
+                const unsigned long long at = atomicAdd(&count[b], 1ull);
+                if (PASS == 1)
+                    entries[first[b] + at] = (static_cast<unsigned long long>((wbase + c) * 64 + lane) << kBucketShift) |
+                                             (key & ((1u << kBucketShift) - 1));
+            }
+        }
+        lo = hi;
+    }
+}
+
+// exclusive prefix of the 16384 bucket counts (one workgroup, 16 buckets per thread); first[16384] = total
+__global__ __launch_bounds__(1024) void eref_bucket_prefix_kernel(const unsigned long long *__restrict__ count,
+                                                                  unsigned long long *__restrict__ first)
+{
+    __shared__ unsigned long long part[1024];
+    unsigned long long v[16], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { v[i] = count[threadIdx.x * 16 + i]; sum += v[i]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned long long add = threadIdx.x >= d ? part[threadIdx.x - d] : 0ull;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    unsigned long long run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { first[threadIdx.x * 16 + i] = run; run += v[i]; }
+    if (threadIdx.x == 1023) first[kBuckets] = run;
+}
+
+// one workgroup per fine bucket: its slice of plane 3 in LDS, its positions tested against it
+__global__ __launch_bounds__(1024) void eref_probe_kernel(const unsigned long long *__restrict__ first,
+                                                          const unsigned long long *__restrict__ entries,
+                                                          const uint32_t *__restrict__ p3,
+                                                          unsigned long long *__restrict__ hit_words)
+{
+    __shared__ uint32_t l3[kSliceWords];
+    const uint32_t b = blockIdx.x;
+    const unsigned long long e0 = first[b], n = first[b + 1] - e0;
+    if (n == 0) return;                                    // uniform for the workgroup
+    const uint4 *g3 = reinterpret_cast<const uint4 *>(p3 + static_cast<size_t>(b) * kSliceWords);
+    for (int i = threadIdx.x; i < kSliceWords / 4; i += blockDim.x) reinterpret_cast<uint4 *>(l3)[i] = g3[i];
+    __syncthreads();
+    const unsigned long long *mine = entries + e0;
+    constexpr int kBatch = 4;                              // entry loads in flight per thread
+    for (unsigned long long i0 = threadIdx.x; i0 < n; i0 += kBatch * blockDim.x) {
+        unsigned long long e[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            const unsigned long long i = i0 + u * blockDim.x;
+            e[u] = i < n ? mine[i] : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            if (i0 + u * blockDim.x >= n) break;
+            const uint32_t k = static_cast<uint32_t>(e[u]) & ((1u << kBucketShift) - 1);
+            if ((l3[k >> 5] >> (k & 31)) & 1u) {
+                const unsigned long long pos = e[u] >> kBucketShift;
+                atomicOr(&hit_words[pos >> 6], 1ull << (pos & 63));
+            }
+        }
+    }
+}
+
 // Phase B probe pruning (exact).  A window can only pass if it holds >= three_min positions where ALL
 // three channels hit (extract_ref.cpp:561), hence >= three_min channel-0 hits.  So channel 0 is probed
 // everywhere first; this kernel marks the 64-position chunks that overlap at least one window with
@@ -1149,56 +1258,179 @@ int palace_eref_index_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_
     return PALACE_OK;
 }
 
+}  // extern "C"
+
+struct palace_eref_probe_index {
+    int64_t n_refs = 0, total_bases = 0;
+    unsigned long long n_entries = 0;
+    unsigned long long *first = nullptr;      // [kBuckets + 1]
+    unsigned long long *entries = nullptr;    // [n_entries]
+};
+
+namespace {
+
+struct ScanBuffers {
+    int64_t *tile_pre, *word_pre;
+    uint64_t *any_w, *all_w, *good_w;
+    uint32_t *any_p, *all_p;
+    uint8_t *need;
+    int64_t max_tiles, max_words;
+};
+
+int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int64_t total_bases, ScanBuffers *b)
+{
+    b->max_tiles = total_bases / kTilePos + n_refs;
+    b->max_words = total_bases / 64 + n_refs + 1;
+    PALACE_REQUIRE(b->max_tiles < (1ll << 31), "too many tiles for one launch");
+    const size_t pre_bytes = align_up((n_refs + 1) * 8, 256);
+    const size_t w64 = align_up(b->max_words * 8, 256), w32 = align_up(b->max_words * 4, 256);
+    const size_t w8 = align_up(b->max_words, 256);
+    int rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32 + w8);
+    if (rc) return rc;
+    char *ws = static_cast<char *>(ctx->ws.ptr);
+    b->tile_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
+    b->word_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
+    b->any_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
+    b->all_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
+    b->good_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
+    b->any_p = reinterpret_cast<uint32_t *>(ws); ws += w32;
+    b->all_p = reinterpret_cast<uint32_t *>(ws); ws += w32;
+    b->need = reinterpret_cast<uint8_t *>(ws);
+    return launch_prefix(ctx, d_offsets, n_refs, b->tile_pre, b->word_pre);
+}
+
+// channel-0 hit bits are in any_w: chunks that can matter -> channels 1 and 2 only there (exact; see
+// eref_need_kernel) -> windows
+int scan_tail(palace_ctx *ctx, const ScanBuffers &b, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_refs,
+              int one_min, int three_min, int32_t *d_rows)
+{
+    hipLaunchKernelGGL(eref_need_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(256), 0, ctx->stream, d_offsets,
+                       n_refs, b.word_pre, b.any_w, b.any_p, b.good_w, b.all_p, three_min, b.need);
+    PALACE_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(eref_ref_kernel<0>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
+                       d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, ctx->plane[2], b.any_w,
+                       b.all_w, static_cast<uint32_t *>(nullptr), static_cast<const int64_t *>(nullptr),
+                       static_cast<const uint8_t *>(b.need));
+    PALACE_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(eref_window_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(256), 0, ctx->stream,
+                       d_offsets, n_refs, b.word_pre, b.any_w, b.all_w, b.any_p, b.all_p, b.good_w, one_min, three_min,
+                       d_rows);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+int scan_args_ok(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_refs, int64_t total_bases,
+                 const int32_t *d_rows)
+{
+    PALACE_REQUIRE(ctx && n_refs >= 0 && total_bases >= 0, "bad argument");
+    if (!ctx->coder_set) { set_error("scan_refs: coder not set"); return PALACE_ESTATE; }
+    PALACE_REQUIRE(n_refs == 0 || (d_bases && d_offsets && d_rows), "null device pointer");
+    PALACE_REQUIRE(n_refs < (1ll << 31), "too many refs for one launch");
+    return PALACE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets,
                           int64_t n_refs, int64_t total_bases, int one_min, int three_min,
                           int32_t *d_rows)
 {
-    PALACE_REQUIRE(ctx && n_refs >= 0 && total_bases >= 0, "bad argument");
-    if (!ctx->coder_set) { set_error("palace_eref_scan_refs: coder not set"); return PALACE_ESTATE; }
-    if (n_refs == 0) return PALACE_OK;
-    PALACE_REQUIRE(d_bases && d_offsets && d_rows, "null device pointer");
-    PALACE_REQUIRE(n_refs < (1ll << 31), "too many refs for one launch");
+    int rc = scan_args_ok(ctx, d_bases, d_offsets, n_refs, total_bases, d_rows);
+    if (rc || n_refs == 0) return rc;
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
-    int rc = ensure_table(ctx);
+    rc = ensure_table(ctx);
     if (rc) return rc;
-    const int64_t max_tiles = total_bases / kTilePos + n_refs;
-    const int64_t max_words = total_bases / 64 + n_refs + 1;
-    PALACE_REQUIRE(max_tiles < (1ll << 31), "too many tiles for one launch");
-    const size_t pre_bytes = align_up((n_refs + 1) * 8, 256);
-    const size_t w64 = align_up(max_words * 8, 256), w32 = align_up(max_words * 4, 256);
-    const size_t w8 = align_up(max_words, 256);
-    rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32 + w8);
+    ScanBuffers b;
+    rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b);
     if (rc) return rc;
-    char *ws = static_cast<char *>(ctx->ws.ptr);
-    int64_t *tile_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
-    int64_t *word_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
-    uint64_t *any_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
-    uint64_t *all_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
-    uint64_t *good_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
-    uint32_t *any_p = reinterpret_cast<uint32_t *>(ws); ws += w32;
-    uint32_t *all_p = reinterpret_cast<uint32_t *>(ws); ws += w32;
-    uint8_t *need = reinterpret_cast<uint8_t *>(ws);
-    rc = launch_prefix(ctx, d_offsets, n_refs, tile_pre, word_pre);
-    if (rc) return rc;
-    // channel 0 everywhere -> chunks that can matter -> channels 1 and 2 only there (exact; see eref_need_kernel)
-    hipLaunchKernelGGL(eref_ref_kernel<2>, dim3(static_cast<unsigned>(max_tiles)), dim3(256), 0, ctx->stream,
-                       d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks, ctx->plane[2], any_w,
-                       all_w, static_cast<uint32_t *>(nullptr), static_cast<const int64_t *>(nullptr),
+    // channel 0 everywhere, recomputed from the bases
+    hipLaunchKernelGGL(eref_ref_kernel<2>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
+                       d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, ctx->plane[2], b.any_w,
+                       b.all_w, static_cast<uint32_t *>(nullptr), static_cast<const int64_t *>(nullptr),
                        static_cast<const uint8_t *>(nullptr));
     PALACE_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(eref_need_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(256), 0, ctx->stream, d_offsets,
-                       n_refs, word_pre, any_w, any_p, good_w, all_p, three_min, need);
-    PALACE_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(eref_ref_kernel<0>, dim3(static_cast<unsigned>(max_tiles)), dim3(256), 0, ctx->stream,
-                       d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks, ctx->plane[2], any_w,
-                       all_w, static_cast<uint32_t *>(nullptr), static_cast<const int64_t *>(nullptr),
-                       static_cast<const uint8_t *>(need));
-    PALACE_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(eref_window_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(256), 0, ctx->stream,
-                       d_offsets, n_refs, word_pre, any_w, all_w, any_p, all_p, good_w, one_min, three_min,
-                       d_rows);
-    PALACE_HIP_TRY(hipGetLastError());
+    return scan_tail(ctx, b, d_bases, d_offsets, n_refs, one_min, three_min, d_rows);
+}
+
+int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_refs,
+                                  int64_t total_bases, palace_eref_probe_index **out)
+{
+    PALACE_REQUIRE(ctx && out && n_refs >= 0 && total_bases >= 0, "bad argument");
+    if (!ctx->coder_set) { set_error("palace_eref_probe_index_build: coder not set"); return PALACE_ESTATE; }
+    PALACE_REQUIRE(n_refs == 0 || (d_bases && d_offsets), "null device pointer");
+    PALACE_REQUIRE(n_refs < (1ll << 31), "too many refs for one launch");
+    PALACE_REQUIRE(total_bases + 64 * (n_refs + 1) < (1ll << 46), "position ids must fit in 46 bits");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    palace_eref_probe_index *ix = new palace_eref_probe_index();
+    ix->n_refs = n_refs; ix->total_bases = total_bases;
+    unsigned long long *count = nullptr;                  // 16384 counters, only during the build
+    auto done = [&](int rc) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (count) (void)hipFree(count);
+        if (rc) palace_eref_probe_index_free(ctx, ix); else *out = ix;
+        return rc;
+    };
+#define TRY_OR_DONE(expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e__ = (expr);                                                                            \
+        if (e__ != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(e__)); return done(PALACE_EHIP); } \
+    } while (0)
+    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->first), (kBuckets + 1) * 8));
+    TRY_OR_DONE(hipMemsetAsync(ix->first, 0, (kBuckets + 1) * 8, ctx->stream));
+    if (n_refs == 0) return done(PALACE_OK);
+    ScanBuffers b;
+    int rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b);     // tile_pre / word_pre exactly as the scans lay them out
+    if (rc) return done(rc);
+    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&count), kBuckets * 8));
+    TRY_OR_DONE(hipMemsetAsync(count, 0, kBuckets * 8, ctx->stream));
+    hipLaunchKernelGGL(eref_probe_index_kernel<0>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
+                       d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, count,
+                       static_cast<const unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr));
+    hipLaunchKernelGGL(eref_bucket_prefix_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, ix->first);
+    TRY_OR_DONE(hipGetLastError());
+    TRY_OR_DONE(hipMemcpyAsync(&ix->n_entries, ix->first + kBuckets, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TRY_OR_DONE(hipStreamSynchronize(ctx->stream));
+    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->entries), std::max<size_t>(8, ix->n_entries * 8)));
+    TRY_OR_DONE(hipMemsetAsync(count, 0, kBuckets * 8, ctx->stream));
+    hipLaunchKernelGGL(eref_probe_index_kernel<1>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
+                       d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, count, ix->first, ix->entries);
+    TRY_OR_DONE(hipGetLastError());
+#undef TRY_OR_DONE
+    return done(PALACE_OK);
+}
+
+int palace_eref_probe_index_free(palace_ctx *ctx, palace_eref_probe_index *ix)
+{
+    if (!ix) return PALACE_OK;
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    if (ix->first) (void)hipFree(ix->first);
+    if (ix->entries) (void)hipFree(ix->entries);
+    delete ix;
     return PALACE_OK;
+}
+
+int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index *ix, const uint8_t *d_bases,
+                                  const int64_t *d_offsets, int64_t n_refs, int64_t total_bases, int one_min,
+                                  int three_min, int32_t *d_rows)
+{
+    PALACE_REQUIRE(ix, "null probe index");
+    int rc = scan_args_ok(ctx, d_bases, d_offsets, n_refs, total_bases, d_rows);
+    if (rc) return rc;
+    PALACE_REQUIRE(ix->n_refs == n_refs && ix->total_bases == total_bases, "probe index was built for another ref set");
+    if (n_refs == 0) return PALACE_OK;
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    rc = ensure_table(ctx);
+    if (rc) return rc;
+    ScanBuffers b;
+    rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b);
+    if (rc) return rc;
+    PALACE_HIP_TRY(hipMemsetAsync(b.any_w, 0, static_cast<size_t>(b.max_words) * 8, ctx->stream));
+    hipLaunchKernelGGL(eref_probe_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, ix->first, ix->entries, ctx->plane[2],
+                       reinterpret_cast<unsigned long long *>(b.any_w));
+    PALACE_HIP_TRY(hipGetLastError());
+    return scan_tail(ctx, b, d_bases, d_offsets, n_refs, one_min, three_min, d_rows);
 }
 
 int palace_eref_table_planes(palace_ctx *ctx, void **d_planes3, size_t *bytes_per_plane)

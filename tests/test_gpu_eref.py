@@ -94,6 +94,12 @@ def test_stdout_equals_reference(ctx, golden_eref, key, hr, pr):
     one_min, three_min = capi.window_minimums(hr, pr)
     ctx.eref_scan_refs(db, do, rs.n, len(rs.bases), one_min, three_min, rows)
     r = rows.to_host()
+    ix = ctx.eref_probe_index_build(db, do, rs.n, len(rs.bases))              # same rows through the per-DB probe index
+    rows2 = ctx.empty((rs.n, 4), np.int32)
+    ctx.eref_scan_refs_indexed(ix, db, do, rs.n, len(rs.bases), one_min, three_min, rows2)
+    assert np.array_equal(rows2.to_host(), r)
+    ctx.eref_probe_index_free(ix)
+    rows2.free()
     out = b""
     for i in range(rs.n):
         n_int, el, L, _ = (int(v) for v in r[i])
@@ -198,13 +204,18 @@ def test_scan_matches_oracle_on_random_coverage(ctx):
     rs = synth.reads_from_list(refs)
     db, do = ctx.upload(rs.bases), ctx.upload(rs.offsets)
     rows = ctx.empty((rs.n, 4), np.int32)
+    rows_ix = ctx.empty((rs.n, 4), np.int32)
+    ix = ctx.eref_probe_index_build(db, do, rs.n, len(rs.bases))
     for hr, pr in ((0.9, 0.85), (0.5, 0.2), (0.99, 0.97), (0.7, 0.7)):
         one_min, three_min = capi.window_minimums(hr, pr)
         ctx.eref_scan_refs(db, do, rs.n, len(rs.bases), one_min, three_min, rows)
         got = rows.to_host()
+        ctx.eref_scan_refs_indexed(ix, db, do, rs.n, len(rs.bases), one_min, three_min, rows_ix)
+        assert np.array_equal(rows_ix.to_host(), got), (hr, pr)
         for i, s in enumerate(refs):
             _, n_int, el, _ = orc.scan_ref(orc.index_ref(s, cc), len(s), t, hr, pr)
             assert (int(got[i, 0]), int(got[i, 1]), int(got[i, 2])) == (n_int, el, len(s)), (i, len(s), hr, pr)
+    ctx.eref_probe_index_free(ix)
     t.free()
 
 
