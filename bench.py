@@ -235,25 +235,11 @@ def make_graph_sample(torch, dev, n_contigs, n_pairs, rank=0, world=1):
 
 
 def graph_to_arcs(cn, n_segs, edges, min_count=5):
-    """host glue between generateGraph's numbers and matching's input (JUNC filter :1056-1061; arc
-    ranking as palace_amd/host/matching_main.cpp).  cn comes from palace_graph_copy_numbers."""
-    copies = np.maximum(1, cn).astype(np.int64)
-    tot = edges["counts"].sum(axis=1).astype(np.int64)
-    e = edges[tot >= min_count]
-    w = tot[tot >= min_count]
-    u = 2 * e["left"].astype(np.int64) + e["oL"]
-    v = 2 * e["right"].astype(np.int64) + e["oR"]
-    selfc = (v ^ 1) == u
-    uu = np.concatenate([u, (v ^ 1)[~selfc]]); vv = np.concatenate([v, (u ^ 1)[~selfc]]); ww = np.concatenate([w, w[~selfc]])
-    V = 2 * n_segs
-    own = uu * V + vv
-    cls = np.minimum(own, (vv ^ 1) * V + (uu ^ 1))
-    if V <= (1 << 21) and (len(ww) == 0 or ww.max() < (1 << 20)):      # one packed 64-bit key: weight desc, class asc, pair order
-        key = ((np.int64((1 << 20) - 1) - ww) << np.int64(43)) | (cls << np.int64(1)) | (own != cls)
-        order = np.argsort(key, kind="stable")
-    else:
-        order = np.lexsort((vv, uu, cls, -ww))
-    return copies, uu[order].astype(np.int32), vv[order].astype(np.int32), ww[order]
+    """host glue between generateGraph's numbers and matching's input (JUNC filter :1056-1061, arc + conjugate,
+    arc ranking): the library's own host routine, the same one palace_amd/host/matching_main.cpp ranks with."""
+    from palace_amd import capi
+    assert len(cn) == n_segs
+    return capi.match_arcs_from_edges(cn, edges, min_count)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -517,12 +503,14 @@ def main():
             copies, src, dst, w = graph_to_arcs(h_cn, nt, h_edges)
             th2 = time.perf_counter()
             if rank == 0:
-                off, verts, kind, it, open_at = capi.match_decompose(g, copies, src, dst, 10, False)
+                res = capi.match_decompose_views(g, copies, src, dst, 10, False)              # views, no copies
                 th3 = time.perf_counter()
+                if not timed or "n_comp" not in last:                                          # bookkeeping for the JSON line only
+                    last.update(n_comp=res.n, n_cycles=int(res.kind.sum()), n_multi=int(((res.off[1:] - res.off[:-1]) > 1).sum()))
+                res.free()
                 if timed:
-                    for k_, v_ in (("d2h_graph", th1 - th0), ("glue_numpy", th2 - th1), ("match_decompose", th3 - th2)):
+                    for k_, v_ in (("d2h_graph", th1 - th0), ("glue", th2 - th1), ("match_decompose", th3 - th2)):
                         host_ms[k_] = host_ms.get(k_, 0.0) + 1e3 * v_ / args.steps
-                last.update(n_comp=len(kind), n_cycles=int(kind.sum()), n_multi=int(((off[1:] - off[:-1]) > 1).sum()))
             last.update(graph=(copies, src, dst, w), n_edges=int(n_e.value), n_cands=int(n_cands), n_arcs=len(src))
 
         if exch:

@@ -228,6 +228,17 @@ int palace_match_greedy(palace_ctx *ctx, int32_t n_vertices, int64_t n_arcs, con
                         const int64_t *d_in_off, const int32_t *d_in_arcs, const uint8_t *d_alive,
                         int32_t *d_next, int32_t *d_prev, int32_t *d_next_arc, int32_t *rounds_out);
 
+/* Host glue between generateGraph's numbers and palace_match_decompose, i.e. what the matching
+ * executable does while it reads the SEG/JUNC text (palace_amd/host/matching_main.cpp): copies[s] =
+ * max(1, cn[s]); every edge whose four counters sum to >= min_count (JUNC filter,
+ * generateGraph.cpp:1056-1061) becomes the arc (left,oL)->(right,oR) plus its conjugate
+ * (right,!oR)->(left,!oL) (make_final_fa.py:20-34), equal arcs merged with their weights added;
+ * arcs come out in rank order (weight descending, class {arc, conjugate} ascending, (u, v) ascending).
+ * Host arrays; src/dst/weight need room for 2 * n_edges arcs.  Pure host code (no GPU work). */
+int palace_match_arcs_from_edges(const int32_t *cn, int32_t n_segs, const palace_graph_edge *edges, int64_t n_edges,
+                                 int32_t min_count, int64_t *copies, int32_t *src, int32_t *dst, int64_t *weight,
+                                 int64_t *n_arcs_out);
+
 /* M1, whole decomposition: `iterations` rounds of {greedy matching on the GPU, read the paths and
  * cycles off the successor links, charge copy numbers, drop exhausted segments} (+ one copy-number
  * blind round when `aggressive`).  Host arrays in: copies[n_segs] (>= 1), arcs in rank order

@@ -92,6 +92,8 @@ _SIGS = {
                               C.c_int64, C.POINTER(C.c_int64)],
     "palace_graph_copy_numbers": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p],
     "palace_match_greedy": [C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 10 + [C.POINTER(C.c_int32)],
+    "palace_match_arcs_from_edges": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],
     "palace_match_decompose": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                C.c_int32, C.POINTER(C.c_void_p)],
     "palace_graph_resolve": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(GraphParams), C.c_void_p,
@@ -285,25 +287,64 @@ class Ctx:
                "palace_eref_table_merge_slices")
 
 
-def match_decompose(ctx: "Ctx", copies: np.ndarray, src: np.ndarray, dst: np.ndarray, iterations: int = 10,
-                    aggressive: bool = False):
-    """palace_match_decompose -> (offsets, verts, kind, iter, open_at) as numpy copies."""
+def match_arcs_from_edges(cn: np.ndarray, edges: np.ndarray, min_count: int = 5):
+    """palace_match_arcs_from_edges (host code of the library) -> (copies, src, dst, weight); `edges` is an
+    EDGE_DTYPE array as palace_graph_resolve writes it."""
+    cn = np.ascontiguousarray(cn, dtype=np.int32)
+    e = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+    copies = np.empty(len(cn), np.int64)
+    src = np.empty(2 * len(e), np.int32); dst = np.empty(2 * len(e), np.int32); w = np.empty(2 * len(e), np.int64)
+    n = C.c_int64()
+    _check(lib().palace_match_arcs_from_edges(cn.ctypes.data, len(cn), e.ctypes.data, len(e), min_count, copies.ctypes.data,
+                                              src.ctypes.data, dst.ctypes.data, w.ctypes.data, C.byref(n)),
+           "palace_match_arcs_from_edges")
+    return copies, src[:n.value], dst[:n.value], w[:n.value]
+
+
+class MatchResult:
+    """Views into a palace_match_result (no copies); call free() -- or use as a context manager -- when done."""
+
+    def __init__(self, handle):
+        L = lib()
+        self._h = handle
+        n = self.n = L.palace_match_result_count(handle)
+        self.off = np.ctypeslib.as_array(L.palace_match_result_offsets(handle), shape=(n + 1,))
+        nv = int(self.off[-1])
+        self.verts = np.ctypeslib.as_array(L.palace_match_result_verts(handle), shape=(max(nv, 1),))[:nv]
+        mk = lambda f, dt: (np.ctypeslib.as_array(f(handle), shape=(max(n, 1),))[:n] if n else np.zeros(0, dt))
+        self.kind = mk(L.palace_match_result_kind, np.uint8)
+        self.iter = mk(L.palace_match_result_iter, np.int32)
+        self.open_at = mk(L.palace_match_result_open_at, np.int32)
+
+    def free(self):
+        if self._h is not None:
+            self.off = self.verts = self.kind = self.iter = self.open_at = None
+            lib().palace_match_result_free(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+
+def match_decompose_views(ctx: "Ctx", copies: np.ndarray, src: np.ndarray, dst: np.ndarray, iterations: int = 10,
+                          aggressive: bool = False) -> MatchResult:
     cp = np.ascontiguousarray(copies, dtype=np.int64)
     s = np.ascontiguousarray(src, dtype=np.int32)
     d = np.ascontiguousarray(dst, dtype=np.int32)
     res = C.c_void_p()
     _check(lib().palace_match_decompose(ctx.h, len(cp), cp.ctypes.data, len(s), s.ctypes.data, d.ctypes.data,
                                         iterations, int(aggressive), C.byref(res)), "palace_match_decompose")
-    L = lib()
-    n = L.palace_match_result_count(res)
-    off = np.ctypeslib.as_array(L.palace_match_result_offsets(res), shape=(n + 1,)).copy()
-    nv = int(off[-1])
-    verts = np.ctypeslib.as_array(L.palace_match_result_verts(res), shape=(max(nv, 1),))[:nv].copy()
-    mk = lambda f, dt: (np.ctypeslib.as_array(f(res), shape=(max(n, 1),))[:n].copy() if n else np.zeros(0, dt))
-    out = (off, verts, mk(L.palace_match_result_kind, np.uint8), mk(L.palace_match_result_iter, np.int32),
-           mk(L.palace_match_result_open_at, np.int32))
-    L.palace_match_result_free(res)
-    return out
+    return MatchResult(res)
+
+
+def match_decompose(ctx: "Ctx", copies: np.ndarray, src: np.ndarray, dst: np.ndarray, iterations: int = 10,
+                    aggressive: bool = False):
+    """palace_match_decompose -> (offsets, verts, kind, iter, open_at) as numpy copies."""
+    with match_decompose_views(ctx, copies, src, dst, iterations, aggressive) as r:
+        return r.off.copy(), r.verts.copy(), r.kind.copy(), r.iter.copy(), r.open_at.copy()
 
 
 def window_minimums(hit_ratio: float, perfect_ratio: float):

@@ -63,10 +63,12 @@ struct palace_ctx {
     int64_t bin_cap_override = 0;
     int64_t slab_override = 0;
     palace::Workspace ws;      // grow-only scratch
+    palace::Workspace pin;     // grow-only pinned host staging
     uint64_t *d_small = nullptr;   // 64 x u64 scratch for reductions
 };
 
 namespace palace {
 int ensure_workspace(palace_ctx *ctx, size_t bytes);
+int ensure_pinned(palace_ctx *ctx, size_t bytes);
 int ensure_table(palace_ctx *ctx);
 }  // namespace palace

@@ -32,6 +32,25 @@ int ensure_workspace(palace_ctx *ctx, size_t bytes)
     return PALACE_OK;
 }
 
+int ensure_pinned(palace_ctx *ctx, size_t bytes)
+{
+    if (ctx->pin.bytes >= bytes) return PALACE_OK;
+    if (ctx->pin.ptr) {
+        PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        PALACE_HIP_TRY(hipHostFree(ctx->pin.ptr));
+        ctx->pin.ptr = nullptr;
+        ctx->pin.bytes = 0;
+    }
+    const size_t want = bytes + bytes / 4 + (1 << 16);
+    hipError_t e = hipHostMalloc(&ctx->pin.ptr, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error("pinned staging hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return PALACE_ENOMEM;
+    }
+    ctx->pin.bytes = want;
+    return PALACE_OK;
+}
+
 int ensure_table(palace_ctx *ctx)
 {
     for (int p = 0; p < 3; p++) {
@@ -92,6 +111,7 @@ int palace_ctx_destroy(palace_ctx *ctx)
     for (int p = 0; p < 3; p++)
         if (ctx->plane[p] && !ctx->planes_external) (void)hipFree(ctx->plane[p]);
     if (ctx->ws.ptr) (void)hipFree(ctx->ws.ptr);
+    if (ctx->pin.ptr) (void)hipHostFree(ctx->pin.ptr);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     for (hipEvent_t e : ctx->marks)
         if (e) (void)hipEventDestroy(e);

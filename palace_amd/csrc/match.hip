@@ -10,6 +10,9 @@
 // greedy matching -- independent of scheduling.  The graph here is the filtered conjugate graph
 // (10^4..10^6 arcs): bandwidth-trivial, latency-bound; rounds are separate small launches.
 #include "common.hpp"
+#include <algorithm>
+#include <memory>
+#include <numeric>
 
 namespace palace {
 
@@ -118,10 +121,17 @@ extern "C" int palace_match_greedy(palace_ctx *ctx, int32_t n_vertices, int64_t 
 }
 
 // ---- whole decomposition: GPU matching per round + host read-off ------------------------------
-struct palace_match_result {
+struct SubResult {                      // components of the arc-bearing sub-graph (small)
     std::vector<int64_t> off{0};
     std::vector<int32_t> verts, iter, open_at;
     std::vector<uint8_t> kind;
+};
+
+struct palace_match_result {            // final result: one entry per component incl. ~n_segs bare segments, so the
+    int64_t n = 0;                      // arrays are allocated once, uninitialised, and written exactly once
+    std::unique_ptr<int64_t[]> off;
+    std::unique_ptr<int32_t[]> verts, iter, open_at;
+    std::unique_ptr<uint8_t[]> kind;
 };
 
 namespace palace {
@@ -152,7 +162,7 @@ using palace::dev_copy;
 
 static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
                           const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
-                          palace_match_result *res)
+                          SubResult *res)
 {
     const int32_t V = 2 * n_segs;
     const int64_t E = n_arcs;
@@ -168,8 +178,15 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
     int32_t *d_src = nullptr, *d_dst = nullptr, *d_oa = nullptr, *d_ia = nullptr, *d_next = nullptr, *d_prev = nullptr, *d_narc = nullptr;
     int64_t *d_oo = nullptr, *d_io = nullptr;
     uint8_t *d_alive = nullptr;
-    std::vector<int32_t> next(V), prev(V), narc(V);
-    std::vector<uint8_t> alive(V);
+    // successor links come back every round: pinned staging (pageable copies run at a fraction of the link
+    // rate), laid out like the three device arrays so that one copy fetches them all
+    const size_t v4 = (static_cast<size_t>(V) * 4 + 255) / 256 * 256;
+    {
+        int rc = palace::ensure_pinned(ctx, 3 * v4 + static_cast<size_t>(V) + 256);
+        if (rc) return rc;
+    }
+    int32_t *next = static_cast<int32_t *>(ctx->pin.ptr), *prev = next + v4 / 4, *narc = prev + v4 / 4;
+    uint8_t *alive = reinterpret_cast<uint8_t *>(narc + v4 / 4);
     const size_t greedy_bytes = (static_cast<size_t>(V) * 8 + 256 + 255) / 256 * 256;
     const size_t arena_bytes = greedy_bytes + 4 * (static_cast<size_t>(E) * 4 + 256) + 2 * (static_cast<size_t>(V + 1) * 8 + 256) +
                                3 * (static_cast<size_t>(V) * 4 + 256) + static_cast<size_t>(V) + 256;
@@ -184,6 +201,10 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
     TRY_OR_CLEAN(dev_copy(ctx, ar, out_arcs.data(), E, &d_oa)); TRY_OR_CLEAN(dev_copy(ctx, ar, in_arcs.data(), E, &d_ia));
     TRY_OR_CLEAN(dev_copy(ctx, ar, out_off.data(), V + 1, &d_oo)); TRY_OR_CLEAN(dev_copy(ctx, ar, in_off.data(), V + 1, &d_io));
     d_next = ar.take<int32_t>(V); d_prev = ar.take<int32_t>(V); d_narc = ar.take<int32_t>(V);   // written by match_init_kernel
+    if (reinterpret_cast<char *>(d_prev) - reinterpret_cast<char *>(d_next) != static_cast<ptrdiff_t>(v4) ||
+        reinterpret_cast<char *>(d_narc) - reinterpret_cast<char *>(d_prev) != static_cast<ptrdiff_t>(v4)) {
+        palace::set_error("decompose: arena layout"); cleanup(); return PALACE_ESTATE;
+    }
     d_alive = ar.take<uint8_t>(V);
     if (ar.used > arena_bytes) { palace::set_error("decompose: arena accounting"); cleanup(); return PALACE_ESTATE; }
 
@@ -200,11 +221,9 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
         bool any = false;
         for (int32_t s = 0; s < n_segs; s++) { alive[2 * s] = alive[2 * s + 1] = left[s] > 0; any |= left[s] > 0; }
         if (!any) continue;                                   // nothing left this round (an `aggressive` round may follow)
-        int rc = palace_h2d(ctx, d_alive, alive.data(), alive.size());
+        int rc = palace_h2d(ctx, d_alive, alive, static_cast<size_t>(V));
         if (!rc) rc = palace_match_greedy(ctx, V, E, d_src, d_dst, d_oo, d_oa, d_io, d_ia, d_alive, d_next, d_prev, d_narc, nullptr);
-        if (!rc) rc = palace_d2h(ctx, next.data(), d_next, next.size() * 4);
-        if (!rc) rc = palace_d2h(ctx, prev.data(), d_prev, prev.size() * 4);
-        if (!rc) rc = palace_d2h(ctx, narc.data(), d_narc, narc.size() * 4);
+        if (!rc) rc = palace_d2h(ctx, next, d_next, 3 * v4);          // next, prev, next_arc lie side by side
         if (rc) { cleanup(); return rc; }
         std::fill(seen.begin(), seen.end(), 0);
         heads.clear();
@@ -238,7 +257,15 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
                 if (narc[pool[k]] > narc[pool[worst]]) worst = k;
             heads.push_back({pool[b], b, e, 1, static_cast<int32_t>((worst + 1 - b) % (e - b))});
         }
-        std::sort(heads.begin(), heads.end(), [](const Head &a, const Head &b) { return a.first < b.first; });
+        {   // emission order = ascending first vertex; first vertices are distinct, so place instead of sorting
+            std::fill(owner.begin(), owner.end(), -1);
+            for (size_t c = 0; c < heads.size(); c++) owner[heads[c].first] = static_cast<int32_t>(c);
+            std::vector<Head> ordered;
+            ordered.reserve(heads.size());
+            for (int32_t v = 0; v < V; v++)
+                if (owner[v] >= 0) ordered.push_back(heads[owner[v]]);
+            heads.swap(ordered);
+        }
         std::fill(owner.begin(), owner.end(), -1);
         for (size_t c = 0; c < heads.size(); c++)
             for (int64_t k = heads[c].begin; k < heads[c].end; k++) owner[pool[k]] = static_cast<int32_t>(c);
@@ -266,7 +293,87 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
     return PALACE_OK;
 }
 
+namespace {
+
+// stable LSD radix sort of `perm` by 16-bit digits of key[perm[i]]; digits that are equal everywhere are skipped
+void radix_by(const std::vector<uint64_t> &key, std::vector<uint32_t> &perm, std::vector<uint32_t> &tmp)
+{
+    const size_t n = perm.size();
+    uint64_t all_or = 0, all_and = ~0ull;
+    for (size_t i = 0; i < n; i++) { all_or |= key[i]; all_and &= key[i]; }
+    const uint64_t varying = all_or ^ all_and;
+    std::vector<uint32_t> hist(65536);
+    for (int shift = 0; shift < 64; shift += 16) {
+        if (((varying >> shift) & 0xffffu) == 0) continue;
+        std::fill(hist.begin(), hist.end(), 0u);
+        for (size_t i = 0; i < n; i++) hist[(key[perm[i]] >> shift) & 0xffffu]++;
+        uint32_t run = 0;
+        for (auto &h : hist) { const uint32_t c = h; h = run; run += c; }
+        for (size_t i = 0; i < n; i++) tmp[hist[(key[perm[i]] >> shift) & 0xffffu]++] = perm[i];
+        perm.swap(tmp);
+    }
+}
+
+}  // namespace
+
 extern "C" {
+
+int palace_match_arcs_from_edges(const int32_t *cn, int32_t n_segs, const palace_graph_edge *edges, int64_t n_edges,
+                                 int32_t min_count, int64_t *copies, int32_t *src, int32_t *dst, int64_t *weight,
+                                 int64_t *n_arcs_out)
+{
+    PALACE_REQUIRE(n_segs >= 0 && n_edges >= 0 && n_arcs_out, "bad argument");
+    PALACE_REQUIRE(n_segs == 0 || (cn && copies), "null segment arrays");
+    PALACE_REQUIRE(n_edges == 0 || (edges && src && dst && weight), "null edge arrays");
+    PALACE_REQUIRE(n_segs < (1 << 30) && n_edges < (1ll << 30), "graph too large for int32 ids");
+    for (int32_t s = 0; s < n_segs; s++) copies[s] = std::max(1, cn[s]);
+    const uint64_t V = 2ull * static_cast<uint64_t>(n_segs);
+    // arcs and conjugates of the junctions that pass the filter (generateGraph.cpp:1056-1061)
+    std::vector<uint64_t> pair;                           // u * V + v
+    std::vector<int64_t> w;
+    pair.reserve(2 * n_edges); w.reserve(2 * n_edges);
+    for (int64_t e = 0; e < n_edges; e++) {
+        const palace_graph_edge &x = edges[e];
+        const int64_t tot = static_cast<int64_t>(x.counts[0]) + x.counts[1] + x.counts[2] + x.counts[3];
+        if (tot < min_count) continue;
+        PALACE_REQUIRE(x.left >= 0 && x.left < n_segs && x.right >= 0 && x.right < n_segs, "edge endpoint out of range");
+        const uint64_t u = 2ull * x.left + (x.oL & 1), v = 2ull * x.right + (x.oR & 1);
+        pair.push_back(u * V + v); w.push_back(tot);
+        if ((v ^ 1) != u) { pair.push_back((v ^ 1) * V + (u ^ 1)); w.push_back(tot); }
+    }
+    const size_t n = pair.size();
+    std::vector<uint32_t> perm(n), tmp(n);
+    std::iota(perm.begin(), perm.end(), 0u);
+    radix_by(pair, perm, tmp);                            // by (u, v): equal arcs become adjacent
+    // merge equal arcs (weights add up), as the matching executable does when it reads JUNC lines
+    std::vector<uint64_t> m_pair, m_cls, m_wkey;
+    std::vector<int64_t> m_w;
+    m_pair.reserve(n); m_w.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        if (!m_pair.empty() && m_pair.back() == pair[perm[i]]) m_w.back() += w[perm[i]];
+        else { m_pair.push_back(pair[perm[i]]); m_w.push_back(w[perm[i]]); }
+    }
+    const size_t m = m_pair.size();
+    int64_t w_max = 0;
+    for (int64_t x : m_w) w_max = std::max(w_max, x);
+    m_cls.resize(m); m_wkey.resize(m);
+    for (size_t i = 0; i < m; i++) {
+        const uint64_t u = m_pair[i] / V, v = m_pair[i] % V;
+        m_cls[i] = std::min(m_pair[i], (v ^ 1) * V + (u ^ 1));
+        m_wkey[i] = static_cast<uint64_t>(w_max - m_w[i]);           // weight descending
+    }
+    // rank order = (weight desc, class asc, (u, v) asc): least significant criterion first, every pass stable
+    perm.resize(m); tmp.resize(m);
+    std::iota(perm.begin(), perm.end(), 0u);                          // already in (u, v) order
+    radix_by(m_cls, perm, tmp);
+    radix_by(m_wkey, perm, tmp);
+    for (size_t i = 0; i < m; i++) {
+        const uint64_t p = m_pair[perm[i]];
+        src[i] = static_cast<int32_t>(p / V); dst[i] = static_cast<int32_t>(p % V); weight[i] = m_w[perm[i]];
+    }
+    *n_arcs_out = static_cast<int64_t>(m);
+    return PALACE_OK;
+}
 
 int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
                            const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
@@ -296,62 +403,64 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
         ssrc[e] = 2 * new_id[src[e] >> 1] + (src[e] & 1);
         sdst[e] = 2 * new_id[dst[e] >> 1] + (dst[e] & 1);
     }
-    palace_match_result sub;
+    SubResult sub;
     int rc = n_sub ? decompose_core(ctx, n_sub, sub_copies.data(), n_arcs, ssrc.data(), sdst.data(), iterations, aggressive, &sub)
                    : PALACE_OK;
     if (rc) return rc;
     for (int32_t &v : sub.verts) v = 2 * old_id[v >> 1] + (v & 1);
-    palace_match_result *res = new palace_match_result();
     const int64_t n_sub_comp = static_cast<int64_t>(sub.kind.size());
     const int last_round = iterations + (aggressive ? 1 : 0) - 1;
     const int64_t n_bare = static_cast<int64_t>(n_segs) - n_sub;
     const int64_t n_out = n_sub_comp + n_bare * (aggressive && last_round > 0 ? 2 : 1);
-    res->off.resize(static_cast<size_t>(n_out) + 1);
-    res->kind.resize(static_cast<size_t>(n_out));
-    res->iter.resize(static_cast<size_t>(n_out));
-    res->open_at.resize(static_cast<size_t>(n_out));
-    res->verts.resize(sub.verts.size() + static_cast<size_t>(n_out - n_sub_comp));
+    const int64_t nv_out = static_cast<int64_t>(sub.verts.size()) + (n_out - n_sub_comp);
+    palace_match_result *res = new palace_match_result();
+    res->off.reset(new int64_t[n_out + 1]);
+    res->kind.reset(new uint8_t[std::max<int64_t>(1, n_out)]);
+    res->iter.reset(new int32_t[std::max<int64_t>(1, n_out)]);
+    res->open_at.reset(new int32_t[std::max<int64_t>(1, n_out)]);
+    res->verts.reset(new int32_t[std::max<int64_t>(1, nv_out)]);
+    int64_t *r_off = res->off.get();
+    int32_t *r_verts = res->verts.get(), *r_iter = res->iter.get(), *r_open = res->open_at.get();
+    uint8_t *r_kind = res->kind.get();
     int64_t oc = 0, ov = 0;                               // next component / vertex slot
-    res->off[0] = 0;
+    r_off[0] = 0;
     auto emit_sub = [&](int64_t c) {
         const int64_t len = sub.off[c + 1] - sub.off[c];
-        std::copy(sub.verts.begin() + sub.off[c], sub.verts.begin() + sub.off[c + 1], res->verts.begin() + ov);
+        std::copy(sub.verts.begin() + sub.off[c], sub.verts.begin() + sub.off[c + 1], r_verts + ov);
         ov += len;
-        res->kind[oc] = sub.kind[c]; res->iter[oc] = sub.iter[c]; res->open_at[oc] = sub.open_at[c];
-        res->off[++oc] = ov;
+        r_kind[oc] = sub.kind[c]; r_iter[oc] = sub.iter[c]; r_open[oc] = sub.open_at[c];
+        r_off[++oc] = ov;
     };
-    auto emit_bare = [&](int32_t s, int round) {
-        res->verts[ov++] = 2 * s;
-        res->kind[oc] = 0; res->iter[oc] = round; res->open_at[oc] = 0;
-        res->off[++oc] = ov;
+    // bare segments from s up to (not including) `until`, as one-vertex paths of `round`
+    auto emit_bare_until = [&](int32_t &s, int32_t until, int round) {
+        for (; s < until; s++) {
+            if (new_id[s] >= 0) continue;
+            r_verts[ov++] = 2 * s;
+            r_kind[oc] = 0; r_iter[oc] = round; r_open[oc] = 0;
+            r_off[++oc] = ov;
+        }
     };
     int64_t c = 0;
     for (int round = 0; round <= last_round; round++) {
         const bool bare_round = round == 0 || (aggressive && round == last_round);
         int32_t s = 0;
-        auto next_bare = [&] { while (s < n_segs && new_id[s] >= 0) s++; };
-        next_bare();
         while (c < n_sub_comp && sub.iter[c] == round) {
-            if (bare_round)
-                while (s < n_segs && 2 * s < sub.verts[sub.off[c]]) { emit_bare(s, round); s++; next_bare(); }
+            if (bare_round) emit_bare_until(s, (sub.verts[sub.off[c]] + 1) >> 1, round);   // bare s with 2s < first vertex
             emit_sub(c++);
         }
-        if (bare_round)
-            while (s < n_segs) { emit_bare(s, round); s++; next_bare(); }
+        if (bare_round) emit_bare_until(s, n_segs, round);
     }
-    res->off.resize(static_cast<size_t>(oc) + 1);
-    res->kind.resize(static_cast<size_t>(oc)); res->iter.resize(static_cast<size_t>(oc)); res->open_at.resize(static_cast<size_t>(oc));
-    res->verts.resize(static_cast<size_t>(ov));
+    res->n = oc;
     *out = res;
     return PALACE_OK;
 }
 
-int64_t palace_match_result_count(const palace_match_result *r) { return r ? static_cast<int64_t>(r->kind.size()) : 0; }
-const int64_t *palace_match_result_offsets(const palace_match_result *r) { return r->off.data(); }
-const int32_t *palace_match_result_verts(const palace_match_result *r) { return r->verts.data(); }
-const uint8_t *palace_match_result_kind(const palace_match_result *r) { return r->kind.data(); }
-const int32_t *palace_match_result_iter(const palace_match_result *r) { return r->iter.data(); }
-const int32_t *palace_match_result_open_at(const palace_match_result *r) { return r->open_at.data(); }
+int64_t palace_match_result_count(const palace_match_result *r) { return r ? r->n : 0; }
+const int64_t *palace_match_result_offsets(const palace_match_result *r) { return r->off.get(); }
+const int32_t *palace_match_result_verts(const palace_match_result *r) { return r->verts.get(); }
+const uint8_t *palace_match_result_kind(const palace_match_result *r) { return r->kind.get(); }
+const int32_t *palace_match_result_iter(const palace_match_result *r) { return r->iter.get(); }
+const int32_t *palace_match_result_open_at(const palace_match_result *r) { return r->open_at.get(); }
 void palace_match_result_free(palace_match_result *r) { delete r; }
 
 }  // extern "C"
