@@ -547,7 +547,8 @@ def main():
         dt = float(tmax.item())
     ms_step = 1e3 * dt / args.steps
     K = range(args.steps)
-    count_ms = np.mean([ctx.mark_elapsed(8 * i, 8 * i + 1) for i in K])            # one launch per step (both FASTQ sides)
+    count_each = [ctx.mark_elapsed(8 * i, 8 * i + 1) for i in K]
+    count_ms = np.mean(count_each)                                                  # one launch per step (both FASTQ sides)
     merge_ms = np.mean([ctx.mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
     scan_ms = np.mean([ctx.mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
     classify_ms = np.mean([ctx_g.mark_elapsed(8 * i, 8 * i + 1) for i in K])
@@ -578,7 +579,7 @@ def main():
                          "traffic": 48.2e9 if (args.contigs == 1_000_000 and world == 1) else None,
                          "traffic_unit": "bytes per launch",
                          "avg_launch_ms": count_ms, "algorithmic_bytes_per_launch": alg_bytes},
-            "stage_ms": {"eref_count_both_sides": count_ms, "eref_table_merge": merge_ms, "eref_scan_refs": scan_ms,
+            "stage_ms": {"eref_count_each_step": [round(float(x), 3) for x in count_each], "eref_count_both_sides": count_ms, "eref_table_merge": merge_ms, "eref_scan_refs": scan_ms,
                          "graph_classify": classify_ms, "graph_resolve": resolve_ms,
                          **{"host_" + k: v for k, v in host_ms.items()},
                          "note": "eref runs on one HIP stream, generateGraph + matching on another; they overlap"},
