@@ -56,14 +56,12 @@ __device__ __forceinline__ Streams ballot_streams(const uint8_t *__restrict__ s,
     return Streams{__ballot(b.p0), __ballot(b.p1), __ballot(b.p2), __ballot(b.ok)};   // p* of invalid bases are never used
 }
 
-// bits [lane, lane+31] of the 128-bit value hi:lo, for lane in 0..63: pick the two 32-bit words that
-// hold them and funnel-shift (v_alignbit_b32).  (Two v_lshl/lshr_b64 on the scalar pairs plus an OR is
-// fewer instructions but measured 30 % slower in bin1: 64-bit shifts are not full rate.)
+// bits [lane, lane+31] of the 128-bit value hi:lo, for lane in 0..63.  lo and hi are wave-uniform
+// (ballots, SGPR pairs): two 64-bit shifts with the scalar pair as source and one OR (selecting the
+// two 32-bit words per lane for a v_alignbit costs three SGPR->VGPR moves and two selects more).
 __device__ __forceinline__ uint32_t window32(uint64_t lo, uint64_t hi, int lane)
 {
-    const uint32_t w0 = static_cast<uint32_t>(lo), w1 = static_cast<uint32_t>(lo >> 32), w2 = static_cast<uint32_t>(hi);
-    const bool upper = lane >= 32;
-    return __builtin_amdgcn_alignbit(upper ? w2 : w1, upper ? w1 : w0, static_cast<uint32_t>(lane) & 31u);
+    return static_cast<uint32_t>(lo >> lane) | static_cast<uint32_t>((hi << 1) << (63 - lane));
 }
 
 __device__ __forceinline__ uint32_t canonical(const CoderMasks &m, int i, uint32_t w0, uint32_t w1,
