@@ -398,19 +398,20 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin1_flat_kernel(const uint8
     });
 }
 
-// Work list of level 2: one entry (tile << 12 | region) per kTileKeys keys that level 1 actually left in a
+// Work list of level 2: one entry (tile << 16 | region) per kTileKeys keys that level 1 actually left in a
 // region, so that bin2 launches no empty workgroups (capacities are ~1.6 x the contents, and uneven).
-// One workgroup; thread t owns regions 4t .. 4t+3.
+// One workgroup; thread t owns kPerThread consecutive regions.
 __global__ __launch_bounds__(1024) void eref_tile_map_kernel(const unsigned int *__restrict__ cursor1, DensityCaps caps1,
                                                              uint32_t *__restrict__ tile_map, uint32_t map_cap,
                                                              unsigned int *__restrict__ n_tiles)
 {
-    static_assert(kL1Buckets * kL1Replicas == 4096, "region id is packed into 12 bits; 4 regions per thread");
+    constexpr int kPerThread = kL1Buckets * kL1Replicas / 1024;
+    static_assert(kL1Buckets * kL1Replicas % 1024 == 0 && kL1Buckets * kL1Replicas <= 65536, "region id is packed into 16 bits");
     __shared__ uint32_t wave_sum[16];
-    uint32_t t[4], mine = 0;
+    uint32_t t[kPerThread], mine = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t region = threadIdx.x * 4 + i;
+    for (int i = 0; i < kPerThread; i++) {
+        const uint32_t region = threadIdx.x * kPerThread + i;
         const uint32_t n = min(cursor1[region], caps1.cap(region / kL1Replicas));
         t[i] = (n + kTileKeys - 1) / kTileKeys;
         mine += t[i];
@@ -431,9 +432,9 @@ __global__ __launch_bounds__(1024) void eref_tile_map_kernel(const unsigned int 
     }
     uint32_t at = before + incl - mine;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < kPerThread; i++)
         for (uint32_t k = 0; k < t[i]; k++, at++)
-            if (at < map_cap) tile_map[at] = (k << 12) | (threadIdx.x * 4 + i);
+            if (at < map_cap) tile_map[at] = (k << 16) | (threadIdx.x * kPerThread + i);
     if (threadIdx.x == 0) *n_tiles = min(total, map_cap);
 }
 
@@ -445,10 +446,12 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin2_kernel(const unsigned i
 {
     __shared__ Stage st;
     if (blockIdx.x >= *n_tiles) return;                    // uniform for the workgroup
+    // (list order = region order on purpose: neighbours read neighbouring keys and write the same 128 fine
+    //  buckets; spreading them over the list with a coprime stride measured 10 % slower)
     const uint32_t entry = tile_map[blockIdx.x];
-    const uint32_t region = entry & 4095u, b1 = region / kL1Replicas, replica = region % kL1Replicas;
+    const uint32_t region = entry & 0xffffu, b1 = region / kL1Replicas, replica = region % kL1Replicas;
     const uint32_t n1 = min(cursor1[region], caps1.cap(b1));
-    const uint32_t start = (entry >> 12) * kTileKeys;
+    const uint32_t start = (entry >> 16) * kTileKeys;
     const uint32_t end = min(n1, start + kTileKeys);
     stage_init(st, false);
     __syncthreads();

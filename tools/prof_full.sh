@@ -9,6 +9,7 @@ echo "fetch pass done"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/${tag}_write --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> gpurun_out/${tag}_write.err || exit 1
 echo "write pass done"
 s=$(find gpurun_out/${tag}_stats -name '*kernel_stats.csv' | head -1)
+t=$(find gpurun_out/${tag}_stats -name '*kernel_trace.csv' | head -1)
 f=$(find gpurun_out/${tag}_fetch -name '*counter_collection.csv' | head -1)
 w=$(find gpurun_out/${tag}_write -name '*counter_collection.csv' | head -1)
-python3 tools/rocprof_summary.py gpurun_out/${tag}.md --stats $s --pmc FETCH_SIZE=$f --pmc WRITE_SIZE=$w
+python3 tools/rocprof_summary.py gpurun_out/${tag}.md --stats $s --trace $t --pmc FETCH_SIZE=$f --pmc WRITE_SIZE=$w

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output (gpurun_out/...) into a small text summary for profiles/.
-usage: rocprof_summary.py <out.md> --stats <kernel_stats.csv> [--pmc NAME=<counter_collection.csv> ...] [--note TEXT]"""
+usage: rocprof_summary.py <out.md> --stats <kernel_stats.csv> [--trace <kernel_trace.csv>] [--pmc NAME=<counter_collection.csv> ...] [--note TEXT]"""
 import collections
 import csv
 import sys
@@ -22,6 +22,20 @@ def main():
                 nm = r["Name"].split("(")[0].replace("void ", "")[:70]
                 lines.append(f"| {nm} | {r['Calls']} | {float(r['AverageNs'])/1e6:.4f} | "
                              f"{float(r['TotalDurationNs'])/1e6:.3f} | {float(r['Percentage']):.2f} |")
+            lines.append("")
+        elif args[i] == "--trace":
+            # per-kernel durations from the kernel trace: median next to the mean (a profiled run now and then
+            # shows one call several times longer than the rest; the median is what the unprofiled bench sees)
+            import statistics
+            dur = collections.defaultdict(list)
+            for r in csv.DictReader(open(args[i + 1])):
+                dur[r["Kernel_Name"].split("(")[0].replace("void ", "")[:70]].append(
+                    (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+            lines.append("## rocprofv3 --kernel-trace: per-kernel duration (palace kernels)\n")
+            lines.append("| kernel | calls | median ms | mean ms | max ms |\n|---|---|---|---|---|")
+            for k, v in sorted(dur.items(), key=lambda kv: -statistics.median(kv[1]) * len(kv[1])):
+                if "palace::" in k:
+                    lines.append(f"| {k} | {len(v)} | {statistics.median(v):.4f} | {sum(v)/len(v):.4f} | {max(v):.4f} |")
             lines.append("")
         elif args[i] == "--pmc":
             name, path = args[i + 1].split("=", 1)
