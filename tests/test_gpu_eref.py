@@ -309,6 +309,38 @@ def test_binned_equals_direct_at_scale(ctx):
         b.free()
 
 
+def test_binned_equals_direct_on_skewed_keys(ctx):
+    """Regions and staging rows are sized by the 2(1-x) density of hash-like keys.  Low-complexity input defeats
+    that model: a few distinct 32-mers, repeated by the million, pile onto a handful of rows and regions, which must
+    overflow into the exact direct path without changing the table."""
+    rng = synth.rng_for(23)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    unit = [synth.random_dna(rng, 150) for _ in range(3)] + [np.frombuffer(b"A" * 150, dtype=np.uint8),
+                                                             np.frombuffer(b"AC" * 75, dtype=np.uint8)]
+    pick = rng.integers(0, len(unit), size=120_000)
+    a = synth.reads_from_list([unit[i] for i in pick])                    # 18 Mbases, ~600 distinct keys
+    b = synth.vector_reads(rng, synth.random_dna(rng, 2_000_000), 60_000, 150)   # plus a normal share
+    bases = np.concatenate([a.bases, b.bases])
+    offsets = np.concatenate([a.offsets, b.offsets[1:] + a.offsets[-1]])
+    db_, do_ = ctx.upload(bases), ctx.upload(offsets)
+    ctx.eref_set_coder(hdr)
+    probe = np.unique(rng.integers(0, 2**32, size=200000, dtype=np.uint64).astype(np.uint32))
+    res = []
+    try:
+        for mode in (1, 2):
+            ctx.eref_set_count_mode(mode, 0)
+            ctx.eref_table_reset()
+            ctx.eref_count_reads(db_, do_, len(offsets) - 1)
+            ctx.sync()
+            res.append((ctx.eref_table_popcounts(), ctx.eref_table_lookup(probe)))
+    finally:
+        ctx.eref_set_count_mode(0, 0)
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    assert res[0][0][2] > 0
+    for x in (db_, do_):
+        x.free()
+
+
 def test_binned_flat_stream_with_offset_base_and_ragged_reads(ctx):
     """flat streaming bin kernel: read set that does not start at offset 0, reads of every length
     class (0, <32, ==32, long), N inside reads, read ends adjacent to chunk boundaries"""
