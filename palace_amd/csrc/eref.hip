@@ -398,60 +398,18 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin1_flat_kernel(const uint8
     });
 }
 
-// Work list of level 2: one entry (tile << 16 | region) per kTileKeys keys that level 1 actually left in a
-// region, so that bin2 launches no empty workgroups (capacities are ~1.6 x the contents, and uneven).
-// One workgroup; thread t owns kPerThread consecutive regions.
-__global__ __launch_bounds__(1024) void eref_tile_map_kernel(const unsigned int *__restrict__ cursor1, DensityCaps caps1,
-                                                             uint32_t *__restrict__ tile_map, uint32_t map_cap,
-                                                             unsigned int *__restrict__ n_tiles)
-{
-    constexpr int kPerThread = kL1Buckets * kL1Replicas / 1024;
-    static_assert(kL1Buckets * kL1Replicas % 1024 == 0 && kL1Buckets * kL1Replicas <= 65536, "region id is packed into 16 bits");
-    __shared__ uint32_t wave_sum[16];
-    uint32_t t[kPerThread], mine = 0;
-#pragma unroll
-    for (int i = 0; i < kPerThread; i++) {
-        const uint32_t region = threadIdx.x * kPerThread + i;
-        const uint32_t n = min(cursor1[region], caps1.cap(region / kL1Replicas));
-        t[i] = (n + kTileKeys - 1) / kTileKeys;
-        mine += t[i];
-    }
-    uint32_t incl = mine;                                   // inclusive scan inside the wave, then over the 16 waves
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d);
-        if (lane >= d) incl += up;
-    }
-    if (lane == 63) wave_sum[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-    for (int w = 0; w < 16; w++) {
-        if (w < wave) before += wave_sum[w];
-        total += wave_sum[w];
-    }
-    uint32_t at = before + incl - mine;
-#pragma unroll
-    for (int i = 0; i < kPerThread; i++)
-        for (uint32_t k = 0; k < t[i]; k++, at++)
-            if (at < map_cap) tile_map[at] = (k << 16) | (threadIdx.x * kPerThread + i);
-    if (threadIdx.x == 0) *n_tiles = min(total, map_cap);
-}
-
-// level 2: one workgroup per work-list entry = kTileKeys keys of one level-1 region (bucket b1, replica)
+// level 2: blockIdx.y = level-1 region (bucket b1, replica), blockIdx.x = tile of kTileKeys of its keys.  The grid
+// covers the largest region's capacity, so most workgroups of the sparser buckets leave at once; a device-built
+// list of the non-empty tiles (one extra single-workgroup kernel) was measured and cost more than it saved.
 __global__ __launch_bounds__(kBinThreads) void eref_bin2_kernel(const unsigned int *__restrict__ cursor1,
                                                                 const uint32_t *__restrict__ buf1, DensityCaps caps1,
-                                                                const uint32_t *__restrict__ tile_map,
-                                                                const unsigned int *__restrict__ n_tiles, BinOut o)
+                                                                BinOut o)
 {
     __shared__ Stage st;
-    if (blockIdx.x >= *n_tiles) return;                    // uniform for the workgroup
-    // (list order = region order on purpose: neighbours read neighbouring keys and write the same 128 fine
-    //  buckets; spreading them over the list with a coprime stride measured 10 % slower)
-    const uint32_t entry = tile_map[blockIdx.x];
-    const uint32_t region = entry & 0xffffu, b1 = region / kL1Replicas, replica = region % kL1Replicas;
+    const uint32_t region = blockIdx.y, b1 = region / kL1Replicas, replica = region % kL1Replicas;
     const uint32_t n1 = min(cursor1[region], caps1.cap(b1));
-    const uint32_t start = (entry >> 16) * kTileKeys;
+    const uint32_t start = blockIdx.x * kTileKeys;
+    if (start >= n1) return;                               // uniform for the workgroup
     const uint32_t end = min(n1, start + kTileKeys);
     stage_init(st, false);
     __syncthreads();
@@ -1142,20 +1100,12 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     const size_t buf2_bytes = align_up(static_cast<size_t>(caps2.prefix(kL1Buckets)) * kL1Buckets * 4, 256);
     const int64_t n_chunks = (total_bases + 63) / 64;
     const size_t ends_bytes = align_up(static_cast<size_t>(n_chunks + 2) * 8, 256);
-    // level-2 work list: the regions cannot hold more than their capacity, so (sum of capacities) / kTileKeys
-    // full tiles plus one partial tile per region bound it for any input
-    const uint64_t map_cap64 = caps1.prefix(kL1Buckets) * kL1Replicas / kTileKeys + kRegions;
-    PALACE_REQUIRE(map_cap64 < (1ull << 31), "slab too large for one level-2 launch");
-    const uint32_t map_cap = static_cast<uint32_t>(map_cap64);
-    const size_t map_bytes = align_up((static_cast<size_t>(map_cap) + 1) * 4, 256);
-    rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + ends_bytes + map_bytes + buf1_bytes + buf2_bytes);
+    rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + ends_bytes + buf1_bytes + buf2_bytes);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
     unsigned int *cursor1 = reinterpret_cast<unsigned int *>(ws); ws += cur1_bytes;
     unsigned int *cursor2 = reinterpret_cast<unsigned int *>(ws); ws += cur2_bytes;
     unsigned long long *ends = reinterpret_cast<unsigned long long *>(ws); ws += ends_bytes;
-    uint32_t *tile_map = reinterpret_cast<uint32_t *>(ws); ws += map_bytes;       // [map_cap] entries, then the count
-    unsigned int *n_tiles = tile_map + map_cap;
     uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
     uint32_t *buf2 = reinterpret_cast<uint32_t *>(ws);
     BinOut o1{cursor1, buf1, caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
@@ -1195,9 +1145,9 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
                                0, ctx->stream, d_bases, d_offsets, total_bases, c_lo, c_hi, ends, ctx->masks, cpw, o1);
         }
         PALACE_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(eref_tile_map_kernel, dim3(1), dim3(1024), 0, ctx->stream, cursor1, caps1, tile_map, map_cap, n_tiles);
-        hipLaunchKernelGGL(eref_bin2_kernel, dim3(map_cap), dim3(kBinThreads), 0, ctx->stream, cursor1, buf1, caps1, tile_map,
-                           n_tiles, o2);
+        const unsigned tiles2 = (caps1.cap(0) + kTileKeys - 1) / kTileKeys;          // bucket 0 has the largest regions
+        hipLaunchKernelGGL(eref_bin2_kernel, dim3(tiles2, static_cast<unsigned>(kRegions)), dim3(kBinThreads), 0, ctx->stream,
+                           cursor1, buf1, caps1, o2);
         PALACE_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, cursor2, buf2, caps2,
                            ctx->plane[0], ctx->plane[1], ctx->plane[2]);
