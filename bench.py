@@ -266,10 +266,14 @@ def reference_eref_check(b1, b2, off, rb, ro, n_ref_s, tmp):
             if frac == 2:                            # untimed run that leaves the index beside the DB
                 subprocess.run([ref_bin, os.path.join(tmp, "s_1.fq"), os.path.join(tmp, "s_2.fq"), fa, os.path.join(tmp, "t.txt"),
                                 "0.9", "0.85", "1"], stdout=subprocess.DEVNULL, check=True, timeout=300)
-            t0 = time.perf_counter()
-            subprocess.run([ref_bin, os.path.join(tmp, "s_1.fq"), os.path.join(tmp, "s_2.fq"), fa, os.path.join(tmp, "t.txt"),
-                            "0.9", "0.85", "1"], stdout=subprocess.DEVNULL, check=True, timeout=300)
-            times[2 * m] = time.perf_counter() - t0
+            best = None
+            for _ in range(2):                       # best of two: the fixed part (4 GiB table, 16 GiB dead arrays) is noisy
+                t0 = time.perf_counter()
+                subprocess.run([ref_bin, os.path.join(tmp, "s_1.fq"), os.path.join(tmp, "s_2.fq"), fa, os.path.join(tmp, "t.txt"),
+                                "0.9", "0.85", "1"], stdout=subprocess.DEVNULL, check=True, timeout=300)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            times[2 * m] = best
         (ra, ta), (rbn, tb) = sorted(times.items())
         marginal = (rbn - ra) / max(1e-9, tb - ta)
         return dict(binary="oracle/_ref/eref_ref (unmodified extract_ref.cpp, -O2, threads=1, cached index)",
