@@ -394,7 +394,12 @@ def main():
     ctx = capi.Ctx(local)                      # eref stream
     ctx_g = capi.Ctx(local, high_priority=True)   # generateGraph + matching stream (independent of eref until the end)
     ctx.eref_set_coder(hdr)
-    sample = make_sample(torch, dev, args.contigs, args.refs, rank, world)
+    # Phase A across ranks.  Sharding the reads costs a count-table exchange: every rank ships (W-1)/W of three 512 MiB
+    # planes and receives the merged ">= 3" plane, about 1.4 GB each way whatever W is, over W-1 xGMI links -- one link
+    # at W = 2 (~15 ms, more than the ~7 ms the split saves), seven at W = 8 (~3.5 ms).  Below four ranks every rank
+    # therefore counts ALL reads (no exchange) and only Phase B, generateGraph and the gathers are sharded.
+    shard_reads = world >= 4 or force_exchange
+    sample = make_sample(torch, dev, args.contigs, args.refs, rank if shard_reads else 0, world if shard_reads else 1)
     gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world)
     if world > 1 or force_exchange:                 # avgDepth is a pipeline input: computed once from all shards
         tot = torch.tensor([float(gs["col"]["ref_len"].sum().item())], device=dev, dtype=torch.float64)
@@ -451,7 +456,7 @@ def main():
         if timed: ctx.mark(m + 1)
 
         def eref_tail():
-            if exch:                                   # count-table exchange (RCCL), then Phase B on this rank's refs
+            if exch and shard_reads:                   # count-table exchange (RCCL), then Phase B on this rank's refs
                 ctx.sync()
                 exch.merge_planes(planes, merge_fn)
                 torch.cuda.synchronize()
@@ -572,7 +577,8 @@ def main():
                                    f"{2 * sample['n_pairs_total']} reads x {READ_LEN} bp, {gs['n_total']} primary BAM records, "
                                    f"{gs['n_fastg']} FASTG links",
                        "stages": ["eref", "generateGraph", "matching"], "seed": SEED,
-                       "parallelism": "1 GPU" if world == 1 else f"reads/records/refs sharded over {world} GPUs (RCCL)",
+                       "parallelism": "1 GPU" if world == 1 else (f"reads/records/refs sharded over {world} GPUs (RCCL)" if shard_reads else
+                                                                   f"records/refs sharded over {world} GPUs (RCCL), reads counted on every GPU"),
                        "ref_index": "per-DB probe index prebuilt, as the reference's cached <fasta>.k32.index.dat (8 B/position in HBM)",
                        "refs_reported": reported, "refs_present": int(len(sample["present"])),
                        "graph": {k: last[k] for k in ("n_cands", "n_edges", "n_arcs", "n_comp", "n_cycles", "n_multi")}},
