@@ -464,21 +464,31 @@ __global__ __launch_bounds__(1024) void eref_lds_count_kernel(const unsigned int
         reinterpret_cast<uint4 *>(l3)[i] = g3[i];
     }
     __syncthreads();
-    const uint32_t *keys = binned + fine_region_base(caps, b >> 7, b & 127);
-    constexpr int kBatch = 8;                              // key loads in flight per thread
-    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kBatch * blockDim.x) {
-        uint32_t k[kBatch];
+    // keys four at a time (regions start on 16-byte boundaries and capacities are multiples of 4 keys, so the last
+    // vector may run past n but not past the region), 4 vector loads in flight per thread
+    const uint4 *keys = reinterpret_cast<const uint4 *>(binned + fine_region_base(caps, b >> 7, b & 127));
+    const uint32_t n4 = (n + 3) / 4;
+    auto apply = [&](uint32_t k) {
+        const uint32_t w = (k & ((1u << kBucketShift) - 1)) >> 5, bit = 1u << (k & 31);
+        if (atomicOr(&l1[w], bit) & bit)
+            if (atomicOr(&l2[w], bit) & bit) atomicOr(&l3[w], bit);
+    };
+    constexpr int kBatch = 4;
+    for (uint32_t i0 = threadIdx.x; i0 < n4; i0 += kBatch * blockDim.x) {
+        uint4 v[kBatch];
 #pragma unroll
         for (int u = 0; u < kBatch; u++) {
             const uint32_t i = i0 + u * blockDim.x;
-            k[u] = (i < n) ? keys[i] : 0xffffffffu;
+            v[u] = i < n4 ? keys[i] : uint4{0, 0, 0, 0};
         }
 #pragma unroll
         for (int u = 0; u < kBatch; u++) {
-            if (i0 + u * blockDim.x >= n) break;
-            const uint32_t w = (k[u] & ((1u << kBucketShift) - 1)) >> 5, bit = 1u << (k[u] & 31);
-            if (atomicOr(&l1[w], bit) & bit)
-                if (atomicOr(&l2[w], bit) & bit) atomicOr(&l3[w], bit);
+            const uint32_t i = i0 + u * blockDim.x;
+            if (i >= n4) break;
+            const uint32_t k[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (4 * i + e < n) apply(k[e]);
         }
     }
     __syncthreads();
