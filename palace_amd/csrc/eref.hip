@@ -572,11 +572,13 @@ __global__ __launch_bounds__(256) void eref_ref_kernel(const uint8_t *__restrict
                                                        uint64_t *__restrict__ all_words,
                                                        uint32_t *__restrict__ idx_out,
                                                        const int64_t *__restrict__ idx_offsets,
-                                                       const uint8_t *__restrict__ need)
+                                                       const uint8_t *__restrict__ need,
+                                                       const uint8_t *__restrict__ active)
 {
     const int64_t tile = blockIdx.x;
     if (tile >= tile_pre[n_refs]) return;
     const int64_t r = find_seq(tile_pre, n_refs, tile);
+    if (MODE == 0 && active && !active[r]) return;       // inactive ref (eref_need_kernel): nobody reads its words
     const int64_t beg = offsets[r], len = offsets[r + 1] - beg;
     const int64_t npos = len - 31;                       // may be <= 0
     const int64_t n_chunks = (len + 63) / 64;
@@ -795,12 +797,13 @@ __global__ __launch_bounds__(1024) void eref_probe_kernel(const unsigned long lo
 // enough channel-0 hits, and only those chunks get the other two probes.  Everywhere else `all` is 0
 // and `any` keeps the channel-0 bits: every window touching such a chunk fails the three_min test
 // with the true bits already, so the substitution cannot change any good[j].
-__global__ __launch_bounds__(256) void eref_need_kernel(const int64_t *__restrict__ offsets, int64_t n_refs,
+constexpr int kRefThreads = 1024;      // per-ref kernels: one workgroup walks a whole ref, so its latency is the kernel's
+__global__ __launch_bounds__(kRefThreads) void eref_need_kernel(const int64_t *__restrict__ offsets, int64_t n_refs,
                                                         const int64_t *__restrict__ word_pre,
                                                         const uint64_t *__restrict__ c0_words,
                                                         uint32_t *__restrict__ c0_pre, uint64_t *__restrict__ cand_words,
                                                         uint32_t *__restrict__ cand_pre, int three_min,
-                                                        uint8_t *__restrict__ need)
+                                                        uint8_t *__restrict__ need, uint8_t *__restrict__ active)
 {
     const int64_t r = blockIdx.x;
     if (r >= n_refs) return;
@@ -810,12 +813,13 @@ __global__ __launch_bounds__(256) void eref_need_kernel(const int64_t *__restric
     uint32_t *PA = c0_pre + w0, *PC = cand_pre + w0;
     uint64_t *C = cand_words + w0;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    __shared__ uint32_t s_part[4];
+    constexpr int kWaves = kRefThreads / 64;
+    __shared__ uint32_t s_part[kWaves];
     __shared__ uint32_t carry;
     auto block_prefix = [&](const uint64_t *W, uint32_t *P) {     // exclusive prefix popcount per word
         if (t == 0) carry = 0;
         __syncthreads();
-        for (int64_t base = 0; base < n_words; base += 256) {
+        for (int64_t base = 0; base < n_words; base += kRefThreads) {
             const int64_t w = base + t;
             const uint32_t c = (w < n_words) ? __popcll(W[w]) : 0;
             uint32_t inc = c;
@@ -830,14 +834,31 @@ __global__ __launch_bounds__(256) void eref_need_kernel(const int64_t *__restric
             for (int k = 0; k < wv; k++) o += s_part[k];
             if (w < n_words) P[w] = o + inc - c;
             __syncthreads();
-            if (t == 255) carry = o + inc;
+            if (t == kRefThreads - 1) carry = o + inc;
             __syncthreads();
         }
     };
+    // A ref with fewer than three_min channel-0 hits altogether has no passing window (most refs of a DB have none
+    // at all): it is marked inactive, and neither the other two channels nor the window scan look at it.
+    {
+        uint32_t mine = 0;
+        for (int64_t w = t; w < n_words; w += kRefThreads) mine += __popcll(A[w]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+        if (lane == 0) s_part[wv] = mine;
+        __syncthreads();
+        uint32_t total = 0;
+        for (int k = 0; k < kWaves; k++) total += s_part[k];
+        const bool live = static_cast<int>(total) >= three_min;
+        if (t == 0) active[r] = live;
+        if (!live) return;                                         // uniform for the workgroup
+        __syncthreads();                                           // s_part is reused below
+    }
     block_prefix(A, PA);
     __threadfence_block();
     __syncthreads();
-    for (int64_t w = wv; w < n_words; w += 4) {                    // cand[j]: channel-0 hits in (j-500, j] >= three_min
+#pragma unroll 4
+    for (int64_t w = wv; w < n_words; w += kWaves) {               // cand[j]: channel-0 hits in (j-500, j] >= three_min
         const int64_t j = w * 64 + lane;
         bool cand = false;
         if (j < len) {
@@ -853,7 +874,12 @@ __global__ __launch_bounds__(256) void eref_need_kernel(const int64_t *__restric
     block_prefix(C, PC);
     __threadfence_block();
     __syncthreads();
-    for (int64_t w = t; w < n_words; w += 256) {                   // chunk w is needed iff a cand j lies in [64w, 64w+562]
+    // no window with enough channel-0 hits anywhere in the ref (the usual case: chance hits are spread thin) -> inactive
+    if (carry == 0) {                                              // carry = number of candidate positions; uniform
+        if (t == 0) active[r] = 0;
+        return;
+    }
+    for (int64_t w = t; w < n_words; w += kRefThreads) {           // chunk w is needed iff a cand j lies in [64w, 64w+562]
         const int64_t hi = min(len - 1, w * 64 + 63 + 499);
         uint32_t upto = prefix_count(C, PC, hi);
         uint32_t before = w ? prefix_count(C, PC, w * 64 - 1) : 0u;
@@ -861,32 +887,38 @@ __global__ __launch_bounds__(256) void eref_need_kernel(const int64_t *__restric
     }
 }
 
-__global__ __launch_bounds__(256) void eref_window_kernel(const int64_t *__restrict__ offsets,
-                                                          int64_t n_refs,
-                                                          const int64_t *__restrict__ word_pre,
-                                                          const uint64_t *__restrict__ any_words,
-                                                          const uint64_t *__restrict__ all_words,
-                                                          uint32_t *__restrict__ any_pre,
-                                                          uint32_t *__restrict__ all_pre,
-                                                          uint64_t *__restrict__ good_words,
-                                                          int one_min, int three_min,
-                                                          int32_t *__restrict__ rows)
+__global__ __launch_bounds__(kRefThreads) void eref_window_kernel(const int64_t *__restrict__ offsets,
+                                                                  int64_t n_refs,
+                                                                  const int64_t *__restrict__ word_pre,
+                                                                  const uint64_t *__restrict__ any_words,
+                                                                  const uint64_t *__restrict__ all_words,
+                                                                  uint32_t *__restrict__ any_pre,
+                                                                  uint32_t *__restrict__ all_pre,
+                                                                  uint64_t *__restrict__ good_words,
+                                                                  int one_min, int three_min,
+                                                                  const uint8_t *__restrict__ active,
+                                                                  int32_t *__restrict__ rows)
 {
     const int64_t r = blockIdx.x;
     if (r >= n_refs) return;
     const int64_t len = offsets[r + 1] - offsets[r];
+    if (!active[r]) {                                              // see eref_need_kernel: no window can pass
+        if (threadIdx.x == 0) { rows[4 * r + 0] = 0; rows[4 * r + 1] = 0; rows[4 * r + 2] = static_cast<int>(len); rows[4 * r + 3] = 0; }
+        return;
+    }
     const int64_t n_words = (len + 63) / 64, w0 = word_pre[r];
     const uint64_t *A = any_words + w0, *T = all_words + w0;
     uint32_t *PA = any_pre + w0, *PT = all_pre + w0;
     uint64_t *G = good_words + w0;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    constexpr int kWaves = kRefThreads / 64;
 
-    // (a) exclusive prefix population counts per 64-position word, 256 words per sweep
-    __shared__ uint32_t s_a[4], s_t[4];
+    // (a) exclusive prefix population counts per 64-position word, kRefThreads words per sweep
+    __shared__ uint32_t s_a[kWaves], s_t[kWaves];
     __shared__ uint32_t carry_a, carry_t;
     if (t == 0) { carry_a = 0; carry_t = 0; }
     __syncthreads();
-    for (int64_t base = 0; base < n_words; base += 256) {
+    for (int64_t base = 0; base < n_words; base += kRefThreads) {
         int64_t w = base + t;
         uint32_t ca = (w < n_words) ? __popcll(A[w]) : 0, ct = (w < n_words) ? __popcll(T[w]) : 0;
         uint32_t ia = ca, it = ct;                     // inclusive scan inside the wave
@@ -901,14 +933,15 @@ __global__ __launch_bounds__(256) void eref_window_kernel(const int64_t *__restr
         for (int k = 0; k < wv; k++) { oa += s_a[k]; ot += s_t[k]; }
         if (w < n_words) { PA[w] = oa + ia - ca; PT[w] = ot + it - ct; }
         __syncthreads();
-        if (t == 255) { carry_a = oa + ia; carry_t = ot + it; }
+        if (t == kRefThreads - 1) { carry_a = oa + ia; carry_t = ot + it; }
         __syncthreads();
     }
     __threadfence_block();
     __syncthreads();
 
     // (b) good[j]: >= one_min any-hits and >= three_min all-hits among positions (j-500, j]
-    for (int64_t w = wv; w < n_words; w += 4) {
+#pragma unroll 4
+    for (int64_t w = wv; w < n_words; w += kWaves) {
         int64_t j = w * 64 + lane;
         bool good = false;
         if (j < len) {
@@ -924,27 +957,59 @@ __global__ __launch_bounds__(256) void eref_window_kernel(const int64_t *__restr
 
     // (c) rising edge -> start = max(1, j-1000); falling edge (or end of ref) -> end =
     //     min(len, j+1000); merge into the previous interval when start - prev_end < 500.
+    //     The edges (a handful per ref) are collected by all threads, ordered and merged by one; a ref with
+    //     more edges than the list holds is walked serially.
+    constexpr int kMaxEdges = 1024;
+    __shared__ uint32_t edge[kMaxEdges];               // position << 1 | rising
+    __shared__ unsigned int n_edge;
+    if (t == 0) n_edge = 0;
+    __syncthreads();
+    for (int64_t w = t; w <= n_words; w += kRefThreads) {          // one virtual zero word closes an open run
+        const uint64_t g = (w < n_words) ? G[w] : 0;
+        const uint64_t prev_bit = w ? (G[w - 1] >> 63) : 0;
+        uint64_t x = g ^ ((g << 1) | prev_bit);
+        while (x) {
+            const int b = __ffsll(static_cast<long long>(x)) - 1;
+            x &= x - 1;
+            const unsigned int at = atomicAdd(&n_edge, 1u);
+            if (at < kMaxEdges) edge[at] = (static_cast<uint32_t>(w * 64 + b) << 1) | static_cast<uint32_t>((g >> b) & 1);
+        }
+    }
+    __syncthreads();
     if (t == 0) {
         int frag = 0, el = 0, start = 0, prev_end = 0;
-        uint64_t prev_bit = 0;
         const int ilen = static_cast<int>(len);
-        for (int64_t w = 0; w <= n_words; w++) {
-            uint64_t g = (w < n_words) ? G[w] : 0;     // one virtual zero word closes an open run
-            uint64_t x = g ^ ((g << 1) | prev_bit);
-            while (x) {
-                int b = __ffsll(static_cast<long long>(x)) - 1;
-                x &= x - 1;
-                int j = static_cast<int>(w * 64 + b);
-                if ((g >> b) & 1) {
-                    start = max(1, j - 1000);
-                } else {
-                    int end = min(ilen, j + 1000);
-                    if (frag > 0 && start - prev_end < 500) { el += end - prev_end; }
-                    else { frag++; el += end - start; }
-                    prev_end = end;
-                }
+        auto on_edge = [&](int j, bool rising) {
+            if (rising) {
+                start = max(1, j - 1000);
+            } else {
+                int end = min(ilen, j + 1000);
+                if (frag > 0 && start - prev_end < 500) { el += end - prev_end; }
+                else { frag++; el += end - start; }
+                prev_end = end;
             }
-            prev_bit = g >> 63;
+        };
+        if (n_edge <= kMaxEdges) {
+            const int n = static_cast<int>(n_edge);
+            for (int i = 1; i < n; i++) {                          // insertion sort: a handful of entries
+                const uint32_t e = edge[i];
+                int k = i - 1;
+                while (k >= 0 && edge[k] > e) { edge[k + 1] = edge[k]; k--; }
+                edge[k + 1] = e;
+            }
+            for (int i = 0; i < n; i++) on_edge(static_cast<int>(edge[i] >> 1), edge[i] & 1u);
+        } else {
+            uint64_t prev_bit = 0;
+            for (int64_t w = 0; w <= n_words; w++) {
+                uint64_t g = (w < n_words) ? G[w] : 0;
+                uint64_t x = g ^ ((g << 1) | prev_bit);
+                while (x) {
+                    int b = __ffsll(static_cast<long long>(x)) - 1;
+                    x &= x - 1;
+                    on_edge(static_cast<int>(w * 64 + b), (g >> b) & 1);
+                }
+                prev_bit = g >> 63;
+            }
         }
         rows[4 * r + 0] = frag;
         rows[4 * r + 1] = el;
@@ -1214,7 +1279,8 @@ int palace_eref_index_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_
     hipLaunchKernelGGL(eref_ref_kernel<1>, dim3(static_cast<unsigned>(max_tiles)), dim3(256), 0, ctx->stream,
                        d_bases, d_offsets, n_refs, tile_pre, word_pre, ctx->masks,
                        static_cast<const uint32_t *>(nullptr), static_cast<uint64_t *>(nullptr),
-                       static_cast<uint64_t *>(nullptr), d_out, d_out_offsets, static_cast<const uint8_t *>(nullptr));
+                       static_cast<uint64_t *>(nullptr), d_out, d_out_offsets, static_cast<const uint8_t *>(nullptr),
+                       static_cast<const uint8_t *>(nullptr));
     PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
 }
@@ -1234,7 +1300,7 @@ struct ScanBuffers {
     int64_t *tile_pre, *word_pre;
     uint64_t *any_w, *all_w, *good_w;
     uint32_t *any_p, *all_p;
-    uint8_t *need;
+    uint8_t *need, *active;                 // per chunk / per ref flags of eref_need_kernel
     int64_t max_tiles, max_words;
 };
 
@@ -1246,7 +1312,7 @@ int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int6
     const size_t pre_bytes = align_up((n_refs + 1) * 8, 256);
     const size_t w64 = align_up(b->max_words * 8, 256), w32 = align_up(b->max_words * 4, 256);
     const size_t w8 = align_up(b->max_words, 256);
-    int rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32 + w8);
+    int rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32 + w8 + align_up(n_refs + 1, 256));
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
     b->tile_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
@@ -1256,7 +1322,8 @@ int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int6
     b->good_w = reinterpret_cast<uint64_t *>(ws); ws += w64;
     b->any_p = reinterpret_cast<uint32_t *>(ws); ws += w32;
     b->all_p = reinterpret_cast<uint32_t *>(ws); ws += w32;
-    b->need = reinterpret_cast<uint8_t *>(ws);
+    b->need = reinterpret_cast<uint8_t *>(ws); ws += w8;
+    b->active = reinterpret_cast<uint8_t *>(ws);
     return launch_prefix(ctx, d_offsets, n_refs, b->tile_pre, b->word_pre);
 }
 
@@ -1265,17 +1332,17 @@ int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int6
 int scan_tail(palace_ctx *ctx, const ScanBuffers &b, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_refs,
               int one_min, int three_min, int32_t *d_rows)
 {
-    hipLaunchKernelGGL(eref_need_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(256), 0, ctx->stream, d_offsets,
-                       n_refs, b.word_pre, b.any_w, b.any_p, b.good_w, b.all_p, three_min, b.need);
+    hipLaunchKernelGGL(eref_need_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(kRefThreads), 0, ctx->stream, d_offsets,
+                       n_refs, b.word_pre, b.any_w, b.any_p, b.good_w, b.all_p, three_min, b.need, b.active);
     PALACE_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(eref_ref_kernel<0>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
                        d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, ctx->plane[2], b.any_w,
                        b.all_w, static_cast<uint32_t *>(nullptr), static_cast<const int64_t *>(nullptr),
-                       static_cast<const uint8_t *>(b.need));
+                       static_cast<const uint8_t *>(b.need), static_cast<const uint8_t *>(b.active));
     PALACE_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(eref_window_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(eref_window_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(kRefThreads), 0, ctx->stream,
                        d_offsets, n_refs, b.word_pre, b.any_w, b.all_w, b.any_p, b.all_p, b.good_w, one_min, three_min,
-                       d_rows);
+                       static_cast<const uint8_t *>(b.active), d_rows);
     PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
 }
@@ -1310,7 +1377,7 @@ int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t
     hipLaunchKernelGGL(eref_ref_kernel<2>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
                        d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, ctx->plane[2], b.any_w,
                        b.all_w, static_cast<uint32_t *>(nullptr), static_cast<const int64_t *>(nullptr),
-                       static_cast<const uint8_t *>(nullptr));
+                       static_cast<const uint8_t *>(nullptr), static_cast<const uint8_t *>(nullptr));
     PALACE_HIP_TRY(hipGetLastError());
     return scan_tail(ctx, b, d_bases, d_offsets, n_refs, one_min, three_min, d_rows);
 }
