@@ -838,21 +838,24 @@ __global__ __launch_bounds__(kRefThreads) void eref_need_kernel(const int64_t *_
             __syncthreads();
         }
     };
-    // A ref with fewer than three_min channel-0 hits altogether has no passing window (most refs of a DB have none
-    // at all): it is marked inactive, and neither the other two channels nor the window scan look at it.
+    // Cheap exclusion first.  A 500-position window with >= three_min channel-0 hits overlaps at most two aligned
+    // 512-position groups (8 words), so one of them holds >= three_min / 2 of its hits.  Chance hits are spread
+    // thin (a few per hundred positions), so for most refs of a DB no group comes close: the ref is marked
+    // inactive -- no window of it can pass -- and neither the other two channels nor the window scan look at it.
     {
-        uint32_t mine = 0;
-        for (int64_t w = t; w < n_words; w += kRefThreads) mine += __popcll(A[w]);
+        bool dense = false;
+        for (int64_t g = t; g * 8 < n_words; g += kRefThreads) {
+            uint32_t c = 0;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
-        if (lane == 0) s_part[wv] = mine;
-        __syncthreads();
-        uint32_t total = 0;
-        for (int k = 0; k < kWaves; k++) total += s_part[k];
-        const bool live = static_cast<int>(total) >= three_min;
-        if (t == 0) active[r] = live;
-        if (!live) return;                                         // uniform for the workgroup
-        __syncthreads();                                           // s_part is reused below
+            for (int k = 0; k < 8; k++) c += (g * 8 + k < n_words) ? __popcll(A[g * 8 + k]) : 0;
+            dense |= 2 * static_cast<int>(c) >= three_min;
+        }
+        const bool live = __syncthreads_or(dense);
+        if (!live) {                                               // uniform for the workgroup
+            if (t == 0) active[r] = 0;
+            return;
+        }
+        if (t == 0) active[r] = 1;
     }
     block_prefix(A, PA);
     __threadfence_block();
