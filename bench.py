@@ -425,6 +425,10 @@ def main():
                                                            "clip_s", "clip_e", "flag", "mapq", "qkey")), P(gs["sa_off"]))
     prm = capi.GraphParams.default()
     exch = multigpu.Exchange(torch, dist, rank, world) if (world > 1 or force_exchange) else None
+    # torch ops and collectives run on torch's current stream, the library's kernels on the two context streams; the
+    # hand-over points wait for exactly the stream that produced the data (a device-wide synchronize here would make the
+    # generateGraph exchange wait for the eref counting kernels and vice versa)
+    tsync = lambda: torch.cuda.current_stream().synchronize()
     if exch:
         planes = [torch.zeros(1 << 29, dtype=torch.uint8, device=dev) for _ in range(3)]   # torch-owned so RCCL
         ctx.eref_table_attach([t.data_ptr() for t in planes])                                # can address them
@@ -432,7 +436,7 @@ def main():
         scratch_consumed = torch.zeros(nt, dtype=torch.int64, device=dev)
 
         def merge_fn(parts, n_parts, slice_off, slice_bytes):
-            torch.cuda.synchronize()
+            tsync()
             ctx.eref_table_merge_slices(parts.data_ptr(), n_parts, slice_off, slice_bytes)
             ctx.sync()
     last = {}
@@ -448,18 +452,22 @@ def main():
     def step(i, timed):
         m = 8 * i
         tot_b = n_side * READ_LEN
-        # ---------------- eref: launched first, runs asynchronously on its own stream ----------------
-        capi._check(L.palace_eref_table_reset(ctx.h), "reset")
-        if timed: ctx.mark(m)
-        # both FASTQ sides as one read set: one binning pass, the plane slices are loaded and stored once
-        capi._check(L.palace_eref_count_reads(ctx.h, P(sample["r12"]), P(sample["read_off"]), 2 * n_side, None, 2 * tot_b), "count")
-        if timed: ctx.mark(m + 1)
+        # ---------------- eref: runs asynchronously on its own stream ----------------
+        def eref_head():
+            capi._check(L.palace_eref_table_reset(ctx.h), "reset")
+            if timed: ctx.mark(m)
+            # both FASTQ sides as one read set: one binning pass, the plane slices are loaded and stored once
+            capi._check(L.palace_eref_count_reads(ctx.h, P(sample["r12"]), P(sample["read_off"]), 2 * n_side, None, 2 * tot_b), "count")
+            if timed: ctx.mark(m + 1)
+
+        if not exch:
+            eref_head()                                # one GPU: launched first, generateGraph + matching overlap it
 
         def eref_tail():
             if exch and shard_reads:                   # count-table exchange (RCCL), then Phase B on this rank's refs
                 ctx.sync()
                 exch.merge_planes(planes, merge_fn)
-                torch.cuda.synchronize()
+                tsync()
             if timed: ctx.mark(m + 2)
             capi._check(L.palace_eref_scan_refs_indexed(ctx.h, probe_index, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
                                                         sample["ref_total"], one_min, three_min, P(rows) + 16 * r_lo), "scan")
@@ -467,7 +475,7 @@ def main():
             if exch:
                 ctx.sync()
                 exch.gather_ranges(rows, ref_ranges)
-                torch.cuda.synchronize()
+                tsync()
 
         if not exch:
             eref_tail()                                # one GPU: queue Phase B right behind the counting kernels
@@ -487,14 +495,14 @@ def main():
             if rank != 0:
                 scratch_consumed.zero_()
                 cons_for_quirk = scratch_consumed
-            torch.cuda.synchronize()
+            tsync()
         n_e = ctypes.c_int64()
         capi._check(L.palace_graph_resolve(g.h, P(all_c), n_cands, gs["n_total"], ctypes.byref(prm), P(cons_for_quirk),
                                            P(e_buf), max(1, n_cands), ctypes.byref(n_e)), "resolve")
         if exch:
             g.sync()
             exch.reduce_sum(consumed)
-            torch.cuda.synchronize()
+            tsync()
         capi._check(L.palace_graph_copy_numbers(g.h, P(consumed), P(gs["tlen"]), nt, gs["avg_depth"], P(cn_dev)), "cn")
         if timed: g.mark(m + 2)
         th0 = time.perf_counter()
@@ -525,8 +533,11 @@ def main():
         if exch:
             # N GPUs: the count-table exchange and Phase B need every rank's host thread for the collectives, so
             # the host-side matching runs beside them in a second thread (ctypes and numpy release the GIL)
+            # Order on N GPUs: generateGraph's small collectives first (behind a saturating count launch they would
+            # wait for it), then rank 0's host matching in its thread, and beside it counting + exchange + Phase B.
             worker = threading.Thread(target=matching)
             worker.start()
+            eref_head()
             eref_tail()
             worker.join()
         else:
