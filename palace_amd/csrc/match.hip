@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <memory>
 #include <numeric>
+#include <thread>
 
 namespace palace {
 
@@ -75,6 +76,22 @@ __global__ void match_init_kernel(MatchArgs a)
 
 using namespace palace;
 
+// A round that changes nothing is a no-op, so rounds are enqueued in batches between host checks of the `changed`
+// word (one stream round trip per batch, not per round; eight cover the usual graph in one).
+constexpr int kRoundsPerCheck = 8;
+
+static int enqueue_rounds(palace_ctx *ctx, const MatchArgs &a, int n)
+{
+    const unsigned blocks = static_cast<unsigned>((a.n_vertices + 255) / 256);
+    PALACE_HIP_TRY(hipMemsetAsync(a.changed, 0, 4, ctx->stream));
+    for (int k = 0; k < n; k++) {
+        hipLaunchKernelGGL(match_propose_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(match_commit_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+    }
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
 extern "C" int palace_match_greedy(palace_ctx *ctx, int32_t n_vertices, int64_t n_arcs, const int32_t *d_src,
                                    const int32_t *d_dst, const int64_t *d_out_off, const int32_t *d_out_arcs,
                                    const int64_t *d_in_off, const int32_t *d_in_arcs, const uint8_t *d_alive,
@@ -98,23 +115,16 @@ extern "C" int palace_match_greedy(palace_ctx *ctx, int32_t n_vertices, int64_t 
     a.changed = reinterpret_cast<unsigned int *>(ctx->d_small);
     const unsigned blocks = static_cast<unsigned>((n_vertices + 255) / 256);
     hipLaunchKernelGGL(match_init_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
-    // A round that changes nothing is a no-op, so rounds are enqueued in batches of kBatch between
-    // host checks of the `changed` word (one stream round trip per batch, not per round).
-    constexpr int kBatch = 4;
     int rounds = 0;
     for (;;) {
-        PALACE_HIP_TRY(hipMemsetAsync(ctx->d_small, 0, 4, ctx->stream));
-        for (int k = 0; k < kBatch; k++) {
-            hipLaunchKernelGGL(match_propose_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
-            hipLaunchKernelGGL(match_commit_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
-        }
-        PALACE_HIP_TRY(hipGetLastError());
         unsigned int changed = 0;
+        rc = enqueue_rounds(ctx, a, kRoundsPerCheck);
+        if (rc) return rc;
         PALACE_HIP_TRY(hipMemcpyAsync(&changed, ctx->d_small, 4, hipMemcpyDeviceToHost, ctx->stream));
         PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        rounds += kBatch;
+        rounds += kRoundsPerCheck;
         if (!changed) break;
-        if (rounds > n_vertices + 2 + kBatch) { set_error("palace_match_greedy: no fixed point"); return PALACE_ESTATE; }
+        if (rounds > n_vertices + 2 + kRoundsPerCheck) { set_error("palace_match_greedy: no fixed point"); return PALACE_ESTATE; }
     }
     if (rounds_out) *rounds_out = rounds;
     return PALACE_OK;
@@ -182,11 +192,12 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
     // rate), laid out like the three device arrays so that one copy fetches them all
     const size_t v4 = (static_cast<size_t>(V) * 4 + 255) / 256 * 256;
     {
-        int rc = palace::ensure_pinned(ctx, 3 * v4 + static_cast<size_t>(V) + 256);
+        int rc = palace::ensure_pinned(ctx, 3 * v4 + static_cast<size_t>(V) + 1024);
         if (rc) return rc;
     }
     int32_t *next = static_cast<int32_t *>(ctx->pin.ptr), *prev = next + v4 / 4, *narc = prev + v4 / 4;
     uint8_t *alive = reinterpret_cast<uint8_t *>(narc + v4 / 4);
+    unsigned int *changed = reinterpret_cast<unsigned int *>(alive + (static_cast<size_t>(V) + 255) / 256 * 256);
     const size_t greedy_bytes = (static_cast<size_t>(V) * 8 + 256 + 255) / 256 * 256;
     const size_t arena_bytes = greedy_bytes + 4 * (static_cast<size_t>(E) * 4 + 256) + 2 * (static_cast<size_t>(V + 1) * 8 + 256) +
                                3 * (static_cast<size_t>(V) * 4 + 256) + static_cast<size_t>(V) + 256;
@@ -221,10 +232,30 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
         bool any = false;
         for (int32_t s = 0; s < n_segs; s++) { alive[2 * s] = alive[2 * s + 1] = left[s] > 0; any |= left[s] > 0; }
         if (!any) continue;                                   // nothing left this round (an `aggressive` round may follow)
-        int rc = palace_h2d(ctx, d_alive, alive, static_cast<size_t>(V));
-        if (!rc) rc = palace_match_greedy(ctx, V, E, d_src, d_dst, d_oo, d_oa, d_io, d_ia, d_alive, d_next, d_prev, d_narc, nullptr);
-        if (!rc) rc = palace_d2h(ctx, next, d_next, 3 * v4);          // next, prev, next_arc lie side by side
-        if (rc) { cleanup(); return rc; }
+        // One stream round trip per outer round: liveness up (pinned, stream-ordered), a batch of matching rounds,
+        // the `changed` word and the three link arrays (side by side) down; more batches only if it had not settled.
+        {
+            MatchArgs a{};
+            a.n_vertices = V; a.n_arcs = E; a.src = d_src; a.dst = d_dst;
+            a.out_off = d_oo; a.in_off = d_io; a.out_arcs = d_oa; a.in_arcs = d_ia;
+            a.alive = d_alive; a.next = d_next; a.prev = d_prev; a.next_arc = d_narc;
+            a.want_out = static_cast<int32_t *>(ctx->ws.ptr);
+            a.want_in = a.want_out + V;
+            a.changed = reinterpret_cast<unsigned int *>(ctx->d_small);
+            hipError_t e = hipMemcpyAsync(d_alive, alive, static_cast<size_t>(V), hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) { palace::set_error("decompose: %s", hipGetErrorString(e)); cleanup(); return PALACE_EHIP; }
+            hipLaunchKernelGGL(match_init_kernel, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, ctx->stream, a);
+            for (int done = 0;; done += kRoundsPerCheck) {
+                int rc = enqueue_rounds(ctx, a, kRoundsPerCheck);
+                if (rc) { cleanup(); return rc; }
+                e = hipMemcpyAsync(changed, ctx->d_small, 4, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(next, d_next, 3 * v4, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) { palace::set_error("decompose: %s", hipGetErrorString(e)); cleanup(); return PALACE_EHIP; }
+                if (!*changed) break;
+                if (done > V + 2) { palace::set_error("decompose: no fixed point"); cleanup(); return PALACE_ESTATE; }
+            }
+        }
         std::fill(seen.begin(), seen.end(), 0);
         heads.clear();
         pool.clear();
@@ -422,33 +453,65 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
     int64_t *r_off = res->off.get();
     int32_t *r_verts = res->verts.get(), *r_iter = res->iter.get(), *r_open = res->open_at.get();
     uint8_t *r_kind = res->kind.get();
-    int64_t oc = 0, ov = 0;                               // next component / vertex slot
     r_off[0] = 0;
-    auto emit_sub = [&](int64_t c) {
-        const int64_t len = sub.off[c + 1] - sub.off[c];
-        std::copy(sub.verts.begin() + sub.off[c], sub.verts.begin() + sub.off[c + 1], r_verts + ov);
-        ov += len;
-        r_kind[oc] = sub.kind[c]; r_iter[oc] = sub.iter[c]; r_open[oc] = sub.open_at[c];
-        r_off[++oc] = ov;
-    };
-    // bare segments from s up to (not including) `until`, as one-vertex paths of `round`
-    auto emit_bare_until = [&](int32_t &s, int32_t until, int round) {
-        for (; s < until; s++) {
-            if (new_id[s] >= 0) continue;
-            r_verts[ov++] = 2 * s;
-            r_kind[oc] = 0; r_iter[oc] = round; r_open[oc] = 0;
+    // Components of a round come out in first-vertex order: sub-graph components (already ordered) interleaved with
+    // the bare segments s (first vertex 2s); a component goes after every bare s with 2s < its first vertex, i.e.
+    // s < split(c).  The ~n_segs outputs of such a round are written by a few threads, each owning a range of
+    // segment ids: its bare segments, and the components whose split point falls into the range.
+    auto split = [&](int64_t c) { return (sub.verts[sub.off[c]] + 1) >> 1; };
+    auto merge_range = [&](int32_t a, int32_t b, int64_t c_lo, int64_t c_hi, int64_t oc, int64_t ov, int round) {
+        int32_t s = a;
+        auto bare_until = [&](int32_t until) {
+            for (; s < until; s++) {
+                if (new_id[s] >= 0) continue;
+                r_verts[ov++] = 2 * s;
+                r_kind[oc] = 0; r_iter[oc] = round; r_open[oc] = 0;
+                r_off[++oc] = ov;
+            }
+        };
+        for (int64_t c = c_lo; c < c_hi; c++) {
+            bare_until(std::min<int32_t>(b, split(c)));
+            const int64_t len = sub.off[c + 1] - sub.off[c];
+            std::copy(sub.verts.begin() + sub.off[c], sub.verts.begin() + sub.off[c + 1], r_verts + ov);
+            ov += len;
+            r_kind[oc] = sub.kind[c]; r_iter[oc] = sub.iter[c]; r_open[oc] = sub.open_at[c];
             r_off[++oc] = ov;
         }
+        bare_until(b);
     };
-    int64_t c = 0;
+    int64_t oc = 0, ov = 0, c = 0;                        // next component / vertex slot, next sub-graph component
     for (int round = 0; round <= last_round; round++) {
+        int64_t c_end = c;
+        while (c_end < n_sub_comp && sub.iter[c_end] == round) c_end++;
         const bool bare_round = round == 0 || (aggressive && round == last_round);
-        int32_t s = 0;
-        while (c < n_sub_comp && sub.iter[c] == round) {
-            if (bare_round) emit_bare_until(s, (sub.verts[sub.off[c]] + 1) >> 1, round);   // bare s with 2s < first vertex
-            emit_sub(c++);
+        if (!bare_round) {                                // sub-graph components only
+            merge_range(0, 0, c, c_end, oc, ov, round);
+            oc += c_end - c; ov += sub.off[c_end] - sub.off[c];
+            c = c_end;
+            continue;
         }
-        if (bare_round) emit_bare_until(s, n_segs, round);
+        const int n_thr = n_segs >= (1 << 17) ? 4 : 1;
+        std::vector<std::thread> pool;
+        int64_t c_lo = c;
+        for (int k = 0; k < n_thr; k++) {
+            const int32_t a = static_cast<int32_t>(static_cast<int64_t>(n_segs) * k / n_thr);
+            const int32_t b = static_cast<int32_t>(static_cast<int64_t>(n_segs) * (k + 1) / n_thr);
+            int64_t c_hi = c_end;                         // components with split(c) < b (all that are left, in the last range)
+            if (k + 1 < n_thr) {
+                int64_t lo = c_lo, hi = c_end;
+                while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (split(mid) < b) lo = mid + 1; else hi = mid; }
+                c_hi = lo;
+            }
+            const int64_t n_sub_in = std::lower_bound(old_id.begin(), old_id.end(), b) - std::lower_bound(old_id.begin(), old_id.end(), a);
+            const int64_t n_bare_in = (b - a) - n_sub_in;
+            if (n_thr == 1) merge_range(a, b, c_lo, c_hi, oc, ov, round);
+            else pool.emplace_back(merge_range, a, b, c_lo, c_hi, oc, ov, round);
+            oc += n_bare_in + (c_hi - c_lo);
+            ov += n_bare_in + (sub.off[c_hi] - sub.off[c_lo]);
+            c_lo = c_hi;
+        }
+        for (auto &t : pool) t.join();
+        c = c_end;
     }
     res->n = oc;
     *out = res;
