@@ -49,6 +49,11 @@ struct Workspace {
 
 }  // namespace palace
 
+namespace palace {
+struct MatchScratch;                      // host temporaries of palace_match_decompose (match.hip)
+void free_match_scratch(MatchScratch *m);
+}  // namespace palace
+
 struct palace_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -64,6 +69,7 @@ struct palace_ctx {
     int64_t slab_override = 0;
     palace::Workspace ws;      // grow-only scratch
     palace::Workspace pin;     // grow-only pinned host staging
+    palace::MatchScratch *match_scratch = nullptr;
     uint64_t *d_small = nullptr;   // 64 x u64 scratch for reductions
 };
 

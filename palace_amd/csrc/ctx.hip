@@ -112,6 +112,7 @@ int palace_ctx_destroy(palace_ctx *ctx)
         if (ctx->plane[p] && !ctx->planes_external) (void)hipFree(ctx->plane[p]);
     if (ctx->ws.ptr) (void)hipFree(ctx->ws.ptr);
     if (ctx->pin.ptr) (void)hipHostFree(ctx->pin.ptr);
+    if (ctx->match_scratch) palace::free_match_scratch(ctx->match_scratch);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     for (hipEvent_t e : ctx->marks)
         if (e) (void)hipEventDestroy(e);

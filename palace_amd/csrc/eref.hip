@@ -860,7 +860,6 @@ __global__ __launch_bounds__(kRefThreads) void eref_need_kernel(const int64_t *_
     block_prefix(A, PA);
     __threadfence_block();
     __syncthreads();
-#pragma unroll 4
     for (int64_t w = wv; w < n_words; w += kWaves) {               // cand[j]: channel-0 hits in (j-500, j] >= three_min
         const int64_t j = w * 64 + lane;
         bool cand = false;
@@ -943,7 +942,6 @@ __global__ __launch_bounds__(kRefThreads) void eref_window_kernel(const int64_t 
     __syncthreads();
 
     // (b) good[j]: >= one_min any-hits and >= three_min all-hits among positions (j-500, j]
-#pragma unroll 4
     for (int64_t w = wv; w < n_words; w += kWaves) {
         int64_t j = w * 64 + lane;
         bool good = false;

@@ -11,7 +11,9 @@
 // (10^4..10^6 arcs): bandwidth-trivial, latency-bound; rounds are separate small launches.
 #include "common.hpp"
 #include <algorithm>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <thread>
 
@@ -137,11 +139,83 @@ struct SubResult {                      // components of the arc-bearing sub-gra
     std::vector<uint8_t> kind;
 };
 
-struct palace_match_result {            // final result: one entry per component incl. ~n_segs bare segments, so the
-    int64_t n = 0;                      // arrays are allocated once, uninitialised, and written exactly once
-    std::unique_ptr<int64_t[]> off;
-    std::unique_ptr<int32_t[]> verts, iter, open_at;
-    std::unique_ptr<uint8_t[]> kind;
+namespace palace {
+
+// Result arrays hold one entry per component incl. ~n_segs bare segments (tens of MB).  Fresh allocations of that
+// size are mmap'ed and cost a page fault per 4 KiB on first touch -- more than writing them -- so released blocks are
+// kept (a handful, library-wide) and handed out again.
+class BlockPool {
+public:
+    void *take(size_t bytes)
+    {
+        bytes = std::max<size_t>(bytes, 64);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].second >= bytes && free_[i].second <= 2 * bytes + (1 << 20)) {
+                    void *p = free_[i].first;
+                    sizes_[p] = free_[i].second;
+                    free_.erase(free_.begin() + i);
+                    return p;
+                }
+        }
+        void *p = std::malloc(bytes);
+        if (p) { std::lock_guard<std::mutex> g(mu_); sizes_[p] = bytes; }
+        return p;
+    }
+    void give(void *p)
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(mu_);
+        const size_t bytes = sizes_[p];
+        sizes_.erase(p);
+        if (free_.size() < 16) free_.emplace_back(p, bytes);
+        else std::free(p);
+    }
+
+private:
+    std::mutex mu_;
+    std::vector<std::pair<void *, size_t>> free_;
+    std::map<void *, size_t> sizes_;
+};
+static BlockPool g_result_pool;
+
+struct Head { int32_t first; int64_t begin, end; uint8_t cycle; int32_t open; };
+
+// Host temporaries of palace_match_decompose, kept in the context between calls for the same reason.
+struct MatchScratch {
+    std::vector<int32_t> new_id, old_id, ssrc, sdst, out_arcs, in_arcs, owner, pool;
+    std::vector<int64_t> sub_copies, out_off, in_off, po, pi, left;
+    std::vector<uint8_t> seen;
+    std::vector<Head> heads, ordered;
+    SubResult sub;
+};
+void free_match_scratch(MatchScratch *m) { delete m; }
+
+// A scratch vector is worked on as a LOCAL object and handed back on scope exit: loops that also store bytes
+// (char-typed stores may alias anything) would otherwise reload the vector's pointers from the heap-resident
+// scratch struct after every such store.
+template <class T>
+struct Borrowed {
+    T &home;
+    T v;
+    explicit Borrowed(T &h) : home(h), v(std::move(h)) {}
+    ~Borrowed() { home = std::move(v); }
+    Borrowed(const Borrowed &) = delete;
+    Borrowed &operator=(const Borrowed &) = delete;
+};
+
+}  // namespace palace
+
+struct palace_match_result {            // final result: arrays from the block pool, written exactly once
+    int64_t n = 0;
+    int64_t *off = nullptr;
+    int32_t *verts = nullptr, *iter = nullptr, *open_at = nullptr;
+    uint8_t *kind = nullptr;
+    ~palace_match_result()
+    {
+        for (void *p : {(void *)off, (void *)verts, (void *)iter, (void *)open_at, (void *)kind}) palace::g_result_pool.give(p);
+    }
 };
 
 namespace palace {
@@ -172,19 +246,23 @@ using palace::dev_copy;
 
 static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
                           const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
-                          SubResult *res)
+                          palace::MatchScratch &ms, SubResult *res)
 {
     const int32_t V = 2 * n_segs;
     const int64_t E = n_arcs;
     // CSR by tail and by head; arc ids ascend inside every list because arcs arrive in rank order
-    std::vector<int64_t> out_off(V + 1, 0), in_off(V + 1, 0);
-    std::vector<int32_t> out_arcs(E), in_arcs(E);
+    palace::Borrowed<std::vector<int64_t>> b_oo(ms.out_off), b_io(ms.in_off), b_po(ms.po), b_pi(ms.pi), b_left(ms.left);
+    palace::Borrowed<std::vector<int32_t>> b_oa(ms.out_arcs), b_ia(ms.in_arcs), b_owner(ms.owner), b_pool(ms.pool);
+    palace::Borrowed<std::vector<uint8_t>> b_seen(ms.seen);
+    palace::Borrowed<std::vector<palace::Head>> b_heads(ms.heads), b_ordered(ms.ordered);
+    auto &out_off = b_oo.v, &in_off = b_io.v, &po = b_po.v, &pi = b_pi.v;
+    auto &out_arcs = b_oa.v, &in_arcs = b_ia.v;
+    out_off.assign(V + 1, 0); in_off.assign(V + 1, 0);
+    out_arcs.resize(E); in_arcs.resize(E);
     for (int64_t e = 0; e < E; e++) { out_off[src[e] + 1]++; in_off[dst[e] + 1]++; }
     for (int32_t v = 0; v < V; v++) { out_off[v + 1] += out_off[v]; in_off[v + 1] += in_off[v]; }
-    {
-        std::vector<int64_t> po(out_off.begin(), out_off.end() - 1), pi(in_off.begin(), in_off.end() - 1);
-        for (int64_t e = 0; e < E; e++) { out_arcs[po[src[e]]++] = static_cast<int32_t>(e); in_arcs[pi[dst[e]]++] = static_cast<int32_t>(e); }
-    }
+    po.assign(out_off.begin(), out_off.end() - 1); pi.assign(in_off.begin(), in_off.end() - 1);
+    for (int64_t e = 0; e < E; e++) { out_arcs[po[src[e]]++] = static_cast<int32_t>(e); in_arcs[pi[dst[e]]++] = static_cast<int32_t>(e); }
     int32_t *d_src = nullptr, *d_dst = nullptr, *d_oa = nullptr, *d_ia = nullptr, *d_next = nullptr, *d_prev = nullptr, *d_narc = nullptr;
     int64_t *d_oo = nullptr, *d_io = nullptr;
     uint8_t *d_alive = nullptr;
@@ -219,13 +297,16 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
     d_alive = ar.take<uint8_t>(V);
     if (ar.used > arena_bytes) { palace::set_error("decompose: arena accounting"); cleanup(); return PALACE_ESTATE; }
 
-    std::vector<int64_t> left(copies, copies + n_segs);
+    using palace::Head;
+    auto &left = b_left.v;
+    auto &seen = b_seen.v;
+    auto &owner = b_owner.v, &pool = b_pool.v;
+    auto &heads = b_heads.v, &ordered = b_ordered.v;
+    left.assign(copies, copies + n_segs);
     for (auto &c : left) c = std::max<int64_t>(1, c);
-    std::vector<uint8_t> seen(V);
-    std::vector<int32_t> owner(V);
-    struct Head { int32_t first; int64_t begin, end; uint8_t cycle; int32_t open; };
-    std::vector<Head> heads;
-    std::vector<int32_t> pool;
+    seen.resize(V); owner.resize(V);
+    heads.clear(); pool.clear();
+    res->off.assign(1, 0); res->verts.clear(); res->iter.clear(); res->open_at.clear(); res->kind.clear();
     const int rounds = iterations + (aggressive ? 1 : 0);
     for (int t = 0; t < rounds; t++) {
         if (aggressive && t == rounds - 1) std::fill(left.begin(), left.end(), 1);
@@ -291,7 +372,7 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
         {   // emission order = ascending first vertex; first vertices are distinct, so place instead of sorting
             std::fill(owner.begin(), owner.end(), -1);
             for (size_t c = 0; c < heads.size(); c++) owner[heads[c].first] = static_cast<int32_t>(c);
-            std::vector<Head> ordered;
+            ordered.clear();
             ordered.reserve(heads.size());
             for (int32_t v = 0; v < V; v++)
                 if (owner[v] >= 0) ordered.push_back(heads[owner[v]]);
@@ -422,20 +503,28 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
     // `aggressive`, of the extra round).  The matching runs on the sub-graph of segments that have
     // arcs, relabelled monotonically so every "smaller vertex id" decision is unchanged; the bare
     // segments are merged back in by first-vertex order.
-    std::vector<int32_t> new_id(n_segs, -1), old_id;
+    if (!ctx->match_scratch) ctx->match_scratch = new palace::MatchScratch();
+    palace::MatchScratch &ms = *ctx->match_scratch;
+    palace::Borrowed<std::vector<int32_t>> b_new(ms.new_id), b_old(ms.old_id), b_ssrc(ms.ssrc), b_sdst(ms.sdst);
+    palace::Borrowed<std::vector<int64_t>> b_sc(ms.sub_copies);
+    auto &new_id = b_new.v, &old_id = b_old.v, &ssrc = b_ssrc.v, &sdst = b_sdst.v;
+    auto &sub_copies = b_sc.v;
+    SubResult &sub = ms.sub;
+    new_id.assign(n_segs, -1);
+    old_id.clear();
     for (int64_t e = 0; e < n_arcs; e++) { new_id[src[e] >> 1] = 0; new_id[dst[e] >> 1] = 0; }
     for (int32_t s = 0; s < n_segs; s++)
         if (new_id[s] == 0) { new_id[s] = static_cast<int32_t>(old_id.size()); old_id.push_back(s); }
     const int32_t n_sub = static_cast<int32_t>(old_id.size());
-    std::vector<int64_t> sub_copies(n_sub);
+    sub_copies.resize(n_sub);
     for (int32_t k = 0; k < n_sub; k++) sub_copies[k] = copies[old_id[k]];
-    std::vector<int32_t> ssrc(n_arcs), sdst(n_arcs);
+    ssrc.resize(n_arcs); sdst.resize(n_arcs);
     for (int64_t e = 0; e < n_arcs; e++) {
         ssrc[e] = 2 * new_id[src[e] >> 1] + (src[e] & 1);
         sdst[e] = 2 * new_id[dst[e] >> 1] + (dst[e] & 1);
     }
-    SubResult sub;
-    int rc = n_sub ? decompose_core(ctx, n_sub, sub_copies.data(), n_arcs, ssrc.data(), sdst.data(), iterations, aggressive, &sub)
+    sub.off.assign(1, 0); sub.verts.clear(); sub.iter.clear(); sub.open_at.clear(); sub.kind.clear();
+    int rc = n_sub ? decompose_core(ctx, n_sub, sub_copies.data(), n_arcs, ssrc.data(), sdst.data(), iterations, aggressive, ms, &sub)
                    : PALACE_OK;
     if (rc) return rc;
     for (int32_t &v : sub.verts) v = 2 * old_id[v >> 1] + (v & 1);
@@ -445,14 +534,19 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
     const int64_t n_out = n_sub_comp + n_bare * (aggressive && last_round > 0 ? 2 : 1);
     const int64_t nv_out = static_cast<int64_t>(sub.verts.size()) + (n_out - n_sub_comp);
     palace_match_result *res = new palace_match_result();
-    res->off.reset(new int64_t[n_out + 1]);
-    res->kind.reset(new uint8_t[std::max<int64_t>(1, n_out)]);
-    res->iter.reset(new int32_t[std::max<int64_t>(1, n_out)]);
-    res->open_at.reset(new int32_t[std::max<int64_t>(1, n_out)]);
-    res->verts.reset(new int32_t[std::max<int64_t>(1, nv_out)]);
-    int64_t *r_off = res->off.get();
-    int32_t *r_verts = res->verts.get(), *r_iter = res->iter.get(), *r_open = res->open_at.get();
-    uint8_t *r_kind = res->kind.get();
+    res->off = static_cast<int64_t *>(palace::g_result_pool.take((n_out + 1) * 8));
+    res->kind = static_cast<uint8_t *>(palace::g_result_pool.take(n_out));
+    res->iter = static_cast<int32_t *>(palace::g_result_pool.take(n_out * 4));
+    res->open_at = static_cast<int32_t *>(palace::g_result_pool.take(n_out * 4));
+    res->verts = static_cast<int32_t *>(palace::g_result_pool.take(nv_out * 4));
+    if (!res->off || !res->kind || !res->iter || !res->open_at || !res->verts) {
+        delete res;
+        palace::set_error("palace_match_decompose: out of host memory");
+        return PALACE_ENOMEM;
+    }
+    int64_t *r_off = res->off;
+    int32_t *r_verts = res->verts, *r_iter = res->iter, *r_open = res->open_at;
+    uint8_t *r_kind = res->kind;
     r_off[0] = 0;
     // Components of a round come out in first-vertex order: sub-graph components (already ordered) interleaved with
     // the bare segments s (first vertex 2s); a component goes after every bare s with 2s < its first vertex, i.e.
@@ -519,11 +613,11 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
 }
 
 int64_t palace_match_result_count(const palace_match_result *r) { return r ? r->n : 0; }
-const int64_t *palace_match_result_offsets(const palace_match_result *r) { return r->off.get(); }
-const int32_t *palace_match_result_verts(const palace_match_result *r) { return r->verts.get(); }
-const uint8_t *palace_match_result_kind(const palace_match_result *r) { return r->kind.get(); }
-const int32_t *palace_match_result_iter(const palace_match_result *r) { return r->iter.get(); }
-const int32_t *palace_match_result_open_at(const palace_match_result *r) { return r->open_at.get(); }
+const int64_t *palace_match_result_offsets(const palace_match_result *r) { return r->off; }
+const int32_t *palace_match_result_verts(const palace_match_result *r) { return r->verts; }
+const uint8_t *palace_match_result_kind(const palace_match_result *r) { return r->kind; }
+const int32_t *palace_match_result_iter(const palace_match_result *r) { return r->iter; }
+const int32_t *palace_match_result_open_at(const palace_match_result *r) { return r->open_at; }
 void palace_match_result_free(palace_match_result *r) { delete r; }
 
 }  // extern "C"
