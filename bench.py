@@ -597,7 +597,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # PMC (separate rocprofv3 passes, profiles/r01q_end_state_fused_launch.md): FETCH_SIZE x2 + WRITE_SIZE of
                          # bin1 + bin2 + lds_count per launch; only valid for the default workload on one GPU
-                         "traffic": 45.4e9 if (args.contigs == 1_000_000 and world == 1) else None,   # PMC passes of profiles/r01t_end_state.md
+                         "traffic": 45.2e9 if (args.contigs == 1_000_000 and world == 1) else None,   # PMC passes of profiles/r01u_end_state.md
                          "traffic_unit": "bytes per launch",
                          "avg_launch_ms": count_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "stage_ms": {"eref_count_each_step": [round(float(x), 3) for x in count_each], "eref_count_both_sides": count_ms, "eref_table_merge": merge_ms, "eref_scan_refs": scan_ms,

@@ -79,8 +79,8 @@ __global__ void match_init_kernel(MatchArgs a)
 using namespace palace;
 
 // A round that changes nothing is a no-op, so rounds are enqueued in batches between host checks of the `changed`
-// word (one stream round trip per batch, not per round; eight cover the usual graph in one).
-constexpr int kRoundsPerCheck = 8;
+// word (one stream round trip per batch, not per round; later outer rounds settle within one batch).
+constexpr int kRoundsPerCheck = 4;
 
 static int enqueue_rounds(palace_ctx *ctx, const MatchArgs &a, int n)
 {
