@@ -184,7 +184,7 @@ struct Head { int32_t first; int64_t begin, end; uint8_t cycle; int32_t open; };
 
 // Host temporaries of palace_match_decompose, kept in the context between calls for the same reason.
 struct MatchScratch {
-    std::vector<int32_t> new_id, old_id, ssrc, sdst, out_arcs, in_arcs, owner, pool;
+    std::vector<int32_t> new_id, old_id, ssrc, sdst, out_arcs, in_arcs, owner, pool, live;
     std::vector<int64_t> sub_copies, out_off, in_off, po, pi, left;
     std::vector<uint8_t> seen;
     std::vector<Head> heads, ordered;
@@ -304,15 +304,21 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
     auto &heads = b_heads.v, &ordered = b_ordered.v;
     left.assign(copies, copies + n_segs);
     for (auto &c : left) c = std::max<int64_t>(1, c);
-    seen.resize(V); owner.resize(V);
+    seen.assign(V, 0); owner.assign(V, -1);
     heads.clear(); pool.clear();
+    palace::Borrowed<std::vector<int32_t>> b_live(ms.live);
+    auto &live = b_live.v;
     res->off.assign(1, 0); res->verts.clear(); res->iter.clear(); res->open_at.clear(); res->kind.clear();
     const int rounds = iterations + (aggressive ? 1 : 0);
     for (int t = 0; t < rounds; t++) {
         if (aggressive && t == rounds - 1) std::fill(left.begin(), left.end(), 1);
-        bool any = false;
-        for (int32_t s = 0; s < n_segs; s++) { alive[2 * s] = alive[2 * s + 1] = left[s] > 0; any |= left[s] > 0; }
-        if (!any) continue;                                   // nothing left this round (an `aggressive` round may follow)
+        live.clear();
+        for (int32_t s = 0; s < n_segs; s++) {
+            const bool on = left[s] > 0;
+            alive[2 * s] = alive[2 * s + 1] = on;
+            if (on) { live.push_back(2 * s); live.push_back(2 * s + 1); }
+        }
+        if (live.empty()) continue;                           // nothing left this round (an `aggressive` round may follow)
         // One stream round trip per outer round: liveness up (pinned, stream-ordered), a batch of matching rounds,
         // the `changed` word and the three link arrays (side by side) down; more batches only if it had not settled.
         {
@@ -337,11 +343,12 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
                 if (done > V + 2) { palace::set_error("decompose: no fixed point"); cleanup(); return PALACE_ESTATE; }
             }
         }
-        std::fill(seen.begin(), seen.end(), 0);
+        // Host read-off over the vertices that are alive this round only (after round 0 that is a small part of the
+        // graph); `seen` and `owner` entries are reset for exactly those vertices afterwards.
         heads.clear();
         pool.clear();
-        for (int32_t v = 0; v < V; v++) {                     // open paths, one representative per conjugate pair
-            if (!alive[v] || seen[v] || prev[v] >= 0) continue;
+        for (const int32_t v : live) {                        // open paths, one representative per conjugate pair
+            if (seen[v] || prev[v] >= 0) continue;
             const int64_t b = static_cast<int64_t>(pool.size());
             for (int32_t x = v; x >= 0; x = next[x]) { pool.push_back(x); seen[x] = 1; }
             const int64_t e = static_cast<int64_t>(pool.size());
@@ -352,8 +359,8 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
             }
             heads.push_back({pool[b], b, e, 0, 0});
         }
-        for (int32_t v = 0; v < V; v++) {                     // closed walks
-            if (!alive[v] || seen[v]) continue;
+        for (const int32_t v : live) {                        // closed walks
+            if (seen[v]) continue;
             const int64_t b = static_cast<int64_t>(pool.size());
             for (int32_t x = v; !seen[x]; x = next[x]) { pool.push_back(x); seen[x] = 1; }
             const int64_t e = static_cast<int64_t>(pool.size());
@@ -370,21 +377,26 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
             heads.push_back({pool[b], b, e, 1, static_cast<int32_t>((worst + 1 - b) % (e - b))});
         }
         {   // emission order = ascending first vertex; first vertices are distinct, so place instead of sorting
-            std::fill(owner.begin(), owner.end(), -1);
+            // (`live` ascends, and a first vertex is a live vertex)
             for (size_t c = 0; c < heads.size(); c++) owner[heads[c].first] = static_cast<int32_t>(c);
             ordered.clear();
             ordered.reserve(heads.size());
-            for (int32_t v = 0; v < V; v++)
-                if (owner[v] >= 0) ordered.push_back(heads[owner[v]]);
+            for (const int32_t v : live)
+                if (owner[v] >= 0) { ordered.push_back(heads[owner[v]]); owner[v] = -1; }
             heads.swap(ordered);
         }
-        std::fill(owner.begin(), owner.end(), -1);
         for (size_t c = 0; c < heads.size(); c++)
             for (int64_t k = heads[c].begin; k < heads[c].end; k++) owner[pool[k]] = static_cast<int32_t>(c);
-        for (const Head &h : heads) {
+        const size_t v_at = res->verts.size(), c_at = res->kind.size();
+        res->verts.resize(v_at + pool.size());
+        res->off.resize(c_at + 1 + heads.size());
+        res->kind.resize(c_at + heads.size()); res->iter.resize(c_at + heads.size()); res->open_at.resize(c_at + heads.size());
+        int32_t *ev = res->verts.data() + v_at;
+        for (size_t c = 0; c < heads.size(); c++) {
+            const Head &h = heads[c];
             // copies paid = min over segments of floor(left / uses); a segment is used twice when both
             // of its orientations lie on this component
-            const int32_t me = static_cast<int32_t>(&h - heads.data());
+            const int32_t me = static_cast<int32_t>(c);
             int64_t pay = -1;
             for (int64_t k = h.begin; k < h.end; k++) {
                 const int64_t uses = 1 + (owner[pool[k] ^ 1] == me);
@@ -393,12 +405,14 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
             }
             pay = std::max<int64_t>(1, pay);
             for (int64_t k = h.begin; k < h.end; k++) { int64_t &l = left[pool[k] >> 1]; l = std::max<int64_t>(0, l - pay); }
-            res->verts.insert(res->verts.end(), pool.begin() + h.begin, pool.begin() + h.end);
-            res->off.push_back(static_cast<int64_t>(res->verts.size()));
-            res->kind.push_back(h.cycle);
-            res->iter.push_back(t);
-            res->open_at.push_back(h.open);
+            ev = std::copy(pool.begin() + h.begin, pool.begin() + h.end, ev);
+            res->off[c_at + 1 + c] = static_cast<int64_t>(ev - res->verts.data());
+            res->kind[c_at + c] = h.cycle;
+            res->iter[c_at + c] = t;
+            res->open_at[c_at + c] = h.open;
         }
+        for (const int32_t v : pool) { owner[v] = -1; }       // leave the scratch clean for the next round
+        for (const int32_t v : live) seen[v] = 0;
     }
     cleanup();
 #undef TRY_OR_CLEAN
