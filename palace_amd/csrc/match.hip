@@ -187,6 +187,7 @@ struct MatchScratch {
     std::vector<int32_t> new_id, old_id, ssrc, sdst, out_arcs, in_arcs, owner, pool, live;
     std::vector<int64_t> sub_copies, out_off, in_off, po, pi, left;
     std::vector<uint8_t> seen;
+    std::vector<uint64_t> has_arc;
     std::vector<Head> heads, ordered;
     SubResult sub;
 };
@@ -524,18 +525,36 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
     auto &new_id = b_new.v, &old_id = b_old.v, &ssrc = b_ssrc.v, &sdst = b_sdst.v;
     auto &sub_copies = b_sc.v;
     SubResult &sub = ms.sub;
-    new_id.assign(n_segs, -1);
+    // arc-bearing segments as a bit set with a rank per 64-bit word: new id of s = rank of its bit (one bit per
+    // segment instead of an int -- the set of ~1e5 among ~1e6 segments is walked by its set bits, not by all ids)
+    const size_t n_words = (static_cast<size_t>(n_segs) + 63) / 64;
+    palace::Borrowed<std::vector<uint64_t>> b_bits(ms.has_arc);
+    auto &has_arc = b_bits.v;
+    has_arc.assign(n_words, 0);
+    for (int64_t e = 0; e < n_arcs; e++) {
+        const int32_t a = src[e] >> 1, b = dst[e] >> 1;
+        has_arc[a >> 6] |= 1ull << (a & 63);
+        has_arc[b >> 6] |= 1ull << (b & 63);
+    }
+    new_id.resize(n_words + 1);                            // new_id[w] = number of arc-bearing segments below 64 * w
     old_id.clear();
-    for (int64_t e = 0; e < n_arcs; e++) { new_id[src[e] >> 1] = 0; new_id[dst[e] >> 1] = 0; }
-    for (int32_t s = 0; s < n_segs; s++)
-        if (new_id[s] == 0) { new_id[s] = static_cast<int32_t>(old_id.size()); old_id.push_back(s); }
+    for (size_t w = 0; w < n_words; w++) {
+        new_id[w] = static_cast<int32_t>(old_id.size());
+        for (uint64_t x = has_arc[w]; x; x &= x - 1) old_id.push_back(static_cast<int32_t>(w * 64 + __builtin_ctzll(x)));
+    }
+    new_id[n_words] = static_cast<int32_t>(old_id.size());
+    auto is_sub = [&](int32_t sg) { return (has_arc[sg >> 6] >> (sg & 63)) & 1ull; };
+    auto sub_rank = [&](int32_t sg) {                      // arc-bearing segments with id < sg (= the new id of sg if it is one)
+        if (sg >= n_segs) return new_id[n_words];
+        return new_id[sg >> 6] + __builtin_popcountll(has_arc[sg >> 6] & ((1ull << (sg & 63)) - 1));
+    };
     const int32_t n_sub = static_cast<int32_t>(old_id.size());
     sub_copies.resize(n_sub);
     for (int32_t k = 0; k < n_sub; k++) sub_copies[k] = copies[old_id[k]];
     ssrc.resize(n_arcs); sdst.resize(n_arcs);
     for (int64_t e = 0; e < n_arcs; e++) {
-        ssrc[e] = 2 * new_id[src[e] >> 1] + (src[e] & 1);
-        sdst[e] = 2 * new_id[dst[e] >> 1] + (dst[e] & 1);
+        ssrc[e] = 2 * sub_rank(src[e] >> 1) + (src[e] & 1);
+        sdst[e] = 2 * sub_rank(dst[e] >> 1) + (dst[e] & 1);
     }
     sub.off.assign(1, 0); sub.verts.clear(); sub.iter.clear(); sub.open_at.clear(); sub.kind.clear();
     int rc = n_sub ? decompose_core(ctx, n_sub, sub_copies.data(), n_arcs, ssrc.data(), sdst.data(), iterations, aggressive, ms, &sub)
@@ -571,7 +590,7 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
         int32_t s = a;
         auto bare_until = [&](int32_t until) {
             for (; s < until; s++) {
-                if (new_id[s] >= 0) continue;
+                if (is_sub(s)) continue;
                 r_verts[ov++] = 2 * s;
                 r_kind[oc] = 0; r_iter[oc] = round; r_open[oc] = 0;
                 r_off[++oc] = ov;
@@ -610,7 +629,7 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
                 while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (split(mid) < b) lo = mid + 1; else hi = mid; }
                 c_hi = lo;
             }
-            const int64_t n_sub_in = std::lower_bound(old_id.begin(), old_id.end(), b) - std::lower_bound(old_id.begin(), old_id.end(), a);
+            const int64_t n_sub_in = sub_rank(b) - sub_rank(a);
             const int64_t n_bare_in = (b - a) - n_sub_in;
             if (n_thr == 1) merge_range(a, b, c_lo, c_hi, oc, ov, round);
             else pool.emplace_back(merge_range, a, b, c_lo, c_hi, oc, ov, round);
