@@ -184,8 +184,8 @@ struct Head { int32_t first; int64_t begin, end; uint8_t cycle; int32_t open; };
 
 // Host temporaries of palace_match_decompose, kept in the context between calls for the same reason.
 struct MatchScratch {
-    std::vector<int32_t> new_id, old_id, ssrc, sdst, out_arcs, in_arcs, owner, pool, live;
-    std::vector<int64_t> sub_copies, out_off, in_off, po, pi, left;
+    std::vector<int32_t> new_id, old_id, ssrc, sdst, owner, pool, live;
+    std::vector<int64_t> sub_copies, po, pi, left;
     std::vector<uint8_t> seen;
     std::vector<uint64_t> has_arc;
     std::vector<Head> heads, ordered;
@@ -251,32 +251,37 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
 {
     const int32_t V = 2 * n_segs;
     const int64_t E = n_arcs;
+    // Host staging in pinned memory (grow-only, owned by the context): the link arrays that come back every round,
+    // laid out like the three device arrays so that one copy fetches them all, the liveness bytes, the `changed`
+    // word, and the CSR of the arcs, so that every upload is a true asynchronous copy.
+    const size_t v4 = (static_cast<size_t>(V) * 4 + 255) / 256 * 256, v1 = (static_cast<size_t>(V) + 255) / 256 * 256;
+    const size_t o8 = (static_cast<size_t>(V + 1) * 8 + 255) / 256 * 256, e4 = (static_cast<size_t>(E) * 4 + 255) / 256 * 256;
+    {
+        int rc = palace::ensure_pinned(ctx, 3 * v4 + v1 + 256 + 2 * o8 + 4 * e4);
+        if (rc) return rc;
+    }
+    char *pin = static_cast<char *>(ctx->pin.ptr);
+    int32_t *next = reinterpret_cast<int32_t *>(pin), *prev = next + v4 / 4, *narc = prev + v4 / 4;
+    uint8_t *alive = reinterpret_cast<uint8_t *>(pin + 3 * v4);
+    unsigned int *changed = reinterpret_cast<unsigned int *>(pin + 3 * v4 + v1);
+    int64_t *out_off = reinterpret_cast<int64_t *>(pin + 3 * v4 + v1 + 256), *in_off = out_off + o8 / 8;
+    int32_t *out_arcs = reinterpret_cast<int32_t *>(in_off + o8 / 8), *in_arcs = out_arcs + e4 / 4;
+    int32_t *p_src = in_arcs + e4 / 4, *p_dst = p_src + e4 / 4;
     // CSR by tail and by head; arc ids ascend inside every list because arcs arrive in rank order
-    palace::Borrowed<std::vector<int64_t>> b_oo(ms.out_off), b_io(ms.in_off), b_po(ms.po), b_pi(ms.pi), b_left(ms.left);
-    palace::Borrowed<std::vector<int32_t>> b_oa(ms.out_arcs), b_ia(ms.in_arcs), b_owner(ms.owner), b_pool(ms.pool);
+    palace::Borrowed<std::vector<int64_t>> b_po(ms.po), b_pi(ms.pi), b_left(ms.left);
+    palace::Borrowed<std::vector<int32_t>> b_owner(ms.owner), b_pool(ms.pool);
     palace::Borrowed<std::vector<uint8_t>> b_seen(ms.seen);
     palace::Borrowed<std::vector<palace::Head>> b_heads(ms.heads), b_ordered(ms.ordered);
-    auto &out_off = b_oo.v, &in_off = b_io.v, &po = b_po.v, &pi = b_pi.v;
-    auto &out_arcs = b_oa.v, &in_arcs = b_ia.v;
-    out_off.assign(V + 1, 0); in_off.assign(V + 1, 0);
-    out_arcs.resize(E); in_arcs.resize(E);
+    auto &po = b_po.v, &pi = b_pi.v;
+    std::fill(out_off, out_off + V + 1, 0); std::fill(in_off, in_off + V + 1, 0);
     for (int64_t e = 0; e < E; e++) { out_off[src[e] + 1]++; in_off[dst[e] + 1]++; }
     for (int32_t v = 0; v < V; v++) { out_off[v + 1] += out_off[v]; in_off[v + 1] += in_off[v]; }
-    po.assign(out_off.begin(), out_off.end() - 1); pi.assign(in_off.begin(), in_off.end() - 1);
+    po.assign(out_off, out_off + V); pi.assign(in_off, in_off + V);
     for (int64_t e = 0; e < E; e++) { out_arcs[po[src[e]]++] = static_cast<int32_t>(e); in_arcs[pi[dst[e]]++] = static_cast<int32_t>(e); }
+    std::copy(src, src + E, p_src); std::copy(dst, dst + E, p_dst);
     int32_t *d_src = nullptr, *d_dst = nullptr, *d_oa = nullptr, *d_ia = nullptr, *d_next = nullptr, *d_prev = nullptr, *d_narc = nullptr;
     int64_t *d_oo = nullptr, *d_io = nullptr;
     uint8_t *d_alive = nullptr;
-    // successor links come back every round: pinned staging (pageable copies run at a fraction of the link
-    // rate), laid out like the three device arrays so that one copy fetches them all
-    const size_t v4 = (static_cast<size_t>(V) * 4 + 255) / 256 * 256;
-    {
-        int rc = palace::ensure_pinned(ctx, 3 * v4 + static_cast<size_t>(V) + 1024);
-        if (rc) return rc;
-    }
-    int32_t *next = static_cast<int32_t *>(ctx->pin.ptr), *prev = next + v4 / 4, *narc = prev + v4 / 4;
-    uint8_t *alive = reinterpret_cast<uint8_t *>(narc + v4 / 4);
-    unsigned int *changed = reinterpret_cast<unsigned int *>(alive + (static_cast<size_t>(V) + 255) / 256 * 256);
     const size_t greedy_bytes = (static_cast<size_t>(V) * 8 + 256 + 255) / 256 * 256;
     const size_t arena_bytes = greedy_bytes + 4 * (static_cast<size_t>(E) * 4 + 256) + 2 * (static_cast<size_t>(V + 1) * 8 + 256) +
                                3 * (static_cast<size_t>(V) * 4 + 256) + static_cast<size_t>(V) + 256;
@@ -287,9 +292,9 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
     palace::Arena ar{static_cast<char *>(ctx->ws.ptr), greedy_bytes};
     auto cleanup = [&] { (void)hipStreamSynchronize(ctx->stream); };   // host vectors must outlive the copies
 #define TRY_OR_CLEAN(expr) do { int rc__ = (expr); if (rc__) { cleanup(); return rc__; } } while (0)
-    TRY_OR_CLEAN(dev_copy(ctx, ar, src, E, &d_src)); TRY_OR_CLEAN(dev_copy(ctx, ar, dst, E, &d_dst));
-    TRY_OR_CLEAN(dev_copy(ctx, ar, out_arcs.data(), E, &d_oa)); TRY_OR_CLEAN(dev_copy(ctx, ar, in_arcs.data(), E, &d_ia));
-    TRY_OR_CLEAN(dev_copy(ctx, ar, out_off.data(), V + 1, &d_oo)); TRY_OR_CLEAN(dev_copy(ctx, ar, in_off.data(), V + 1, &d_io));
+    TRY_OR_CLEAN(dev_copy(ctx, ar, p_src, E, &d_src)); TRY_OR_CLEAN(dev_copy(ctx, ar, p_dst, E, &d_dst));
+    TRY_OR_CLEAN(dev_copy(ctx, ar, out_arcs, E, &d_oa)); TRY_OR_CLEAN(dev_copy(ctx, ar, in_arcs, E, &d_ia));
+    TRY_OR_CLEAN(dev_copy(ctx, ar, out_off, V + 1, &d_oo)); TRY_OR_CLEAN(dev_copy(ctx, ar, in_off, V + 1, &d_io));
     d_next = ar.take<int32_t>(V); d_prev = ar.take<int32_t>(V); d_narc = ar.take<int32_t>(V);   // written by match_init_kernel
     if (reinterpret_cast<char *>(d_prev) - reinterpret_cast<char *>(d_next) != static_cast<ptrdiff_t>(v4) ||
         reinterpret_cast<char *>(d_narc) - reinterpret_cast<char *>(d_prev) != static_cast<ptrdiff_t>(v4)) {
