@@ -239,7 +239,7 @@ def graph_to_arcs(cn, n_segs, edges, min_count=5):
     arc ranking): the library's own host routine, the same one palace_amd/host/matching_main.cpp ranks with."""
     from palace_amd import capi
     assert len(cn) == n_segs
-    return capi.match_arcs_from_edges(cn, edges, min_count)
+    return capi.match_arcs_from_edges(cn, edges, min_count, reuse=True)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -429,6 +429,8 @@ def main():
     # hand-over points wait for exactly the stream that produced the data (a device-wide synchronize here would make the
     # generateGraph exchange wait for the eref counting kernels and vice versa)
     tsync = lambda: torch.cuda.current_stream().synchronize()
+    from concurrent.futures import ThreadPoolExecutor
+    match_thread = ThreadPoolExecutor(max_workers=1) if exch else None
     if exch:
         planes = [torch.zeros(1 << 29, dtype=torch.uint8, device=dev) for _ in range(3)]   # torch-owned so RCCL
         ctx.eref_table_attach([t.data_ptr() for t in planes])                                # can address them
@@ -535,11 +537,10 @@ def main():
             # the host-side matching runs beside them in a second thread (ctypes and numpy release the GIL)
             # Order on N GPUs: generateGraph's small collectives first (behind a saturating count launch they would
             # wait for it), then rank 0's host matching in its thread, and beside it counting + exchange + Phase B.
-            worker = threading.Thread(target=matching)
-            worker.start()
+            worker = match_thread.submit(matching)      # one long-lived thread: the library keeps per-thread scratch
             eref_head()
             eref_tail()
-            worker.join()
+            worker.result()
         else:
             matching()
         # ---------------- join: eref results to the host ----------------

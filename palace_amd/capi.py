@@ -287,13 +287,24 @@ class Ctx:
                "palace_eref_table_merge_slices")
 
 
-def match_arcs_from_edges(cn: np.ndarray, edges: np.ndarray, min_count: int = 5):
+_ARC_BUFFERS = {}
+
+
+def match_arcs_from_edges(cn: np.ndarray, edges: np.ndarray, min_count: int = 5, reuse: bool = False):
     """palace_match_arcs_from_edges (host code of the library) -> (copies, src, dst, weight); `edges` is an
-    EDGE_DTYPE array as palace_graph_resolve writes it."""
+    EDGE_DTYPE array as palace_graph_resolve writes it.  reuse=True hands out the same output arrays on every call
+    of this size (valid until the next call) instead of fresh ones."""
     cn = np.ascontiguousarray(cn, dtype=np.int32)
     e = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
-    copies = np.empty(len(cn), np.int64)
-    src = np.empty(2 * len(e), np.int32); dst = np.empty(2 * len(e), np.int32); w = np.empty(2 * len(e), np.int64)
+    key = (len(cn), len(e))
+    if reuse and key in _ARC_BUFFERS:
+        copies, src, dst, w = _ARC_BUFFERS[key]
+    else:
+        copies = np.empty(len(cn), np.int64)
+        src = np.empty(2 * len(e), np.int32); dst = np.empty(2 * len(e), np.int32); w = np.empty(2 * len(e), np.int64)
+        if reuse:
+            _ARC_BUFFERS.clear()
+            _ARC_BUFFERS[key] = (copies, src, dst, w)
     n = C.c_int64()
     _check(lib().palace_match_arcs_from_edges(cn.ctypes.data, len(cn), e.ctypes.data, len(e), min_count, copies.ctypes.data,
                                               src.ctypes.data, dst.ctypes.data, w.ctypes.data, C.byref(n)),

@@ -460,9 +460,12 @@ int palace_match_arcs_from_edges(const int32_t *cn, int32_t n_segs, const palace
     PALACE_REQUIRE(n_segs < (1 << 30) && n_edges < (1ll << 30), "graph too large for int32 ids");
     for (int32_t s = 0; s < n_segs; s++) copies[s] = std::max(1, cn[s]);
     const uint64_t V = 2ull * static_cast<uint64_t>(n_segs);
-    // arcs and conjugates of the junctions that pass the filter (generateGraph.cpp:1056-1061)
-    std::vector<uint64_t> pair;                           // u * V + v
-    std::vector<int64_t> w;
+    // arcs and conjugates of the junctions that pass the filter (generateGraph.cpp:1056-1061); the temporaries are
+    // kept per thread between calls (fresh megabyte-sized vectors cost a page fault per 4 KiB)
+    static thread_local std::vector<uint64_t> pair, m_pair, m_cls, m_wkey;     // pair = u * V + v
+    static thread_local std::vector<int64_t> w, m_w;
+    static thread_local std::vector<uint32_t> perm, tmp;
+    pair.clear(); w.clear(); m_pair.clear(); m_w.clear();
     pair.reserve(2 * n_edges); w.reserve(2 * n_edges);
     for (int64_t e = 0; e < n_edges; e++) {
         const palace_graph_edge &x = edges[e];
@@ -474,12 +477,10 @@ int palace_match_arcs_from_edges(const int32_t *cn, int32_t n_segs, const palace
         if ((v ^ 1) != u) { pair.push_back((v ^ 1) * V + (u ^ 1)); w.push_back(tot); }
     }
     const size_t n = pair.size();
-    std::vector<uint32_t> perm(n), tmp(n);
+    perm.resize(n); tmp.resize(n);
     std::iota(perm.begin(), perm.end(), 0u);
     radix_by(pair, perm, tmp);                            // by (u, v): equal arcs become adjacent
     // merge equal arcs (weights add up), as the matching executable does when it reads JUNC lines
-    std::vector<uint64_t> m_pair, m_cls, m_wkey;
-    std::vector<int64_t> m_w;
     m_pair.reserve(n); m_w.reserve(n);
     for (size_t i = 0; i < n; i++) {
         if (!m_pair.empty() && m_pair.back() == pair[perm[i]]) m_w.back() += w[perm[i]];
