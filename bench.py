@@ -377,6 +377,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if os.environ.get("PALACE_BENCH_ONE_DEVICE") == "1":   # rehearsal only: every rank on GPU 0 (with PALACE_BENCH_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -386,7 +388,11 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        backend = os.environ.get("PALACE_BENCH_BACKEND", "nccl")           # "nccl" is RCCL; gloo only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     from palace_amd import capi, multigpu
     from oracle import binding as orc       # header helper + cpu_baseline leg only
 

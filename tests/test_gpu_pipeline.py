@@ -61,3 +61,19 @@ def test_bench_exchange_path_rehearsal():
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
     assert a["config"]["graph"] == b["config"]["graph"]
     assert a["config"]["graph"]["n_edges"] > 0
+
+
+@pytest.mark.parametrize("world,port", [(2, 29521), (4, 29522)])
+def test_bench_multi_rank_rehearsal_on_one_gpu(world, port):
+    """The N-rank step (world 2: every rank counts all reads, Phase B / generateGraph / gathers sharded; world 4: reads
+    sharded too, count-table exchange + merge) with all ranks on GPU 0 and the collectives over gloo (RCCL refuses two
+    ranks on one device): the same refs and the same graph as the single-process run."""
+    size = ["--contigs", "20000", "--refs", "200", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    a = json.loads(sh([sys.executable, os.path.join(ROOT, "bench.py")] + size).decode().strip().splitlines()[-1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + size
+    out = sh(cmd, env=dict(os.environ, PALACE_BENCH_ONE_DEVICE="1", PALACE_BENCH_BACKEND="gloo")).decode()
+    b = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == world
+    assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
+    assert a["config"]["graph"] == b["config"]["graph"]
