@@ -81,15 +81,16 @@ def test_bench_shaped_sample_equals_oracle(tmp_path):
     assert want.count("JUNC") > 50
 
 
-def test_bench_matching_stage_equals_oracle(tmp_path):
+@pytest.mark.parametrize("n", [30000, 300000])
+def test_bench_matching_stage_equals_oracle(tmp_path, n):
     """bench.py's glue (graph_to_arcs) + palace_match_decompose, formatted the way matching_main.cpp formats,
-    equal the oracle's linear/cycle files for the same SEG/JUNC text."""
+    equal the oracle's linear/cycle files for the same SEG/JUNC text.  (n = 300000: above 2^17 segments the bare
+    segments are merged back by several threads.)"""
     import bench
     from oracle import binding as orc
     from palace_amd import capi
 
     rng = np.random.Generator(np.random.PCG64(4))
-    n = 30000
     names = [f"EDGE_{i + 1}_length_{int(rng.integers(60, 5000))}_cov_{rng.random() * 20:.4f}" for i in range(n)]
     cn = rng.integers(0, 4, size=n).astype(np.int32)
     e = np.zeros(40000, dtype=capi.EDGE_DTYPE)
