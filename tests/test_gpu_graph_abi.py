@@ -81,8 +81,8 @@ def test_bench_shaped_sample_equals_oracle(tmp_path):
     assert want.count("JUNC") > 50
 
 
-@pytest.mark.parametrize("n", [30000, 300000])
-def test_bench_matching_stage_equals_oracle(tmp_path, n):
+@pytest.mark.parametrize("n,aggressive", [(30000, False), (300000, False), (300000, True)])
+def test_bench_matching_stage_equals_oracle(tmp_path, n, aggressive):
     """bench.py's glue (graph_to_arcs) + palace_match_decompose, formatted the way matching_main.cpp formats,
     equal the oracle's linear/cycle files for the same SEG/JUNC text.  (n = 300000: above 2^17 segments the bare
     segments are merged back by several threads.)"""
@@ -105,7 +105,7 @@ def test_bench_matching_stage_equals_oracle(tmp_path, n):
     e = e[np.unique(key, return_index=True)[1]]
     copies, src, dst, w = bench.graph_to_arcs(cn, n, e)
     with capi.Ctx(0) as ctx:
-        off, verts, kind, it, open_at = capi.match_decompose(ctx, copies, src, dst, 10, False)
+        off, verts, kind, it, open_at = capi.match_decompose(ctx, copies, src, dst, 10, aggressive)
     tok = lambda v: names[v >> 1] + "+-"[v & 1]
     lin, cyc, seen_l, seen_c = [], [], set(), set()
     for c in range(len(kind)):
@@ -125,7 +125,7 @@ def test_bench_matching_stage_equals_oracle(tmp_path, n):
         f.write("".join(f"JUNC {names[l]} {'+-'[a]} {names[r]} {'+-'[b]} {t} 0\n"
                         for l, r, a, b, t in zip(e["left"].tolist(), e["right"].tolist(), e["oL"].tolist(), e["oR"].tolist(), tot.tolist())
                         if t >= 5))
-    want_lin, want_cyc = orc.match_run(g, None, 10)
+    want_lin, want_cyc = orc.match_run(g, None, 10, aggressive=aggressive, cap=256 * 1024 * 1024)
     assert "".join(lin).encode() == want_lin
     assert "".join(cyc).encode() == want_cyc
     assert want_cyc.count(b"iter") > 0
