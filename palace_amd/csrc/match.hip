@@ -325,9 +325,15 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
             if (on) { live.push_back(2 * s); live.push_back(2 * s + 1); }
         }
         if (live.empty()) continue;                           // nothing left this round (an `aggressive` round may follow)
+        // Late rounds often have no arc left between two live segments: then there is nothing to match (every live
+        // vertex is a path of its own) and no reason to visit the GPU.
+        bool arcs_alive = t == 0;
+        for (int64_t e = 0; e < E && !arcs_alive; e++) arcs_alive = alive[src[e]] && alive[dst[e]];
+        if (!arcs_alive) {
+            for (const int32_t v : live) { next[v] = -1; prev[v] = -1; narc[v] = -1; }
+        } else {
         // One stream round trip per outer round: liveness up (pinned, stream-ordered), a batch of matching rounds,
         // the `changed` word and the three link arrays (side by side) down; more batches only if it had not settled.
-        {
             MatchArgs a{};
             a.n_vertices = V; a.n_arcs = E; a.src = d_src; a.dst = d_dst;
             a.out_off = d_oo; a.in_off = d_io; a.out_arcs = d_oa; a.in_arcs = d_ia;
