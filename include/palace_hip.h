@@ -74,9 +74,7 @@ int palace_eref_index_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_
  * d_keep (optional, 1 B/read) carries the E3 subsampling decision (extract_ref.cpp:955-960).
  * total_bases = d_offsets[n_reads] - d_offsets[0] when the caller knows it (keeps the call
  * asynchronous), or -1 to have it read back.
- * The table is held as three 2^32-bit planes "count >= 1 / >= 2 / >= 3".
- * After palace_eref_table_reset the library assumes zero planes until its own next write (the first count launch then
- * does not read them): a caller that owns the planes (palace_eref_table_attach) must not write them in between. */
+ * The table is held as three 2^32-bit planes "count >= 1 / >= 2 / >= 3". */
 int palace_eref_table_reset(palace_ctx *ctx);
 int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets,
                             int64_t n_reads, const uint8_t *d_keep, int64_t total_bases);

@@ -64,7 +64,6 @@ struct palace_ctx {
     palace::CoderMasks masks{};
     uint32_t *plane[3] = {nullptr, nullptr, nullptr};
     bool planes_external = false;
-    bool table_zero = false;        // the planes are known to hold zeros only (fresh or just reset): the first count launch need not load them
     int count_mode = 0;             // 0 auto, 1 direct atomics, 2 binned
     int64_t bin_cap_override = 0;
     int64_t slab_override = 0;

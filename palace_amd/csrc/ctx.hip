@@ -61,7 +61,6 @@ int ensure_table(palace_ctx *ctx)
             return PALACE_ENOMEM;
         }
         PALACE_HIP_TRY(hipMemsetAsync(ctx->plane[p], 0, kPlaneBytes, ctx->stream));
-        ctx->table_zero = true;
     }
     return PALACE_OK;
 }

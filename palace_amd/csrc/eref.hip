@@ -214,7 +214,6 @@ struct BinOut {
     uint32_t *buf;                 // destination regions, laid out by `caps`
     DensityCaps caps;              // capacity of a destination region of level-1 bucket b
     uint32_t *p1, *p2, *p3;        // overflow path
-    unsigned int *spilled;         // set when a key took the overflow path (the count kernel then may not assume zero planes)
 };
 
 // Level-1 regions: the kL1Replicas regions of bucket b lie side by side, buckets in order.
@@ -236,19 +235,12 @@ struct Stage {
     uint32_t start[kL1Buckets + 1];
 };
 
-// A key that found its staging row or its region full: exact slow path, straight onto the planes.
-__device__ __forceinline__ void spill_key(uint32_t key, const BinOut &o)
-{
-    *o.spilled = 1u;
-    count_key(key, o.p1, o.p2, o.p3);
-}
-
 __device__ __forceinline__ void stage_append(Stage &st, uint32_t row, uint32_t key, const BinOut &o)
 {
     const unsigned long long r = atomicAdd(&st.rows[row], 1ull);
     const uint32_t at = static_cast<uint32_t>(r), end = static_cast<uint32_t>(r >> 32);
     if (at < end) st.slot[at] = key;
-    else spill_key(key, o);                                   // row full
+    else count_key(key, o.p1, o.p2, o.p3);                    // row full: exact slow path
 }
 
 // stage -> reserve -> copy out.  `dest(row)` names the row's destination: region index (cursor slot),
@@ -283,7 +275,7 @@ __device__ __forceinline__ void flush_rows(Stage &st, const BinOut &o, D dest)
         for (uint32_t p = lane; p < cj; p += 64) {             // the longest row is 135 slots: up to three passes
             const uint32_t k = st.slot[sj + p];
             if (gj + p < capj) dst[p] = k;
-            else spill_key(k, o);                              // region full
+            else count_key(k, o.p1, o.p2, o.p3);               // region full: exact slow path
         }
     }
 }
@@ -394,7 +386,7 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin1_flat_kernel(const uint8
                 for (int i = 0; i < 3; i++) {
                     const uint32_t at = static_cast<uint32_t>(r[i]);
                     if (at < static_cast<uint32_t>(r[i] >> 32)) st.slot[at] = key[i];
-                    else spill_key(key[i], o);
+                    else count_key(key[i], o.p1, o.p2, o.p3);
                 }
             }
             lo = hi;
@@ -445,7 +437,7 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin2_kernel(const unsigned i
             if (i + e < end) {
                 const uint32_t at = static_cast<uint32_t>(r[e]);
                 if (at < static_cast<uint32_t>(r[e] >> 32)) st.slot[at] = k[e];
-                else spill_key(k[e], o);
+                else count_key(k[e], o.p1, o.p2, o.p3);
             }
     }
     flush_rows(st, o, [&](uint32_t row) {
@@ -457,29 +449,19 @@ __global__ __launch_bounds__(1024) void eref_lds_count_kernel(const unsigned int
                                                               const uint32_t *__restrict__ binned,
                                                               DensityCaps caps, uint32_t *__restrict__ p1,
                                                               uint32_t *__restrict__ p2,
-                                                              uint32_t *__restrict__ p3,
-                                                              const unsigned int *__restrict__ spilled, int planes_zero)
+                                                              uint32_t *__restrict__ p3)
 {
     __shared__ uint32_t l1[kSliceWords], l2[kSliceWords], l3[kSliceWords];      // 3 x 32 KiB
     const uint32_t b = blockIdx.x;
     const uint32_t n = min(cursor[b], caps.cap(b >> 7));
     if (n == 0) return;                                    // uniform for the whole workgroup
     const size_t w0 = static_cast<size_t>(b) * kSliceWords;
-    // first launch after a reset, and no key of this launch went onto the planes directly: the slices are zero
-    if (planes_zero && *spilled == 0u) {
-        for (int i = threadIdx.x; i < kSliceWords / 4; i += blockDim.x) {
-            reinterpret_cast<uint4 *>(l1)[i] = uint4{0, 0, 0, 0};
-            reinterpret_cast<uint4 *>(l2)[i] = uint4{0, 0, 0, 0};
-            reinterpret_cast<uint4 *>(l3)[i] = uint4{0, 0, 0, 0};
-        }
-    } else {
-        const uint4 *g1 = reinterpret_cast<const uint4 *>(p1 + w0), *g2 = reinterpret_cast<const uint4 *>(p2 + w0),
-                    *g3 = reinterpret_cast<const uint4 *>(p3 + w0);
-        for (int i = threadIdx.x; i < kSliceWords / 4; i += blockDim.x) {
-            reinterpret_cast<uint4 *>(l1)[i] = g1[i];
-            reinterpret_cast<uint4 *>(l2)[i] = g2[i];
-            reinterpret_cast<uint4 *>(l3)[i] = g3[i];
-        }
+    const uint4 *g1 = reinterpret_cast<const uint4 *>(p1 + w0), *g2 = reinterpret_cast<const uint4 *>(p2 + w0),
+                *g3 = reinterpret_cast<const uint4 *>(p3 + w0);
+    for (int i = threadIdx.x; i < kSliceWords / 4; i += blockDim.x) {
+        reinterpret_cast<uint4 *>(l1)[i] = g1[i];
+        reinterpret_cast<uint4 *>(l2)[i] = g2[i];
+        reinterpret_cast<uint4 *>(l3)[i] = g3[i];
     }
     __syncthreads();
     // keys four at a time (regions start on 16-byte boundaries and capacities are multiples of 4 keys, so the last
@@ -1136,7 +1118,6 @@ int palace_eref_table_reset(palace_ctx *ctx)
     if (rc) return rc;
     if (!fresh)
         for (int p = 0; p < 3; p++) PALACE_HIP_TRY(hipMemsetAsync(ctx->plane[p], 0, kPlaneBytes, ctx->stream));
-    ctx->table_zero = true;
     return PALACE_OK;
 }
 
@@ -1162,7 +1143,6 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     }
     const bool binned = ctx->count_mode == 2 || (ctx->count_mode == 0 && total_bases >= (1ll << 22));
     if (!binned) {
-        ctx->table_zero = false;
         int64_t blocks = (n_reads + 3) / 4;                 // 4 waves (reads) per 256-thread block
         int64_t cap = static_cast<int64_t>(kCUs) * 8 * 8;   // grid-stride beyond 16 Ki blocks
         if (blocks > cap) blocks = cap;
@@ -1191,7 +1171,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     }
     PALACE_REQUIRE(caps1.cap(0) < (1u << 31) && caps2.cap(0) < (1u << 31), "slab too large for 32-bit region cursors");
     const size_t cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
-    const size_t cur2_bytes = align_up((kBuckets + 1) * sizeof(unsigned int), 256);     // fine-bucket cursors, then the `spilled` word
+    const size_t cur2_bytes = align_up(kBuckets * sizeof(unsigned int), 256);
     const size_t buf1_bytes = align_up(static_cast<size_t>(caps1.prefix(kL1Buckets)) * kL1Replicas * 4, 256);
     const size_t buf2_bytes = align_up(static_cast<size_t>(caps2.prefix(kL1Buckets)) * kL1Buckets * 4, 256);
     const int64_t n_chunks = (total_bases + 63) / 64;
@@ -1204,11 +1184,8 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     unsigned long long *ends = reinterpret_cast<unsigned long long *>(ws); ws += ends_bytes;
     uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
     uint32_t *buf2 = reinterpret_cast<uint32_t *>(ws);
-    unsigned int *spilled = cursor2 + kBuckets;
-    BinOut o1{cursor1, buf1, caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], spilled};
-    BinOut o2{cursor2, buf2, caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2], spilled};
-    const bool planes_zero = ctx->table_zero;              // holds for the first slab only
-    ctx->table_zero = false;
+    BinOut o1{cursor1, buf1, caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
+    BinOut o2{cursor2, buf2, caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
     if (!d_keep) {                                   // read ends as a bit per position, once for the whole set
         PALACE_HIP_TRY(hipMemsetAsync(ends, 0, static_cast<size_t>(n_chunks + 1) * 8, ctx->stream));
         hipLaunchKernelGGL(mark_read_ends_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
@@ -1249,7 +1226,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
                            cursor1, buf1, caps1, o2);
         PALACE_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, cursor2, buf2, caps2,
-                           ctx->plane[0], ctx->plane[1], ctx->plane[2], spilled, (planes_zero && slab == 0) ? 1 : 0);
+                           ctx->plane[0], ctx->plane[1], ctx->plane[2]);
         PALACE_HIP_TRY(hipGetLastError());
     }
     return PALACE_OK;
@@ -1508,7 +1485,6 @@ int palace_eref_table_attach(palace_ctx *ctx, void *const d_planes3[3])
         ctx->plane[p] = static_cast<uint32_t *>(d_planes3[p]);
     }
     ctx->planes_external = true;
-    ctx->table_zero = false;                               // caller-owned memory: content unknown
     return PALACE_OK;
 }
 
@@ -1521,7 +1497,6 @@ int palace_eref_table_merge_slices(palace_ctx *ctx, const void *d_parts, int n_p
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
-    ctx->table_zero = false;
     size_t n16 = slice_bytes / 16;
     if (n16 == 0) return PALACE_OK;
     char *b1 = reinterpret_cast<char *>(ctx->plane[0]) + slice_off;
