@@ -266,16 +266,26 @@ __device__ __forceinline__ void flush_rows(Stage &st, const BinOut &o, D dest)
         cap = d.cap; base_lo = static_cast<uint32_t>(d.base); base_hi = static_cast<uint32_t>(d.base >> 32);
         if (c) g = atomicAdd(&o.cursor[d.region], c);
     }
+    // The first 64 slots of row j+1 are read from LDS while row j is stored (one LDS round trip per row would
+    // otherwise sit between any two stores); the second and third 64-slot pass of a long row are read in place.
+    uint32_t k_next = st.slot[min(static_cast<uint32_t>(__builtin_amdgcn_readlane(s0, 0)) + lane, static_cast<uint32_t>(kStageSlots - 1))];
 #pragma unroll
     for (int j = 0; j < rows_per_wave; j++) {
         const uint32_t cj = __builtin_amdgcn_readlane(c, j), sj = __builtin_amdgcn_readlane(s0, j),
                        gj = __builtin_amdgcn_readlane(g, j), capj = __builtin_amdgcn_readlane(cap, j);
         const uint32_t bl = __builtin_amdgcn_readlane(base_lo, j), bh = __builtin_amdgcn_readlane(base_hi, j);   // (the builtin returns int)
         uint32_t *dst = o.buf + ((static_cast<uint64_t>(bh) << 32) | bl) + gj;
-        for (uint32_t p = lane; p < cj; p += 64) {             // the longest row is 135 slots: up to three passes
+        const uint32_t k0 = k_next;
+        if (j + 1 < rows_per_wave)
+            k_next = st.slot[min(static_cast<uint32_t>(__builtin_amdgcn_readlane(s0, j + 1)) + lane, static_cast<uint32_t>(kStageSlots - 1))];
+        if (lane < cj) {
+            if (gj + lane < capj) dst[lane] = k0;
+            else count_key(k0, o.p1, o.p2, o.p3);              // region full: exact slow path
+        }
+        for (uint32_t p = 64 + lane; p < cj; p += 64) {        // the longest row is 135 slots: up to three passes
             const uint32_t k = st.slot[sj + p];
             if (gj + p < capj) dst[p] = k;
-            else count_key(k, o.p1, o.p2, o.p3);               // region full: exact slow path
+            else count_key(k, o.p1, o.p2, o.p3);
         }
     }
 }
