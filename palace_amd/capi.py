@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libpalace_hip.so")
+SO_PATH = os.environ.get("PALACE_HIP_SO") or os.path.join(_HERE, "libpalace_hip.so")     # override: A/B timing of two builds
 _LIB = None
 
 
