@@ -447,9 +447,16 @@ def main():
         ref_ranges = [multigpu.split_by_weight(sample["ref_lens"], r, world) for r in range(world)]
         scratch_consumed = torch.zeros(nt, dtype=torch.int64, device=dev)
 
-        def merge_fn(parts, n_parts, slice_off, slice_bytes):
+        low_plane = torch.zeros(1 << 29, dtype=torch.uint8, device=dev)
+
+        def pack_fn():                              # two planes per peer instead of three (include/palace_hip.h)
+            ctx.eref_table_pack_low(low_plane.data_ptr())
+            ctx.sync()
+            return low_plane
+
+        def merge_fn(parts, n_parts, slice_off, slice_bytes, packed=False):
             tsync()
-            ctx.eref_table_merge_slices(parts.data_ptr(), n_parts, slice_off, slice_bytes)
+            ctx.eref_table_merge_slices(parts.data_ptr(), n_parts, slice_off, slice_bytes, packed)
             ctx.sync()
     last = {}
     host_ms = {}
@@ -478,7 +485,7 @@ def main():
         def eref_tail():
             if exch and shard_reads:                   # count-table exchange (RCCL), then Phase B on this rank's refs
                 ctx.sync()
-                exch.merge_planes(planes, merge_fn)
+                exch.merge_planes(planes, merge_fn, pack_fn)
                 tsync()
             if timed: ctx.mark(m + 2)
             capi._check(L.palace_eref_scan_refs_indexed(ctx.h, probe_index, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,

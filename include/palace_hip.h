@@ -121,6 +121,14 @@ int palace_eref_table_attach(palace_ctx *ctx, void *const d_planes3[3]);
 int palace_eref_table_merge_slices(palace_ctx *ctx, const void *d_parts, int n_parts,
                                    size_t slice_off, size_t slice_bytes);
 
+/* The same exchange with two planes per peer instead of three: the unary planes of a partial table carry two bits per
+ * key, the count's low bit (count>=1 ^ count>=2 ^ count>=3) and its high bit (count>=2).  palace_eref_table_pack_low
+ * writes the low-bit plane of the context's table into d_low (2^29 bytes, 16-byte aligned); the sender ships d_low and
+ * its count>=2 plane; palace_eref_table_merge_slices_packed folds parts laid out [2][n_parts][slice] = (low, high). */
+int palace_eref_table_pack_low(palace_ctx *ctx, void *d_low);
+int palace_eref_table_merge_slices_packed(palace_ctx *ctx, const void *d_parts, int n_parts, size_t slice_off,
+                                          size_t slice_bytes);
+
 /* Test hooks: counts (0..3) of `n` indices; population count of each plane. */
 int palace_eref_table_lookup(palace_ctx *ctx, const uint32_t *d_keys, int64_t n, uint8_t *d_counts);
 int palace_eref_table_popcounts(palace_ctx *ctx, uint64_t out3[3]);

@@ -85,6 +85,8 @@ _SIGS = {
     "palace_eref_table_planes": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
     "palace_eref_table_attach": [C.c_void_p, C.POINTER(C.c_void_p)],
     "palace_eref_table_merge_slices": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t],
+    "palace_eref_table_merge_slices_packed": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t],
+    "palace_eref_table_pack_low": [C.c_void_p, C.c_void_p],
     "palace_eref_table_lookup": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "palace_eref_table_popcounts": [C.c_void_p, C.POINTER(C.c_uint64)],
     "palace_graph_classify": [C.c_void_p, C.POINTER(BamCols), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
@@ -282,9 +284,12 @@ class Ctx:
         arr = (C.c_void_p * 3)(*[int(p) for p in ptrs])
         _check(lib().palace_eref_table_attach(self.h, arr), "palace_eref_table_attach")
 
-    def eref_table_merge_slices(self, parts_ptr: int, n_parts: int, slice_off: int, slice_bytes: int):
-        _check(lib().palace_eref_table_merge_slices(self.h, parts_ptr, n_parts, slice_off, slice_bytes),
-               "palace_eref_table_merge_slices")
+    def eref_table_merge_slices(self, parts_ptr: int, n_parts: int, slice_off: int, slice_bytes: int, packed: bool = False):
+        fn = lib().palace_eref_table_merge_slices_packed if packed else lib().palace_eref_table_merge_slices
+        _check(fn(self.h, parts_ptr, n_parts, slice_off, slice_bytes), "palace_eref_table_merge_slices")
+
+    def eref_table_pack_low(self, low_ptr: int):
+        _check(lib().palace_eref_table_pack_low(self.h, low_ptr), "palace_eref_table_pack_low")
 
 
 _ARC_BUFFERS = {}

@@ -1055,7 +1055,21 @@ __global__ __launch_bounds__(256) void plane_popcount_kernel(const uint4 *__rest
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 
-// saturating unary add of n_parts partial tables into the context's planes (16 B per lane)
+// The unary planes of a partial table (p3 subset of p2 subset of p1) hold two bits of information per key: the
+// count's low bit p1 ^ p2 ^ p3 and its high bit p2.  Peers are sent those two planes instead of three.
+__global__ __launch_bounds__(256) void pack_low_kernel(const uint4 *__restrict__ p1, const uint4 *__restrict__ p2,
+                                                       const uint4 *__restrict__ p3, size_t n16, uint4 *__restrict__ low)
+{
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const uint4 a = p1[i], b = p2[i], c = p3[i];
+        low[i] = make_uint4(a.x ^ b.x ^ c.x, a.y ^ b.y ^ c.y, a.z ^ b.z ^ c.z, a.w ^ b.w ^ c.w);
+    }
+}
+
+// saturating unary add of n_parts partial tables into the context's planes (16 B per lane); PACKED: the parts come
+// as (low bit, high bit) planes, layout [2][part][slice], otherwise as the three unary planes, layout [3][part][slice]
+template <bool PACKED>
 __global__ __launch_bounds__(256) void merge_slices_kernel(const uint4 *__restrict__ parts, int n_parts,
                                                            size_t slice16, uint4 *__restrict__ d1,
                                                            uint4 *__restrict__ d2, uint4 *__restrict__ d3)
@@ -1063,10 +1077,15 @@ __global__ __launch_bounds__(256) void merge_slices_kernel(const uint4 *__restri
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < slice16;
          i += static_cast<size_t>(gridDim.x) * blockDim.x) {
         uint32_t a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, a3[4] = {0, 0, 0, 0};
-        for (int p = 0; p < n_parts; p++) {           // layout [plane][part][slice]
+        for (int p = 0; p < n_parts; p++) {
             const size_t np = static_cast<size_t>(n_parts);
             uint4 v1 = parts[(0 * np + p) * slice16 + i], v2 = parts[(1 * np + p) * slice16 + i],
-                  v3 = parts[(2 * np + p) * slice16 + i];
+                  v3 = PACKED ? v2 : parts[(2 * np + p) * slice16 + i];
+            if (PACKED) {                             // (low, high) -> count >= 1, >= 2, >= 3
+                const uint4 lo = v1, hi = v2;
+                v1 = make_uint4(lo.x | hi.x, lo.y | hi.y, lo.z | hi.z, lo.w | hi.w);
+                v3 = make_uint4(lo.x & hi.x, lo.y & hi.y, lo.z & hi.z, lo.w & hi.w);
+            }
             uint32_t b1[4] = {v1.x, v1.y, v1.z, v1.w}, b2[4] = {v2.x, v2.y, v2.z, v2.w},
                      b3[4] = {v3.x, v3.y, v3.z, v3.w};
 #pragma unroll
@@ -1498,8 +1517,7 @@ int palace_eref_table_attach(palace_ctx *ctx, void *const d_planes3[3])
     return PALACE_OK;
 }
 
-int palace_eref_table_merge_slices(palace_ctx *ctx, const void *d_parts, int n_parts, size_t slice_off,
-                                   size_t slice_bytes)
+static int merge_slices_impl(palace_ctx *ctx, const void *d_parts, int n_parts, size_t slice_off, size_t slice_bytes, bool packed)
 {
     PALACE_REQUIRE(ctx && d_parts && n_parts > 0, "bad argument");
     PALACE_REQUIRE(slice_off % 16 == 0 && slice_bytes % 16 == 0 && slice_off + slice_bytes <= kPlaneBytes,
@@ -1513,9 +1531,41 @@ int palace_eref_table_merge_slices(palace_ctx *ctx, const void *d_parts, int n_p
     char *b2 = reinterpret_cast<char *>(ctx->plane[1]) + slice_off;
     char *b3 = reinterpret_cast<char *>(ctx->plane[2]) + slice_off;
     unsigned blocks = static_cast<unsigned>(std::min<size_t>((n16 + 255) / 256, kCUs * 8));
-    hipLaunchKernelGGL(merge_slices_kernel, dim3(blocks), dim3(256), 0, ctx->stream,
-                       static_cast<const uint4 *>(d_parts), n_parts, n16, reinterpret_cast<uint4 *>(b1),
-                       reinterpret_cast<uint4 *>(b2), reinterpret_cast<uint4 *>(b3));
+    if (packed)
+        hipLaunchKernelGGL(merge_slices_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
+                           static_cast<const uint4 *>(d_parts), n_parts, n16, reinterpret_cast<uint4 *>(b1),
+                           reinterpret_cast<uint4 *>(b2), reinterpret_cast<uint4 *>(b3));
+    else
+        hipLaunchKernelGGL(merge_slices_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream,
+                           static_cast<const uint4 *>(d_parts), n_parts, n16, reinterpret_cast<uint4 *>(b1),
+                           reinterpret_cast<uint4 *>(b2), reinterpret_cast<uint4 *>(b3));
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+int palace_eref_table_merge_slices(palace_ctx *ctx, const void *d_parts, int n_parts, size_t slice_off,
+                                   size_t slice_bytes)
+{
+    return merge_slices_impl(ctx, d_parts, n_parts, slice_off, slice_bytes, false);
+}
+
+int palace_eref_table_merge_slices_packed(palace_ctx *ctx, const void *d_parts, int n_parts, size_t slice_off,
+                                          size_t slice_bytes)
+{
+    return merge_slices_impl(ctx, d_parts, n_parts, slice_off, slice_bytes, true);
+}
+
+int palace_eref_table_pack_low(palace_ctx *ctx, void *d_low)
+{
+    PALACE_REQUIRE(ctx && d_low, "null argument");
+    PALACE_REQUIRE(reinterpret_cast<uintptr_t>(d_low) % 16 == 0, "buffer must be 16-byte aligned");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_table(ctx);
+    if (rc) return rc;
+    const size_t n16 = kPlaneBytes / 16;
+    hipLaunchKernelGGL(pack_low_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const uint4 *>(ctx->plane[0]), reinterpret_cast<const uint4 *>(ctx->plane[1]),
+                       reinterpret_cast<const uint4 *>(ctx->plane[2]), n16, static_cast<uint4 *>(d_low));
     PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
 }

@@ -39,22 +39,30 @@ class Exchange:
         self._recv = None
 
     # ---- eref count table ------------------------------------------------------------------------
-    def merge_planes(self, planes, merge_fn):
+    def merge_planes(self, planes, merge_fn, pack_fn=None):
         """planes: three 1-D uint8 tensors (this rank's partial planes, equal length B with
         B % (16 * world) == 0).  merge_fn(parts, n_parts, slice_off, slice_bytes) must fold
         parts[plane][part][slice] into the planes at slice_off (the HIP library in production).
+        With pack_fn (-> 1-D uint8 tensor of length B: the low bit of every key's count, p1 ^ p2 ^ p3) only TWO
+        planes travel -- (low bit, count >= 2) carry everything the three unary planes do -- and merge_fn is called
+        with packed=True on parts laid out [2][part][slice].
         On return planes[2] is the global '>= 3' plane on every rank."""
         torch, dist, W = self.torch, self.dist, self.world
         B = planes[0].numel()
         assert B % (16 * W) == 0 and all(p.numel() == B for p in planes)
         S = B // W
-        if self._recv is None or self._recv.numel() != 3 * B:
-            self._recv = torch.empty((3, W, S), dtype=torch.uint8, device=planes[0].device)
+        send = planes if pack_fn is None else [pack_fn(), planes[1]]
+        n_pl = len(send)
+        if self._recv is None or self._recv.numel() != n_pl * B:
+            self._recv = torch.empty((n_pl, W, S), dtype=torch.uint8, device=planes[0].device)
         # one all_to_all per plane: a plane already is [peer][slice], so it is its own send buffer, and a
         # message stays <= 512/W MiB (RCCL 2.26 corrupts single all_to_all calls above 1 GiB per rank)
-        for p in range(3):
-            dist.all_to_all_single(self._recv[p].view(-1), planes[p])
-        merge_fn(self._recv, W, self.rank * S, S)
+        for p in range(n_pl):
+            dist.all_to_all_single(self._recv[p].view(-1), send[p])
+        if pack_fn is None:
+            merge_fn(self._recv, W, self.rank * S, S)
+        else:
+            merge_fn(self._recv, W, self.rank * S, S, packed=True)
         mine = planes[2][self.rank * S:(self.rank + 1) * S].clone()
         dist.all_gather_into_tensor(planes[2], mine)
 

@@ -257,7 +257,17 @@ def test_properties_full_size(ctx):
     ctx.eref_table_merge_slices(parts.ptr, 2, 0, nbytes)
     ctx.sync()
     assert ctx.eref_table_popcounts() == p_ab and np.array_equal(ctx.eref_table_lookup(probe), l_ab)
-    for buf in (da, dao, dbb, dbo, parts):
+    # the same merge from two planes per part: (low bit of the count, count >= 2), layout [2][part][slice]
+    packed = ctx.empty(2 * 2 * nbytes, np.uint8)
+    for k, S in enumerate((A, B)):
+        run([S])
+        ctx.eref_table_pack_low(packed.ptr + (0 * 2 + k) * nbytes)
+        ctx.d2d(packed.ptr + (1 * 2 + k) * nbytes, planes[1], nbytes)
+    ctx.eref_table_reset()
+    ctx.eref_table_merge_slices(packed.ptr, 2, 0, nbytes, packed=True)
+    ctx.sync()
+    assert ctx.eref_table_popcounts() == p_ab and np.array_equal(ctx.eref_table_lookup(probe), l_ab)
+    for buf in (da, dao, dbb, dbo, parts, packed):
         buf.free()
 
 

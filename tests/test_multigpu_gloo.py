@@ -20,10 +20,14 @@ def planes_from_counts(c):
 
 
 def torch_merge(planes):
-    def fn(parts, n_parts, slice_off, slice_bytes):
+    def fn(parts, n_parts, slice_off, slice_bytes, packed=False):
         a1 = torch.zeros(slice_bytes, dtype=torch.uint8); a2 = a1.clone(); a3 = a1.clone()
         for p in range(n_parts):
-            b1, b2, b3 = parts[0, p], parts[1, p], parts[2, p]
+            if packed:                                  # (low bit, high bit) of the count -> unary planes
+                lo, hi = parts[0, p], parts[1, p]
+                b1, b2, b3 = lo | hi, hi, lo & hi
+            else:
+                b1, b2, b3 = parts[0, p], parts[1, p], parts[2, p]
             a3 = a3 | b3 | (a2 & b1) | (a1 & b2)
             a2 = a2 | b2 | (a1 & b1)
             a1 = a1 | b1
@@ -40,13 +44,16 @@ def worker(rank, world, port, q):
         rng = np.random.Generator(np.random.PCG64(5))
         n_keys = 1 << 16
         counts = [rng.integers(0, 4, size=n_keys) * (rng.random(n_keys) < 0.3) for _ in range(world)]
-        planes = planes_from_counts(counts[rank])
-        ex.merge_planes(planes, torch_merge(planes))
         want = planes_from_counts(np.minimum(3, sum(counts)))
-        ok_planes = bool(torch.equal(planes[2], want[2]))
-        S = planes[0].numel() // world
-        own = slice(rank * S, (rank + 1) * S)
-        ok_planes &= bool(torch.equal(planes[0][own], want[0][own]) and torch.equal(planes[1][own], want[1][own]))
+        ok_planes = True
+        for packed in (False, True):                    # three unary planes per peer, or (low bit, count >= 2)
+            planes = planes_from_counts(counts[rank])
+            pack = (lambda pl=planes: pl[0] ^ pl[1] ^ pl[2]) if packed else None
+            ex.merge_planes(planes, torch_merge(planes), pack)
+            ok_planes &= bool(torch.equal(planes[2], want[2]))
+            S = planes[0].numel() // world
+            own = slice(rank * S, (rank + 1) * S)
+            ok_planes &= bool(torch.equal(planes[0][own], want[0][own]) and torch.equal(planes[1][own], want[1][own]))
         # rows by ranges
         lens = rng.integers(100, 1000, size=37)
         ranges = [multigpu.split_by_weight(lens, r, world) for r in range(world)]
