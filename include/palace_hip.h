@@ -33,6 +33,9 @@ const char *palace_last_error(void);
 const char *palace_version(void);
 
 /* ---- context, memory, stream plumbing --------------------------------------------------- */
+/* A context owns one HIP stream, the eref count table, grow-only device / pinned / host scratch.  Calls on ONE context
+ * must come from one thread at a time (they are ordered on its stream); DIFFERENT contexts may be used concurrently from
+ * different threads and their work overlaps on the device.  palace_last_error() is per thread. */
 int palace_ctx_create(int device, palace_ctx **out);
 /* same, with the context's stream at the device's highest priority when high_priority != 0 (for
  * small latency-bound work that runs beside bulk kernels of another context) */
