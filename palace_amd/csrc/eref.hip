@@ -1319,6 +1319,7 @@ int palace_eref_index_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_
 
 struct palace_eref_probe_index {
     int64_t n_refs = 0, total_bases = 0;
+    palace::CoderMasks masks{};               // the coder the indices were computed with
     unsigned long long n_entries = 0;
     unsigned long long *first = nullptr;      // [kBuckets + 1]
     unsigned long long *entries = nullptr;    // [n_entries]
@@ -1422,7 +1423,7 @@ int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const
     PALACE_REQUIRE(total_bases + 64 * (n_refs + 1) < (1ll << 46), "position ids must fit in 46 bits");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     palace_eref_probe_index *ix = new palace_eref_probe_index();
-    ix->n_refs = n_refs; ix->total_bases = total_bases;
+    ix->n_refs = n_refs; ix->total_bases = total_bases; ix->masks = ctx->masks;
     unsigned long long *count = nullptr;                  // 16384 counters, only during the build
     auto done = [&](int rc) {
         (void)hipStreamSynchronize(ctx->stream);
@@ -1477,6 +1478,7 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     int rc = scan_args_ok(ctx, d_bases, d_offsets, n_refs, total_bases, d_rows);
     if (rc) return rc;
     PALACE_REQUIRE(ix->n_refs == n_refs && ix->total_bases == total_bases, "probe index was built for another ref set");
+    PALACE_REQUIRE(std::memcmp(&ix->masks, &ctx->masks, sizeof(CoderMasks)) == 0, "probe index was built with another coder");
     if (n_refs == 0) return PALACE_OK;
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     rc = ensure_table(ctx);

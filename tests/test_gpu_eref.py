@@ -98,6 +98,12 @@ def test_stdout_equals_reference(ctx, golden_eref, key, hr, pr):
     rows2 = ctx.empty((rs.n, 4), np.int32)
     ctx.eref_scan_refs_indexed(ix, db, do, rs.n, len(rs.bases), one_min, three_min, rows2)
     assert np.array_equal(rows2.to_host(), r)
+    other = orc.header_from_picks((np.arange(32) * 5 + 1) % 6)                 # an index is tied to the coder it was built with
+    if not np.array_equal(other, g["index_header"]):
+        ctx.eref_set_coder(other)
+        with pytest.raises(capi.PalaceError, match="another coder"):
+            ctx.eref_scan_refs_indexed(ix, db, do, rs.n, len(rs.bases), one_min, three_min, rows2)
+        ctx.eref_set_coder(g["index_header"])
     ctx.eref_probe_index_free(ix)
     rows2.free()
     out = b""
