@@ -598,7 +598,7 @@ def main():
         alg_bytes = (READ_LEN + 6 * (READ_LEN - 31)) * 2 * n_side        # per launch (both FASTQ sides of this rank)
         achieved = alg_bytes / (count_ms * 1e-3) / 1e9
         out = {
-            "metric": "contigs/sec eref+generate_graph+matching, 1M-contig synth",
+            "metric": "contigs/sec eref+generate_graph+matching, 1M-contig synth, 1/2/4/8 GPU",       # BASELINE.json, verbatim
             "value": args.contigs / (ms_step * 1e-3), "unit": "contigs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
