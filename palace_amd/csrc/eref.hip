@@ -1183,7 +1183,14 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     }
     // Large read sets are processed in slabs of at most kSlabBases positions (the planes accumulate across
     // slabs), which bounds the workspace at ~30 GB whatever the input size.
-    const int64_t kSlabBases = ctx->slab_override > 0 ? ctx->slab_override : (1ll << 30);   // multiple of 64
+    // Slab size: 2^30 positions (workspace ~40 GB); 2^31 when the read set is larger than that AND the device has the
+    // room (~80 GB of workspace) -- every slab rewrites all plane slices once, so fewer slabs mean less traffic.
+    int64_t default_slab = 1ll << 30;
+    if (ctx->slab_override == 0 && total_bases > default_slab) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + ctx->ws.bytes >= (160ull << 30)) default_slab = 1ll << 31;
+    }
+    const int64_t kSlabBases = ctx->slab_override > 0 ? ctx->slab_override : default_slab;   // multiple of 64
     const int64_t n_slabs = (total_bases + kSlabBases - 1) / kSlabBases;
     const int64_t slab_bases = std::min(total_bases, kSlabBases);
     // capacities: the key upper bound of one slab shared out by the key density with 20 % head room, plus a
