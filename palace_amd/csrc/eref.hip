@@ -1182,7 +1182,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         return PALACE_OK;
     }
     // Large read sets are processed in slabs of at most kSlabBases positions (the planes accumulate across
-    // slabs), which bounds the workspace at ~30 GB whatever the input size.
+    // slabs), which bounds the workspace whatever the input size.
     // Slab size: 2^30 positions (workspace ~40 GB); 2^31 when the read set is larger than that AND the device has the
     // room (~80 GB of workspace) -- every slab rewrites all plane slices once, so fewer slabs mean less traffic.
     int64_t default_slab = 1ll << 30;
