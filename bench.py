@@ -536,6 +536,9 @@ def main():
         th1 = time.perf_counter()
         # ---------------- matching (small; rank 0 owns it, components are independent) ----------------
         def matching():
+            if rank != 0:                               # rank 0 owns the (small) matching stage
+                last.update(n_edges=int(n_e.value), n_cands=int(n_cands))
+                return
             copies, src, dst, w = graph_to_arcs(h_cn, nt, h_edges)
             th2 = time.perf_counter()
             if rank == 0:
