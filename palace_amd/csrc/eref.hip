@@ -24,6 +24,10 @@
 //    and does the 500-base window test with prefix population counts.
 #include "common.hpp"
 
+#ifndef PALACE_ABL
+#define PALACE_ABL 0        // ablation switches of diagnostic builds (tools/build_ablate.sh); the product is built with 0
+#endif
+
 
 namespace palace {
 
@@ -159,15 +163,12 @@ constexpr int kBuckets = 1 << kBucketBits;            // 16384 fine buckets
 constexpr int kBucketShift = 32 - kBucketBits;        // 18: keys per fine bucket = 2^18
 constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 per plane per bucket
 constexpr int kL1Buckets = 128, kL1Shift = 25;        // level 1: key >> 25
-constexpr int kFlatMaxChunks = 6;                     // 64-position chunks one wave walks in the flat bin1 kernel
 constexpr int kL1Replicas = 32;                       // level-1 bucket regions are split 32 ways so that the
                                                       // per-tile reservations do not pile onto 128 addresses
 constexpr int kBinThreads = 512;                      // 8 waves; 37.5 KiB of LDS -> 4 workgroups per CU
 constexpr int kRowSlots = 72;                         // mean staging row
 constexpr int kStageSlots = kL1Buckets * kRowSlots;   // 9216 keys staged per workgroup
 constexpr int kRowPad = 8;                            // density-independent part of a level-1 row
-constexpr int kTileKeys = kBinThreads * 12;           // level-2 tile: 2/3 of the staging area (row mean 48 of 72: +3.5 sigma)
-constexpr int kTile1Keys = 6200;                      // level-1 tile target (rows sized by density: +3.6 sigma or more)
 
 // Capacity of the slot range that belongs to level-1 bucket b when a total is shared out by the key
 // density: prefix(b) = pad*b + share*b*(256-b)/128, capacity(b) = prefix(b+1) - prefix(b)
@@ -187,28 +188,6 @@ __host__ __device__ constexpr uint32_t l1_row_start(uint32_t b)
 }
 static_assert(l1_row_start(kL1Buckets) == kStageSlots, "rows tile the staging area");
 
-template <class F>
-__device__ __forceinline__ void for_each_key(const uint8_t *__restrict__ s, int64_t len, int lane,
-                                             const CoderMasks &masks, F f)
-{
-    const int64_t npos = len - 31;
-    if (npos <= 0) return;
-    Streams lo = ballot_streams(s, lane, len);
-    for (int64_t base = 0; base < npos; base += 64) {
-        Streams hi = ballot_streams(s, base + 64 + lane, len);
-        const int64_t j = base + lane;
-        uint32_t wv = window32(lo.ok, hi.ok, lane);
-        if (j < npos && wv == 0xffffffffu) {
-            uint32_t key[3];
-            kmer_keys(masks, window32(lo.p0, hi.p0, lane), window32(lo.p1, hi.p1, lane),
-                      window32(lo.p2, hi.p2, lane), key);
-#pragma unroll
-            for (int i = 0; i < 3; i++) f(key[i]);
-        }
-        lo = hi;
-    }
-}
-
 struct BinOut {
     unsigned int *cursor;          // per destination region: keys reserved so far
     uint32_t *buf;                 // destination regions, laid out by `caps`
@@ -216,15 +195,13 @@ struct BinOut {
     uint32_t *p1, *p2, *p3;        // overflow path
 };
 
+// Level-1 cursors are laid out replica-major: the 16 reservations of a wave (16 consecutive buckets, one replica) fall
+// into 64 consecutive bytes instead of 16 different cache lines.
+__host__ __device__ constexpr uint32_t l1_cursor(uint32_t b, uint32_t replica) { return replica * kL1Buckets + b; }
 // Level-1 regions: the kL1Replicas regions of bucket b lie side by side, buckets in order.
 __device__ __forceinline__ uint64_t l1_region_base(const DensityCaps &c, uint32_t b, uint32_t replica)
 {
     return c.prefix(b) * kL1Replicas + static_cast<uint64_t>(replica) * c.cap(b);
-}
-// Fine-bucket regions: the 128 fine buckets of level-1 bucket b1 lie side by side, equal capacity.
-__device__ __forceinline__ uint64_t fine_region_base(const DensityCaps &c, uint32_t b1, uint32_t sub)
-{
-    return c.prefix(b1) * kL1Buckets + static_cast<uint64_t>(sub) * c.cap(b1);
 }
 
 // The staging area: rows[b] = (row end << 32) | next free slot, so ONE 64-bit LDS atomic hands a key
@@ -235,58 +212,75 @@ struct Stage {
     uint32_t start[kL1Buckets + 1];
 };
 
-__device__ __forceinline__ void stage_append(Stage &st, uint32_t row, uint32_t key, const BinOut &o)
-{
-    const unsigned long long r = atomicAdd(&st.rows[row], 1ull);
-    const uint32_t at = static_cast<uint32_t>(r), end = static_cast<uint32_t>(r >> 32);
-    if (at < end) st.slot[at] = key;
-    else count_key(key, o.p1, o.p2, o.p3);                    // row full: exact slow path
-}
-
 // stage -> reserve -> copy out.  `dest(row)` names the row's destination: region index (cursor slot),
 // first key of the region in o.buf, region capacity.
 struct Dest { uint32_t region; uint64_t base; uint32_t cap; };
+
+typedef uint32_t __attribute__((address_space(1))) global_u32;
 
 template <class D>
 __device__ __forceinline__ void flush_rows(Stage &st, const BinOut &o, D dest)
 {
     constexpr int rows_per_wave = kL1Buckets / (kBinThreads / 64);
     __syncthreads();
-    // The first lanes of a wave reserve the runs of the wave's 16 rows (all atomics in flight together);
-    // the wave then walks its rows with count, source, destination and capacity in SGPRs (v_readlane).
+    // The first lanes of a wave reserve the runs of the wave's 16 rows (all atomics in flight together) and work out
+    // each row's destination pointer; the wave then walks its rows with count, source and pointer in SGPRs
+    // (v_readlane): four scalar reads per row and no address arithmetic (the scalar unit is shared by the CU's
+    // 32 waves and was the busiest unit of the first version of this loop).
     const int lane = threadIdx.x & 63;
     const int row0 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) * rows_per_wave;
-    uint32_t c = 0, s0 = 0, g = 0, cap = 0, base_lo = 0, base_hi = 0;
+    uint32_t c = 0, s0 = 0, g = 0, cap = 0, p_lo = 0, p_hi = 0;
+    bool over = false;
     if (lane < rows_per_wave) {
         const uint32_t row = row0 + lane;
         const unsigned long long r = st.rows[row];
         s0 = st.start[row];
         c = min(static_cast<uint32_t>(r), static_cast<uint32_t>(r >> 32)) - s0;
         const Dest d = dest(row);
-        cap = d.cap; base_lo = static_cast<uint32_t>(d.base); base_hi = static_cast<uint32_t>(d.base >> 32);
+        cap = d.cap;
+#if PALACE_ABL & 1      // diagnostic build: no reservation atomics (runs land somewhere inside the region)
+        if (c) g = (blockIdx.x * 2654435761u) % max(1u, cap - min(cap, c));
+#else
         if (c) g = atomicAdd(&o.cursor[d.region], c);
+#endif
+        over = static_cast<uint64_t>(g) + c > cap;
+        const uint64_t ptr = reinterpret_cast<uint64_t>(o.buf + d.base + min(g, cap));
+        p_lo = static_cast<uint32_t>(ptr); p_hi = static_cast<uint32_t>(ptr >> 32);
     }
+    const unsigned long long over_rows = __ballot(over);          // rows whose run does not fit: rare, exact slow path
     // The first 64 slots of row j+1 are read from LDS while row j is stored (one LDS round trip per row would
-    // otherwise sit between any two stores); the second and third 64-slot pass of a long row are read in place.
+    // otherwise sit between any two stores); later 64-slot passes of a long row are read in place.
     uint32_t k_next = st.slot[min(static_cast<uint32_t>(__builtin_amdgcn_readlane(s0, 0)) + lane, static_cast<uint32_t>(kStageSlots - 1))];
 #pragma unroll
     for (int j = 0; j < rows_per_wave; j++) {
-        const uint32_t cj = __builtin_amdgcn_readlane(c, j), sj = __builtin_amdgcn_readlane(s0, j),
-                       gj = __builtin_amdgcn_readlane(g, j), capj = __builtin_amdgcn_readlane(cap, j);
-        const uint32_t bl = __builtin_amdgcn_readlane(base_lo, j), bh = __builtin_amdgcn_readlane(base_hi, j);   // (the builtin returns int)
-        uint32_t *dst = o.buf + ((static_cast<uint64_t>(bh) << 32) | bl) + gj;
+        const uint32_t cj = __builtin_amdgcn_readlane(c, j), sj = __builtin_amdgcn_readlane(s0, j);
+        const uint32_t bl = __builtin_amdgcn_readlane(p_lo, j), bh = __builtin_amdgcn_readlane(p_hi, j);   // (the builtin returns int)
+        // (a pointer rebuilt from two scalars must be told that it points to global memory, or the stores become flat)
+        global_u32 *dst = reinterpret_cast<global_u32 *>((static_cast<uint64_t>(bh) << 32) | bl);
         const uint32_t k0 = k_next;
         if (j + 1 < rows_per_wave)
             k_next = st.slot[min(static_cast<uint32_t>(__builtin_amdgcn_readlane(s0, j + 1)) + lane, static_cast<uint32_t>(kStageSlots - 1))];
-        if (lane < cj) {
-            if (gj + lane < capj) dst[lane] = k0;
-            else count_key(k0, o.p1, o.p2, o.p3);              // region full: exact slow path
+#if PALACE_ABL & 2      // diagnostic build: no run stores
+        if (k0 == 0x12345u && cj == 77777u) dst[lane] = k0;
+        continue;
+#endif
+        if ((over_rows >> j) & 1ull) {                             // wave-uniform
+            const uint32_t capj = __builtin_amdgcn_readlane(cap, j), gj = __builtin_amdgcn_readlane(g, j);
+            const uint32_t room = capj - (gj < capj ? gj : capj);
+#pragma unroll 1
+            for (uint32_t q = 0; q < cj; q += 64) {
+                if (q + lane < cj) {
+                    const uint32_t k = st.slot[sj + q + lane];
+                    if (q + lane < room) dst[q + lane] = k;
+                    else count_key(k, o.p1, o.p2, o.p3);
+                }
+            }
+            continue;
         }
-        for (uint32_t p = 64 + lane; p < cj; p += 64) {        // the longest row is 135 slots: up to three passes
-            const uint32_t k = st.slot[sj + p];
-            if (gj + p < capj) dst[p] = k;
-            else count_key(k, o.p1, o.p2, o.p3);
-        }
+        if (lane < cj) dst[lane] = k0;
+#pragma unroll 1
+        for (uint32_t q = 64; q < cj; q += 64)                     // the longest row is 135 slots: up to three passes
+            if (q + lane < cj) dst[q + lane] = st.slot[sj + q + lane];
     }
 }
 
@@ -304,33 +298,8 @@ __device__ __forceinline__ void stage_init(Stage &st, bool by_density)
     }
 }
 
-__global__ __launch_bounds__(kBinThreads) void eref_bin1_kernel(const uint8_t *__restrict__ bases,
-                                                                const int64_t *__restrict__ offsets,
-                                                                int64_t n_reads,
-                                                                const uint8_t *__restrict__ keep,
-                                                                CoderMasks masks, int reads_per_tile, BinOut o)
-{
-    __shared__ Stage st;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int n_waves = kBinThreads / 64;
-    stage_init(st, true);
-    __syncthreads();
-    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * reads_per_tile;
-    const int64_t r1 = min(n_reads, r0 + reads_per_tile);
-    for (int64_t r = r0 + wave; r < r1; r += n_waves) {
-        if (keep && !keep[r]) continue;
-        const int64_t beg = offsets[r];
-        for_each_key(bases + beg, offsets[r + 1] - beg, lane, masks,
-                     [&](uint32_t k) { stage_append(st, k >> kL1Shift, k, o); });
-    }
-    const uint32_t replica = blockIdx.x % kL1Replicas;
-    flush_rows(st, o, [&](uint32_t row) {
-        return Dest{row * kL1Replicas + replica, l1_region_base(o.caps, row, replica), o.caps.cap(row)};
-    });
-}
-
 // Read ends as a bit per base position (bit p set <=> position p is the last base of a read), so
-// the flat kernel below needs no per-read offset lookups: a 32-mer starting at p is inside one read
+// the kernels below need no per-read offset lookups: a 32-mer starting at p is inside one read
 // iff no end bit lies in [p, p+30].
 __global__ void mark_read_ends_kernel(const int64_t *__restrict__ offsets, int64_t n_reads,
                                       unsigned long long *__restrict__ ends)
@@ -341,170 +310,365 @@ __global__ void mark_read_ends_kernel(const int64_t *__restrict__ offsets, int64
     if (b > a) atomicOr(&ends[(b - 1) >> 6], 1ull << ((b - 1) & 63));
 }
 
-// bin1 without per-read work: the concatenated bases are one stream; a wave walks consecutive
-// 64-position chunks (one coalesced byte load per chunk, no dependent loads), windows that would
-// cross a read end are masked with the end bits.  Used when no keep mask is given.
-// (Measured and dropped: several tiles per workgroup with the next tile's loads issued before the
-// current tile's appends -- 11 % slower than one tile per workgroup; the hardware's own overlap of
-// four resident workgroups per CU does better than the longer-lived, larger-register variant.)
-__global__ __launch_bounds__(kBinThreads) void eref_bin1_flat_kernel(const uint8_t *__restrict__ all_bases,
-                                                                     const int64_t *__restrict__ offsets, int64_t total,
-                                                                     int64_t chunk_lo, int64_t chunk_hi,
-                                                                     const unsigned long long *__restrict__ ends,
-                                                                     CoderMasks masks, int chunks_per_wave, BinOut o)
+// E3 keep mask as a bit per base position: every base of a read with keep[r] == 0 is marked dropped
+// (the stream kernel below then treats it as an invalid base, so none of its 32-mers is counted --
+// exactly the reads the reference skips at extract_ref.cpp:955-960).
+__global__ void mark_dropped_kernel(const int64_t *__restrict__ offsets, int64_t n_reads,
+                                    const uint8_t *__restrict__ keep, unsigned long long *__restrict__ dropped)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r >= n_reads || keep[r]) return;
+    const int64_t a = offsets[r] - offsets[0], b = offsets[r + 1] - offsets[0];      // [a, b)
+    for (int64_t w = a >> 6; w <= (b - 1) >> 6 && b > a; w++) {
+        const int64_t lo = max(a, w << 6), hi = min(b, (w + 1) << 6);            // bits [lo, hi) of word w
+        const unsigned long long m = ((hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1)) << (lo & 63);
+        atomicOr(&dropped[w], m);
+    }
+}
+
+// The read set as four packed bit streams, one bit per base position (u32 word w = positions 32w .. 32w+31): the three
+// projections P0, P1, P2 of every base and U, "a 32-mer may start here": its 32 bases are valid (and not dropped), it
+// does not run over a read end or over the end of the set.  One pass over the bases (16 B per lane), 0.5 B/base
+// written; everything downstream -- the partition kernel -- then gets a 32-mer's three projection windows with one
+// v_alignbit each instead of a byte load, a classification, four ballots and ten 64-bit shifts per position.
+//
+// Per dword of four ASCII bases the class bits are computed on all four bytes at once (bit k of a byte is brought to
+// bit 0 of that byte by x >> k; what the shift drags in from the next byte lands in bits 1..7 and is masked off):
+//   A 0x41, C 0x43, G 0x47, T 0x54 (bit 5 = case, ignored):  c = x >> 1:  {A,T} = !(c & 1), {A,C} = !(c & 2),
+//   {A,G} = !((c ^ c >> 1) & 1) as in classify();  valid = b6 & !b7 & !b3 & (b4 ? b2 & !b1 & !b0 : b0 & (b1 | !b2)).
+__device__ __forceinline__ uint32_t gather4(uint32_t y)        // bit 0 of bytes 0..3 -> bits 0..3
+{
+    y &= 0x01010101u;
+    y |= y >> 7;
+    return (y | (y >> 14)) & 15u;
+}
+
+__device__ __forceinline__ void class_bits4(uint32_t x, uint32_t &p0, uint32_t &p1, uint32_t &p2, uint32_t &ok)
+{
+    const uint32_t b0 = x, b1 = x >> 1, b2 = x >> 2, b3 = x >> 3, b4 = x >> 4, b6 = x >> 6, b7 = x >> 7;
+    p0 = gather4(~b1);
+    p1 = gather4(~b2);
+    p2 = gather4(~(b1 ^ b2));
+    const uint32_t t_like = b2 & ~b1 & ~b0, acg_like = b0 & (b1 | ~b2);
+    ok = gather4(b6 & ~b7 & ~b3 & ((b4 & t_like) | (~b4 & acg_like)));
+}
+
+__global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__restrict__ all_bases,
+                                                           const int64_t *__restrict__ offsets, int64_t total,
+                                                           uint16_t *__restrict__ s0, uint16_t *__restrict__ s1,
+                                                           uint16_t *__restrict__ s2, uint16_t *__restrict__ sok)
+{
+    const uint8_t *bases = all_bases + offsets[0];
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;      // 16 positions per lane
+    const int64_t p = i * 16;
+    if (p >= total) return;
+    uint32_t x[4];
+    if (p + 16 <= total && (reinterpret_cast<uintptr_t>(bases + p) & 15) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(bases + p);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else {                                               // unaligned read set or the last, partial group
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            x[d] = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (p + 4 * d + j < total) x[d] |= static_cast<uint32_t>(bases[p + 4 * d + j]) << (8 * j);
+        }
+    }
+    uint32_t o0 = 0, o1 = 0, o2 = 0, ok = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t a, b, c, v;
+        class_bits4(x[d], a, b, c, v);
+        o0 |= a << (4 * d); o1 |= b << (4 * d); o2 |= c << (4 * d); ok |= v << (4 * d);
+    }
+    s0[i] = static_cast<uint16_t>(o0); s1[i] = static_cast<uint16_t>(o1);
+    s2[i] = static_cast<uint16_t>(o2); sok[i] = static_cast<uint16_t>(ok);
+}
+
+// U from the validity stream, the read ends and the dropped reads: one lane per 64 positions.
+__global__ __launch_bounds__(256) void eref_usable_kernel(const unsigned long long *__restrict__ ok_words,
+                                                          const unsigned long long *__restrict__ ends,
+                                                          const unsigned long long *__restrict__ dropped,
+                                                          int64_t n_chunks, unsigned long long *__restrict__ su)
+{
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    // (the words behind the last chunk are zero: set by the caller)
+    unsigned long long a_lo = ok_words[c], a_hi = ok_words[c + 1];
+    if (dropped) { a_lo &= ~dropped[c]; a_hi &= ~dropped[c + 1]; }
+    // bit p of a_lo: positions p .. p+31 all valid (AND over a 32-bit window, log steps on the 128-bit pair)
+#pragma unroll
+    for (int s = 1; s < 32; s <<= 1) {
+        a_lo &= (a_lo >> s) | (a_hi << (64 - s));
+        a_hi &= a_hi >> s;
+    }
+    // bit p of e_lo: a read end in [p, p+30] (OR over a 31-bit window: 2, 4, 8, 16, then 16 + 15)
+    unsigned long long e_lo = ends[c], e_hi = ends[c + 1];
+#pragma unroll
+    for (int s = 1; s < 16; s <<= 1) {
+        e_lo |= (e_lo >> s) | (e_hi << (64 - s));
+        e_hi |= e_hi >> s;
+    }
+    e_lo |= (e_lo >> 15) | (e_hi << 49);
+    su[c] = a_lo & ~e_lo;
+}
+
+// bin1 over the bit streams: a lane owns P consecutive positions p .. p+P-1, loads three words of each projection
+// once, funnels them to the 64 bits that start at p (two v_alignbit) and then gets every window with one more
+// v_alignbit.  All row appends of the lane's positions are issued together before their results are used.
+template <int P>
+__global__ __launch_bounds__(kBinThreads) void eref_bin1_streams_kernel(const uint32_t *__restrict__ s0,
+                                                                        const uint32_t *__restrict__ s1,
+                                                                        const uint32_t *__restrict__ s2,
+                                                                        const uint32_t *__restrict__ su,
+                                                                        int64_t pos_lo, int64_t pos_hi,
+                                                                        CoderMasks masks, BinOut o)
 {
     __shared__ Stage st;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int n_waves = kBinThreads / 64;
+    const int64_t p = pos_lo + (static_cast<int64_t>(blockIdx.x) * kBinThreads + threadIdx.x) * P;
+    // every load of the lane is issued before the staging area is set up (the streams are padded: see the caller)
+    const int64_t g = min(p, pos_hi) >> 5;
+    const int sh = static_cast<int>(p & 31);
+    uint32_t w[3][3], uw[2];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { w[0][q] = s0[g + q]; w[1][q] = s1[g + q]; w[2][q] = s2[g + q]; }
+    uw[0] = su[g]; uw[1] = su[g + 1];
     stage_init(st, true);
     __syncthreads();
-    const uint8_t *bases = all_bases + offsets[0];      // the read set starts at its first offset
-    const int64_t n_chunks = (total + 63) >> 6;
-    const int64_t c0 = chunk_lo + (static_cast<int64_t>(blockIdx.x) * n_waves + wave) * chunks_per_wave;
-    const int64_t c1 = min(chunk_hi, c0 + chunks_per_wave);       // windows starting in [chunk_lo, chunk_hi) chunks
-    if (c0 < c1) {
-        // Every load of this wave's chunk range -- base bytes AND read-end words -- is issued before the
-        // first use (the loop used to pay two dependent memory round trips per 64 positions).
-        uint32_t ch[kFlatMaxChunks + 1];
-        unsigned long long en[kFlatMaxChunks + 1];
+    uint32_t u = __builtin_amdgcn_alignbit(uw[1], uw[0], sh) & ((1u << P) - 1);
+    if (p >= pos_hi) u = 0;
+    else if (p + P > pos_hi) u &= (1u << (pos_hi - p)) - 1;     // the slab's last lane
+    if (u) {
+        uint32_t lo[3], hi[3];
 #pragma unroll
-        for (int q = 0; q <= kFlatMaxChunks; q++) {
-            const int64_t c = c0 + q;
-            const int64_t idx = c * 64 + lane;
-            const bool in = c <= c1;
-            ch[q] = (in && idx < total) ? bases[idx] : 0u;
-            en[q] = (in && c < n_chunks) ? ends[c] : 0ull;
+        for (int q = 0; q < 3; q++) {
+            lo[q] = __builtin_amdgcn_alignbit(w[q][1], w[q][0], sh);
+            hi[q] = __builtin_amdgcn_alignbit(w[q][2], w[q][1], sh);
         }
-        BaseBits b0 = classify(ch[0]);
-        Streams lo{__ballot(b0.p0), __ballot(b0.p1), __ballot(b0.p2), __ballot(b0.ok)};
+        uint32_t key[P][3];
+        unsigned long long r[P][3];
 #pragma unroll
-        for (int q = 0; q < kFlatMaxChunks; q++) {
-            if (c0 + q >= c1) break;                             // wave-uniform
-            BaseBits bn = classify(ch[q + 1]);
-            Streams hi{__ballot(bn.p0), __ballot(bn.p1), __ballot(bn.p2), __ballot(bn.ok)};
-            const uint32_t ok = window32(lo.ok, hi.ok, lane);
-            const uint32_t cross = window32(en[q], en[q + 1], lane) & 0x7fffffffu;     // an end inside [p, p+30]
-            if (ok == 0xffffffffu && cross == 0u) {
-                uint32_t key[3];
-                kmer_keys(masks, window32(lo.p0, hi.p0, lane), window32(lo.p1, hi.p1, lane),
-                          window32(lo.p2, hi.p2, lane), key);
-                // the three row appends of a position are issued together before their results are used
-                unsigned long long r[3];
+        for (int t = 0; t < P; t++) {
+            kmer_keys(masks, __builtin_amdgcn_alignbit(hi[0], lo[0], t), __builtin_amdgcn_alignbit(hi[1], lo[1], t),
+                      __builtin_amdgcn_alignbit(hi[2], lo[2], t), key[t]);
+#if !(PALACE_ABL & 4)
+            if ((u >> t) & 1u) {
 #pragma unroll
-                for (int i = 0; i < 3; i++) r[i] = atomicAdd(&st.rows[key[i] >> kL1Shift], 1ull);
+                for (int i = 0; i < 3; i++) r[t][i] = atomicAdd(&st.rows[key[t][i] >> kL1Shift], 1ull);
+            }
+#endif
+        }
+#if PALACE_ABL & 4      // diagnostic build: keys computed, nothing appended
+        uint32_t acc = 0;
+#pragma unroll
+        for (int t = 0; t < P; t++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) acc ^= key[t][i];
+        if (acc == 0x9e3779b9u) st.slot[threadIdx.x] = acc;
+        u = 0;
+#endif
+#pragma unroll
+        for (int t = 0; t < P; t++) {
+            if ((u >> t) & 1u) {
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
-                    const uint32_t at = static_cast<uint32_t>(r[i]);
-                    if (at < static_cast<uint32_t>(r[i] >> 32)) st.slot[at] = key[i];
-                    else count_key(key[i], o.p1, o.p2, o.p3);
+                    const uint32_t at = static_cast<uint32_t>(r[t][i]);
+                    if (at < static_cast<uint32_t>(r[t][i] >> 32)) st.slot[at] = key[t][i];
+                    else count_key(key[t][i], o.p1, o.p2, o.p3);
                 }
             }
-            lo = hi;
         }
     }
     const uint32_t replica = blockIdx.x % kL1Replicas;
     flush_rows(st, o, [&](uint32_t row) {
-        return Dest{row * kL1Replicas + replica, l1_region_base(o.caps, row, replica), o.caps.cap(row)};
+        return Dest{l1_cursor(row, replica), l1_region_base(o.caps, row, replica), o.caps.cap(row)};
     });
 }
 
-// level 2: blockIdx.y = level-1 region (bucket b1, replica), blockIdx.x = tile of kTileKeys of its keys.  The grid
-// covers the largest region's capacity, so most workgroups of the sparser buckets leave at once; a device-built
-// list of the non-empty tiles (one extra single-workgroup kernel) was measured and cost more than it saved.
-__global__ __launch_bounds__(kBinThreads) void eref_bin2_kernel(const unsigned int *__restrict__ cursor1,
-                                                                const uint32_t *__restrict__ buf1, DensityCaps caps1,
-                                                                BinOut o)
+// level 2: blockIdx.y = level-1 region (bucket b1, replica), blockIdx.x = tile of kTile2Keys of its keys.  The 25 low
+// bits of a key split into a fine row (bits 24..16: 512 rows) and a 16-bit payload, and only the payload is staged and
+// written: below this level a key costs 2 bytes, not 4.  The grid covers the largest region's capacity, so most
+// workgroups of the sparser buckets leave at once (a device-built list of the non-empty tiles was measured and cost
+// more than it saved).
+constexpr int kFineBits = 16;                         // fine bucket = key >> 16: 65536 slices of 2^16 keys
+constexpr int kFine = 1 << kFineBits;
+constexpr int kL2Rows = kFine / kL1Buckets;           // 512 fine rows per level-1 bucket
+constexpr int kBin2Threads = 1024;                    // 16 waves; 78 KiB of LDS -> 2 workgroups per CU
+constexpr int kKeys2PerThread = 24;
+constexpr int kTile2Keys = kBin2Threads * kKeys2PerThread;   // 24576 keys: row mean 48 of 72 slots (+3.5 sigma)
+constexpr int kStage2Slots = kL2Rows * kRowSlots;
+
+struct Stage2 {
+    uint16_t slot[kStage2Slots];                      // 72 KiB
+    unsigned long long rows[kL2Rows];                 // (row end << 32) | next free slot
+};
+
+struct Bin2Out {
+    unsigned int *cursor;          // per fine bucket: keys reserved so far
+    uint16_t *buf;                 // fine-bucket regions (16-bit payloads)
+    DensityCaps caps;              // capacity of a fine region of level-1 bucket b1, in PAIRS of keys
+    uint32_t *p1, *p2, *p3;        // overflow path
+};
+
+// Fine-bucket regions: the 512 fine buckets of level-1 bucket b1 lie side by side, equal capacity; capacities are
+// counted in pairs of 16-bit keys, so regions start on 16-byte boundaries (caps are multiples of 4 pairs).
+__device__ __forceinline__ uint64_t fine_region_base(const DensityCaps &c, uint32_t b1, uint32_t sub)
 {
-    __shared__ Stage st;
+    return 2 * (c.prefix(b1) * kL2Rows + static_cast<uint64_t>(sub) * c.cap(b1));
+}
+__device__ __forceinline__ uint32_t fine_region_cap(const DensityCaps &c, uint32_t b1) { return 2 * c.cap(b1); }
+
+typedef uint16_t __attribute__((address_space(1))) global_u16;
+
+__global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned int *__restrict__ cursor1,
+                                                                 const uint32_t *__restrict__ buf1, DensityCaps caps1,
+                                                                 Bin2Out o)
+{
+    __shared__ Stage2 st;
     const uint32_t region = blockIdx.y, b1 = region / kL1Replicas, replica = region % kL1Replicas;
-    const uint32_t n1 = min(cursor1[region], caps1.cap(b1));
-    const uint32_t start = blockIdx.x * kTileKeys;
+    const uint32_t n1 = min(cursor1[l1_cursor(b1, replica)], caps1.cap(b1));
+    const uint32_t start = blockIdx.x * kTile2Keys;
     if (start >= n1) return;                               // uniform for the workgroup
-    const uint32_t end = min(n1, start + kTileKeys);
-    stage_init(st, false);
-    __syncthreads();
+    const uint32_t end = min(n1, start + kTile2Keys);
     // all of a thread's keys are loaded (16 bytes at a time: regions and tiles start on 16-byte boundaries and
-    // capacities are multiples of 4 keys, so a vector may run past n1 but not past the region) before the first
-    // append: the kernel is latency-bound with one load in flight per wave
+    // capacities are multiples of 4 keys, so a vector may run past n1 but not past the region) before the first append
     const uint4 *src = reinterpret_cast<const uint4 *>(buf1 + l1_region_base(caps1, b1, replica));
-    constexpr int kVecs = (kTileKeys + 4 * kBinThreads - 1) / (4 * kBinThreads);
+    constexpr int kVecs = kKeys2PerThread / 4;
     uint4 v[kVecs];
 #pragma unroll
     for (int it = 0; it < kVecs; it++) {
-        const uint32_t i = start + (it * kBinThreads + threadIdx.x) * 4;
+        const uint32_t i = start + (it * kBin2Threads + threadIdx.x) * 4;
         v[it] = i < end ? src[i >> 2] : uint4{0, 0, 0, 0};
     }
+    if (threadIdx.x < kL2Rows)
+        st.rows[threadIdx.x] = (static_cast<unsigned long long>((threadIdx.x + 1) * kRowSlots) << 32) | (threadIdx.x * kRowSlots);
+    __syncthreads();
+    const uint32_t hi_bits = b1 << kL1Shift;
 #pragma unroll
     for (int it = 0; it < kVecs; it++) {
-        const uint32_t i = start + (it * kBinThreads + threadIdx.x) * 4;
+        const uint32_t i = start + (it * kBin2Threads + threadIdx.x) * 4;
         const uint32_t k[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
         unsigned long long r[4];
 #pragma unroll
         for (int e = 0; e < 4; e++)
-            if (i + e < end) r[e] = atomicAdd(&st.rows[(k[e] >> kBucketShift) & (kL1Buckets - 1)], 1ull);
+            if (i + e < end) r[e] = atomicAdd(&st.rows[(k[e] >> kFineBits) & (kL2Rows - 1)], 1ull);
 #pragma unroll
         for (int e = 0; e < 4; e++)
             if (i + e < end) {
                 const uint32_t at = static_cast<uint32_t>(r[e]);
-                if (at < static_cast<uint32_t>(r[e] >> 32)) st.slot[at] = k[e];
-                else count_key(k[e], o.p1, o.p2, o.p3);
+                if (at < static_cast<uint32_t>(r[e] >> 32)) st.slot[at] = static_cast<uint16_t>(k[e]);
+                else count_key(hi_bits | (k[e] & ((1u << kL1Shift) - 1)), o.p1, o.p2, o.p3);   // row full: exact slow path
             }
     }
-    flush_rows(st, o, [&](uint32_t row) {
-        return Dest{b1 * kL1Buckets + row, fine_region_base(o.caps, b1, row), o.caps.cap(b1)};
-    });
+    __syncthreads();
+    // flush: a wave owns 32 rows; the first 32 lanes reserve the runs (one 128-byte piece of the cursor array) and work
+    // out the destination pointers, then the wave walks the rows with count / source / pointer in SGPRs
+    constexpr int rows_per_wave = kL2Rows / (kBin2Threads / 64);
+    const int lane = threadIdx.x & 63;
+    const int row0 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) * rows_per_wave;
+    const uint32_t cap = fine_region_cap(o.caps, b1);
+    uint32_t c = 0, g = 0, p_lo = 0, p_hi = 0;
+    bool over = false;
+    if (lane < rows_per_wave) {
+        const uint32_t row = row0 + lane;
+        const unsigned long long r = st.rows[row];
+        c = min(static_cast<uint32_t>(r), static_cast<uint32_t>(r >> 32)) - row * kRowSlots;
+        if (c) g = atomicAdd(&o.cursor[b1 * kL2Rows + row], c);
+        over = static_cast<uint64_t>(g) + c > cap;
+        const uint64_t ptr = reinterpret_cast<uint64_t>(o.buf + fine_region_base(o.caps, b1, row) + min(g, cap));
+        p_lo = static_cast<uint32_t>(ptr); p_hi = static_cast<uint32_t>(ptr >> 32);
+    }
+    const unsigned long long over_rows = __ballot(over);
+#pragma unroll 4
+    for (int j = 0; j < rows_per_wave; j++) {
+        const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+        const uint32_t bl = __builtin_amdgcn_readlane(p_lo, j), bh = __builtin_amdgcn_readlane(p_hi, j);
+        global_u16 *dst = reinterpret_cast<global_u16 *>((static_cast<uint64_t>(bh) << 32) | bl);
+        const uint16_t *row_slots = st.slot + (row0 + j) * kRowSlots;
+        if ((over_rows >> j) & 1ull) {                             // wave-uniform, rare: the run does not fit its region
+            const uint32_t gj = __builtin_amdgcn_readlane(g, j);
+            const uint32_t room = cap - (gj < cap ? gj : cap);
+            const uint32_t fine = b1 * kL2Rows + row0 + j;
+#pragma unroll 1
+            for (uint32_t q = 0; q < cj; q += 64) {
+                if (q + lane < cj) {
+                    const uint32_t k = row_slots[q + lane];
+                    if (q + lane < room) dst[q + lane] = static_cast<uint16_t>(k);
+                    else count_key((fine << kFineBits) | k, o.p1, o.p2, o.p3);
+                }
+            }
+            continue;
+        }
+        if (lane < cj) dst[lane] = row_slots[lane];
+        if (cj > 64 && lane + 64 < cj) dst[lane + 64] = row_slots[lane + 64];     // a row holds at most 72 slots
+    }
 }
 
-__global__ __launch_bounds__(1024) void eref_lds_count_kernel(const unsigned int *__restrict__ cursor,
-                                                              const uint32_t *__restrict__ binned,
-                                                              DensityCaps caps, uint32_t *__restrict__ p1,
-                                                              uint32_t *__restrict__ p2,
-                                                              uint32_t *__restrict__ p3)
+// one workgroup per fine bucket: its 2^16-key slice of the three planes (3 x 8 KiB) lives in LDS, is seeded from the
+// global planes, takes the bucket's 16-bit keys with LDS atomicOr climbing 1 -> 2 -> 3, and is written back
+constexpr int kFineWords = kFine / 32;               // 2048 u32 per plane per fine bucket
+constexpr int kCountThreads = 256;
+__global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const unsigned int *__restrict__ cursor,
+                                                                       const uint16_t *__restrict__ binned,
+                                                                       DensityCaps caps, uint32_t *__restrict__ p1,
+                                                                       uint32_t *__restrict__ p2,
+                                                                       uint32_t *__restrict__ p3)
 {
-    __shared__ uint32_t l1[kSliceWords], l2[kSliceWords], l3[kSliceWords];      // 3 x 32 KiB
-    const uint32_t b = blockIdx.x;
-    const uint32_t n = min(cursor[b], caps.cap(b >> 7));
+    __shared__ uint32_t l1[kFineWords], l2[kFineWords], l3[kFineWords];
+    const uint32_t b = blockIdx.x, b1 = b / kL2Rows;
+    const uint32_t n = min(cursor[b], fine_region_cap(caps, b1));
     if (n == 0) return;                                    // uniform for the whole workgroup
-    const size_t w0 = static_cast<size_t>(b) * kSliceWords;
+    const size_t w0 = static_cast<size_t>(b) * kFineWords;
     const uint4 *g1 = reinterpret_cast<const uint4 *>(p1 + w0), *g2 = reinterpret_cast<const uint4 *>(p2 + w0),
                 *g3 = reinterpret_cast<const uint4 *>(p3 + w0);
-    for (int i = threadIdx.x; i < kSliceWords / 4; i += blockDim.x) {
+    // keys eight at a time (regions start on 16-byte boundaries and capacities are multiples of 8 keys, so the last
+    // vector may run past n but not past the region); the first batch of key loads is issued together with the seeds
+    const uint4 *keys = reinterpret_cast<const uint4 *>(binned + fine_region_base(caps, b1, b % kL2Rows));
+    const uint32_t n8 = (n + 7) / 8;
+    constexpr int kBatch = 4;
+    uint4 v[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; u++) {
+        const uint32_t i = threadIdx.x + u * kCountThreads;
+        v[u] = i < n8 ? keys[i] : uint4{0, 0, 0, 0};
+    }
+    for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) {
         reinterpret_cast<uint4 *>(l1)[i] = g1[i];
         reinterpret_cast<uint4 *>(l2)[i] = g2[i];
         reinterpret_cast<uint4 *>(l3)[i] = g3[i];
     }
     __syncthreads();
-    // keys four at a time (regions start on 16-byte boundaries and capacities are multiples of 4 keys, so the last
-    // vector may run past n but not past the region), 4 vector loads in flight per thread
-    const uint4 *keys = reinterpret_cast<const uint4 *>(binned + fine_region_base(caps, b >> 7, b & 127));
-    const uint32_t n4 = (n + 3) / 4;
     auto apply = [&](uint32_t k) {
-        const uint32_t w = (k & ((1u << kBucketShift) - 1)) >> 5, bit = 1u << (k & 31);
+        const uint32_t w = k >> 5, bit = 1u << (k & 31);
         if (atomicOr(&l1[w], bit) & bit)
             if (atomicOr(&l2[w], bit) & bit) atomicOr(&l3[w], bit);
     };
-    constexpr int kBatch = 4;
-    for (uint32_t i0 = threadIdx.x; i0 < n4; i0 += kBatch * blockDim.x) {
-        uint4 v[kBatch];
+    for (uint32_t i0 = threadIdx.x; i0 < n8; i0 += kBatch * kCountThreads) {
+        uint4 nx[kBatch];
 #pragma unroll
-        for (int u = 0; u < kBatch; u++) {
-            const uint32_t i = i0 + u * blockDim.x;
-            v[u] = i < n4 ? keys[i] : uint4{0, 0, 0, 0};
+        for (int u = 0; u < kBatch; u++) {                 // the next batch is in flight while this one is applied
+            const uint32_t i = i0 + (kBatch + u) * kCountThreads;
+            nx[u] = i < n8 ? keys[i] : uint4{0, 0, 0, 0};
         }
 #pragma unroll
         for (int u = 0; u < kBatch; u++) {
-            const uint32_t i = i0 + u * blockDim.x;
-            if (i >= n4) break;
-            const uint32_t k[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            const uint32_t i = i0 + u * kCountThreads;
+            if (i >= n8) break;
+            const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (4 * i + e < n) apply(k[e]);
+            for (int e = 0; e < 4; e++) {
+                if (8 * i + 2 * e < n) apply(d[e] & 0xffffu);
+                if (8 * i + 2 * e + 1 < n) apply(d[e] >> 16);
+            }
         }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) v[u] = nx[u];
     }
     __syncthreads();
     uint4 *o1 = reinterpret_cast<uint4 *>(p1 + w0), *o2 = reinterpret_cast<uint4 *>(p2 + w0),
           *o3 = reinterpret_cast<uint4 *>(p3 + w0);
-    for (int i = threadIdx.x; i < kSliceWords / 4; i += blockDim.x) {
+    for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) {
         o1[i] = reinterpret_cast<const uint4 *>(l1)[i];
         o2[i] = reinterpret_cast<const uint4 *>(l2)[i];
         o3[i] = reinterpret_cast<const uint4 *>(l3)[i];
@@ -1193,12 +1357,11 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     const int64_t kSlabBases = ctx->slab_override > 0 ? ctx->slab_override : default_slab;   // multiple of 64
     const int64_t n_slabs = (total_bases + kSlabBases - 1) / kSlabBases;
     const int64_t slab_bases = std::min(total_bases, kSlabBases);
-    // capacities: the key upper bound of one slab shared out by the key density with 20 % head room, plus a
-    // flat pad of 1/8 of the mean and a constant (with a keep mask slabs are read ranges of equal count, so
-    // allow them to be 1.5 x the mean)
-    const int64_t max_keys = 3 * (d_keep && n_slabs > 1 ? slab_bases + slab_bases / 2 : slab_bases);
+    // capacities: the key upper bound of one slab (a position range) shared out by the key density with 20 % head
+    // room, plus a flat pad of 1/8 of the mean and a constant
+    const int64_t max_keys = 3 * slab_bases;
     constexpr int64_t kRegions = static_cast<int64_t>(kL1Buckets) * kL1Replicas;
-    const int64_t mean1 = max_keys / kRegions, mean2 = max_keys / kBuckets;
+    const int64_t mean1 = max_keys / kRegions, mean2 = max_keys / kFine / 2;    // mean2: in pairs of 16-bit keys
     DensityCaps caps1{static_cast<uint64_t>(mean1 + mean1 / 5) / 4, static_cast<uint32_t>(mean1 / 8 + 4096) / 4};   // per level-1 region
     DensityCaps caps2{static_cast<uint64_t>(mean2 + mean2 / 5) / 4, static_cast<uint32_t>(mean2 / 8 + 2048) / 4};   // per fine bucket
     if (ctx->bin_cap_override > 0) {                       // test hook: uniform, deliberately small regions
@@ -1207,61 +1370,72 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     }
     PALACE_REQUIRE(caps1.cap(0) < (1u << 31) && caps2.cap(0) < (1u << 31), "slab too large for 32-bit region cursors");
     const size_t cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
-    const size_t cur2_bytes = align_up(kBuckets * sizeof(unsigned int), 256);
+    const size_t cur2_bytes = align_up(kFine * sizeof(unsigned int), 256);
     const size_t buf1_bytes = align_up(static_cast<size_t>(caps1.prefix(kL1Buckets)) * kL1Replicas * 4, 256);
-    const size_t buf2_bytes = align_up(static_cast<size_t>(caps2.prefix(kL1Buckets)) * kL1Buckets * 4, 256);
+    const size_t buf2_bytes = align_up(static_cast<size_t>(caps2.prefix(kL1Buckets)) * kL2Rows * 4, 256);    // pairs of 2-byte keys
     const int64_t n_chunks = (total_bases + 63) / 64;
-    const size_t ends_bytes = align_up(static_cast<size_t>(n_chunks + 2) * 8, 256);
-    rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + ends_bytes + buf1_bytes + buf2_bytes);
+    const size_t words_bytes = align_up(static_cast<size_t>(n_chunks + 2) * 8, 256);       // one u64 per 64 positions (+ pad)
+    rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + 7 * words_bytes + buf1_bytes + buf2_bytes);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
     unsigned int *cursor1 = reinterpret_cast<unsigned int *>(ws); ws += cur1_bytes;
     unsigned int *cursor2 = reinterpret_cast<unsigned int *>(ws); ws += cur2_bytes;
-    unsigned long long *ends = reinterpret_cast<unsigned long long *>(ws); ws += ends_bytes;
+    unsigned long long *ends = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes;
+    unsigned long long *dropped = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes;
+    unsigned long long *strm[5];                           // P0, P1, P2, U, validity
+    for (int q = 0; q < 5; q++) { strm[q] = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes; }
     uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
-    uint32_t *buf2 = reinterpret_cast<uint32_t *>(ws);
+    uint16_t *buf2 = reinterpret_cast<uint16_t *>(ws);
     BinOut o1{cursor1, buf1, caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
-    BinOut o2{cursor2, buf2, caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
-    if (!d_keep) {                                   // read ends as a bit per position, once for the whole set
-        PALACE_HIP_TRY(hipMemsetAsync(ends, 0, static_cast<size_t>(n_chunks + 1) * 8, ctx->stream));
-        hipLaunchKernelGGL(mark_read_ends_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
-                           ctx->stream, d_offsets, n_reads, ends);
+    Bin2Out o2{cursor2, buf2, caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
+    // the read set as bit streams, once for the whole set: P0, P1, P2, validity; read ends (and dropped reads) -> U
+    PALACE_HIP_TRY(hipMemsetAsync(ends, 0, (d_keep ? 2 : 1) * words_bytes, ctx->stream));
+    hipLaunchKernelGGL(mark_read_ends_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
+                       ctx->stream, d_offsets, n_reads, ends);
+    if (d_keep)
+        hipLaunchKernelGGL(mark_dropped_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
+                           ctx->stream, d_offsets, n_reads, d_keep, dropped);
+    PALACE_HIP_TRY(hipGetLastError());
+    for (int q = 0; q < 5; q++)                           // the last word of each stream may be partly written, and the
+        PALACE_HIP_TRY(hipMemsetAsync(strm[q] + n_chunks - 1, 0, 24, ctx->stream));   // two pad words behind it are read
+    {
+        const int64_t lanes = (total_bases + 15) / 16, blocks = (lanes + 255) / 256;
+        PALACE_REQUIRE(blocks < (1ll << 31), "too many tiles for one launch");
+        hipLaunchKernelGGL(eref_streams_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d_bases,
+                           d_offsets, total_bases, reinterpret_cast<uint16_t *>(strm[0]), reinterpret_cast<uint16_t *>(strm[1]),
+                           reinterpret_cast<uint16_t *>(strm[2]), reinterpret_cast<uint16_t *>(strm[4]));
+        hipLaunchKernelGGL(eref_usable_kernel, dim3(static_cast<unsigned>((n_chunks + 255) / 256)), dim3(256), 0, ctx->stream,
+                           strm[4], ends, d_keep ? dropped : nullptr, n_chunks, strm[3]);
         PALACE_HIP_TRY(hipGetLastError());
     }
-    const int64_t keys_per_read = std::max<int64_t>(1, 3 * (total_bases / n_reads - 31));
-    constexpr int waves = kBinThreads / 64;
+    // positions per lane of the partition kernel: a tile of 512 lanes should hold about 6000 keys (the staging rows
+    // take 6144 at +3.5 sigma); a position yields 3 * (1 - 31 / read length) keys on average
+    const double keys_per_pos = 3.0 * std::max(0.02, 1.0 - 31.0 * static_cast<double>(n_reads) / std::max<double>(1.0, static_cast<double>(total_bases)));
+    const int ppl = keys_per_pos > 2.55 ? 4 : keys_per_pos > 2.1 ? 5 : keys_per_pos > 1.6 ? 6 : 8;
     for (int64_t slab = 0; slab < n_slabs; slab++) {
         PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes, ctx->stream));
-        if (d_keep) {
-            // per-read kernel over this slab's share of the reads; a tile holds about kTile1Keys keys
-            const int64_t r_lo = n_reads * slab / n_slabs, r_hi = n_reads * (slab + 1) / n_slabs;
-            int64_t rpt = std::max<int64_t>(1, kTile1Keys / keys_per_read);
-            if (rpt >= waves) rpt -= rpt % waves;
-            rpt = std::min<int64_t>(rpt, 1 << 20);
-            const int64_t tiles = (r_hi - r_lo + rpt - 1) / rpt;
-            PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
-            if (tiles > 0)
-                hipLaunchKernelGGL(eref_bin1_kernel, dim3(static_cast<unsigned>(tiles)), dim3(kBinThreads), 0,
-                                   ctx->stream, d_bases, d_offsets + r_lo, r_hi - r_lo, d_keep + r_lo, ctx->masks,
-                                   static_cast<int>(rpt), o1);
-        } else {
-            // flat stream: tiles of (waves x chunks_per_wave) 64-position chunks sized to about kTile1Keys keys
-            const int64_t c_lo = slab * (kSlabBases / 64), c_hi = std::min(n_chunks, (slab + 1) * (kSlabBases / 64));
-            const double keys_per_pos = std::max(0.05, static_cast<double>(keys_per_read) /
-                                                           std::max<double>(1.0, static_cast<double>(total_bases) / n_reads));
-            int cpw = static_cast<int>(static_cast<double>(kTile1Keys) / (keys_per_pos * 64.0 * waves));
-            cpw = std::max(1, std::min(cpw, kFlatMaxChunks));
-            const int64_t flat_tiles = (c_hi - c_lo + static_cast<int64_t>(waves) * cpw - 1) / (static_cast<int64_t>(waves) * cpw);
-            PALACE_REQUIRE(flat_tiles < (1ll << 31), "too many tiles for one launch");
-            hipLaunchKernelGGL(eref_bin1_flat_kernel, dim3(static_cast<unsigned>(flat_tiles)), dim3(kBinThreads),
-                               0, ctx->stream, d_bases, d_offsets, total_bases, c_lo, c_hi, ends, ctx->masks, cpw, o1);
+        const int64_t p_lo = slab * kSlabBases, p_hi = std::min(total_bases, (slab + 1) * kSlabBases);
+        const int64_t tile_pos = static_cast<int64_t>(kBinThreads) * ppl;
+        const int64_t tiles = (p_hi - p_lo + tile_pos - 1) / tile_pos;
+        PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
+        const uint32_t *w0 = reinterpret_cast<const uint32_t *>(strm[0]), *w1 = reinterpret_cast<const uint32_t *>(strm[1]),
+                       *w2 = reinterpret_cast<const uint32_t *>(strm[2]), *wu = reinterpret_cast<const uint32_t *>(strm[3]);
+        const dim3 grid(static_cast<unsigned>(tiles)), block(kBinThreads);
+        switch (ppl) {
+        case 4: hipLaunchKernelGGL(eref_bin1_streams_kernel<4>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
+        case 5: hipLaunchKernelGGL(eref_bin1_streams_kernel<5>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
+        case 6: hipLaunchKernelGGL(eref_bin1_streams_kernel<6>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
+        default: hipLaunchKernelGGL(eref_bin1_streams_kernel<8>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
         }
         PALACE_HIP_TRY(hipGetLastError());
-        const unsigned tiles2 = (caps1.cap(0) + kTileKeys - 1) / kTileKeys;          // bucket 0 has the largest regions
-        hipLaunchKernelGGL(eref_bin2_kernel, dim3(tiles2, static_cast<unsigned>(kRegions)), dim3(kBinThreads), 0, ctx->stream,
+#if PALACE_ABL          // diagnostic build: the partition output is garbage, only the first kernel is timed
+        continue;
+#endif
+        const unsigned tiles2 = (caps1.cap(0) + kTile2Keys - 1) / kTile2Keys;        // bucket 0 has the largest regions
+        hipLaunchKernelGGL(eref_bin2_kernel, dim3(tiles2, static_cast<unsigned>(kRegions)), dim3(kBin2Threads), 0, ctx->stream,
                            cursor1, buf1, caps1, o2);
         PALACE_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, cursor2, buf2, caps2,
+        hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, cursor2, buf2, caps2,
                            ctx->plane[0], ctx->plane[1], ctx->plane[2]);
         PALACE_HIP_TRY(hipGetLastError());
     }

@@ -1,6 +1,9 @@
 # usage (on the GPU box): bash tools/prof_full.sh <tag>   -> gpurun_out/<tag>.md (+ bench line gpurun_out/<tag>_bench.json)
+: "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
 tag=${1:-prof}
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_fetch gpurun_out/${tag}_write
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_stats.err || exit 1
 echo "stats pass done"
