@@ -82,12 +82,13 @@ int palace_eref_table_reset(palace_ctx *ctx);
 int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets,
                             int64_t n_reads, const uint8_t *d_keep, int64_t total_bases);
 
-/* Tuning / test hook for count_reads: mode 0 = automatic (binned LDS counting for large inputs,
- * direct global atomics for tiny ones), 1 = always direct, 2 = always binned; bucket_cap > 0
- * overrides the per-bucket capacity of the binned path (keys beyond it take the direct path);
- * mode 13 sets the slab size in bases
- * (bucket_cap = bases, multiple of 64; 0 = default 2^30) that large read sets are processed in. */
+/* Tuning knobs of count_reads (no reference counterpart; results are identical for every setting, which is what the
+ * tests use them for).  set_count_mode: mode 0 = automatic (partition + LDS counting for large inputs, direct global
+ * atomics for tiny ones), 1 = always direct, 2 = always partitioned; bucket_cap > 0 overrides the per-bucket capacity
+ * of the partitioned path (keys beyond it take the direct path).  set_option(name, value):
+ *   "slab_bases"  positions per slab that large read sets are processed in (multiple of 64; 0 = default 2^30 / 2^31) */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap);
+int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value);
 
 /* E5 + E6. For each ref: look the three indices of every position up in the table and run the
  * 500-base window scan (read_index + slide_window, extract_ref.cpp:813-903, 504-617).

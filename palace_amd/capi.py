@@ -76,6 +76,7 @@ _SIGS = {
     "palace_eref_table_reset": [C.c_void_p],
     "palace_eref_count_reads": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64],
     "palace_eref_set_count_mode": [C.c_void_p, C.c_int, C.c_int64],
+    "palace_eref_set_option": [C.c_void_p, C.c_char_p, C.c_int64],
     "palace_eref_scan_refs": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
                               C.c_void_p],
     "palace_eref_probe_index_build": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)],
@@ -235,6 +236,9 @@ class Ctx:
 
     def eref_set_count_mode(self, mode: int, bucket_cap: int = 0):
         _check(lib().palace_eref_set_count_mode(self.h, mode, bucket_cap), "palace_eref_set_count_mode")
+
+    def eref_set_option(self, name: str, value: int):
+        _check(lib().palace_eref_set_option(self.h, name.encode(), value), "palace_eref_set_option")
 
     def eref_scan_refs(self, d_bases: DevBuf, d_offsets: DevBuf, n_refs: int, total_bases: int,
                        one_min: int, three_min: int, d_rows: DevBuf):

@@ -353,37 +353,46 @@ __device__ __forceinline__ void class_bits4(uint32_t x, uint32_t &p0, uint32_t &
     ok = gather4(b6 & ~b7 & ~b3 & ((b4 & t_like) | (~b4 & acg_like)));
 }
 
+constexpr int kStreamGroups = 4;                       // 16-base groups per lane (their loads are in flight together)
 __global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__restrict__ all_bases,
                                                            const int64_t *__restrict__ offsets, int64_t total,
                                                            uint16_t *__restrict__ s0, uint16_t *__restrict__ s1,
                                                            uint16_t *__restrict__ s2, uint16_t *__restrict__ sok)
 {
     const uint8_t *bases = all_bases + offsets[0];
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;      // 16 positions per lane
-    const int64_t p = i * 16;
-    if (p >= total) return;
-    uint32_t x[4];
-    if (p + 16 <= total && (reinterpret_cast<uintptr_t>(bases + p) & 15) == 0) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(bases + p);
-        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-    } else {                                               // unaligned read set or the last, partial group
+    const bool aligned = (reinterpret_cast<uintptr_t>(bases) & 15) == 0;
+    uint32_t x[kStreamGroups][4];
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
-            x[d] = 0;
+    for (int k = 0; k < kStreamGroups; k++) {
+        const int64_t i = (static_cast<int64_t>(blockIdx.x) * kStreamGroups + k) * 256 + threadIdx.x;     // 16 positions
+        const int64_t p = i * 16;
+        if (p + 16 <= total && aligned) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(bases + p);
+            x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w;
+        } else {                                           // unaligned read set, the last partial group, or nothing
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (p + 4 * d + j < total) x[d] |= static_cast<uint32_t>(bases[p + 4 * d + j]) << (8 * j);
+            for (int d = 0; d < 4; d++) {
+                x[k][d] = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (p + 4 * d + j < total) x[k][d] |= static_cast<uint32_t>(bases[p + 4 * d + j]) << (8 * j);
+            }
         }
     }
-    uint32_t o0 = 0, o1 = 0, o2 = 0, ok = 0;
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
-        uint32_t a, b, c, v;
-        class_bits4(x[d], a, b, c, v);
-        o0 |= a << (4 * d); o1 |= b << (4 * d); o2 |= c << (4 * d); ok |= v << (4 * d);
+    for (int k = 0; k < kStreamGroups; k++) {
+        const int64_t i = (static_cast<int64_t>(blockIdx.x) * kStreamGroups + k) * 256 + threadIdx.x;
+        if (i * 16 >= total) break;
+        uint32_t o0 = 0, o1 = 0, o2 = 0, ok = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            uint32_t a, b, c, v;
+            class_bits4(x[k][d], a, b, c, v);
+            o0 |= a << (4 * d); o1 |= b << (4 * d); o2 |= c << (4 * d); ok |= v << (4 * d);
+        }
+        s0[i] = static_cast<uint16_t>(o0); s1[i] = static_cast<uint16_t>(o1);
+        s2[i] = static_cast<uint16_t>(o2); sok[i] = static_cast<uint16_t>(ok);
     }
-    s0[i] = static_cast<uint16_t>(o0); s1[i] = static_cast<uint16_t>(o1);
-    s2[i] = static_cast<uint16_t>(o2); sok[i] = static_cast<uint16_t>(ok);
 }
 
 // U from the validity stream, the read ends and the dropped reads: one lane per 64 positions.
@@ -1399,7 +1408,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     for (int q = 0; q < 5; q++)                           // the last word of each stream may be partly written, and the
         PALACE_HIP_TRY(hipMemsetAsync(strm[q] + n_chunks - 1, 0, 24, ctx->stream));   // two pad words behind it are read
     {
-        const int64_t lanes = (total_bases + 15) / 16, blocks = (lanes + 255) / 256;
+        const int64_t lanes = (total_bases + 15) / 16, blocks = (lanes + 256 * kStreamGroups - 1) / (256 * kStreamGroups);
         PALACE_REQUIRE(blocks < (1ll << 31), "too many tiles for one launch");
         hipLaunchKernelGGL(eref_streams_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d_bases,
                            d_offsets, total_bases, reinterpret_cast<uint16_t *>(strm[0]), reinterpret_cast<uint16_t *>(strm[1]),
@@ -1420,6 +1429,9 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
         const uint32_t *w0 = reinterpret_cast<const uint32_t *>(strm[0]), *w1 = reinterpret_cast<const uint32_t *>(strm[1]),
                        *w2 = reinterpret_cast<const uint32_t *>(strm[2]), *wu = reinterpret_cast<const uint32_t *>(strm[3]);
+        // one tile per workgroup.  (Measured and dropped, twice: persistent workgroups that walk several tiles with the
+        // next tile's loads in flight -- 25-40 % slower; the workgroups of a CU then run their append / reserve / copy
+        // phases in step, while freshly dispatched ones interleave them.)
         const dim3 grid(static_cast<unsigned>(tiles)), block(kBinThreads);
         switch (ppl) {
         case 4: hipLaunchKernelGGL(eref_bin1_streams_kernel<4>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
@@ -1442,18 +1454,25 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     return PALACE_OK;
 }
 
-/* Test / tuning hook: 0 = automatic, 1 = always direct global atomics, 2 = always binned;
- * bucket_cap > 0 overrides the per-bucket capacity (to exercise the overflow path). */
+/* Tuning knobs of count_reads (see include/palace_hip.h). */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap)
 {
-    if (ctx && mode == 13) {                      // test hook: slab size in bases (0 = default 2^30), multiple of 64
-        PALACE_REQUIRE(bucket_cap >= 0 && bucket_cap % 64 == 0, "slab size must be a multiple of 64");
-        ctx->slab_override = bucket_cap;
-        return PALACE_OK;
-    }
     PALACE_REQUIRE(ctx && mode >= 0 && mode <= 2 && bucket_cap >= 0 && bucket_cap < (1ll << 31), "bad argument");
     ctx->count_mode = mode;
     ctx->bin_cap_override = bucket_cap;
+    return PALACE_OK;
+}
+
+int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value)
+{
+    PALACE_REQUIRE(ctx && name, "null argument");
+    if (!std::strcmp(name, "slab_bases")) {
+        PALACE_REQUIRE(value >= 0 && value % 64 == 0, "slab size must be a non-negative multiple of 64");
+        ctx->slab_override = value;
+    } else {
+        set_error("palace_eref_set_option: unknown option '%s'", name);
+        return PALACE_EINVAL;
+    }
     return PALACE_OK;
 }
 

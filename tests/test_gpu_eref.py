@@ -398,10 +398,10 @@ def test_binned_slabs(ctx, with_keep):
     keep = (rng.random(rs.n) < 0.7).astype(np.uint8) if with_keep else None
     try:
         ctx.eref_set_count_mode(2, 0)
-        ctx.eref_set_count_mode(13, 64 * 1024)                                 # 64 Ki-base slabs -> 10 slabs
+        ctx.eref_set_option("slab_bases", 64 * 1024)                                # 64 Ki-base slabs -> 10 slabs
         count_on_gpu(ctx, [(rs.bases, rs.offsets)], hdr, keep=[keep] if with_keep else None)
     finally:
-        ctx.eref_set_count_mode(13, 0)
+        ctx.eref_set_option("slab_bases", 0)
         ctx.eref_set_count_mode(0, 0)
     kept = synth.reads_from_list([rs.read(i) for i in range(rs.n) if keep is None or keep[i]])
     u, c = oracle_key_counts(kept.bases, kept.offsets, cc)
