@@ -89,16 +89,21 @@ int palace_ctx_create_prio(int device, int high_priority, palace_ctx **out)
     PALACE_HIP_TRY(hipSetDevice(device));
     palace_ctx *ctx = new palace_ctx();
     ctx->device = device;
+    auto fail = [&](const char *what, hipError_t err) {      // nothing half-built is left behind
+        set_error("%s failed: %s", what, hipGetErrorString(err));
+        palace_ctx_destroy(ctx);
+        return PALACE_EHIP;
+    };
     if (high_priority) {
         int least = 0, greatest = 0;                       // numerically lower = more urgent
-        PALACE_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        PALACE_HIP_TRY(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest));
+        if ((e = hipDeviceGetStreamPriorityRange(&least, &greatest)) != hipSuccess) return fail("hipDeviceGetStreamPriorityRange", e);
+        if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest)) != hipSuccess) return fail("hipStreamCreateWithPriority", e);
     } else {
-        PALACE_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreateWithFlags", e);
     }
-    PALACE_HIP_TRY(hipEventCreate(&ctx->ev0));
-    PALACE_HIP_TRY(hipEventCreate(&ctx->ev1));
-    PALACE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_small), 64 * sizeof(uint64_t)));
+    if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_small), 64 * sizeof(uint64_t))) != hipSuccess) return fail("hipMalloc", e);
     *out = ctx;
     return PALACE_OK;
 }
@@ -107,7 +112,7 @@ int palace_ctx_destroy(palace_ctx *ctx)
 {
     if (!ctx) return PALACE_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int p = 0; p < 3; p++)
         if (ctx->plane[p] && !ctx->planes_external) (void)hipFree(ctx->plane[p]);
     if (ctx->ws.ptr) (void)hipFree(ctx->ws.ptr);
@@ -116,9 +121,9 @@ int palace_ctx_destroy(palace_ctx *ctx)
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     for (hipEvent_t e : ctx->marks)
         if (e) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(ctx->ev0);
-    (void)hipEventDestroy(ctx->ev1);
-    (void)hipStreamDestroy(ctx->stream);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PALACE_OK;
 }

@@ -658,11 +658,11 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
 }
 
 int64_t palace_match_result_count(const palace_match_result *r) { return r ? r->n : 0; }
-const int64_t *palace_match_result_offsets(const palace_match_result *r) { return r->off; }
-const int32_t *palace_match_result_verts(const palace_match_result *r) { return r->verts; }
-const uint8_t *palace_match_result_kind(const palace_match_result *r) { return r->kind; }
-const int32_t *palace_match_result_iter(const palace_match_result *r) { return r->iter; }
-const int32_t *palace_match_result_open_at(const palace_match_result *r) { return r->open_at; }
+const int64_t *palace_match_result_offsets(const palace_match_result *r) { return r ? r->off : nullptr; }
+const int32_t *palace_match_result_verts(const palace_match_result *r) { return r ? r->verts : nullptr; }
+const uint8_t *palace_match_result_kind(const palace_match_result *r) { return r ? r->kind : nullptr; }
+const int32_t *palace_match_result_iter(const palace_match_result *r) { return r ? r->iter : nullptr; }
+const int32_t *palace_match_result_open_at(const palace_match_result *r) { return r ? r->open_at : nullptr; }
 void palace_match_result_free(palace_match_result *r) { delete r; }
 
 }  // extern "C"

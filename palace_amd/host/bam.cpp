@@ -1,8 +1,13 @@
 #include "bam.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
@@ -17,16 +22,29 @@ namespace {
 uint32_t le32(const uint8_t *p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
 uint16_t le16(const uint8_t *p) { uint16_t v; std::memcpy(&v, p, 2); return v; }
 
-std::vector<uint8_t> slurp(const std::string &path)
-{
-    std::ifstream f(path, std::ios::binary | std::ios::ate);
-    if (!f) throw std::runtime_error("Failed to open BAM " + path);
-    std::streamsize n = f.tellg();
-    f.seekg(0);
-    std::vector<uint8_t> buf(static_cast<size_t>(n));
-    if (n && !f.read(reinterpret_cast<char *>(buf.data()), n)) throw std::runtime_error("Failed to read BAM " + path);
-    return buf;
-}
+// The compressed file, mapped read-only (no copy of it is made).
+struct MappedFile {
+    const uint8_t *data = nullptr;
+    size_t size = 0;
+    explicit MappedFile(const std::string &path)
+    {
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("Failed to open BAM " + path);
+        struct stat st;
+        if (::fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("Failed to open BAM " + path); }
+        size = static_cast<size_t>(st.st_size);
+        if (size) {
+            void *m = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); throw std::runtime_error("Failed to read BAM " + path); }
+            ::madvise(m, size, MADV_SEQUENTIAL);
+            data = static_cast<const uint8_t *>(m);
+        }
+        ::close(fd);
+    }
+    ~MappedFile() { if (data) ::munmap(const_cast<uint8_t *>(data), size); }
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+};
 
 template <class F>
 void parallel_for(size_t n, int threads, F f)
@@ -41,43 +59,50 @@ void parallel_for(size_t n, int threads, F f)
     for (auto &th : pool) th.join();
 }
 
-// BGZF: gzip members with a BC extra subfield carrying the member size (SAM spec 4.1).
-void inflate_bgzf(const std::vector<uint8_t> &file, int threads, std::vector<uint8_t> &out)
+// BGZF: gzip members with a BC extra subfield carrying the member size (SAM spec 4.1).  Every field that comes from the
+// file is checked against the file before it is used: a member is 12 + XLEN header bytes, the deflate stream and an
+// 8-byte trailer, BSIZE + 1 bytes in all, and holds at most 64 KiB of data.
+void inflate_bgzf(const uint8_t *file, size_t file_size, int threads, std::vector<uint8_t> &out)
 {
     struct Block { size_t in_off, in_len, out_off, out_len; };
     std::vector<Block> blocks;
     size_t p = 0, total = 0;
-    while (p + 18 <= file.size()) {
-        const uint8_t *h = file.data() + p;
+    while (p + 18 <= file_size) {
+        const uint8_t *h = file + p;
         if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) throw std::runtime_error("Failed to read BAM header");
-        size_t xlen = le16(h + 10), q = 12, bsize = 0;
+        const size_t xlen = le16(h + 10), left = file_size - p;
+        if (12 + xlen + 8 > left) throw std::runtime_error("truncated BGZF block");
+        size_t q = 12, bsize = 0;
         while (q + 4 <= 12 + xlen) {
-            size_t slen = le16(h + q + 2);
+            const size_t slen = le16(h + q + 2);
+            if (q + 4 + slen > 12 + xlen) throw std::runtime_error("malformed BGZF extra field");
             if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2) bsize = static_cast<size_t>(le16(h + q + 4)) + 1;
             q += 4 + slen;
         }
-        if (!bsize || p + bsize > file.size()) throw std::runtime_error("truncated BGZF block");
-        size_t isize = le32(h + bsize - 4);
+        if (bsize < 12 + xlen + 8 || bsize > left) throw std::runtime_error("truncated BGZF block");
+        const size_t isize = le32(h + bsize - 4);
+        if (isize > 65536) throw std::runtime_error("malformed BGZF block (ISIZE > 64 KiB)");
         blocks.push_back({p + 12 + xlen, bsize - xlen - 20, total, isize});
         total += isize;
         p += bsize;
     }
     out.resize(total);
-    bool bad = false;
+    std::atomic<bool> bad{false};
     parallel_for(blocks.size(), threads, [&](size_t a, size_t b, int) {
-        for (size_t i = a; i < b; i++) {
+        z_stream zs{};
+        if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
+        for (size_t i = a; i < b && !bad; i++) {
             const Block &k = blocks[i];
             if (!k.out_len) continue;
-            z_stream zs{};
-            if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
-            zs.next_in = const_cast<Bytef *>(file.data() + k.in_off);
+            if (inflateReset(&zs) != Z_OK) { bad = true; break; }
+            zs.next_in = const_cast<Bytef *>(file + k.in_off);
             zs.avail_in = static_cast<uInt>(k.in_len);
             zs.next_out = out.data() + k.out_off;
             zs.avail_out = static_cast<uInt>(k.out_len);
-            int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = true; return; }
+            const int rc = inflate(&zs, Z_FINISH);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = true; break; }
         }
+        inflateEnd(&zs);
     });
     if (bad) throw std::runtime_error("BGZF inflate failed");
 }
@@ -161,10 +186,16 @@ size_t aux_size(uint8_t type, const uint8_t *p, const uint8_t *end)
     case 's': case 'S': return 2;
     case 'i': case 'I': case 'f': return 4;
     case 'Z': case 'H': { const void *z = std::memchr(p, 0, static_cast<size_t>(end - p)); return z ? static_cast<const uint8_t *>(z) - p + 1 : 0; }
-    case 'B': {
+    case 'B': {                                            // subtype, int32 count, count elements
         if (end - p < 5) return 0;
-        size_t es = (p[0] == 'c' || p[0] == 'C') ? 1 : (p[0] == 's' || p[0] == 'S') ? 2 : 4;
-        return 5 + es * le32(p + 1);
+        size_t es;
+        switch (p[0]) {
+        case 'c': case 'C': es = 1; break;
+        case 's': case 'S': es = 2; break;
+        case 'i': case 'I': case 'f': es = 4; break;
+        default: return 0;
+        }
+        return 5 + es * static_cast<size_t>(le32(p + 1));
     }
     default: return 0;
     }
@@ -189,8 +220,8 @@ void rekey(BamColumns &c, uint64_t seed)
 void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumns &c)
 {
     {
-        std::vector<uint8_t> file = slurp(path);
-        inflate_bgzf(file, threads, c.raw);
+        MappedFile file(path);
+        inflate_bgzf(file.data, file.size, threads, c.raw);
     }
     const uint8_t *d = c.raw.data();
     const size_t N = c.raw.size();
@@ -211,8 +242,13 @@ void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumn
     }
     std::vector<uint64_t> rec_at;
     while (p + 4 <= N) {
-        uint32_t bs = le32(d + p);
-        if (bs < 32 || p + 4 + bs > N) break;                   // truncated tail: stop like a failed sam_read1
+        const size_t bs = le32(d + p);
+        if (bs < 32 || bs > N - p - 4) break;                   // truncated tail: stop like a failed sam_read1
+        // the variable-length fields must fit the record (htslib's bam_read1 fails on such a record, which ends the
+        // reference's `while (sam_read1(...) >= 0)` loop at generate_graph.cpp:644): name, CIGAR, packed bases, qualities
+        const uint8_t *r = d + p + 4;
+        const size_t l_name = r[8], n_cig = le16(r + 12), l_seq = le32(r + 16);
+        if (l_name < 1 || l_seq > 0x7fffffffu || 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs) break;
         rec_at.push_back(p + 4);
         p += 4 + bs;
     }
@@ -247,10 +283,30 @@ void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumn
             c.qname_len[i] = static_cast<uint8_t>(nlen);
             c.qkey[i] = name_key(reinterpret_cast<const char *>(name), nlen, key_seed);
             const uint8_t *cg = name + l_name;
+            const uint8_t *x0 = cg + 4 * n_cig + (l_seq + 1) / 2 + l_seq;      // first aux field
+            // A CIGAR of more than 65535 ops is stored in a CG:B,I tag behind a placeholder (SAM spec 4.2.2); htslib
+            // puts it back in place inside bam_read1 (bam_tag2cigar), so that is what the reference sees.
+            const uint8_t *ops = cg;
+            size_t n_ops = n_cig;
+            if (n_cig > 0 && tid >= 0 && static_cast<int32_t>(le32(r + 4)) >= 0 && (le32(cg) & 15) == 4 && (le32(cg) >> 4) == l_seq) {
+                for (const uint8_t *x = x0; x + 3 <= end;) {
+                    const uint8_t *v = x + 3;
+                    const size_t sz = aux_size(x[2], v, end);
+                    if (!sz || sz > static_cast<size_t>(end - v)) break;
+                    if (x[0] == 'C' && x[1] == 'G') {              // first CG tag decides (bam_aux_get)
+                        if (x[2] == 'B' && (v[0] == 'I' || v[0] == 'i') && le32(v + 1) >= n_cig && le32(v + 1) < (1u << 29)) {
+                            ops = v + 5;
+                            n_ops = le32(v + 1);
+                        }
+                        break;
+                    }
+                    x = v + sz;
+                }
+            }
             int32_t rl = 0, ql = 0;
             OpScan sc;
-            for (size_t k = 0; k < n_cig; k++) {
-                uint32_t v = le32(cg + 4 * k);
+            for (size_t k = 0; k < n_ops; k++) {
+                uint32_t v = le32(ops + 4 * k);
                 int op = v & 15, len = static_cast<int>(v >> 4);
                 if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += len;   // bam_cigar2rlen
                 if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) ql += len;   // getReadLength (:385-397)
@@ -259,16 +315,16 @@ void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumn
             ClipInfo ci = sc.done();
             c.ref_len[i] = rl;
             c.read_len[i] = ql;
-            c.clip_s[i] = n_cig ? ci.clip_s : -1;
+            c.clip_s[i] = n_ops ? ci.clip_s : -1;
             c.clip_e[i] = ci.clip_e;
             // aux: first NM (integer types only, like bam_aux2i) and first SA (Z)
-            const uint8_t *x = cg + 4 * n_cig + (l_seq + 1) / 2 + l_seq;
+            const uint8_t *x = x0;
             bool have_nm = false, have_sa = false;
             while (x + 3 <= end && !(have_nm && have_sa)) {
                 uint8_t ty = x[2];
                 const uint8_t *v = x + 3;
                 size_t sz = aux_size(ty, v, end);
-                if (!sz || v + sz > end) break;
+                if (!sz || sz > static_cast<size_t>(end - v)) break;
                 if (!have_nm && x[0] == 'N' && x[1] == 'M') {
                     have_nm = true;
                     int64_t val = 0;
