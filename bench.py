@@ -2,8 +2,10 @@
 """Headline bench: contigs/s over eref + generateGraph + matching on the 1M-contig synthetic
 (BASELINE.json `metric`), inputs resident in HBM, one process per GPU.
 
-  python bench.py [--gpus N --steps K --warmup W] [--contigs 1000000]
+  python bench.py [--gpus N --steps K --warmup W] [--contigs 1000000] [--workload default|long]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(`python bench.py --gpus N` without a launcher starts its N ranks itself, as child processes, before this process
+touches a GPU, relays rank 0's JSON line and exits with their status.)
 
 One "step" = one full pass of the hot path over the whole synthetic sample:
   eref:   zero the count table, count every read of both FASTQ sides, scan every phage ref
@@ -34,20 +36,37 @@ READ_LEN = 150
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--contigs", type=int, default=1_000_000)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=("default", "long"), default="default",
+                    help="default: BASELINE configs[1..3] shape (log-normal contigs, median 800 bp); long: configs[4] "
+                         "(100k contigs, N50 ~ 50 kb, tail > 120 kb, evidence that reaches the exp-underflow gate)")
+    ap.add_argument("--contigs", type=int, default=None)
     ap.add_argument("--refs", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-reads", type=int, default=40000)
-    ap.add_argument("--cpu-sample-records", type=int, default=300000)
-    return ap.parse_args()
+    ap.add_argument("--no-e2e", action="store_true", help="skip the files -> files leg (CLI chain on generated files)")
+    ap.add_argument("--soak-seconds", type=float, default=2.0,
+                    help="after the K timed steps keep stepping (untimed for `value`) until this much wall time has passed")
+    ap.add_argument("--cpu-sample-frac", type=float, default=0.10, help="share of reads / records the CPU baseline is timed on")
+    a = ap.parse_args()
+    if a.contigs is None:
+        a.contigs = 100_000 if a.workload == "long" else 1_000_000
+    return a
 
 
 # ----------------------------------------------------------------------------------------------
 # synthetic sample, generated on the device (SURVEY.md section 8(d) shapes)
 # ----------------------------------------------------------------------------------------------
-def make_sample(torch, dev, n_contigs, n_refs, rank=0, world=1):
+def contig_lengths(n_contigs, long_mode):
+    """log-normal contig lengths: median 800 (sigma 1, min 56), or the long-contig set: median 30 kb, sigma 0.9
+    (N50 ~ 50 kb, 7 % of the contigs above 110 kb, where exp(-d/150) underflows: generate_graph.cpp:255-260)."""
+    rng = np.random.Generator(np.random.PCG64(SEED + 7))
+    if long_mode:
+        return np.maximum(56, rng.lognormal(np.log(30000.0), 0.9, size=n_contigs)).astype(np.int64)
+    return np.maximum(56, rng.lognormal(np.log(800.0), 1.0, size=n_contigs)).astype(np.int64)
+
+
+def make_sample(torch, dev, n_contigs, n_refs, rank=0, world=1, long_mode=False):
     g = torch.Generator(device=dev)
     g.manual_seed(SEED)
     rng = np.random.Generator(np.random.PCG64(SEED))
@@ -63,14 +82,14 @@ def make_sample(torch, dev, n_contigs, n_refs, rank=0, world=1):
             out[s:s + m] = lut[torch.randint(0, 4, (m,), generator=g, device=dev)]
         return out
 
-    scale = n_contigs / 1_000_000
+    scale = 1.0 if long_mode else n_contigs / 1_000_000     # the long-contig set keeps the read volume of the 1M config
     # phage DB: n_refs refs, length U[20 kb, 60 kb]
     ref_lens = rng.integers(20000, 60001, size=n_refs).astype(np.int64)
     ref_off = np.zeros(n_refs + 1, dtype=np.int64)
     np.cumsum(ref_lens, out=ref_off[1:])
     ref_bases = dna(int(ref_off[-1]))
     # contigs: log-normal lengths (median 800, sigma 1, min 56); the read pool
-    c_lens = np.maximum(56, rng.lognormal(np.log(800.0), 1.0, size=n_contigs)).astype(np.int64)
+    c_lens = contig_lengths(n_contigs, long_mode)
     c_off = np.zeros(n_contigs + 1, dtype=np.int64)
     np.cumsum(c_lens, out=c_off[1:])
     pool = dna(int(c_off[-1]))
@@ -124,11 +143,11 @@ def make_sample(torch, dev, n_contigs, n_refs, rank=0, world=1):
 # ----------------------------------------------------------------------------------------------
 # BAM-side sample: one primary record per read, coordinate sorted, as decoded columns in HBM
 # ----------------------------------------------------------------------------------------------
-def make_graph_sample(torch, dev, n_contigs, n_pairs, rank=0, world=1):
+def make_graph_sample(torch, dev, n_contigs, n_pairs, rank=0, world=1, long_mode=False):
     g = torch.Generator(device=dev)
     g.manual_seed(SEED + 1)
     rng = np.random.Generator(np.random.PCG64(SEED + 1))
-    c_lens = np.maximum(56, np.random.Generator(np.random.PCG64(SEED)).lognormal(np.log(800.0), 1.0, size=n_contigs)).astype(np.int64)
+    c_lens = contig_lengths(n_contigs, long_mode)
     ids = rng.permutation(np.arange(1, 4 * n_contigs + 1))[:n_contigs]
     covs = rng.gamma(2.0, 8.0, size=n_contigs)
     names = [f"EDGE_{i}_length_{l}_cov_{c:.6f}" for i, l, c in zip(ids.tolist(), c_lens.tolist(), covs.tolist())]
@@ -180,6 +199,13 @@ def make_graph_sample(torch, dev, n_contigs, n_pairs, rank=0, world=1):
     ta[cross] = xa; tb[cross] = link_t[xa]
     p1[cross] = end_pos(lens_t[xa], nx); p2[cross] = start_pos(lens_t[link_t[xa]], nx)
     rev1[cross] = False; rev2[cross] = True
+    if long_mode:
+        # half of the cross pairs as (a-, b+): read 1 reverse at a's START, mate reverse at b's START.  The '-' side measures
+        # its distance to the far end of a (nearEndDistances, generate_graph.cpp:310-318), so on contigs above ~110 kb the
+        # score underflows to 0 and the evidence is rejected -- the G5 gate this configuration is about.
+        flip = cross & (torch.rand(n_pairs, generator=g, device=dev) < 0.5)
+        p1[flip] = start_pos(lens_t[ta[flip]], int(flip.sum().item()))
+        rev1[flip] = True
     sa_a = hot_s[torch.randint(0, len(hot_s), (ns,), generator=g, device=dev)]
     ta[split] = sa_a; tb[split] = sa_a
     p1[split] = end_pos(lens_t[sa_a], ns); p2[split] = torch.clamp(p1[split] - 250, min=0)
@@ -229,7 +255,7 @@ def make_graph_sample(torch, dev, n_contigs, n_pairs, rank=0, world=1):
     sa[:n_sa, 0] = sa_tid[hs].to(i32); sa[:n_sa, 1] = sa_pos[hs].to(i32); sa[:n_sa, 2] = sa_mq[hs].to(i32)
     sa[:n_sa, 3] = sa_nm[hs]; sa[:n_sa, 4] = 90; sa[:n_sa, 5] = 0; sa[:n_sa, 6] = 150; sa[:n_sa, 7] = 0
     total_ref = float(col["ref_len"].sum().item()) if world == 1 else None
-    return dict(col=col, sa_off=sa_off, sa=sa, n_sa=n_sa, n=hi - lo, ord_base=lo, n_total=n_rec,
+    return dict(col=col, sa_off=sa_off, sa=sa, n_sa=n_sa, n=hi - lo, ord_base=lo, n_total=n_rec, fastg_links=(a, b, o1, o2),
                 tlen=T(c_lens, i32), trank=T(trank), fastg=T(fastg.view(np.int64)), n_fastg=len(fastg),
                 names=names, lens=c_lens, link=link, avg_depth=None if total_ref is None else float(f"{total_ref / c_lens.sum():.6g}"))
 
@@ -240,6 +266,157 @@ def graph_to_arcs(cn, n_segs, edges, min_count=5):
     from palace_amd import capi
     assert len(cn) == n_segs
     return capi.match_arcs_from_edges(cn, edges, min_count, reuse=True)
+
+
+# ----------------------------------------------------------------------------------------------
+# files -> files: the same sample as the FILES the pipeline hands to the three executables, and the CLI chain on them
+# ----------------------------------------------------------------------------------------------
+def fastq_to_file(torch, reads, n, tag, path):
+    """4-line FASTQ, fixed-width names @r0000000/<tag> (extract_ref.cpp:940-1004 reads line 1 of every 4), built on the
+    device as an [n, record] byte matrix."""
+    dev = reads.device
+    digits = 8
+    w = 2 + digits + 3 + READ_LEN + 3 + READ_LEN + 1                    # "@r" d "/t\n" seq "\n+\n" qual "\n"
+    step = 1 << 20
+    with open(path, "wb") as f:
+        for lo in range(0, n, step):
+            m = min(step, n - lo)
+            rec = torch.empty((m, w), dtype=torch.uint8, device=dev)
+            idx = torch.arange(lo, lo + m, device=dev)
+            rec[:, 0] = 64; rec[:, 1] = 114
+            for k in range(digits):
+                rec[:, 2 + k] = ((idx // 10 ** (digits - 1 - k)) % 10 + 48).to(torch.uint8)
+            o = 2 + digits
+            rec[:, o] = 47; rec[:, o + 1] = ord(tag); rec[:, o + 2] = 10
+            o += 3
+            rec[:, o:o + READ_LEN] = reads[lo * READ_LEN:(lo + m) * READ_LEN].view(m, READ_LEN)
+            o += READ_LEN
+            rec[:, o] = 10; rec[:, o + 1] = 43; rec[:, o + 2] = 10
+            rec[:, o + 3:o + 3 + READ_LEN] = 73
+            rec[:, o + 3 + READ_LEN] = 10
+            f.write(rec.cpu().numpy().tobytes())
+
+
+def write_e2e_inputs(torch, sample, gs, hdr, work):
+    """Every file of palace:473-480 and 555-600 for this sample.  Generation is not timed."""
+    t0 = time.perf_counter()
+    P = {k: os.path.join(work, v) for k, v in dict(
+        fq1="reads_1.fq", fq2="reads_2.fq", fa="phagedb.fa", hdr="coder.hdr", bam="reads_pe_primary.sort.bam", cols="bam_cols",
+        fastg_fai="assembly_graph.fastg.fai", fasta_fai="assembly_graph.fasta.fai", blast="assembly_graph.fasta.blast",
+        hit="hit_seqs.out", score="node_scores.out", paths="contigs.paths", graph="s_graph.txt", pre="s_filtered_graph_pre.txt",
+        filt="s_filtered_graph.txt", allhit="all_hit_segs.txt", lin="s_linear.txt", cyc="s_cycle.txt", nodup="s_cycle_nodup.txt",
+        result="s_all_result.txt", refnames="s_ref_names.txt", tmp="s_tmp.txt").items()}
+    n_side = sample["n_reads_side"]
+    fastq_to_file(torch, sample["r1"], n_side, "1", P["fq1"])
+    fastq_to_file(torch, sample["r2"], n_side, "2", P["fq2"])
+    rb, ro = sample["ref_bases"].cpu().numpy(), sample["ref_off"].cpu().numpy()
+    with open(P["fa"], "wb") as f:
+        for i in range(sample["n_refs"]):
+            b = rb[ro[i]:ro[i + 1]].tobytes()
+            f.write(b">phage_%d synthetic\n" % (i + 1) + b"\n".join(b[k:k + 80] for k in range(0, len(b), 80)) + b"\n")
+    open(P["hdr"], "wb").write(np.asarray(hdr, dtype=np.uint8).tobytes())
+    # BAM: the decoded columns go through palace_amd/bin/synthbam (multi-threaded BGZF writer)
+    os.makedirs(P["cols"], exist_ok=True)
+    names, lens = gs["names"], gs["lens"]
+    c = gs["col"]
+    for k in ("tid", "pos", "mtid", "mpos", "nm", "ref_len", "clip_e"):
+        c[k].cpu().numpy().astype(np.int32).tofile(os.path.join(P["cols"], k + ".i32"))
+    gs["sa_off"].cpu().numpy().astype(np.int32).tofile(os.path.join(P["cols"], "sa_off.i32"))
+    gs["sa"][: max(1, gs["n_sa"])].cpu().numpy().astype(np.int32).tofile(os.path.join(P["cols"], "sa.i32"))
+    c["flag"].cpu().numpy().view(np.uint16).tofile(os.path.join(P["cols"], "flag.u16"))
+    c["mapq"].cpu().numpy().tofile(os.path.join(P["cols"], "mapq.u8"))
+    c["qkey"].cpu().numpy().view(np.uint64).tofile(os.path.join(P["cols"], "qkey.u64"))
+    with open(os.path.join(P["cols"], "targets.tsv"), "w") as f:
+        f.write("".join(f"{n}\t{l}\n" for n, l in zip(names, lens.tolist())))
+    import subprocess
+    subprocess.run([os.path.join(ROOT, "palace_amd", "bin", "synthbam"), P["cols"], P["bam"], str(min(16, os.cpu_count() or 1)), "1"], check=True)
+    # FASTG .fai (generate_graph.cpp:119-169 reads column 0 only): one line per link
+    a, b, o1, o2 = gs["fastg_links"]
+    q = "'"
+    with open(P["fastg_fai"], "w") as f:
+        f.write("".join(f"{names[x]}{q if u else ''}:{names[y]}{q if (u ^ v) else ''};\t{lens[x]}\t0\t60\t61\n"
+                        for x, y, u, v in zip(a.tolist(), b.tolist(), o1.tolist(), o2.tolist())))
+    # side inputs of filter_graph.py (SURVEY.md 8(d)): hit_seqs 3 % of the contigs, node_scores all of them (uniform, some in
+    # e-05 notation), .blast for 2 %, one contigs.paths entry per 3 contigs
+    rng = np.random.Generator(np.random.PCG64(SEED + 2))
+    n = len(names)
+    with open(P["fasta_fai"], "w") as f:
+        f.write("".join(f"{nm}\t{l}\t{7 + 100 * i}\t60\t61\n" for i, (nm, l) in enumerate(zip(names, lens.tolist()))))
+    hit = rng.choice(n, size=max(1, n * 3 // 100), replace=False)
+    with open(P["hit"], "w") as f:
+        f.write("".join(f"{names[i]}\t{k}\n" for i, k in zip(hit.tolist(), rng.integers(1, 9, size=len(hit)).tolist())))
+    sc = rng.random(n)
+    tiny = rng.random(n) < 0.05
+    with open(P["score"], "w") as f:
+        f.write("".join(f"{nm}\t{(f'{x * 9:.4f}e-05' if t else f'{x:.6f}')}\n" for nm, x, t in zip(names, sc.tolist(), tiny.tolist())))
+    bl = rng.choice(n, size=max(1, n // 50), replace=False)
+    with open(P["blast"], "w") as f:
+        for i, ident, frac, ref in zip(bl.tolist(), rng.choice([99.5, 85.0, 69.9], size=len(bl)).tolist(),
+                                       rng.choice([0.3, 0.8, 0.95], size=len(bl)).tolist(), rng.integers(1, 200, size=len(bl)).tolist()):
+            L = int(lens[i]); al = max(30, int(L * frac))
+            f.write(f"{names[i]}\tphage_{ref}\t{ident:.3f}\t{al}\t3\t0\t1\t{al}\t100\t{100 + al}\t1e-50\t200\t{L}\t40000\n")
+    ids = [nm.split("_")[1] for nm in names]
+    k_paths = max(1, n // 3)
+    mem = rng.integers(0, n, size=(k_paths, 3))
+    sg = rng.integers(0, 2, size=(k_paths, 3))
+    with open(P["paths"], "w") as f:
+        out = []
+        for k in range(k_paths):
+            fwd = [ids[j] + "+-"[t] for j, t in zip(mem[k].tolist(), sg[k].tolist())]
+            rc = [t[:-1] + ("-" if t[-1] == "+" else "+") for t in reversed(fwd)]
+            tot = int(lens[mem[k]].sum())
+            out.append(f"NODE_{k + 1}_length_{tot}_cov_9.5\n{','.join(fwd)}\nNODE_{k + 1}_length_{tot}_cov_9.5'\n{','.join(rc)}\n")
+        f.write("".join(out))
+    P["gen_s"] = time.perf_counter() - t0
+    P["bytes"] = {k: os.path.getsize(P[k]) for k in ("fq1", "fq2", "fa", "bam", "fastg_fai")}
+    return P
+
+
+def run_e2e(P, avg_depth, n_contigs, rows_host, n_junc_expected):
+    """The chain of palace:473-480 and 555-600 on the files, one process per stage as the driver runs them.  Returns wall
+    seconds per stage.  eref is run twice: the first run builds <db>.k32.index.dat (once per DB, extract_ref.cpp:1245-1251),
+    the second finds it -- the steady state of a DB shared by many samples and the one that enters `seconds`."""
+    import subprocess
+    B = os.path.join(ROOT, "palace_amd", "bin")
+    S = os.path.join(ROOT, "palace_amd", "scripts")
+    threads = str(min(16, os.cpu_count() or 1))
+    st = {}
+
+    def timed(key, cmd, stdout=None, env=None):
+        t0 = time.perf_counter()
+        subprocess.run(cmd, check=True, stdout=stdout, env=env)
+        st[key] = time.perf_counter() - t0
+
+    eref = [os.path.join(B, "eref"), P["fq1"], P["fq2"], P["fa"], P["tmp"], "0.9", "0.85", threads]
+    with open(P["refnames"], "wb") as f:
+        timed("eref_first_run_builds_index", eref, stdout=f, env=dict(os.environ, PALACE_CODER_HEADER=P["hdr"]))
+    with open(P["refnames"], "wb") as f:
+        timed("eref", eref, stdout=f)
+    timed("generateGraph", [os.path.join(B, "generateGraph"), P["bam"], P["fastg_fai"], P["graph"], f"{avg_depth:.6g}"])
+    timed("filter_graph.py", [sys.executable, os.path.join(S, "filter_graph.py"), P["fastg_fai"], P["graph"], P["pre"], f"{avg_depth:.6g}", "0",
+                              P["hit"], P["score"], P["blast"], "0.7", P["fasta_fai"], P["allhit"], P["paths"], "0.7"])
+    with open(P["filt"], "wb") as f:
+        timed("uniq", ["uniq", P["pre"]], stdout=f)
+    timed("matching", [os.path.join(B, "matching"), "-g", P["filt"], "-r", P["lin"], "-c", P["cyc"], "-s", "-i", "10", "-l", P["paths"]])
+    timed("remove_cycle_dup.py", [sys.executable, os.path.join(S, "remove_cycle_dup.py"), P["cyc"], P["nodup"]])
+    t0 = time.perf_counter()
+    with open(P["result"], "wb") as f:
+        for k in ("lin", "nodup"):
+            f.write(open(P[k], "rb").read())
+    st["cat"] = time.perf_counter() - t0
+    # cross-check against the HBM-resident step (same coder header, same sample): reported refs and kept junctions
+    r = rows_host
+    want = {(i + 1, int(r[i, 0]), int(r[i, 1])) for i in range(len(r))
+            if r[i, 1] > 0 and np.float32(r[i, 1]) / np.float32(r[i, 2]) > np.float32(0.75)}
+    got = {tuple(int(x) for x in l.split("\t")[1:4]) for l in open(P["refnames"]).read().splitlines()}
+    n_junc = sum(1 for l in open(P["graph"]) if l.startswith("JUNC"))
+    total = sum(v for k, v in st.items() if k != "eref_first_run_builds_index")
+    return dict(seconds=total, contigs_per_s=n_contigs / total, stage_s={k: round(v, 3) for k, v in st.items()},
+                agrees_with_resident_step=bool(got == want and n_junc == n_junc_expected),
+                refs_reported=len(got), junc_lines=n_junc, result_lines=sum(1 for _ in open(P["result"])),
+                input_bytes=P["bytes"], input_generation_s=round(P["gen_s"], 1),
+                note="wall clock of eref + generateGraph + filter_graph.py + uniq + matching + remove_cycle_dup.py + cat, one process "
+                     "per stage, files in the page cache; eref with the index file of the DB present (built by the first run)")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -283,15 +460,20 @@ def reference_eref_check(b1, b2, off, rb, ro, n_ref_s, tmp):
         return dict(error=str(e)[:200])
 
 
-def cpu_baseline(torch, sample, gs, header, n_reads, n_records, graph_out):
-    """The oracle (CPU restatement of the reference algorithm, 1 thread) on a bounded sample of every
-    stage, extrapolated linearly to the whole workload.  Returns contigs/s and a description."""
+def cpu_baseline(torch, sample, gs, header, frac, graph_out):
+    """The oracle (CPU restatement of the reference algorithm) on a bounded sample of every stage, extrapolated linearly to
+    the whole workload: at threads = 1 (the only configuration in which the reference's semantics are defined, SURVEY.md
+    F5) -> `value`; with the read counting on min(nproc, 16) threads (race-free: saturating increment by compare-and-swap)
+    -> `multi_thread`; and with the reference's dead 16.3 GiB allocation + memset (extract_ref.cpp:1296-1299) added at
+    threads = 1 -> `as_shipped`.  The oracle keeps the reference's 32-step inner loop per (position, channel)."""
     import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import binding as orc
     from palace_amd.synth import BamRecord
+    cores = max(1, min(os.cpu_count() or 1, 16))
     cc = orc.header_to_cc(header)
     # ---- eref ----
-    n_side = min(n_reads // 2, sample["n_reads_side"])
+    n_side = max(1000, min(sample["n_reads_side"], int(frac * sample["n_reads_side"])))
     b1 = sample["r1"][: n_side * READ_LEN].cpu().numpy()
     b2 = sample["r2"][: n_side * READ_LEN].cpu().numpy()
     off = np.arange(n_side + 1, dtype=np.int64) * READ_LEN
@@ -311,11 +493,25 @@ def cpu_baseline(torch, sample, gs, header, n_reads, n_records, graph_out):
     for i in range(n_ref_s):
         orc.scan_ref(idx[i], int(ro[i + 1] - ro[i]), table, 0.9, 0.85)
     t_refs = time.perf_counter() - t0
+    table.clear()
+    t0 = time.perf_counter()
+    table.count_mt(b1, off, cc, cores)
+    table.count_mt(b2, off, cc, cores)
+    t_reads_mt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:     # refs are independent (the reference splits them over T threads,
+        list(ex.map(lambda i: orc.scan_ref(idx[i], int(ro[i + 1] - ro[i]), table, 0.9, 0.85), range(n_ref_s)))   # :1314-1329)
+    t_refs_mt = time.perf_counter() - t0
     table.free()
+    t0 = time.perf_counter()
+    dead = orc.lib().orc_eref_reference_dead_cost()        # 16 GiB + 300 MB allocated and zeroed, never read
+    t_dead = time.perf_counter() - t0 if dead else None
     total_reads = 2 * sample["n_pairs_total"]
-    t_eref = t_clear + t_reads * total_reads / (2 * n_side) + t_refs * sample["n_refs"] / n_ref_s
-    # ---- generateGraph: first n_records records of the sorted stream, rebuilt as BAM-level records ----
-    m = min(n_records, gs["n"])
+    up_reads, up_refs = total_reads / (2 * n_side), sample["n_refs"] / n_ref_s
+    t_eref = t_clear + t_reads * up_reads + t_refs * up_refs
+    t_eref_mt = t_clear + t_reads_mt * up_reads + t_refs_mt * up_refs
+    # ---- generateGraph: first m records of the sorted stream, rebuilt as BAM-level records (single thread, as the reference) ----
+    m = max(1000, min(gs["n"], int(frac * gs["n"])))
     c = {k: v[:m].cpu().numpy() for k, v in gs["col"].items()}
     so = gs["sa_off"][: m + 1].cpu().numpy()
     sa = gs["sa"][: max(1, int(so[-1]))].cpu().numpy()
@@ -348,28 +544,69 @@ def cpu_baseline(torch, sample, gs, header, n_reads, n_records, graph_out):
         keep = src <= (dst ^ 1)                      # one line per conjugate pair
         f.write("".join(f"JUNC {names[u >> 1]} {'+-'[u & 1]} {names[v >> 1]} {'+-'[v & 1]} {x} 0\n"
                         for u, v, x in zip(src[keep].tolist(), dst[keep].tolist(), w[keep].tolist())))
-    orc.lib()
     cap = 128 * len(names) + (1 << 20)
     t0 = time.perf_counter()
     orc.match_run(gpath, None, 10, cap=cap)
     t_match = time.perf_counter() - t0
-    t_full = t_eref + t_graph + t_match
-    ref_check = reference_eref_check(b1, b2, off, rb, ro, n_ref_s, tmp)
+    t_full, t_full_mt = t_eref + t_graph + t_match, t_eref_mt + t_graph + t_match
+    # the COMPILED reference, when it travels with the repo, on a small part of the same reads: a cross-check of the port's rate
+    k = min(n_side, 20000)
+    ref_check = reference_eref_check(b1[: k * READ_LEN], b2[: k * READ_LEN], off[: k + 1], rb, ro, n_ref_s, tmp)
     if ref_check is not None and "error" not in ref_check and sample["n_contigs"] == 1_000_000:
-        ref_check["full_size_note"] = ("measured once on a GPU box, not in this run: the compiled reference on this workload's full eref "
-                                       "input (5000 refs, 6.67 M reads) took 595.6 s at threads=1 incl. its index build, stdout "
+        ref_check["full_size_note"] = ("measured once on a GPU box, not in this run: the compiled reference on the full eref input of "
+                                       "this workload (5000 refs, 6.67 M reads) took 595.6 s at threads=1 incl. its index build, stdout "
                                        "byte-identical to ours (profiles/ref_compare_eref_full.log)")
-    return dict(reference_eref=ref_check, value=sample["n_contigs"] / t_full, unit="contigs/s", cores=1, kind="port",
-                sample=(f"oracle/ (1 thread). eref: {2 * n_side} of {total_reads} reads x{READ_LEN} bp ({t_reads:.1f} s) + 4 GiB "
-                        f"table memset ({t_clear:.1f} s, fixed) + scan of {n_ref_s} of {sample['n_refs']} refs ({t_refs:.2f} s) "
-                        f"-> {t_eref:.0f} s extrapolated; generateGraph: first {m} of {gs['n_total']} decoded records "
-                        f"({t_graph_s:.1f} s, BGZF/BAM decode and full .fai parse excluded) -> {t_graph:.0f} s; matching: whole "
-                        f"graph ({t_match:.1f} s, own algorithm, reference absent). Dead 16 GiB Peaks memset excluded."),
-                stage_s=dict(eref=t_eref, generateGraph=t_graph, matching=t_match), port_reads_per_s=2 * n_side / t_reads)
+    nc = sample["n_contigs"]
+    out = dict(value=nc / t_full, unit="contigs/s", cores=1, kind="port",
+               sample=(f"oracle/ at threads=1. eref: {2 * n_side} of {total_reads} reads x{READ_LEN} bp ({t_reads:.1f} s) + 4 GiB table "
+                       f"memset ({t_clear:.1f} s, fixed) + scan of {n_ref_s} of {sample['n_refs']} refs ({t_refs:.2f} s) -> {t_eref:.0f} s "
+                       f"extrapolated; generateGraph: first {m} of {gs['n_total']} decoded records ({t_graph_s:.1f} s; BGZF/BAM decode and "
+                       f"full .fai parse excluded) -> {t_graph:.0f} s; matching: whole graph ({t_match:.1f} s; own algorithm, reference "
+                       f"absent)."),
+               stage_s=dict(eref=t_eref, generateGraph=t_graph, matching=t_match), port_reads_per_s=2 * n_side / t_reads,
+               multi_thread=dict(value=nc / t_full_mt, unit="contigs/s", cores=cores, kind="port",
+                                 note=f"read counting and ref scan on {cores} threads (same sample: {t_reads_mt:.1f} s and {t_refs_mt:.2f} s); "
+                                      "generateGraph and matching single-threaded, as the reference's are",
+                                 stage_s=dict(eref=t_eref_mt, generateGraph=t_graph, matching=t_match)),
+               reference_eref=ref_check)
+    if t_dead is not None:
+        out["as_shipped"] = dict(value=nc / (t_full + t_dead), unit="contigs/s", cores=1, kind="port",
+                                 note=f"threads=1 plus the reference's never-read Peaks arrays: 16 GiB + 300 MB allocated and zeroed "
+                                      f"({t_dead:.1f} s on this host, fixed per run; extract_ref.cpp:1296-1299)")
+    return out
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (torch.distributed.run, one rank
+    per GPU, rendezvous on 127.0.0.1) before this process has touched a GPU, let them print the JSON line, return their
+    exit status.  (Never exec from a process that initialised the GPU.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def phase_a_traffic(args, world):
+    """HBM bytes per count_reads launch from the committed PMC profile of the CURRENT kernels (profiles/phase_a_traffic.json,
+    written by tools/prof_full.sh + tools/traffic_json.py): FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE over the
+    launch's kernels.  Only quoted for the workload it was measured on; otherwise null."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "phase_a_traffic.json")))
+    except Exception:
+        return None, None
+    if world != 1 or t.get("contigs") != args.contigs or t.get("workload", "default") != args.workload:
+        return None, None
+    return t.get("bytes_per_launch"), t.get("source")
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 when a process group
     # initialises, so everything written to fd 1 before the final line is routed to stderr.
     sys.stdout.flush()
@@ -379,8 +616,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if os.environ.get("PALACE_BENCH_ONE_DEVICE") == "1":   # rehearsal only: every rank on GPU 0 (with PALACE_BENCH_BACKEND=gloo)
         local = 0
     torch.cuda.set_device(local)
@@ -397,10 +632,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    from palace_amd import capi, multigpu
-    from oracle import binding as orc       # header helper + cpu_baseline leg only
+    from palace_amd import capi, coder, multigpu       # (oracle/ is imported by the cpu_baseline leg only)
 
-    hdr = orc.header_from_picks(np.random.Generator(np.random.PCG64(SEED)).integers(0, 6, size=32))
+    hdr = coder.header_from_picks(np.random.Generator(np.random.PCG64(SEED)).integers(0, 6, size=32))
     ctx = capi.Ctx(local)                      # eref stream
     ctx_g = capi.Ctx(local, high_priority=True)   # generateGraph + matching stream (independent of eref until the end)
     ctx.eref_set_coder(hdr)
@@ -412,8 +646,9 @@ def main():
     # at W = 2 (~15 ms, more than the ~7 ms the split saves), seven at W = 8 (~3.5 ms).  Below four ranks every rank
     # therefore counts ALL reads (no exchange) and only Phase B, generateGraph and the gathers are sharded.
     shard_reads = world >= 4 or force_exchange
-    sample = make_sample(torch, dev, args.contigs, args.refs, rank if shard_reads else 0, world if shard_reads else 1)
-    gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world)
+    long_mode = args.workload == "long"
+    sample = make_sample(torch, dev, args.contigs, args.refs, rank if shard_reads else 0, world if shard_reads else 1, long_mode)
+    gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world, long_mode)
     if world > 1 or force_exchange:                 # avgDepth is a pipeline input: computed once from all shards
         tot = torch.tensor([float(gs["col"]["ref_len"].sum().item())], device=dev, dtype=torch.float64)
         dist.all_reduce(tot)
@@ -462,6 +697,7 @@ def main():
             ctx.eref_table_merge_slices(parts.data_ptr(), n_parts, slice_off, slice_bytes, packed)
             ctx.sync()
     last = {}
+    h_last = {}
     host_ms = {}
     ref_off_local = sample["ref_off"][r_lo:r_hi + 1].contiguous()
     # Per-DB probe index of this rank's refs, built once outside the timed region: the reference, too, scans a
@@ -544,6 +780,8 @@ def main():
                 return
             copies, src, dst, w = graph_to_arcs(h_cn, nt, h_edges)
             th2 = time.perf_counter()
+            if not timed:
+                h_last["edges"] = h_edges.copy()
             if rank == 0:
                 res = capi.match_decompose_views(g, copies, src, dst, 10, False)              # views, no copies
                 th3 = time.perf_counter()
@@ -590,6 +828,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_step = 1e3 * dt / args.steps
+    # soak: the K timed steps above are what `value` is computed from; when they took less than --soak-seconds the same
+    # step keeps running (untimed for `value`) so that an outside GPU-activity sampler has something to see
+    soak = None
+    if dt < args.soak_seconds and not exch:
+        t1, n_soak = time.perf_counter(), 0
+        while time.perf_counter() - t1 < args.soak_seconds - dt:
+            for _ in range(10):
+                step(0, False)
+            barrier()
+            n_soak += 10
+        soak = dict(steps=n_soak, seconds=time.perf_counter() - t1, ms_per_step=1e3 * (time.perf_counter() - t1) / max(1, n_soak))
     K = range(args.steps)
     count_each = [ctx.mark_elapsed(8 * i, 8 * i + 1) for i in K]
     count_ms = np.mean(count_each)                                                  # one launch per step (both FASTQ sides)
@@ -601,6 +850,7 @@ def main():
     reported = int(((r[:, 1] > 0) & (r[:, 1].astype(np.float32) / r[:, 2].astype(np.float32) > 0.75)).sum())
 
     if rank == 0:
+        traffic, traffic_src = phase_a_traffic(args, world)
         alg_bytes = (READ_LEN + 6 * (READ_LEN - 31)) * 2 * n_side        # per launch (both FASTQ sides of this rank)
         achieved = alg_bytes / (count_ms * 1e-3) / 1e9
         out = {
@@ -611,27 +861,39 @@ def main():
             "config": {"workload": f"{args.contigs}-contig synthetic sample: {n_refs} phage refs ({sample['ref_total']} bp), "
                                    f"{2 * sample['n_pairs_total']} reads x {READ_LEN} bp, {gs['n_total']} primary BAM records, "
                                    f"{gs['n_fastg']} FASTG links",
-                       "stages": ["eref", "generateGraph", "matching"], "seed": SEED,
+                       "stages": ["eref", "generateGraph", "matching"], "seed": SEED, "workload_kind": args.workload,
                        "parallelism": "1 GPU" if world == 1 else (f"reads/records/refs sharded over {world} GPUs (RCCL)" if shard_reads else
                                                                    f"records/refs sharded over {world} GPUs (RCCL), reads counted on every GPU"),
                        "ref_index": "per-DB probe index prebuilt, as the reference's cached <fasta>.k32.index.dat (8 B/position in HBM)",
                        "refs_reported": reported, "refs_present": int(len(sample["present"])),
                        "graph": {k: last[k] for k in ("n_cands", "n_edges", "n_arcs", "n_comp", "n_cycles", "n_multi")}},
-            "roofline": {"bound": "hbm", "kernel": "eref count_reads (bin1 + bin2 + lds_count kernels of one launch)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "eref count_reads (streams + bin1 + bin2 + lds_count kernels of one launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # PMC (separate rocprofv3 passes, profiles/r01q_end_state_fused_launch.md): FETCH_SIZE x2 + WRITE_SIZE of
                          # bin1 + bin2 + lds_count per launch; only valid for the default workload on one GPU
-                         "traffic": 45.2e9 if (args.contigs == 1_000_000 and world == 1) else None,   # PMC passes of profiles/r01u_end_state.md
-                         "traffic_unit": "bytes per launch",
+                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "avg_launch_ms": count_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "stage_ms": {"eref_count_each_step": [round(float(x), 3) for x in count_each], "eref_count_both_sides": count_ms, "eref_table_merge": merge_ms, "eref_scan_refs": scan_ms,
                          "graph_classify": classify_ms, "graph_resolve": resolve_ms,
                          **{"host_" + k: v for k, v in host_ms.items()},
                          "note": "eref runs on one HIP stream, generateGraph + matching on another; they overlap"},
         }
+        if soak:
+            out["soak"] = soak
+        if world == 1 and not args.no_e2e:
+            import shutil
+            import tempfile
+            work = tempfile.mkdtemp(prefix="palace_e2e_", dir=os.environ.get("PALACE_BENCH_TMP", "/tmp"))
+            try:
+                paths = write_e2e_inputs(torch, sample, gs, hdr, work)
+                n_junc = int((h_last["edges"]["counts"].sum(axis=1) >= 5).sum())
+                out["e2e"] = run_e2e(paths, gs["avg_depth"], args.contigs, r, n_junc)
+            except Exception as e:                   # never let this leg break the headline line
+                out["e2e"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            finally:
+                shutil.rmtree(work, ignore_errors=True)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(torch, sample, gs, hdr, args.cpu_sample_reads, args.cpu_sample_records,
-                                               last["graph"])
+            out["cpu_baseline"] = cpu_baseline(torch, sample, gs, hdr, args.cpu_sample_frac, last["graph"])
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     capi._check(L.palace_eref_probe_index_free(ctx.h, probe_index), "probe index free")

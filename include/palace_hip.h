@@ -50,6 +50,13 @@ int palace_memset(palace_ctx *ctx, void *d_ptr, int value, size_t bytes);
 int palace_h2d(palace_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int palace_d2h(palace_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int palace_d2d(palace_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+/* Streaming ingest (the reference reads its inputs with T threads per phase, extract_ref.cpp:1267-1291,
+ * and streams the BAM, generate_graph.cpp:644): page-locked host staging buffers, and a host-to-device copy that only
+ * enqueues -- the source must stay untouched until a later palace_mark() on the stream has been waited for with
+ * palace_mark_wait() (or palace_sync()). */
+int palace_host_alloc(palace_ctx *ctx, size_t bytes, void **h_out);
+int palace_host_free(palace_ctx *ctx, void *h_ptr);
+int palace_h2d_async(palace_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 /* HIP-event timing on the context's stream: begin/end bracket, elapsed in milliseconds. */
 int palace_timer_begin(palace_ctx *ctx);
 int palace_timer_end(palace_ctx *ctx, float *ms_out);
@@ -57,6 +64,7 @@ int palace_timer_end(palace_ctx *ctx, float *ms_out);
  * (0 <= i < 4096) on the stream; mark_elapsed(a, b) waits for event b and returns b - a in ms. */
 int palace_mark(palace_ctx *ctx, int i);
 int palace_mark_elapsed(palace_ctx *ctx, int a, int b, float *ms_out);
+int palace_mark_wait(palace_ctx *ctx, int i);
 
 /* ---- eref: k-mer screening of reads against the phage DB (bin/extract_ref.cpp) ---------- */
 

@@ -88,6 +88,12 @@ class CountTable:
         k = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
         lib().orc_count_reads(_p(b), _p(o), len(o) - 1, None if k is None else _p(k), _p(cc), self.ptr)
 
+    def count_mt(self, bases: np.ndarray, offsets: np.ndarray, cc: np.ndarray, threads: int, keep: np.ndarray | None = None):
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        k = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+        lib().orc_count_reads_mt(_p(b), _p(o), C.c_int64(len(o) - 1), None if k is None else _p(k), _p(cc), C.c_void_p(self.ptr), C.c_int(threads))
+
     def clear(self):
         lib().orc_table_clear(self.ptr)
 

@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 
 #define K 32
 #define NCH 3
@@ -138,6 +139,45 @@ void orc_count_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_rea
     for (int64_t r = 0; r < n_reads; r++)
         if (!keep || keep[r])
             orc_count_read(bases + offsets[r], offsets[r + 1] - offsets[r], cc, table);
+}
+
+/* The same Phase A on `threads` threads (reference: T x thread(read_fastq, byte range), extract_ref.cpp:1269-1291).  The
+ * reference's threaded update is a non-atomic read-modify-write on the shared table and its chunks overrun their ends
+ * (SURVEY.md F5), so its threads > 1 result is not defined; this restatement splits the reads by index and makes the
+ * saturating increment a compare-and-swap, which gives exactly the threads = 1 table for any thread count.  Used for
+ * the multi-core CPU baseline figure. */
+typedef struct { const uint8_t *bases; const int64_t *offsets; int64_t r0, r1; const uint8_t *keep; const int16_t *cc; uint8_t *table; } orc_mt_job;
+static void *orc_mt_worker(void *arg)
+{
+    orc_mt_job *j = (orc_mt_job *)arg;
+    for (int64_t r = j->r0; r < j->r1; r++) {
+        if (j->keep && !j->keep[r]) continue;
+        const unsigned char *s = j->bases + j->offsets[r];
+        int64_t len = j->offsets[r + 1] - j->offsets[r];
+        for (int64_t p = 0; p + K <= len; p++)
+            for (int i = 0; i < NCH; i++) {
+                int ok;
+                uint32_t idx = orc_canonical_index(s + p, j->cc, i, &ok);
+                if (!ok) continue;
+                uint8_t v = __atomic_load_n(&j->table[idx], __ATOMIC_RELAXED);
+                while (v < 3 && !__atomic_compare_exchange_n(&j->table[idx], &v, (uint8_t)(v + 1), 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
+            }
+    }
+    return NULL;
+}
+void orc_count_reads_mt(const uint8_t *bases, const int64_t *offsets, int64_t n_reads, const uint8_t *keep,
+                        const int16_t cc[96], uint8_t *table, int threads)
+{
+    if (!g_tables_ready) init_tables();
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256];
+    orc_mt_job job[256];
+    for (int t = 0; t < threads; t++) {
+        job[t] = (orc_mt_job){bases, offsets, n_reads * t / threads, n_reads * (t + 1) / threads, keep, cc, table};
+        pthread_create(&th[t], NULL, orc_mt_worker, &job[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
 }
 
 /* extract_ref.cpp:711-738 (read_ref, one record): 3 canonical indices per position, 0 when the

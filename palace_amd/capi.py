@@ -67,6 +67,10 @@ _SIGS = {
     "palace_h2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "palace_d2h": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "palace_d2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "palace_host_alloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
+    "palace_host_free": [C.c_void_p, C.c_void_p],
+    "palace_h2d_async": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "palace_mark_wait": [C.c_void_p, C.c_int],
     "palace_timer_begin": [C.c_void_p],
     "palace_timer_end": [C.c_void_p, C.POINTER(C.c_float)],
     "palace_mark": [C.c_void_p, C.c_int],

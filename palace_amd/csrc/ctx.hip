@@ -175,6 +175,41 @@ int palace_h2d(palace_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
     return PALACE_OK;
 }
 
+int palace_host_alloc(palace_ctx *ctx, size_t bytes, void **h_out)
+{
+    PALACE_REQUIRE(ctx && h_out, "null argument");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(h_out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return PALACE_ENOMEM;
+    }
+    return PALACE_OK;
+}
+
+int palace_host_free(palace_ctx *ctx, void *h_ptr)
+{
+    PALACE_REQUIRE(ctx, "ctx is null");
+    if (!h_ptr) return PALACE_OK;
+    PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    PALACE_HIP_TRY(hipHostFree(h_ptr));
+    return PALACE_OK;
+}
+
+int palace_h2d_async(palace_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    PALACE_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), "null argument");
+    if (bytes) PALACE_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return PALACE_OK;
+}
+
+int palace_mark_wait(palace_ctx *ctx, int i)
+{
+    PALACE_REQUIRE(ctx && i >= 0 && static_cast<size_t>(i) < ctx->marks.size() && ctx->marks[i], "mark not recorded");
+    PALACE_HIP_TRY(hipEventSynchronize(ctx->marks[i]));
+    return PALACE_OK;
+}
+
 int palace_d2h(palace_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 {
     PALACE_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "null argument");

@@ -14,6 +14,8 @@
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/palace_hip.h"
 #include "fastx.hpp"
@@ -67,8 +69,16 @@ bool file_exists(const std::string &p)
 // random_coder (extract_ref.cpp:1082-1102): one of six orders of (0,1,2) per k-mer offset.  The
 // reference seeds this with time(0); any choice is valid, so a fixed default keeps runs
 // reproducible (override with PALACE_CODER_SEED).
-void make_header(uint8_t hdr[400])
+bool make_header(uint8_t hdr[400])
 {
+    // PALACE_CODER_HEADER=<file>: take the 400-byte coder header from a file (e.g. the first 400 bytes of an index built
+    // elsewhere) instead of drawing one -- several machines can then build interchangeable indices of one DB without
+    // shipping 12 bytes per reference position.
+    if (const char *path = std::getenv("PALACE_CODER_HEADER")) {
+        std::ifstream f(path, std::ios::binary);
+        if (!f.read(reinterpret_cast<char *>(hdr), 400)) { std::cerr << "eref: cannot read 400 bytes from " << path << "\n"; return false; }
+        return true;
+    }
     static const int16_t orders[18] = {0, 1, 2, 0, 2, 1, 1, 2, 0, 1, 0, 2, 2, 0, 1, 2, 1, 0};
     const char *env = std::getenv("PALACE_CODER_SEED");
     GlibcRand g(env ? static_cast<unsigned>(std::strtoul(env, nullptr, 10)) : 20261003u);
@@ -82,6 +92,7 @@ void make_header(uint8_t hdr[400])
         uint32_t w = static_cast<uint16_t>(cc[j]) | (static_cast<uint32_t>(static_cast<uint16_t>(cc[j + 1])) << 16);
         std::memcpy(hdr + 4 * j, &w, 4);
     }
+    return true;
 }
 
 template <class T>
@@ -109,14 +120,34 @@ int main(int argc, char **argv)
     const int window = 500;
     const int one_min = window * hit_ratio, three_min = window * perfect_ratio;   // :513-514
 
+    // The HIP runtime comes up (device, stream, 3 x 512 MiB of planes zeroed) on its own thread while this one maps and
+    // scans the text inputs: neither waits for the other (the reference, too, reads with T threads per phase, :1267-1291).
     palace_ctx *ctx = nullptr;
-    CK(palace_ctx_create(0, &ctx));
+    int ctx_rc = 0;
+    std::string ctx_err;
+    std::thread hip_up([&] {
+        ctx_rc = palace_ctx_create(0, &ctx);
+        if (!ctx_rc) ctx_rc = palace_eref_table_reset(ctx);
+        if (ctx_rc) ctx_err = palace_last_error();          // (the message is per thread)
+    });
+    MappedText fq_txt[2];
+    FastqPlan plan[2];
+    std::string in_err;
+    std::thread fq_scan([&] {                                // pass 1 over both FASTQ files: parts, line phases, sizes
+        try {
+            for (int side = 0; side < 2; side++) {
+                fq_txt[side].open(side == 0 ? fq1 : fq2);
+                plan_fastq(fq_txt[side], threads, plan[side]);
+            }
+        } catch (const std::exception &e) { in_err = e.what(); }
+    });
 
     // ---- references: FASTA -> records longer than k=32 (:697), index-file contract ----
     SeqSet db_all, db;
     try {
-        parse_fasta(read_file(fasta), db_all);
-    } catch (const std::exception &e) { std::cerr << "eref: " << e.what() << "\n"; return 1; }
+        MappedText fa_txt(fasta);
+        parse_fasta(fa_txt.data, fa_txt.size, db_all);
+    } catch (const std::exception &e) { std::cerr << "eref: " << e.what() << "\n"; hip_up.join(); fq_scan.join(); return 1; }
     std::vector<int64_t> cum(db_all.n() + 1, 0);
     for (int64_t i = 0; i < db_all.n(); i++) {
         cum[i + 1] = cum[i] + db_all.len(i);
@@ -132,6 +163,8 @@ int main(int argc, char **argv)
     for (int64_t r = 0; r < n_refs; r++) idx_off[r + 1] = idx_off[r] + 3 * (db.len(r) - 31);
     const uint64_t index_bytes = 400 + 4ull * n_refs + 4ull * static_cast<uint64_t>(idx_off[n_refs]);
 
+    hip_up.join();
+    if (ctx_rc) { std::cerr << "eref: cannot set up the GPU: " << ctx_err << "\n"; fq_scan.join(); return 1; }
     uint8_t *d_ref = nullptr; int64_t *d_ref_off = nullptr;
     CK(upload(ctx, db.bases.data(), db.bases.size(), &d_ref));
     CK(upload(ctx, db.offsets.data(), db.offsets.size(), &d_ref_off));
@@ -139,7 +172,7 @@ int main(int argc, char **argv)
     const std::string index_name = fasta + ".k32.index.dat";                   // :1245
     uint8_t hdr[400];
     if (!file_exists(index_name)) {                                            // :1246-1251 -> read_ref
-        make_header(hdr);
+        if (!make_header(hdr)) return 1;
         CK(palace_eref_set_coder(ctx, hdr));
         uint32_t *d_idx = nullptr; int64_t *d_idx_off = nullptr;
         void *p = nullptr;
@@ -173,32 +206,66 @@ int main(int argc, char **argv)
     }
 
     // ---- reads: Phase A ----
-    CK(palace_eref_table_reset(ctx));
-    GlibcRand rng(1);                                                           // :1239-1240
-    int down_sam_ratio = 100;
-    for (int side = 0; side < 2; side++) {
-        SeqSet rs;
-        try {
-            parse_fastq(read_file(side == 0 ? fq1 : fq2), threads, rs);
-        } catch (const std::exception &e) { std::cerr << "eref: " << e.what() << "\n"; return 1; }
-        if (side == 0) {                                                        // cal_sam_ratio (:1124-1148)
-            long sample = static_cast<long>(rs.bases.size()) * 2;
-            long target = 2000000000L;                                          // down_sampling_size (:1230)
-            if (const char *t = std::getenv("PALACE_EREF_SAMPLE_TARGET")) target = std::atol(t);   // test hook
-            down_sam_ratio = sample > 0 ? static_cast<int>(100L * target / sample) : 100;
-        }
-        std::vector<uint8_t> keep;
-        if (down_sam_ratio < 100) {                                             // one draw per sequence line (:955-960)
-            keep.resize(static_cast<size_t>(rs.n()));
-            for (int64_t i = 0; i < rs.n(); i++) keep[i] = (rng.next() % 100) < down_sam_ratio;
-        }
-        uint8_t *d_b = nullptr, *d_k = nullptr; int64_t *d_o = nullptr;
-        CK(upload(ctx, rs.bases.data(), rs.bases.size(), &d_b));
-        CK(upload(ctx, rs.offsets.data(), rs.offsets.size(), &d_o));
-        if (!keep.empty()) CK(upload(ctx, keep.data(), keep.size(), &d_k));
-        CK(palace_eref_count_reads(ctx, d_b, d_o, rs.n(), d_k, static_cast<int64_t>(rs.bases.size())));
-        CK(palace_free(ctx, d_b)); CK(palace_free(ctx, d_o)); CK(palace_free(ctx, d_k));
+    // Both FASTQ sides become ONE read set in HBM (side 2 behind side 1) and are counted by one launch: the partition
+    // kernels then run once and every plane slice is loaded and stored once.  Pass 2 over the text copies the sequence
+    // lines of a run of parts straight to their place in a page-locked staging buffer (all threads), which goes to the
+    // device with an asynchronous copy while the other staging buffer is being filled.
+    fq_scan.join();
+    if (!in_err.empty()) { std::cerr << "eref: " << in_err << "\n"; return 1; }
+    const int64_t n_reads = plan[0].n_reads + plan[1].n_reads, n_bases = plan[0].n_bases + plan[1].n_bases;
+    long sample = static_cast<long>(plan[0].n_bases) * 2;                       // cal_sam_ratio (:1124-1148)
+    long target = 2000000000L;                                                  // down_sampling_size (:1230)
+#ifdef PALACE_TEST_HOOKS
+    if (const char *t = std::getenv("PALACE_EREF_SAMPLE_TARGET")) target = std::atol(t);   // test builds only (bin/eref_testhooks)
+#endif
+    const int down_sam_ratio = sample > 0 ? static_cast<int>(100L * target / sample) : 100;
+    uint8_t *d_b = nullptr, *d_k = nullptr; int64_t *d_o = nullptr;
+    {
+        void *p = nullptr;
+        CK(palace_malloc(ctx, static_cast<size_t>(n_bases) + 64, &p)); d_b = static_cast<uint8_t *>(p);
+        CK(palace_malloc(ctx, static_cast<size_t>(n_reads + 1) * 8, &p)); d_o = static_cast<int64_t *>(p);
     }
+    std::vector<int64_t> offsets(static_cast<size_t>(n_reads) + 1, 0);
+    constexpr int64_t kStage = 96ll << 20;
+    uint8_t *stage[2] = {nullptr, nullptr};
+    for (int k = 0; k < 2; k++) { void *p = nullptr; CK(palace_host_alloc(ctx, static_cast<size_t>(kStage), &p)); stage[k] = static_cast<uint8_t *>(p); }
+    int n_sent = 0;
+    for (int side = 0; side < 2; side++) {
+        const FastqPlan &pl = plan[side];
+        const int64_t byte_base = side == 0 ? 0 : plan[0].n_bases, read_base = side == 0 ? 0 : plan[0].n_reads;
+        for (size_t i0 = 0; i0 < pl.parts.size();) {
+            size_t i1 = i0;                                                      // parts [i0, i1): as many as the buffer takes
+            const int64_t b0 = pl.parts[i0].byte0;
+            while (i1 < pl.parts.size() && pl.parts[i1].byte0 + pl.parts[i1].seq_bytes() - b0 <= kStage) i1++;
+            uint8_t *dst = stage[n_sent & 1];
+            std::vector<uint8_t> big;                                            // one part larger than the buffer (huge lines)
+            if (i1 == i0) { i1 = i0 + 1; big.resize(static_cast<size_t>(pl.parts[i0].seq_bytes())); dst = big.data(); }
+            else if (n_sent >= 2) CK(palace_mark_wait(ctx, 100 + ((n_sent - 2) & 1)));   // this buffer's previous copy has landed
+            pool_for(i1 - i0, threads, [&](size_t k) {
+                extract_fastq_part(pl, i0 + k, dst, b0, offsets.data() + read_base, byte_base);
+            });
+            const int64_t nb = pl.parts[i1 - 1].byte0 + pl.parts[i1 - 1].seq_bytes() - b0;
+            if (big.empty()) {
+                CK(palace_h2d_async(ctx, d_b + byte_base + b0, dst, static_cast<size_t>(nb)));
+                CK(palace_mark(ctx, 100 + (n_sent & 1)));
+                n_sent++;
+            } else {
+                CK(palace_h2d(ctx, d_b + byte_base + b0, dst, static_cast<size_t>(nb)));
+            }
+            i0 = i1;
+        }
+    }
+    CK(palace_h2d(ctx, d_o, offsets.data(), offsets.size() * 8));               // (also waits for the staged copies)
+    if (down_sam_ratio < 100) {                                                 // one draw per sequence line, file order (:955-960)
+        GlibcRand rng(1);                                                       // :1239-1240
+        std::vector<uint8_t> keep(static_cast<size_t>(n_reads));
+        for (int64_t i = 0; i < n_reads; i++) keep[static_cast<size_t>(i)] = (rng.next() % 100) < down_sam_ratio;
+        CK(upload(ctx, keep.data(), keep.size(), &d_k));
+    }
+    if (n_reads) CK(palace_eref_count_reads(ctx, d_b, d_o, n_reads, d_k, n_bases));
+    for (int k = 0; k < 2; k++) CK(palace_host_free(ctx, stage[k]));
+    CK(palace_free(ctx, d_b)); CK(palace_free(ctx, d_o)); CK(palace_free(ctx, d_k));
+    for (int side = 0; side < 2; side++) plan[side].parts.clear();
 
     // ---- references: Phase B ----
     std::vector<int32_t> rows(static_cast<size_t>(4 * n_refs));

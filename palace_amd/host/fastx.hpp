@@ -101,9 +101,8 @@ inline std::string fasta_name(const std::string &line)
 }
 
 // FASTA: every '>' record (also empty / short ones: the caller applies the len > 32 rule).
-inline void parse_fasta(const std::vector<char> &txt, SeqSet &out)
+inline void parse_fasta(const char *txt, size_t N, SeqSet &out)
 {
-    const size_t N = txt.size();
     out.bases.clear(); out.bases.reserve(N);
     out.offsets.assign(1, 0);
     // text ahead of the first header belongs to an implicit record "start" with ordinal 0
@@ -112,19 +111,148 @@ inline void parse_fasta(const std::vector<char> &txt, SeqSet &out)
     bool open = true;
     int64_t rec = 0;
     for (size_t p = 0; p < N;) {
-        const void *nl = std::memchr(txt.data() + p, '\n', N - p);
-        size_t e = nl ? static_cast<const char *>(nl) - txt.data() : N;
+        const void *nl = std::memchr(txt + p, '\n', N - p);
+        size_t e = nl ? static_cast<const char *>(nl) - txt : N;
         if (e > p && txt[p] == '>') {
             if (open) out.offsets.push_back(static_cast<int64_t>(out.bases.size()));
-            out.names.push_back(fasta_name(std::string(txt.data() + p, e - p)));
+            out.names.push_back(fasta_name(std::string(txt + p, e - p)));
             out.ordinal.push_back(++rec);
             open = true;
         } else if (open) {
-            out.bases.insert(out.bases.end(), txt.data() + p, txt.data() + e);
+            out.bases.insert(out.bases.end(), txt + p, txt + e);
         }
         p = nl ? e + 1 : N;
     }
     if (open) out.offsets.push_back(static_cast<int64_t>(out.bases.size()));
+}
+inline void parse_fasta(const std::vector<char> &txt, SeqSet &out) { parse_fasta(txt.data(), txt.size(), out); }
+
+}  // namespace palace_host
+
+// ------------------------------------------------------------------------------------------------
+// Streaming FASTQ ingest for the executables: the file is mapped, cut into parts of a few MiB at line
+// boundaries, and every part is scanned by a pool of threads -- first for its line / sequence-line / sequence-byte counts
+// under each of the four possible line phases (so the parts can be placed without a serial pass), then to copy its
+// sequence lines to their final place in a staging buffer.  Same getline semantics as parse_fastq above.
+// ------------------------------------------------------------------------------------------------
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <functional>
+
+namespace palace_host {
+
+struct MappedText {
+    const char *data = nullptr;
+    size_t size = 0;
+    MappedText() = default;
+    explicit MappedText(const std::string &path) { open(path); }
+    void open(const std::string &path)
+    {
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + path);
+        struct stat st;
+        if (::fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("cannot open " + path); }
+        size = static_cast<size_t>(st.st_size);
+        if (size) {
+            void *m = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); throw std::runtime_error("cannot read " + path); }
+            data = static_cast<const char *>(m);
+        }
+        ::close(fd);
+    }
+    ~MappedText() { if (data) ::munmap(const_cast<char *>(data), size); }
+    MappedText(const MappedText &) = delete;
+    MappedText &operator=(const MappedText &) = delete;
+};
+
+// run f(i) for i in [0, n) on `threads` threads (dynamic hand-out, small n per call is fine)
+inline void pool_for(size_t n, int threads, const std::function<void(size_t)> &f)
+{
+    threads = std::max(1, std::min<int>(threads, static_cast<int>(std::max<size_t>(1, n))));
+    if (threads == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
+    for (auto &th : pool) th.join();
+}
+
+struct FastqPart {
+    size_t a = 0, b = 0;                 // text range, starts at a line start
+    int64_t lines = 0;
+    int64_t n_by_phase[4] = {0, 0, 0, 0}, bytes_by_phase[4] = {0, 0, 0, 0};   // lines with (local index & 3) == c
+    int64_t line0 = 0, read0 = 0, byte0 = 0;                                  // after place(): global bases of this part
+    int64_t n_seq() const { return n_by_phase[(1 - line0) & 3]; }
+    int64_t seq_bytes() const { return bytes_by_phase[(1 - line0) & 3]; }
+};
+
+struct FastqPlan {
+    const MappedText *txt = nullptr;
+    std::vector<FastqPart> parts;
+    int64_t n_reads = 0, n_bases = 0;
+};
+
+// pass 1: cut + count.  part_bytes: target text size of a part.
+inline void plan_fastq(const MappedText &txt, int threads, FastqPlan &plan, size_t part_bytes = 4u << 20)
+{
+    plan.txt = &txt;
+    plan.parts.clear();
+    const size_t N = txt.size;
+    for (size_t p = 0; p < N;) {
+        size_t q = std::min(N, p + part_bytes);
+        if (q < N) {
+            const void *nl = std::memchr(txt.data + q, '\n', N - q);
+            q = nl ? static_cast<const char *>(nl) - txt.data + 1 : N;
+        }
+        FastqPart part;
+        part.a = p; part.b = q;
+        plan.parts.push_back(part);
+        p = q;
+    }
+    pool_for(plan.parts.size(), threads, [&](size_t i) {
+        FastqPart &pt = plan.parts[i];
+        int64_t l = 0;
+        for (size_t p = pt.a; p < pt.b; l++) {
+            const void *nl = std::memchr(txt.data + p, '\n', pt.b - p);
+            const size_t e = nl ? static_cast<const char *>(nl) - txt.data : pt.b;
+            pt.n_by_phase[l & 3]++;
+            pt.bytes_by_phase[l & 3] += static_cast<int64_t>(e - p);
+            p = nl ? e + 1 : pt.b;
+        }
+        pt.lines = l;
+    });
+    int64_t line = 0, read = 0, byte = 0;
+    for (FastqPart &pt : plan.parts) {
+        pt.line0 = line; pt.read0 = read; pt.byte0 = byte;
+        line += pt.lines; read += pt.n_seq(); byte += pt.seq_bytes();
+    }
+    plan.n_reads = read; plan.n_bases = byte;
+}
+
+// pass 2 for one part: its sequence lines go to bases_dst + (byte0 - bytes_base); offsets_dst[read0 + i + 1] gets the
+// GLOBAL end offset (offset_base + byte0 + ...) of its i-th read.
+inline void extract_fastq_part(const FastqPlan &plan, size_t i, uint8_t *bases_dst, int64_t bytes_base, int64_t *offsets_dst,
+                               int64_t offset_base)
+{
+    const FastqPart &pt = plan.parts[i];
+    const char *d = plan.txt->data;
+    uint8_t *w = bases_dst + (pt.byte0 - bytes_base);
+    int64_t at = offset_base + pt.byte0, r = pt.read0, l = pt.line0;
+    for (size_t p = pt.a; p < pt.b; l++) {
+        const void *nl = std::memchr(d + p, '\n', pt.b - p);
+        const size_t e = nl ? static_cast<const char *>(nl) - d : pt.b;
+        if ((l & 3) == 1) {
+            std::memcpy(w, d + p, e - p);
+            w += e - p;
+            at += static_cast<int64_t>(e - p);
+            offsets_dst[++r] = at;
+        }
+        p = nl ? e + 1 : pt.b;
+    }
 }
 
 }  // namespace palace_host

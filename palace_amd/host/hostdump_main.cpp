@@ -1,7 +1,7 @@
 // hostdump -- prints what the host-side parsers hand to the GPU, as text (no GPU needed).
 // Test tool for the CPU test suite:
 //   hostdump bam   <file.bam>          header + one line per record (decoded columns + parsed SA items)
-//   hostdump fastq <file.fq> <threads> one line per sequence line
+//   hostdump fastq <file.fq> <threads> [part_bytes]  one line per sequence line
 //   hostdump fasta <file.fa>           one line per record (ordinal, name, length, sequence)
 #include <cstdio>
 #include <cstring>
@@ -32,10 +32,17 @@ int main(int argc, char **argv)
                 std::printf("\n");
             }
         } else if (mode == "fastq") {
-            SeqSet rs;
-            parse_fastq(read_file(argv[2]), argc > 3 ? std::atoi(argv[3]) : 1, rs);
-            for (int64_t i = 0; i < rs.n(); i++) {
-                std::fwrite(rs.bases.data() + rs.offsets[i], 1, static_cast<size_t>(rs.len(i)), stdout);
+            // the executable's own ingest path: mapped file, parts, two passes (fastx.hpp); optional 4th argument =
+            // part size in bytes, so that tests can force many parts on a small file
+            const int threads = argc > 3 ? std::atoi(argv[3]) : 1;
+            MappedText txt(argv[2]);
+            FastqPlan plan;
+            plan_fastq(txt, threads, plan, argc > 4 ? static_cast<size_t>(std::atol(argv[4])) : (4u << 20));
+            std::vector<uint8_t> bases(static_cast<size_t>(plan.n_bases) + 1);
+            std::vector<int64_t> off(static_cast<size_t>(plan.n_reads) + 1, 0);
+            pool_for(plan.parts.size(), threads, [&](size_t i) { extract_fastq_part(plan, i, bases.data(), 0, off.data(), 0); });
+            for (int64_t i = 0; i < plan.n_reads; i++) {
+                std::fwrite(bases.data() + off[i], 1, static_cast<size_t>(off[i + 1] - off[i]), stdout);
                 std::fputc('\n', stdout);
             }
         } else if (mode == "fasta") {

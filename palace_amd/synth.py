@@ -421,3 +421,59 @@ def filter_side_files(rng, names, lens, ref_names=("phageA", "phageB", "phageC")
                 paths.append(",".join(toks) + "\n")
     return dict(fasta_fai=fasta_fai, blast="".join(blast), hit_seqs=hit, node_scores="".join(scores),
                 contigs_paths="".join(paths))
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE config[1]: 50k contigs / 5k-phage ref DB (eref side), vectorised so it is quick at 200 Mb
+# --------------------------------------------------------------------------------------
+def eref_config_inputs(seed: int = 20261003, n_refs: int = 5000, n_pairs: int = 166_666, read_len: int = 150,
+                       pool_bases: int = 60_000_000, arrays: bool = False, n_present: int | None = None,
+                       n_phage_pairs: int | None = None):
+    """Phage DB + read pairs of the 50k-contig configuration (3.33 read pairs per contig as in SURVEY.md section 8(d):
+    5e8 fq1 bases per 1M contigs): refs U[20 kb, 60 kb]; 1 % of them present, covered by a fifth of the pairs with
+    0.5 % substitutions; the rest of the pairs from a random contig pool.  Returns (fasta_bytes, fq1_bytes, fq2_bytes), or
+    with arrays=True also (refs: list of base arrays, r1, r2: [n_pairs, read_len] base matrices in file order).
+    tools/ref_compare_eref.py and tests/golden/make_eref_50k_golden.py feed exactly these bytes to the compiled
+    reference; tests regenerate them from the seed."""
+    rng = rng_for(seed)
+    lens = rng.integers(20000, 60001, size=n_refs)
+    refs = [random_dna(rng, int(L)) for L in lens]
+    fa = []
+    for i, s in enumerate(refs):
+        b = s.tobytes()
+        fa.append(b">phage_%d synthetic\n" % (i + 1) + b"\n".join(b[k:k + 80] for k in range(0, len(b), 80)) + b"\n")
+    present = rng.choice(n_refs, size=max(1, n_refs // 100) if n_present is None else n_present, replace=False)
+    pool = random_dna(rng, pool_bases)
+    n_ph = n_pairs // 5 if n_phage_pairs is None else n_phage_pairs
+    ar = np.arange(read_len)
+
+    def cut(src, st):
+        return src[st[:, None] + ar[None, :]]
+
+    ins = np.clip(rng.normal(400, 40, size=n_pairs), read_len, 800).astype(np.int64)
+    st_pool = rng.integers(0, len(pool) - 1000, size=n_pairs - n_ph)
+    r1 = [cut(pool, st_pool)]
+    r2 = [cut(pool, st_pool + ins[: n_pairs - n_ph] - read_len)]
+    which = rng.integers(0, len(present), size=n_ph)
+    a1 = np.zeros((n_ph, read_len), dtype=np.uint8)
+    a2 = np.zeros((n_ph, read_len), dtype=np.uint8)
+    for k in range(len(present)):
+        idx = np.nonzero(which == k)[0]
+        s = refs[present[k]]
+        st = rng.integers(0, len(s) - 900, size=len(idx))
+        a1[idx] = cut(s, st)
+        a2[idx] = cut(s, st + ins[n_pairs - n_ph:][idx] - read_len)
+    for a in (a1, a2):
+        m = rng.random(a.shape) < 0.005
+        a[m] = ACGT[rng.integers(0, 4, size=int(m.sum()))]
+    r1 = np.concatenate(r1 + [a1])
+    r2 = _COMP[np.concatenate(r2 + [a2])[:, ::-1]]
+    perm = rng.permutation(n_pairs)
+    q = b"I" * read_len
+    fq = []
+    r1, r2 = r1[perm], r2[perm]
+    for tag, arr in ((b"1", r1), (b"2", r2)):
+        fq.append(b"".join(b"@r%d/%s\n" % (i, tag) + arr[i].tobytes() + b"\n+\n" + q + b"\n" for i in range(n_pairs)))
+    if arrays:
+        return b"".join(fa), fq[0], fq[1], refs, r1, r2
+    return b"".join(fa), fq[0], fq[1]

@@ -1,0 +1,254 @@
+"""BASELINE.json configs at their own size on one MI355X (driver-visible: these run in `pytest -m gpu`).
+
+  configs[1]  50k contigs / 5k-phage ref DB: the eref CLI and the C ABI (unindexed and indexed scan) against stdout,
+              index file and genome.len file of the COMPILED REFERENCE run on the same bytes (tests/golden/eref_50k.npz,
+              made by tests/golden/make_eref_50k_golden.py in the build container).
+  configs[3]  5M contigs (33 M reads, 5 Gbase) on ONE GPU: the slab path at its default slab size -- order independence,
+              equality with direct-mode counting on a slab-sized part.  (The 8-GPU leg is the driver's SCALE run.)
+  configs[4]  long contigs (100k contigs, N50 ~ 50 kb, tail > 120 kb): generateGraph through the C ABI at full size, a
+              60k-record part compared exactly with the oracle (exp-underflow candidates present), shard independence.
+"""
+import ctypes
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+from palace_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "palace_amd", "bin")
+
+
+# ------------------------------------------------------------------------------------------------
+# configs[1]
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def cfg1(tmp_path_factory):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "eref_50k.npz"))
+    seed, n_refs, n_pairs = (int(x) for x in g["params"])
+    fa, fq1, fq2, refs, r1, r2 = synth.eref_config_inputs(seed, n_refs, n_pairs, arrays=True)
+    for key, b in (("sha256_db_fa", fa), ("sha256_fq1", fq1), ("sha256_fq2", fq2)):
+        assert hashlib.sha256(b).hexdigest() == str(g[key]), f"regenerated input differs from the one the reference ran on ({key})"
+    d = tmp_path_factory.mktemp("cfg1")
+    for name, b in (("db.fa", fa), ("r_1.fq", fq1), ("r_2.fq", fq2)):
+        open(d / name, "wb").write(b)
+    open(d / "coder.hdr", "wb").write(g["index_header"].tobytes())
+    return g, d, refs, r1, r2
+
+
+def lines_from_rows(rows):
+    out = []
+    for i, (n_int, el, ln, _) in enumerate(rows.tolist()):
+        if el > 0 and np.float32(el) / np.float32(ln) > np.float32(0.75):
+            out.append(orc.format_line(i + 1, n_int, el, ln))
+    return b"".join(out)
+
+
+def test_config1_cli_equals_reference(cfg1):
+    g, d, *_ = cfg1
+    args = [os.path.join(BIN, "eref"), str(d / "r_1.fq"), str(d / "r_2.fq"), str(d / "db.fa"), str(d / "tmp.txt")]
+    # first run: no index beside the DB -> built with the coder the reference drew, then used
+    p = subprocess.run(args + ["0.9", "0.85", "8"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, PALACE_CODER_HEADER=str(d / "coder.hdr")))
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == g["stdout_090_085"].tobytes()
+    h = hashlib.sha256()
+    with open(str(d / "db.fa") + ".k32.index.dat", "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    assert h.hexdigest() == str(g["index_sha256"])                      # the 2.4 GB index file, byte for byte
+    assert hashlib.sha256(open(str(d / "db.fa") + ".genome.len.txt", "rb").read()).hexdigest() == str(g["genome_len_sha256"])
+    # second run: the index is found and only its header is read
+    p = subprocess.run(args + ["0.8", "0.5", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == g["stdout_080_050"].tobytes()
+
+
+def test_config1_c_abi_equals_reference(cfg1):
+    g, d, refs, r1, r2 = cfg1
+    ref_off = np.zeros(len(refs) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in refs], out=ref_off[1:])
+    ref_bases = np.concatenate(refs)
+    n, L = r1.shape
+    off = np.arange(n + 1, dtype=np.int64) * L
+    with capi.Ctx(0) as ctx:
+        ctx.eref_set_coder(g["index_header"])
+        ctx.eref_table_reset()
+        for r in (r1, r2):
+            db, do = ctx.upload(np.ascontiguousarray(r).reshape(-1)), ctx.upload(off)
+            ctx.eref_count_reads(db, do, n)
+            ctx.sync()
+            db.free(); do.free()
+        rb, ro = ctx.upload(ref_bases), ctx.upload(ref_off)
+        ix = ctx.eref_probe_index_build(rb, ro, len(refs), len(ref_bases))
+        for key, hr, pr in (("stdout_090_085", 0.9, 0.85), ("stdout_080_050", 0.8, 0.5)):
+            one_min, three_min = capi.window_minimums(hr, pr)
+            rows, rows_ix = ctx.empty((len(refs), 4), np.int32), ctx.empty((len(refs), 4), np.int32)
+            ctx.eref_scan_refs(rb, ro, len(refs), len(ref_bases), one_min, three_min, rows)
+            ctx.eref_scan_refs_indexed(ix, rb, ro, len(refs), len(ref_bases), one_min, three_min, rows_ix)
+            a, b = rows.to_host(), rows_ix.to_host()
+            assert np.array_equal(a, b)
+            assert lines_from_rows(a) == g[key].tobytes()
+        ctx.eref_probe_index_free(ix)
+
+
+# ------------------------------------------------------------------------------------------------
+# configs[3]: 5M-contig scale on one GPU
+# ------------------------------------------------------------------------------------------------
+def test_config3_5m_contig_scale_slab_path():
+    import torch
+
+    import bench
+    from palace_amd import coder
+    dev = torch.device("cuda", 0)
+    sample = bench.make_sample(torch, dev, 5_000_000, 5000)             # 33.3 M reads x 150 bp = 5 Gbase
+    torch.cuda.synchronize()
+    n_side, P = sample["n_reads_side"], (lambda t: t.data_ptr())
+    tot = n_side * bench.READ_LEN
+    assert 2 * tot > (1 << 32)                                          # several slabs at either default slab size
+    hdr = coder.header_from_picks(np.random.Generator(np.random.PCG64(1)).integers(0, 6, size=32))
+    L = capi.lib()
+    probe = np.unique(np.random.Generator(np.random.PCG64(2)).integers(0, 2**32, size=400000, dtype=np.uint64).astype(np.uint32))
+    off_side = sample["read_off"][: n_side + 1].contiguous()
+    with capi.Ctx(0) as ctx:
+        ctx.eref_set_coder(hdr)
+
+        def run(calls):
+            ctx.eref_table_reset()
+            for bases, offs, n, total in calls:
+                capi._check(L.palace_eref_count_reads(ctx.h, P(bases), P(offs), n, None, total), "count")
+            ctx.sync()
+            return ctx.eref_table_popcounts(), ctx.eref_table_lookup(probe)
+
+        both = run([(sample["r12"], sample["read_off"], 2 * n_side, 2 * tot)])        # one launch, default slabs
+        assert both[0][0] > both[0][1] > both[0][2] > 0
+        # order independence and additivity across calls: side 2 then side 1, each in its own slabs
+        swapped = run([(sample["r2"], off_side, n_side, tot), (sample["r1"], off_side, n_side, tot)])
+        assert both[0] == swapped[0] and np.array_equal(both[1], swapped[1])
+        # a different slab size cuts the position range elsewhere: same table
+        ctx.eref_set_option("slab_bases", 3 * (1 << 28))
+        resliced = run([(sample["r12"], sample["read_off"], 2 * n_side, 2 * tot)])
+        ctx.eref_set_option("slab_bases", 0)
+        assert both[0] == resliced[0] and np.array_equal(both[1], resliced[1])
+        # a slab-sized part (2^30 bases) through the partition kernels == the same part through direct global atomics
+        n_part = (1 << 30) // bench.READ_LEN
+        part = (sample["r12"], sample["read_off"], n_part, n_part * bench.READ_LEN)
+        binned = run([part])
+        ctx.eref_set_count_mode(1, 0)
+        direct = run([part])
+        ctx.eref_set_count_mode(0, 0)
+        assert binned[0] == direct[0] and np.array_equal(binned[1], direct[1])
+    del sample
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------
+# configs[4]: long contigs
+# ------------------------------------------------------------------------------------------------
+def graph_on_gpu(ctx, gs, lo, hi, shards=1):
+    """classify records [lo, hi) of the sample (in `shards` shards with their ordinal bases), resolve, copy numbers."""
+    import torch
+    L, P = capi.lib(), (lambda t: t.data_ptr())
+    nt = len(gs["names"])
+    dev = gs["tlen"].device
+    consumed = torch.zeros(nt, dtype=torch.int64, device=dev)
+    n = hi - lo
+    cap = n + gs["n_sa"] + 1
+    cands = torch.zeros((cap, 64), dtype=torch.uint8, device=dev)
+    edges = torch.zeros((cap, 32), dtype=torch.uint8, device=dev)
+    cn = torch.zeros(nt, dtype=torch.int32, device=dev)
+    prm = capi.GraphParams.default()
+    n_total = 0
+    for s in range(shards):
+        a, b = lo + n * s // shards, lo + n * (s + 1) // shards
+        sa_lo = int(gs["sa_off"][a].item())
+        sa_local = (gs["sa_off"][a:b + 1] - sa_lo).contiguous()   # (kept alive until the call has finished)
+        cols = capi.BamCols(b - a, *(P(gs["col"][k][a:b]) for k in ("tid", "pos", "mtid", "mpos", "nm", "ref_len", "read_len",
+                                                                 "clip_s", "clip_e", "flag", "mapq", "qkey")), P(sa_local))
+        keep = [cols, sa_local]
+        n_c = ctypes.c_int64()
+        capi._check(L.palace_graph_classify(ctx.h, ctypes.byref(cols), P(gs["sa"][sa_lo:]), nt, P(gs["tlen"]), P(gs["trank"]),
+                                            P(gs["fastg"]), gs["n_fastg"], ctypes.byref(prm), a - lo, P(consumed),
+                                            P(cands[n_total:]), cap - n_total, ctypes.byref(n_c)), "classify")
+        ctx.sync()
+        n_total += n_c.value
+        del keep
+    h_cands = cands[:n_total].cpu().numpy().view(capi.CAND_DTYPE).reshape(-1).copy()
+    n_e = ctypes.c_int64()
+    capi._check(L.palace_graph_resolve(ctx.h, P(cands), n_total, n, ctypes.byref(prm), P(consumed), P(edges), cap, ctypes.byref(n_e)), "resolve")
+    capi._check(L.palace_graph_copy_numbers(ctx.h, P(consumed), P(gs["tlen"]), nt, gs["avg_depth"], P(cn)), "cn")
+    ctx.sync()
+    e = edges[: n_e.value].cpu().numpy().view(capi.EDGE_DTYPE).reshape(-1)
+    key = (e["left"].astype(np.int64) << 34) | (e["right"].astype(np.int64) << 2) | (e["oL"].astype(np.int64) << 1) | e["oR"]
+    return consumed.cpu().numpy(), cn.cpu().numpy(), e[np.argsort(key)], h_cands
+
+
+def graph_text(names, lens, cons, cn, edges):
+    order = np.argsort(np.array(names, dtype="S"))
+    rank = np.empty(len(names), dtype=np.int64)
+    rank[order] = np.arange(len(names))
+    out = ["SEG %s %s %d\n" % (names[i], "%g" % (cons[i] / max(1, lens[i])), cn[i]) for i in order]
+    for left, right, counts, oL, oR, _ in sorted(edges.tolist(), key=lambda e: (rank[e[0]], rank[e[1]], e[3], e[4])):
+        supp, supp_nf, span, span_nf = counts
+        if supp + supp_nf + span + span_nf >= 5:
+            out.append("JUNC %s %s %s %s %d %d\n" % (names[left], "+-"[oL], names[right], "+-"[oR], supp + span + supp_nf, span_nf))
+    return "".join(out)
+
+
+def test_config4_long_contigs_full_size_and_oracle_sample(tmp_path):
+    import torch
+
+    import bench
+    from palace_amd.synth import BamRecord
+    dev = torch.device("cuda", 0)
+    n_contigs, n_pairs = 100_000, 3_333_333
+    gs = bench.make_graph_sample(torch, dev, n_contigs, n_pairs, long_mode=True)
+    torch.cuda.synchronize()
+    names, lens = gs["names"], gs["lens"]
+    assert (lens > 120_000).sum() > 1000 and np.sort(lens)[::-1].cumsum().searchsorted(lens.sum() / 2) < n_contigs // 3   # N50 far above the median
+    with capi.Ctx(0) as ctx:
+        # ---- full size (6.67 M records): one shot == four shards with ordinal bases ----
+        cons1, cn1, e1, c1 = graph_on_gpu(ctx, gs, 0, gs["n"])
+        cons4, cn4, e4, _ = graph_on_gpu(ctx, gs, 0, gs["n"], shards=4)
+        assert np.array_equal(cons1, cons4) and np.array_equal(cn1, cn4)
+        assert e1.tobytes() == e4.tobytes() and len(e1) > 1000
+        gate = (c1["cls"] == 2).sum()                                   # decided by host libm: the exp-underflow zone
+        assert gate > 1000, gate
+        far = (c1["dL"].astype(np.int64) + c1["dR"]) > 120_000           # well inside the zone: exp() is 0, evidence rejected
+        assert far.sum() > 1000
+        assert int(cons1.sum()) >= int(gs["col"]["ref_len"].sum().item())   # depth: every primary record (+ the mate quirk)
+        # ---- a 60k-record part, exactly, against the oracle ----
+        m = 60_000
+        lo = int(torch.nonzero(gs["col"]["tid"] == int(np.argmax(lens))).min().item())   # starts on the longest contig
+        lo = max(0, min(lo, gs["n"] - m))
+        cons, cn, edges, cs = graph_on_gpu(ctx, gs, lo, lo + m)
+        assert (cs["cls"] == 2).sum() > 0
+    c = {k: v[lo:lo + m].cpu().numpy() for k, v in gs["col"].items()}
+    so = gs["sa_off"][lo:lo + m + 1].cpu().numpy()
+    sa = gs["sa"].cpu().numpy()
+    recs = []
+    for i in range(m):
+        s_txt = None
+        if so[i + 1] > so[i]:
+            it = sa[so[i]]
+            s_txt = f"{names[it[0]]},{it[1]},{'-' if it[7] else '+'},{it[4]}S{it[6] - it[4]}M,{it[2]},{it[3]};"
+        cig = f"{c['ref_len'][i]}M{c['clip_e'][i]}S" if c["clip_e"][i] else "150M"
+        recs.append(BamRecord(f"q{c['qkey'][i] & 0xffffffffffff:x}", int(c["flag"][i]) & 0xffff, int(c["tid"][i]), int(c["pos"][i]),
+                              int(c["mapq"][i]), cig, int(c["mtid"][i]), int(c["mpos"][i]), nm=int(c["nm"][i]), sa=s_txt))
+    fai = str(tmp_path / "g.fastg.fai")
+    a, b, o1, o2 = gs["fastg_links"]
+    touched = set(c["tid"].tolist()) | set(c["mtid"].tolist()) | {int(x) for x in sa[so[0]:so[-1], 0]}
+    q = "'"
+    with open(fai, "w") as f:
+        for x, y, u, v in zip(a.tolist(), b.tolist(), o1.tolist(), o2.tolist()):
+            if x in touched or y in touched:
+                f.write(f"{names[x]}{q if u else ''}:{names[y]}{q if (u ^ v) else ''};\t{lens[x]}\t0\t60\t61\n")
+    want = orc.graph_run(recs, list(zip(names, lens.tolist())), fai, gs["avg_depth"]).decode()
+    assert graph_text(names, lens, cons, cn, edges) == want
+    assert want.count("JUNC") > 0

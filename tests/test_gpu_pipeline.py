@@ -55,7 +55,7 @@ def test_stage4_chain_equals_oracle_chain(tmp_path):
 def test_bench_exchange_path_rehearsal():
     """world_size 1 over RCCL: same results as the plain single-GPU run."""
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--contigs", "20000", "--refs", "200", "--steps", "1",
-            "--warmup", "0", "--no-cpu-baseline"]
+            "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--soak-seconds", "0"]
     a = json.loads(sh(base).decode().strip().splitlines()[-1])
     b = json.loads(sh(base, env=dict(os.environ, PALACE_FORCE_EXCHANGE="1")).decode().strip().splitlines()[-1])
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
@@ -68,12 +68,26 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(world, port):
     """The N-rank step (world 2: every rank counts all reads, Phase B / generateGraph / gathers sharded; world 4: reads
     sharded too, count-table exchange + merge) with all ranks on GPU 0 and the collectives over gloo (RCCL refuses two
     ranks on one device): the same refs and the same graph as the single-process run."""
-    size = ["--contigs", "20000", "--refs", "200", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    size = ["--contigs", "20000", "--refs", "200", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--soak-seconds", "0"]
     a = json.loads(sh([sys.executable, os.path.join(ROOT, "bench.py")] + size).decode().strip().splitlines()[-1])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + size
     out = sh(cmd, env=dict(os.environ, PALACE_BENCH_ONE_DEVICE="1", PALACE_BENCH_BACKEND="gloo")).decode()
     b = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
     assert b["n_gpus"] == world
+    assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
+    assert a["config"]["graph"] == b["config"]["graph"]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the ranks are started as child processes (before the parent
+    touches a GPU), rank 0's JSON line comes through and the exit status is theirs.  Rehearsed on one GPU over gloo."""
+    size = ["--contigs", "20000", "--refs", "200", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--soak-seconds", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PALACE_BENCH_ONE_DEVICE="1", PALACE_BENCH_BACKEND="gloo")
+    a = json.loads(sh([sys.executable, os.path.join(ROOT, "bench.py")] + size).decode().strip().splitlines()[-1])
+    out = sh([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + size, env=env).decode()
+    b = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 2
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
     assert a["config"]["graph"] == b["config"]["graph"]

@@ -121,12 +121,15 @@ def test_fastq_line_semantics(tmp_path):
     want = b"".join(l + b"\n" for i, l in enumerate(lines) if i % 4 == 1)
     for threads in ("1", "3", "16"):
         assert dump("fastq", p, threads) == want
+        for part_bytes in ("1", "7", "40"):                  # many parts: every line phase at a part start
+            assert dump("fastq", p, threads, part_bytes) == want
     # a bigger file: chunking over threads must not change anything
     rng = synth.rng_for(2)
     rs = synth.vector_reads(rng, synth.random_dna(rng, 50000), 2000, 77)
     rs.write_fastq(str(tmp_path / "b.fq"), "1")
     one = dump("fastq", str(tmp_path / "b.fq"), "1")
     assert one == dump("fastq", str(tmp_path / "b.fq"), "7") and one.count(b"\n") == 2000
+    assert one == dump("fastq", str(tmp_path / "b.fq"), "5", "1000")
 
 
 def test_fasta_record_semantics(tmp_path):
@@ -140,3 +143,48 @@ def test_fasta_record_semantics(tmp_path):
     got = [l.split(b"\t") for l in dump("fasta", p).split(b"\n") if l]
     assert got == [[b"0", b"start", b"8", b"ACGTACGT"], [b"1", b"one", b"8", b"ACGTACGT"], [b"2", b"two", b"5", b"NNNN\r"],
                    [b"3", b"", b"0", b""], [b"4", b"four", b"4", b"acgt"]]
+
+
+def test_synthbam_round_trip(tmp_path):
+    """bench.py's end-to-end leg writes its BAM with palace_amd/bin/synthbam (columns -> file); what the product's reader
+    decodes from that file must be the columns again."""
+    import numpy as np
+    subprocess.run(["make", "-C", os.path.join(ROOT, "palace_amd", "host"), os.path.join("..", "bin", "synthbam")], check=True,
+                   stdout=subprocess.DEVNULL)
+    rng = synth.rng_for(5)
+    n, nt = 5000, 40
+    names = [f"EDGE_{i}_length_{1000 + i}_cov_1.5" for i in range(nt)]
+    d = tmp_path / "cols"
+    d.mkdir()
+    open(d / "targets.tsv", "w").write("".join(f"{nm}\t{1000 + i}\n" for i, nm in enumerate(names)))
+    col = dict(tid=rng.integers(0, nt, n), pos=rng.integers(0, 900, n), mtid=rng.integers(-1, nt, n), mpos=rng.integers(-1, 900, n),
+               nm=rng.integers(0, 9, n), ref_len=np.full(n, 150), clip_e=np.zeros(n, dtype=np.int64))
+    has_sa = rng.random(n) < 0.2
+    col["ref_len"][has_sa] = 90
+    col["clip_e"][has_sa] = 60
+    sa_off = np.zeros(n + 1, dtype=np.int32)
+    sa_off[1:] = np.cumsum(has_sa)
+    m = int(sa_off[-1])
+    sa = np.stack([rng.integers(0, nt, m), rng.integers(1, 900, m), rng.integers(0, 61, m), rng.integers(0, 5, m),
+                   np.full(m, 90), np.zeros(m, dtype=np.int64), np.full(m, 150), rng.integers(0, 2, m)], axis=1).astype(np.int32)
+    flag = rng.integers(0, 256, n).astype(np.uint16)
+    mapq = rng.integers(0, 61, n).astype(np.uint8)
+    qkey = rng.integers(0, 1 << 62, n).astype(np.uint64)
+    for k, v in col.items():
+        v.astype(np.int32).tofile(d / f"{k}.i32")
+    sa_off.tofile(d / "sa_off.i32"); sa.tofile(d / "sa.i32"); flag.tofile(d / "flag.u16"); mapq.tofile(d / "mapq.u8"); qkey.tofile(d / "qkey.u64")
+    bam = str(tmp_path / "s.bam")
+    subprocess.run([os.path.join(ROOT, "palace_amd", "bin", "synthbam"), str(d), bam, "3", "1"], check=True)
+    body = [l.split("\t") for l in dump("bam", bam, "2").decode().split("\n") if l and not l.startswith("@SQ")]
+    assert len(body) == n
+    k = 0
+    for i, f in enumerate(body):
+        want = [f"q{int(qkey[i]) & 0xffffffffffff:x}", flag[i], col["tid"][i], col["pos"][i], mapq[i], col["mtid"][i], col["mpos"][i], col["nm"][i],
+                col["ref_len"][i], 150, 0, col["clip_e"][i]]
+        assert f[:12] == [str(x) for x in want], (i, f)
+        if has_sa[i]:
+            s = sa[k]; k += 1
+            tid2 = -1 if s[0] == col["tid"][i] else s[0]
+            assert f[12:] == [f"SA:{tid2},{s[1]},{s[7]},{s[2]},{s[3]},90,0,150"], (i, f)
+        else:
+            assert len(f) == 12
