@@ -8,6 +8,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <memory>
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
@@ -62,9 +64,10 @@ void parallel_for(size_t n, int threads, F f)
 // BGZF: gzip members with a BC extra subfield carrying the member size (SAM spec 4.1).  Every field that comes from the
 // file is checked against the file before it is used: a member is 12 + XLEN header bytes, the deflate stream and an
 // 8-byte trailer, BSIZE + 1 bytes in all, and holds at most 64 KiB of data.
-void inflate_bgzf(const uint8_t *file, size_t file_size, int threads, std::vector<uint8_t> &out)
+struct Block { size_t in_off, in_len, out_off, out_len; };
+
+std::vector<Block> index_bgzf(const uint8_t *file, size_t file_size, size_t *total_out)
 {
-    struct Block { size_t in_off, in_len, out_off, out_len; };
     std::vector<Block> blocks;
     size_t p = 0, total = 0;
     while (p + 18 <= file_size) {
@@ -86,25 +89,8 @@ void inflate_bgzf(const uint8_t *file, size_t file_size, int threads, std::vecto
         total += isize;
         p += bsize;
     }
-    out.resize(total);
-    std::atomic<bool> bad{false};
-    parallel_for(blocks.size(), threads, [&](size_t a, size_t b, int) {
-        z_stream zs{};
-        if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
-        for (size_t i = a; i < b && !bad; i++) {
-            const Block &k = blocks[i];
-            if (!k.out_len) continue;
-            if (inflateReset(&zs) != Z_OK) { bad = true; break; }
-            zs.next_in = const_cast<Bytef *>(file + k.in_off);
-            zs.avail_in = static_cast<uInt>(k.in_len);
-            zs.next_out = out.data() + k.out_off;
-            zs.avail_out = static_cast<uInt>(k.out_len);
-            const int rc = inflate(&zs, Z_FINISH);
-            if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = true; break; }
-        }
-        inflateEnd(&zs);
-    });
-    if (bad) throw std::runtime_error("BGZF inflate failed");
+    *total_out = total;
+    return blocks;
 }
 
 // One CIGAR as parseCigarReadInterval sees it (generate_graph.cpp:330-366): zero-length ops are
@@ -217,33 +203,121 @@ void rekey(BamColumns &c, uint64_t seed)
         c.qkey[i] = name_key(reinterpret_cast<const char *>(c.raw.data()) + c.qname_at[i], c.qname_len[i], seed);
 }
 
-void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumns &c)
-{
+// The loader as a pipeline (the reference streams the file through htslib, generate_graph.cpp:644):
+//   inflate workers   take the BGZF members round-robin, so the inflated stream grows from the front;
+//   load_bam_begin    returns as soon as the members that hold the header are there and the header is parsed -- the caller
+//                     can start what depends on the target names only (name ranks, FASTG keys) beside the rest;
+//   load_bam_finish   walks the record boundaries behind the inflate front (that walk is serial: a record's size is its
+//                     first word), then decodes the records on all threads.
+struct BamLoad {
+    std::unique_ptr<MappedFile> file;
+    std::vector<Block> blocks;
+    std::unique_ptr<std::atomic<uint8_t>[]> done;
+    std::vector<std::thread> workers;
+    std::atomic<bool> bad{false};
+    BamColumns *c = nullptr;
+    int threads = 1;
+    size_t ready_blocks = 0;             // members [0, ready_blocks) are inflated
+    size_t first_record = 0;             // offset of the first alignment record in the inflated stream
+    int32_t n_ref = 0;
+
+    // bytes of the inflated stream that are final: everything in front of the first member still missing.  Blocks
+    // until at least `need` bytes are there (or everything that will ever come is).
+    size_t wait_for(size_t need)
     {
-        MappedFile file(path);
-        inflate_bgzf(file.data, file.size, threads, c.raw);
+        for (;;) {
+            while (ready_blocks < blocks.size() && done[ready_blocks].load(std::memory_order_acquire)) ready_blocks++;
+            const size_t have = ready_blocks < blocks.size() ? blocks[ready_blocks].out_off : c->raw.size();
+            if (have >= need || ready_blocks == blocks.size()) return have;
+            if (bad) throw std::runtime_error("BGZF inflate failed");
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
     }
+    ~BamLoad()
+    {
+        for (auto &t : workers) if (t.joinable()) t.join();
+    }
+};
+
+BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c)
+{
+    std::unique_ptr<BamLoad> L(new BamLoad());
+    L->c = &c;
+    L->threads = threads = std::max(1, threads);
+    L->file.reset(new MappedFile(path));
+    size_t total = 0;
+    L->blocks = index_bgzf(L->file->data, L->file->size, &total);
+    c.raw.alloc(total);
+    const size_t nb = L->blocks.size();
+    L->done.reset(new std::atomic<uint8_t>[nb ? nb : 1]);
+    for (size_t i = 0; i < nb; i++) L->done[i].store(0, std::memory_order_relaxed);
+    BamLoad *ld = L.get();
+    for (int t = 0; t < threads; t++)
+        L->workers.emplace_back([ld, t, threads, nb] {
+            z_stream zs{};
+            if (inflateInit2(&zs, -15) != Z_OK) { ld->bad = true; return; }
+            uint8_t *out = ld->c->raw.data();
+            for (size_t i = static_cast<size_t>(t); i < nb && !ld->bad; i += static_cast<size_t>(threads)) {
+                const Block &k = ld->blocks[i];
+                if (k.out_len) {
+                    if (inflateReset(&zs) != Z_OK) { ld->bad = true; break; }
+                    zs.next_in = const_cast<Bytef *>(ld->file->data + k.in_off);
+                    zs.avail_in = static_cast<uInt>(k.in_len);
+                    zs.next_out = out + k.out_off;
+                    zs.avail_out = static_cast<uInt>(k.out_len);
+                    if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) { ld->bad = true; break; }
+                }
+                ld->done[i].store(1, std::memory_order_release);
+            }
+            inflateEnd(&zs);
+        });
+    // ---- header (BAM spec 4.2): magic, l_text, text, n_ref, then (l_name, name, l_ref) per reference ----
     const uint8_t *d = c.raw.data();
-    const size_t N = c.raw.size();
-    if (N < 12 || std::memcmp(d, "BAM\1", 4) != 0) throw std::runtime_error("Failed to read BAM header");
-    size_t p = 8 + le32(d + 4);
-    if (p + 4 > N) throw std::runtime_error("Failed to read BAM header");
-    int32_t n_ref = static_cast<int32_t>(le32(d + p));
+    auto need = [&](size_t upto) {
+        if (L->wait_for(upto) < upto) throw std::runtime_error("Failed to read BAM header");
+    };
+    need(12);
+    if (std::memcmp(d, "BAM\1", 4) != 0) throw std::runtime_error("Failed to read BAM header");
+    size_t p = 8 + static_cast<size_t>(le32(d + 4));
+    need(p + 4);
+    const int32_t n_ref = static_cast<int32_t>(le32(d + p));
     p += 4;
     for (int32_t i = 0; i < n_ref; i++) {
-        if (p + 4 > N) throw std::runtime_error("Failed to read BAM header");
-        uint32_t l = le32(d + p);
-        if (p + 4 + l + 4 > N) throw std::runtime_error("Failed to read BAM header");
+        need(p + 4);
+        const size_t l = le32(d + p);
+        need(p + 4 + l + 4);
         std::string nm(reinterpret_cast<const char *>(d + p + 4), l ? l - 1 : 0);
         c.target_name.push_back(nm);
         c.target_len.push_back(static_cast<int32_t>(le32(d + p + 4 + l)));
         c.name_to_tid[nm] = i;
         p += 8 + l;
     }
+    L->first_record = p;
+    L->n_ref = n_ref;
+    return L.release();
+}
+
+void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumns &c)
+{
+    load_bam_finish(load_bam_begin(path, threads, c), key_seed);
+}
+
+void load_bam_finish(BamLoad *load, uint64_t key_seed)
+{
+    std::unique_ptr<BamLoad> L(load);
+    BamColumns &c = *L->c;
+    const int32_t n_ref = L->n_ref;
+    int threads = L->threads;
+    const uint8_t *d = c.raw.data();
+    // ---- record boundaries, behind the inflate front ----
     std::vector<uint64_t> rec_at;
-    while (p + 4 <= N) {
+    rec_at.reserve(c.raw.size() / 300 + 16);
+    size_t p = L->first_record, have = L->wait_for(p + 4);
+    for (;;) {
+        if (p + 4 > have) { have = L->wait_for(p + 4); if (p + 4 > have) break; }
         const size_t bs = le32(d + p);
-        if (bs < 32 || bs > N - p - 4) break;                   // truncated tail: stop like a failed sam_read1
+        if (bs < 32) break;                                       // truncated tail: stop like a failed sam_read1
+        if (p + 4 + bs > have) { have = L->wait_for(p + 4 + bs); if (p + 4 + bs > have) break; }
         // the variable-length fields must fit the record (htslib's bam_read1 fails on such a record, which ends the
         // reference's `while (sam_read1(...) >= 0)` loop at generate_graph.cpp:644): name, CIGAR, packed bases, qualities
         const uint8_t *r = d + p + 4;
@@ -252,6 +326,9 @@ void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumn
         rec_at.push_back(p + 4);
         p += 4 + bs;
     }
+    for (auto &t : L->workers) t.join();                          // (members behind a malformed record are still inflated)
+    if (L->bad) throw std::runtime_error("BGZF inflate failed");
+    L->file.reset();
     const size_t n = rec_at.size();
     for (auto *v : {&c.tid, &c.pos, &c.mtid, &c.mpos, &c.nm, &c.ref_len, &c.read_len, &c.clip_s, &c.clip_e})
         v->assign(n, 0);

@@ -4,6 +4,7 @@
 // (generate_graph.cpp:611-698); written against the SAM/BAM specification, not against htslib.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -11,6 +12,16 @@
 #include "../../include/palace_hip.h"
 
 namespace palace_host {
+
+// the inflated stream: allocated once, not zero-filled (the inflate threads are the first to touch its pages)
+struct RawBuf {
+    std::unique_ptr<uint8_t[]> p;
+    size_t n = 0;
+    void alloc(size_t bytes) { p.reset(new uint8_t[bytes ? bytes : 1]); n = bytes; }
+    uint8_t *data() { return p.get(); }
+    const uint8_t *data() const { return p.get(); }
+    size_t size() const { return n; }
+};
 
 struct BamColumns {
     // header
@@ -24,7 +35,7 @@ struct BamColumns {
     std::vector<uint64_t> qkey;
     std::vector<palace_sa_item> sa;
     // read names stay in the inflated stream; (offset, length) per record for the exactness guard
-    std::vector<uint8_t> raw;
+    RawBuf raw;
     std::vector<uint64_t> qname_at;
     std::vector<uint8_t> qname_len;
     int64_t n() const { return static_cast<int64_t>(flag.size()); }
@@ -39,6 +50,11 @@ uint64_t name_key(const char *s, size_t n, uint64_t seed);
 
 // Reads, inflates (threads) and decodes a whole BAM file.  Throws std::runtime_error.
 void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumns &out);
+// The same in two steps: begin() returns once the header (target names and lengths, name_to_tid) is in `out`, with the
+// inflate threads still running; finish() delivers the records.  `out` must stay where it is in between.
+struct BamLoad;
+BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &out);
+void load_bam_finish(BamLoad *load, uint64_t key_seed);
 
 // Re-key every read name with another seed (collision escape hatch).
 void rekey(BamColumns &cols, uint64_t key_seed);

@@ -19,6 +19,7 @@
 
 #include "../../include/palace_hip.h"
 #include "fastx.hpp"
+#include "trace.hpp"
 
 using namespace palace_host;
 
@@ -120,6 +121,7 @@ int main(int argc, char **argv)
     const int window = 500;
     const int one_min = window * hit_ratio, three_min = window * perfect_ratio;   // :513-514
 
+    Trace tr("eref");
     // The HIP runtime comes up (device, stream, 3 x 512 MiB of planes zeroed) on its own thread while this one maps and
     // scans the text inputs: neither waits for the other (the reference, too, reads with T threads per phase, :1267-1291).
     palace_ctx *ctx = nullptr;
@@ -158,12 +160,14 @@ int main(int argc, char **argv)
             db.ordinal.push_back(i);                     // position in db_all
         }
     }
+    tr.lap("fasta parsed");
     const int64_t n_refs = db.n();
     std::vector<int64_t> idx_off(n_refs + 1, 0);
     for (int64_t r = 0; r < n_refs; r++) idx_off[r + 1] = idx_off[r] + 3 * (db.len(r) - 31);
     const uint64_t index_bytes = 400 + 4ull * n_refs + 4ull * static_cast<uint64_t>(idx_off[n_refs]);
 
     hip_up.join();
+    tr.lap("hip runtime up (joined)");
     if (ctx_rc) { std::cerr << "eref: cannot set up the GPU: " << ctx_err << "\n"; fq_scan.join(); return 1; }
     uint8_t *d_ref = nullptr; int64_t *d_ref_off = nullptr;
     CK(upload(ctx, db.bases.data(), db.bases.size(), &d_ref));
@@ -210,7 +214,9 @@ int main(int argc, char **argv)
     // kernels then run once and every plane slice is loaded and stored once.  Pass 2 over the text copies the sequence
     // lines of a run of parts straight to their place in a page-locked staging buffer (all threads), which goes to the
     // device with an asynchronous copy while the other staging buffer is being filled.
+    tr.lap("refs uploaded / index ready");
     fq_scan.join();
+    tr.lap("fastq pass 1 (joined)");
     if (!in_err.empty()) { std::cerr << "eref: " << in_err << "\n"; return 1; }
     const int64_t n_reads = plan[0].n_reads + plan[1].n_reads, n_bases = plan[0].n_bases + plan[1].n_bases;
     long sample = static_cast<long>(plan[0].n_bases) * 2;                       // cal_sam_ratio (:1124-1148)
@@ -225,10 +231,12 @@ int main(int argc, char **argv)
         CK(palace_malloc(ctx, static_cast<size_t>(n_bases) + 64, &p)); d_b = static_cast<uint8_t *>(p);
         CK(palace_malloc(ctx, static_cast<size_t>(n_reads + 1) * 8, &p)); d_o = static_cast<int64_t *>(p);
     }
+    tr.lap("device buffers");
     std::vector<int64_t> offsets(static_cast<size_t>(n_reads) + 1, 0);
     constexpr int64_t kStage = 96ll << 20;
     uint8_t *stage[2] = {nullptr, nullptr};
     for (int k = 0; k < 2; k++) { void *p = nullptr; CK(palace_host_alloc(ctx, static_cast<size_t>(kStage), &p)); stage[k] = static_cast<uint8_t *>(p); }
+    tr.lap("pinned staging");
     int n_sent = 0;
     for (int side = 0; side < 2; side++) {
         const FastqPlan &pl = plan[side];
@@ -255,7 +263,9 @@ int main(int argc, char **argv)
             i0 = i1;
         }
     }
+    tr.lap("fastq pass 2 + staged h2d");
     CK(palace_h2d(ctx, d_o, offsets.data(), offsets.size() * 8));               // (also waits for the staged copies)
+    tr.lap("offsets h2d");
     if (down_sam_ratio < 100) {                                                 // one draw per sequence line, file order (:955-960)
         GlibcRand rng(1);                                                       // :1239-1240
         std::vector<uint8_t> keep(static_cast<size_t>(n_reads));
@@ -263,6 +273,7 @@ int main(int argc, char **argv)
         CK(upload(ctx, keep.data(), keep.size(), &d_k));
     }
     if (n_reads) CK(palace_eref_count_reads(ctx, d_b, d_o, n_reads, d_k, n_bases));
+    tr.lap("count_reads enqueued");
     for (int k = 0; k < 2; k++) CK(palace_host_free(ctx, stage[k]));
     CK(palace_free(ctx, d_b)); CK(palace_free(ctx, d_o)); CK(palace_free(ctx, d_k));
     for (int side = 0; side < 2; side++) plan[side].parts.clear();
@@ -276,7 +287,9 @@ int main(int argc, char **argv)
                                  static_cast<int32_t *>(p)));
         CK(palace_d2h(ctx, rows.data(), p, rows.size() * 4));
     }
+    tr.lap("scan_refs + rows d2h");
     palace_ctx_destroy(ctx);
+    tr.lap("ctx destroyed");
 
     { std::ofstream trunc(interval_name, std::ios::out | std::ios::trunc); }   // :825, :899 (left empty)
     std::string out;
@@ -289,5 +302,6 @@ int main(int argc, char **argv)
                                            static_cast<double>(ratio)));
     }
     std::fwrite(out.data(), 1, out.size(), stdout);
+    tr.lap("stdout");
     return 0;
 }

@@ -5,6 +5,7 @@
 // per-evidence work runs in HIP through libpalace_hip.so (palace_graph_classify / _resolve);
 // there is no CPU path for it.
 #include <getopt.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -15,11 +16,14 @@
 #include <iostream>
 #include <numeric>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <unordered_map>
 #include <vector>
 
 #include "bam.hpp"
+#include "fastx.hpp"
+#include "trace.hpp"
 
 using namespace palace_host;
 
@@ -61,43 +65,89 @@ int upload(palace_ctx *ctx, const std::vector<T> &v, T **d)
     return palace_h2d(ctx, p, v.data(), v.size() * sizeof(T));
 }
 
-// parseFastgFile (generate_graph.cpp:119-169) reduced to the pairs whose two names are BAM targets
-std::vector<uint64_t> fastg_keys(const std::string &path, const BamColumns &c)
+// parseFastgFile (generate_graph.cpp:119-169) reduced to the pairs whose two names are BAM targets.  The file is mapped
+// and cut into parts at line ends; every part is parsed by a thread with string views (no per-line allocation).
+std::vector<uint64_t> fastg_keys(const std::string &path, const BamColumns &c, int threads)
 {
-    std::vector<uint64_t> keys;
-    std::ifstream in(path);
-    std::string line;
-    auto tid_of = [&](const std::string &n) -> int64_t {
-        auto it = c.name_to_tid.find(n);
-        return it == c.name_to_tid.end() ? -1 : it->second;
+    MappedText txt;
+    try { txt.open(path); } catch (const std::exception &) { return {}; }     // the reference reads an unopenable file as empty
+    std::unordered_map<std::string_view, int32_t> tid_of;
+    tid_of.reserve(c.target_name.size() * 2);
+    for (size_t i = 0; i < c.target_name.size(); i++) tid_of[std::string_view(c.target_name[i])] = static_cast<int32_t>(i);   // last duplicate wins (:624-627)
+    auto lookup = [&](std::string_view n) -> int64_t {
+        auto it = tid_of.find(n);
+        return it == tid_of.end() ? -1 : it->second;
     };
-    while (std::getline(in, line)) {
-        size_t semi = line.find(';');
-        std::string head = line.substr(0, semi);
-        size_t colon = head.find(':');
-        if (colon == std::string::npos) continue;
-        std::string name = head.substr(0, colon);
-        bool rev = !name.empty() && name.back() == '\'';
-        if (rev) name.pop_back();
-        int64_t a = tid_of(name);
-        size_t p = colon + 1;
-        while (p < head.size()) {
-            size_t comma = head.find(',', p);
-            std::string lk = head.substr(p, comma == std::string::npos ? std::string::npos : comma - p);
-            p = comma == std::string::npos ? head.size() : comma + 1;
-            if (lk.empty()) continue;
-            bool lrev = lk.back() == '\'';
-            if (lrev) lk.pop_back();
-            int64_t b = tid_of(lk);
-            if (a < 0 || b < 0) continue;
-            uint64_t o1 = rev ? 1 : 0, o2 = (rev != lrev) ? 1 : 0;       // :151-157
-            keys.push_back((static_cast<uint64_t>(a) << 33) | (static_cast<uint64_t>(b) << 2) | (o1 << 1) | o2);
-            keys.push_back((static_cast<uint64_t>(b) << 33) | (static_cast<uint64_t>(a) << 2) | ((o1 ^ 1) << 1) | (o2 ^ 1));
-        }
+    const size_t N = txt.size;
+    std::vector<size_t> cut{0};
+    const size_t n_parts = static_cast<size_t>(std::max(1, threads)) * 4;
+    for (size_t k = 1; k < n_parts; k++) {
+        size_t p = std::max(cut.back(), N * k / n_parts);
+        const void *nl = p < N ? std::memchr(txt.data + p, '\n', N - p) : nullptr;
+        cut.push_back(nl ? static_cast<const char *>(nl) - txt.data + 1 : N);
     }
+    cut.push_back(N);
+    std::vector<std::vector<uint64_t>> part(cut.size() - 1);
+    pool_for(part.size(), threads, [&](size_t k) {
+        auto &keys = part[k];
+        for (size_t p = cut[k]; p < cut[k + 1];) {
+            const void *nl = std::memchr(txt.data + p, '\n', cut[k + 1] - p);
+            const size_t e = nl ? static_cast<const char *>(nl) - txt.data : cut[k + 1];
+            std::string_view line(txt.data + p, e - p);
+            p = nl ? e + 1 : cut[k + 1];
+            std::string_view head = line.substr(0, line.find(';'));           // getline(ss, fullName, ';')
+            const size_t colon = head.find(':');
+            if (colon == std::string_view::npos) continue;                     // no linked contigs
+            std::string_view name = head.substr(0, colon);
+            const bool rev = !name.empty() && name.back() == '\'';
+            if (rev) name.remove_suffix(1);
+            const int64_t a = lookup(name);
+            for (size_t q = colon + 1; q < head.size();) {
+                const size_t comma = head.find(',', q);
+                std::string_view lk = head.substr(q, comma == std::string_view::npos ? std::string_view::npos : comma - q);
+                q = comma == std::string_view::npos ? head.size() : comma + 1;
+                if (lk.empty()) continue;
+                const bool lrev = lk.back() == '\'';
+                if (lrev) lk.remove_suffix(1);
+                const int64_t b = lookup(lk);
+                if (a < 0 || b < 0) continue;
+                const uint64_t o1 = rev ? 1 : 0, o2 = (rev != lrev) ? 1 : 0;  // :151-157
+                keys.push_back((static_cast<uint64_t>(a) << 33) | (static_cast<uint64_t>(b) << 2) | (o1 << 1) | o2);
+                keys.push_back((static_cast<uint64_t>(b) << 33) | (static_cast<uint64_t>(a) << 2) | ((o1 ^ 1) << 1) | (o2 ^ 1));
+            }
+        }
+    });
+    std::vector<uint64_t> keys;
+    for (auto &v : part) keys.insert(keys.end(), v.begin(), v.end());
     std::sort(keys.begin(), keys.end());
     keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
     return keys;
+}
+
+// dense rank of every target name in byte order (the `cR < cL` test :856 and the output order :1048): sort by the first
+// eight bytes as one big-endian word, finish ties with the full comparison
+void name_ranks(const std::vector<std::string> &names, std::vector<int32_t> &by_name, std::vector<int32_t> &rank)
+{
+    const int32_t nt = static_cast<int32_t>(names.size());
+    std::vector<std::pair<uint64_t, int32_t>> key(static_cast<size_t>(nt));
+    for (int32_t i = 0; i < nt; i++) {
+        uint64_t k = 0;
+        const std::string &s = names[static_cast<size_t>(i)];
+        for (size_t b = 0; b < 8; b++) k = (k << 8) | (b < s.size() ? static_cast<unsigned char>(s[b]) : 0);
+        key[static_cast<size_t>(i)] = {k, i};
+    }
+    std::sort(key.begin(), key.end(), [&](const std::pair<uint64_t, int32_t> &a, const std::pair<uint64_t, int32_t> &b) {
+        if (a.first != b.first) return a.first < b.first;
+        const int c = names[static_cast<size_t>(a.second)].compare(names[static_cast<size_t>(b.second)]);
+        return c != 0 ? c < 0 : a.second < b.second;
+    });
+    by_name.resize(static_cast<size_t>(nt));
+    rank.assign(static_cast<size_t>(nt), 0);
+    for (int32_t k = 0, r = -1; k < nt; k++) {
+        by_name[static_cast<size_t>(k)] = key[static_cast<size_t>(k)].second;
+        if (k == 0 || names[static_cast<size_t>(by_name[k])] != names[static_cast<size_t>(by_name[k - 1])]) r++;
+        rank[static_cast<size_t>(by_name[k])] = r;
+    }
 }
 
 }  // namespace
@@ -138,28 +188,47 @@ int main(int argc, char **argv)
     const std::string bam_path = argv[optind], fai_path = argv[optind + 1], out_path = argv[optind + 2];
     const double avg_depth = std::atof(argv[optind + 3]);
 
+    Trace tr("generateGraph");
     BamColumns c;
     const int threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     uint64_t seed = 1;
+    BamLoad *load = nullptr;
     try {
-        load_bam(bam_path, threads, seed, c);
+        load = load_bam_begin(bam_path, threads, c);             // header parsed, the rest of the file is being inflated
     } catch (const std::exception &e) {
         std::cerr << e.what() << "\n";
         return 1;
     }
+    tr.lap("bam header");
     const int32_t nt = static_cast<int32_t>(c.target_name.size());
-    // dense rank of every target name in byte order: the `cR < cL` test and the output order
-    std::vector<int32_t> by_name(nt), rank(nt, 0);
-    std::iota(by_name.begin(), by_name.end(), 0);
-    std::sort(by_name.begin(), by_name.end(), [&](int32_t a, int32_t b) { return c.target_name[a] < c.target_name[b]; });
-    for (int32_t k = 0, r = -1; k < nt; k++) {
-        if (k == 0 || c.target_name[by_name[k]] != c.target_name[by_name[k - 1]]) r++;
-        rank[by_name[k]] = r;
-    }
-    std::vector<uint64_t> fkeys = fastg_keys(fai_path, c);
-
+    // what depends on the target names only runs beside the inflate / decode of the records: the name ranks, the FASTG
+    // keys, and the HIP runtime coming up
+    std::vector<int32_t> by_name, rank;
+    std::vector<uint64_t> fkeys;
     palace_ctx *ctx = nullptr;
-    CK(palace_ctx_create(0, &ctx));
+    int ctx_rc = 0;
+    std::string ctx_err;
+    std::thread side([&] {
+        name_ranks(c.target_name, by_name, rank);
+        fkeys = fastg_keys(fai_path, c, 4);
+    });
+    std::thread hip_up([&] {
+        ctx_rc = palace_ctx_create(0, &ctx);
+        if (ctx_rc) ctx_err = palace_last_error();
+    });
+    try {
+        load_bam_finish(load, seed);
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << "\n";
+        side.join(); hip_up.join();
+        return 1;
+    }
+    tr.lap("bam records");
+    side.join();
+    tr.lap("name ranks + fastg keys (joined)");
+    hip_up.join();
+    if (ctx_rc) { std::cerr << "generateGraph: cannot set up the GPU: " << ctx_err << "\n"; return 1; }
+    tr.lap("hip runtime up (joined)");
     palace_bam_cols cols{};
     cols.n = c.n();
     int32_t *d_tid, *d_pos, *d_mtid, *d_mpos, *d_nm, *d_rl, *d_ql, *d_cs, *d_ce, *d_sao, *d_tlen, *d_rank;
@@ -180,6 +249,7 @@ int main(int argc, char **argv)
     CK(palace_malloc(ctx, static_cast<size_t>(cand_cap) * sizeof(palace_graph_cand), &p));
     palace_graph_cand *d_cands = static_cast<palace_graph_cand *>(p);
 
+    tr.lap("uploads");
     std::vector<palace_graph_cand> cands;
     int64_t n_cands = 0;
     for (int attempt = 0;; attempt++) {
@@ -201,6 +271,7 @@ int main(int argc, char **argv)
         rekey(c, ++seed);
         CK(palace_h2d(ctx, d_qkey, c.qkey.data(), c.qkey.size() * 8));
     }
+    tr.lap("classify + name guard");
     CK(palace_malloc(ctx, static_cast<size_t>(std::max<int64_t>(1, n_cands)) * sizeof(palace_graph_edge), &p));
     palace_graph_edge *d_edges = static_cast<palace_graph_edge *>(p);
     int64_t n_edges = 0;
@@ -213,30 +284,44 @@ int main(int argc, char **argv)
     CK(palace_d2h(ctx, cn_dev.data(), p, cn_dev.size() * 4));
     CK(palace_d2h(ctx, consumed.data(), d_consumed, consumed.size() * 8));
     CK(palace_d2h(ctx, edges.data(), d_edges, edges.size() * sizeof(palace_graph_edge)));
+    tr.lap("resolve + d2h");
     palace_ctx_destroy(ctx);
+    tr.lap("ctx destroy");
 
     // ---- text output (generate_graph.cpp:1019-1076) ----
     FILE *out = std::fopen(out_path.c_str(), "w");
     if (!out) { std::cerr << "Failed to open output " << out_path << "\n"; return 1; }
     std::vector<char> big(1 << 22);
     std::setvbuf(out, big.data(), _IOFBF, big.size());
-    for (int32_t k = 0; k < nt; k++) {
-        // std::map keeps one entry per distinct name; a later duplicate overwrites an earlier one (:1033)
-        if (k + 1 < nt && rank[by_name[k + 1]] == rank[by_name[k]]) continue;
-        int32_t best = -1;
-        for (int32_t j = k; j >= 0 && rank[by_name[j]] == rank[by_name[k]]; j--)
-            if (c.target_len[by_name[j]] > 0) best = std::max(best, by_name[j]);
-        if (best < 0) continue;                                       // L <= 0 targets are skipped (:1023)
-        // refConsumed is keyed by NAME (:631, :659): duplicates share one sum
-        double sum = 0.0;
-        for (int32_t j = k; j >= 0 && rank[by_name[j]] == rank[by_name[k]]; j--) sum += static_cast<double>(consumed[by_name[j]]);
-        const int32_t L = c.target_len[best];
-        const double depth = sum / std::max(1, L);
-        const bool unique_name = (k == 0 || rank[by_name[k - 1]] != rank[by_name[k]]);
-        const double cnf = avg_depth > 0.0 ? depth / avg_depth : 0.0;
-        const int cn = unique_name ? cn_dev[best] : static_cast<int>(std::floor(cnf + 0.5));   // device value; host only for duplicate names
-        std::fprintf(out, "SEG %s %g %d\n", c.target_name[best].c_str(), depth, cn);
-    }
+    // SEG lines in name order; formatted by all threads (a slice of the order each), written in order
+    std::vector<std::string> seg_text(static_cast<size_t>(threads) * 4);
+    pool_for(seg_text.size(), threads, [&](size_t part) {
+        std::string &txt = seg_text[part];
+        char line[512];
+        const int32_t k0 = static_cast<int32_t>(static_cast<int64_t>(nt) * part / seg_text.size());
+        const int32_t k1 = static_cast<int32_t>(static_cast<int64_t>(nt) * (part + 1) / seg_text.size());
+        txt.reserve(static_cast<size_t>(k1 - k0) * 48);
+        for (int32_t k = k0; k < k1; k++) {
+            // std::map keeps one entry per distinct name; a later duplicate overwrites an earlier one (:1033)
+            if (k + 1 < nt && rank[by_name[k + 1]] == rank[by_name[k]]) continue;
+            int32_t best = -1;
+            for (int32_t j = k; j >= 0 && rank[by_name[j]] == rank[by_name[k]]; j--)
+                if (c.target_len[by_name[j]] > 0) best = std::max(best, by_name[j]);
+            if (best < 0) continue;                                       // L <= 0 targets are skipped (:1023)
+            // refConsumed is keyed by NAME (:631, :659): duplicates share one sum
+            double sum = 0.0;
+            for (int32_t j = k; j >= 0 && rank[by_name[j]] == rank[by_name[k]]; j--) sum += static_cast<double>(consumed[by_name[j]]);
+            const int32_t L = c.target_len[best];
+            const double depth = sum / std::max(1, L);
+            const bool unique_name = (k == 0 || rank[by_name[k - 1]] != rank[by_name[k]]);
+            const double cnf = avg_depth > 0.0 ? depth / avg_depth : 0.0;
+            const int cn = unique_name ? cn_dev[best] : static_cast<int>(std::floor(cnf + 0.5));   // device value; host only for duplicate names
+            const std::string &nm = c.target_name[best];
+            if (nm.size() < 400) txt.append(line, static_cast<size_t>(std::snprintf(line, sizeof line, "SEG %s %g %d\n", nm.c_str(), depth, cn)));
+            else { txt += "SEG " + nm; txt.append(line, static_cast<size_t>(std::snprintf(line, sizeof line, " %g %d\n", depth, cn))); }
+        }
+    });
+    for (const std::string &txt : seg_text) std::fwrite(txt.data(), 1, txt.size(), out);
     std::sort(edges.begin(), edges.end(), [&](const palace_graph_edge &a, const palace_graph_edge &b) {
         if (rank[a.left] != rank[b.left]) return rank[a.left] < rank[b.left];
         if (rank[a.right] != rank[b.right]) return rank[a.right] < rank[b.right];
@@ -251,5 +336,7 @@ int main(int argc, char **argv)
                      c.target_name[e.right].c_str(), e.oR ? '-' : '+', supp + span + supp_nf, span_nf);
     }
     std::fclose(out);
-    return 0;
+    tr.lap("text output");
+    std::fflush(nullptr);
+    _exit(0);                   // the output is complete and closed: skip tearing down gigabytes of host containers
 }

@@ -16,11 +16,14 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <unistd.h>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
 #include "../../include/palace_hip.h"
+#include "trace.hpp"
 
 namespace {
 
@@ -153,10 +156,19 @@ int main(int argc, char **argv)
                      "[-l <contigs.paths>] [--aggressive]\n";
         return 1;
     }
+    palace_host::Trace tr("matching");
+    palace_ctx *ctx = nullptr;                                // the HIP runtime comes up while the graph text is read
+    int ctx_rc = 0;
+    std::string ctx_err;
+    std::thread hip_up([&] {
+        ctx_rc = palace_ctx_create(0, &ctx);
+        if (ctx_rc) ctx_err = palace_last_error();
+    });
     ConjGraph g;
     try {
         load_graph(g, opt);
-    } catch (const std::exception &e) { std::cerr << "matching: " << e.what() << "\n"; return 1; }
+    } catch (const std::exception &e) { std::cerr << "matching: " << e.what() << "\n"; hip_up.join(); return 1; }
+    tr.lap("graph + paths read");
     const int32_t S = static_cast<int32_t>(g.name.size()), V = 2 * S;
     for (Arc &a : g.arcs) {
         uint64_t k1 = static_cast<uint64_t>(a.u) * V + a.v, k2 = static_cast<uint64_t>(a.v ^ 1) * V + (a.u ^ 1);
@@ -172,10 +184,13 @@ int main(int argc, char **argv)
     std::vector<int32_t> src(E), dst(E);
     for (int64_t e = 0; e < E; e++) { src[e] = g.arcs[e].u; dst[e] = g.arcs[e].v; }
 
-    palace_ctx *ctx = nullptr;
-    CK(palace_ctx_create(0, &ctx));
+    tr.lap("arcs ranked");
+    hip_up.join();
+    if (ctx_rc) { std::cerr << "matching: cannot set up the GPU: " << ctx_err << "\n"; return 1; }
+    tr.lap("hip runtime up (joined)");
     palace_match_result *res = nullptr;
     CK(palace_match_decompose(ctx, S, g.copies.data(), E, src.data(), dst.data(), opt.iterations, opt.aggressive, &res));
+    tr.lap("decompose");
     palace_ctx_destroy(ctx);
 
     const int64_t n_comp = palace_match_result_count(res);
@@ -220,5 +235,8 @@ int main(int argc, char **argv)
     if (!fl || !fc) { std::cerr << "matching: cannot write outputs\n"; return 1; }
     fl << lin;
     fc << cyc;
-    return 0;
+    fl.close(); fc.close();
+    tr.lap("text output");
+    std::fflush(nullptr);
+    _exit(0);                   // outputs are complete and closed: skip the teardown of the host containers
 }

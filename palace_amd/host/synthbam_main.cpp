@@ -7,7 +7,8 @@
 // <dir> holds little-endian raw arrays, one file per column, n records each:
 //   tid.i32 pos.i32 mtid.i32 mpos.i32 nm.i32 ref_len.i32 clip_e.i32 sa_off.i32 (n+1) flag.u16 mapq.u8 qkey.u64
 //   sa.i32 (rows of 8: tid2 pos2 mapq2 nm2 clip_s2 clip_e2 len2 rev2)   targets.tsv (name \t length per line)
-// Record i: qname "q<qkey & 2^48-1 in hex>", CIGAR <ref_len>M[<clip_e>S], 150 bases, NM:C, SA:Z when it has items.
+// Record i: qname "q<qkey & 2^48-1 in hex>", CIGAR <ref_len>M[<clip_e>S], 150 pseudo-random bases + binned qualities,
+// NM:C, SA:Z when it has items.
 #include <zlib.h>
 
 #include <algorithm>
@@ -107,8 +108,18 @@ int main(int argc, char **argv)
             o.insert(o.end(), buf, buf + nl);
             if (clip_e[i]) { put32(o, (static_cast<uint32_t>(ref_len[i]) << 4) | 0); put32(o, (static_cast<uint32_t>(clip_e[i]) << 4) | 4); }
             else put32(o, (150u << 4) | 0);
-            o.insert(o.end(), (l_seq + 1) / 2, 0x11);
-            o.insert(o.end(), l_seq, 0x28);
+            // pseudo-random packed bases and Illumina-like binned qualities, so that the file compresses about as a real BAM
+            // does (constant bytes would make the BGZF inflate of the consumer unrealistically cheap)
+            uint64_t h = qkey[i] * 0x9e3779b97f4a7c15ull + flag[i];
+            for (int k = 0; k < (l_seq + 1) / 2; k++) {
+                h ^= h >> 29; h *= 0xbf58476d1ce4e5b9ull; h ^= h >> 32;
+                o.push_back(static_cast<uint8_t>((1u << (h & 3)) << 4 | (1u << ((h >> 2) & 3))));
+            }
+            static const uint8_t qbin[8] = {37, 37, 37, 37, 37, 25, 11, 2};
+            for (int k = 0; k < l_seq; k++) {
+                if ((k & 15) == 0) { h ^= h >> 31; h *= 0x94d049bb133111ebull; h ^= h >> 29; }
+                o.push_back(qbin[(h >> (4 * (k & 15))) & 7]);
+            }
             o.insert(o.end(), {'N', 'M', 'C', static_cast<uint8_t>(nm[i])});
             if (sa_off[i + 1] > sa_off[i]) {
                 o.insert(o.end(), {'S', 'A', 'Z'});

@@ -16,3 +16,19 @@ def pytest_configure(config):
 def golden_eref():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "eref_toy.npz"))
+
+
+def _torch_claims_the_gpu_first():
+    """Tests that use both torch (sample generation on the device) and libpalace_hip.so in one process: torch's bundled HIP
+    runtime has to be the one that is loaded -- if the library's first HIP call came first, the system runtime would be
+    loaded beside torch's and torch would later report that no device exists (measured: tools/dbg/torch_order.py).
+    bench.py imports torch first for the same reason.  Without a GPU this does nothing."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except ImportError:
+        pass
+
+
+_torch_claims_the_gpu_first()            # at import of conftest: before any test module can touch the library
