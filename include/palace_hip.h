@@ -87,6 +87,9 @@ int palace_eref_index_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_
  * asynchronous), or -1 to have it read back.
  * The table is held as three 2^32-bit planes "count >= 1 / >= 2 / >= 3". */
 int palace_eref_table_reset(palace_ctx *ctx);
+/* Optional: allocate the table and the scratch memory a count_reads call over `total_bases` bases will need now (tens of
+ * GB at a gigabase; the allocation alone can take from a millisecond to a second), e.g. while the caller is still parsing. */
+int palace_eref_reserve(palace_ctx *ctx, int64_t total_bases);
 int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets,
                             int64_t n_reads, const uint8_t *d_keep, int64_t total_bases);
 
@@ -231,6 +234,17 @@ int palace_graph_resolve(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_
  * cn = (int)floor(depth / avg_depth + 0.5) (0 when avg_depth <= 0), per target, in IEEE double. */
 int palace_graph_copy_numbers(palace_ctx *ctx, const uint64_t *d_consumed, const int32_t *d_tlen,
                               int32_t n_targets, double avg_depth, int32_t *d_cn);
+
+/* ---- depth stage: `samtools depth <bam> | awk '{sum+=$3} END {print sum/NR}'` (palace:538-552) ------------------ */
+
+/* The two numbers of that mean.  A match segment is one M / = / X CIGAR operation of a record whose UNMAP, SECONDARY,
+ * QCFAIL and DUP flags are clear (samtools depth, default options: deletions and reference skips do not count): target,
+ * 0-based reference position, length.  sum_out = total length of the segments (cut at the end of their contig),
+ * covered_out = number of distinct reference positions they cover = the NR of the awk line.  d_tbase[t] = sum of the
+ * lengths of targets 0..t-1 (int64, n_targets entries), total_len = sum of all lengths. */
+int palace_depth_sum_covered(palace_ctx *ctx, int64_t n_segs, const int32_t *d_seg_tid, const int32_t *d_seg_pos,
+                             const int32_t *d_seg_len, int32_t n_targets, const int32_t *d_tlen, const int64_t *d_tbase,
+                             int64_t total_len, uint64_t *sum_out, uint64_t *covered_out);
 
 /* ---- matching: path / cycle decomposition of the conjugate graph ------------------------- */
 

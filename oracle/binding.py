@@ -231,6 +231,18 @@ class GraphInput:
         return buf.raw[:got]
 
 
+def depth_mean(records, targets):
+    """-> (text awk would print, sum, NR) for `samtools depth | awk '{sum+=$3} END {print sum/NR}'` (palace:538-552)."""
+    gin = GraphInput(records, targets)
+    L = lib()
+    L.orc_depth_mean.restype = C.c_long
+    L.orc_depth_mean.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    buf = C.create_string_buffer(64)
+    s, nr = C.c_uint64(), C.c_uint64()
+    n = L.orc_depth_mean(C.byref(gin.R), gin.n_targets, gin.tlen.ctypes.data, buf, 64, C.byref(s), C.byref(nr))
+    return (None if n < 0 else buf.raw[:n].decode()), s.value, nr.value
+
+
 def graph_run(records, targets, fastg_fai: str, avg_depth: float, opts: GraphOpts | None = None) -> bytes:
     """records: list of palace_amd.synth.BamRecord (file order); targets: [(name, len)]."""
     return GraphInput(records, targets).run(fastg_fai, avg_depth, opts)

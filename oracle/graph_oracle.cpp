@@ -360,3 +360,43 @@ long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const
 }
 
 }  // extern "C"
+
+// ---- depth stage (palace:538-552): `samtools depth <bam> | awk '{sum+=$3} END { print sum/NR }'` ------------------------
+// Restated from the samtools documentation (samtools is not in this image: parity UNPINNED).  samtools depth with default
+// options (1.13 or later: no depth cap) prints one line per reference position whose depth is > 0; a record counts at the
+// positions of its M, = and X operations (deletions and reference skips only with -J), unless one of UNMAP (0x4),
+// SECONDARY (0x100), QCFAIL (0x200), DUP (0x400) is set.  Per-base counters, as the tool keeps them; the awk line then
+// divides the sum of column 3 by the number of lines.  Writes the text awk prints into `out` (integral values are printed
+// as integers, everything else with OFMT = "%.6g"); returns its length, or -1 when no line would exist (awk: division by zero).
+extern "C" long orc_depth_mean(const OrcRecords *R, int n_targets, const int32_t *tlen, char *out, size_t cap,
+                               uint64_t *sum_out, uint64_t *nr_out)
+{
+    std::vector<std::vector<uint32_t>> depth(static_cast<size_t>(n_targets));
+    for (int64_t i = 0; i < R->n; i++) {
+        if (R->flag[i] & 0x704) continue;
+        const int32_t t = R->tid[i];
+        if (t < 0 || t >= n_targets || R->pos[i] < 0) continue;
+        auto &d = depth[static_cast<size_t>(t)];
+        if (d.empty()) d.assign(static_cast<size_t>(std::max(0, tlen[t])), 0);
+        int64_t p = R->pos[i];
+        for (int64_t k = R->cigar_off[i]; k < R->cigar_off[i + 1]; k++) {
+            const uint32_t op = R->cigar[k] & 15, len = R->cigar[k] >> 4;
+            if (op == 0 || op == 7 || op == 8) {                        // M, =, X
+                for (int64_t q = p; q < p + len && q < static_cast<int64_t>(d.size()); q++) d[static_cast<size_t>(q)]++;
+                p += len;
+            } else if (op == 2 || op == 3) p += len;                     // D, N: reference advances, nothing counted
+        }
+    }
+    uint64_t sum = 0, nr = 0;
+    for (auto &d : depth)
+        for (uint32_t v : d)
+            if (v) { sum += v; nr++; }
+    if (sum_out) *sum_out = sum;
+    if (nr_out) *nr_out = nr;
+    if (nr == 0) return -1;
+    const double mean = static_cast<double>(sum) / static_cast<double>(nr);
+    int n;
+    if (mean == std::floor(mean) && std::fabs(mean) < 1e15) n = std::snprintf(out, cap, "%lld", static_cast<long long>(mean));
+    else n = std::snprintf(out, cap, "%.6g", mean);
+    return n;
+}

@@ -78,6 +78,7 @@ _SIGS = {
     "palace_eref_set_coder": [C.c_void_p, C.c_void_p],
     "palace_eref_index_refs": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     "palace_eref_table_reset": [C.c_void_p],
+    "palace_eref_reserve": [C.c_void_p, C.c_int64],
     "palace_eref_count_reads": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64],
     "palace_eref_set_count_mode": [C.c_void_p, C.c_int, C.c_int64],
     "palace_eref_set_option": [C.c_void_p, C.c_char_p, C.c_int64],
@@ -97,6 +98,8 @@ _SIGS = {
     "palace_graph_classify": [C.c_void_p, C.POINTER(BamCols), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_int64, C.POINTER(GraphParams), C.c_int64, C.c_void_p, C.c_void_p,
                               C.c_int64, C.POINTER(C.c_int64)],
+    "palace_depth_sum_covered": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "palace_graph_copy_numbers": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p],
     "palace_match_greedy": [C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 10 + [C.POINTER(C.c_int32)],
     "palace_match_arcs_from_edges": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,

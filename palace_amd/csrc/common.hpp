@@ -68,6 +68,7 @@ struct palace_ctx {
     int64_t bin_cap_override = 0;
     int64_t slab_override = 0;
     palace::Workspace ws;      // grow-only scratch
+    bool ws_grown = false;
     palace::Workspace pin;     // grow-only pinned host staging
     palace::MatchScratch *match_scratch = nullptr;
     uint64_t *d_small = nullptr;   // 64 x u64 scratch for reductions

@@ -22,7 +22,9 @@ int ensure_workspace(palace_ctx *ctx, size_t bytes)
         ctx->ws.ptr = nullptr;
         ctx->ws.bytes = 0;
     }
-    size_t want = bytes + bytes / 4 + (1 << 20);
+    // the first request is taken as it is (a one-shot executable would only waste the head room); later growth adds 25 %
+    size_t want = bytes + (ctx->ws_grown ? bytes / 4 : 0) + (1 << 20);
+    ctx->ws_grown = true;
     hipError_t e = hipMalloc(&ctx->ws.ptr, want);
     if (e != hipSuccess) {
         set_error("workspace hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));

@@ -1323,6 +1323,65 @@ int palace_eref_table_reset(palace_ctx *ctx)
     return PALACE_OK;
 }
 
+namespace {
+// Workspace of one count_reads call over `total_bases` positions: slab size, region capacities, byte counts.
+struct CountPlan {
+    int64_t slab_bases_max = 0, n_slabs = 0, n_chunks = 0;
+    DensityCaps caps1{}, caps2{};
+    size_t cur1_bytes = 0, cur2_bytes = 0, buf1_bytes = 0, buf2_bytes = 0, words_bytes = 0;
+    size_t total() const { return cur1_bytes + cur2_bytes + 7 * words_bytes + buf1_bytes + buf2_bytes; }
+};
+constexpr int64_t kRegions = static_cast<int64_t>(kL1Buckets) * kL1Replicas;
+
+int plan_count(palace_ctx *ctx, int64_t total_bases, CountPlan *pl)
+{
+    // Large read sets are processed in slabs of at most slab_bases_max positions (the planes accumulate across slabs),
+    // which bounds the workspace whatever the input size.  Slab size: 2^30 positions (workspace ~25 GB); 2^31 when the
+    // read set is larger than that AND the device has the room (~50 GB of workspace) -- every slab rewrites all plane
+    // slices once, so fewer slabs mean less traffic.
+    int64_t default_slab = 1ll << 30;
+    if (ctx->slab_override == 0 && total_bases > default_slab) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + ctx->ws.bytes >= (160ull << 30)) default_slab = 1ll << 31;
+    }
+    pl->slab_bases_max = ctx->slab_override > 0 ? ctx->slab_override : default_slab;   // multiple of 64
+    pl->n_slabs = (total_bases + pl->slab_bases_max - 1) / pl->slab_bases_max;
+    const int64_t slab_bases = std::min(total_bases, pl->slab_bases_max);
+    // capacities: the key upper bound of one slab (a position range) shared out by the key density with 20 % head
+    // room, plus a flat pad of 1/8 of the mean and a constant
+    const int64_t max_keys = 3 * slab_bases;
+    const int64_t mean1 = max_keys / kRegions, mean2 = max_keys / kFine / 2;    // mean2: in pairs of 16-bit keys
+    pl->caps1 = DensityCaps{static_cast<uint64_t>(mean1 + mean1 / 5) / 4, static_cast<uint32_t>(mean1 / 8 + 4096) / 4};   // per level-1 region
+    pl->caps2 = DensityCaps{static_cast<uint64_t>(mean2 + mean2 / 5) / 4, static_cast<uint32_t>(mean2 / 8 + 2048) / 4};   // per fine bucket
+    if (ctx->bin_cap_override > 0) {                       // test hook: uniform, deliberately small regions
+        pl->caps2 = DensityCaps{0, static_cast<uint32_t>((ctx->bin_cap_override + 3) / 4)};
+        pl->caps1 = DensityCaps{0, static_cast<uint32_t>(ctx->bin_cap_override)};
+    }
+    PALACE_REQUIRE(pl->caps1.cap(0) < (1u << 31) && pl->caps2.cap(0) < (1u << 30), "slab too large for 32-bit region cursors");
+    pl->cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
+    pl->cur2_bytes = align_up(kFine * sizeof(unsigned int), 256);
+    pl->buf1_bytes = align_up(static_cast<size_t>(pl->caps1.prefix(kL1Buckets)) * kL1Replicas * 4, 256);
+    pl->buf2_bytes = align_up(static_cast<size_t>(pl->caps2.prefix(kL1Buckets)) * kL2Rows * 4, 256);    // pairs of 2-byte keys
+    pl->n_chunks = (total_bases + 63) / 64;
+    pl->words_bytes = align_up(static_cast<size_t>(pl->n_chunks + 2) * 8, 256);       // one u64 per 64 positions (+ pad)
+    return PALACE_OK;
+}
+}  // namespace
+
+int palace_eref_reserve(palace_ctx *ctx, int64_t total_bases)
+{
+    PALACE_REQUIRE(ctx && total_bases >= 0, "bad argument");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_table(ctx);
+    if (rc) return rc;
+    const bool binned = ctx->count_mode == 2 || (ctx->count_mode == 0 && total_bases >= (1ll << 22));
+    if (!binned) return PALACE_OK;
+    CountPlan pl;
+    rc = plan_count(ctx, total_bases, &pl);
+    if (rc) return rc;
+    return ensure_workspace(ctx, pl.total());
+}
+
 int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets,
                             int64_t n_reads, const uint8_t *d_keep, int64_t total_bases)
 {
@@ -1354,37 +1413,15 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         PALACE_HIP_TRY(hipGetLastError());
         return PALACE_OK;
     }
-    // Large read sets are processed in slabs of at most kSlabBases positions (the planes accumulate across
-    // slabs), which bounds the workspace whatever the input size.
-    // Slab size: 2^30 positions (workspace ~40 GB); 2^31 when the read set is larger than that AND the device has the
-    // room (~80 GB of workspace) -- every slab rewrites all plane slices once, so fewer slabs mean less traffic.
-    int64_t default_slab = 1ll << 30;
-    if (ctx->slab_override == 0 && total_bases > default_slab) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + ctx->ws.bytes >= (160ull << 30)) default_slab = 1ll << 31;
-    }
-    const int64_t kSlabBases = ctx->slab_override > 0 ? ctx->slab_override : default_slab;   // multiple of 64
-    const int64_t n_slabs = (total_bases + kSlabBases - 1) / kSlabBases;
-    const int64_t slab_bases = std::min(total_bases, kSlabBases);
-    // capacities: the key upper bound of one slab (a position range) shared out by the key density with 20 % head
-    // room, plus a flat pad of 1/8 of the mean and a constant
-    const int64_t max_keys = 3 * slab_bases;
-    constexpr int64_t kRegions = static_cast<int64_t>(kL1Buckets) * kL1Replicas;
-    const int64_t mean1 = max_keys / kRegions, mean2 = max_keys / kFine / 2;    // mean2: in pairs of 16-bit keys
-    DensityCaps caps1{static_cast<uint64_t>(mean1 + mean1 / 5) / 4, static_cast<uint32_t>(mean1 / 8 + 4096) / 4};   // per level-1 region
-    DensityCaps caps2{static_cast<uint64_t>(mean2 + mean2 / 5) / 4, static_cast<uint32_t>(mean2 / 8 + 2048) / 4};   // per fine bucket
-    if (ctx->bin_cap_override > 0) {                       // test hook: uniform, deliberately small regions
-        caps2 = DensityCaps{0, static_cast<uint32_t>((ctx->bin_cap_override + 3) / 4)};
-        caps1 = DensityCaps{0, static_cast<uint32_t>(ctx->bin_cap_override)};
-    }
-    PALACE_REQUIRE(caps1.cap(0) < (1u << 31) && caps2.cap(0) < (1u << 31), "slab too large for 32-bit region cursors");
-    const size_t cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
-    const size_t cur2_bytes = align_up(kFine * sizeof(unsigned int), 256);
-    const size_t buf1_bytes = align_up(static_cast<size_t>(caps1.prefix(kL1Buckets)) * kL1Replicas * 4, 256);
-    const size_t buf2_bytes = align_up(static_cast<size_t>(caps2.prefix(kL1Buckets)) * kL2Rows * 4, 256);    // pairs of 2-byte keys
-    const int64_t n_chunks = (total_bases + 63) / 64;
-    const size_t words_bytes = align_up(static_cast<size_t>(n_chunks + 2) * 8, 256);       // one u64 per 64 positions (+ pad)
-    rc = ensure_workspace(ctx, cur1_bytes + cur2_bytes + 7 * words_bytes + buf1_bytes + buf2_bytes);
+    CountPlan pl;
+    rc = plan_count(ctx, total_bases, &pl);
+    if (rc) return rc;
+    const int64_t kSlabBases = pl.slab_bases_max, n_slabs = pl.n_slabs, n_chunks = pl.n_chunks;
+    const DensityCaps caps1 = pl.caps1, caps2 = pl.caps2;
+    const size_t cur1_bytes = pl.cur1_bytes, cur2_bytes = pl.cur2_bytes, buf1_bytes = pl.buf1_bytes, buf2_bytes = pl.buf2_bytes,
+                 words_bytes = pl.words_bytes;
+    (void)buf2_bytes;
+    rc = ensure_workspace(ctx, pl.total());
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
     unsigned int *cursor1 = reinterpret_cast<unsigned int *>(ws); ws += cur1_bytes;

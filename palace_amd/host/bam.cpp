@@ -282,6 +282,10 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c)
     need(p + 4);
     const int32_t n_ref = static_cast<int32_t>(le32(d + p));
     p += 4;
+    if (n_ref > 0) {                                             // (bounded by what the stream can hold: >= 9 bytes per reference)
+        const size_t cap = std::min<size_t>(static_cast<size_t>(n_ref), c.raw.size() / 9 + 1);
+        c.target_name.reserve(cap); c.target_len.reserve(cap); c.name_to_tid.reserve(cap);
+    }
     for (int32_t i = 0; i < n_ref; i++) {
         need(p + 4);
         const size_t l = le32(d + p);
@@ -337,6 +341,7 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
     c.qname_at.assign(n, 0); c.qname_len.assign(n, 0);
     threads = std::max(1, threads);
     std::vector<std::vector<palace_sa_item>> sa_part(static_cast<size_t>(threads));
+    std::vector<std::vector<int32_t>> ms_part(static_cast<size_t>(threads));        // (tid, pos, len) triples
     std::vector<int32_t> sa_cnt(n, 0);
     parallel_for(n, threads, [&](size_t a, size_t b, int t) {
         static const char opchr[] = "MIDNSHP=XB??????";
@@ -382,9 +387,14 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
             }
             int32_t rl = 0, ql = 0;
             OpScan sc;
+            const bool depth_counts = !(le16(r + 14) & 0x704) && tid >= 0 && tid < n_ref && static_cast<int32_t>(le32(r + 4)) >= 0;
             for (size_t k = 0; k < n_ops; k++) {
                 uint32_t v = le32(ops + 4 * k);
                 int op = v & 15, len = static_cast<int>(v >> 4);
+                if (depth_counts && len > 0 && (op == 0 || op == 7 || op == 8)) {        // a match segment at pos + (ref consumed so far)
+                    auto &m = ms_part[static_cast<size_t>(t)];
+                    m.push_back(tid); m.push_back(static_cast<int32_t>(le32(r + 4)) + rl); m.push_back(len);
+                }
                 if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += len;   // bam_cigar2rlen
                 if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) ql += len;   // getReadLength (:385-397)
                 sc.add(len, opchr[op]);
@@ -436,6 +446,11 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
     c.sa.clear();
     c.sa.reserve(static_cast<size_t>(c.sa_off[n]) + 1);
     for (auto &part : sa_part) c.sa.insert(c.sa.end(), part.begin(), part.end());   // thread ranges are in record order
+    size_t n_ms = 0;
+    for (auto &part : ms_part) n_ms += part.size() / 3;
+    c.mseg_tid.reserve(n_ms); c.mseg_pos.reserve(n_ms); c.mseg_len.reserve(n_ms);
+    for (auto &part : ms_part)
+        for (size_t k = 0; k + 2 < part.size(); k += 3) { c.mseg_tid.push_back(part[k]); c.mseg_pos.push_back(part[k + 1]); c.mseg_len.push_back(part[k + 2]); }
 }
 
 }  // namespace palace_host

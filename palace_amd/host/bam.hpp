@@ -34,6 +34,9 @@ struct BamColumns {
     std::vector<uint8_t> mapq;
     std::vector<uint64_t> qkey;
     std::vector<palace_sa_item> sa;
+    // depth stage (palace:538-552): one entry per M / = / X CIGAR operation of the records `samtools depth` counts
+    // (UNMAP, SECONDARY, QCFAIL, DUP clear): target, 0-based reference position, length.  Order is irrelevant.
+    std::vector<int32_t> mseg_tid, mseg_pos, mseg_len;
     // read names stay in the inflated stream; (offset, length) per record for the exactness guard
     RawBuf raw;
     std::vector<uint64_t> qname_at;

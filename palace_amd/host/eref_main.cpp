@@ -1,5 +1,7 @@
 // eref -- drop-in for the reference executable (bin/extract_ref.cpp; call site palace:475-477):
-//     eref <fq1> <fq2> <phagedb.fa> <tmp.txt> <hit_ratio> <perfect_ratio> <threads>  > ref_names.txt
+//     eref <fq1> <fq2> <phagedb.fa> <tmp.txt> <hit_ratio> <perfect_ratio> <threads> [<refs_out.fasta> <percent_out.txt>]  > ref_names.txt
+// The two optional arguments fold the next pipeline step in (palace:483-498, get_ref_by_index.py + the .fai it reads): the
+// reported references as FASTA and the "name <TAB> ratio" table, written from the DB this run has parsed anyway.
 // Host side: text parsing, the index file contract, stdout formatting.  The k-mer work (index
 // build, read counting, reference scan) runs in HIP through libpalace_hip.so; no CPU path exists.
 //
@@ -8,10 +10,13 @@
 // in index order.  <threads> only sizes the host-side text parsing.
 #include <sys/stat.h>
 
+#include <algorithm>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <string>
 #include <thread>
@@ -126,30 +131,34 @@ int main(int argc, char **argv)
     // scans the text inputs: neither waits for the other (the reference, too, reads with T threads per phase, :1267-1291).
     palace_ctx *ctx = nullptr;
     int ctx_rc = 0;
-    std::string ctx_err;
-    std::thread hip_up([&] {
-        ctx_rc = palace_ctx_create(0, &ctx);
-        if (!ctx_rc) ctx_rc = palace_eref_table_reset(ctx);
-        if (ctx_rc) ctx_err = palace_last_error();          // (the message is per thread)
-    });
+    std::string ctx_err, in_err;
     MappedText fq_txt[2];
     FastqPlan plan[2];
-    std::string in_err;
-    std::thread fq_scan([&] {                                // pass 1 over both FASTQ files: parts, line phases, sizes
+    std::shared_future<void> scan_done = std::async(std::launch::async, [&] {   // pass 1 over both FASTQ files: parts, line phases, sizes
         try {
             for (int side = 0; side < 2; side++) {
                 fq_txt[side].open(side == 0 ? fq1 : fq2);
                 plan_fastq(fq_txt[side], threads, plan[side]);
             }
         } catch (const std::exception &e) { in_err = e.what(); }
+    }).share();
+    std::thread hip_up([&] {
+        ctx_rc = palace_ctx_create(0, &ctx);
+        if (!ctx_rc) ctx_rc = palace_eref_table_reset(ctx);
+        if (!ctx_rc) {                                      // ... and the scratch memory of the count, as soon as its size is known
+            scan_done.wait();
+            if (in_err.empty()) ctx_rc = palace_eref_reserve(ctx, plan[0].n_bases + plan[1].n_bases);
+        }
+        if (ctx_rc) ctx_err = palace_last_error();          // (the message is per thread)
     });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } join_hip{hip_up};
 
     // ---- references: FASTA -> records longer than k=32 (:697), index-file contract ----
     SeqSet db_all, db;
     try {
         MappedText fa_txt(fasta);
         parse_fasta(fa_txt.data, fa_txt.size, db_all);
-    } catch (const std::exception &e) { std::cerr << "eref: " << e.what() << "\n"; hip_up.join(); fq_scan.join(); return 1; }
+    } catch (const std::exception &e) { std::cerr << "eref: " << e.what() << "\n"; return 1; }
     std::vector<int64_t> cum(db_all.n() + 1, 0);
     for (int64_t i = 0; i < db_all.n(); i++) {
         cum[i + 1] = cum[i] + db_all.len(i);
@@ -168,7 +177,7 @@ int main(int argc, char **argv)
 
     hip_up.join();
     tr.lap("hip runtime up (joined)");
-    if (ctx_rc) { std::cerr << "eref: cannot set up the GPU: " << ctx_err << "\n"; fq_scan.join(); return 1; }
+    if (ctx_rc) { std::cerr << "eref: cannot set up the GPU: " << ctx_err << "\n"; return 1; }
     uint8_t *d_ref = nullptr; int64_t *d_ref_off = nullptr;
     CK(upload(ctx, db.bases.data(), db.bases.size(), &d_ref));
     CK(upload(ctx, db.offsets.data(), db.offsets.size(), &d_ref_off));
@@ -215,7 +224,7 @@ int main(int argc, char **argv)
     // lines of a run of parts straight to their place in a page-locked staging buffer (all threads), which goes to the
     // device with an asynchronous copy while the other staging buffer is being filled.
     tr.lap("refs uploaded / index ready");
-    fq_scan.join();
+    scan_done.wait();
     tr.lap("fastq pass 1 (joined)");
     if (!in_err.empty()) { std::cerr << "eref: " << in_err << "\n"; return 1; }
     const int64_t n_reads = plan[0].n_reads + plan[1].n_reads, n_bases = plan[0].n_bases + plan[1].n_bases;
@@ -302,6 +311,33 @@ int main(int argc, char **argv)
                                            static_cast<double>(ratio)));
     }
     std::fwrite(out.data(), 1, out.size(), stdout);
+    if (argc >= 10) {
+        // get_ref_by_index.py:6-89: the first integer of a stdout line is taken as the 1-based ROW of <db>.fai, i.e. the
+        // record number among ALL records of the FASTA (a DB with records of <= 32 bases therefore names the wrong
+        // record, as in the reference pipeline: SURVEY.md row E5); name = header up to the first white space, sequence with
+        // the line ends removed, percentage = Python's str(float(<ratio text>)); ascending index order.
+        std::ofstream fa(argv[8], std::ios::binary), pc(argv[9], std::ios::binary);
+        if (!fa || !pc) { std::cerr << "eref: cannot write " << argv[8] << " / " << argv[9] << "\n"; return 1; }
+        std::vector<int64_t> by_ordinal(static_cast<size_t>(db_all.n()) + 2, -1);
+        for (int64_t i = 0; i < db_all.n(); i++)
+            if (db_all.ordinal[i] >= 1 && db_all.ordinal[i] < static_cast<int64_t>(by_ordinal.size())) by_ordinal[static_cast<size_t>(db_all.ordinal[i])] = i;
+        for (int64_t r = 0; r < n_refs; r++) {
+            const int el = rows[4 * r + 1], len = rows[4 * r + 2];
+            const float ratio = static_cast<float>(el) / static_cast<float>(len);
+            if (!(el > 0 && ratio > 0.75)) continue;
+            const int64_t row = r + 1;
+            if (row >= static_cast<int64_t>(by_ordinal.size()) || by_ordinal[static_cast<size_t>(row)] < 0) continue;   // "Index not found in FAI file"
+            const int64_t i = by_ordinal[static_cast<size_t>(row)];
+            std::snprintf(line, sizeof line, "%g", static_cast<double>(ratio));
+            std::string pct = line;
+            if (pct.find_first_of(".en") == std::string::npos) pct += ".0";      // float("1") prints as 1.0
+            fa << '>' << db_all.ids[static_cast<size_t>(i)] << '\n';
+            std::string seq(reinterpret_cast<const char *>(db_all.bases.data() + db_all.offsets[i]), static_cast<size_t>(db_all.len(i)));
+            seq.erase(std::remove_if(seq.begin(), seq.end(), [](char ch) { return std::isspace(static_cast<unsigned char>(ch)); }), seq.end());
+            fa << seq << '\n';                                                  // (Bio.SeqIO drops white space inside sequence lines)
+            pc << db_all.ids[static_cast<size_t>(i)] << '\t' << pct << '\n';
+        }
+    }
     tr.lap("stdout");
     return 0;
 }

@@ -4,6 +4,7 @@
 // without '\n' still counts, FASTQ sequence lines are those with (0-based line index) % 4 == 1.
 #pragma once
 #include <algorithm>
+#include <cctype>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
@@ -17,7 +18,8 @@ namespace palace_host {
 struct SeqSet {
     std::vector<uint8_t> bases;
     std::vector<int64_t> offsets{0};
-    std::vector<std::string> names;      // FASTA only
+    std::vector<std::string> names;      // FASTA only: get_read_ID view of the header (extract_ref.cpp:246-254)
+    std::vector<std::string> ids;        // FASTA only: header up to the first white space (what `samtools faidx` lists)
     std::vector<int64_t> ordinal;        // FASTA only: 1-based record number in the file
     int64_t n() const { return static_cast<int64_t>(offsets.size()) - 1; }
     int64_t len(int64_t i) const { return offsets[i + 1] - offsets[i]; }
@@ -107,7 +109,7 @@ inline void parse_fasta(const char *txt, size_t N, SeqSet &out)
     out.offsets.assign(1, 0);
     // text ahead of the first header belongs to an implicit record "start" with ordinal 0
     // (extract_ref.cpp:672, 688: pre_name = "start", ref_index = 0)
-    out.names.assign(1, "start"); out.ordinal.assign(1, 0);
+    out.names.assign(1, "start"); out.ordinal.assign(1, 0); out.ids.assign(1, "");
     bool open = true;
     int64_t rec = 0;
     for (size_t p = 0; p < N;) {
@@ -116,6 +118,11 @@ inline void parse_fasta(const char *txt, size_t N, SeqSet &out)
         if (e > p && txt[p] == '>') {
             if (open) out.offsets.push_back(static_cast<int64_t>(out.bases.size()));
             out.names.push_back(fasta_name(std::string(txt + p, e - p)));
+            {
+                size_t w = p + 1;
+                while (w < e && !std::isspace(static_cast<unsigned char>(txt[w]))) w++;
+                out.ids.emplace_back(txt + p + 1, w - p - 1);
+            }
             out.ordinal.push_back(++rec);
             open = true;
         } else if (open) {

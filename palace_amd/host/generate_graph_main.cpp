@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "bam.hpp"
+#include "depth_host.hpp"
 #include "fastx.hpp"
 #include "trace.hpp"
 
@@ -64,6 +65,8 @@ int upload(palace_ctx *ctx, const std::vector<T> &v, T **d)
     *d = static_cast<T *>(p);
     return palace_h2d(ctx, p, v.data(), v.size() * sizeof(T));
 }
+
+void radix_sort_u64(std::vector<uint64_t> &v);
 
 // parseFastgFile (generate_graph.cpp:119-169) reduced to the pairs whose two names are BAM targets.  The file is mapped
 // and cut into parts at line ends; every part is parsed by a thread with string views (no per-line allocation).
@@ -119,7 +122,7 @@ std::vector<uint64_t> fastg_keys(const std::string &path, const BamColumns &c, i
     });
     std::vector<uint64_t> keys;
     for (auto &v : part) keys.insert(keys.end(), v.begin(), v.end());
-    std::sort(keys.begin(), keys.end());
+    radix_sort_u64(keys);
     keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
     return keys;
 }
@@ -129,24 +132,41 @@ std::vector<uint64_t> fastg_keys(const std::string &path, const BamColumns &c, i
 void name_ranks(const std::vector<std::string> &names, std::vector<int32_t> &by_name, std::vector<int32_t> &rank)
 {
     const int32_t nt = static_cast<int32_t>(names.size());
-    std::vector<std::pair<uint64_t, int32_t>> key(static_cast<size_t>(nt));
+    struct Key { uint64_t hi, lo; int32_t id; };
+    std::vector<Key> key(static_cast<size_t>(nt));
     for (int32_t i = 0; i < nt; i++) {
-        uint64_t k = 0;
+        uint64_t k[2] = {0, 0};
         const std::string &s = names[static_cast<size_t>(i)];
-        for (size_t b = 0; b < 8; b++) k = (k << 8) | (b < s.size() ? static_cast<unsigned char>(s[b]) : 0);
-        key[static_cast<size_t>(i)] = {k, i};
+        for (size_t b = 0; b < 16; b++) k[b >> 3] = (k[b >> 3] << 8) | (b < s.size() ? static_cast<unsigned char>(s[b]) : 0);
+        key[static_cast<size_t>(i)] = {k[0], k[1], i};
     }
-    std::sort(key.begin(), key.end(), [&](const std::pair<uint64_t, int32_t> &a, const std::pair<uint64_t, int32_t> &b) {
-        if (a.first != b.first) return a.first < b.first;
-        const int c = names[static_cast<size_t>(a.second)].compare(names[static_cast<size_t>(b.second)]);
-        return c != 0 ? c < 0 : a.second < b.second;
+    std::sort(key.begin(), key.end(), [&](const Key &a, const Key &b) {
+        if (a.hi != b.hi) return a.hi < b.hi;
+        if (a.lo != b.lo) return a.lo < b.lo;
+        const int c = names[static_cast<size_t>(a.id)].compare(names[static_cast<size_t>(b.id)]);   // (a NUL inside a name also lands here)
+        return c != 0 ? c < 0 : a.id < b.id;
     });
     by_name.resize(static_cast<size_t>(nt));
     rank.assign(static_cast<size_t>(nt), 0);
     for (int32_t k = 0, r = -1; k < nt; k++) {
-        by_name[static_cast<size_t>(k)] = key[static_cast<size_t>(k)].second;
+        by_name[static_cast<size_t>(k)] = key[static_cast<size_t>(k)].id;
         if (k == 0 || names[static_cast<size_t>(by_name[k])] != names[static_cast<size_t>(by_name[k - 1])]) r++;
         rank[static_cast<size_t>(by_name[k])] = r;
+    }
+}
+
+// ascending order of 64-bit keys by least-significant-digit radix passes of 11 bits (only over the bits in use)
+void radix_sort_u64(std::vector<uint64_t> &v)
+{
+    uint64_t all = 0;
+    for (uint64_t x : v) all |= x;
+    std::vector<uint64_t> tmp(v.size());
+    for (int shift = 0; shift < 64 && (all >> shift) != 0; shift += 11) {
+        size_t count[2049] = {0};
+        for (uint64_t x : v) count[((x >> shift) & 2047) + 1]++;
+        for (int b = 0; b < 2048; b++) count[b + 1] += count[b];
+        for (uint64_t x : v) tmp[count[(x >> shift) & 2047]++] = x;
+        v.swap(tmp);
     }
 }
 
@@ -186,7 +206,10 @@ int main(int argc, char **argv)
     }
     if (argc - optind < 4) { usage(argv[0]); return 1; }
     const std::string bam_path = argv[optind], fai_path = argv[optind + 1], out_path = argv[optind + 2];
-    const double avg_depth = std::atof(argv[optind + 3]);
+    // <avgDepth> = "auto": the depth stage (palace:538-552) is done here, on the records this run decodes anyway; the value
+    // goes through the same text the driver would have passed ("%.6g" of awk, then atof)
+    const bool auto_depth = std::string(argv[optind + 3]) == "auto";
+    double avg_depth = auto_depth ? 0.0 : std::atof(argv[optind + 3]);
 
     Trace tr("generateGraph");
     BamColumns c;
@@ -229,6 +252,15 @@ int main(int argc, char **argv)
     hip_up.join();
     if (ctx_rc) { std::cerr << "generateGraph: cannot set up the GPU: " << ctx_err << "\n"; return 1; }
     tr.lap("hip runtime up (joined)");
+    if (auto_depth) {
+        std::string text;
+        const int drc = first_depth(ctx, c, text);
+        if (drc < 0) { std::cerr << "generateGraph: " << palace_last_error() << "\n"; return 1; }
+        if (drc > 0) { std::cerr << "generateGraph: no position is covered, cannot derive avgDepth\n"; return 1; }
+        avg_depth = std::atof(text.c_str());
+        std::cerr << "Average sequencing depth: " << text << "\n";               // the driver logs the same line (palace:551)
+        tr.lap("depth stage");
+    }
     palace_bam_cols cols{};
     cols.n = c.n();
     int32_t *d_tid, *d_pos, *d_mtid, *d_mpos, *d_nm, *d_rl, *d_ql, *d_cs, *d_ce, *d_sao, *d_tlen, *d_rank;

@@ -33,3 +33,30 @@ def records():
 # ctgC = 500/400 = 1.25 -> floor(2.5+.5)=3
 EXPECTED = (b"SEG ctgA 1.36 3\nSEG ctgB 0.06 0\nSEG ctgC 1.25 3\n"
             b"JUNC ctgA + ctgB + 7 0\nJUNC ctgA + ctgC + 0 5\n")
+
+
+# ---- depth stage (palace:538-552): samtools depth | awk '{sum+=$3} END {print sum/NR}', derived by hand -------------
+DEPTH_TARGETS = [("ctgA", 100), ("ctgB", 50)]
+
+
+def depth_records():
+    B = BamRecord
+    return [
+        B("d1", 0, 0, 10, 60, "5S20M"),             # ctgA [10,30)
+        B("d2", 0, 0, 20, 60, "10M5D10M"),          # ctgA [20,30) and [35,45): the deletion is not counted (no -J)
+        B("d3", 0x100, 0, 0, 60, "50M"),            # secondary: skipped
+        B("d4", 0x400, 0, 0, 60, "50M"),            # duplicate: skipped
+        B("d5", 0x800, 0, 50, 60, "10M"),           # supplementary: counted by samtools depth  [50,60)
+        B("d6", 0x4, -1, -1, 0, ""),                # unmapped
+        B("d7", 0, 0, 70, 60, "5M10N5M"),           # reference skip not counted  [70,75) [85,90)
+        B("d8", 0, 0, 0, 60, "3=2X"),               # = and X count  [0,5)
+        B("d9", 0, 0, 90, 60, "4M3I4M"),            # insertion consumes no reference  [90,98)
+        B("d10", 0x200, 0, 0, 60, "50M"),           # QC fail: skipped
+        B("d11", 0, 1, 45, 60, "10M"),              # ctgB [45,50): runs to the contig end exactly... (45+10 = 55 > 50: cut at 50)
+    ]
+
+
+# ctgA: [0,5) x1, [10,20) x1, [20,30) x2, [35,45) x1, [50,60) x1, [70,75) x1, [85,90) x1, [90,98) x1 ; ctgB: [45,50) x1
+DEPTH_SUM = 5 + 10 + 20 + 10 + 10 + 5 + 5 + 8 + 5          # 78
+DEPTH_NR = 5 + 10 + 10 + 10 + 10 + 5 + 5 + 8 + 5           # 68
+DEPTH_TEXT = "1.14706"                                     # 78 / 68 = 1.147058...  ("%.6g")

@@ -45,3 +45,13 @@ def test_long_contig_underflow_gate(tmp_path):
     assert b"JUNC" not in out_long
     out_short = run([mk(i, 50000) for i in range(6)], tmp_path, [("ctgA", 50000), ("ctgB", 2000)], fai)
     assert b"JUNC ctgA + ctgB + 6 0" in out_short
+
+
+def test_depth_stage_hand_case():
+    text, s, nr = orc.depth_mean(gc.depth_records(), gc.DEPTH_TARGETS)
+    assert (s, nr, text) == (gc.DEPTH_SUM, gc.DEPTH_NR, gc.DEPTH_TEXT)
+    # an integral mean is printed the way awk prints integers
+    from palace_amd.synth import BamRecord
+    text, s, nr = orc.depth_mean([BamRecord("a", 0, 0, 0, 60, "10M"), BamRecord("b", 0, 0, 0, 60, "10M")], [("c", 100)])
+    assert (text, s, nr) == ("2", 20, 10)
+    assert orc.depth_mean([BamRecord("u", 4, -1, -1, 0, "")], [("c", 100)])[0] is None
