@@ -7,6 +7,6 @@ export TMPDIR=/tmp
 for rep in $(seq 1 ${1:-3}); do
   for f in $(ls "$GRAFT_REPO_ROOT"/tools/ab/lib_*.so | sort); do
     v=$(basename $f .so)
-    PALACE_HIP_SO=$f timeout -k 10 300 python bench.py --steps 8 --warmup 1 --no-cpu-baseline 2> gpurun_out/ab.err | python tools/bench_median.py $v.$rep
+    PALACE_HIP_SO=$f timeout -k 10 300 python bench.py --steps 8 --warmup 1 --no-cpu-baseline --no-e2e --soak-seconds 0 2> gpurun_out/ab.err | python tools/bench_median.py $v.$rep
   done
 done

@@ -9,7 +9,7 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_V
            "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INST_CYCLES_VMEM_WR SQ_VMEM_WR_TA_DATA_FIFO_FULL" \
            "SQ_LEVEL_WAVES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_ACTIVE_INST_ANY SQ_INSTS SQ_CYCLES"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $grp -d gpurun_out/pmcsq/g$i --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmcsq_g$i.log 2>&1 || exit 1
+  timeout -k 10 240 rocprofv3 --pmc $grp -d gpurun_out/pmcsq/g$i --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --soak-seconds 0 > gpurun_out/pmcsq_g$i.log 2>&1 || exit 1
   echo "group $i done"
 done
 python3 tools/pmc_table.py gpurun_out/pmcsq > gpurun_out/pmcsq_table.txt

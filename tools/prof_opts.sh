@@ -7,7 +7,7 @@ opt=$1; shift
 for v in "$@"; do
   rm -rf gpurun_out/po_$v
   export PALACE_OPT_$opt=$v
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/po_$v --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/po_$v.json 2> gpurun_out/po_$v.err || { echo "$v failed"; tail -3 gpurun_out/po_$v.err; continue; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/po_$v --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --soak-seconds 0 > gpurun_out/po_$v.json 2> gpurun_out/po_$v.err || { echo "$v failed"; tail -3 gpurun_out/po_$v.err; continue; }
   s=$(find gpurun_out/po_$v -name '*kernel_stats.csv' | head -1)
   t=$(find gpurun_out/po_$v -name '*kernel_trace.csv' | head -1)
   python3 tools/rocprof_summary.py gpurun_out/po_$v.md --stats $s --trace $t
