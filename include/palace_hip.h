@@ -246,6 +246,14 @@ int palace_depth_sum_covered(palace_ctx *ctx, int64_t n_segs, const int32_t *d_s
                              const int32_t *d_seg_len, int32_t n_targets, const int32_t *d_tlen, const int64_t *d_tbase,
                              int64_t total_len, uint64_t *sum_out, uint64_t *covered_out);
 
+/* The same per contig as well: d_contig_sum[t] / d_contig_covered[t] (device, n_targets entries each) = what
+ * `tabix fetch(contig)` on the depth file yields, reduced to sum and count (create_sub_graph.py:186-234 reads exactly
+ * that: mean = sum / count, weight = count). */
+int palace_depth_per_contig(palace_ctx *ctx, int64_t n_segs, const int32_t *d_seg_tid, const int32_t *d_seg_pos,
+                            const int32_t *d_seg_len, int32_t n_targets, const int32_t *d_tlen, const int64_t *d_tbase,
+                            int64_t total_len, uint64_t *sum_out, uint64_t *covered_out, uint64_t *d_contig_sum,
+                            uint64_t *d_contig_covered);
+
 /* ---- matching: path / cycle decomposition of the conjugate graph ------------------------- */
 
 /* M1. One greedy matching over the arcs of the conjugate graph, computed as rounds of locally

@@ -15,7 +15,8 @@ namespace palace {
 __global__ __launch_bounds__(256) void depth_mark_kernel(const int32_t *__restrict__ seg_tid, const int32_t *__restrict__ seg_pos,
                                                          const int32_t *__restrict__ seg_len, int64_t n, int32_t n_targets,
                                                          const int32_t *__restrict__ tlen, const int64_t *__restrict__ base,
-                                                         unsigned long long *__restrict__ bits, unsigned long long *__restrict__ sum)
+                                                         unsigned long long *__restrict__ bits, unsigned long long *__restrict__ sum,
+                                                         unsigned long long *__restrict__ contig_sum)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     long long mine = 0;
@@ -27,6 +28,7 @@ __global__ __launch_bounds__(256) void depth_mark_kernel(const int32_t *__restri
             const int64_t b = min(a + len, L);                     // (a record that runs past its contig is cut there)
             if (b > a) {
                 mine = b - a;
+                if (contig_sum) atomicAdd(&contig_sum[t], static_cast<unsigned long long>(mine));
                 const int64_t g0 = base[t] + a, g1 = base[t] + b;   // [g0, g1)
                 for (int64_t w = g0 >> 6; w <= (g1 - 1) >> 6; w++) {
                     const int64_t lo = max(g0, w << 6), hi = min(g1, (w + 1) << 6);
@@ -50,17 +52,40 @@ __global__ __launch_bounds__(256) void depth_popcount_kernel(const unsigned long
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
 
+// covered positions per contig: population count of its bit range (one thread per contig)
+__global__ __launch_bounds__(256) void depth_contig_cover_kernel(const unsigned long long *__restrict__ bits, int32_t n_targets,
+                                                                 const int32_t *__restrict__ tlen, const int64_t *__restrict__ base,
+                                                                 unsigned long long *__restrict__ covered)
+{
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_targets) return;
+    const int64_t g0 = base[t], g1 = g0 + max(0, tlen[t]);
+    unsigned long long acc = 0;
+    for (int64_t w = g0 >> 6; g1 > g0 && w <= (g1 - 1) >> 6; w++) {
+        const int64_t lo = max(g0, w << 6), hi = min(g1, (w + 1) << 6);
+        const unsigned long long m = ((hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1)) << (lo & 63);
+        acc += __popcll(bits[w] & m);
+    }
+    covered[t] = acc;
+}
+
 }  // namespace palace
 
 using namespace palace;
 
-extern "C" int palace_depth_sum_covered(palace_ctx *ctx, int64_t n_segs, const int32_t *d_seg_tid, const int32_t *d_seg_pos,
-                                        const int32_t *d_seg_len, int32_t n_targets, const int32_t *d_tlen,
-                                        const int64_t *d_tbase, int64_t total_len, uint64_t *sum_out, uint64_t *covered_out)
+static int depth_impl(palace_ctx *ctx, int64_t n_segs, const int32_t *d_seg_tid, const int32_t *d_seg_pos,
+                      const int32_t *d_seg_len, int32_t n_targets, const int32_t *d_tlen, const int64_t *d_tbase, int64_t total_len,
+                      uint64_t *sum_out, uint64_t *covered_out, uint64_t *d_contig_sum, uint64_t *d_contig_covered)
 {
     PALACE_REQUIRE(ctx && sum_out && covered_out && n_segs >= 0 && n_targets >= 0 && total_len >= 0, "bad argument");
     *sum_out = 0; *covered_out = 0;
-    if (n_segs == 0 || n_targets == 0) return PALACE_OK;
+    if (n_targets == 0) return PALACE_OK;
+    if (n_segs == 0) {
+        PALACE_HIP_TRY(hipSetDevice(ctx->device));
+        if (d_contig_sum) PALACE_HIP_TRY(hipMemsetAsync(d_contig_sum, 0, static_cast<size_t>(n_targets) * 8, ctx->stream));
+        if (d_contig_covered) PALACE_HIP_TRY(hipMemsetAsync(d_contig_covered, 0, static_cast<size_t>(n_targets) * 8, ctx->stream));
+        return PALACE_OK;
+    }
     PALACE_REQUIRE(d_seg_tid && d_seg_pos && d_seg_len && d_tlen && d_tbase, "null device pointer");
     PALACE_REQUIRE((n_segs + 255) / 256 < (1ll << 31), "too many segments for one launch");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
@@ -71,13 +96,35 @@ extern "C" int palace_depth_sum_covered(palace_ctx *ctx, int64_t n_segs, const i
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(ctx->d_small);
     PALACE_HIP_TRY(hipMemsetAsync(bits, 0, static_cast<size_t>(n_words) * 8, ctx->stream));
     PALACE_HIP_TRY(hipMemsetAsync(acc, 0, 16, ctx->stream));
+    if (d_contig_sum) PALACE_HIP_TRY(hipMemsetAsync(d_contig_sum, 0, static_cast<size_t>(n_targets) * 8, ctx->stream));
     hipLaunchKernelGGL(depth_mark_kernel, dim3(static_cast<unsigned>((n_segs + 255) / 256)), dim3(256), 0, ctx->stream, d_seg_tid,
-                       d_seg_pos, d_seg_len, n_segs, n_targets, d_tlen, d_tbase, bits, acc);
+                       d_seg_pos, d_seg_len, n_segs, n_targets, d_tlen, d_tbase, bits, acc,
+                       reinterpret_cast<unsigned long long *>(d_contig_sum));
     hipLaunchKernelGGL(depth_popcount_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream, bits, n_words, acc + 1);
+    if (d_contig_covered)
+        hipLaunchKernelGGL(depth_contig_cover_kernel, dim3((n_targets + 255) / 256), dim3(256), 0, ctx->stream, bits, n_targets, d_tlen,
+                           d_tbase, reinterpret_cast<unsigned long long *>(d_contig_covered));
     PALACE_HIP_TRY(hipGetLastError());
     uint64_t h[2];
     PALACE_HIP_TRY(hipMemcpyAsync(h, acc, 16, hipMemcpyDeviceToHost, ctx->stream));
     PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
     *sum_out = h[0]; *covered_out = h[1];
     return PALACE_OK;
+}
+
+extern "C" int palace_depth_sum_covered(palace_ctx *ctx, int64_t n_segs, const int32_t *d_seg_tid, const int32_t *d_seg_pos,
+                                        const int32_t *d_seg_len, int32_t n_targets, const int32_t *d_tlen,
+                                        const int64_t *d_tbase, int64_t total_len, uint64_t *sum_out, uint64_t *covered_out)
+{
+    return depth_impl(ctx, n_segs, d_seg_tid, d_seg_pos, d_seg_len, n_targets, d_tlen, d_tbase, total_len, sum_out, covered_out, nullptr, nullptr);
+}
+
+extern "C" int palace_depth_per_contig(palace_ctx *ctx, int64_t n_segs, const int32_t *d_seg_tid, const int32_t *d_seg_pos,
+                                       const int32_t *d_seg_len, int32_t n_targets, const int32_t *d_tlen,
+                                       const int64_t *d_tbase, int64_t total_len, uint64_t *sum_out, uint64_t *covered_out,
+                                       uint64_t *d_contig_sum, uint64_t *d_contig_covered)
+{
+    PALACE_REQUIRE(n_targets == 0 || (d_contig_sum && d_contig_covered), "null device pointer");
+    return depth_impl(ctx, n_segs, d_seg_tid, d_seg_pos, d_seg_len, n_targets, d_tlen, d_tbase, total_len, sum_out, covered_out, d_contig_sum,
+                      d_contig_covered);
 }

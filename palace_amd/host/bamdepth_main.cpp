@@ -1,7 +1,10 @@
 // bamdepth -- the mean depth the driver computes before generateGraph (palace:538-552):
 //     samtools depth -@ T <bam> > <bam>.depth ; first_depth=$(awk '{sum+=$3} END { print sum/NR }' <bam>.depth)
 // as one command:   first_depth=$(bamdepth <bam>)
-// prints exactly what the awk line prints.  (The per-base <bam>.depth.gz that step 5 reads through tabix is not written;
+// prints exactly what the awk line prints.
+//     bamdepth --per-contig <bam> > contig_depth.tsv
+// prints `contig <TAB> depth sum <TAB> covered positions` for every contig with coverage: the two numbers step 5 takes from
+// the tabix-indexed depth file per contig (create_sub_graph.py:186-234); palace_amd/scripts/create_sub_graph.py reads it.  (The per-base <bam>.depth.gz that step 5 reads through tabix is not written;
 // `generateGraph <bam> <fai> <out> auto` uses the same number without a second pass over the BAM.)
 #include <algorithm>
 #include <iostream>
@@ -14,17 +17,27 @@ using namespace palace_host;
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { std::cerr << "Usage: " << argv[0] << " <bam>\n"; return 1; }
+    const bool per_contig = argc >= 3 && std::string(argv[1]) == "--per-contig";
+    if (argc < 2 || (per_contig && argc < 3)) { std::cerr << "Usage: " << argv[0] << " [--per-contig] <bam>\n"; return 1; }
+    const char *bam = per_contig ? argv[2] : argv[1];
     BamColumns c;
     try {
-        load_bam(argv[1], static_cast<int>(std::max(1u, std::min(16u, std::thread::hardware_concurrency()))), 1, c);
+        load_bam(bam, static_cast<int>(std::max(1u, std::min(16u, std::thread::hardware_concurrency()))), 1, c);
     } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return 1; }
     palace_ctx *ctx = nullptr;
     if (palace_ctx_create(0, &ctx)) { std::cerr << "bamdepth: " << palace_last_error() << "\n"; return 1; }
     std::string text;
-    const int rc = first_depth(ctx, c, text);
+    std::vector<uint64_t> cs, cc;
+    const int rc = per_contig ? first_depth(ctx, c, text, nullptr, nullptr, &cs, &cc) : first_depth(ctx, c, text);
     palace_ctx_destroy(ctx);
     if (rc < 0) { std::cerr << "bamdepth: " << palace_last_error() << "\n"; return 1; }
+    if (per_contig) {
+        std::string out;
+        for (size_t t = 0; t < cs.size(); t++)
+            if (cc[t]) out += c.target_name[t] + "\t" + std::to_string(cs[t]) + "\t" + std::to_string(cc[t]) + "\n";
+        std::cout << out;
+        return 0;
+    }
     if (rc > 0) { std::cerr << "bamdepth: no position is covered (awk: division by zero)\n"; return 2; }
     std::cout << text << "\n";
     return 0;

@@ -37,7 +37,7 @@ namespace {
     } while (0)
 
 struct Options {
-    std::string graph, linear, cycle, paths;
+    std::string graph, linear, cycle, paths, batch;
     int iterations = 10;
     bool self_loops = false, break_cycles = false, aggressive = false;
 };
@@ -57,10 +57,11 @@ bool parse_args(int argc, char **argv, Options &o)
         else if (a == "-s" || a == "--self_l") o.self_loops = true;
         else if (a == "-b" || a == "--break_c") o.break_cycles = true;
         else if (a == "--aggressive") o.aggressive = true;
+        else if (a == "--batch") { if (!take(o.batch)) return false; }
         else if (a == "-h" || a == "--help") return false;
         else { std::cerr << "matching: unknown option " << a << "\n"; return false; }
     }
-    return !o.graph.empty() && !o.linear.empty() && !o.cycle.empty();
+    return !o.batch.empty() || (!o.graph.empty() && !o.linear.empty() && !o.cycle.empty());
 }
 
 struct Arc { int32_t u, v; int64_t w; int32_t backed; uint64_t cls; };
@@ -109,10 +110,54 @@ std::vector<std::string> words(const std::string &line)
     return t;
 }
 
-void load_graph(ConjGraph &g, const Options &o)
+// contigs.paths (SPAdes): lines of comma-separated `<contig id><+|->` tokens (NODE header lines skipped); consecutive
+// tokens back the arc between them.  Parsed once; a batch run applies to each graph only the lines that mention one of
+// its contigs.
+struct PathTok { std::string id; bool minus; bool ok; };
+typedef std::vector<PathTok> PathLine;
+
+std::vector<PathLine> load_paths(const std::string &path)
 {
-    std::ifstream in(o.graph);
-    if (!in) throw std::runtime_error("cannot open graph " + o.graph);
+    std::vector<PathLine> out;
+    if (path.empty()) return out;
+    std::ifstream pin(path);
+    std::string line;
+    while (std::getline(pin, line)) {
+        if (line.rfind("NODE", 0) == 0) continue;
+        PathLine pl;
+        size_t p = 0;
+        while (p <= line.size()) {
+            size_t c = line.find(',', p);
+            std::string tok = line.substr(p, c == std::string::npos ? std::string::npos : c - p);
+            p = c == std::string::npos ? line.size() + 1 : c + 1;
+            while (!tok.empty() && (tok.back() == ';' || tok.back() == '\r' || tok.back() == ' ')) tok.pop_back();
+            PathTok t{"", false, false};
+            if (tok.size() >= 2 && (tok.back() == '+' || tok.back() == '-')) { t.id = tok.substr(0, tok.size() - 1); t.minus = tok.back() == '-'; t.ok = true; }
+            pl.push_back(t);
+        }
+        out.push_back(std::move(pl));
+    }
+    return out;
+}
+
+void apply_path(ConjGraph &g, const PathLine &line)
+{
+    int32_t before = -1;
+    for (const PathTok &t : line) {
+        int32_t here = -1;
+        if (t.ok) {
+            auto it = g.seg_of_id.find(t.id);
+            if (it != g.seg_of_id.end()) here = 2 * it->second + (t.minus ? 1 : 0);
+        }
+        if (before >= 0 && here >= 0) g.add(before, here, 0, 1);
+        before = here;
+    }
+}
+
+void load_graph_text(ConjGraph &g, const std::string &graph_path)
+{
+    std::ifstream in(graph_path);
+    if (!in) throw std::runtime_error("cannot open graph " + graph_path);
     std::string line;
     while (std::getline(in, line)) {
         auto t = words(line);
@@ -124,26 +169,6 @@ void load_graph(ConjGraph &g, const Options &o)
             g.add(2 * a + (t[2] == "-"), 2 * b + (t[4] == "-"), std::atol(t[5].c_str()) + std::atol(t[6].c_str()), 0);
         }
     }
-    if (o.paths.empty()) return;
-    std::ifstream pin(o.paths);
-    while (std::getline(pin, line)) {
-        if (line.rfind("NODE", 0) == 0) continue;
-        int32_t before = -1;
-        size_t p = 0;
-        while (p <= line.size()) {
-            size_t c = line.find(',', p);
-            std::string tok = line.substr(p, c == std::string::npos ? std::string::npos : c - p);
-            p = c == std::string::npos ? line.size() + 1 : c + 1;
-            while (!tok.empty() && (tok.back() == ';' || tok.back() == '\r' || tok.back() == ' ')) tok.pop_back();
-            int32_t here = -1;
-            if (tok.size() >= 2 && (tok.back() == '+' || tok.back() == '-')) {
-                auto it = g.seg_of_id.find(tok.substr(0, tok.size() - 1));
-                if (it != g.seg_of_id.end()) here = 2 * it->second + (tok.back() == '-');
-            }
-            if (before >= 0 && here >= 0) g.add(before, here, 0, 1);
-            before = here;
-        }
-    }
 }
 
 }  // namespace
@@ -153,7 +178,8 @@ int main(int argc, char **argv)
     Options opt;
     if (!parse_args(argc, argv, opt)) {
         std::cerr << "Usage: matching -g <graph> -r <linear out> -c <cycle out> [-s] [-i <iterations>] [-b] "
-                     "[-l <contigs.paths>] [--aggressive]\n";
+                     "[-l <contigs.paths>] [--aggressive]\n"
+                     "       matching --batch <list of '<graph> <linear out> <cycle out>' lines> [-s] [-i <iterations>] [-b] [-l ...] [--aggressive]\n";
         return 1;
     }
     palace_host::Trace tr("matching");
@@ -164,32 +190,77 @@ int main(int argc, char **argv)
         ctx_rc = palace_ctx_create(0, &ctx);
         if (ctx_rc) ctx_err = palace_last_error();
     });
-    ConjGraph g;
+    // one job per graph: the plain command line is a batch of one
+    struct Job { std::string graph, linear, cycle; ConjGraph g; int32_t v0 = 0; std::string lin, cyc, selfs; std::unordered_set<std::string> lin_seen, cyc_seen; };
+    std::vector<Job> jobs;
     try {
-        load_graph(g, opt);
+        if (opt.batch.empty()) { jobs.emplace_back(); jobs[0].graph = opt.graph; jobs[0].linear = opt.linear; jobs[0].cycle = opt.cycle; }
+        else {
+            // --batch <list>: one "<graph> <linear out> <cycle out>" triple per line (white space separated); every graph is
+            // decomposed with the options of this command line, all of them in ONE run on the GPU -- the step-5 loop of the
+            // driver (palace:651-806) starts a process per *.second sub-graph, hundreds per sample
+            std::ifstream lf(opt.batch);
+            if (!lf) throw std::runtime_error("cannot open batch list " + opt.batch);
+            for (std::string line; std::getline(lf, line);) {
+                auto t = words(line);
+                if (t.empty()) continue;
+                if (t.size() != 3) throw std::runtime_error("batch list: expected '<graph> <linear> <cycle>' per line");
+                jobs.emplace_back(); jobs.back().graph = t[0]; jobs.back().linear = t[1]; jobs.back().cycle = t[2];
+            }
+        }
+        const std::vector<PathLine> paths = load_paths(opt.paths);
+        std::unordered_map<std::string, std::vector<uint32_t>> lines_of;       // contig id -> path lines that mention it
+        if (jobs.size() > 1)
+            for (uint32_t li = 0; li < paths.size(); li++)
+                for (const PathTok &t : paths[li])
+                    if (t.ok) { auto &v = lines_of[t.id]; if (v.empty() || v.back() != li) v.push_back(li); }
+        for (Job &j : jobs) {
+            load_graph_text(j.g, j.graph);
+            if (jobs.size() == 1) { for (const PathLine &pl : paths) apply_path(j.g, pl); continue; }
+            std::vector<uint32_t> mine;
+            for (const auto &kv : j.g.seg_of_id) {
+                auto it = lines_of.find(kv.first);
+                if (it != lines_of.end()) mine.insert(mine.end(), it->second.begin(), it->second.end());
+            }
+            std::sort(mine.begin(), mine.end());
+            mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
+            for (uint32_t li : mine) apply_path(j.g, paths[li]);
+        }
     } catch (const std::exception &e) { std::cerr << "matching: " << e.what() << "\n"; hip_up.join(); return 1; }
-    tr.lap("graph + paths read");
-    const int32_t S = static_cast<int32_t>(g.name.size()), V = 2 * S;
-    for (Arc &a : g.arcs) {
+    tr.lap("graphs + paths read");
+    // The union of all graphs as one conjugate graph (vertex ids offset per graph).  Components never span two graphs and
+    // come out in first-vertex order, and the arc order (weight, path-backed, class key, ends) compares two arcs of one
+    // graph the same way with or without the offset, so every graph gets exactly the decomposition of a run of its own.
+    int64_t S_total = 0, E = 0;
+    for (Job &j : jobs) { j.v0 = static_cast<int32_t>(2 * S_total); S_total += static_cast<int64_t>(j.g.name.size()); E += static_cast<int64_t>(j.g.arcs.size()); }
+    if (2 * S_total >= (1ll << 31)) { std::cerr << "matching: too many segments\n"; hip_up.join(); return 1; }
+    const int32_t S = static_cast<int32_t>(S_total), V = 2 * S;
+    std::vector<Arc> arcs;
+    arcs.reserve(static_cast<size_t>(E));
+    std::vector<int64_t> copies;
+    copies.reserve(static_cast<size_t>(S));
+    for (Job &j : jobs) {
+        copies.insert(copies.end(), j.g.copies.begin(), j.g.copies.end());
+        for (Arc a : j.g.arcs) { a.u += j.v0; a.v += j.v0; arcs.push_back(a); }
+    }
+    for (Arc &a : arcs) {
         uint64_t k1 = static_cast<uint64_t>(a.u) * V + a.v, k2 = static_cast<uint64_t>(a.v ^ 1) * V + (a.u ^ 1);
         a.cls = std::min(k1, k2);
     }
-    std::sort(g.arcs.begin(), g.arcs.end(), [](const Arc &x, const Arc &y) {       // rank order
+    std::sort(arcs.begin(), arcs.end(), [](const Arc &x, const Arc &y) {       // rank order
         if (x.w != y.w) return x.w > y.w;
         if (x.backed != y.backed) return x.backed > y.backed;
         if (x.cls != y.cls) return x.cls < y.cls;
         return x.u != y.u ? x.u < y.u : x.v < y.v;
     });
-    const int64_t E = static_cast<int64_t>(g.arcs.size());
-    std::vector<int32_t> src(E), dst(E);
-    for (int64_t e = 0; e < E; e++) { src[e] = g.arcs[e].u; dst[e] = g.arcs[e].v; }
-
+    std::vector<int32_t> src(static_cast<size_t>(E)), dst(static_cast<size_t>(E));
+    for (int64_t e = 0; e < E; e++) { src[static_cast<size_t>(e)] = arcs[static_cast<size_t>(e)].u; dst[static_cast<size_t>(e)] = arcs[static_cast<size_t>(e)].v; }
     tr.lap("arcs ranked");
     hip_up.join();
     if (ctx_rc) { std::cerr << "matching: cannot set up the GPU: " << ctx_err << "\n"; return 1; }
     tr.lap("hip runtime up (joined)");
     palace_match_result *res = nullptr;
-    CK(palace_match_decompose(ctx, S, g.copies.data(), E, src.data(), dst.data(), opt.iterations, opt.aggressive, &res));
+    CK(palace_match_decompose(ctx, S, copies.data(), E, src.data(), dst.data(), opt.iterations, opt.aggressive, &res));
     tr.lap("decompose");
     palace_ctx_destroy(ctx);
 
@@ -198,44 +269,46 @@ int main(int argc, char **argv)
     const int32_t *verts = palace_match_result_verts(res), *iter = palace_match_result_iter(res),
                   *open_at = palace_match_result_open_at(res);
     const uint8_t *kind = palace_match_result_kind(res);
-    auto line_of = [&](int64_t c, int64_t first) {
-        const int64_t n = off[c + 1] - off[c];
-        std::string s;
-        for (int64_t i = 0; i < n; i++) {
-            const int32_t v = verts[off[c] + (first + i) % n];
-            if (i) s += '\t';
-            s += g.name[v >> 1];
-            s += (v & 1) ? '-' : '+';
-        }
-        s += '\n';
-        return s;
-    };
-    std::string lin, cyc, selfs;
-    std::unordered_set<std::string> lin_seen, cyc_seen;
+    std::vector<int32_t> v0s;
+    for (const Job &j : jobs) v0s.push_back(j.v0);
     for (int64_t c = 0; c < n_comp; c++) {
         const int64_t n = off[c + 1] - off[c];
+        if (n == 0) continue;
+        Job &j = jobs[static_cast<size_t>(std::upper_bound(v0s.begin(), v0s.end(), verts[off[c]]) - v0s.begin() - 1)];
+        auto line_of = [&](int64_t first) {
+            std::string s;
+            for (int64_t i = 0; i < n; i++) {
+                const int32_t v = verts[off[c] + (first + i) % n] - j.v0;
+                if (i) s += '\t';
+                s += j.g.name[static_cast<size_t>(v >> 1)];
+                s += (v & 1) ? '-' : '+';
+            }
+            s += '\n';
+            return s;
+        };
         if (!kind[c]) {
             if (n == 1 && iter[c] > 0) continue;               // a bare segment is reported once, in round 0
-            std::string s = line_of(c, 0);
-            if (lin_seen.insert(s).second) lin += s;
+            std::string s = line_of(0);
+            if (j.lin_seen.insert(s).second) j.lin += s;
             continue;
         }
-        std::string s = line_of(c, 0);
-        if (!cyc_seen.insert(s).second) continue;
-        if (n == 1 && opt.self_loops) selfs += "self\n" + s;
-        else cyc += "iter " + std::to_string(iter[c]) + "\n" + s;
+        std::string s = line_of(0);
+        if (!j.cyc_seen.insert(s).second) continue;
+        if (n == 1 && opt.self_loops) j.selfs += "self\n" + s;
+        else j.cyc += "iter " + std::to_string(iter[c]) + "\n" + s;
         if (opt.break_cycles) {                                 // also report it opened at its weakest arc
-            std::string open = line_of(c, open_at[c]);
-            if (lin_seen.insert(open).second) lin += open;
+            std::string open = line_of(open_at[c]);
+            if (j.lin_seen.insert(open).second) j.lin += open;
         }
     }
     palace_match_result_free(res);
-    cyc += selfs;
-    std::ofstream fl(opt.linear, std::ios::binary), fc(opt.cycle, std::ios::binary);
-    if (!fl || !fc) { std::cerr << "matching: cannot write outputs\n"; return 1; }
-    fl << lin;
-    fc << cyc;
-    fl.close(); fc.close();
+    for (Job &j : jobs) {
+        j.cyc += j.selfs;
+        std::ofstream fl(j.linear, std::ios::binary), fc(j.cycle, std::ios::binary);
+        if (!fl || !fc) { std::cerr << "matching: cannot write outputs of " << j.graph << "\n"; return 1; }
+        fl << j.lin;
+        fc << j.cyc;
+    }
     tr.lap("text output");
     std::fflush(nullptr);
     _exit(0);                   // outputs are complete and closed: skip the teardown of the host containers

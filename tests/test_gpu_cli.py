@@ -301,3 +301,59 @@ def test_depth_stage_random_equals_oracle_and_auto_graph(tmp_path, seed, n_conti
     assert pa.returncode == 0 and pb.returncode == 0, (pa.stderr, pb.stderr)
     assert open(a, "rb").read() == open(b, "rb").read() == orc.graph_run(recs, targets, fai, float(text))
     assert f"Average sequencing depth: {text}".encode() in pa.stderr
+    # per contig (what step 5 takes from the tabix-indexed depth file): restated here with per-base arrays
+    depth = {i: np.zeros(L, dtype=np.int64) for i, (_, L) in enumerate(targets)}
+    for r in recs:
+        if (r.flag & 0x704) or r.tid < 0 or r.pos < 0:
+            continue
+        at = r.pos
+        for n, op in synth.parse_cigar(r.cigar):
+            if op in (0, 7, 8):
+                depth[r.tid][at:at + n] += 1
+            if op in (0, 2, 3, 7, 8):
+                at += n
+    want = "".join(f"{targets[i][0]}\t{int(d.sum())}\t{int((d > 0).sum())}\n" for i, d in depth.items() if (d > 0).any())
+    pc = run([os.path.join(BIN, "bamdepth"), "--per-contig", bam])
+    assert pc.returncode == 0, pc.stderr
+    assert pc.stdout.decode() == want
+    assert sum(int(l.split("\t")[1]) for l in want.splitlines()) == s and sum(int(l.split("\t")[2]) for l in want.splitlines()) == nr
+
+
+def test_matching_batch_equals_one_process_per_graph(tmp_path):
+    """N3: `matching --batch <list>` (every *.second sub-graph of step 5 in ONE process / one GPU run, palace:651-806)
+    writes byte for byte what one `matching -g ... -b --aggressive` process per graph writes -- and what the oracle writes.
+    Sub-graphs share contigs (the same SEG name in several graphs), carry the 7th SEG column (create_sub_graph.py:77,89)
+    and include an empty one."""
+    rng = synth.rng_for(31)
+    names, lens = synth.contig_names(rng, 3000)
+    side = synth.filter_side_files(rng, names, lens)
+    paths = str(tmp_path / "contigs.paths")
+    open(paths, "w").write(side["contigs_paths"])
+    flags = ["-i", "10", "-b", "--aggressive"]
+    jobs = []
+    for k in range(40):
+        m = int(rng.integers(0, 150)) if k != 7 else 0
+        mine = rng.choice(len(names), size=m, replace=False) if m else []
+        seg = "".join(f"SEG {names[i]} {rng.random() * 30:.4g} {int(rng.integers(0, 4))} 0 0.100 1 {int(rng.integers(-1, 9))}\n" for i in mine)
+        junc = []
+        for _ in range(2 * m):
+            a, b = int(rng.choice(mine)), int(rng.choice(mine))
+            junc.append(f"JUNC {names[a]} {'+-'[int(rng.integers(0, 2))]} {names[b]} {'+-'[int(rng.integers(0, 2))]} "
+                        f"{int(rng.integers(1, 40))} {int(rng.integers(0, 5))}\n")
+        g = str(tmp_path / f"s_ref{k}ref.second")
+        open(g, "w").write(seg + "".join(junc))
+        jobs.append(g)
+    lst = str(tmp_path / "batch.txt")
+    open(lst, "w").write("".join(f"{g}\t{g[:-7]}_linear.txt\t{g[:-7]}_cycle.txt\n" for g in jobs))
+    r = run([os.path.join(BIN, "matching"), "--batch", lst, *flags, "-l", paths])
+    assert r.returncode == 0, r.stderr
+    n_cyc = 0
+    for g in jobs:
+        lin1, cyc1 = g + ".lin1", g + ".cyc1"
+        r = run([os.path.join(BIN, "matching"), "-g", g, "-r", lin1, "-c", cyc1, *flags, "-l", paths])
+        assert r.returncode == 0, r.stderr
+        got = (open(g[:-7] + "_linear.txt", "rb").read(), open(g[:-7] + "_cycle.txt", "rb").read())
+        assert got == (open(lin1, "rb").read(), open(cyc1, "rb").read()), g
+        assert got == orc.match_run(g, paths, 10, False, True, True), g
+        n_cyc += got[1].count(b"iter")
+    assert n_cyc > 10
