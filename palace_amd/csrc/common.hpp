@@ -64,6 +64,7 @@ struct palace_ctx {
     palace::CoderMasks masks{};
     uint32_t *plane[3] = {nullptr, nullptr, nullptr};
     bool planes_external = false;
+    bool table_clean = false;       // every plane bit is zero (set by reset, cleared by whatever writes the planes)
     int count_mode = 0;             // 0 auto, 1 direct atomics, 2 binned
     int64_t bin_cap_override = 0;
     int64_t slab_override = 0;

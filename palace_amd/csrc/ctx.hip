@@ -63,6 +63,7 @@ int ensure_table(palace_ctx *ctx)
             return PALACE_ENOMEM;
         }
         PALACE_HIP_TRY(hipMemsetAsync(ctx->plane[p], 0, kPlaneBytes, ctx->stream));
+        if (p == 2) ctx->table_clean = true;                 // freshly allocated and zeroed
     }
     return PALACE_OK;
 }

@@ -163,7 +163,10 @@ constexpr int kBuckets = 1 << kBucketBits;            // 16384 fine buckets
 constexpr int kBucketShift = 32 - kBucketBits;        // 18: keys per fine bucket = 2^18
 constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 per plane per bucket
 constexpr int kL1Buckets = 128, kL1Shift = 25;        // level 1: key >> 25
-constexpr int kL1Replicas = 32;                       // level-1 bucket regions are split 32 ways so that the
+#ifndef PALACE_L1_REPLICAS
+#define PALACE_L1_REPLICAS 32
+#endif
+constexpr int kL1Replicas = PALACE_L1_REPLICAS;                       // level-1 bucket regions are split 32 ways so that the
                                                       // per-tile reservations do not pile onto 128 addresses
 constexpr int kBinThreads = 512;                      // 8 waves; 37.5 KiB of LDS -> 4 workgroups per CU
 constexpr int kRowSlots = 72;                         // mean staging row
@@ -188,11 +191,21 @@ __host__ __device__ constexpr uint32_t l1_row_start(uint32_t b)
 }
 static_assert(l1_row_start(kL1Buckets) == kStageSlots, "rows tile the staging area");
 
+// the exact slow path of the partition kernels: the key goes straight to the planes, and its fine bucket is marked so
+// that the count kernel knows this slice of the planes is not what it was when the launch began
+__device__ __forceinline__ void count_key_marked(uint32_t key, uint32_t *__restrict__ p1, uint32_t *__restrict__ p2,
+                                                 uint32_t *__restrict__ p3, unsigned int *__restrict__ touched)
+{
+    atomicOr(&touched[key >> 21], 1u << ((key >> 16) & 31));
+    count_key(key, p1, p2, p3);
+}
+
 struct BinOut {
     unsigned int *cursor;          // per destination region: keys reserved so far
     uint32_t *buf;                 // destination regions, laid out by `caps`
     DensityCaps caps;              // capacity of a destination region of level-1 bucket b
     uint32_t *p1, *p2, *p3;        // overflow path
+    unsigned int *touched;         // one bit per fine bucket: the overflow path wrote into its plane slices
 };
 
 // Level-1 cursors are laid out replica-major: the 16 reservations of a wave (16 consecutive buckets, one replica) fall
@@ -218,10 +231,10 @@ struct Dest { uint32_t region; uint64_t base; uint32_t cap; };
 
 typedef uint32_t __attribute__((address_space(1))) global_u32;
 
-template <class D>
+template <int THREADS = kBinThreads, class D>
 __device__ __forceinline__ void flush_rows(Stage &st, const BinOut &o, D dest)
 {
-    constexpr int rows_per_wave = kL1Buckets / (kBinThreads / 64);
+    constexpr int rows_per_wave = kL1Buckets / (THREADS / 64);
     __syncthreads();
     // The first lanes of a wave reserve the runs of the wave's 16 rows (all atomics in flight together) and work out
     // each row's destination pointer; the wave then walks its rows with count, source and pointer in SGPRs
@@ -272,7 +285,7 @@ __device__ __forceinline__ void flush_rows(Stage &st, const BinOut &o, D dest)
                 if (q + lane < cj) {
                     const uint32_t k = st.slot[sj + q + lane];
                     if (q + lane < room) dst[q + lane] = k;
-                    else count_key(k, o.p1, o.p2, o.p3);
+                    else count_key_marked(k, o.p1, o.p2, o.p3, o.touched);
                 }
             }
             continue;
@@ -354,35 +367,54 @@ __device__ __forceinline__ void class_bits4(uint32_t x, uint32_t &p0, uint32_t &
 }
 
 constexpr int kStreamGroups = 4;                       // 16-base groups per lane (their loads are in flight together)
-__global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__restrict__ all_bases,
-                                                           const int64_t *__restrict__ offsets, int64_t total,
-                                                           uint16_t *__restrict__ s0, uint16_t *__restrict__ s1,
-                                                           uint16_t *__restrict__ s2, uint16_t *__restrict__ sok)
+constexpr int kStreamTile = kStreamGroups * 256;       // groups per workgroup
+
+__device__ __forceinline__ void load_group(const uint8_t *__restrict__ bases, int64_t p, int64_t total, bool aligned, uint32_t x[4])
 {
-    const uint8_t *bases = all_bases + offsets[0];
-    const bool aligned = (reinterpret_cast<uintptr_t>(bases) & 15) == 0;
-    uint32_t x[kStreamGroups][4];
+    if (p + 16 <= total && aligned) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(bases + p);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else {                                               // unaligned read set, the last partial group, or nothing
 #pragma unroll
-    for (int k = 0; k < kStreamGroups; k++) {
-        const int64_t i = (static_cast<int64_t>(blockIdx.x) * kStreamGroups + k) * 256 + threadIdx.x;     // 16 positions
-        const int64_t p = i * 16;
-        if (p + 16 <= total && aligned) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(bases + p);
-            x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w;
-        } else {                                           // unaligned read set, the last partial group, or nothing
+        for (int d = 0; d < 4; d++) {
+            x[d] = 0;
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                x[k][d] = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (p + 4 * d + j < total) x[k][d] |= static_cast<uint32_t>(bases[p + 4 * d + j]) << (8 * j);
-            }
+            for (int j = 0; j < 4; j++)
+                if (p + 4 * d + j < total) x[d] |= static_cast<uint32_t>(bases[p + 4 * d + j]) << (8 * j);
         }
     }
+}
+
+// One workgroup: 1024 groups of 16 positions.  Every lane classifies its groups (P0, P1, P2 and the validity bits); the
+// validity bits of the whole tile, its read-end bits and its dropped bits (+ two groups of look-ahead each) meet in LDS
+// as 16-bit pieces, and every lane then derives U for its own groups from three consecutive pieces of each: bit t of a
+// group = the 32 positions from t on are valid and not dropped (AND over a 32-bit window, log steps) and no read ends
+// among the first 31 of them (OR over a 31-bit window).
+__global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__restrict__ all_bases,
+                                                           const int64_t *__restrict__ offsets, int64_t total,
+                                                           const uint16_t *__restrict__ ends16,
+                                                           const uint16_t *__restrict__ dropped16,
+                                                           uint16_t *__restrict__ s0, uint16_t *__restrict__ s1,
+                                                           uint16_t *__restrict__ s2, uint16_t *__restrict__ su)
+{
+    __shared__ uint16_t ok_lds[kStreamTile + 2], en_lds[kStreamTile + 2];
+    const uint8_t *bases = all_bases + offsets[0];
+    const bool aligned = (reinterpret_cast<uintptr_t>(bases) & 15) == 0;
+    const int64_t g0 = static_cast<int64_t>(blockIdx.x) * kStreamTile;
+    const int64_t n_groups = (total + 15) >> 4;
+    uint32_t x[kStreamGroups + 1][4];
+    uint16_t en[kStreamGroups + 1], dr[kStreamGroups + 1];
 #pragma unroll
-    for (int k = 0; k < kStreamGroups; k++) {
-        const int64_t i = (static_cast<int64_t>(blockIdx.x) * kStreamGroups + k) * 256 + threadIdx.x;
-        if (i * 16 >= total) break;
+    for (int k = 0; k <= kStreamGroups; k++) {
+        if (k == kStreamGroups && threadIdx.x >= 2) break;         // the last round is the two look-ahead groups
+        const int64_t i = g0 + (k < kStreamGroups ? k * 256 : kStreamTile) + threadIdx.x;
+        load_group(bases, i * 16, total, aligned, x[k]);
+        en[k] = i < n_groups ? ends16[i] : static_cast<uint16_t>(0);          // (the bit arrays are padded: see the caller)
+        dr[k] = (dropped16 && i < n_groups) ? dropped16[i] : static_cast<uint16_t>(0);
+    }
+#pragma unroll
+    for (int k = 0; k <= kStreamGroups; k++) {
+        if (k == kStreamGroups && threadIdx.x >= 2) break;
         uint32_t o0 = 0, o1 = 0, o2 = 0, ok = 0;
 #pragma unroll
         for (int d = 0; d < 4; d++) {
@@ -390,44 +422,38 @@ __global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__rest
             class_bits4(x[k][d], a, b, c, v);
             o0 |= a << (4 * d); o1 |= b << (4 * d); o2 |= c << (4 * d); ok |= v << (4 * d);
         }
-        s0[i] = static_cast<uint16_t>(o0); s1[i] = static_cast<uint16_t>(o1);
-        s2[i] = static_cast<uint16_t>(o2); sok[i] = static_cast<uint16_t>(ok);
+        const int local = (k < kStreamGroups ? k * 256 : kStreamTile) + static_cast<int>(threadIdx.x);
+        ok_lds[local] = static_cast<uint16_t>(ok & ~static_cast<uint32_t>(dr[k]));
+        en_lds[local] = en[k];
+        const int64_t i = g0 + local;
+        if (k < kStreamGroups && i < n_groups) {
+            s0[i] = static_cast<uint16_t>(o0); s1[i] = static_cast<uint16_t>(o1); s2[i] = static_cast<uint16_t>(o2);
+        }
     }
-}
-
-// U from the validity stream, the read ends and the dropped reads: one lane per 64 positions.
-__global__ __launch_bounds__(256) void eref_usable_kernel(const unsigned long long *__restrict__ ok_words,
-                                                          const unsigned long long *__restrict__ ends,
-                                                          const unsigned long long *__restrict__ dropped,
-                                                          int64_t n_chunks, unsigned long long *__restrict__ su)
-{
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
-    // (the words behind the last chunk are zero: set by the caller)
-    unsigned long long a_lo = ok_words[c], a_hi = ok_words[c + 1];
-    if (dropped) { a_lo &= ~dropped[c]; a_hi &= ~dropped[c + 1]; }
-    // bit p of a_lo: positions p .. p+31 all valid (AND over a 32-bit window, log steps on the 128-bit pair)
+    __syncthreads();
 #pragma unroll
-    for (int s = 1; s < 32; s <<= 1) {
-        a_lo &= (a_lo >> s) | (a_hi << (64 - s));
-        a_hi &= a_hi >> s;
-    }
-    // bit p of e_lo: a read end in [p, p+30] (OR over a 31-bit window: 2, 4, 8, 16, then 16 + 15)
-    unsigned long long e_lo = ends[c], e_hi = ends[c + 1];
+    for (int k = 0; k < kStreamGroups; k++) {
+        const int local = k * 256 + static_cast<int>(threadIdx.x);
+        const int64_t i = g0 + local;
+        if (i >= n_groups) break;
+        unsigned long long a = static_cast<unsigned long long>(ok_lds[local]) | (static_cast<unsigned long long>(ok_lds[local + 1]) << 16) |
+                               (static_cast<unsigned long long>(ok_lds[local + 2]) << 32);
 #pragma unroll
-    for (int s = 1; s < 16; s <<= 1) {
-        e_lo |= (e_lo >> s) | (e_hi << (64 - s));
-        e_hi |= e_hi >> s;
+        for (int s = 1; s < 32; s <<= 1) a &= a >> s;             // bit t: positions t .. t+31 all valid
+        unsigned long long e = static_cast<unsigned long long>(en_lds[local]) | (static_cast<unsigned long long>(en_lds[local + 1]) << 16) |
+                               (static_cast<unsigned long long>(en_lds[local + 2]) << 32);
+#pragma unroll
+        for (int s = 1; s < 16; s <<= 1) e |= e >> s;
+        e |= e >> 15;                                             // bit t: a read end in [t, t+30]
+        su[i] = static_cast<uint16_t>(a & ~e);
     }
-    e_lo |= (e_lo >> 15) | (e_hi << 49);
-    su[c] = a_lo & ~e_lo;
 }
 
 // bin1 over the bit streams: a lane owns P consecutive positions p .. p+P-1, loads three words of each projection
 // once, funnels them to the 64 bits that start at p (two v_alignbit) and then gets every window with one more
 // v_alignbit.  All row appends of the lane's positions are issued together before their results are used.
-template <int P>
-__global__ __launch_bounds__(kBinThreads) void eref_bin1_streams_kernel(const uint32_t *__restrict__ s0,
+template <int P, int THREADS = kBinThreads>
+__global__ __launch_bounds__(THREADS) void eref_bin1_streams_kernel(const uint32_t *__restrict__ s0,
                                                                         const uint32_t *__restrict__ s1,
                                                                         const uint32_t *__restrict__ s2,
                                                                         const uint32_t *__restrict__ su,
@@ -435,7 +461,7 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin1_streams_kernel(const ui
                                                                         CoderMasks masks, BinOut o)
 {
     __shared__ Stage st;
-    const int64_t p = pos_lo + (static_cast<int64_t>(blockIdx.x) * kBinThreads + threadIdx.x) * P;
+    const int64_t p = pos_lo + (static_cast<int64_t>(blockIdx.x) * THREADS + threadIdx.x) * P;
     // every load of the lane is issued before the staging area is set up (the streams are padded: see the caller)
     const int64_t g = min(p, pos_hi) >> 5;
     const int sh = static_cast<int>(p & 31);
@@ -484,13 +510,13 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin1_streams_kernel(const ui
                 for (int i = 0; i < 3; i++) {
                     const uint32_t at = static_cast<uint32_t>(r[t][i]);
                     if (at < static_cast<uint32_t>(r[t][i] >> 32)) st.slot[at] = key[t][i];
-                    else count_key(key[t][i], o.p1, o.p2, o.p3);
+                    else count_key_marked(key[t][i], o.p1, o.p2, o.p3, o.touched);
                 }
             }
         }
     }
     const uint32_t replica = blockIdx.x % kL1Replicas;
-    flush_rows(st, o, [&](uint32_t row) {
+    flush_rows<THREADS>(st, o, [&](uint32_t row) {
         return Dest{l1_cursor(row, replica), l1_region_base(o.caps, row, replica), o.caps.cap(row)};
     });
 }
@@ -518,6 +544,7 @@ struct Bin2Out {
     uint16_t *buf;                 // fine-bucket regions (16-bit payloads)
     DensityCaps caps;              // capacity of a fine region of level-1 bucket b1, in PAIRS of keys
     uint32_t *p1, *p2, *p3;        // overflow path
+    unsigned int *touched;
 };
 
 // Fine-bucket regions: the 512 fine buckets of level-1 bucket b1 lie side by side, equal capacity; capacities are
@@ -530,14 +557,25 @@ __device__ __forceinline__ uint32_t fine_region_cap(const DensityCaps &c, uint32
 
 typedef uint16_t __attribute__((address_space(1))) global_u16;
 
+// tiles of kTile2Keys keys that cover the capacity of one region of level-1 bucket b
+__host__ __device__ inline uint32_t tiles_of_bucket(const DensityCaps &c, uint32_t b) { return (c.cap(b) + kTile2Keys - 1) / kTile2Keys; }
+
+struct Bin2Grid { uint32_t first[kL1Buckets + 1]; };   // first[b] = workgroups in front of bucket b (tiles x replicas, prefix)
+
 __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned int *__restrict__ cursor1,
                                                                  const uint32_t *__restrict__ buf1, DensityCaps caps1,
-                                                                 Bin2Out o)
+                                                                 Bin2Grid grid, Bin2Out o)
 {
     __shared__ Stage2 st;
-    const uint32_t region = blockIdx.y, b1 = region / kL1Replicas, replica = region % kL1Replicas;
+    // The grid is sized by the CAPACITY of every region, which follows the key density (bucket 0: twice the mean, bucket
+    // 127: almost nothing), not by the largest region times the region count: half as many workgroups start only to
+    // find nothing to do.  blockIdx.x -> (bucket, replica, tile): binary search in the 129-entry prefix.
+    uint32_t lo = 0, hi = kL1Buckets;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (grid.first[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    const uint32_t b1 = lo, within = blockIdx.x - grid.first[b1], per_region = tiles_of_bucket(caps1, b1);
+    const uint32_t replica = within / per_region, tile = within % per_region;
     const uint32_t n1 = min(cursor1[l1_cursor(b1, replica)], caps1.cap(b1));
-    const uint32_t start = blockIdx.x * kTile2Keys;
+    const uint32_t start = tile * kTile2Keys;
     if (start >= n1) return;                               // uniform for the workgroup
     const uint32_t end = min(n1, start + kTile2Keys);
     // all of a thread's keys are loaded (16 bytes at a time: regions and tiles start on 16-byte boundaries and
@@ -553,7 +591,6 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
     if (threadIdx.x < kL2Rows)
         st.rows[threadIdx.x] = (static_cast<unsigned long long>((threadIdx.x + 1) * kRowSlots) << 32) | (threadIdx.x * kRowSlots);
     __syncthreads();
-    const uint32_t hi_bits = b1 << kL1Shift;
 #pragma unroll
     for (int it = 0; it < kVecs; it++) {
         const uint32_t i = start + (it * kBin2Threads + threadIdx.x) * 4;
@@ -567,7 +604,7 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
             if (i + e < end) {
                 const uint32_t at = static_cast<uint32_t>(r[e]);
                 if (at < static_cast<uint32_t>(r[e] >> 32)) st.slot[at] = static_cast<uint16_t>(k[e]);
-                else count_key(hi_bits | (k[e] & ((1u << kL1Shift) - 1)), o.p1, o.p2, o.p3);   // row full: exact slow path
+                else count_key_marked(k[e], o.p1, o.p2, o.p3, o.touched);   // row full: exact slow path
             }
     }
     __syncthreads();
@@ -604,7 +641,7 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
                 if (q + lane < cj) {
                     const uint32_t k = row_slots[q + lane];
                     if (q + lane < room) dst[q + lane] = static_cast<uint16_t>(k);
-                    else count_key((fine << kFineBits) | k, o.p1, o.p2, o.p3);
+                    else count_key_marked((fine << kFineBits) | k, o.p1, o.p2, o.p3, o.touched);
                 }
             }
             continue;
@@ -618,11 +655,15 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
 // global planes, takes the bucket's 16-bit keys with LDS atomicOr climbing 1 -> 2 -> 3, and is written back
 constexpr int kFineWords = kFine / 32;               // 2048 u32 per plane per fine bucket
 constexpr int kCountThreads = 256;
+// CLEAN: the planes were all zero when this launch began (first count after a reset), so a slice is only read when the
+// overflow path of the partition kernels has written into it (`touched`); otherwise it starts from zero in LDS.
+template <bool CLEAN>
 __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const unsigned int *__restrict__ cursor,
                                                                        const uint16_t *__restrict__ binned,
                                                                        DensityCaps caps, uint32_t *__restrict__ p1,
                                                                        uint32_t *__restrict__ p2,
-                                                                       uint32_t *__restrict__ p3)
+                                                                       uint32_t *__restrict__ p3,
+                                                                       const unsigned int *__restrict__ touched)
 {
     __shared__ uint32_t l1[kFineWords], l2[kFineWords], l3[kFineWords];
     const uint32_t b = blockIdx.x, b1 = b / kL2Rows;
@@ -642,10 +683,12 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
         const uint32_t i = threadIdx.x + u * kCountThreads;
         v[u] = i < n8 ? keys[i] : uint4{0, 0, 0, 0};
     }
+    const bool seed = !CLEAN || ((touched[b >> 5] >> (b & 31)) & 1u);      // uniform for the workgroup
     for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) {
-        reinterpret_cast<uint4 *>(l1)[i] = g1[i];
-        reinterpret_cast<uint4 *>(l2)[i] = g2[i];
-        reinterpret_cast<uint4 *>(l3)[i] = g3[i];
+        const uint4 z{0, 0, 0, 0};
+        reinterpret_cast<uint4 *>(l1)[i] = seed ? g1[i] : z;
+        reinterpret_cast<uint4 *>(l2)[i] = seed ? g2[i] : z;
+        reinterpret_cast<uint4 *>(l3)[i] = seed ? g3[i] : z;
     }
     __syncthreads();
     auto apply = [&](uint32_t k) {
@@ -1320,16 +1363,18 @@ int palace_eref_table_reset(palace_ctx *ctx)
     if (rc) return rc;
     if (!fresh)
         for (int p = 0; p < 3; p++) PALACE_HIP_TRY(hipMemsetAsync(ctx->plane[p], 0, kPlaneBytes, ctx->stream));
+    ctx->table_clean = true;
     return PALACE_OK;
 }
 
 namespace {
 // Workspace of one count_reads call over `total_bases` positions: slab size, region capacities, byte counts.
+constexpr size_t kTouchedBytes = 8192 + 256;             // one bit per fine bucket (2^16 bits), padded
 struct CountPlan {
     int64_t slab_bases_max = 0, n_slabs = 0, n_chunks = 0;
     DensityCaps caps1{}, caps2{};
     size_t cur1_bytes = 0, cur2_bytes = 0, buf1_bytes = 0, buf2_bytes = 0, words_bytes = 0;
-    size_t total() const { return cur1_bytes + cur2_bytes + 7 * words_bytes + buf1_bytes + buf2_bytes; }
+    size_t total() const { return cur1_bytes + cur2_bytes + kTouchedBytes + 6 * words_bytes + buf1_bytes + buf2_bytes; }
 };
 constexpr int64_t kRegions = static_cast<int64_t>(kL1Buckets) * kL1Replicas;
 
@@ -1411,6 +1456,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
                            d_bases, d_offsets, n_reads, d_keep, ctx->masks, ctx->plane[0], ctx->plane[1],
                            ctx->plane[2]);
         PALACE_HIP_TRY(hipGetLastError());
+        ctx->table_clean = false;
         return PALACE_OK;
     }
     CountPlan pl;
@@ -1426,14 +1472,15 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     char *ws = static_cast<char *>(ctx->ws.ptr);
     unsigned int *cursor1 = reinterpret_cast<unsigned int *>(ws); ws += cur1_bytes;
     unsigned int *cursor2 = reinterpret_cast<unsigned int *>(ws); ws += cur2_bytes;
+    unsigned int *touched = reinterpret_cast<unsigned int *>(ws); ws += kTouchedBytes;
     unsigned long long *ends = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes;
     unsigned long long *dropped = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes;
-    unsigned long long *strm[5];                           // P0, P1, P2, U, validity
-    for (int q = 0; q < 5; q++) { strm[q] = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes; }
+    unsigned long long *strm[4];                           // P0, P1, P2, U
+    for (int q = 0; q < 4; q++) { strm[q] = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes; }
     uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
     uint16_t *buf2 = reinterpret_cast<uint16_t *>(ws);
-    BinOut o1{cursor1, buf1, caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
-    Bin2Out o2{cursor2, buf2, caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2]};
+    BinOut o1{cursor1, buf1, caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], touched};
+    Bin2Out o2{cursor2, buf2, caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2], touched};
     // the read set as bit streams, once for the whole set: P0, P1, P2, validity; read ends (and dropped reads) -> U
     PALACE_HIP_TRY(hipMemsetAsync(ends, 0, (d_keep ? 2 : 1) * words_bytes, ctx->stream));
     hipLaunchKernelGGL(mark_read_ends_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
@@ -1442,16 +1489,15 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         hipLaunchKernelGGL(mark_dropped_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
                            ctx->stream, d_offsets, n_reads, d_keep, dropped);
     PALACE_HIP_TRY(hipGetLastError());
-    for (int q = 0; q < 5; q++)                           // the last word of each stream may be partly written, and the
+    for (int q = 0; q < 4; q++)                           // the last word of each stream may be partly written, and the
         PALACE_HIP_TRY(hipMemsetAsync(strm[q] + n_chunks - 1, 0, 24, ctx->stream));   // two pad words behind it are read
     {
-        const int64_t lanes = (total_bases + 15) / 16, blocks = (lanes + 256 * kStreamGroups - 1) / (256 * kStreamGroups);
+        const int64_t groups = (total_bases + 15) / 16, blocks = (groups + kStreamTile - 1) / kStreamTile;
         PALACE_REQUIRE(blocks < (1ll << 31), "too many tiles for one launch");
         hipLaunchKernelGGL(eref_streams_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d_bases,
-                           d_offsets, total_bases, reinterpret_cast<uint16_t *>(strm[0]), reinterpret_cast<uint16_t *>(strm[1]),
-                           reinterpret_cast<uint16_t *>(strm[2]), reinterpret_cast<uint16_t *>(strm[4]));
-        hipLaunchKernelGGL(eref_usable_kernel, dim3(static_cast<unsigned>((n_chunks + 255) / 256)), dim3(256), 0, ctx->stream,
-                           strm[4], ends, d_keep ? dropped : nullptr, n_chunks, strm[3]);
+                           d_offsets, total_bases, reinterpret_cast<const uint16_t *>(ends),
+                           d_keep ? reinterpret_cast<const uint16_t *>(dropped) : nullptr, reinterpret_cast<uint16_t *>(strm[0]),
+                           reinterpret_cast<uint16_t *>(strm[1]), reinterpret_cast<uint16_t *>(strm[2]), reinterpret_cast<uint16_t *>(strm[3]));
         PALACE_HIP_TRY(hipGetLastError());
     }
     // positions per lane of the partition kernel: a tile of 512 lanes should hold about 6000 keys (the staging rows
@@ -1459,14 +1505,16 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     const double keys_per_pos = 3.0 * std::max(0.02, 1.0 - 31.0 * static_cast<double>(n_reads) / std::max<double>(1.0, static_cast<double>(total_bases)));
     const int ppl = keys_per_pos > 2.55 ? 4 : keys_per_pos > 2.1 ? 5 : keys_per_pos > 1.6 ? 6 : 8;
     for (int64_t slab = 0; slab < n_slabs; slab++) {
-        PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes, ctx->stream));
+        PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes + kTouchedBytes, ctx->stream));
+        const bool clean = ctx->table_clean && slab == 0;        // every plane bit is still zero: slices need no reading
         const int64_t p_lo = slab * kSlabBases, p_hi = std::min(total_bases, (slab + 1) * kSlabBases);
         const int64_t tile_pos = static_cast<int64_t>(kBinThreads) * ppl;
         const int64_t tiles = (p_hi - p_lo + tile_pos - 1) / tile_pos;
         PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
         const uint32_t *w0 = reinterpret_cast<const uint32_t *>(strm[0]), *w1 = reinterpret_cast<const uint32_t *>(strm[1]),
                        *w2 = reinterpret_cast<const uint32_t *>(strm[2]), *wu = reinterpret_cast<const uint32_t *>(strm[3]);
-        // one tile per workgroup.  (Measured and dropped, twice: persistent workgroups that walk several tiles with the
+        // one tile per workgroup, 8 waves.  (Measured and dropped: 256-thread workgroups with twice the positions per lane
+        // -- the same tile, half the waves per CU -- 13 % slower; and, twice: persistent workgroups that walk several tiles with the
         // next tile's loads in flight -- 25-40 % slower; the workgroups of a CU then run their append / reserve / copy
         // phases in step, while freshly dispatched ones interleave them.)
         const dim3 grid(static_cast<unsigned>(tiles)), block(kBinThreads);
@@ -1480,13 +1528,19 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
 #if PALACE_ABL          // diagnostic build: the partition output is garbage, only the first kernel is timed
         continue;
 #endif
-        const unsigned tiles2 = (caps1.cap(0) + kTile2Keys - 1) / kTile2Keys;        // bucket 0 has the largest regions
-        hipLaunchKernelGGL(eref_bin2_kernel, dim3(tiles2, static_cast<unsigned>(kRegions)), dim3(kBin2Threads), 0, ctx->stream,
-                           cursor1, buf1, caps1, o2);
+        Bin2Grid g2;
+        g2.first[0] = 0;
+        for (uint32_t b = 0; b < kL1Buckets; b++) g2.first[b + 1] = g2.first[b] + tiles_of_bucket(caps1, b) * kL1Replicas;
+        hipLaunchKernelGGL(eref_bin2_kernel, dim3(g2.first[kL1Buckets]), dim3(kBin2Threads), 0, ctx->stream, cursor1, buf1, caps1, g2, o2);
         PALACE_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(eref_lds_count_kernel, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, cursor2, buf2, caps2,
-                           ctx->plane[0], ctx->plane[1], ctx->plane[2]);
+        if (clean)
+            hipLaunchKernelGGL(eref_lds_count_kernel<true>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, cursor2, buf2, caps2,
+                               ctx->plane[0], ctx->plane[1], ctx->plane[2], touched);
+        else
+            hipLaunchKernelGGL(eref_lds_count_kernel<false>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, cursor2, buf2, caps2,
+                               ctx->plane[0], ctx->plane[1], ctx->plane[2], touched);
         PALACE_HIP_TRY(hipGetLastError());
+        ctx->table_clean = false;
     }
     return PALACE_OK;
 }
@@ -1753,6 +1807,7 @@ int palace_eref_table_attach(palace_ctx *ctx, void *const d_planes3[3])
         ctx->plane[p] = static_cast<uint32_t *>(d_planes3[p]);
     }
     ctx->planes_external = true;
+    ctx->table_clean = false;                              // caller-owned memory: contents unknown
     return PALACE_OK;
 }
 
@@ -1766,6 +1821,7 @@ static int merge_slices_impl(palace_ctx *ctx, const void *d_parts, int n_parts, 
     if (rc) return rc;
     size_t n16 = slice_bytes / 16;
     if (n16 == 0) return PALACE_OK;
+    ctx->table_clean = false;
     char *b1 = reinterpret_cast<char *>(ctx->plane[0]) + slice_off;
     char *b2 = reinterpret_cast<char *>(ctx->plane[1]) + slice_off;
     char *b3 = reinterpret_cast<char *>(ctx->plane[2]) + slice_off;

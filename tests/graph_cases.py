@@ -60,3 +60,66 @@ def depth_records():
 DEPTH_SUM = 5 + 10 + 20 + 10 + 10 + 5 + 5 + 8 + 5          # 78
 DEPTH_NR = 5 + 10 + 10 + 10 + 10 + 5 + 5 + 8 + 5           # 68
 DEPTH_TEXT = "1.14706"                                     # 78 / 68 = 1.147058...  ("%.6g")
+
+
+# ---- every orientation / region combination of the two layout checks, expectation derived from the rules --------------
+# checkPairedEndLayout (generate_graph.cpp:465-506): in the layout the LEFT read must run forward on the left contig's
+# physical right end, the RIGHT read reverse on the right contig's physical left end.  A read qualifies for either side iff
+# it is (forward, END) or (reverse, START) -- the same set for both sides -- so a pair is evidence iff both reads are in that
+# set, and since order 0 (this record's read on the left) is tried first (:916) it always wins:
+#     oL = '+' for (forward, END), '-' for (reverse, START);   oR = '+' for (reverse, START), '-' for (forward, END).
+# checkSplitReadLayout (:510-538): both segments must run forward in the layout; the one that comes first in READ
+# coordinates (canStitchReadIntervals, :401-428) is the left one:
+#     left  qualifies as (forward, END) -> '+' or (reverse, START) -> '-'
+#     right qualifies as (forward, START) -> '+' or (reverse, END) -> '-'.
+# A layout with cR < cL (byte order of the names) is reported as (cR, flip(oR), cL, flip(oL)) (:855-861, :991-997).
+LAYOUT_TARGETS = [("ctgA", 2000), ("ctgB", 2000)]
+START_POS, END_POS = 9, 1899                      # 0-based; 1-based 10 <= min(300, L/2) and 1900 > max(L-300, L/2)
+
+
+def flip(o):
+    return "-" if o == "+" else "+"
+
+
+def canonical(cl, ol, cr, o_r):
+    return (cr, flip(o_r), cl, flip(ol)) if cr < cl else (cl, ol, cr, o_r)
+
+
+def paired_case(rev1, end1, rev2, end2, swap_names=False):
+    """5 records of read 1 only (the mate records are left out so that the :891 quirk stays out of the picture)."""
+    a, b = (1, 0) if swap_names else (0, 1)
+    flag = 0x41 | (0x10 if rev1 else 0) | (0x20 if rev2 else 0)
+    recs = [BamRecord(f"p{i}", flag, a, END_POS if end1 else START_POS, 60, "100M", mtid=b, mpos=END_POS if end2 else START_POS, nm=0)
+            for i in range(5)]
+    left_ok = (not rev1 and end1) or (rev1 and not end1)
+    right_ok = (rev2 and not end2) or (not rev2 and end2)
+    if not (left_ok and right_ok):
+        return recs, None
+    ol = "+" if (not rev1 and end1) else "-"
+    o_r = "+" if (rev2 and not end2) else "-"
+    cl, cr = LAYOUT_TARGETS[a][0], LAYOUT_TARGETS[b][0]
+    k = canonical(cl, ol, cr, o_r)
+    return recs, f"JUNC {k[0]} {k[1]} {k[2]} {k[3]} 0 5\n"        # not in the FASTG: spanCountNoFastg (second number)
+
+
+def split_case(rev_p, end_p, rev_s, end_s, primary_first=True, swap_names=False):
+    """5 split reads of 100 bases: one part covers read bases 1-60, the other 61-100 (forward: 60M40S / 60S40M; on the
+    reverse strand the same read intervals are 40S60M / 40M60S, generate_graph.cpp:330-383)."""
+    a, b = (1, 0) if swap_names else (0, 1)
+    first_cigar = lambda rev: "40S60M" if rev else "60M40S"       # read bases 1-60
+    second_cigar = lambda rev: "40M60S" if rev else "60S40M"      # read bases 61-100
+    cg_p = first_cigar(rev_p) if primary_first else second_cigar(rev_p)
+    cg_s = second_cigar(rev_s) if primary_first else first_cigar(rev_s)
+    pos_p = END_POS if end_p else START_POS
+    pos_s = (END_POS if end_s else START_POS) + 1                  # SA positions are 1-based text
+    sa = f"{LAYOUT_TARGETS[b][0]},{pos_s},{'-' if rev_s else '+'},{cg_s},60,0;"
+    recs = [BamRecord(f"s{i}", 0x10 if rev_p else 0, a, pos_p, 60, cg_p, nm=0, sa=sa) for i in range(5)]
+    (rev_l, end_l, c_l), (rev_r, end_r, c_r) = ((rev_p, end_p, a), (rev_s, end_s, b)) if primary_first else ((rev_s, end_s, b), (rev_p, end_p, a))
+    left_ok = (not rev_l and end_l) or (rev_l and not end_l)
+    right_ok = (not rev_r and not end_r) or (rev_r and end_r)
+    if not (left_ok and right_ok):
+        return recs, None
+    ol = "+" if not rev_l else "-"
+    o_r = "+" if not rev_r else "-"
+    k = canonical(LAYOUT_TARGETS[c_l][0], ol, LAYOUT_TARGETS[c_r][0], o_r)
+    return recs, f"JUNC {k[0]} {k[1]} {k[2]} {k[3]} 5 0\n"        # supplementCountNoFastg counts into the first number

@@ -357,3 +357,31 @@ def test_matching_batch_equals_one_process_per_graph(tmp_path):
         assert got == orc.match_run(g, paths, 10, False, True, True), g
         n_cyc += got[1].count(b"iter")
     assert n_cyc > 10
+
+
+def test_graph_every_layout_combination(tmp_path):
+    """All 16 + 32 orientation / region combinations of the pair and split-read layout checks (tests/graph_cases.py, with
+    and without the name swap), each on its own contig pair, in ONE BAM: the JUNC block must be exactly the rule table's."""
+    import dataclasses
+    import itertools
+    targets, recs, want = [], [], []
+    cases = []
+    for b in itertools.product([False, True], repeat=4):
+        for swap in (False, True):
+            cases.append(gc.paired_case(*b, swap))
+            cases.append(gc.split_case(*b, True, swap))
+            cases.append(gc.split_case(*b, False, swap))
+    for k, (rs, line) in enumerate(cases):
+        base = len(targets)
+        names = [f"c{k:03d}A", f"c{k:03d}B"]
+        targets += [(names[0], 2000), (names[1], 2000)]
+        for r in rs:
+            sa = r.sa.replace("ctgA", names[0]).replace("ctgB", names[1]) if r.sa else r.sa
+            recs.append(dataclasses.replace(r, qname=f"k{k}_{r.qname}", tid=base + r.tid, mtid=(base + r.mtid if r.mtid >= 0 else r.mtid), sa=sa))
+        if line:
+            want.append(line.replace("ctgA", names[0]).replace("ctgB", names[1]))
+    recs.sort(key=lambda r: (r.tid, r.pos))
+    got, fai = graph_cli(tmp_path, targets, "", recs, 1.0)
+    juncs = [l + "\n" for l in got.decode().splitlines() if l.startswith("JUNC")]
+    assert sorted(juncs) == sorted(want) and len(want) == 24
+    assert got == orc.graph_run(recs, targets, fai, 1.0)

@@ -55,3 +55,38 @@ def test_depth_stage_hand_case():
     text, s, nr = orc.depth_mean([BamRecord("a", 0, 0, 0, 60, "10M"), BamRecord("b", 0, 0, 0, 60, "10M")], [("c", 100)])
     assert (text, s, nr) == ("2", 20, 10)
     assert orc.depth_mean([BamRecord("u", 4, -1, -1, 0, "")], [("c", 100)])[0] is None
+
+
+import itertools
+
+import pytest
+
+BOOLS = list(itertools.product([False, True], repeat=4))
+
+
+def junc_lines(out):
+    return "".join(l + "\n" for l in out.decode().splitlines() if l.startswith("JUNC"))
+
+
+@pytest.mark.parametrize("swap", [False, True])
+@pytest.mark.parametrize("rev1,end1,rev2,end2", BOOLS)
+def test_paired_layout_every_orientation_and_region(tmp_path, rev1, end1, rev2, end2, swap):
+    recs, want = gc.paired_case(rev1, end1, rev2, end2, swap)
+    out = run(recs, tmp_path, gc.LAYOUT_TARGETS, "", 1.0)
+    assert junc_lines(out) == (want or "")
+
+
+@pytest.mark.parametrize("swap", [False, True])
+@pytest.mark.parametrize("primary_first", [True, False])
+@pytest.mark.parametrize("rev_p,end_p,rev_s,end_s", BOOLS)
+def test_split_layout_every_orientation_and_region(tmp_path, rev_p, end_p, rev_s, end_s, primary_first, swap):
+    recs, want = gc.split_case(rev_p, end_p, rev_s, end_s, primary_first, swap)
+    out = run(recs, tmp_path, gc.LAYOUT_TARGETS, "", 1.0)
+    assert junc_lines(out) == (want or "")
+    assert sum(w is not None for w in [want]) in (0, 1)
+
+
+def test_layout_tables_have_four_valid_rows_each():
+    assert sum(gc.paired_case(*b)[1] is not None for b in BOOLS) == 4
+    assert sum(gc.split_case(*b)[1] is not None for b in BOOLS) == 4
+    assert sum(gc.split_case(*b, primary_first=False)[1] is not None for b in BOOLS) == 4

@@ -3,10 +3,10 @@
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p tools/ab /tmp/abl
 for n in "$@"; do
-  for f in ctx eref graph match; do
+  for f in ctx eref graph match depth; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DPALACE_ABL=$n -c palace_amd/csrc/$f.hip -o /tmp/abl/$f.$n.o &
   done
   wait
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/ab/lib_abl$n.so /tmp/abl/ctx.$n.o /tmp/abl/eref.$n.o /tmp/abl/graph.$n.o /tmp/abl/match.$n.o
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/ab/lib_abl$n.so /tmp/abl/ctx.$n.o /tmp/abl/eref.$n.o /tmp/abl/graph.$n.o /tmp/abl/match.$n.o /tmp/abl/depth.$n.o
 done
 ls -la tools/ab
