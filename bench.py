@@ -783,10 +783,11 @@ def main():
             if not timed:
                 h_last["edges"] = h_edges.copy()
             if rank == 0:
-                res = capi.match_decompose_views(g, copies, src, dst, 10, False)              # views, no copies
+                # compact result: components that hold an arc-bearing segment + one bit per bare segment (views, no copies)
+                res = capi.match_decompose_views(g, copies, src, dst, 10, False, compact=True)
                 th3 = time.perf_counter()
                 if not timed or "n_comp" not in last:                                          # bookkeeping for the JSON line only
-                    last.update(n_comp=res.n, n_cycles=int(res.kind.sum()), n_multi=int(((res.off[1:] - res.off[:-1]) > 1).sum()))
+                    last.update(n_comp=res.n + res.n_bare, n_cycles=int(res.kind.sum()), n_multi=int(((res.off[1:] - res.off[:-1]) > 1).sum()))
                 res.free()
                 if timed:
                     for k_, v_ in (("d2h_graph", th1 - th0), ("glue", th2 - th1), ("match_decompose", th3 - th2)):

@@ -293,6 +293,17 @@ typedef struct palace_match_result palace_match_result;
 int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
                            const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
                            palace_match_result **out);
+/* The same with `compact` != 0: only components that hold a segment with at least one arc are listed (same order, same
+ * fields); the segments without any arc -- each a one-vertex path of round 0, and again of the extra round when
+ * `aggressive`, that a full result lists in first-vertex order between the others -- are given as one bit per segment
+ * (palace_match_result_bare: ceil(n_segs / 64) words, bit s of word s / 64; palace_match_result_bare_count of them).  A
+ * graph of a million segments of which a few percent touch a junction is the normal case: the full listing is almost
+ * all single-vertex entries. */
+int palace_match_decompose_ex(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
+                              const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
+                              int32_t compact, palace_match_result **out);
+const uint64_t *palace_match_result_bare(const palace_match_result *r);
+int64_t palace_match_result_bare_count(const palace_match_result *r);
 int64_t palace_match_result_count(const palace_match_result *r);
 const int64_t *palace_match_result_offsets(const palace_match_result *r);
 const int32_t *palace_match_result_verts(const palace_match_result *r);

@@ -108,6 +108,8 @@ _SIGS = {
                                      C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],
     "palace_match_decompose": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                C.c_int32, C.POINTER(C.c_void_p)],
+    "palace_match_decompose_ex": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                  C.c_int32, C.c_int32, C.POINTER(C.c_void_p)],
     "palace_graph_resolve": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(GraphParams), C.c_void_p,
                              C.c_void_p, C.c_int64, C.POINTER(C.c_int64)],
 }
@@ -132,7 +134,7 @@ def lib() -> C.CDLL:
         _LIB.palace_version.restype = C.c_char_p
         _LIB.palace_stream.restype = C.c_void_p
         _LIB.palace_stream.argtypes = [C.c_void_p]
-        for nm, rt in (("count", C.c_int64), ("offsets", C.POINTER(C.c_int64)), ("verts", C.POINTER(C.c_int32)),
+        for nm, rt in (("count", C.c_int64), ("bare_count", C.c_int64), ("bare", C.POINTER(C.c_uint64)), ("offsets", C.POINTER(C.c_int64)), ("verts", C.POINTER(C.c_int32)),
                        ("kind", C.POINTER(C.c_uint8)), ("iter", C.POINTER(C.c_int32)), ("open_at", C.POINTER(C.c_int32))):
             fn = getattr(_LIB, "palace_match_result_" + nm)
             fn.argtypes = [C.c_void_p]
@@ -359,14 +361,19 @@ class MatchResult:
 
 
 def match_decompose_views(ctx: "Ctx", copies: np.ndarray, src: np.ndarray, dst: np.ndarray, iterations: int = 10,
-                          aggressive: bool = False) -> MatchResult:
+                          aggressive: bool = False, compact: bool = False) -> MatchResult:
     cp = np.ascontiguousarray(copies, dtype=np.int64)
     s = np.ascontiguousarray(src, dtype=np.int32)
     d = np.ascontiguousarray(dst, dtype=np.int32)
     res = C.c_void_p()
-    _check(lib().palace_match_decompose(ctx.h, len(cp), cp.ctypes.data, len(s), s.ctypes.data, d.ctypes.data,
-                                        iterations, int(aggressive), C.byref(res)), "palace_match_decompose")
-    return MatchResult(res)
+    _check(lib().palace_match_decompose_ex(ctx.h, len(cp), cp.ctypes.data, len(s), s.ctypes.data, d.ctypes.data,
+                                           iterations, int(aggressive), int(compact), C.byref(res)), "palace_match_decompose")
+    r = MatchResult(res)
+    if compact:
+        r.n_bare = int(lib().palace_match_result_bare_count(res))
+        words = (len(cp) + 63) // 64
+        r.bare = np.ctypeslib.as_array(lib().palace_match_result_bare(res), shape=(max(1, words),))[:words]
+    return r
 
 
 def match_decompose(ctx: "Ctx", copies: np.ndarray, src: np.ndarray, dst: np.ndarray, iterations: int = 10,

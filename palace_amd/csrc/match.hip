@@ -213,9 +213,11 @@ struct palace_match_result {            // final result: arrays from the block p
     int64_t *off = nullptr;
     int32_t *verts = nullptr, *iter = nullptr, *open_at = nullptr;
     uint8_t *kind = nullptr;
+    uint64_t *bare = nullptr;            // compact results: bit s set = segment s has no arc (bare path of round 0 [+ the aggressive round])
+    int64_t n_bare = 0;
     ~palace_match_result()
     {
-        for (void *p : {(void *)off, (void *)verts, (void *)iter, (void *)open_at, (void *)kind}) palace::g_result_pool.give(p);
+        for (void *p : {(void *)off, (void *)verts, (void *)iter, (void *)open_at, (void *)kind, (void *)bare}) palace::g_result_pool.give(p);
     }
 };
 
@@ -518,6 +520,13 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
                            const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
                            palace_match_result **out)
 {
+    return palace_match_decompose_ex(ctx, n_segs, copies, n_arcs, src, dst, iterations, aggressive, 0, out);
+}
+
+int palace_match_decompose_ex(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
+                              const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
+                              int32_t compact, palace_match_result **out)
+{
     PALACE_REQUIRE(ctx && out && n_segs >= 0 && n_arcs >= 0 && iterations >= 1, "bad argument");
     PALACE_REQUIRE(n_segs == 0 || copies, "null copies");
     PALACE_REQUIRE(n_arcs == 0 || (src && dst), "null arc arrays");
@@ -576,6 +585,35 @@ int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copie
     const int64_t n_sub_comp = static_cast<int64_t>(sub.kind.size());
     const int last_round = iterations + (aggressive ? 1 : 0) - 1;
     const int64_t n_bare = static_cast<int64_t>(n_segs) - n_sub;
+    if (compact) {
+        // only the components that hold an arc-bearing segment are listed; the bare segments -- each a one-vertex path of
+        // round 0 (and of the extra round when `aggressive`), in first-vertex order between the listed ones -- are given
+        // as a bit per segment
+        palace_match_result *res = new palace_match_result();
+        const int64_t nv = static_cast<int64_t>(sub.verts.size());
+        res->off = static_cast<int64_t *>(palace::g_result_pool.take((n_sub_comp + 1) * 8));
+        res->kind = static_cast<uint8_t *>(palace::g_result_pool.take(n_sub_comp + 1));
+        res->iter = static_cast<int32_t *>(palace::g_result_pool.take((n_sub_comp + 1) * 4));
+        res->open_at = static_cast<int32_t *>(palace::g_result_pool.take((n_sub_comp + 1) * 4));
+        res->verts = static_cast<int32_t *>(palace::g_result_pool.take((nv + 1) * 4));
+        res->bare = static_cast<uint64_t *>(palace::g_result_pool.take((n_words + 1) * 8));
+        if (!res->off || !res->kind || !res->iter || !res->open_at || !res->verts || !res->bare) {
+            delete res;
+            palace::set_error("palace_match_decompose: out of host memory");
+            return PALACE_ENOMEM;
+        }
+        std::copy(sub.off.begin(), sub.off.end(), res->off);
+        std::copy(sub.kind.begin(), sub.kind.end(), res->kind);
+        std::copy(sub.iter.begin(), sub.iter.end(), res->iter);
+        std::copy(sub.open_at.begin(), sub.open_at.end(), res->open_at);
+        std::copy(sub.verts.begin(), sub.verts.end(), res->verts);
+        for (size_t w = 0; w < n_words; w++) res->bare[w] = ~has_arc[w];
+        if (n_segs & 63) res->bare[n_words - 1] &= (1ull << (n_segs & 63)) - 1;
+        res->n = n_sub_comp;
+        res->n_bare = n_bare;
+        *out = res;
+        return PALACE_OK;
+    }
     const int64_t n_out = n_sub_comp + n_bare * (aggressive && last_round > 0 ? 2 : 1);
     const int64_t nv_out = static_cast<int64_t>(sub.verts.size()) + (n_out - n_sub_comp);
     palace_match_result *res = new palace_match_result();
@@ -663,6 +701,8 @@ const int32_t *palace_match_result_verts(const palace_match_result *r) { return 
 const uint8_t *palace_match_result_kind(const palace_match_result *r) { return r ? r->kind : nullptr; }
 const int32_t *palace_match_result_iter(const palace_match_result *r) { return r ? r->iter : nullptr; }
 const int32_t *palace_match_result_open_at(const palace_match_result *r) { return r ? r->open_at : nullptr; }
+const uint64_t *palace_match_result_bare(const palace_match_result *r) { return r ? r->bare : nullptr; }
+int64_t palace_match_result_bare_count(const palace_match_result *r) { return r ? r->n_bare : 0; }
 void palace_match_result_free(palace_match_result *r) { delete r; }
 
 }  // extern "C"

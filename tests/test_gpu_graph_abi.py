@@ -129,3 +129,39 @@ def test_bench_matching_stage_equals_oracle(tmp_path, n, aggressive):
     assert "".join(lin).encode() == want_lin
     assert "".join(cyc).encode() == want_cyc
     assert want_cyc.count(b"iter") > 0
+
+
+def test_compact_decomposition_equals_full():
+    """palace_match_decompose_ex(compact=1): the listed components + the bare-segment bits are exactly the full listing."""
+    from palace_amd import capi
+    rng = np.random.Generator(np.random.PCG64(8))
+    n = 50_000
+    cn = rng.integers(0, 4, size=n).astype(np.int32)
+    e = np.zeros(6000, dtype=capi.EDGE_DTYPE)
+    e["left"] = rng.integers(0, n, len(e)); e["right"] = rng.integers(0, n, len(e))
+    e["oL"] = rng.integers(0, 2, len(e)); e["oR"] = rng.integers(0, 2, len(e))
+    e["counts"] = rng.integers(0, 6, size=(len(e), 4))
+    key = (e["left"].astype(np.int64) << 34) | (e["right"].astype(np.int64) << 2) | (e["oL"] << 1) | e["oR"]
+    e = e[np.unique(key, return_index=True)[1]]
+    import bench
+    copies, src, dst, w = bench.graph_to_arcs(cn, n, e)
+    for aggressive in (False, True):
+        with capi.Ctx(0) as ctx:
+            off, verts, kind, it, open_at = capi.match_decompose(ctx, copies, src, dst, 10, aggressive)
+            with capi.match_decompose_views(ctx, copies, src, dst, 10, aggressive, compact=True) as r:
+                c_off, c_verts, c_kind, c_it, c_open, bare, n_bare = (r.off.copy(), r.verts.copy(), r.kind.copy(), r.iter.copy(),
+                                                                    r.open_at.copy(), r.bare.copy(), r.n_bare)
+        is_bare = np.unpackbits(bare.view(np.uint8), bitorder="little")[:n].astype(bool)
+        assert is_bare.sum() == n_bare
+        touched = np.zeros(n, dtype=bool); touched[src >> 1] = True; touched[dst >> 1] = True
+        assert np.array_equal(is_bare, ~touched)
+        # full listing = compact components + bare singletons (round 0 and, when aggressive, the extra round), first-vertex order per round
+        first = verts[off[:-1]]
+        single_bare = ((off[1:] - off[:-1]) == 1) & is_bare[first >> 1] & (kind == 0)
+        keep = ~single_bare
+        assert np.array_equal(kind[keep], c_kind) and np.array_equal(it[keep], c_it) and np.array_equal(open_at[keep], c_open)
+        lens = (off[1:] - off[:-1])[keep]
+        assert np.array_equal(np.cumsum(lens), c_off[1:])
+        vmask = np.repeat(keep, off[1:] - off[:-1])
+        assert np.array_equal(verts[vmask], c_verts)
+        assert single_bare.sum() == n_bare * (2 if aggressive else 1)
