@@ -252,3 +252,31 @@ def test_config4_long_contigs_full_size_and_oracle_sample(tmp_path):
     want = orc.graph_run(recs, list(zip(names, lens.tolist())), fai, gs["avg_depth"]).decode()
     assert graph_text(names, lens, cons, cn, edges) == want
     assert want.count("JUNC") > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# E3 at its real threshold: more than 1 Gbase in fq1 switches the reference's read subsampling on
+# ------------------------------------------------------------------------------------------------
+def test_e3_subsampling_at_the_real_threshold_equals_reference(tmp_path):
+    """8.4 M read pairs (1.26 Gbase per side): cal_sam_ratio gives 79, so one glibc rand() % 100 draw per sequence line
+    (seed 1, fq1 then fq2) decides which reads are counted (extract_ref.cpp:955-960, 1124-1148, 1239-1240).  Golden = stdout
+    of the compiled reference on the same bytes (tests/golden/make_eref_e3_golden.py, ~50 min of CPU in the build container);
+    100 of the 200 refs are present at 3-10x, so the dropped fifth of the reads changes the answer."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "eref_e3.npz"))
+    seed, n_refs, n_pairs, n_present, n_phage = (int(x) for x in g["params"])
+    fa, fq1, fq2 = synth.eref_config_inputs(seed, n_refs, n_pairs, n_present=n_present, n_phage_pairs=n_phage)
+    for key, b in (("sha256_db_fa", fa), ("sha256_fq1", fq1), ("sha256_fq2", fq2)):
+        assert hashlib.sha256(b).hexdigest() == str(g[key]), f"regenerated input differs from the one the reference ran on ({key})"
+    for name, b in (("db.fa", fa), ("r_1.fq", fq1), ("r_2.fq", fq2)):
+        open(tmp_path / name, "wb").write(b)
+    del fa, fq1, fq2
+    open(tmp_path / "coder.hdr", "wb").write(g["index_header"].tobytes())
+    args = [os.path.join(BIN, "eref"), str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq"), str(tmp_path / "db.fa"), str(tmp_path / "tmp.txt")]
+    p = subprocess.run(args + ["0.9", "0.85", "16"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, PALACE_CODER_HEADER=str(tmp_path / "coder.hdr")))
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == g["stdout_090_085"].tobytes()
+    p = subprocess.run(args + ["0.8", "0.5", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == g["stdout_080_050"].tobytes()
+    assert g["stdout_090_085"].tobytes().count(b"\n") < g["stdout_080_050"].tobytes().count(b"\n") < n_present
