@@ -24,8 +24,11 @@
 //    and does the 500-base window test with prefix population counts.
 #include "common.hpp"
 
-#ifndef PALACE_ABL
-#define PALACE_ABL 0        // ablation switches of diagnostic builds (tools/build_ablate.sh); the product is built with 0
+#ifdef PALACE_STAMPS        // diagnostic build (tools/dbg/stamps.py): per-workgroup phase stamps of the partition kernels
+__device__ unsigned long long palace_stamp_buf[8 * 65536];
+#define STAMP(arr, i) do { if (arr) (arr)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(arr, i) do { } while (0)
 #endif
 
 
@@ -137,59 +140,46 @@ __global__ __launch_bounds__(256) void eref_count_kernel(const uint8_t *__restri
 
 
 // ------------------------------------------------------------------------------------------
-// E4, binned path: no global atomics on the table.  Two radix-partition levels of 7 bits each
-// bring every key into one of 2^14 fine buckets (key >> 18), then one workgroup per bucket counts
-// in LDS.
-//   bin1 kernel   a workgroup owns a tile of the base stream (~5 K keys).  Each key is appended to its
-//                 level-1 bucket's staging row in LDS (one 64-bit LDS atomic returns slot and row end).
-//                 At the end a lane per row reserves the row's run in the bucket's global region with
-//                 ONE global atomicAdd and the rows are copied out -- contiguous, so the stores
-//                 coalesce into whole lines (4-byte stores scattered over 16 Ki destinations do not
-//                 combine in L2: measured 21 ms vs 3 ms).
-//   bin2 kernel   the same step over a level-1 region's keys, on key bits 24..18.
-//   count kernel  one workgroup per fine bucket: its 2^18-key slice of the three planes
-//                 (3 x 32 KiB) lives in LDS, is seeded from the global planes, takes the bucket's keys
-//                 with LDS atomicOr climbing 1 -> 2 -> 3, and is written back with 16-byte stores.
-// The canonical index is min(forward, reverse complement) of two hash-like 32-bit words, so for ANY
-// input its density over the key space is 2(1-x): level-1 bucket 0 receives twice the mean, bucket
-// 127 almost nothing.  Staging rows, level-1 regions and fine-bucket regions are therefore sized
-// by that density (a constant pad plus a share proportional to 255-2b), not uniformly.
-// A key that finds its staging row or its region full takes the global atomicOr path, so the
-// result stays exact for any input.
-// Traffic per key: 4 B x (write, read, write, read) instead of ~52 B of memory-side atomic requests.
+// E4, partitioned path: no global atomics on the table.  The 2.4e9 keys of a gigabase of reads are radix-partitioned in
+// two levels into 2^16 fine buckets (key >> 16), then one workgroup per fine bucket counts in LDS.
+//   stream kernel  bases -> packed bit streams P0, P1, P2 (projections) and U (a 32-mer may start here)
+//   level 1        a workgroup owns a tile of positions: keys from the bit streams (one v_alignbit per window), sorted by
+//                  their top 7 bits in LDS (counting sort), every bucket's run written to that bucket's region with
+//                  16-byte stores; one global atomicAdd per bucket and tile reserves the run
+//   level 2        the same for a tile of one level-1 region, on key bits 24..16 (512 fine rows), writing only the low
+//                  16 bits of every key: below this level a key costs 2 bytes
+//   count kernel   one workgroup per fine bucket: its 2^16-key slice of the three planes (3 x 8 KiB) lives in LDS,
+//                  takes the bucket's keys with LDS atomicOr climbing 1 -> 2 -> 3, and is written back
+// The canonical index is min(forward, reverse complement) of two hash-like 32-bit words, so for ANY input its density
+// over the key space is 2(1-x): level-1 bucket 0 receives twice the mean, bucket 127 almost nothing.  Level-1 regions
+// and fine-bucket regions are therefore sized by that density (a constant pad plus a share proportional to 255-2b).
+// A key that finds its region (or, in level 2, its staging row) full goes straight to the planes with global atomics,
+// so the result stays exact for any input.
+// Traffic per key: 4 B written + 4 B read + 2 B written + 2 B read, instead of ~52 B of memory-side atomic requests.
 // ------------------------------------------------------------------------------------------
-constexpr int kBucketBits = 14;
-constexpr int kBuckets = 1 << kBucketBits;            // 16384 fine buckets
-constexpr int kBucketShift = 32 - kBucketBits;        // 18: keys per fine bucket = 2^18
-constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 per plane per bucket
+constexpr int kBucketBits = 14;                       // probe index of Phase B: 2^14 groups of 2^18 keys
+constexpr int kBuckets = 1 << kBucketBits;
+constexpr int kBucketShift = 32 - kBucketBits;
+constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 of a plane per probe group
 constexpr int kL1Buckets = 128, kL1Shift = 25;        // level 1: key >> 25
 #ifndef PALACE_L1_REPLICAS
 #define PALACE_L1_REPLICAS 32
 #endif
-constexpr int kL1Replicas = PALACE_L1_REPLICAS;                       // level-1 bucket regions are split 32 ways so that the
-                                                      // per-tile reservations do not pile onto 128 addresses
-constexpr int kBinThreads = 512;                      // 8 waves; 37.5 KiB of LDS -> 4 workgroups per CU
-constexpr int kRowSlots = 72;                         // mean staging row
-constexpr int kStageSlots = kL1Buckets * kRowSlots;   // 9216 keys staged per workgroup
-constexpr int kRowPad = 8;                            // density-independent part of a level-1 row
+constexpr int kL1Replicas = PALACE_L1_REPLICAS;       // level-1 bucket regions are split 32 ways so that the per-tile
+                                                      // reservations do not pile onto 128 addresses (8 ... 64: no difference)
+constexpr int kBinThreads = 512;                      // level 1: 8 waves, ~35 KiB of LDS -> 4 workgroups per CU
+constexpr int kRowSlots = 72;                         // level 2: slots of a staging row (mean fill 48: +3.5 sigma)
 
 // Capacity of the slot range that belongs to level-1 bucket b when a total is shared out by the key
 // density: prefix(b) = pad*b + share*b*(256-b)/128, capacity(b) = prefix(b+1) - prefix(b)
 //        = pad + share*(255-2b)/128 (up to rounding); prefix(128) = 128*(pad + share).
 struct DensityCaps {
-    uint64_t share;      // mean capacity handed out by density, in units of 4 keys
-    uint32_t pad;        // flat capacity every bucket gets, in units of 4 keys
-    // multiples of 4 keys, so that regions start on 16-byte boundaries
-    __host__ __device__ uint64_t prefix(uint32_t b) const { return 4 * (static_cast<uint64_t>(pad) * b + ((share * (b * (256u - b))) >> 7)); }
+    uint64_t share;      // mean capacity handed out by density, in units of `unit` keys
+    uint32_t pad;        // flat capacity every bucket gets, in units of `unit` keys
+    uint32_t unit = 4;   // capacities and region starts are multiples of this many keys (4 keys = 16 bytes)
+    __host__ __device__ uint64_t prefix(uint32_t b) const { return unit * (static_cast<uint64_t>(pad) * b + ((share * (b * (256u - b))) >> 7)); }
     __host__ __device__ uint32_t cap(uint32_t b) const { return static_cast<uint32_t>(prefix(b + 1) - prefix(b)); }
 };
-
-// first staging slot of level-1 row b (b = 128: total), rows sized by density
-__host__ __device__ constexpr uint32_t l1_row_start(uint32_t b)
-{
-    return kRowPad * b + (((kRowSlots - kRowPad) * b * (256u - b)) >> 7);
-}
-static_assert(l1_row_start(kL1Buckets) == kStageSlots, "rows tile the staging area");
 
 // the exact slow path of the partition kernels: the key goes straight to the planes, and its fine bucket is marked so
 // that the count kernel knows this slice of the planes is not what it was when the launch began
@@ -208,107 +198,16 @@ struct BinOut {
     unsigned int *touched;         // one bit per fine bucket: the overflow path wrote into its plane slices
 };
 
-// Level-1 cursors are laid out replica-major: the 16 reservations of a wave (16 consecutive buckets, one replica) fall
-// into 64 consecutive bytes instead of 16 different cache lines.
-__host__ __device__ constexpr uint32_t l1_cursor(uint32_t b, uint32_t replica) { return replica * kL1Buckets + b; }
+// Level-1 cursors are laid out replica-major, and inside a replica by (bucket % 8, bucket / 8): the 16 reservations of a
+// wave (buckets w, w + 8, ..., one replica) fall into 64 consecutive bytes instead of 16 different cache lines.
+__host__ __device__ constexpr uint32_t l1_cursor(uint32_t b, uint32_t replica)
+{
+    return replica * kL1Buckets + (b % (kBinThreads / 64)) * (kL1Buckets / (kBinThreads / 64)) + b / (kBinThreads / 64);
+}
 // Level-1 regions: the kL1Replicas regions of bucket b lie side by side, buckets in order.
 __device__ __forceinline__ uint64_t l1_region_base(const DensityCaps &c, uint32_t b, uint32_t replica)
 {
     return c.prefix(b) * kL1Replicas + static_cast<uint64_t>(replica) * c.cap(b);
-}
-
-// The staging area: rows[b] = (row end << 32) | next free slot, so ONE 64-bit LDS atomic hands a key
-// its slot and tells it whether the row is full.
-struct Stage {
-    uint32_t slot[kStageSlots];
-    unsigned long long rows[kL1Buckets];
-    uint32_t start[kL1Buckets + 1];
-};
-
-// stage -> reserve -> copy out.  `dest(row)` names the row's destination: region index (cursor slot),
-// first key of the region in o.buf, region capacity.
-struct Dest { uint32_t region; uint64_t base; uint32_t cap; };
-
-typedef uint32_t __attribute__((address_space(1))) global_u32;
-
-template <int THREADS = kBinThreads, class D>
-__device__ __forceinline__ void flush_rows(Stage &st, const BinOut &o, D dest)
-{
-    constexpr int rows_per_wave = kL1Buckets / (THREADS / 64);
-    __syncthreads();
-    // The first lanes of a wave reserve the runs of the wave's 16 rows (all atomics in flight together) and work out
-    // each row's destination pointer; the wave then walks its rows with count, source and pointer in SGPRs
-    // (v_readlane): four scalar reads per row and no address arithmetic (the scalar unit is shared by the CU's
-    // 32 waves and was the busiest unit of the first version of this loop).
-    const int lane = threadIdx.x & 63;
-    const int row0 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) * rows_per_wave;
-    uint32_t c = 0, s0 = 0, g = 0, cap = 0, p_lo = 0, p_hi = 0;
-    bool over = false;
-    if (lane < rows_per_wave) {
-        const uint32_t row = row0 + lane;
-        const unsigned long long r = st.rows[row];
-        s0 = st.start[row];
-        c = min(static_cast<uint32_t>(r), static_cast<uint32_t>(r >> 32)) - s0;
-        const Dest d = dest(row);
-        cap = d.cap;
-#if PALACE_ABL & 1      // diagnostic build: no reservation atomics (runs land somewhere inside the region)
-        if (c) g = (blockIdx.x * 2654435761u) % max(1u, cap - min(cap, c));
-#else
-        if (c) g = atomicAdd(&o.cursor[d.region], c);
-#endif
-        over = static_cast<uint64_t>(g) + c > cap;
-        const uint64_t ptr = reinterpret_cast<uint64_t>(o.buf + d.base + min(g, cap));
-        p_lo = static_cast<uint32_t>(ptr); p_hi = static_cast<uint32_t>(ptr >> 32);
-    }
-    const unsigned long long over_rows = __ballot(over);          // rows whose run does not fit: rare, exact slow path
-    // The first 64 slots of row j+1 are read from LDS while row j is stored (one LDS round trip per row would
-    // otherwise sit between any two stores); later 64-slot passes of a long row are read in place.
-    uint32_t k_next = st.slot[min(static_cast<uint32_t>(__builtin_amdgcn_readlane(s0, 0)) + lane, static_cast<uint32_t>(kStageSlots - 1))];
-#pragma unroll
-    for (int j = 0; j < rows_per_wave; j++) {
-        const uint32_t cj = __builtin_amdgcn_readlane(c, j), sj = __builtin_amdgcn_readlane(s0, j);
-        const uint32_t bl = __builtin_amdgcn_readlane(p_lo, j), bh = __builtin_amdgcn_readlane(p_hi, j);   // (the builtin returns int)
-        // (a pointer rebuilt from two scalars must be told that it points to global memory, or the stores become flat)
-        global_u32 *dst = reinterpret_cast<global_u32 *>((static_cast<uint64_t>(bh) << 32) | bl);
-        const uint32_t k0 = k_next;
-        if (j + 1 < rows_per_wave)
-            k_next = st.slot[min(static_cast<uint32_t>(__builtin_amdgcn_readlane(s0, j + 1)) + lane, static_cast<uint32_t>(kStageSlots - 1))];
-#if PALACE_ABL & 2      // diagnostic build: no run stores
-        if (k0 == 0x12345u && cj == 77777u) dst[lane] = k0;
-        continue;
-#endif
-        if ((over_rows >> j) & 1ull) {                             // wave-uniform
-            const uint32_t capj = __builtin_amdgcn_readlane(cap, j), gj = __builtin_amdgcn_readlane(g, j);
-            const uint32_t room = capj - (gj < capj ? gj : capj);
-#pragma unroll 1
-            for (uint32_t q = 0; q < cj; q += 64) {
-                if (q + lane < cj) {
-                    const uint32_t k = st.slot[sj + q + lane];
-                    if (q + lane < room) dst[q + lane] = k;
-                    else count_key_marked(k, o.p1, o.p2, o.p3, o.touched);
-                }
-            }
-            continue;
-        }
-        if (lane < cj) dst[lane] = k0;
-#pragma unroll 1
-        for (uint32_t q = 64; q < cj; q += 64)                     // the longest row is 135 slots: up to three passes
-            if (q + lane < cj) dst[q + lane] = st.slot[sj + q + lane];
-    }
-}
-
-// rows sized by density (level 1) or all equal (level 2)
-__device__ __forceinline__ void stage_init(Stage &st, bool by_density)
-{
-    if (threadIdx.x <= kL1Buckets) {
-        const uint32_t b = threadIdx.x;
-        const uint32_t s0 = by_density ? l1_row_start(b) : b * kRowSlots;
-        st.start[b] = s0;
-        if (b < kL1Buckets) {
-            const uint32_t s1 = by_density ? l1_row_start(b + 1) : (b + 1) * kRowSlots;
-            st.rows[b] = (static_cast<unsigned long long>(s1) << 32) | s0;
-        }
-    }
 }
 
 // Read ends as a bit per base position (bit p set <=> position p is the last base of a read), so
@@ -449,31 +348,60 @@ __global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__rest
     }
 }
 
-// bin1 over the bit streams: a lane owns P consecutive positions p .. p+P-1, loads three words of each projection
-// once, funnels them to the 64 bits that start at p (two v_alignbit) and then gets every window with one more
-// v_alignbit.  All row appends of the lane's positions are issued together before their results are used.
-template <int P, int THREADS = kBinThreads>
-__global__ __launch_bounds__(THREADS) void eref_bin1_streams_kernel(const uint32_t *__restrict__ s0,
-                                                                        const uint32_t *__restrict__ s1,
-                                                                        const uint32_t *__restrict__ s2,
-                                                                        const uint32_t *__restrict__ su,
-                                                                        int64_t pos_lo, int64_t pos_hi,
-                                                                        CoderMasks masks, BinOut o)
+// ------------------------------------------------------------------------------------------------------------------
+// Level 1 as a counting sort in LDS (third version of this kernel).  What the first two versions had in common -- a
+// staging row per bucket with slack, one store instruction per row -- made them STORE-INSTRUCTION bound: a microbenchmark
+// of the same pattern (tools/microbench/scatter_runs.hip) writes 192-byte runs at 2.2 TB/s and 1-KiB runs at 4.6 TB/s,
+// ~12.5 G partial-wave store instructions per second chip-wide whatever their width, and the kernel issued 62 M of
+// them (its in-kernel stamps showed every other phase stretch when one phase was made shorter).  So:
+//   1. the lane computes its keys (registers) and counts them per bucket in an LDS histogram;
+//   2. one wave turns the histogram into row starts, every row padded to a multiple of 4 keys; the pad slots get a
+//      SENTINEL -- a key whose top 7 bits name another bucket, which level 2 skips -- so that rows, global runs and
+//      16-byte vectors all stay aligned;
+//   3. 128 lanes reserve the (padded) runs in the bucket regions -- these global atomics are in flight while
+//   4. every lane places its keys at row start + running count (one returning LDS add each);
+//   5. the compact, bucket-sorted tile is swept with 16-byte loads from LDS and 16-byte stores: a lane's four keys belong
+//      to one row (rows are 4-aligned), the row is the keys' own top bits, its destination one LDS read.
+// ~25 full-width store instructions per tile instead of ~160 partial ones.
+// ------------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr uint32_t l1_sentinel(uint32_t b) { return (b ^ 64u) << kL1Shift; }
+constexpr uint32_t kRunAlign = 4;                     // keys: every run of level 1 is padded to a multiple of this (16 bytes)
+
+template <int P>
+__global__ __launch_bounds__(kBinThreads) void eref_bin1_sort_kernel(const uint32_t *__restrict__ s0,
+                                                                     const uint32_t *__restrict__ s1,
+                                                                     const uint32_t *__restrict__ s2,
+                                                                     const uint32_t *__restrict__ su,
+                                                                     int64_t pos_lo, int64_t pos_hi,
+                                                                     CoderMasks masks, BinOut o)
 {
-    __shared__ Stage st;
-    const int64_t p = pos_lo + (static_cast<int64_t>(blockIdx.x) * THREADS + threadIdx.x) * P;
-    // every load of the lane is issued before the staging area is set up (the streams are padded: see the caller)
+    constexpr int kMaxKeys = kBinThreads * P * 3 + kL1Buckets * (kRunAlign - 1);     // every key of the tile + the pad slots of every row
+    __shared__ __attribute__((aligned(16))) uint32_t tile[kMaxKeys];
+    __shared__ uint32_t hist[kL1Buckets], fill[kL1Buckets], start[kL1Buckets + 1], room[kL1Buckets];
+    __shared__ unsigned long long dst[kL1Buckets];       // key index in o.buf of the row's compact slot 0; bit 63: run did not fit whole
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef PALACE_STAMPS
+    unsigned long long stamp_arr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long *stamps = (threadIdx.x == 0 && blockIdx.x % 7 == 0 && blockIdx.x / 7 < 65536) ? stamp_arr : nullptr;
+#else
+    unsigned long long *stamps = nullptr;
+#endif
+    STAMP(stamps, 0);
+    const int64_t p = pos_lo + (static_cast<int64_t>(blockIdx.x) * kBinThreads + threadIdx.x) * P;
+    // every load of the lane is issued before anything else (the streams are padded: see the caller)
     const int64_t g = min(p, pos_hi) >> 5;
     const int sh = static_cast<int>(p & 31);
     uint32_t w[3][3], uw[2];
 #pragma unroll
     for (int q = 0; q < 3; q++) { w[0][q] = s0[g + q]; w[1][q] = s1[g + q]; w[2][q] = s2[g + q]; }
     uw[0] = su[g]; uw[1] = su[g + 1];
-    stage_init(st, true);
+    if (threadIdx.x < kL1Buckets) { hist[threadIdx.x] = 0; fill[threadIdx.x] = 0; }
     __syncthreads();
+    // ---- 1. keys and histogram ----
     uint32_t u = __builtin_amdgcn_alignbit(uw[1], uw[0], sh) & ((1u << P) - 1);
     if (p >= pos_hi) u = 0;
     else if (p + P > pos_hi) u &= (1u << (pos_hi - p)) - 1;     // the slab's last lane
+    uint32_t key[P][3];
     if (u) {
         uint32_t lo[3], hi[3];
 #pragma unroll
@@ -481,44 +409,88 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_streams_kernel(const uint32
             lo[q] = __builtin_amdgcn_alignbit(w[q][1], w[q][0], sh);
             hi[q] = __builtin_amdgcn_alignbit(w[q][2], w[q][1], sh);
         }
-        uint32_t key[P][3];
-        unsigned long long r[P][3];
 #pragma unroll
         for (int t = 0; t < P; t++) {
             kmer_keys(masks, __builtin_amdgcn_alignbit(hi[0], lo[0], t), __builtin_amdgcn_alignbit(hi[1], lo[1], t),
                       __builtin_amdgcn_alignbit(hi[2], lo[2], t), key[t]);
-#if !(PALACE_ABL & 4)
             if ((u >> t) & 1u) {
 #pragma unroll
-                for (int i = 0; i < 3; i++) r[t][i] = atomicAdd(&st.rows[key[t][i] >> kL1Shift], 1ull);
-            }
-#endif
-        }
-#if PALACE_ABL & 4      // diagnostic build: keys computed, nothing appended
-        uint32_t acc = 0;
-#pragma unroll
-        for (int t = 0; t < P; t++)
-#pragma unroll
-            for (int i = 0; i < 3; i++) acc ^= key[t][i];
-        if (acc == 0x9e3779b9u) st.slot[threadIdx.x] = acc;
-        u = 0;
-#endif
-#pragma unroll
-        for (int t = 0; t < P; t++) {
-            if ((u >> t) & 1u) {
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    const uint32_t at = static_cast<uint32_t>(r[t][i]);
-                    if (at < static_cast<uint32_t>(r[t][i] >> 32)) st.slot[at] = key[t][i];
-                    else count_key_marked(key[t][i], o.p1, o.p2, o.p3, o.touched);
-                }
+                for (int i = 0; i < 3; i++) atomicAdd(&hist[key[t][i] >> kL1Shift], 1u);
             }
         }
     }
+    STAMP(stamps, 1);
+    __syncthreads();
+    STAMP(stamps, 2);
+    // ---- 2. row starts (wave 0: two rows per lane), pad slots ----
+    if (wave == 0) {
+        const uint32_t c0 = hist[2 * lane], c1 = hist[2 * lane + 1];
+        const uint32_t pc0 = (c0 + kRunAlign - 1) & ~(kRunAlign - 1), pc1 = (c1 + kRunAlign - 1) & ~(kRunAlign - 1);
+        uint32_t incl = pc0 + pc1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t a0 = incl - pc0 - pc1, a1 = a0 + pc0;
+        start[2 * lane] = a0; start[2 * lane + 1] = a1;
+        if (lane == 63) start[kL1Buckets] = incl;
+        for (uint32_t q = c0; q < pc0; q++) tile[a0 + q] = l1_sentinel(2 * lane);
+        for (uint32_t q = c1; q < pc1; q++) tile[a1 + q] = l1_sentinel(2 * lane + 1);
+    }
+    __syncthreads();
+    STAMP(stamps, 3);
+    // ---- 3. reservations (in flight during 4.) ----
     const uint32_t replica = blockIdx.x % kL1Replicas;
-    flush_rows<THREADS>(st, o, [&](uint32_t row) {
-        return Dest{l1_cursor(row, replica), l1_region_base(o.caps, row, replica), o.caps.cap(row)};
-    });
+    uint32_t my_pc = 0, my_g = 0;
+    if (threadIdx.x < kL1Buckets) {
+        my_pc = start[threadIdx.x + 1] - start[threadIdx.x];
+        if (my_pc) my_g = atomicAdd(&o.cursor[l1_cursor(threadIdx.x, replica)], my_pc);
+    }
+    // ---- 4. placement ----
+    if (u) {
+#pragma unroll
+        for (int t = 0; t < P; t++) {
+            if ((u >> t) & 1u) {
+                uint32_t at[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) at[i] = atomicAdd(&fill[key[t][i] >> kL1Shift], 1u);
+#pragma unroll
+                for (int i = 0; i < 3; i++) tile[start[key[t][i] >> kL1Shift] + at[i]] = key[t][i];
+            }
+        }
+    }
+    if (threadIdx.x < kL1Buckets) {
+        const uint32_t cap = o.caps.cap(threadIdx.x);
+        const bool whole = static_cast<uint64_t>(my_g) + my_pc <= cap;
+        room[threadIdx.x] = cap - min(cap, my_g);                 // keys of the run that fit (a multiple of 4)
+        dst[threadIdx.x] = (l1_region_base(o.caps, threadIdx.x, replica) + my_g - start[threadIdx.x]) | (whole ? 0ull : 1ull << 63);
+    }
+    __syncthreads();
+    STAMP(stamps, 4);
+    // ---- 5. sweep ----
+    const uint32_t total = start[kL1Buckets];
+    for (uint32_t x = threadIdx.x * 4; x < total; x += kBinThreads * 4) {
+        const uint4 k = *reinterpret_cast<const uint4 *>(&tile[x]);
+        // the row of the group: its keys' own top bits (a group of four pads names row ^ 64: they are the tail of that row)
+        const uint32_t row = k.x >> kL1Shift;                     // (the first key of an aligned group of four is never a pad)
+        const unsigned long long d = dst[row];
+        if (!(d >> 63) || x - start[row] < room[row]) {
+            *reinterpret_cast<uint4 *>(o.buf + ((d & ~(1ull << 63)) + x)) = k;
+        } else {                                                   // the region is full: exact slow path, pads skipped
+            const uint32_t kk[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if ((kk[e] >> kL1Shift) == row) count_key_marked(kk[e], o.p1, o.p2, o.p3, o.touched);
+        }
+    }
+    STAMP(stamps, 5);
+#ifdef PALACE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(stamps, 6);
+    if (stamps)
+        for (int i = 0; i < 8; i++) palace_stamp_buf[(blockIdx.x / 7) * 8 + i] = stamp_arr[i];
+#endif
 }
 
 // level 2: blockIdx.y = level-1 region (bucket b1, replica), blockIdx.x = tile of kTile2Keys of its keys.  The 25 low
@@ -596,12 +568,15 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
         const uint32_t i = start + (it * kBin2Threads + threadIdx.x) * 4;
         const uint32_t k[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
         unsigned long long r[4];
+        bool real[4];                                       // (level 1 pads its runs with keys of another bucket)
+#pragma unroll
+        for (int e = 0; e < 4; e++) real[e] = i + e < end && (k[e] >> kL1Shift) == b1;
 #pragma unroll
         for (int e = 0; e < 4; e++)
-            if (i + e < end) r[e] = atomicAdd(&st.rows[(k[e] >> kFineBits) & (kL2Rows - 1)], 1ull);
+            if (real[e]) r[e] = atomicAdd(&st.rows[(k[e] >> kFineBits) & (kL2Rows - 1)], 1ull);
 #pragma unroll
         for (int e = 0; e < 4; e++)
-            if (i + e < end) {
+            if (real[e]) {
                 const uint32_t at = static_cast<uint32_t>(r[e]);
                 if (at < static_cast<uint32_t>(r[e] >> 32)) st.slot[at] = static_cast<uint16_t>(k[e]);
                 else count_key_marked(k[e], o.p1, o.p2, o.p3, o.touched);   // row full: exact slow path
@@ -626,28 +601,45 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
         p_lo = static_cast<uint32_t>(ptr); p_hi = static_cast<uint32_t>(ptr >> 32);
     }
     const unsigned long long over_rows = __ballot(over);
-#pragma unroll 4
-    for (int j = 0; j < rows_per_wave; j++) {
+    // rows in batches of 16: all LDS reads of a batch first, then its stores back to back (a row holds at most 72 slots:
+    // one more, short pass for the fullest rows)
+#pragma unroll
+    for (int j0 = 0; j0 < rows_per_wave; j0 += 16) {
+        uint16_t k[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) k[j] = st.slot[(row0 + j0 + j) * kRowSlots + lane];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t cj = __builtin_amdgcn_readlane(c, j0 + j);
+            const uint32_t bl = __builtin_amdgcn_readlane(p_lo, j0 + j), bh = __builtin_amdgcn_readlane(p_hi, j0 + j);
+            global_u16 *dst = reinterpret_cast<global_u16 *>((static_cast<uint64_t>(bh) << 32) | bl);
+            if ((over_rows >> (j0 + j)) & 1ull) continue;          // wave-uniform; handled below
+            if (lane < cj) dst[lane] = k[j];
+        }
+    }
+    unsigned long long more = __ballot(lane < rows_per_wave && (c > 64 || over));
+    while (more) {
+        const int j = __builtin_ctzll(more);
+        more &= more - 1;
         const uint32_t cj = __builtin_amdgcn_readlane(c, j);
         const uint32_t bl = __builtin_amdgcn_readlane(p_lo, j), bh = __builtin_amdgcn_readlane(p_hi, j);
         global_u16 *dst = reinterpret_cast<global_u16 *>((static_cast<uint64_t>(bh) << 32) | bl);
         const uint16_t *row_slots = st.slot + (row0 + j) * kRowSlots;
-        if ((over_rows >> j) & 1ull) {                             // wave-uniform, rare: the run does not fit its region
+        if ((over_rows >> j) & 1ull) {                             // rare: the run does not fit its region
             const uint32_t gj = __builtin_amdgcn_readlane(g, j);
             const uint32_t room = cap - (gj < cap ? gj : cap);
             const uint32_t fine = b1 * kL2Rows + row0 + j;
 #pragma unroll 1
             for (uint32_t q = 0; q < cj; q += 64) {
                 if (q + lane < cj) {
-                    const uint32_t k = row_slots[q + lane];
-                    if (q + lane < room) dst[q + lane] = static_cast<uint16_t>(k);
-                    else count_key_marked((fine << kFineBits) | k, o.p1, o.p2, o.p3, o.touched);
+                    const uint32_t kk = row_slots[q + lane];
+                    if (q + lane < room) dst[q + lane] = static_cast<uint16_t>(kk);
+                    else count_key_marked((fine << kFineBits) | kk, o.p1, o.p2, o.p3, o.touched);
                 }
             }
             continue;
         }
-        if (lane < cj) dst[lane] = row_slots[lane];
-        if (cj > 64 && lane + 64 < cj) dst[lane + 64] = row_slots[lane + 64];     // a row holds at most 72 slots
+        if (lane + 64 < cj) dst[lane + 64] = row_slots[lane + 64];
     }
 }
 
@@ -1395,12 +1387,13 @@ int plan_count(palace_ctx *ctx, int64_t total_bases, CountPlan *pl)
     // capacities: the key upper bound of one slab (a position range) shared out by the key density with 20 % head
     // room, plus a flat pad of 1/8 of the mean and a constant
     const int64_t max_keys = 3 * slab_bases;
-    const int64_t mean1 = max_keys / kRegions, mean2 = max_keys / kFine / 2;    // mean2: in pairs of 16-bit keys
-    pl->caps1 = DensityCaps{static_cast<uint64_t>(mean1 + mean1 / 5) / 4, static_cast<uint32_t>(mean1 / 8 + 4096) / 4};   // per level-1 region
+    // (level-1 runs are padded to 4 keys: on average 1.5 pad keys per run of ~48)
+    const int64_t mean1 = max_keys / kRegions * 25 / 24, mean2 = max_keys / kFine / 2;    // mean2: in pairs of 16-bit keys
+    pl->caps1 = DensityCaps{static_cast<uint64_t>(mean1 + mean1 / 5) / kRunAlign, static_cast<uint32_t>(mean1 / 8 + 4096) / kRunAlign, kRunAlign};   // per level-1 region
     pl->caps2 = DensityCaps{static_cast<uint64_t>(mean2 + mean2 / 5) / 4, static_cast<uint32_t>(mean2 / 8 + 2048) / 4};   // per fine bucket
     if (ctx->bin_cap_override > 0) {                       // test hook: uniform, deliberately small regions
         pl->caps2 = DensityCaps{0, static_cast<uint32_t>((ctx->bin_cap_override + 3) / 4)};
-        pl->caps1 = DensityCaps{0, static_cast<uint32_t>(ctx->bin_cap_override)};
+        pl->caps1 = DensityCaps{0, static_cast<uint32_t>(ctx->bin_cap_override), kRunAlign};
     }
     PALACE_REQUIRE(pl->caps1.cap(0) < (1u << 31) && pl->caps2.cap(0) < (1u << 30), "slab too large for 32-bit region cursors");
     pl->cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
@@ -1519,15 +1512,12 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         // phases in step, while freshly dispatched ones interleave them.)
         const dim3 grid(static_cast<unsigned>(tiles)), block(kBinThreads);
         switch (ppl) {
-        case 4: hipLaunchKernelGGL(eref_bin1_streams_kernel<4>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
-        case 5: hipLaunchKernelGGL(eref_bin1_streams_kernel<5>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
-        case 6: hipLaunchKernelGGL(eref_bin1_streams_kernel<6>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
-        default: hipLaunchKernelGGL(eref_bin1_streams_kernel<8>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
+        case 4: hipLaunchKernelGGL(eref_bin1_sort_kernel<4>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
+        case 5: hipLaunchKernelGGL(eref_bin1_sort_kernel<5>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
+        case 6: hipLaunchKernelGGL(eref_bin1_sort_kernel<6>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
+        default: hipLaunchKernelGGL(eref_bin1_sort_kernel<8>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
         }
         PALACE_HIP_TRY(hipGetLastError());
-#if PALACE_ABL          // diagnostic build: the partition output is garbage, only the first kernel is timed
-        continue;
-#endif
         Bin2Grid g2;
         g2.first[0] = 0;
         for (uint32_t b = 0; b < kL1Buckets; b++) g2.first[b + 1] = g2.first[b] + tiles_of_bucket(caps1, b) * kL1Replicas;
@@ -1898,3 +1888,12 @@ int palace_eref_table_popcounts(palace_ctx *ctx, uint64_t out3[3])
 }
 
 }  // extern "C"
+
+#ifdef PALACE_STAMPS
+extern "C" int palace_debug_stamps(palace_ctx *ctx, unsigned long long *h_out, int64_t n_words)
+{
+    PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    PALACE_HIP_TRY(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(palace_stamp_buf), static_cast<size_t>(n_words) * 8));
+    return PALACE_OK;
+}
+#endif
