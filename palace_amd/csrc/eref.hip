@@ -28,7 +28,7 @@
 __device__ unsigned long long palace_stamp_buf[8 * 65536];
 #define STAMP(arr, i) do { if (arr) (arr)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
-#define STAMP(arr, i) do { } while (0)
+#define STAMP(arr, i) do { } while (0)      // (the argument is not even named in product builds)
 #endif
 
 
@@ -162,10 +162,7 @@ constexpr int kBuckets = 1 << kBucketBits;
 constexpr int kBucketShift = 32 - kBucketBits;
 constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 of a plane per probe group
 constexpr int kL1Buckets = 128, kL1Shift = 25;        // level 1: key >> 25
-#ifndef PALACE_L1_REPLICAS
-#define PALACE_L1_REPLICAS 32
-#endif
-constexpr int kL1Replicas = PALACE_L1_REPLICAS;       // level-1 bucket regions are split 32 ways so that the per-tile
+constexpr int kL1Replicas = 32;                       // level-1 bucket regions are split 32 ways so that the per-tile
                                                       // reservations do not pile onto 128 addresses (8 ... 64: no difference)
 constexpr int kBinThreads = 512;                      // level 1: 8 waves, ~35 KiB of LDS -> 4 workgroups per CU
 constexpr int kRowSlots = 72;                         // level 2: slots of a staging row (mean fill 48: +3.5 sigma)
@@ -198,12 +195,9 @@ struct BinOut {
     unsigned int *touched;         // one bit per fine bucket: the overflow path wrote into its plane slices
 };
 
-// Level-1 cursors are laid out replica-major, and inside a replica by (bucket % 8, bucket / 8): the 16 reservations of a
-// wave (buckets w, w + 8, ..., one replica) fall into 64 consecutive bytes instead of 16 different cache lines.
-__host__ __device__ constexpr uint32_t l1_cursor(uint32_t b, uint32_t replica)
-{
-    return replica * kL1Buckets + (b % (kBinThreads / 64)) * (kL1Buckets / (kBinThreads / 64)) + b / (kBinThreads / 64);
-}
+// Level-1 cursors are laid out replica-major: the 128 reservations of a tile (one per bucket, lanes 0..127) fall into
+// 512 consecutive bytes instead of 128 different cache lines.
+__host__ __device__ constexpr uint32_t l1_cursor(uint32_t b, uint32_t replica) { return replica * kL1Buckets + b; }
 // Level-1 regions: the kL1Replicas regions of bucket b lie side by side, buckets in order.
 __device__ __forceinline__ uint64_t l1_region_base(const DensityCaps &c, uint32_t b, uint32_t replica)
 {
@@ -359,7 +353,7 @@ __global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__rest
 //      SENTINEL -- a key whose top 7 bits name another bucket, which level 2 skips -- so that rows, global runs and
 //      16-byte vectors all stay aligned;
 //   3. 128 lanes reserve the (padded) runs in the bucket regions -- these global atomics are in flight while
-//   4. every lane places its keys at row start + running count (one returning LDS add each);
+//   4. every lane places its keys at row start + the rank the histogram add returned;
 //   5. the compact, bucket-sorted tile is swept with 16-byte loads from LDS and 16-byte stores: a lane's four keys belong
 //      to one row (rows are 4-aligned), the row is the keys' own top bits, its destination one LDS read.
 // ~25 full-width store instructions per tile instead of ~160 partial ones.
@@ -367,27 +361,25 @@ __global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__rest
 __host__ __device__ constexpr uint32_t l1_sentinel(uint32_t b) { return (b ^ 64u) << kL1Shift; }
 constexpr uint32_t kRunAlign = 4;                     // keys: every run of level 1 is padded to a multiple of this (16 bytes)
 
-template <int P>
-__global__ __launch_bounds__(kBinThreads) void eref_bin1_sort_kernel(const uint32_t *__restrict__ s0,
+template <int P, int THREADS>
+__global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t *__restrict__ s0,
                                                                      const uint32_t *__restrict__ s1,
                                                                      const uint32_t *__restrict__ s2,
                                                                      const uint32_t *__restrict__ su,
                                                                      int64_t pos_lo, int64_t pos_hi,
                                                                      CoderMasks masks, BinOut o)
 {
-    constexpr int kMaxKeys = kBinThreads * P * 3 + kL1Buckets * (kRunAlign - 1);     // every key of the tile + the pad slots of every row
+    constexpr int kMaxKeys = THREADS * P * 3 + kL1Buckets * (kRunAlign - 1);     // every key of the tile + the pad slots of every row
     __shared__ __attribute__((aligned(16))) uint32_t tile[kMaxKeys];
-    __shared__ uint32_t hist[kL1Buckets], fill[kL1Buckets], start[kL1Buckets + 1], room[kL1Buckets];
+    __shared__ uint32_t hist[kL1Buckets], start[kL1Buckets + 1], room[kL1Buckets];
     __shared__ unsigned long long dst[kL1Buckets];       // key index in o.buf of the row's compact slot 0; bit 63: run did not fit whole
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #ifdef PALACE_STAMPS
     unsigned long long stamp_arr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long *stamps = (threadIdx.x == 0 && blockIdx.x % 7 == 0 && blockIdx.x / 7 < 65536) ? stamp_arr : nullptr;
-#else
-    unsigned long long *stamps = nullptr;
 #endif
     STAMP(stamps, 0);
-    const int64_t p = pos_lo + (static_cast<int64_t>(blockIdx.x) * kBinThreads + threadIdx.x) * P;
+    const int64_t p = pos_lo + (static_cast<int64_t>(blockIdx.x) * THREADS + threadIdx.x) * P;
     // every load of the lane is issued before anything else (the streams are padded: see the caller)
     const int64_t g = min(p, pos_hi) >> 5;
     const int sh = static_cast<int>(p & 31);
@@ -395,13 +387,13 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin1_sort_kernel(const uint3
 #pragma unroll
     for (int q = 0; q < 3; q++) { w[0][q] = s0[g + q]; w[1][q] = s1[g + q]; w[2][q] = s2[g + q]; }
     uw[0] = su[g]; uw[1] = su[g + 1];
-    if (threadIdx.x < kL1Buckets) { hist[threadIdx.x] = 0; fill[threadIdx.x] = 0; }
+    if (threadIdx.x < kL1Buckets) hist[threadIdx.x] = 0;
     __syncthreads();
     // ---- 1. keys and histogram ----
     uint32_t u = __builtin_amdgcn_alignbit(uw[1], uw[0], sh) & ((1u << P) - 1);
     if (p >= pos_hi) u = 0;
     else if (p + P > pos_hi) u &= (1u << (pos_hi - p)) - 1;     // the slab's last lane
-    uint32_t key[P][3];
+    uint32_t key[P][3], rank[P][3];
     if (u) {
         uint32_t lo[3], hi[3];
 #pragma unroll
@@ -415,7 +407,7 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin1_sort_kernel(const uint3
                       __builtin_amdgcn_alignbit(hi[2], lo[2], t), key[t]);
             if ((u >> t) & 1u) {
 #pragma unroll
-                for (int i = 0; i < 3; i++) atomicAdd(&hist[key[t][i] >> kL1Shift], 1u);
+                for (int i = 0; i < 3; i++) rank[t][i] = atomicAdd(&hist[key[t][i] >> kL1Shift], 1u);   // its rank in the row
             }
         }
     }
@@ -452,11 +444,8 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin1_sort_kernel(const uint3
 #pragma unroll
         for (int t = 0; t < P; t++) {
             if ((u >> t) & 1u) {
-                uint32_t at[3];
 #pragma unroll
-                for (int i = 0; i < 3; i++) at[i] = atomicAdd(&fill[key[t][i] >> kL1Shift], 1u);
-#pragma unroll
-                for (int i = 0; i < 3; i++) tile[start[key[t][i] >> kL1Shift] + at[i]] = key[t][i];
+                for (int i = 0; i < 3; i++) tile[start[key[t][i] >> kL1Shift] + rank[t][i]] = key[t][i];
             }
         }
     }
@@ -470,7 +459,7 @@ __global__ __launch_bounds__(kBinThreads) void eref_bin1_sort_kernel(const uint3
     STAMP(stamps, 4);
     // ---- 5. sweep ----
     const uint32_t total = start[kL1Buckets];
-    for (uint32_t x = threadIdx.x * 4; x < total; x += kBinThreads * 4) {
+    for (uint32_t x = threadIdx.x * 4; x < total; x += THREADS * 4) {
         const uint4 k = *reinterpret_cast<const uint4 *>(&tile[x]);
         // the row of the group: its keys' own top bits (a group of four pads names row ^ 64: they are the tail of that row)
         const uint32_t row = k.x >> kL1Shift;                     // (the first key of an aligned group of four is never a pad)
@@ -1507,15 +1496,15 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         const uint32_t *w0 = reinterpret_cast<const uint32_t *>(strm[0]), *w1 = reinterpret_cast<const uint32_t *>(strm[1]),
                        *w2 = reinterpret_cast<const uint32_t *>(strm[2]), *wu = reinterpret_cast<const uint32_t *>(strm[3]);
         // one tile per workgroup, 8 waves.  (Measured and dropped: 256-thread workgroups with twice the positions per lane
-        // -- the same tile, half the waves per CU -- 13 % slower; and, twice: persistent workgroups that walk several tiles with the
-        // next tile's loads in flight -- 25-40 % slower; the workgroups of a CU then run their append / reserve / copy
-        // phases in step, while freshly dispatched ones interleave them.)
+        // -- the same tile, half the waves per CU -- 8-13 % slower; 10 positions per lane: the same time, 16: +45 % (one
+        // workgroup per CU); and, twice: persistent workgroups that walk several tiles with the next tile's loads in
+        // flight -- 25-40 % slower; the workgroups of a CU then run their phases in step, freshly dispatched ones interleave them.)
         const dim3 grid(static_cast<unsigned>(tiles)), block(kBinThreads);
         switch (ppl) {
-        case 4: hipLaunchKernelGGL(eref_bin1_sort_kernel<4>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
-        case 5: hipLaunchKernelGGL(eref_bin1_sort_kernel<5>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
-        case 6: hipLaunchKernelGGL(eref_bin1_sort_kernel<6>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
-        default: hipLaunchKernelGGL(eref_bin1_sort_kernel<8>, grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
+        case 4: hipLaunchKernelGGL((eref_bin1_sort_kernel<4, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
+        case 5: hipLaunchKernelGGL((eref_bin1_sort_kernel<5, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
+        case 6: hipLaunchKernelGGL((eref_bin1_sort_kernel<6, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
+        default: hipLaunchKernelGGL((eref_bin1_sort_kernel<8, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
         }
         PALACE_HIP_TRY(hipGetLastError());
         Bin2Grid g2;
