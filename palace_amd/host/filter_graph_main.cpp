@@ -1,0 +1,501 @@
+// filter_graph -- native core of palace_amd/scripts/filter_graph.py (same 13 positional arguments, same two output files,
+// byte for byte the script's output; the script hands over to this executable when it is built).
+//
+// Counterpart of the reference's share/palace/scripts/filter_graph.py (call site palace:568-579).  At the 1M-contig
+// configuration the script is 60 % of the files -> files time of the whole path (4.9 s of pure-Python line handling);
+// this is the same selection over mapped files with interned names.  No GPU work: the stage is a few hash look-ups per
+// line.  Line citations below are to the reference script.
+//
+//   filter_graph fastg.fai graph.txt out.txt depth f_th hit_seqs.out node_scores.out contigs.blast blast_ratio
+//                contigs.fasta.fai all_hit_segs.txt contigs.paths score_threshold
+//
+// Inputs the script would die on with a Python exception (a junction or path naming an unknown contig, a short line)
+// end this program with exit code 1 and a message instead.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "trace.hpp"
+
+namespace {
+
+using sv = std::string_view;
+
+[[noreturn]] void die(const std::string &what)
+{
+    std::fprintf(stderr, "filter_graph: %s\n", what.c_str());
+    std::exit(1);
+}
+
+struct Mapped {
+    const char *p = nullptr;
+    size_t n = 0;
+    explicit Mapped(const char *path)
+    {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) die(std::string("cannot open ") + path);
+        struct stat st{};
+        if (fstat(fd, &st) != 0) die(std::string("cannot stat ") + path);
+        n = static_cast<size_t>(st.st_size);
+        if (n) {
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) die(std::string("cannot map ") + path);
+            p = static_cast<const char *>(m);
+        }
+        ::close(fd);
+    }
+    // calls f(line) for every line, the line INCLUDING its '\n' when it has one (Python's iteration over a file)
+    template <class F>
+    void lines(F f) const
+    {
+        size_t a = 0;
+        while (a < n) {
+            const void *e = std::memchr(p + a, '\n', n - a);
+            const size_t b = e ? static_cast<size_t>(static_cast<const char *>(e) - p) + 1 : n;
+            f(sv(p + a, b - a));
+            a = b;
+        }
+    }
+};
+
+bool is_space(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+sv rstrip(sv s) { while (!s.empty() && is_space(s.back())) s.remove_suffix(1); return s; }
+sv strip(sv s) { s = rstrip(s); while (!s.empty() && is_space(s.front())) s.remove_prefix(1); return s; }
+
+// str.split(sep): every separator counts, empty fields kept
+void split_on(sv s, char sep, std::vector<sv> &out)
+{
+    out.clear();
+    size_t a = 0;
+    for (;;) {
+        const size_t b = s.find(sep, a);
+        if (b == sv::npos) { out.push_back(s.substr(a)); return; }
+        out.push_back(s.substr(a, b - a));
+        a = b + 1;
+    }
+}
+// str.split(): runs of whitespace, no empty fields
+void split_ws(sv s, std::vector<sv> &out)
+{
+    out.clear();
+    size_t a = 0;
+    while (a < s.size()) {
+        while (a < s.size() && is_space(s[a])) a++;
+        size_t b = a;
+        while (b < s.size() && !is_space(s[b])) b++;
+        if (b > a) out.push_back(s.substr(a, b - a));
+        a = b;
+    }
+}
+
+bool has_e(sv s) { return s.find('e') != sv::npos || s.find('E') != sv::npos; }
+
+// float(text): the whole (stripped) token must be a number
+bool to_double(sv tok, double &v)
+{
+    const std::string t(strip(tok));
+    if (t.empty() || t.find('x') != std::string::npos || t.find('X') != std::string::npos) return false;
+    char *end = nullptr;
+    v = std::strtod(t.c_str(), &end);
+    return end == t.c_str() + t.size();
+}
+double need_double(sv tok, const char *what)
+{
+    double v;
+    if (!to_double(tok, v)) die(std::string("not a number in ") + what + ": '" + std::string(tok) + "'");
+    return v;
+}
+long long need_int(sv tok, const char *what)
+{
+    const sv t = strip(tok);
+    size_t i = 0;
+    bool neg = false;
+    if (i < t.size() && (t[i] == '+' || t[i] == '-')) neg = t[i++] == '-';
+    long long v = 0;
+    const size_t first = i;
+    for (; i < t.size() && t[i] >= '0' && t[i] <= '9'; i++) v = v * 10 + (t[i] - '0');
+    if (i == first || i != t.size() || i - first > 18) die(std::string("not an integer in ") + what + ": '" + std::string(t) + "'");
+    return neg ? -v : v;
+}
+std::string fixed3(double v)
+{
+    char buf[400];
+    std::snprintf(buf, sizeof buf, "%.3f", v);
+    return buf;
+}
+sv field(const std::vector<sv> &cols, size_t i, const char *what)
+{
+    if (i >= cols.size()) die(std::string("short line in ") + what);
+    return cols[i];
+}
+// the token between the 3rd and 4th '_' of a contig name (EDGE_<id>_length_<L>_cov_<c>)
+long long name_length(sv name)
+{
+    size_t a = 0;
+    for (int k = 0; k < 3; k++) {
+        a = name.find('_', a);
+        if (a == sv::npos) die("contig name without a length token: " + std::string(name));
+        a++;
+    }
+    const size_t b = name.find('_', a);
+    return need_int(name.substr(a, b == sv::npos ? sv::npos : b - a), "a contig name");
+}
+
+// fields written in scientific notation become plain (l.178-188)
+std::string plain_number(sv tok)
+{
+    double v;
+    if (!has_e(tok) || !to_double(tok, v)) return std::string(tok);
+    char buf[400];
+    if (std::isfinite(v) && v == std::floor(v)) {
+        std::snprintf(buf, sizeof buf, "%.0f", v);
+        if (buf[0] == '-' && buf[1] == '0' && buf[2] == 0) return "0";      // str(int(-0.0))
+        return buf;
+    }
+    std::string s = fixed3(v);
+    while (!s.empty() && s.back() == '0') s.pop_back();
+    if (!s.empty() && s.back() == '.') s.pop_back();
+    return s;
+}
+
+uint64_t hash_bytes(sv s)                          // FNV-1a over 8-byte steps, finished with a multiply-shift mix
+{
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ s.size();
+    size_t i = 0;
+    for (; i + 8 <= s.size(); i += 8) {
+        uint64_t w;
+        std::memcpy(&w, s.data() + i, 8);
+        h = (h ^ w) * 0x100000001b3ull;
+        h ^= h >> 29;
+    }
+    uint64_t w = 0;
+    if (i < s.size()) std::memcpy(&w, s.data() + i, s.size() - i);
+    h = (h ^ w) * 0xbf58476d1ce4e5b9ull;
+    return h ^ (h >> 32);
+}
+
+// string -> dense id, open addressing (a node-based map spends most of this program's time in malloc and cache misses)
+struct Names {
+    std::vector<uint64_t> slots;                   // (hash & ~mask_low32) | (id + 1); 0 = empty
+    std::vector<sv> names;
+    size_t mask = 0;
+    void reserve(size_t n)
+    {
+        size_t cap = 1024;
+        while (cap < 2 * n) cap <<= 1;
+        if (cap <= slots.size()) return;
+        slots.assign(cap, 0);
+        mask = cap - 1;
+        for (size_t id = 0; id < names.size(); id++) place(hash_bytes(names[id]), static_cast<int>(id));
+    }
+    void place(uint64_t h, int id)
+    {
+        size_t at = h & mask;
+        while (slots[at]) at = (at + 1) & mask;
+        slots[at] = (h & 0xffffffff00000000ull) | static_cast<uint32_t>(id + 1);
+    }
+    int find_hashed(sv s, uint64_t h) const
+    {
+        if (slots.empty()) return -1;
+        for (size_t at = h & mask; slots[at]; at = (at + 1) & mask)
+            if ((slots[at] ^ h) >> 32 == 0) {
+                const int id = static_cast<int>(static_cast<uint32_t>(slots[at])) - 1;
+                if (names[static_cast<size_t>(id)] == s) return id;
+            }
+        return -1;
+    }
+    int find(sv s) const { return find_hashed(s, hash_bytes(s)); }
+    int intern(sv s)
+    {
+        if (2 * (names.size() + 1) > slots.size()) reserve(2 * names.size() + 512);
+        const uint64_t h = hash_bytes(s);
+        const int got = find_hashed(s, h);
+        if (got >= 0) return got;
+        names.push_back(s);
+        place(h, static_cast<int>(names.size()) - 1);
+        return static_cast<int>(names.size()) - 1;
+    }
+};
+
+struct Facts {                                     // per name id
+    long long length = -1;                         // fasta .fai
+    bool blast = false, score_hit = false, has_score = false, gene = false;
+    std::string score_text;                        // "%.3f" text (or "0.0")
+    double score = 0;                              // float(score_text), 0 without a score
+    sv raw;                                        // the name's latest SEG line of the graph
+    bool has_raw = false, seed = false, near = false, in_already = false;
+    size_t text_at = 0, text_len = 0;              // the name's first SEG text in the output block
+    const char *text_of = nullptr;                 // the SEG line the latest text was made from
+    std::vector<std::string> more_texts;           // further, different texts of the same name (duplicate SEG lines)
+};
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc < 14) {
+        std::fprintf(stderr, "usage: filter_graph fastg.fai graph.txt out.txt depth f_th hit_seqs.out node_scores.out contigs.blast "
+                             "blast_ratio contigs.fasta.fai all_hit_segs.txt contigs.paths score_threshold\n");
+        return 2;
+    }
+    const char *fastg_fai = argv[1], *graph_path = argv[2], *out_path = argv[3], *gene_file = argv[6], *score_file = argv[7],
+               *blast_file = argv[8], *fasta_fai = argv[10], *hit_segs_path = argv[11], *paths_file = argv[12];
+    (void)need_double(argv[4], "<depth>");                                        // parsed, unused (l.11)
+    const double blast_ratio = need_double(argv[9], "<blast_ratio>"), score_threshold = need_double(argv[13], "<score_threshold>");
+
+    palace_host::Trace trace("filter_graph");
+    Names names;
+    std::vector<Facts> facts;
+    auto id_of = [&](sv s) {
+        const int id = names.intern(s);
+        if (static_cast<size_t>(id) >= facts.size()) facts.resize(static_cast<size_t>(id) + 1);
+        return id;
+    };
+    std::vector<sv> cols, parts;
+
+    // contigs.fasta.fai: lengths, and the id token -> name map contigs.paths is read with
+    Mapped fai(fasta_fai);
+    Names tokens;                                  // id token of a name (EDGE_<token>_...) -> name id
+    std::vector<int> token_name;
+    {
+        size_t n_lines = 0;
+        for (size_t i = 0; i < fai.n; i++) n_lines += fai.p[i] == '\n';
+        names.reserve(n_lines + 16);
+        tokens.reserve(n_lines + 16);
+        facts.reserve(n_lines + 16);
+    }
+    fai.lines([&](sv line) {
+        split_on(strip(line), '\t', cols);
+        const int id = id_of(cols[0]);
+        facts[static_cast<size_t>(id)].length = need_int(field(cols, 1, "the fasta index"), "the fasta index");
+        split_on(cols[0], '_', parts);
+        const int t = tokens.intern(field(parts, 1, "a fasta index name"));
+        if (static_cast<size_t>(t) >= token_name.size()) token_name.resize(static_cast<size_t>(t) + 1);
+        token_name[static_cast<size_t>(t)] = id;                                  // (a later line with the same token wins, as in a dict)
+    });
+
+    trace.lap("fasta index");
+    // contigs.blast: consecutive rows of one (query, subject) pair form a group (l.66-94)
+    Mapped blast(blast_file);
+    {
+        sv cur_q, cur_s;
+        long long aligned = 0;
+        const double cut = blast_ratio * 100;
+        auto group_done = [&](sv q) {
+            const int id = names.find(q);
+            if (id < 0 || facts[static_cast<size_t>(id)].length < 0) die("BLAST query not in the fasta index: " + std::string(q));
+            const long long len = facts[static_cast<size_t>(id)].length;
+            if (len == 0) die("contig of length 0 in the fasta index: " + std::string(q));
+            if (static_cast<double>(aligned) / static_cast<double>(len) > blast_ratio || aligned > 2000) facts[static_cast<size_t>(id)].blast = true;
+        };
+        blast.lines([&](sv line) {
+            split_on(strip(line), '\t', cols);
+            const sv q = field(cols, 0, "the BLAST table"), s = field(cols, 1, "the BLAST table");
+            const double ident = need_double(field(cols, 2, "the BLAST table"), "the BLAST table");
+            const long long alen = need_int(field(cols, 3, "the BLAST table"), "the BLAST table");
+            const bool new_group = (cur_q != q && !cur_q.empty()) || (cur_s != s && !cur_s.empty());
+            if (new_group) {
+                group_done(cur_q);
+                aligned = ident > cut ? alen : 0;
+            } else if (ident > cut) {
+                aligned += alen;
+            }
+            cur_q = q; cur_s = s;
+        });
+        if (!cur_q.empty()) {
+            const int id = names.find(cur_q);
+            if (id >= 0 && facts[static_cast<size_t>(id)].length >= 0) group_done(cur_q);
+        }
+    }
+
+    trace.lap("blast table");
+    // hit_seqs.out: first column, untrimmed (l.101)
+    Mapped genes(gene_file);
+    genes.lines([&](sv line) {
+        const size_t t = line.find('\t');
+        facts[static_cast<size_t>(id_of(t == sv::npos ? line : line.substr(0, t)))].gene = true;
+    });
+
+    // node_scores.out (l.104-112)
+    Mapped scores(score_file);
+    scores.lines([&](sv line) {
+        split_on(strip(line), '\t', cols);
+        const sv val = field(cols, 1, "the score table");
+        Facts &f = facts[static_cast<size_t>(id_of(cols[0]))];
+        f.score_text = has_e(val) ? std::string("0.0") : fixed3(need_double(val, "the score table"));
+        f.has_score = true;
+        f.score = std::strtod(f.score_text.c_str(), nullptr);
+        f.score_hit = f.score > score_threshold;
+    });
+
+    trace.lap("gene hits, scores");
+    { Mapped unused(fastg_fai); }                                                 // opened like the reference does (l.114-120)
+
+    Mapped graph(graph_path);
+    std::string seg_block;                                                        // SEG texts in first-selection order
+    std::vector<int> selected_order;
+    auto flags_of = [&](const Facts &f) {
+        std::string s;
+        if (f.blast) s += "ref+";
+        if (f.score > score_threshold) s += "score+";
+        if (f.gene) s += "gene+";
+        return s;
+    };
+    std::string text;
+    std::vector<sv> toks;
+    auto select = [&](int id) {
+        Facts &f = facts[static_cast<size_t>(id)];
+        if (!f.has_raw) die("junction names a contig without a SEG line: " + std::string(names.names[static_cast<size_t>(id)]));
+        if (f.text_of == f.raw.data()) return;                // the text of this very line is out already
+        f.text_of = f.raw.data();
+        split_ws(f.raw, toks);
+        text.clear();
+        for (size_t i = 0; i < toks.size(); i++) {
+            if (i) text += ' ';
+            if (i < 2) text.append(toks[i]); else text += plain_number(toks[i]);
+        }
+        text += ' ';
+        text += f.gene ? "1" : "0";
+        text += ' ';
+        text += f.has_score ? f.score_text : std::string("0.000");
+        text += f.blast ? " 1\n" : " 0\n";
+        if (f.text_len) {
+            if (sv(seg_block).substr(f.text_at, f.text_len) == text) return;
+            for (const std::string &e : f.more_texts)
+                if (e == text) return;
+            f.more_texts.push_back(text);
+        } else {
+            f.text_at = seg_block.size();
+            f.text_len = text.size();
+        }
+        seg_block += text;
+        // `already` of the script: the second space-separated token of every selected text
+        const size_t a = text.find(' ');
+        if (a != std::string::npos) {
+            const size_t b = text.find(' ', a + 1);
+            const int t = names.find(sv(text).substr(a + 1, (b == std::string::npos ? text.size() : b) - a - 1));
+            if (t >= 0) facts[static_cast<size_t>(t)].in_already = true;
+        }
+    };
+
+    struct End { sv line; int left, right; };
+    std::vector<End> ends;
+    std::vector<std::pair<int, std::string>> hit_rows;       // first position of every name that has flags
+    std::vector<char> hit_listed;
+    graph.lines([&](sv line) {                                // pass 1: SEG lines, seeds; junction ends
+        split_on(rstrip(line), ' ', cols);
+        if (cols[0] != "SEG") {
+            const int l = id_of(field(cols, 1, "a JUNC line")), r = id_of(field(cols, 3, "a JUNC line"));
+            ends.push_back(End{line, l, r});
+            return;
+        }
+        const int id = id_of(field(cols, 1, "a SEG line"));
+        Facts &f = facts[static_cast<size_t>(id)];
+        f.raw = line;
+        f.has_raw = true;
+        const std::string flags = flags_of(f);
+        if (!flags.empty()) {
+            f.seed = true;
+            select(id);
+            if (hit_listed.size() < facts.size()) hit_listed.resize(facts.size(), 0);
+            if (!hit_listed[static_cast<size_t>(id)]) { hit_listed[static_cast<size_t>(id)] = 1; hit_rows.emplace_back(id, flags); }
+        }
+    });
+    trace.lap("graph pass 1");
+    // (the script collects the junction lines after pass 1; a junction in front of its SEG lines is therefore fine, and
+    //  select() below sees every name's LAST SEG line, as the script's raw_seg does)
+    std::vector<sv> juncs;
+    for (const End &e : ends) {                               // pass 2: junctions touching a seed, and self loops
+        if (e.left == e.right || facts[static_cast<size_t>(e.left)].seed || facts[static_cast<size_t>(e.right)].seed) {
+            juncs.push_back(e.line);
+            select(e.left);
+            select(e.right);
+            facts[static_cast<size_t>(e.left)].near = facts[static_cast<size_t>(e.right)].near = true;
+        }
+    }
+    for (Facts &f : facts) f.near = f.near || f.seed;
+    for (const End &e : ends) {                               // pass 3: junctions touching seeds or their neighbours
+        if (facts[static_cast<size_t>(e.left)].near || facts[static_cast<size_t>(e.right)].near) {
+            juncs.push_back(e.line);
+            select(e.left);
+            select(e.right);
+        }
+    }
+
+    trace.lap("graph passes 2, 3");
+    // contigs.paths rescue (l.126-151)
+    Mapped paths(paths_file);
+    std::vector<int> rescued;
+    {
+        std::vector<char> seen(facts.size(), 0);
+        std::string clean;
+        std::vector<int> members;
+        paths.lines([&](sv raw_line) {
+            const sv s = strip(raw_line);
+            clean.clear();
+            for (char c : s) if (c != ';') clean += c;
+            if (sv(clean).substr(0, 4) == "NODE") return;
+            split_on(clean, ',', cols);
+            members.clear();
+            long long total = 0, backed = 0;
+            for (sv tok : cols) {
+                const sv key = tok.empty() ? tok : tok.substr(0, tok.size() - 1);
+                const int t = tokens.find(key);
+                if (t < 0) die("contigs.paths names an unknown contig id: '" + std::string(key) + "'");
+                const int m = token_name[static_cast<size_t>(t)];
+                members.push_back(m);
+                const Facts &f = facts[static_cast<size_t>(m)];
+                const long long len = name_length(names.names[static_cast<size_t>(m)]);
+                total += len;
+                if (f.blast || f.gene || f.score_hit) backed += len;
+            }
+            if (backed > 0 && (static_cast<double>(backed) / static_cast<double>(total) >= 0.5 || backed > 2000))
+                for (int m : members)
+                    if (!seen[static_cast<size_t>(m)]) { seen[static_cast<size_t>(m)] = 1; rescued.push_back(m); }
+        });
+    }
+
+    trace.lap("paths rescue");
+    FILE *out = std::fopen(out_path, "wb");
+    if (!out) die(std::string("cannot write ") + out_path);
+    std::fwrite(seg_block.data(), 1, seg_block.size(), out);
+    for (int m : rescued) {
+        const Facts &f = facts[static_cast<size_t>(m)];
+        if (f.in_already) continue;
+        if (!f.has_raw) die("contigs.paths names a contig without a SEG line: " + std::string(names.names[static_cast<size_t>(m)]));
+        const sv raw = strip(f.raw);
+        std::fwrite(raw.data(), 1, raw.size(), out);
+        std::fputs(" 0 1.0 0\n", out);
+    }
+    {
+        std::unordered_set<sv> emitted;
+        emitted.reserve(2 * juncs.size() + 16);
+        for (sv j : juncs)
+            if (emitted.insert(j).second) std::fwrite(j.data(), 1, j.size(), out);
+    }
+    if (std::fclose(out) != 0) die(std::string("write failed: ") + out_path);
+
+    FILE *hits = std::fopen(hit_segs_path, "wb");
+    if (!hits) die(std::string("cannot write ") + hit_segs_path);
+    for (const auto &row : hit_rows) {
+        const sv name = names.names[static_cast<size_t>(row.first)];
+        std::fputs("SAMPLE\t", hits);
+        std::fwrite(name.data(), 1, name.size(), hits);
+        std::fprintf(hits, "\t%s\n", row.second.c_str());
+    }
+    if (std::fclose(hits) != 0) die(std::string("write failed: ") + hit_segs_path);
+    trace.lap("outputs");
+    return 0;
+}
