@@ -22,16 +22,24 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
+#include "textio.hpp"
 #include "trace.hpp"
 
 namespace {
 
-using sv = std::string_view;
+using palace_host::sv;
+using palace_host::strip;
+using palace_host::rstrip;
+using palace_host::split_on;
+using palace_host::split_ws;
+using palace_host::Names;
 
 [[noreturn]] void die(const std::string &what)
 {
@@ -69,36 +77,6 @@ struct Mapped {
         }
     }
 };
-
-bool is_space(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
-sv rstrip(sv s) { while (!s.empty() && is_space(s.back())) s.remove_suffix(1); return s; }
-sv strip(sv s) { s = rstrip(s); while (!s.empty() && is_space(s.front())) s.remove_prefix(1); return s; }
-
-// str.split(sep): every separator counts, empty fields kept
-void split_on(sv s, char sep, std::vector<sv> &out)
-{
-    out.clear();
-    size_t a = 0;
-    for (;;) {
-        const size_t b = s.find(sep, a);
-        if (b == sv::npos) { out.push_back(s.substr(a)); return; }
-        out.push_back(s.substr(a, b - a));
-        a = b + 1;
-    }
-}
-// str.split(): runs of whitespace, no empty fields
-void split_ws(sv s, std::vector<sv> &out)
-{
-    out.clear();
-    size_t a = 0;
-    while (a < s.size()) {
-        while (a < s.size() && is_space(s[a])) a++;
-        size_t b = a;
-        while (b < s.size() && !is_space(s[b])) b++;
-        if (b > a) out.push_back(s.substr(a, b - a));
-        a = b;
-    }
-}
 
 bool has_e(sv s) { return s.find('e') != sv::npos || s.find('E') != sv::npos; }
 
@@ -170,65 +148,6 @@ std::string plain_number(sv tok)
     return s;
 }
 
-uint64_t hash_bytes(sv s)                          // FNV-1a over 8-byte steps, finished with a multiply-shift mix
-{
-    uint64_t h = 0x9e3779b97f4a7c15ull ^ s.size();
-    size_t i = 0;
-    for (; i + 8 <= s.size(); i += 8) {
-        uint64_t w;
-        std::memcpy(&w, s.data() + i, 8);
-        h = (h ^ w) * 0x100000001b3ull;
-        h ^= h >> 29;
-    }
-    uint64_t w = 0;
-    if (i < s.size()) std::memcpy(&w, s.data() + i, s.size() - i);
-    h = (h ^ w) * 0xbf58476d1ce4e5b9ull;
-    return h ^ (h >> 32);
-}
-
-// string -> dense id, open addressing (a node-based map spends most of this program's time in malloc and cache misses)
-struct Names {
-    std::vector<uint64_t> slots;                   // (hash & ~mask_low32) | (id + 1); 0 = empty
-    std::vector<sv> names;
-    size_t mask = 0;
-    void reserve(size_t n)
-    {
-        size_t cap = 1024;
-        while (cap < 2 * n) cap <<= 1;
-        if (cap <= slots.size()) return;
-        slots.assign(cap, 0);
-        mask = cap - 1;
-        for (size_t id = 0; id < names.size(); id++) place(hash_bytes(names[id]), static_cast<int>(id));
-    }
-    void place(uint64_t h, int id)
-    {
-        size_t at = h & mask;
-        while (slots[at]) at = (at + 1) & mask;
-        slots[at] = (h & 0xffffffff00000000ull) | static_cast<uint32_t>(id + 1);
-    }
-    int find_hashed(sv s, uint64_t h) const
-    {
-        if (slots.empty()) return -1;
-        for (size_t at = h & mask; slots[at]; at = (at + 1) & mask)
-            if ((slots[at] ^ h) >> 32 == 0) {
-                const int id = static_cast<int>(static_cast<uint32_t>(slots[at])) - 1;
-                if (names[static_cast<size_t>(id)] == s) return id;
-            }
-        return -1;
-    }
-    int find(sv s) const { return find_hashed(s, hash_bytes(s)); }
-    int intern(sv s)
-    {
-        if (2 * (names.size() + 1) > slots.size()) reserve(2 * names.size() + 512);
-        const uint64_t h = hash_bytes(s);
-        const int got = find_hashed(s, h);
-        if (got >= 0) return got;
-        names.push_back(s);
-        place(h, static_cast<int>(names.size()) - 1);
-        return static_cast<int>(names.size()) - 1;
-    }
-};
-
 struct Facts {                                     // per name id
     long long length = -1;                         // fasta .fai
     bool blast = false, score_hit = false, has_score = false, gene = false;
@@ -256,40 +175,55 @@ int main(int argc, char **argv)
     const double blast_ratio = need_double(argv[9], "<blast_ratio>"), score_threshold = need_double(argv[13], "<score_threshold>");
 
     palace_host::Trace trace("filter_graph");
+    // Every large file is parsed in parts on threads (line splitting, number parsing, name hashing and look-up: read-only
+    // work) and the results are applied in file order by this thread, so the outcome does not depend on the thread count.
+    size_t n_threads = std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+    bool forced = false;                                                          // (tests: small files in several parts)
+    if (const char *e = std::getenv("PALACE_HOST_THREADS")) { n_threads = static_cast<size_t>(std::max(1, std::atoi(e))); forced = true; }
+    auto cuts_of = [&](const Mapped &m) { return palace_host::line_cuts(m.p, m.n, (m.n < (1u << 20) && !forced) ? 1 : n_threads); };
     Names names;
     std::vector<Facts> facts;
-    auto id_of = [&](sv s) {
-        const int id = names.intern(s);
-        if (static_cast<size_t>(id) >= facts.size()) facts.resize(static_cast<size_t>(id) + 1);
-        return id;
-    };
-    std::vector<sv> cols, parts;
+    auto grow = [&](int id) { if (static_cast<size_t>(id) >= facts.size()) facts.resize(static_cast<size_t>(id) + 1); return id; };
+    auto id_of = [&](sv s) { return grow(names.intern(s)); };
 
     // contigs.fasta.fai: lengths, and the id token -> name map contigs.paths is read with
     Mapped fai(fasta_fai);
     Names tokens;                                  // id token of a name (EDGE_<token>_...) -> name id
     std::vector<int> token_name;
     {
+        struct Row { sv name, token; uint64_t h_name, h_token; long long len; };
+        const std::vector<size_t> cut = cuts_of(fai);
+        std::vector<std::vector<Row>> rows(cut.size() - 1);
+        palace_host::for_parts(cut, [&](size_t k, size_t a, size_t b) {
+            std::vector<sv> cols, parts;
+            palace_host::for_each_line(fai.p + a, b - a, [&](sv line) {
+                split_on(strip(line), '\t', cols);
+                split_on(cols[0], '_', parts);
+                const sv token = field(parts, 1, "a fasta index name");
+                rows[k].push_back(Row{cols[0], token, palace_host::hash_bytes(cols[0]), palace_host::hash_bytes(token),
+                                      need_int(field(cols, 1, "the fasta index"), "the fasta index")});
+            });
+        });
         size_t n_lines = 0;
-        for (size_t i = 0; i < fai.n; i++) n_lines += fai.p[i] == '\n';
+        for (const auto &r : rows) n_lines += r.size();
         names.reserve(n_lines + 16);
         tokens.reserve(n_lines + 16);
         facts.reserve(n_lines + 16);
+        for (const auto &part : rows)
+            for (const Row &r : part) {
+                const int id = grow(names.intern_hashed(r.name, r.h_name));
+                facts[static_cast<size_t>(id)].length = r.len;
+                const int t = tokens.intern_hashed(r.token, r.h_token);
+                if (static_cast<size_t>(t) >= token_name.size()) token_name.resize(static_cast<size_t>(t) + 1);
+                token_name[static_cast<size_t>(t)] = id;                              // (a later line with the same token wins, as in a dict)
+            }
     }
-    fai.lines([&](sv line) {
-        split_on(strip(line), '\t', cols);
-        const int id = id_of(cols[0]);
-        facts[static_cast<size_t>(id)].length = need_int(field(cols, 1, "the fasta index"), "the fasta index");
-        split_on(cols[0], '_', parts);
-        const int t = tokens.intern(field(parts, 1, "a fasta index name"));
-        if (static_cast<size_t>(t) >= token_name.size()) token_name.resize(static_cast<size_t>(t) + 1);
-        token_name[static_cast<size_t>(t)] = id;                                  // (a later line with the same token wins, as in a dict)
-    });
-
     trace.lap("fasta index");
+
     // contigs.blast: consecutive rows of one (query, subject) pair form a group (l.66-94)
     Mapped blast(blast_file);
     {
+        std::vector<sv> cols;
         sv cur_q, cur_s;
         long long aligned = 0;
         const double cut = blast_ratio * 100;
@@ -319,8 +253,8 @@ int main(int argc, char **argv)
             if (id >= 0 && facts[static_cast<size_t>(id)].length >= 0) group_done(cur_q);
         }
     }
-
     trace.lap("blast table");
+
     // hit_seqs.out: first column, untrimmed (l.101)
     Mapped genes(gene_file);
     genes.lines([&](sv line) {
@@ -330,22 +264,39 @@ int main(int argc, char **argv)
 
     // node_scores.out (l.104-112)
     Mapped scores(score_file);
-    scores.lines([&](sv line) {
-        split_on(strip(line), '\t', cols);
-        const sv val = field(cols, 1, "the score table");
-        Facts &f = facts[static_cast<size_t>(id_of(cols[0]))];
-        f.score_text = has_e(val) ? std::string("0.0") : fixed3(need_double(val, "the score table"));
-        f.has_score = true;
-        f.score = std::strtod(f.score_text.c_str(), nullptr);
-        f.score_hit = f.score > score_threshold;
-    });
-
+    {
+        struct Row { sv name; uint64_t h; double score; char text[24]; };      // "%.3f" of anything below 1e19 fits
+        const std::vector<size_t> cut = cuts_of(scores);
+        std::vector<std::vector<Row>> rows(cut.size() - 1);
+        std::vector<std::vector<std::string>> long_text(cut.size() - 1);        // (texts that do not fit: row.text[0] == 0)
+        palace_host::for_parts(cut, [&](size_t k, size_t a, size_t b) {
+            std::vector<sv> cols;
+            palace_host::for_each_line(scores.p + a, b - a, [&](sv line) {
+                split_on(strip(line), '\t', cols);
+                const sv val = field(cols, 1, "the score table");
+                const std::string text = has_e(val) ? std::string("0.0") : fixed3(need_double(val, "the score table"));
+                Row r{cols[0], palace_host::hash_bytes(cols[0]), std::strtod(text.c_str(), nullptr), {0}};
+                if (text.size() < sizeof r.text) std::memcpy(r.text, text.c_str(), text.size() + 1);
+                else long_text[k].push_back(text);
+                rows[k].push_back(r);
+            });
+        });
+        for (size_t k = 0; k < rows.size(); k++) {
+            size_t next_long = 0;
+            for (const Row &r : rows[k]) {
+                Facts &f = facts[static_cast<size_t>(grow(names.intern_hashed(r.name, r.h)))];
+                f.score_text = r.text[0] ? std::string(r.text) : long_text[k][next_long++];
+                f.has_score = true;
+                f.score = r.score;
+                f.score_hit = f.score > score_threshold;
+            }
+        }
+    }
     trace.lap("gene hits, scores");
     { Mapped unused(fastg_fai); }                                                 // opened like the reference does (l.114-120)
 
     Mapped graph(graph_path);
     std::string seg_block;                                                        // SEG texts in first-selection order
-    std::vector<int> selected_order;
     auto flags_of = [&](const Facts &f) {
         std::string s;
         if (f.blast) s += "ref+";
@@ -353,14 +304,9 @@ int main(int argc, char **argv)
         if (f.gene) s += "gene+";
         return s;
     };
-    std::string text;
-    std::vector<sv> toks;
-    auto select = [&](int id) {
-        Facts &f = facts[static_cast<size_t>(id)];
-        if (!f.has_raw) die("junction names a contig without a SEG line: " + std::string(names.names[static_cast<size_t>(id)]));
-        if (f.text_of == f.raw.data()) return;                // the text of this very line is out already
-        f.text_of = f.raw.data();
-        split_ws(f.raw, toks);
+    // the SEG text of a name whose latest SEG line is `raw` (l.190-197)
+    auto render = [&](const Facts &f, sv raw, std::vector<sv> &toks, std::string &text) {
+        split_ws(raw, toks);
         text.clear();
         for (size_t i = 0; i < toks.size(); i++) {
             if (i) text += ' ';
@@ -371,48 +317,93 @@ int main(int argc, char **argv)
         text += ' ';
         text += f.has_score ? f.score_text : std::string("0.000");
         text += f.blast ? " 1\n" : " 0\n";
+    };
+    auto emit = [&](Facts &f, sv text) {                      // select() of the script: a text is written once
         if (f.text_len) {
             if (sv(seg_block).substr(f.text_at, f.text_len) == text) return;
             for (const std::string &e : f.more_texts)
                 if (e == text) return;
-            f.more_texts.push_back(text);
+            f.more_texts.emplace_back(text);
         } else {
             f.text_at = seg_block.size();
             f.text_len = text.size();
         }
-        seg_block += text;
+        seg_block.append(text);
         // `already` of the script: the second space-separated token of every selected text
         const size_t a = text.find(' ');
-        if (a != std::string::npos) {
+        if (a != sv::npos) {
             const size_t b = text.find(' ', a + 1);
-            const int t = names.find(sv(text).substr(a + 1, (b == std::string::npos ? text.size() : b) - a - 1));
+            const int t = names.find(text.substr(a + 1, (b == sv::npos ? text.size() : b) - a - 1));
             if (t >= 0) facts[static_cast<size_t>(t)].in_already = true;
         }
+    };
+    std::string text;
+    std::vector<sv> toks;
+    auto select = [&](int id) {
+        Facts &f = facts[static_cast<size_t>(id)];
+        if (!f.has_raw) die("junction names a contig without a SEG line: " + std::string(names.names[static_cast<size_t>(id)]));
+        if (f.text_of == f.raw.data()) return;                // the text of this very line is out already
+        f.text_of = f.raw.data();
+        render(f, f.raw, toks, text);
+        emit(f, text);
     };
 
     struct End { sv line; int left, right; };
     std::vector<End> ends;
     std::vector<std::pair<int, std::string>> hit_rows;       // first position of every name that has flags
-    std::vector<char> hit_listed;
-    graph.lines([&](sv line) {                                // pass 1: SEG lines, seeds; junction ends
-        split_on(rstrip(line), ' ', cols);
-        if (cols[0] != "SEG") {
-            const int l = id_of(field(cols, 1, "a JUNC line")), r = id_of(field(cols, 3, "a JUNC line"));
-            ends.push_back(End{line, l, r});
-            return;
-        }
-        const int id = id_of(field(cols, 1, "a SEG line"));
-        Facts &f = facts[static_cast<size_t>(id)];
-        f.raw = line;
-        f.has_raw = true;
-        const std::string flags = flags_of(f);
-        if (!flags.empty()) {
-            f.seed = true;
-            select(id);
-            if (hit_listed.size() < facts.size()) hit_listed.resize(facts.size(), 0);
-            if (!hit_listed[static_cast<size_t>(id)]) { hit_listed[static_cast<size_t>(id)] = 1; hit_rows.emplace_back(id, flags); }
-        }
-    });
+    {
+        // pass 1: SEG lines, seeds; junction ends.  The parts resolve names and, for seeds, render the text (every fact a
+        // text depends on is final by now); names the graph alone knows (id -1) are interned when the part is applied.
+        struct Rec { sv line, a, b; int ia, ib; bool seg; uint32_t text_at, text_len; };
+        const std::vector<size_t> cut = cuts_of(graph);
+        std::vector<std::vector<Rec>> recs(cut.size() - 1);
+        std::vector<std::string> texts(cut.size() - 1);
+        const size_t known = facts.size();
+        palace_host::for_parts(cut, [&](size_t k, size_t a, size_t b) {
+            std::vector<sv> cols, tk;
+            std::string one;
+            palace_host::for_each_line(graph.p + a, b - a, [&](sv line) {
+                split_on(rstrip(line), ' ', cols);
+                if (cols[0] != "SEG") {
+                    const sv l = field(cols, 1, "a JUNC line"), r = field(cols, 3, "a JUNC line");
+                    recs[k].push_back(Rec{line, l, r, names.find(l), names.find(r), false, 0, 0});
+                    return;
+                }
+                const sv name = field(cols, 1, "a SEG line");
+                Rec rec{line, name, sv(), names.find(name), -1, true, 0, 0};
+                if (rec.ia >= 0 && static_cast<size_t>(rec.ia) < known) {
+                    const Facts &f = facts[static_cast<size_t>(rec.ia)];
+                    if (f.blast || f.score > score_threshold || f.gene) {
+                        render(f, line, tk, one);
+                        rec.text_at = static_cast<uint32_t>(texts[k].size());
+                        rec.text_len = static_cast<uint32_t>(one.size());
+                        texts[k] += one;
+                    }
+                }
+                recs[k].push_back(rec);
+            });
+        });
+        std::vector<char> hit_listed;
+        for (size_t k = 0; k < recs.size(); k++)
+            for (const Rec &r : recs[k]) {
+                if (!r.seg) {
+                    const int l = r.ia >= 0 ? r.ia : id_of(r.a), rr = r.ib >= 0 ? r.ib : id_of(r.b);
+                    ends.push_back(End{r.line, l, rr});
+                    continue;
+                }
+                const int id = r.ia >= 0 ? r.ia : id_of(r.a);
+                Facts &f = facts[static_cast<size_t>(id)];
+                f.raw = r.line;
+                f.has_raw = true;
+                if (r.text_len) {                             // a seed
+                    f.seed = true;
+                    f.text_of = r.line.data();
+                    emit(f, sv(texts[k]).substr(r.text_at, r.text_len));
+                    if (hit_listed.size() < facts.size()) hit_listed.resize(facts.size(), 0);
+                    if (!hit_listed[static_cast<size_t>(id)]) { hit_listed[static_cast<size_t>(id)] = 1; hit_rows.emplace_back(id, flags_of(f)); }
+                }
+            }
+    }
     trace.lap("graph pass 1");
     // (the script collects the junction lines after pass 1; a junction in front of its SEG lines is therefore fine, and
     //  select() below sees every name's LAST SEG line, as the script's raw_seg does)
@@ -433,38 +424,45 @@ int main(int argc, char **argv)
             select(e.right);
         }
     }
-
     trace.lap("graph passes 2, 3");
-    // contigs.paths rescue (l.126-151)
+
+    // contigs.paths rescue (l.126-151): the parts work out which lines pass and list their members
     Mapped paths(paths_file);
     std::vector<int> rescued;
     {
-        std::vector<char> seen(facts.size(), 0);
-        std::string clean;
-        std::vector<int> members;
-        paths.lines([&](sv raw_line) {
-            const sv s = strip(raw_line);
-            clean.clear();
-            for (char c : s) if (c != ';') clean += c;
-            if (sv(clean).substr(0, 4) == "NODE") return;
-            split_on(clean, ',', cols);
-            members.clear();
-            long long total = 0, backed = 0;
-            for (sv tok : cols) {
-                const sv key = tok.empty() ? tok : tok.substr(0, tok.size() - 1);
-                const int t = tokens.find(key);
-                if (t < 0) die("contigs.paths names an unknown contig id: '" + std::string(key) + "'");
-                const int m = token_name[static_cast<size_t>(t)];
-                members.push_back(m);
-                const Facts &f = facts[static_cast<size_t>(m)];
-                const long long len = name_length(names.names[static_cast<size_t>(m)]);
-                total += len;
-                if (f.blast || f.gene || f.score_hit) backed += len;
-            }
-            if (backed > 0 && (static_cast<double>(backed) / static_cast<double>(total) >= 0.5 || backed > 2000))
-                for (int m : members)
-                    if (!seen[static_cast<size_t>(m)]) { seen[static_cast<size_t>(m)] = 1; rescued.push_back(m); }
+        const std::vector<size_t> cut = cuts_of(paths);
+        std::vector<std::vector<int>> passing(cut.size() - 1);            // members of the passing lines of a part, in order
+        palace_host::for_parts(cut, [&](size_t k, size_t a, size_t b) {
+            std::vector<sv> cols;
+            std::string clean;
+            std::vector<int> members;
+            palace_host::for_each_line(paths.p + a, b - a, [&](sv raw_line) {
+                const sv s = strip(raw_line);
+                clean.clear();
+                for (char c : s) if (c != ';') clean += c;
+                if (sv(clean).substr(0, 4) == "NODE") return;
+                split_on(clean, ',', cols);
+                members.clear();
+                long long total = 0, backed = 0;
+                for (sv tok : cols) {
+                    const sv key = tok.empty() ? tok : tok.substr(0, tok.size() - 1);
+                    const int t = tokens.find(key);
+                    if (t < 0) die("contigs.paths names an unknown contig id: '" + std::string(key) + "'");
+                    const int m = token_name[static_cast<size_t>(t)];
+                    members.push_back(m);
+                    const Facts &f = facts[static_cast<size_t>(m)];
+                    const long long len = name_length(names.names[static_cast<size_t>(m)]);
+                    total += len;
+                    if (f.blast || f.gene || f.score_hit) backed += len;
+                }
+                if (backed > 0 && (static_cast<double>(backed) / static_cast<double>(total) >= 0.5 || backed > 2000))
+                    passing[k].insert(passing[k].end(), members.begin(), members.end());
+            });
         });
+        std::vector<char> seen(facts.size(), 0);
+        for (const auto &part : passing)
+            for (int m : part)
+                if (!seen[static_cast<size_t>(m)]) { seen[static_cast<size_t>(m)] = 1; rescued.push_back(m); }
     }
 
     trace.lap("paths rescue");

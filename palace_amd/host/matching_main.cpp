@@ -14,6 +14,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <unistd.h>
@@ -23,9 +24,13 @@
 #include <vector>
 
 #include "../../include/palace_hip.h"
+#include "fastx.hpp"
+#include "textio.hpp"
 #include "trace.hpp"
 
 namespace {
+
+using palace_host::sv;
 
 #define CK(call)                                                                       \
     do {                                                                               \
@@ -69,24 +74,31 @@ struct Arc { int32_t u, v; int64_t w; int32_t backed; uint64_t cls; };
 struct ConjGraph {
     std::vector<std::string> name;
     std::vector<int64_t> copies;
-    std::unordered_map<std::string, int32_t> seg_of, seg_of_id;
+    palace_host::Names seg_of, seg_of_id;              // keys are views of the mapped graph text (kept by the job)
+    std::vector<int32_t> id_seg;                       // seg_of_id's dense id -> segment (a later SEG with the same id wins)
     std::unordered_map<uint64_t, size_t> arc_of;       // (u << 32 | v) -> index in arcs
     std::vector<Arc> arcs;
 
-    int32_t seg(const std::string &n)
+    int32_t seg(sv n)
     {
-        auto it = seg_of.find(n);
-        if (it != seg_of.end()) return it->second;
-        int32_t s = static_cast<int32_t>(name.size());
-        seg_of.emplace(n, s);
-        name.push_back(n);
+        const int before = static_cast<int>(seg_of.names.size());
+        const int32_t s = seg_of.intern(n);
+        if (s < before) return s;
+        name.emplace_back(n);
         copies.push_back(1);
-        size_t a = n.find('_');
-        if (a != std::string::npos) {
-            size_t b = n.find('_', a + 1);
-            seg_of_id[n.substr(a + 1, b == std::string::npos ? std::string::npos : b - a - 1)] = s;   // later wins
+        const size_t a = n.find('_');
+        if (a != sv::npos) {
+            const size_t b = n.find('_', a + 1);
+            const int t = seg_of_id.intern(n.substr(a + 1, b == sv::npos ? sv::npos : b - a - 1));
+            if (static_cast<size_t>(t) >= id_seg.size()) id_seg.resize(static_cast<size_t>(t) + 1);
+            id_seg[static_cast<size_t>(t)] = s;
         }
         return s;
+    }
+    int32_t seg_by_id(sv id) const
+    {
+        const int t = seg_of_id.find(id);
+        return t < 0 ? -1 : id_seg[static_cast<size_t>(t)];
     }
     void bump(int32_t u, int32_t v, int64_t w, int32_t backed)
     {
@@ -110,65 +122,78 @@ std::vector<std::string> words(const std::string &line)
     return t;
 }
 
-// contigs.paths (SPAdes): lines of comma-separated `<contig id><+|->` tokens (NODE header lines skipped); consecutive
-// tokens back the arc between them.  Parsed once; a batch run applies to each graph only the lines that mention one of
-// its contigs.
-struct PathTok { std::string id; bool minus; bool ok; };
-typedef std::vector<PathTok> PathLine;
-
-std::vector<PathLine> load_paths(const std::string &path)
+// atof / atol of a token of a mapped file (no terminator there): the longest numeric prefix, 0 without one
+double num_prefix(sv tok)
 {
-    std::vector<PathLine> out;
-    if (path.empty()) return out;
-    std::ifstream pin(path);
-    std::string line;
-    while (std::getline(pin, line)) {
-        if (line.rfind("NODE", 0) == 0) continue;
-        PathLine pl;
+    char buf[64];
+    const size_t n = std::min(tok.size(), sizeof buf - 1);
+    std::memcpy(buf, tok.data(), n);
+    buf[n] = 0;
+    return std::atof(buf);
+}
+long int_prefix(sv tok)
+{
+    char buf[64];
+    const size_t n = std::min(tok.size(), sizeof buf - 1);
+    std::memcpy(buf, tok.data(), n);
+    buf[n] = 0;
+    return std::atol(buf);
+}
+
+// contigs.paths (SPAdes): lines of comma-separated `<contig id><+|->` tokens (NODE header lines skipped); consecutive
+// tokens back the arc between them.  Read once, straight from the mapped file; a batch run applies to each graph only
+// the lines that mention one of its contigs.
+struct PathTok { sv id; bool minus; bool ok; };
+
+template <class F>
+void for_each_path_line(const palace_host::MappedText &txt, F f)      // f(tokens of one line)
+{
+    std::vector<PathTok> pl;
+    palace_host::for_each_line(txt.data, txt.size, [&](sv line) {
+        if (!line.empty() && line.back() == '\n') line.remove_suffix(1);
+        if (line.substr(0, 4) == "NODE") return;
+        pl.clear();
         size_t p = 0;
         while (p <= line.size()) {
-            size_t c = line.find(',', p);
-            std::string tok = line.substr(p, c == std::string::npos ? std::string::npos : c - p);
-            p = c == std::string::npos ? line.size() + 1 : c + 1;
-            while (!tok.empty() && (tok.back() == ';' || tok.back() == '\r' || tok.back() == ' ')) tok.pop_back();
-            PathTok t{"", false, false};
+            const size_t c = line.find(',', p);
+            sv tok = line.substr(p, c == sv::npos ? sv::npos : c - p);
+            p = c == sv::npos ? line.size() + 1 : c + 1;
+            while (!tok.empty() && (tok.back() == ';' || tok.back() == '\r' || tok.back() == ' ')) tok.remove_suffix(1);
+            PathTok t{sv(), false, false};
             if (tok.size() >= 2 && (tok.back() == '+' || tok.back() == '-')) { t.id = tok.substr(0, tok.size() - 1); t.minus = tok.back() == '-'; t.ok = true; }
             pl.push_back(t);
         }
-        out.push_back(std::move(pl));
-    }
-    return out;
+        f(pl);
+    });
 }
 
-void apply_path(ConjGraph &g, const PathLine &line)
+void apply_path(ConjGraph &g, const std::vector<PathTok> &line)
 {
     int32_t before = -1;
     for (const PathTok &t : line) {
         int32_t here = -1;
         if (t.ok) {
-            auto it = g.seg_of_id.find(t.id);
-            if (it != g.seg_of_id.end()) here = 2 * it->second + (t.minus ? 1 : 0);
+            const int32_t s = g.seg_by_id(t.id);
+            if (s >= 0) here = 2 * s + (t.minus ? 1 : 0);
         }
         if (before >= 0 && here >= 0) g.add(before, here, 0, 1);
         before = here;
     }
 }
 
-void load_graph_text(ConjGraph &g, const std::string &graph_path)
+void load_graph_text(ConjGraph &g, const palace_host::MappedText &txt)
 {
-    std::ifstream in(graph_path);
-    if (!in) throw std::runtime_error("cannot open graph " + graph_path);
-    std::string line;
-    while (std::getline(in, line)) {
-        auto t = words(line);
+    std::vector<sv> t;
+    palace_host::for_each_line(txt.data, txt.size, [&](sv line) {
+        palace_host::split_ws(line, t);
         if (t.size() >= 4 && t[0] == "SEG") {
-            int32_t s = g.seg(t[1]);
-            g.copies[s] = std::max<int64_t>(1, static_cast<int64_t>(std::atof(t[3].c_str())));
+            const int32_t s = g.seg(t[1]);
+            g.copies[static_cast<size_t>(s)] = std::max<int64_t>(1, static_cast<int64_t>(num_prefix(t[3])));
         } else if (t.size() >= 7 && t[0] == "JUNC") {
-            int32_t a = g.seg(t[1]), b = g.seg(t[3]);
-            g.add(2 * a + (t[2] == "-"), 2 * b + (t[4] == "-"), std::atol(t[5].c_str()) + std::atol(t[6].c_str()), 0);
+            const int32_t a = g.seg(t[1]), b = g.seg(t[3]);
+            g.add(2 * a + (t[2] == "-"), 2 * b + (t[4] == "-"), int_prefix(t[5]) + int_prefix(t[6]), 0);
         }
-    }
+    });
 }
 
 }  // namespace
@@ -191,8 +216,9 @@ int main(int argc, char **argv)
         if (ctx_rc) ctx_err = palace_last_error();
     });
     // one job per graph: the plain command line is a batch of one
-    struct Job { std::string graph, linear, cycle; ConjGraph g; int32_t v0 = 0; std::string lin, cyc, selfs; std::unordered_set<std::string> lin_seen, cyc_seen; };
+    struct Job { std::string graph, linear, cycle; std::unique_ptr<palace_host::MappedText> text; ConjGraph g; int32_t v0 = 0; std::string lin, cyc, selfs; std::unordered_set<std::string> lin_seen, cyc_seen; };
     std::vector<Job> jobs;
+    std::unique_ptr<palace_host::MappedText> paths_text;
     try {
         if (opt.batch.empty()) { jobs.emplace_back(); jobs[0].graph = opt.graph; jobs[0].linear = opt.linear; jobs[0].cycle = opt.cycle; }
         else {
@@ -208,23 +234,39 @@ int main(int argc, char **argv)
                 jobs.emplace_back(); jobs.back().graph = t[0]; jobs.back().linear = t[1]; jobs.back().cycle = t[2];
             }
         }
-        const std::vector<PathLine> paths = load_paths(opt.paths);
-        std::unordered_map<std::string, std::vector<uint32_t>> lines_of;       // contig id -> path lines that mention it
-        if (jobs.size() > 1)
-            for (uint32_t li = 0; li < paths.size(); li++)
-                for (const PathTok &t : paths[li])
-                    if (t.ok) { auto &v = lines_of[t.id]; if (v.empty() || v.back() != li) v.push_back(li); }
         for (Job &j : jobs) {
-            load_graph_text(j.g, j.graph);
-            if (jobs.size() == 1) { for (const PathLine &pl : paths) apply_path(j.g, pl); continue; }
-            std::vector<uint32_t> mine;
-            for (const auto &kv : j.g.seg_of_id) {
-                auto it = lines_of.find(kv.first);
-                if (it != lines_of.end()) mine.insert(mine.end(), it->second.begin(), it->second.end());
-            }
-            std::sort(mine.begin(), mine.end());
-            mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
-            for (uint32_t li : mine) apply_path(j.g, paths[li]);
+            try { j.text = std::make_unique<palace_host::MappedText>(j.graph); }
+            catch (const std::exception &) { throw std::runtime_error("cannot open graph " + j.graph); }
+            load_graph_text(j.g, *j.text);
+        }
+        if (!opt.paths.empty()) {
+            try { paths_text = std::make_unique<palace_host::MappedText>(opt.paths); }
+            catch (const std::exception &) { paths_text.reset(); }                  // (an unreadable paths file backs nothing, as before)
+        }
+        if (paths_text && jobs.size() == 1) {
+            for_each_path_line(*paths_text, [&](const std::vector<PathTok> &pl) { apply_path(jobs[0].g, pl); });
+        } else if (paths_text) {
+            // which graphs know a contig id: a path line is applied, in file order, to every graph that knows one of its ids
+            palace_host::Names ids;
+            std::vector<std::vector<uint32_t>> jobs_of;
+            for (uint32_t ji = 0; ji < jobs.size(); ji++)
+                for (sv id : jobs[ji].g.seg_of_id.names) {
+                    const int t = ids.intern(id);
+                    if (static_cast<size_t>(t) >= jobs_of.size()) jobs_of.resize(static_cast<size_t>(t) + 1);
+                    jobs_of[static_cast<size_t>(t)].push_back(ji);
+                }
+            std::vector<uint32_t> touched;
+            for_each_path_line(*paths_text, [&](const std::vector<PathTok> &pl) {
+                touched.clear();
+                for (const PathTok &t : pl) {
+                    if (!t.ok) continue;
+                    const int k = ids.find(t.id);
+                    if (k >= 0) touched.insert(touched.end(), jobs_of[static_cast<size_t>(k)].begin(), jobs_of[static_cast<size_t>(k)].end());
+                }
+                std::sort(touched.begin(), touched.end());
+                touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+                for (uint32_t ji : touched) apply_path(jobs[ji].g, pl);
+            });
         }
     } catch (const std::exception &e) { std::cerr << "matching: " << e.what() << "\n"; hip_up.join(); return 1; }
     tr.lap("graphs + paths read");

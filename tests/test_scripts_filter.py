@@ -106,14 +106,15 @@ def test_filter_graph_native_equals_python(tmp_path, seed, n):
     for k, v in side.items():
         open(P(k), "w").write(v)
     outs = {}
-    for impl in ("1", "0"):
-        args = [P("fastg_fai"), P("graph"), P(f"pre{impl}"), "12.5", "0", P("hit_seqs"), P("node_scores"), P("blast"), "0.7",
-                P("fasta_fai"), P(f"hits{impl}"), P("contigs_paths"), "0.7"]
+    for impl, threads in (("1", "1"), ("0", "1"), ("0", "5")):       # the native core parses in parts on threads
+        tag = impl + threads
+        args = [P("fastg_fai"), P("graph"), P(f"pre{tag}"), "12.5", "0", P("hit_seqs"), P("node_scores"), P("blast"), "0.7",
+                P("fasta_fai"), P(f"hits{tag}"), P("contigs_paths"), "0.7"]
         subprocess.run([sys.executable, os.path.join(SCRIPTS, "filter_graph.py")] + args, check=True,
-                       env=dict(os.environ, PALACE_FILTER_PY=impl))
-        outs[impl] = (open(P(f"pre{impl}"), "rb").read(), open(P(f"hits{impl}"), "rb").read())
-    assert outs["1"][0].count(b"SEG") > 3 and outs["1"][0].count(b"JUNC") > 3 and outs["1"][1].count(b"SAMPLE") > 1
-    assert outs["0"] == outs["1"]
+                       env=dict(os.environ, PALACE_FILTER_PY=impl, PALACE_HOST_THREADS=threads))
+        outs[tag] = (open(P(f"pre{tag}"), "rb").read(), open(P(f"hits{tag}"), "rb").read())
+    assert outs["11"][0].count(b"SEG") > 3 and outs["11"][0].count(b"JUNC") > 3 and outs["11"][1].count(b"SAMPLE") > 1
+    assert outs["01"] == outs["11"] and outs["05"] == outs["11"]
 
 
 def test_filter_graph_native_rejects_unknown_contig(tmp_path):
