@@ -149,7 +149,7 @@ bool parse_sa(const char *b, const char *e, const BamColumns &cols, int32_t own_
     }
     for (int k = 0; k < 6; k++) trim_ws(fb[k], fe[k]);
     if (fb[0] == fe[0] || fb[1] == fe[1]) return false;
-    std::string rname(fb[0], fe[0]);
+    const std::string_view rname(fb[0], static_cast<size_t>(fe[0] - fb[0]));
     out.pos2 = std::atoi(std::string(fb[1], fe[1]).c_str());
     out.rev2 = (fe[2] - fb[2] == 1 && *fb[2] == '-') ? 1 : 0;
     ClipInfo ci = clip_from_text(fb[3], static_cast<size_t>(fe[3] - fb[3]));
@@ -158,8 +158,7 @@ bool parse_sa(const char *b, const char *e, const BamColumns &cols, int32_t own_
     out.nm2 = std::atoi(std::string(fb[5], fe[5]).c_str());
     out.tid2 = -1;
     if (own_tid >= 0 && rname != cols.target_name[own_tid]) {       // r1 == r2 -> skip (:731)
-        auto it = cols.name_to_tid.find(rname);
-        if (it != cols.name_to_tid.end()) out.tid2 = it->second;     // unknown name -> skip (:733-734)
+        out.tid2 = cols.tid_of(rname);                                 // unknown name -> -1 -> skip (:733-734)
     }
     return true;
 }
@@ -282,19 +281,44 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c)
     need(p + 4);
     const int32_t n_ref = static_cast<int32_t>(le32(d + p));
     p += 4;
-    if (n_ref > 0) {                                             // (bounded by what the stream can hold: >= 9 bytes per reference)
-        const size_t cap = std::min<size_t>(static_cast<size_t>(n_ref), c.raw.size() / 9 + 1);
-        c.target_name.reserve(cap); c.target_len.reserve(cap); c.name_to_tid.reserve(cap);
-    }
+    // (n_ref is bounded by what the stream can hold: >= 9 bytes per reference)
+    const size_t cap = n_ref > 0 ? std::min<size_t>(static_cast<size_t>(n_ref), c.raw.size() / 9 + 1) : 0;
+    std::vector<size_t> name_at;                                 // offset of every l_name word: a serial walk, each size is in the stream
+    name_at.reserve(cap);
     for (int32_t i = 0; i < n_ref; i++) {
         need(p + 4);
         const size_t l = le32(d + p);
         need(p + 4 + l + 4);
-        std::string nm(reinterpret_cast<const char *>(d + p + 4), l ? l - 1 : 0);
-        c.target_name.push_back(nm);
-        c.target_len.push_back(static_cast<int32_t>(le32(d + p + 4 + l)));
-        c.name_to_tid[nm] = i;
+        name_at.push_back(p);
         p += 8 + l;
+    }
+    // names, lengths and name hashes on the threads; the index itself is filled by this thread (hashes in hand)
+    const size_t nr = name_at.size();
+    c.target_name.resize(nr);
+    c.target_len.resize(nr);
+    std::vector<uint64_t> hash(nr);
+    {
+        const size_t parts = nr < 4096 ? 1 : static_cast<size_t>(std::min(threads, 8));
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < parts; t++)
+            pool.emplace_back([&, t] {
+                for (size_t i = nr * t / parts; i < nr * (t + 1) / parts; i++) {
+                    const size_t at = name_at[i], l = le32(d + at);
+                    const std::string_view nm(reinterpret_cast<const char *>(d + at + 4), l ? l - 1 : 0);
+                    c.target_name[i].assign(nm);
+                    c.target_len[i] = static_cast<int32_t>(le32(d + at + 4 + l));
+                    hash[i] = hash_bytes(nm);
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
+    c.tid_names.reserve(nr + 16);
+    c.tid_of_name.reserve(nr + 16);
+    for (size_t i = 0; i < nr; i++) {
+        const size_t at = name_at[i], l = le32(d + at);
+        const int k = c.tid_names.intern_hashed(std::string_view(reinterpret_cast<const char *>(d + at + 4), l ? l - 1 : 0), hash[i]);
+        if (static_cast<size_t>(k) >= c.tid_of_name.size()) c.tid_of_name.resize(static_cast<size_t>(k) + 1);
+        c.tid_of_name[static_cast<size_t>(k)] = static_cast<int32_t>(i);
     }
     L->first_record = p;
     L->n_ref = n_ref;

@@ -6,10 +6,11 @@
 #include <cstdint>
 #include <memory>
 #include <string>
-#include <unordered_map>
+#include <string_view>
 #include <vector>
 
 #include "../../include/palace_hip.h"
+#include "textio.hpp"
 
 namespace palace_host {
 
@@ -27,7 +28,13 @@ struct BamColumns {
     // header
     std::vector<std::string> target_name;
     std::vector<int32_t> target_len;
-    std::unordered_map<std::string, int32_t> name_to_tid;      // last duplicate wins (:624-627)
+    Names tid_names;                               // target name -> tid, keys are views of `raw` (the inflated header)
+    std::vector<int32_t> tid_of_name;              // ... by tid_names' dense id; the last duplicate wins (:624-627)
+    int32_t tid_of(std::string_view name) const
+    {
+        const int k = tid_names.find(name);
+        return k < 0 ? -1 : tid_of_name[static_cast<size_t>(k)];
+    }
     // one entry per record, file order
     std::vector<int32_t> tid, pos, mtid, mpos, nm, ref_len, read_len, clip_s, clip_e, sa_off;
     std::vector<uint16_t> flag;
@@ -53,7 +60,7 @@ uint64_t name_key(const char *s, size_t n, uint64_t seed);
 
 // Reads, inflates (threads) and decodes a whole BAM file.  Throws std::runtime_error.
 void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumns &out);
-// The same in two steps: begin() returns once the header (target names and lengths, name_to_tid) is in `out`, with the
+// The same in two steps: begin() returns once the header (target names and lengths, the name index) is in `out`, with the
 // inflate threads still running; finish() delivers the records.  `out` must stay where it is in between.
 struct BamLoad;
 BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &out);

@@ -74,13 +74,7 @@ std::vector<uint64_t> fastg_keys(const std::string &path, const BamColumns &c, i
 {
     MappedText txt;
     try { txt.open(path); } catch (const std::exception &) { return {}; }     // the reference reads an unopenable file as empty
-    std::unordered_map<std::string_view, int32_t> tid_of;
-    tid_of.reserve(c.target_name.size() * 2);
-    for (size_t i = 0; i < c.target_name.size(); i++) tid_of[std::string_view(c.target_name[i])] = static_cast<int32_t>(i);   // last duplicate wins (:624-627)
-    auto lookup = [&](std::string_view n) -> int64_t {
-        auto it = tid_of.find(n);
-        return it == tid_of.end() ? -1 : it->second;
-    };
+    auto lookup = [&](std::string_view n) -> int64_t { return c.tid_of(n); };       // last duplicate wins (:624-627)
     const size_t N = txt.size;
     std::vector<size_t> cut{0};
     const size_t n_parts = static_cast<size_t>(std::max(1, threads)) * 4;
@@ -231,10 +225,8 @@ int main(int argc, char **argv)
     palace_ctx *ctx = nullptr;
     int ctx_rc = 0;
     std::string ctx_err;
-    std::thread side([&] {
-        name_ranks(c.target_name, by_name, rank);
-        fkeys = fastg_keys(fai_path, c, 4);
-    });
+    std::thread side([&] { name_ranks(c.target_name, by_name, rank); });
+    std::thread side2([&] { fkeys = fastg_keys(fai_path, c, 4); });
     std::thread hip_up([&] {
         ctx_rc = palace_ctx_create(0, &ctx);
         if (ctx_rc) ctx_err = palace_last_error();
@@ -243,11 +235,12 @@ int main(int argc, char **argv)
         load_bam_finish(load, seed);
     } catch (const std::exception &e) {
         std::cerr << e.what() << "\n";
-        side.join(); hip_up.join();
+        side.join(); side2.join(); hip_up.join();
         return 1;
     }
     tr.lap("bam records");
     side.join();
+    side2.join();
     tr.lap("name ranks + fastg keys (joined)");
     hip_up.join();
     if (ctx_rc) { std::cerr << "generateGraph: cannot set up the GPU: " << ctx_err << "\n"; return 1; }

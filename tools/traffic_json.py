@@ -9,7 +9,7 @@ import csv
 import json
 import sys
 
-KERNELS = ("mark_read_ends_kernel", "mark_dropped_kernel", "eref_streams_kernel", "eref_usable_kernel", "eref_bin1_streams_kernel",
+KERNELS = ("mark_read_ends_kernel", "mark_dropped_kernel", "eref_streams_kernel", "eref_usable_kernel", "eref_bin1_sort_kernel",
            "eref_bin2_kernel", "eref_lds_count_kernel")
 
 
