@@ -638,7 +638,7 @@ def main():
     ctx = capi.Ctx(local)                      # eref stream
     ctx_g = capi.Ctx(local, high_priority=True)   # generateGraph + matching stream (independent of eref until the end)
     ctx.eref_set_coder(hdr)
-    for opt in ("slab_bases",):        # tuning runs only (tools/): PALACE_OPT_BIN1_GRID=768 python bench.py
+    for opt in ("slab_bases", "bin1_ppl"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
         if os.environ.get("PALACE_OPT_" + opt.upper()):
             ctx.eref_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
     # Phase A across ranks.  Sharding the reads costs a count-table exchange: every rank ships (W-1)/W of three 512 MiB

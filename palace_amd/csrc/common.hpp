@@ -68,6 +68,7 @@ struct palace_ctx {
     int count_mode = 0;             // 0 auto, 1 direct atomics, 2 binned
     int64_t bin_cap_override = 0;
     int64_t slab_override = 0;
+    int bin1_ppl = 0;               // level 1: positions per lane (0 = by key density)
     palace::Workspace ws;      // grow-only scratch
     bool ws_grown = false;
     palace::Workspace pin;     // grow-only pinned host staging

@@ -164,7 +164,7 @@ constexpr int kSliceWords = 1 << (kBucketShift - 5);  // 8192 u32 of a plane per
 constexpr int kL1Buckets = 128, kL1Shift = 25;        // level 1: key >> 25
 constexpr int kL1Replicas = 32;                       // level-1 bucket regions are split 32 ways so that the per-tile
                                                       // reservations do not pile onto 128 addresses (8 ... 64: no difference)
-constexpr int kBinThreads = 512;                      // level 1: 8 waves, ~35 KiB of LDS -> 4 workgroups per CU
+constexpr int kBinThreads = 512;                      // level 1: 8 waves, <= 39.5 KiB of LDS -> 4 workgroups per CU
 constexpr int kRowSlots = 72;                         // level 2: slots of a staging row (mean fill 48: +3.5 sigma)
 
 // Capacity of the slot range that belongs to level-1 bucket b when a total is shared out by the key
@@ -343,20 +343,24 @@ __global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Level 1 as a counting sort in LDS (third version of this kernel).  What the first two versions had in common -- a
-// staging row per bucket with slack, one store instruction per row -- made them STORE-INSTRUCTION bound: a microbenchmark
-// of the same pattern (tools/microbench/scatter_runs.hip) writes 192-byte runs at 2.2 TB/s and 1-KiB runs at 4.6 TB/s,
-// ~12.5 G partial-wave store instructions per second chip-wide whatever their width, and the kernel issued 62 M of
-// them (its in-kernel stamps showed every other phase stretch when one phase was made shorter).  So:
-//   1. the lane computes its keys (registers) and counts them per bucket in an LDS histogram;
+// Level 1 as a counting sort in LDS (third version of this kernel; the first two staged a row per bucket with slack and
+// wrote one partial-wave store per row).
+//   1. the lane computes its keys (registers) and counts them per bucket in an LDS histogram; the returning add gives
+//      the key its rank in the row;
 //   2. one wave turns the histogram into row starts, every row padded to a multiple of 4 keys; the pad slots get a
 //      SENTINEL -- a key whose top 7 bits name another bucket, which level 2 skips -- so that rows, global runs and
 //      16-byte vectors all stay aligned;
-//   3. 128 lanes reserve the (padded) runs in the bucket regions -- these global atomics are in flight while
-//   4. every lane places its keys at row start + the rank the histogram add returned;
+//   3. meanwhile 128 lanes of two other waves reserve the (padded) runs in the bucket regions: these global atomics are
+//      in flight during 2. and 4.;
+//   4. every lane places its keys at row start + rank;
 //   5. the compact, bucket-sorted tile is swept with 16-byte loads from LDS and 16-byte stores: a lane's four keys belong
 //      to one row (rows are 4-aligned), the row is the keys' own top bits, its destination one LDS read.
-// ~25 full-width store instructions per tile instead of ~160 partial ones.
+// What bounds it (kernel cut short after each step, 1M-contig set): launch + stream loads + keys 1.5 ms, + histogram and
+// row starts 1.7, + placement 2.6, + reservations and sweep without the stores 3.4, all of it 4.1 -- each workgroup is a
+// chain of latencies of ~11 us whatever its tile size (the same with 256 threads, with 10 positions per lane), so the
+// throughput is the key slots the LDS of a CU holds (4 workgroups) divided by that latency; HBM moves 10.7 GB in that
+// time, half of what it could.  No change from: one LDS atomic less per key, earlier reservations, unrolled sweep
+// (no store waits for the previous one), 95- to 380-byte runs, 8 to 64 replicas, contiguous instead of scattered stores.
 // ------------------------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr uint32_t l1_sentinel(uint32_t b) { return (b ^ 64u) << kL1Shift; }
 constexpr uint32_t kRunAlign = 4;                     // keys: every run of level 1 is padded to a multiple of this (16 bytes)
@@ -372,7 +376,9 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
     constexpr int kMaxKeys = THREADS * P * 3 + kL1Buckets * (kRunAlign - 1);     // every key of the tile + the pad slots of every row
     __shared__ __attribute__((aligned(16))) uint32_t tile[kMaxKeys];
     __shared__ uint32_t hist[kL1Buckets], start[kL1Buckets + 1], room[kL1Buckets];
-    __shared__ unsigned long long dst[kL1Buckets];       // key index in o.buf of the row's compact slot 0; bit 63: run did not fit whole
+    __shared__ uint32_t dst[kL1Buckets];                 // 16-byte group index in o.buf of the row's compact slot 0, modulo 2^32 (regions,
+                                                         // runs and row starts are multiples of 4 keys; a slab's regions hold < 2^32 groups)
+    __shared__ uint32_t any_partial;                     // some run of this tile did not fit its region whole (rare): check `room`
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #ifdef PALACE_STAMPS
     unsigned long long stamp_arr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -388,6 +394,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
     for (int q = 0; q < 3; q++) { w[0][q] = s0[g + q]; w[1][q] = s1[g + q]; w[2][q] = s2[g + q]; }
     uw[0] = su[g]; uw[1] = su[g + 1];
     if (threadIdx.x < kL1Buckets) hist[threadIdx.x] = 0;
+    if (threadIdx.x == kL1Buckets) any_partial = 0;
     __syncthreads();
     // ---- 1. keys and histogram ----
     uint32_t u = __builtin_amdgcn_alignbit(uw[1], uw[0], sh) & ((1u << P) - 1);
@@ -414,7 +421,12 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
     STAMP(stamps, 1);
     __syncthreads();
     STAMP(stamps, 2);
-    // ---- 2. row starts (wave 0: two rows per lane), pad slots ----
+    // ---- 2. row starts (wave 0: two rows per lane), pad slots; 3. meanwhile waves 1-2 reserve the padded runs in the
+    // bucket regions (a run's size needs its own count only): these global atomics are in flight during 2. and 4. ----
+    const uint32_t replica = blockIdx.x % kL1Replicas;
+    const bool reserver = threadIdx.x >= 64 && threadIdx.x < 64 + kL1Buckets;
+    const uint32_t my_row = threadIdx.x - 64;
+    uint32_t my_pc = 0, my_g = 0;
     if (wave == 0) {
         const uint32_t c0 = hist[2 * lane], c1 = hist[2 * lane + 1];
         const uint32_t pc0 = (c0 + kRunAlign - 1) & ~(kRunAlign - 1), pc1 = (c1 + kRunAlign - 1) & ~(kRunAlign - 1);
@@ -429,16 +441,12 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
         if (lane == 63) start[kL1Buckets] = incl;
         for (uint32_t q = c0; q < pc0; q++) tile[a0 + q] = l1_sentinel(2 * lane);
         for (uint32_t q = c1; q < pc1; q++) tile[a1 + q] = l1_sentinel(2 * lane + 1);
+    } else if (reserver) {
+        my_pc = (hist[my_row] + kRunAlign - 1) & ~(kRunAlign - 1);
+        if (my_pc) my_g = atomicAdd(&o.cursor[l1_cursor(my_row, replica)], my_pc);
     }
     __syncthreads();
     STAMP(stamps, 3);
-    // ---- 3. reservations (in flight during 4.) ----
-    const uint32_t replica = blockIdx.x % kL1Replicas;
-    uint32_t my_pc = 0, my_g = 0;
-    if (threadIdx.x < kL1Buckets) {
-        my_pc = start[threadIdx.x + 1] - start[threadIdx.x];
-        if (my_pc) my_g = atomicAdd(&o.cursor[l1_cursor(threadIdx.x, replica)], my_pc);
-    }
     // ---- 4. placement ----
     if (u) {
 #pragma unroll
@@ -449,28 +457,48 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
             }
         }
     }
-    if (threadIdx.x < kL1Buckets) {
-        const uint32_t cap = o.caps.cap(threadIdx.x);
+    if (reserver) {
+        const uint32_t cap = o.caps.cap(my_row);
         const bool whole = static_cast<uint64_t>(my_g) + my_pc <= cap;
-        room[threadIdx.x] = cap - min(cap, my_g);                 // keys of the run that fit (a multiple of 4)
-        dst[threadIdx.x] = (l1_region_base(o.caps, threadIdx.x, replica) + my_g - start[threadIdx.x]) | (whole ? 0ull : 1ull << 63);
+        room[my_row] = cap - min(cap, my_g);                      // keys of the run that fit (a multiple of 4)
+        dst[my_row] = static_cast<uint32_t>((l1_region_base(o.caps, my_row, replica) + my_g - start[my_row]) >> 2);
+        if (!whole) any_partial = 1;
     }
     __syncthreads();
     STAMP(stamps, 4);
-    // ---- 5. sweep ----
+    // ---- 5. sweep: unrolled, the 16-byte stores of a lane go out back to back (as a loop the compiler made every
+    // iteration wait for the previous iteration's store to be acknowledged: three HBM round trips in a row per tile) ----
     const uint32_t total = start[kL1Buckets];
-    for (uint32_t x = threadIdx.x * 4; x < total; x += THREADS * 4) {
-        const uint4 k = *reinterpret_cast<const uint4 *>(&tile[x]);
-        // the row of the group: its keys' own top bits (a group of four pads names row ^ 64: they are the tail of that row)
-        const uint32_t row = k.x >> kL1Shift;                     // (the first key of an aligned group of four is never a pad)
-        const unsigned long long d = dst[row];
-        if (!(d >> 63) || x - start[row] < room[row]) {
-            *reinterpret_cast<uint4 *>(o.buf + ((d & ~(1ull << 63)) + x)) = k;
-        } else {                                                   // the region is full: exact slow path, pads skipped
-            const uint32_t kk[4] = {k.x, k.y, k.z, k.w};
+    const bool check = any_partial != 0;                           // uniform
+    constexpr int kSweeps = (kMaxKeys + THREADS * 4 - 1) / (THREADS * 4);
+    uint32_t slow = 0;
+    uint4 k[kSweeps];
+    uint32_t to[kSweeps], live = 0;                                // 16-byte group index in o.buf; bit it of live: group it is stored
 #pragma unroll
+    for (int it = 0; it < kSweeps; it++) {                         // every LDS read of the lane first ...
+        const uint32_t x = (it * THREADS + threadIdx.x) * 4;
+        to[it] = 0;
+        k[it] = uint4{0, 0, 0, 0};
+        if (x < total) {
+            k[it] = *reinterpret_cast<const uint4 *>(&tile[x]);
+            // the row of the group: its keys' own top bits (a group of four pads names row ^ 64: they are the tail of that row)
+            const uint32_t row = k[it].x >> kL1Shift;             // (the first key of an aligned group of four is never a pad)
+            if (!check || x - start[row] < room[row]) { to[it] = dst[row] + (x >> 2); live |= 1u << it; }
+            else slow |= 1u << it;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < kSweeps; it++)                           // ... then its stores, in distinct registers
+        if (live & (1u << it)) reinterpret_cast<uint4 *>(o.buf)[to[it]] = k[it];
+    if (slow) {                                                    // the region is full: exact slow path, pads skipped
+#pragma unroll 1
+        for (int it = 0; it < kSweeps; it++) {
+            if (!((slow >> it) & 1u)) continue;
+            const uint32_t x = (it * THREADS + threadIdx.x) * 4;
+            const uint32_t row = tile[x] >> kL1Shift;
+#pragma unroll 1
             for (int e = 0; e < 4; e++)
-                if ((kk[e] >> kL1Shift) == row) count_key_marked(kk[e], o.p1, o.p2, o.p3, o.touched);
+                if ((tile[x + e] >> kL1Shift) == row) count_key_marked(tile[x + e], o.p1, o.p2, o.p3, o.touched);
         }
     }
     STAMP(stamps, 5);
@@ -1388,6 +1416,7 @@ int plan_count(palace_ctx *ctx, int64_t total_bases, CountPlan *pl)
     pl->cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
     pl->cur2_bytes = align_up(kFine * sizeof(unsigned int), 256);
     pl->buf1_bytes = align_up(static_cast<size_t>(pl->caps1.prefix(kL1Buckets)) * kL1Replicas * 4, 256);
+    PALACE_REQUIRE(pl->buf1_bytes < (1ull << 36), "slab too large: level 1 addresses its regions as 2^32 groups of 16 bytes");
     pl->buf2_bytes = align_up(static_cast<size_t>(pl->caps2.prefix(kL1Buckets)) * kL2Rows * 4, 256);    // pairs of 2-byte keys
     pl->n_chunks = (total_bases + 63) / 64;
     pl->words_bytes = align_up(static_cast<size_t>(pl->n_chunks + 2) * 8, 256);       // one u64 per 64 positions (+ pad)
@@ -1482,10 +1511,11 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
                            reinterpret_cast<uint16_t *>(strm[1]), reinterpret_cast<uint16_t *>(strm[2]), reinterpret_cast<uint16_t *>(strm[3]));
         PALACE_HIP_TRY(hipGetLastError());
     }
-    // positions per lane of the partition kernel: a tile of 512 lanes should hold about 6000 keys (the staging rows
-    // take 6144 at +3.5 sigma); a position yields 3 * (1 - 31 / read length) keys on average
+    // positions per lane of the level-1 kernel.  Its throughput is (key slots the CU's LDS holds) / (latency of a tile,
+    // ~11 us whatever the tile size): 6 positions x 3 keys x 512 lanes + pads = 39.5 KiB, the most that still fits four
+    // times into 160 KiB (5: +4 %, 4: +8 %, 8 -- three workgroups per CU --: +2 %).  Sparse sets (short reads) take 8.
     const double keys_per_pos = 3.0 * std::max(0.02, 1.0 - 31.0 * static_cast<double>(n_reads) / std::max<double>(1.0, static_cast<double>(total_bases)));
-    const int ppl = keys_per_pos > 2.55 ? 4 : keys_per_pos > 2.1 ? 5 : keys_per_pos > 1.6 ? 6 : 8;
+    const int ppl = ctx->bin1_ppl ? ctx->bin1_ppl : keys_per_pos > 1.6 ? 6 : 8;
     for (int64_t slab = 0; slab < n_slabs; slab++) {
         PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes + kTouchedBytes, ctx->stream));
         const bool clean = ctx->table_clean && slab == 0;        // every plane bit is still zero: slices need no reading
@@ -1499,6 +1529,10 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         // -- the same tile, half the waves per CU -- 8-13 % slower; 10 positions per lane: the same time, 16: +45 % (one
         // workgroup per CU); and, twice: persistent workgroups that walk several tiles with the next tile's loads in
         // flight -- 25-40 % slower; the workgroups of a CU then run their phases in step, freshly dispatched ones interleave them.)
+        // one tile per workgroup, 8 waves.  Measured and dropped: workgroups that walk over several tiles with the next
+        // tile's words in flight (three times, the last with this kernel: 7.5 ms instead of 4.1 -- all workgroups of the chip
+        // then run the same phase at the same time, while freshly dispatched ones interleave loads, LDS work and stores);
+        // 256-thread workgroups (+3 %); 10 / 16 positions per lane (the same / +45 %).
         const dim3 grid(static_cast<unsigned>(tiles)), block(kBinThreads);
         switch (ppl) {
         case 4: hipLaunchKernelGGL((eref_bin1_sort_kernel<4, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
@@ -1539,6 +1573,9 @@ int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value)
     if (!std::strcmp(name, "slab_bases")) {
         PALACE_REQUIRE(value >= 0 && value % 64 == 0, "slab size must be a non-negative multiple of 64");
         ctx->slab_override = value;
+    } else if (!std::strcmp(name, "bin1_ppl")) {              // 0: by key density, else positions per lane of level 1 (4, 5, 6, 8)
+        PALACE_REQUIRE(value == 0 || value == 4 || value == 5 || value == 6 || value == 8, "bin1_ppl must be 0, 4, 5, 6 or 8");
+        ctx->bin1_ppl = static_cast<int>(value);
     } else {
         set_error("palace_eref_set_option: unknown option '%s'", name);
         return PALACE_EINVAL;
