@@ -360,7 +360,8 @@ __global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__rest
 // chain of latencies of ~11 us whatever its tile size (the same with 256 threads, with 10 positions per lane), so the
 // throughput is the key slots the LDS of a CU holds (4 workgroups) divided by that latency; HBM moves 10.7 GB in that
 // time, half of what it could.  No change from: one LDS atomic less per key, earlier reservations, unrolled sweep
-// (no store waits for the previous one), 95- to 380-byte runs, 8 to 64 replicas, contiguous instead of scattered stores.
+// (no store waits for the previous one), 95- to 380-byte runs, 8 to 64 replicas, contiguous instead of scattered stores,
+// touching the stream lines of a later tile of the same XCD (-2 %).  Non-temporal stores: +25 %.
 // ------------------------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr uint32_t l1_sentinel(uint32_t b) { return (b ^ 64u) << kL1Shift; }
 constexpr uint32_t kRunAlign = 4;                     // keys: every run of level 1 is padded to a multiple of this (16 bytes)
