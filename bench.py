@@ -17,6 +17,7 @@ the CPU restatement of the reference algorithm, timed on a bounded sample on thi
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -788,6 +789,13 @@ def main():
                 th3 = time.perf_counter()
                 if not timed or "n_comp" not in last:                                          # bookkeeping for the JSON line only
                     last.update(n_comp=res.n + res.n_bare, n_cycles=int(res.kind.sum()), n_multi=int(((res.off[1:] - res.off[:-1]) > 1).sum()))
+                    # digest of the step's results: the lines of an N-GPU run and of the 1-GPU run must carry the same one
+                    e64 = np.ascontiguousarray(h_edges).view(np.uint64).reshape(-1, 4)
+                    e64 = e64[np.lexsort((e64[:, 3], e64[:, 2], e64[:, 1], e64[:, 0]))]
+                    hsh = hashlib.sha256()
+                    for arr in (e64, h_cn, np.asarray(res.off), np.asarray(res.verts), np.asarray(res.kind), np.asarray(res.iter), np.asarray(res.bare)):
+                        hsh.update(np.ascontiguousarray(arr).tobytes())
+                    last["digest_graph"] = hsh.hexdigest()[:16]
                 res.free()
                 if timed:
                     for k_, v_ in (("d2h_graph", th1 - th0), ("glue", th2 - th1), ("match_decompose", th3 - th2)):
@@ -867,6 +875,9 @@ def main():
                                                                    f"records/refs sharded over {world} GPUs (RCCL), reads counted on every GPU"),
                        "ref_index": "per-DB probe index prebuilt, as the reference's cached <fasta>.k32.index.dat (8 B/position in HBM)",
                        "refs_reported": reported, "refs_present": int(len(sample["present"])),
+                       "result_digest": {"eref_rows": hashlib.sha256(np.ascontiguousarray(r).tobytes()).hexdigest()[:16],
+                                         "graph_and_components": last.get("digest_graph"),
+                                         "note": "sha256 prefixes of the last step's results; equal for every --gpus N"},
                        "graph": {k: last[k] for k in ("n_cands", "n_edges", "n_arcs", "n_comp", "n_cycles", "n_multi")}},
             "roofline": {"bound": "hbm", "kernel": "eref count_reads (streams + bin1 + bin2 + lds_count kernels of one launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

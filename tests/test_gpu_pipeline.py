@@ -60,6 +60,7 @@ def test_bench_exchange_path_rehearsal():
     b = json.loads(sh(base, env=dict(os.environ, PALACE_FORCE_EXCHANGE="1")).decode().strip().splitlines()[-1])
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
     assert a["config"]["graph"] == b["config"]["graph"]
+    assert a["config"]["result_digest"] == b["config"]["result_digest"] and a["config"]["result_digest"]["graph_and_components"]
     assert a["config"]["graph"]["n_edges"] > 0
 
 
@@ -77,6 +78,7 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(world, port):
     assert b["n_gpus"] == world
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
     assert a["config"]["graph"] == b["config"]["graph"]
+    assert a["config"]["result_digest"] == b["config"]["result_digest"] and a["config"]["result_digest"]["graph_and_components"]
 
 
 def test_bench_starts_its_own_ranks():
@@ -91,3 +93,4 @@ def test_bench_starts_its_own_ranks():
     assert b["n_gpus"] == 2
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
     assert a["config"]["graph"] == b["config"]["graph"]
+    assert a["config"]["result_digest"] == b["config"]["result_digest"] and a["config"]["result_digest"]["graph_and_components"]
