@@ -232,11 +232,12 @@ __global__ void mark_dropped_kernel(const int64_t *__restrict__ offsets, int64_t
     }
 }
 
-// The read set as four packed bit streams, one bit per base position (u32 word w = positions 32w .. 32w+31): the three
-// projections P0, P1, P2 of every base and U, "a 32-mer may start here": its 32 bases are valid (and not dropped), it
-// does not run over a read end or over the end of the set.  One pass over the bases (16 B per lane), 0.5 B/base
-// written; everything downstream -- the partition kernel -- then gets a 32-mer's three projection windows with one
-// v_alignbit each instead of a byte load, a classification, four ballots and ten 64-bit shifts per position.
+// The read set packed to two bits per base plus a start mask, as three bit streams (u32 word w = positions 32w .. 32w+31):
+// the projections P0 = {A,T} and P1 = {A,C} of every base -- together the base itself; the third projection the coder
+// uses, P2 = {A,G}, is ~(P0 ^ P1) -- and U, "a 32-mer may start here": its 32 bases are valid (and not dropped), it does
+// not run over a read end or over the end of the set.  One pass over the bases (16 B per lane), 0.375 B/base written;
+// everything downstream -- the partition kernel -- then gets a 32-mer's projection windows with one v_alignbit each
+// instead of a byte load, a classification, four ballots and ten 64-bit shifts per position.
 //
 // Per dword of four ASCII bases the class bits are computed on all four bytes at once (bit k of a byte is brought to
 // bit 0 of that byte by x >> k; what the shift drags in from the next byte lands in bits 1..7 and is masked off):
@@ -249,12 +250,11 @@ __device__ __forceinline__ uint32_t gather4(uint32_t y)        // bit 0 of bytes
     return (y | (y >> 14)) & 15u;
 }
 
-__device__ __forceinline__ void class_bits4(uint32_t x, uint32_t &p0, uint32_t &p1, uint32_t &p2, uint32_t &ok)
+__device__ __forceinline__ void class_bits4(uint32_t x, uint32_t &p0, uint32_t &p1, uint32_t &ok)
 {
     const uint32_t b0 = x, b1 = x >> 1, b2 = x >> 2, b3 = x >> 3, b4 = x >> 4, b6 = x >> 6, b7 = x >> 7;
     p0 = gather4(~b1);
     p1 = gather4(~b2);
-    p2 = gather4(~(b1 ^ b2));
     const uint32_t t_like = b2 & ~b1 & ~b0, acg_like = b0 & (b1 | ~b2);
     ok = gather4(b6 & ~b7 & ~b3 & ((b4 & t_like) | (~b4 & acg_like)));
 }
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__rest
                                                            const uint16_t *__restrict__ ends16,
                                                            const uint16_t *__restrict__ dropped16,
                                                            uint16_t *__restrict__ s0, uint16_t *__restrict__ s1,
-                                                           uint16_t *__restrict__ s2, uint16_t *__restrict__ su)
+                                                           uint16_t *__restrict__ su)
 {
     __shared__ uint16_t ok_lds[kStreamTile + 2], en_lds[kStreamTile + 2];
     const uint8_t *bases = all_bases + offsets[0];
@@ -308,19 +308,19 @@ __global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__rest
 #pragma unroll
     for (int k = 0; k <= kStreamGroups; k++) {
         if (k == kStreamGroups && threadIdx.x >= 2) break;
-        uint32_t o0 = 0, o1 = 0, o2 = 0, ok = 0;
+        uint32_t o0 = 0, o1 = 0, ok = 0;
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-            uint32_t a, b, c, v;
-            class_bits4(x[k][d], a, b, c, v);
-            o0 |= a << (4 * d); o1 |= b << (4 * d); o2 |= c << (4 * d); ok |= v << (4 * d);
+            uint32_t a, b, v;
+            class_bits4(x[k][d], a, b, v);
+            o0 |= a << (4 * d); o1 |= b << (4 * d); ok |= v << (4 * d);
         }
         const int local = (k < kStreamGroups ? k * 256 : kStreamTile) + static_cast<int>(threadIdx.x);
         ok_lds[local] = static_cast<uint16_t>(ok & ~static_cast<uint32_t>(dr[k]));
         en_lds[local] = en[k];
         const int64_t i = g0 + local;
         if (k < kStreamGroups && i < n_groups) {
-            s0[i] = static_cast<uint16_t>(o0); s1[i] = static_cast<uint16_t>(o1); s2[i] = static_cast<uint16_t>(o2);
+            s0[i] = static_cast<uint16_t>(o0); s1[i] = static_cast<uint16_t>(o1);
         }
     }
     __syncthreads();
@@ -369,7 +369,6 @@ constexpr uint32_t kRunAlign = 4;                     // keys: every run of leve
 template <int P, int THREADS>
 __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t *__restrict__ s0,
                                                                      const uint32_t *__restrict__ s1,
-                                                                     const uint32_t *__restrict__ s2,
                                                                      const uint32_t *__restrict__ su,
                                                                      int64_t pos_lo, int64_t pos_hi,
                                                                      CoderMasks masks, BinOut o)
@@ -390,9 +389,9 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
     // every load of the lane is issued before anything else (the streams are padded: see the caller)
     const int64_t g = min(p, pos_hi) >> 5;
     const int sh = static_cast<int>(p & 31);
-    uint32_t w[3][3], uw[2];
+    uint32_t w[2][3], uw[2];
 #pragma unroll
-    for (int q = 0; q < 3; q++) { w[0][q] = s0[g + q]; w[1][q] = s1[g + q]; w[2][q] = s2[g + q]; }
+    for (int q = 0; q < 3; q++) { w[0][q] = s0[g + q]; w[1][q] = s1[g + q]; }
     uw[0] = su[g]; uw[1] = su[g + 1];
     if (threadIdx.x < kL1Buckets) hist[threadIdx.x] = 0;
     if (threadIdx.x == kL1Buckets) any_partial = 0;
@@ -403,16 +402,16 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
     else if (p + P > pos_hi) u &= (1u << (pos_hi - p)) - 1;     // the slab's last lane
     uint32_t key[P][3], rank[P][3];
     if (u) {
-        uint32_t lo[3], hi[3];
+        uint32_t lo[2], hi[2];
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
+        for (int q = 0; q < 2; q++) {
             lo[q] = __builtin_amdgcn_alignbit(w[q][1], w[q][0], sh);
             hi[q] = __builtin_amdgcn_alignbit(w[q][2], w[q][1], sh);
         }
 #pragma unroll
         for (int t = 0; t < P; t++) {
-            kmer_keys(masks, __builtin_amdgcn_alignbit(hi[0], lo[0], t), __builtin_amdgcn_alignbit(hi[1], lo[1], t),
-                      __builtin_amdgcn_alignbit(hi[2], lo[2], t), key[t]);
+            const uint32_t a0 = __builtin_amdgcn_alignbit(hi[0], lo[0], t), a1 = __builtin_amdgcn_alignbit(hi[1], lo[1], t);
+            kmer_keys(masks, a0, a1, ~(a0 ^ a1), key[t]);                       // {A,G} = not ({A,T} xor {A,C})
             if ((u >> t) & 1u) {
 #pragma unroll
                 for (int i = 0; i < 3; i++) rank[t][i] = atomicAdd(&hist[key[t][i] >> kL1Shift], 1u);   // its rank in the row
@@ -1384,7 +1383,7 @@ struct CountPlan {
     int64_t slab_bases_max = 0, n_slabs = 0, n_chunks = 0;
     DensityCaps caps1{}, caps2{};
     size_t cur1_bytes = 0, cur2_bytes = 0, buf1_bytes = 0, buf2_bytes = 0, words_bytes = 0;
-    size_t total() const { return cur1_bytes + cur2_bytes + kTouchedBytes + 6 * words_bytes + buf1_bytes + buf2_bytes; }
+    size_t total() const { return cur1_bytes + cur2_bytes + kTouchedBytes + 5 * words_bytes + buf1_bytes + buf2_bytes; }
 };
 constexpr int64_t kRegions = static_cast<int64_t>(kL1Buckets) * kL1Replicas;
 
@@ -1487,8 +1486,8 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     unsigned int *touched = reinterpret_cast<unsigned int *>(ws); ws += kTouchedBytes;
     unsigned long long *ends = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes;
     unsigned long long *dropped = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes;
-    unsigned long long *strm[4];                           // P0, P1, P2, U
-    for (int q = 0; q < 4; q++) { strm[q] = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes; }
+    unsigned long long *strm[3];                           // P0, P1, U
+    for (int q = 0; q < 3; q++) { strm[q] = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes; }
     uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
     uint16_t *buf2 = reinterpret_cast<uint16_t *>(ws);
     BinOut o1{cursor1, buf1, caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], touched};
@@ -1501,7 +1500,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         hipLaunchKernelGGL(mark_dropped_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
                            ctx->stream, d_offsets, n_reads, d_keep, dropped);
     PALACE_HIP_TRY(hipGetLastError());
-    for (int q = 0; q < 4; q++)                           // the last word of each stream may be partly written, and the
+    for (int q = 0; q < 3; q++)                           // the last word of each stream may be partly written, and the
         PALACE_HIP_TRY(hipMemsetAsync(strm[q] + n_chunks - 1, 0, 24, ctx->stream));   // two pad words behind it are read
     {
         const int64_t groups = (total_bases + 15) / 16, blocks = (groups + kStreamTile - 1) / kStreamTile;
@@ -1509,7 +1508,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         hipLaunchKernelGGL(eref_streams_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d_bases,
                            d_offsets, total_bases, reinterpret_cast<const uint16_t *>(ends),
                            d_keep ? reinterpret_cast<const uint16_t *>(dropped) : nullptr, reinterpret_cast<uint16_t *>(strm[0]),
-                           reinterpret_cast<uint16_t *>(strm[1]), reinterpret_cast<uint16_t *>(strm[2]), reinterpret_cast<uint16_t *>(strm[3]));
+                           reinterpret_cast<uint16_t *>(strm[1]), reinterpret_cast<uint16_t *>(strm[2]));
         PALACE_HIP_TRY(hipGetLastError());
     }
     // positions per lane of the level-1 kernel.  Its throughput is (key slots the CU's LDS holds) / (latency of a tile,
@@ -1525,7 +1524,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         const int64_t tiles = (p_hi - p_lo + tile_pos - 1) / tile_pos;
         PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
         const uint32_t *w0 = reinterpret_cast<const uint32_t *>(strm[0]), *w1 = reinterpret_cast<const uint32_t *>(strm[1]),
-                       *w2 = reinterpret_cast<const uint32_t *>(strm[2]), *wu = reinterpret_cast<const uint32_t *>(strm[3]);
+                       *wu = reinterpret_cast<const uint32_t *>(strm[2]);
         // one tile per workgroup, 8 waves.  (Measured and dropped: 256-thread workgroups with twice the positions per lane
         // -- the same tile, half the waves per CU -- 8-13 % slower; 10 positions per lane: the same time, 16: +45 % (one
         // workgroup per CU); and, twice: persistent workgroups that walk several tiles with the next tile's loads in
@@ -1536,10 +1535,10 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         // 256-thread workgroups (+3 %); 10 / 16 positions per lane (the same / +45 %).
         const dim3 grid(static_cast<unsigned>(tiles)), block(kBinThreads);
         switch (ppl) {
-        case 4: hipLaunchKernelGGL((eref_bin1_sort_kernel<4, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
-        case 5: hipLaunchKernelGGL((eref_bin1_sort_kernel<5, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
-        case 6: hipLaunchKernelGGL((eref_bin1_sort_kernel<6, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
-        default: hipLaunchKernelGGL((eref_bin1_sort_kernel<8, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, w2, wu, p_lo, p_hi, ctx->masks, o1); break;
+        case 4: hipLaunchKernelGGL((eref_bin1_sort_kernel<4, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
+        case 5: hipLaunchKernelGGL((eref_bin1_sort_kernel<5, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
+        case 6: hipLaunchKernelGGL((eref_bin1_sort_kernel<6, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
+        default: hipLaunchKernelGGL((eref_bin1_sort_kernel<8, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
         }
         PALACE_HIP_TRY(hipGetLastError());
         Bin2Grid g2;
