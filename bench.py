@@ -903,7 +903,8 @@ def main():
             except Exception as e:                   # never let this leg break the headline line
                 out["e2e"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             finally:
-                shutil.rmtree(work, ignore_errors=True)
+                if not os.environ.get("PALACE_BENCH_KEEP"):      # (tools/eref_cli_repeat.sh re-runs the executables on these files)
+                    shutil.rmtree(work, ignore_errors=True)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, sample, gs, hdr, args.cpu_sample_frac, last["graph"])
         sys.stdout.flush()
