@@ -363,6 +363,10 @@ __global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__rest
 // (no store waits for the previous one), 95- to 380-byte runs, 8 to 64 replicas, contiguous instead of scattered stores,
 // touching the stream lines of a later tile of the same XCD (-2 %).  Non-temporal stores: +25 %.
 // ------------------------------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS accesses only.  __syncthreads() also fences global memory, i.e. waits (vmcnt) for every
+// global atomic and store the wave has in flight -- which is exactly what the kernels below want to keep in flight.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __host__ __device__ constexpr uint32_t l1_sentinel(uint32_t b) { return (b ^ 64u) << kL1Shift; }
 constexpr uint32_t kRunAlign = 4;                     // keys: every run of level 1 is padded to a multiple of this (16 bytes)
 
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
     uw[0] = su[g]; uw[1] = su[g + 1];
     if (threadIdx.x < kL1Buckets) hist[threadIdx.x] = 0;
     if (threadIdx.x == kL1Buckets) any_partial = 0;
-    __syncthreads();
+    lds_barrier();
     // ---- 1. keys and histogram ----
     uint32_t u = __builtin_amdgcn_alignbit(uw[1], uw[0], sh) & ((1u << P) - 1);
     if (p >= pos_hi) u = 0;
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
         }
     }
     STAMP(stamps, 1);
-    __syncthreads();
+    lds_barrier();
     STAMP(stamps, 2);
     // ---- 2. row starts (wave 0: two rows per lane), pad slots; 3. meanwhile waves 1-2 reserve the padded runs in the
     // bucket regions (a run's size needs its own count only): these global atomics are in flight during 2. and 4. ----
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
         my_pc = (hist[my_row] + kRunAlign - 1) & ~(kRunAlign - 1);
         if (my_pc) my_g = atomicAdd(&o.cursor[l1_cursor(my_row, replica)], my_pc);
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(stamps, 3);
     // ---- 4. placement ----
     if (u) {
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
         dst[my_row] = static_cast<uint32_t>((l1_region_base(o.caps, my_row, replica) + my_g - start[my_row]) >> 2);
         if (!whole) any_partial = 1;
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(stamps, 4);
     // ---- 5. sweep: unrolled, the 16-byte stores of a lane go out back to back (as a loop the compiler made every
     // iteration wait for the previous iteration's store to be acknowledged: three HBM round trips in a row per tile) ----
@@ -1529,10 +1533,10 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         // -- the same tile, half the waves per CU -- 8-13 % slower; 10 positions per lane: the same time, 16: +45 % (one
         // workgroup per CU); and, twice: persistent workgroups that walk several tiles with the next tile's loads in
         // flight -- 25-40 % slower; the workgroups of a CU then run their phases in step, freshly dispatched ones interleave them.)
-        // one tile per workgroup, 8 waves.  Measured and dropped: workgroups that walk over several tiles with the next
-        // tile's words in flight (three times, the last with this kernel: 7.5 ms instead of 4.1 -- all workgroups of the chip
-        // then run the same phase at the same time, while freshly dispatched ones interleave loads, LDS work and stores);
-        // 256-thread workgroups (+3 %); 10 / 16 positions per lane (the same / +45 %).
+        // one tile per workgroup, 8 waves.  Measured and dropped: workgroups that take several tiles with the next tile's
+        // words in flight -- five variants; the last one (a loader wave with direct-to-LDS loads,
+        // LDS-only barriers, hand-placed waits: nothing of the previous tile is waited for) 4.4 ms against 4.07 at the same
+        // tile size; 256-thread workgroups (+3 %); 10 / 16 positions per lane (the same / +45 %).
         const dim3 grid(static_cast<unsigned>(tiles)), block(kBinThreads);
         switch (ppl) {
         case 4: hipLaunchKernelGGL((eref_bin1_sort_kernel<4, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;

@@ -406,3 +406,4 @@ def test_binned_slabs(ctx, with_keep):
     kept = synth.reads_from_list([rs.read(i) for i in range(rs.n) if keep is None or keep[i]])
     u, c = oracle_key_counts(kept.bases, kept.offsets, cc)
     assert_table_equals(ctx, u, c)
+
