@@ -367,6 +367,20 @@ __global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__rest
 // global atomic and store the wave has in flight -- which is exactly what the kernels below want to keep in flight.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (VALU only).  __shfl_up is a ds_bpermute: six of them in
+// a row queue up behind the LDS traffic of the whole CU -- in the level-1 kernel the scan of ONE wave, which the other
+// seven wait for at a barrier, took 2.2 us that way.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);        // row_shr:1  (within rows of 16 lanes)
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true);        // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true);        // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true);        // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);       // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);       // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 __host__ __device__ constexpr uint32_t l1_sentinel(uint32_t b) { return (b ^ 64u) << kL1Shift; }
 constexpr uint32_t kRunAlign = 4;                     // keys: every run of level 1 is padded to a multiple of this (16 bytes)
 
@@ -434,12 +448,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
     if (wave == 0) {
         const uint32_t c0 = hist[2 * lane], c1 = hist[2 * lane + 1];
         const uint32_t pc0 = (c0 + kRunAlign - 1) & ~(kRunAlign - 1), pc1 = (c1 + kRunAlign - 1) & ~(kRunAlign - 1);
-        uint32_t incl = pc0 + pc1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
+        const uint32_t incl = wave_inclusive_scan(pc0 + pc1);
         const uint32_t a0 = incl - pc0 - pc1, a1 = a0 + pc0;
         start[2 * lane] = a0; start[2 * lane + 1] = a1;
         if (lane == 63) start[kL1Buckets] = incl;
