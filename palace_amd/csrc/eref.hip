@@ -1015,26 +1015,46 @@ __global__ __launch_bounds__(1024) void eref_probe_kernel(const unsigned long lo
     const uint32_t b = blockIdx.x;
     const unsigned long long e0 = first[b], n = first[b + 1] - e0;
     if (n == 0) return;                                    // uniform for the workgroup
+    // Entries two at a time (16-byte loads; the group is widened to even entry indices and the strangers at its ends are
+    // skipped), the first batch requested before the slice is: it does not depend on it.
+    const unsigned long long lo = e0 & ~1ull, hi = e0 + n;            // entries [lo, hi) are loaded, [e0, hi) tested
+    const unsigned long long n2 = (hi - lo + 1) / 2;                  // pairs (the array is padded by one entry: see the builder)
+    const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(entries + lo);
+    constexpr int kFirst = 8;                              // pair loads in flight per thread ahead of the slice
+    ulonglong2 e[kFirst];
+#pragma unroll
+    for (int u = 0; u < kFirst; u++) {
+        const unsigned long long i = threadIdx.x + static_cast<unsigned long long>(u) * blockDim.x;
+        e[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
+    }
     const uint4 *g3 = reinterpret_cast<const uint4 *>(p3 + static_cast<size_t>(b) * kSliceWords);
     for (int i = threadIdx.x; i < kSliceWords / 4; i += blockDim.x) reinterpret_cast<uint4 *>(l3)[i] = g3[i];
     __syncthreads();
-    const unsigned long long *mine = entries + e0;
-    constexpr int kBatch = 4;                              // entry loads in flight per thread
-    for (unsigned long long i0 = threadIdx.x; i0 < n; i0 += kBatch * blockDim.x) {
-        unsigned long long e[kBatch];
+    auto test = [&](unsigned long long ent, unsigned long long at) {  // at: global index of the entry
+        if (at < e0 || at >= hi) return;
+        const uint32_t k = static_cast<uint32_t>(ent) & ((1u << kBucketShift) - 1);
+        if ((l3[k >> 5] >> (k & 31)) & 1u) {
+            const unsigned long long pos = ent >> kBucketShift;
+            atomicOr(&hit_words[pos >> 6], 1ull << (pos & 63));
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < kFirst; u++) {
+        const unsigned long long i = threadIdx.x + static_cast<unsigned long long>(u) * blockDim.x;
+        if (i < n2) { test(e[u].x, lo + 2 * i); test(e[u].y, lo + 2 * i + 1); }
+    }
+    constexpr int kBatch = 4;                              // the rest (buckets of more than 16384 entries), four loads at a time
+    for (unsigned long long i0 = threadIdx.x + static_cast<unsigned long long>(kFirst) * blockDim.x; i0 < n2; i0 += kBatch * blockDim.x) {
+        ulonglong2 r[kBatch];
 #pragma unroll
         for (int u = 0; u < kBatch; u++) {
             const unsigned long long i = i0 + u * blockDim.x;
-            e[u] = i < n ? mine[i] : ~0ull;
+            r[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
         }
 #pragma unroll
         for (int u = 0; u < kBatch; u++) {
-            if (i0 + u * blockDim.x >= n) break;
-            const uint32_t k = static_cast<uint32_t>(e[u]) & ((1u << kBucketShift) - 1);
-            if ((l3[k >> 5] >> (k & 31)) & 1u) {
-                const unsigned long long pos = e[u] >> kBucketShift;
-                atomicOr(&hit_words[pos >> 6], 1ull << (pos & 63));
-            }
+            const unsigned long long i = i0 + u * blockDim.x;
+            if (i < n2) { test(r[u].x, lo + 2 * i); test(r[u].y, lo + 2 * i + 1); }
         }
     }
 }
@@ -1771,7 +1791,7 @@ int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const
     TRY_OR_DONE(hipGetLastError());
     TRY_OR_DONE(hipMemcpyAsync(&ix->n_entries, ix->first + kBuckets, 8, hipMemcpyDeviceToHost, ctx->stream));
     TRY_OR_DONE(hipStreamSynchronize(ctx->stream));
-    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->entries), std::max<size_t>(8, ix->n_entries * 8)));
+    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->entries), (ix->n_entries + 2) * 8));      // (+ pad: the probe kernel loads pairs)
     TRY_OR_DONE(hipMemsetAsync(count, 0, kBuckets * 8, ctx->stream));
     hipLaunchKernelGGL(eref_probe_index_kernel<1>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
                        d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, count, ix->first, ix->entries);
