@@ -44,7 +44,8 @@ using palace_host::Names;
 [[noreturn]] void die(const std::string &what)
 {
     std::fprintf(stderr, "filter_graph: %s\n", what.c_str());
-    std::exit(1);
+    std::fflush(stderr);
+    _exit(1);                                      // (may be called from a parser thread: no static destructors beside running threads)
 }
 
 struct Mapped {
