@@ -68,6 +68,11 @@ def test_config1_cli_equals_reference(cfg1):
     p = subprocess.run(args + ["0.8", "0.5", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr
     assert p.stdout == g["stdout_080_050"].tobytes()
+    # third run: the reads counted in many small slabs (the executable's default is 2^28 positions; here 2^22 -> 12 passes)
+    p = subprocess.run(args + ["0.9", "0.85", "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, PALACE_EREF_SLAB=str(1 << 22)))
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == g["stdout_090_085"].tobytes()
 
 
 def test_config1_c_abi_equals_reference(cfg1):
