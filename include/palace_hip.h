@@ -97,7 +97,8 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
  * tests use them for).  set_count_mode: mode 0 = automatic (partition + LDS counting for large inputs, direct global
  * atomics for tiny ones), 1 = always direct, 2 = always partitioned; bucket_cap > 0 overrides the per-bucket capacity
  * of the partitioned path (keys beyond it take the direct path).  set_option(name, value):
- *   "slab_bases"  positions per slab that large read sets are processed in (multiple of 64; 0 = default 2^30 / 2^31) */
+ *   "slab_bases"  positions per slab that large read sets are processed in (multiple of 64; 0 = default 2^30 / 2^31)
+ *   "bin1_ppl"    read positions per lane of the first partition kernel (4, 5, 6 or 8; 0 = by key density) */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap);
 int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value);
 
