@@ -781,8 +781,7 @@ def main():
                 return
             copies, src, dst, w = graph_to_arcs(h_cn, nt, h_edges)
             th2 = time.perf_counter()
-            if not timed:
-                h_last["edges"] = h_edges.copy()
+            h_last["edges"] = h_edges                     # (a view of the pinned buffer: read right after the last step)
             if rank == 0:
                 # compact result: components that hold an arc-bearing segment + one bit per bare segment (views, no copies)
                 res = capi.match_decompose_views(g, copies, src, dst, 10, False, compact=True)
@@ -847,7 +846,8 @@ def main():
                 step(0, False)
             barrier()
             n_soak += 10
-        soak = dict(steps=n_soak, seconds=time.perf_counter() - t1, ms_per_step=1e3 * (time.perf_counter() - t1) / max(1, n_soak))
+        soak = dict(steps=n_soak, seconds=time.perf_counter() - t1, ms_per_step=1e3 * (time.perf_counter() - t1) / max(1, n_soak),
+                    note="untimed steps also lexsort and sha256 the results for `result_digest` (bookkeeping): not comparable with ms_per_step")
     K = range(args.steps)
     count_each = [ctx.mark_elapsed(8 * i, 8 * i + 1) for i in K]
     count_ms = np.mean(count_each)                                                  # one launch per step (both FASTQ sides)

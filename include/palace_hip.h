@@ -134,6 +134,12 @@ int palace_eref_table_planes(palace_ctx *ctx, void **d_planes3, size_t *bytes_pe
 /* Use three caller-owned device buffers (each 2^29 bytes, 16-byte aligned) as the table from now on
  * (so a collective library can address them directly); the context no longer frees table memory. */
 int palace_eref_table_attach(palace_ctx *ctx, void *const d_planes3[3]);
+/* Contract for planes the caller can write (attached ones, or the pointers of palace_eref_table_planes): the library
+ * remembers that a table_reset left every bit zero and lets the first count_reads after it skip reading the plane
+ * slices.  Between a table_reset and the next count_reads the planes may therefore only be modified through library
+ * calls -- or the caller says so: palace_eref_table_invalidate() makes the next count_reads read what is there.
+ * (attach itself invalidates; merge_slices and count_reads do as well.) */
+int palace_eref_table_invalidate(palace_ctx *ctx);
 int palace_eref_table_merge_slices(palace_ctx *ctx, const void *d_parts, int n_parts,
                                    size_t slice_off, size_t slice_bytes);
 

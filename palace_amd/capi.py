@@ -90,6 +90,7 @@ _SIGS = {
                                       C.c_void_p],
     "palace_eref_table_planes": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
     "palace_eref_table_attach": [C.c_void_p, C.POINTER(C.c_void_p)],
+    "palace_eref_table_invalidate": [C.c_void_p],
     "palace_eref_table_merge_slices": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t],
     "palace_eref_table_merge_slices_packed": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t],
     "palace_eref_table_pack_low": [C.c_void_p, C.c_void_p],
@@ -298,6 +299,9 @@ class Ctx:
     def eref_table_attach(self, ptrs):
         arr = (C.c_void_p * 3)(*[int(p) for p in ptrs])
         _check(lib().palace_eref_table_attach(self.h, arr), "palace_eref_table_attach")
+
+    def eref_table_invalidate(self):
+        _check(lib().palace_eref_table_invalidate(self.h), "palace_eref_table_invalidate")
 
     def eref_table_merge_slices(self, parts_ptr: int, n_parts: int, slice_off: int, slice_bytes: int, packed: bool = False):
         fn = lib().palace_eref_table_merge_slices_packed if packed else lib().palace_eref_table_merge_slices

@@ -1558,10 +1558,6 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
         const uint32_t *w0 = reinterpret_cast<const uint32_t *>(strm[0]), *w1 = reinterpret_cast<const uint32_t *>(strm[1]),
                        *wu = reinterpret_cast<const uint32_t *>(strm[2]);
-        // one tile per workgroup, 8 waves.  (Measured and dropped: 256-thread workgroups with twice the positions per lane
-        // -- the same tile, half the waves per CU -- 8-13 % slower; 10 positions per lane: the same time, 16: +45 % (one
-        // workgroup per CU); and, twice: persistent workgroups that walk several tiles with the next tile's loads in
-        // flight -- 25-40 % slower; the workgroups of a CU then run their phases in step, freshly dispatched ones interleave them.)
         // one tile per workgroup, 8 waves.  Measured and dropped: workgroups that take several tiles with the next tile's
         // words in flight -- five variants; the last one (a loader wave with direct-to-LDS loads,
         // LDS-only barriers, hand-placed waits: nothing of the previous tile is waited for) 4.4 ms against 4.07 at the same
@@ -1857,6 +1853,13 @@ int palace_eref_table_attach(palace_ctx *ctx, void *const d_planes3[3])
     }
     ctx->planes_external = true;
     ctx->table_clean = false;                              // caller-owned memory: contents unknown
+    return PALACE_OK;
+}
+
+int palace_eref_table_invalidate(palace_ctx *ctx)
+{
+    PALACE_REQUIRE(ctx, "ctx is null");
+    ctx->table_clean = false;
     return PALACE_OK;
 }
 

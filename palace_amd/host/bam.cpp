@@ -234,6 +234,7 @@ struct BamLoad {
     }
     ~BamLoad()
     {
+        bad = true;                          // unwinding from a header / record error: the workers stop at their next member
         for (auto &t : workers) if (t.joinable()) t.join();
     }
 };

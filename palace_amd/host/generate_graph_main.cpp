@@ -360,7 +360,10 @@ int main(int argc, char **argv)
         std::fprintf(out, "JUNC %s %c %s %c %u %u\n", c.target_name[e.left].c_str(), e.oL ? '-' : '+',
                      c.target_name[e.right].c_str(), e.oR ? '-' : '+', supp + span + supp_nf, span_nf);
     }
-    std::fclose(out);
+    if (std::ferror(out) | std::fclose(out)) {            // a short write must not exit 0
+        std::cerr << "Error: failed writing " << out_path << "\n";
+        return 1;
+    }
     tr.lap("text output");
     std::fflush(nullptr);
     _exit(0);                   // the output is complete and closed: skip tearing down gigabytes of host containers

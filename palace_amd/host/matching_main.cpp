@@ -350,6 +350,8 @@ int main(int argc, char **argv)
         if (!fl || !fc) { std::cerr << "matching: cannot write outputs of " << j.graph << "\n"; return 1; }
         fl << j.lin;
         fc << j.cyc;
+        fl.close(); fc.close();
+        if (fl.fail() || fc.fail()) { std::cerr << "matching: failed writing the outputs of " << j.graph << "\n"; return 1; }
     }
     tr.lap("text output");
     std::fflush(nullptr);

@@ -55,8 +55,10 @@ class Exchange:
         n_pl = len(send)
         if self._recv is None or self._recv.numel() != n_pl * B:
             self._recv = torch.empty((n_pl, W, S), dtype=torch.uint8, device=planes[0].device)
-        # one all_to_all per plane: a plane already is [peer][slice], so it is its own send buffer, and a
-        # message stays <= 512/W MiB (RCCL 2.26 corrupts single all_to_all calls above 1 GiB per rank)
+        # one all_to_all per plane: a plane already is [peer][slice], so it is its own send buffer, and a call moves
+        # 512 MiB per rank.  (Round 1 saw wrong data from ONE call of 1.5 GiB in a world-size-1 rehearsal; the cause
+        # was never isolated -- an element count or byte offset above 2^31 in that call is as likely as a library
+        # fault -- so nothing is claimed about RCCL here: calls of this size have been checked, larger ones have not.)
         for p in range(n_pl):
             dist.all_to_all_single(self._recv[p].view(-1), send[p])
         if pack_fn is None:

@@ -18,30 +18,35 @@ Parity status: UNPINNED -- the reference script cannot run here (Bio is absent);
 import sys
 
 
-def parse_ref_file(path):
-    ref = {}
-    with open(path) as f:
-        for line in f:
-            line = line.strip()
-            if not line.startswith("ref_index"):
+def _as_float(token):
+    try:
+        return float(token)
+    except ValueError:
+        return None
+
+
+def reported_rows(eref_stdout_path):
+    """{1-based .fai row: percentage text value} of eref's report lines.  A report line is `ref_index`, then white-space
+    separated fields: the row is the first field made of digits only, the percentage the LAST field float() accepts
+    (eref prints it last: `ref_index<TAB>row<TAB>n_intervals<TAB>el<TAB>ref_len<TAB>ratio`).  Lines without both are skipped;
+    when a row is reported twice the later line wins."""
+    rows = {}
+    with open(eref_stdout_path) as f:
+        for raw in f:
+            fields = raw.split()
+            if not fields or not fields[0].startswith("ref_index"):
                 continue
-            parts = line.split()
-            index = next((int(p) for p in parts[1:] if p.isdigit()), None)
-            percentage = None
-            for p in reversed(parts):
-                try:
-                    percentage = float(p)
-                    break
-                except ValueError:
-                    continue
-            if index is not None and percentage is not None:
-                ref[index] = percentage
-    return ref
+            row = next((int(t) for t in fields[1:] if t.isdigit()), None)
+            pct = next((v for v in map(_as_float, reversed(fields)) if v is not None), None)
+            if row is not None and pct is not None:
+                rows[row] = pct
+    return rows
 
 
-def load_fai_index(path):
-    with open(path) as f:
-        return {i: line.split("\t")[0] for i, line in enumerate(f, 1)}
+def fai_row_names(fai_path):
+    """Column 0 of every `.fai` line, as a list: names[k] belongs to 1-based row k + 1."""
+    with open(fai_path) as f:
+        return [line.split("\t")[0] for line in f]
 
 
 def fasta_records(path, wanted):
@@ -77,23 +82,24 @@ def main(argv=None):
         return 2
     fasta_file, fai_file, ref_file, out_fasta, out_percent = argv
     print("Loading FAI index...")
-    index_to_name = load_fai_index(fai_file)
+    names = fai_row_names(fai_file)
     print("Processing reference file...")
-    ref_data = parse_ref_file(ref_file)
+    hits = reported_rows(ref_file)
+    known = {row: names[row - 1] for row in hits if 1 <= row <= len(names)}
     print("Loading FASTA sequences...")
-    records = fasta_records(fasta_file, {index_to_name[i] for i in ref_data if i in index_to_name})
+    records = fasta_records(fasta_file, set(known.values()))
     print("Writing output files...")
     with open(out_fasta, "w") as fa, open(out_percent, "w") as pc:
-        for index, percentage in sorted(ref_data.items()):
-            if index not in index_to_name:
-                print(f"Warning: Index {index} not found in FAI file")
+        for row in sorted(hits):
+            if row not in known:
+                print(f"Warning: Index {row} not found in FAI file")
                 continue
-            name = index_to_name[index]
+            name = known[row]
             if name not in records:
                 print(f"Warning: Sequence '{name}' not found in FASTA file")
                 continue
             fa.write(f">{name}\n{records[name]}\n")
-            pc.write(f"{name}\t{percentage}\n")
+            pc.write(f"{name}\t{hits[row]}\n")
     print("Processing complete!")
     return 0
 

@@ -31,4 +31,10 @@ def _torch_claims_the_gpu_first():
         pass
 
 
-_torch_claims_the_gpu_first()            # at import of conftest: before any test module can touch the library
+def pytest_collection_modifyitems(config, items):
+    # only sessions that really run a GPU test initialise the device (after collection, before the first test touches the
+    # library); host-only selections -- parsers, scripts, the sanitizer build -- leave the GPU alone
+    if any(it.get_closest_marker("gpu") is not None for it in items if not it.get_closest_marker("skip")):
+        deselected = config.getoption("-m") or ""
+        if "not gpu" not in deselected:
+            _torch_claims_the_gpu_first()

@@ -277,6 +277,44 @@ def test_properties_full_size(ctx):
         buf.free()
 
 
+def test_planes_written_by_the_caller_between_reset_and_count(ctx):
+    """The contract of palace_eref_table_invalidate (include/palace_hip.h): a caller that writes the planes itself after a
+    reset -- a collective receiving into attached planes -- says so, and the binned count then reads the slices instead of
+    starting them from zero.  External bits: every key of read set A counted once (written with a device copy, as RCCL would)."""
+    rng = synth.rng_for(31)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    pool = synth.random_dna(rng, 300_000)
+    a = synth.vector_reads(rng, pool, 3000, 150)
+    b = synth.vector_reads(rng, pool, 3000, 150)
+    ctx.eref_set_coder(hdr)
+    da, dao, dbb, dbo = ctx.upload(a.bases), ctx.upload(a.offsets), ctx.upload(b.bases), ctx.upload(b.offsets)
+    probe = np.unique(rng.integers(0, 2**32, size=50000, dtype=np.uint64).astype(np.uint32))
+    saved = ctx.empty(3 * (1 << 29), np.uint8)
+    try:
+        ctx.eref_set_count_mode(2, 0)                       # the binned kernels (the only ones with the clean-table fast path)
+        ctx.eref_table_reset()
+        ctx.eref_count_reads(da, dao, a.n)
+        ctx.eref_count_reads(dbb, dbo, b.n)
+        ctx.sync()
+        want = (ctx.eref_table_popcounts(), ctx.eref_table_lookup(probe))
+        planes, nbytes = ctx.eref_table_planes()
+        ctx.eref_table_reset()
+        ctx.eref_count_reads(da, dao, a.n)
+        for p in range(3):
+            ctx.d2d(saved.ptr + p * nbytes, planes[p], nbytes)
+        ctx.eref_table_reset()
+        for p in range(3):                                  # "received" planes: written behind the library's back
+            ctx.d2d(planes[p], saved.ptr + p * nbytes, nbytes)
+        ctx.eref_table_invalidate()
+        ctx.eref_count_reads(dbb, dbo, b.n)
+        ctx.sync()
+        assert (ctx.eref_table_popcounts(), ) == (want[0], ) and np.array_equal(ctx.eref_table_lookup(probe), want[1])
+    finally:
+        ctx.eref_set_count_mode(0, 0)
+        for buf in (da, dao, dbb, dbo, saved):
+            buf.free()
+
+
 @pytest.mark.parametrize("mode,cap", [(2, 0), (2, 64), (2, 1), (2, 140000)])
 def test_binned_path_equals_oracle(ctx, golden_eref, mode, cap):
     """LDS-binned counting (forced on small inputs), incl. bucket overflow into the direct path; cap 140000 puts

@@ -34,7 +34,7 @@ def test_get_ref_by_index_parse_takes_first_index_and_last_float(tmp_path_factor
         f.write("header line\n")
         for idx, n_int, ratio in rows:
             f.write(f"ref_index\t{idx}\t{n_int}\t100\t200\t{ratio:g}\n")
-    got = grbi.parse_ref_file(str(p))
+    got = grbi.reported_rows(str(p))
     want = {}
     for idx, _, ratio in rows:
         want[idx] = float(f"{ratio:g}")                                  # a repeated index keeps the later line
