@@ -297,6 +297,11 @@ int palace_match_arcs_from_edges(const int32_t *cn, int32_t n_segs, const palace
  * open_at[c] = position after the cycle's weakest arc (where -b opens it; 0 for paths).
  * Duplicate and later-round singleton components are NOT filtered here (the caller formats). */
 typedef struct palace_match_result palace_match_result;
+/* Tuning knob (results are identical for every setting): "iters_per_round" = matching iterations enqueued per round before
+ * the host looks (0 = default 12, at most 64).  The decomposition runs on the device without the host in the loop; a round
+ * that needs more iterations than were enqueued is detected at the end and the whole decomposition is redone with the host
+ * checking every round's fixed point. */
+int palace_match_set_option(palace_ctx *ctx, const char *name, int64_t value);
 int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
                            const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
                            palace_match_result **out);

@@ -107,6 +107,7 @@ _SIGS = {
     "palace_match_greedy": [C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 10 + [C.POINTER(C.c_int32)],
     "palace_match_arcs_from_edges": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],
+    "palace_match_set_option": [C.c_void_p, C.c_char_p, C.c_int64],
     "palace_match_decompose": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                C.c_int32, C.POINTER(C.c_void_p)],
     "palace_match_decompose_ex": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
@@ -299,6 +300,9 @@ class Ctx:
     def eref_table_attach(self, ptrs):
         arr = (C.c_void_p * 3)(*[int(p) for p in ptrs])
         _check(lib().palace_eref_table_attach(self.h, arr), "palace_eref_table_attach")
+
+    def match_set_option(self, name: str, value: int):
+        _check(lib().palace_match_set_option(self.h, name.encode(), value), "palace_match_set_option")
 
     def eref_table_invalidate(self):
         _check(lib().palace_eref_table_invalidate(self.h), "palace_eref_table_invalidate")

@@ -73,6 +73,7 @@ struct palace_ctx {
     bool ws_grown = false;
     palace::Workspace pin;     // grow-only pinned host staging
     palace::MatchScratch *match_scratch = nullptr;
+    int match_iters = 0;            // matching iterations enqueued per round (0 = default; tests lower it to force the checked path)
     uint64_t *d_small = nullptr;   // 64 x u64 scratch for reductions
 };
 

@@ -1,0 +1,422 @@
+// matching on gfx950, whole decomposition on the device: rounds of {greedy matching of the conjugate graph, read the paths
+// and cycles off the successor links, charge copy numbers, drop exhausted segments}.  The reference's `matching` binary is
+// absent; the algorithm is this repository's own, pinned to oracle/match_oracle.cpp.
+//
+// Everything here is latency-bound indexing work on a small graph (10^4 .. 10^6 arcs): what counts is that the host never
+// waits.  So every kernel is grid-stride with a fixed grid and reads its sizes (S, V, E, output cursors) from device memory,
+// a fixed number of matching iterations is enqueued per round and the ones behind the fixed point return at once (a flag per
+// iteration says whether it still took an arc), and the host reads two counters back at the very end.
+//
+//   matching     an arc is taken when it is the best remaining arc of both its tail's out-slot and its head's in-slot
+//                (locally dominant arcs: the fixed point is the sequential greedy matching in rank order, whatever the
+//                scheduling).  Rank = 128-bit key (khi, klo), lower is better: per iteration a pass of 64-bit atomicMin on
+//                the stamped khi, a pass of atomicMin on klo among the arcs that tie on khi, and the commit pass.  The
+//                stamp (iteration number, descending) in the top bits of khi lets newer proposals displace older ones, so
+//                the slot arrays are never cleared inside a round.
+//   read-off     a vertex without predecessor walks its path; what no walk reaches lies on cycles, and the smallest vertex
+//                of a cycle walks it.  Of a component and its conjugate twin exactly one walker -- the one with the smaller
+//                first vertex -- reports (make_final_fa.py:20-34 for the conjugate rule).  Reported lengths are scanned over
+//                the vertex ids, which puts the components of a round in ascending first-vertex order, and a second walk
+//                writes the vertices out and charges the copy numbers.
+#include "decomp.hpp"
+
+namespace palace {
+
+namespace {
+
+constexpr uint64_t kNoKey = ~0ull;
+constexpr int kStampShift = 42;                        // khi < 2^42; the iteration stamp lives above
+constexpr uint64_t kLenMask = (1ull << 40) - 1;
+
+__device__ __forceinline__ int tid_global() { return static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x); }
+__device__ __forceinline__ int n_threads() { return static_cast<int>(gridDim.x * blockDim.x); }
+
+// ---- exclusive scan over u64, count on the device -------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t u = __shfl_up(v, d);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kDecompBlock) void scan_partials_kernel(const uint64_t *__restrict__ in, const int32_t *__restrict__ n_dev,
+                                                                     uint64_t *__restrict__ partials)
+{
+    __shared__ uint64_t part[kDecompBlock / 64];
+    const int64_t n = *n_dev, chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t a = min(n, static_cast<int64_t>(blockIdx.x) * chunk), e = min(n, a + chunk);
+    uint64_t s = 0;
+    for (int64_t i = a + threadIdx.x; i < e; i += blockDim.x) s += in[i];
+    const int lane = threadIdx.x & 63;
+    s = wave_incl_scan(s, lane);
+    if (lane == 63) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < kDecompBlock / 64; w++) t += part[w];
+        partials[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(kDecompBlock) void scan_prefix_kernel(uint64_t *__restrict__ partials, int n_parts, uint64_t *__restrict__ total)
+{
+    __shared__ uint64_t part[kDecompBlock / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t x = static_cast<int>(threadIdx.x) < n_parts ? partials[threadIdx.x] : 0;
+    const uint64_t incl = wave_incl_scan(x, lane);
+    if (lane == 63) part[wv] = incl;
+    __syncthreads();
+    uint64_t before = 0;
+    for (int w = 0; w < wv; w++) before += part[w];
+    if (static_cast<int>(threadIdx.x) < n_parts) partials[threadIdx.x] = before + incl - x;
+    if (threadIdx.x == kDecompBlock - 1) *total = before + incl;
+}
+
+__global__ __launch_bounds__(kDecompBlock) void scan_apply_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                                  const int32_t *__restrict__ n_dev, const uint64_t *__restrict__ partials)
+{
+    __shared__ uint64_t part[kDecompBlock / 64];
+    const int64_t n = *n_dev, chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t a = min(n, static_cast<int64_t>(blockIdx.x) * chunk), e = min(n, a + chunk);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint64_t carry = partials[blockIdx.x];
+    for (int64_t base = a; base < e; base += blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        const uint64_t x = i < e ? in[i] : 0;
+        const uint64_t incl = wave_incl_scan(x, lane);
+        if (lane == 63) part[wv] = incl;
+        __syncthreads();
+        uint64_t before = 0, all = 0;
+        for (int w = 0; w < kDecompBlock / 64; w++) { if (w < wv) before += part[w]; all += part[w]; }
+        if (i < e) out[i] = carry + before + incl - x;
+        carry += all;
+        __syncthreads();
+    }
+}
+
+// ---- decomposition -----------------------------------------------------------------------------------------------------
+__global__ void dec_init_kernel(DecompBufs b, int64_t comp_cap, int64_t vert_cap, int n_flags)
+{
+    DecompState *st = b.st;
+    const int V = st->V;
+    for (int i = tid_global(); i < V; i += n_threads()) { b.bo_hi[i] = kNoKey; b.bi_hi[i] = kNoKey; b.on_path[i] = 0; }
+    for (int i = tid_global(); i < n_flags; i += n_threads()) b.changed[i] = 0;
+    if (tid_global() == 0) {
+        st->n_comp = 0; st->n_vert = 0; st->comp_cap = comp_cap; st->vert_cap = vert_cap;
+        st->unsettled = 0; st->overflow = 0; st->scan_total = 0;
+        if (comp_cap >= 0) b.o_off[0] = 0;
+    }
+}
+
+__global__ void dec_round_begin_kernel(DecompBufs b, int reset_left)
+{
+    const int V = b.st->V;
+    for (int i = tid_global(); i < V; i += n_threads()) {
+        const int s = i >> 1;
+        const int64_t l = reset_left ? 1 : b.left[s];          // the aggressive round: every segment gets one more copy
+        if (reset_left && !(i & 1)) b.left[s] = 1;
+        b.alive[i] = l > 0;
+        b.next[i] = -1; b.prev[i] = -1;
+        b.bo_lo[i] = kNoKey; b.bo_lo[V + i] = kNoKey; b.bi_lo[i] = kNoKey; b.bi_lo[V + i] = kNoKey;
+        b.len_a[i] = 0;
+    }
+}
+
+struct IterArgs {
+    uint64_t stamp;           // (descending iteration stamp) << kStampShift
+    int parity;               // which half of the klo slot arrays this iteration uses
+    int prev_flag, flag;      // index of the previous iteration's `changed` word in this round (-1: first) / of this one's
+    int unique_hi;
+};
+
+__device__ __forceinline__ bool arc_open(const DecompBufs &b, int u, int v)
+{
+    return b.alive[u] && b.alive[v] && b.next[u] < 0 && b.prev[v] < 0;
+}
+
+// pass 1: stamped khi into both slots; the klo halves of the OTHER parity (written one iteration ago, needed again in the
+// next one) are reset here, where nothing writes next / prev and "open" is the same for every thread that looks
+__global__ void dec_propose_hi_kernel(DecompBufs b, IterArgs a)
+{
+    if (a.prev_flag >= 0 && !b.changed[a.prev_flag]) return;           // the round reached its fixed point
+    const int64_t E = b.st->E;
+    const int V = b.st->V;
+    const int other = (a.parity ^ 1) * V;
+    for (int64_t e = tid_global(); e < E; e += n_threads()) {
+        const int u = b.src[e], v = b.dst[e];
+        if (!arc_open(b, u, v)) continue;
+        const uint64_t k = a.stamp | b.khi[e];
+        atomicMin(reinterpret_cast<unsigned long long *>(&b.bo_hi[u]), static_cast<unsigned long long>(k));
+        atomicMin(reinterpret_cast<unsigned long long *>(&b.bi_hi[v]), static_cast<unsigned long long>(k));
+        if (!a.unique_hi) { b.bo_lo[other + u] = kNoKey; b.bi_lo[other + v] = kNoKey; }
+    }
+}
+
+// pass 2: among the arcs that tie on khi in a slot, the smallest klo
+__global__ void dec_propose_lo_kernel(DecompBufs b, IterArgs a)
+{
+    if (a.prev_flag >= 0 && !b.changed[a.prev_flag]) return;
+    const int64_t E = b.st->E;
+    const int mine = a.parity * b.st->V;
+    for (int64_t e = tid_global(); e < E; e += n_threads()) {
+        const int u = b.src[e], v = b.dst[e];
+        if (!arc_open(b, u, v)) continue;
+        const uint64_t k = a.stamp | b.khi[e], lo = b.klo[e];
+        if (b.bo_hi[u] == k) atomicMin(reinterpret_cast<unsigned long long *>(&b.bo_lo[mine + u]), static_cast<unsigned long long>(lo));
+        if (b.bi_hi[v] == k) atomicMin(reinterpret_cast<unsigned long long *>(&b.bi_lo[mine + v]), static_cast<unsigned long long>(lo));
+    }
+}
+
+// pass 3: an arc that is the best of both its slots is taken (slot owners are unique: keys are distinct)
+__global__ void dec_commit_kernel(DecompBufs b, IterArgs a)
+{
+    if (a.prev_flag >= 0 && !b.changed[a.prev_flag]) return;
+    const int64_t E = b.st->E;
+    const int mine = a.parity * b.st->V;
+    for (int64_t e = tid_global(); e < E; e += n_threads()) {
+        const int u = b.src[e], v = b.dst[e];
+        if (!arc_open(b, u, v)) continue;            // (a slot taken a moment ago by another arc of this pass reads as closed: that arc held the slot's best key, not this one)
+        const uint64_t k = a.stamp | b.khi[e], lo = b.klo[e];
+        if (b.bo_hi[u] != k || b.bi_hi[v] != k) continue;
+        if (!a.unique_hi && (b.bo_lo[mine + u] != lo || b.bi_lo[mine + v] != lo)) continue;
+        b.next[u] = v; b.prev[v] = u;
+        b.nhi[u] = b.khi[e]; b.nlo[u] = lo;
+        b.changed[a.flag] = 1u;
+    }
+}
+
+// open walks: every live vertex without predecessor walks to the end of its path; the walker whose first vertex is the smaller
+// one of {P, conj P} reports
+__global__ void dec_heads_kernel(DecompBufs b, int round, int last_flag)
+{
+    DecompState *st = b.st;
+    if (tid_global() == 0 && last_flag >= 0 && b.changed[last_flag]) st->unsettled = 1;
+    const int V = st->V;
+    for (int v = tid_global(); v < V; v += n_threads()) {
+        if (!b.alive[v] || b.prev[v] >= 0) continue;
+        int len = 0, last = v;
+        int64_t least = b.left[v >> 1];
+        for (int x = v; x >= 0; x = b.next[x]) {
+            b.on_path[x] = round + 1;
+            last = x;
+            len++;
+            least = min(least, b.left[x >> 1]);
+        }
+        const int twin_first = last ^ 1;                          // first vertex of the conjugate path
+        if (v > twin_first) continue;                             // the twin's walker reports
+        const int64_t uses = twin_first == v ? 2 : 1;             // the path is its own conjugate: every segment lies on it twice
+        b.len_a[v] = (1ull << 40) | static_cast<uint64_t>(len);
+        b.pay[v] = max(static_cast<int64_t>(1), least / uses);
+        b.kind[v] = 0;
+        b.open_at[v] = 0;
+    }
+}
+
+// closed walks: a live vertex no open walk reached lies on a cycle; it walks until it meets a smaller vertex (then it is not
+// the cycle's first vertex) or itself
+__global__ void dec_cycles_kernel(DecompBufs b, int round)
+{
+    const int V = b.st->V;
+    for (int v = tid_global(); v < V; v += n_threads()) {
+        if (!b.alive[v] || b.on_path[v] == round + 1) continue;
+        int len = 1, twin_least = v ^ 1, worst = 0;
+        uint64_t whi = b.nhi[v], wlo = b.nlo[v];
+        int64_t least = b.left[v >> 1];
+        bool first = true;
+        for (int x = b.next[v]; x != v; x = b.next[x]) {
+            if (x < v) { first = false; break; }           // (also ends the walk should x ever be -1: every vertex here has a successor)
+            twin_least = min(twin_least, x ^ 1);
+            const uint64_t hi = b.nhi[x], lo = b.nlo[x];
+            if (hi > whi || (hi == whi && lo > wlo)) { whi = hi; wlo = lo; worst = len; }
+            least = min(least, b.left[x >> 1]);
+            len++;
+        }
+        if (!first || v > twin_least) continue;                   // the conjugate cycle starts lower: its first vertex reports
+        const int64_t uses = twin_least == v ? 2 : 1;
+        b.len_a[v] = (1ull << 40) | static_cast<uint64_t>(len);
+        b.pay[v] = max(static_cast<int64_t>(1), least / uses);
+        b.kind[v] = 1;
+        b.open_at[v] = (worst + 1) % len;                         // position behind the weakest arc (where -b opens the cycle)
+    }
+}
+
+// second walk of the reporting vertices: the component into the output arrays, copies charged
+__global__ void dec_emit_kernel(DecompBufs b, int round)
+{
+    DecompState *st = b.st;
+    const int V = st->V;
+    const int64_t c0 = st->n_comp, v0 = st->n_vert;
+    for (int v = tid_global(); v < V; v += n_threads()) {
+        const uint64_t la = b.len_a[v];
+        if (!la) continue;
+        const int64_t len = static_cast<int64_t>(la & kLenMask);
+        const uint64_t p = b.pos[v];
+        const int64_t c = c0 + static_cast<int64_t>(p >> 40), at = v0 + static_cast<int64_t>(p & kLenMask);
+        const int64_t pay = b.pay[v];
+        const bool room = c < st->comp_cap && at + len <= st->vert_cap;
+        if (!room) st->overflow = 1;
+        else { b.o_off[c] = at; b.o_kind[c] = b.kind[v]; b.o_iter[c] = round; b.o_open[c] = b.open_at[v]; }
+        int x = v;
+        for (int64_t k = 0; k < len; k++) {
+            if (room) b.o_verts[at + k] = 2 * b.orig[x >> 1] + (x & 1);
+            const int64_t l = b.left[x >> 1];
+            b.left[x >> 1] = max(static_cast<int64_t>(0), l - pay);
+            x = b.next[x];
+        }
+    }
+}
+
+__global__ void dec_round_end_kernel(DecompBufs b)
+{
+    DecompState *st = b.st;
+    if (tid_global() != 0) return;
+    st->n_comp += static_cast<int64_t>(st->scan_total >> 40);
+    st->n_vert += static_cast<int64_t>(st->scan_total & kLenMask);
+    if (st->n_comp <= st->comp_cap) b.o_off[st->n_comp] = st->n_vert;       // (o_off has comp_cap + 1 entries)
+}
+
+size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct Carver {
+    char *base;
+    size_t used = 0;
+    template <class T>
+    T *take(size_t n)
+    {
+        T *p = base ? reinterpret_cast<T *>(base + used) : nullptr;
+        used += up256(std::max<size_t>(1, n) * sizeof(T));
+        return p;
+    }
+};
+
+size_t carve_all(DecompBufs &b, char *base, int64_t s_cap, int64_t e_cap, int64_t comp_cap, int64_t vert_cap, int rounds, int iters)
+{
+    Carver c{base};
+    const size_t S = static_cast<size_t>(std::max<int64_t>(1, s_cap)), V = 2 * S, E = static_cast<size_t>(std::max<int64_t>(1, e_cap));
+    b.st = c.take<DecompState>(1);
+    b.src = c.take<int32_t>(E); b.dst = c.take<int32_t>(E);
+    b.khi = c.take<uint64_t>(E); b.klo = c.take<uint64_t>(E);
+    b.left = c.take<int64_t>(S); b.orig = c.take<int32_t>(S);
+    b.next = c.take<int32_t>(V); b.prev = c.take<int32_t>(V); b.on_path = c.take<int32_t>(V); b.open_at = c.take<int32_t>(V);
+    b.nhi = c.take<uint64_t>(V); b.nlo = c.take<uint64_t>(V);
+    b.bo_hi = c.take<uint64_t>(V); b.bi_hi = c.take<uint64_t>(V);
+    b.bo_lo = c.take<uint64_t>(2 * V); b.bi_lo = c.take<uint64_t>(2 * V);
+    b.len_a = c.take<uint64_t>(V); b.pos = c.take<uint64_t>(V);
+    b.pay = c.take<int64_t>(V);
+    b.alive = c.take<uint8_t>(V); b.kind = c.take<uint8_t>(V);
+    b.partials = c.take<uint64_t>(kDecompGrid + 1);
+    b.changed = c.take<uint32_t>(static_cast<size_t>(rounds) * static_cast<size_t>(iters));
+    b.o_off = c.take<int64_t>(static_cast<size_t>(comp_cap) + 1);
+    b.o_verts = c.take<int32_t>(static_cast<size_t>(vert_cap));
+    b.o_iter = c.take<int32_t>(static_cast<size_t>(comp_cap));
+    b.o_open = c.take<int32_t>(static_cast<size_t>(comp_cap));
+    b.o_kind = c.take<uint8_t>(static_cast<size_t>(comp_cap));
+    return c.used;
+}
+
+}  // namespace
+
+size_t decomp_bytes(int64_t s_cap, int64_t e_cap, int64_t comp_cap, int64_t vert_cap, int rounds, int iters)
+{
+    DecompBufs tmp;
+    return carve_all(tmp, nullptr, s_cap, e_cap, comp_cap, vert_cap, rounds, iters);
+}
+
+void decomp_carve(DecompBufs &b, char *base, int64_t s_cap, int64_t e_cap, int64_t comp_cap, int64_t vert_cap, int rounds, int iters)
+{
+    carve_all(b, base, s_cap, e_cap, comp_cap, vert_cap, rounds, iters);
+}
+
+int scan_u64(palace_ctx *ctx, const uint64_t *in, uint64_t *out, const int32_t *n_dev, uint64_t *partials, uint64_t *total_dev)
+{
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(kDecompGrid), dim3(kDecompBlock), 0, ctx->stream, in, n_dev, partials);
+    hipLaunchKernelGGL(scan_prefix_kernel, dim3(1), dim3(kDecompBlock), 0, ctx->stream, partials, kDecompGrid, total_dev);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(kDecompGrid), dim3(kDecompBlock), 0, ctx->stream, in, out, n_dev, partials);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+namespace {
+
+const dim3 kGrid(kDecompGrid), kBlock(kDecompBlock);
+
+// `n` matching iterations of one round; `first` = the number (inside the round) of the first of them, `count` = iterations
+// enqueued since the state was initialised (the stamp), flags[flag0 ..] their `changed` words.  The first iteration of a batch
+// runs unconditionally (the caller knows the previous batch, if any, still took an arc).
+void enqueue_iterations(palace_ctx *ctx, const DecompBufs &b, int first, int n, uint64_t *count, int flag0, bool unique_hi)
+{
+    for (int k = 0; k < n; k++) {
+        IterArgs a{((1ull << 21) - 1 - *count) << kStampShift, (first + k) & 1, k ? flag0 + k - 1 : -1, flag0 + k, unique_hi ? 1 : 0};
+        (*count)++;
+        hipLaunchKernelGGL(dec_propose_hi_kernel, kGrid, kBlock, 0, ctx->stream, b, a);
+        if (!unique_hi) hipLaunchKernelGGL(dec_propose_lo_kernel, kGrid, kBlock, 0, ctx->stream, b, a);
+        hipLaunchKernelGGL(dec_commit_kernel, kGrid, kBlock, 0, ctx->stream, b, a);
+    }
+}
+
+int enqueue_read_off(palace_ctx *ctx, const DecompBufs &b, int round, int last_flag)
+{
+    hipLaunchKernelGGL(dec_heads_kernel, kGrid, kBlock, 0, ctx->stream, b, round, last_flag);
+    hipLaunchKernelGGL(dec_cycles_kernel, kGrid, kBlock, 0, ctx->stream, b, round);
+    int rc = scan_u64(ctx, b.len_a, b.pos, &b.st->V, b.partials, &b.st->scan_total);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dec_emit_kernel, kGrid, kBlock, 0, ctx->stream, b, round);
+    hipLaunchKernelGGL(dec_round_end_kernel, dim3(1), dim3(64), 0, ctx->stream, b);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+}  // namespace
+
+int decomp_enqueue(palace_ctx *ctx, const DecompBufs &b, int rounds, int aggressive, int iters, bool unique_hi,
+                   int64_t comp_cap, int64_t vert_cap)
+{
+    PALACE_REQUIRE(rounds >= 1 && rounds <= kMaxRounds && iters >= 1 && iters <= kMaxIters, "round / iteration count out of range");
+    static_assert(kDecompGrid <= kDecompBlock, "scan_prefix_kernel scans the block sums with one workgroup");
+    hipLaunchKernelGGL(dec_init_kernel, kGrid, kBlock, 0, ctx->stream, b, comp_cap, vert_cap, rounds * iters);
+    uint64_t count = 0;                                                     // < 2^16: the stamp fits above bit 42
+    for (int t = 0; t < rounds; t++) {
+        hipLaunchKernelGGL(dec_round_begin_kernel, kGrid, kBlock, 0, ctx->stream, b, (aggressive && t == rounds - 1) ? 1 : 0);
+        enqueue_iterations(ctx, b, 0, iters, &count, t * iters, unique_hi);
+        int rc = enqueue_read_off(ctx, b, t, t * iters + iters - 1);
+        if (rc) return rc;
+    }
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+// The same decomposition with the host in the loop: batches of iterations until the round's fixed point, however many it
+// takes (a chain of ascending weights needs as many iterations as it has arcs).  Only used when decomp_enqueue's fixed
+// number of iterations did not suffice (`unsettled`); needs rounds * 2^21 / ... never more than 2^21 iterations in all.
+int decomp_run_checked(palace_ctx *ctx, const DecompBufs &b, int rounds, int aggressive, bool unique_hi, int64_t comp_cap,
+                       int64_t vert_cap, int64_t max_iterations)
+{
+    PALACE_REQUIRE(rounds >= 1 && rounds <= kMaxRounds, "round count out of range");
+    constexpr int kBatch = 16;                                              // even: the klo parity carries over
+    hipLaunchKernelGGL(dec_init_kernel, kGrid, kBlock, 0, ctx->stream, b, comp_cap, vert_cap, kBatch);
+    uint64_t count = 0;
+    for (int t = 0; t < rounds; t++) {
+        hipLaunchKernelGGL(dec_round_begin_kernel, kGrid, kBlock, 0, ctx->stream, b, (aggressive && t == rounds - 1) ? 1 : 0);
+        for (int first = 0;; first += kBatch) {
+            PALACE_HIP_TRY(hipMemsetAsync(b.changed, 0, kBatch * sizeof(uint32_t), ctx->stream));
+            enqueue_iterations(ctx, b, first, kBatch, &count, 0, unique_hi);
+            uint32_t last = 0;
+            PALACE_HIP_TRY(hipMemcpyAsync(&last, b.changed + kBatch - 1, sizeof last, hipMemcpyDeviceToHost, ctx->stream));
+            PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (!last) break;
+            if (static_cast<int64_t>(count) > max_iterations || count + kBatch >= (1ull << 21)) {
+                set_error("matching: no fixed point after %llu iterations", static_cast<unsigned long long>(count));
+                return PALACE_ESTATE;
+            }
+        }
+        PALACE_HIP_TRY(hipMemsetAsync(b.changed, 0, kBatch * sizeof(uint32_t), ctx->stream));    // settled: heads must not flag the round
+        int rc = enqueue_read_off(ctx, b, t, kBatch - 1);
+        if (rc) return rc;
+    }
+    return PALACE_OK;
+}
+
+}  // namespace palace

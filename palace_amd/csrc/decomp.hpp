@@ -1,0 +1,68 @@
+// Internal interface of the device-resident path / cycle decomposition (decomp.hip), shared by the two entry points that
+// feed it: palace_match_decompose[_ex] (arcs ranked by the host, match.hip) and the resident stage-04 path (arcs built on the
+// device from the filtered graph, filter.hip).  Not part of the C ABI.
+#pragma once
+#include "common.hpp"
+
+namespace palace {
+
+constexpr int kDecompGrid = 256;           // every kernel of the decomposition is grid-stride over a count it reads from device
+constexpr int kDecompBlock = 256;          // memory: the launch sequence never depends on a number only the device knows
+constexpr int kMaxRounds = 1024;           // iterations (+1 when aggressive) of a decomposition
+constexpr int kMaxIters = 64;              // matching iterations enqueued per round at most
+
+// scalars of one decomposition, device resident (the host reads them back once, at the end)
+struct DecompState {
+    int32_t S, V;                          // segments / oriented vertices of the arc-bearing sub-graph
+    int64_t E;                             // arcs
+    int64_t n_comp, n_vert;                // components / vertex slots written so far
+    int64_t comp_cap, vert_cap;            // room in the output arrays
+    uint32_t unsettled;                    // a round ran out of enqueued matching iterations before its fixed point
+    uint32_t overflow;                     // output arrays too small
+    uint32_t bad;                          // inconsistent input (filter path: unknown contig in contigs.paths, ...)
+    uint32_t pad;
+    uint64_t scan_total;                   // last scan: sum of all inputs
+};
+
+struct DecompBufs {
+    DecompState *st = nullptr;
+    // arcs [E]: tail, head (sub-graph vertex ids) and rank key -- lower (khi, klo) is better, keys are distinct
+    int32_t *src = nullptr, *dst = nullptr;
+    uint64_t *khi = nullptr, *klo = nullptr;
+    // segments [S]: copies left, id of the segment in the caller's graph (vertices are reported as 2 * orig + orientation)
+    int64_t *left = nullptr;
+    int32_t *orig = nullptr;
+    // vertices [V]
+    int32_t *next = nullptr, *prev = nullptr, *on_path = nullptr, *open_at = nullptr;
+    uint64_t *nhi = nullptr, *nlo = nullptr;            // key of the arc leaving the vertex
+    uint64_t *bo_hi = nullptr, *bi_hi = nullptr;        // best proposal per out / in slot (stamped)
+    uint64_t *bo_lo = nullptr, *bi_lo = nullptr;        // [2][V], by iteration parity
+    uint64_t *len_a = nullptr, *pos = nullptr;          // scan input / output: (1 << 40 | length) at emitting first vertices
+    int64_t *pay = nullptr;
+    uint8_t *alive = nullptr, *kind = nullptr;
+    uint64_t *partials = nullptr;                       // [kDecompGrid + 1]
+    uint32_t *changed = nullptr;                        // [rounds][iters]: a matching iteration took an arc
+    // outputs (device)
+    int64_t *o_off = nullptr;
+    int32_t *o_verts = nullptr, *o_iter = nullptr, *o_open = nullptr;
+    uint8_t *o_kind = nullptr;
+};
+
+// bytes of device memory carve() takes for a sub-graph of at most s_cap segments, e_cap arcs and the given output room
+size_t decomp_bytes(int64_t s_cap, int64_t e_cap, int64_t comp_cap, int64_t vert_cap, int rounds, int iters);
+// lays the arrays of `b` out in [base, base + decomp_bytes(...))
+void decomp_carve(DecompBufs &b, char *base, int64_t s_cap, int64_t e_cap, int64_t comp_cap, int64_t vert_cap, int rounds, int iters);
+// Enqueue the whole decomposition on the context's stream (no host synchronisation): `rounds` rounds of at most `iters`
+// matching iterations each.  b.st->S/V/E, the arcs, left and orig must be in place (stream order); comp_cap / vert_cap are
+// stored into the state.  When `unique_hi`, khi alone ranks the arcs (the second proposal pass is skipped).
+int decomp_enqueue(palace_ctx *ctx, const DecompBufs &b, int rounds, int aggressive, int iters, bool unique_hi,
+                   int64_t comp_cap, int64_t vert_cap);
+
+// The same with the host checking for each round's fixed point (any number of iterations); synchronises the stream.
+int decomp_run_checked(palace_ctx *ctx, const DecompBufs &b, int rounds, int aggressive, bool unique_hi, int64_t comp_cap,
+                       int64_t vert_cap, int64_t max_iterations);
+
+// exclusive scan of u64 values whose count *n_dev lives on the device: 3 launches on the stream; total -> *total_dev
+int scan_u64(palace_ctx *ctx, const uint64_t *in, uint64_t *out, const int32_t *n_dev, uint64_t *partials, uint64_t *total_dev);
+
+}  // namespace palace

@@ -1453,6 +1453,16 @@ int plan_count(palace_ctx *ctx, int64_t total_bases, CountPlan *pl)
     pl->buf2_bytes = align_up(static_cast<size_t>(pl->caps2.prefix(kL1Buckets)) * kL2Rows * 4, 256);    // pairs of 2-byte keys
     pl->n_chunks = (total_bases + 63) / 64;
     pl->words_bytes = align_up(static_cast<size_t>(pl->n_chunks + 2) * 8, 256);       // one u64 per 64 positions (+ pad)
+    // The invariants the level-1 kernel relies on, stated where the sizes are made (round 2 lost an afternoon's variant to
+    // an out-of-range access whose source was not kept -- DESIGN.md section 4 item 6):
+    //  (a) a lane reads the u32 stream words g .. g+2 with g <= pos_hi >> 5 <= total_bases >> 5: the pad behind the last
+    //      word of a stream must cover two more words, for the last tile of EVERY slab (inner slabs read real words);
+    PALACE_REQUIRE(pl->words_bytes >= (static_cast<size_t>(total_bases >> 5) + 3) * 4, "stream pad does not cover the last tile's look-ahead");
+    //  (b) destinations are 32-bit indices of 16-byte groups into buf1: base of the last region + its capacity < 2^32 groups;
+    PALACE_REQUIRE(pl->caps1.prefix(kL1Buckets) * kL1Replicas / 4 < (1ull << 32), "level-1 regions exceed 2^32 groups of 16 bytes");
+    //  (c) a region cursor keeps counting when its region is full (the excess takes the exact path): it must not wrap even
+    //      if every key of the slab's tiles of one replica lands in one bucket.
+    PALACE_REQUIRE(3ull * static_cast<uint64_t>(slab_bases) / kL1Replicas + (1ull << 20) < (1ull << 32), "slab too large for 32-bit region cursors");
     return PALACE_OK;
 }
 }  // namespace

@@ -2,14 +2,17 @@
 // arcs.  The reference implementation of `matching` is not available; this is the
 // repository's own algorithm (DESIGN.md "matching"), pinned to oracle/match_oracle.cpp.
 //
-// A vertex owns two slots: "out" (its successor) and "in" (its predecessor).  Arc ids are ranks
-// (0 = best).  Per round: every free out-slot proposes the lowest-id arc whose head's in-slot is
-// free, every free in-slot proposes the lowest-id arc whose tail's out-slot is free; an arc
-// proposed from both sides is taken.  The globally best remaining arc is always taken, and any
-// arc taken this way is one the sequential greedy pass would also take, so the fixed point is the
-// greedy matching -- independent of scheduling.  The graph here is the filtered conjugate graph
-// (10^4..10^6 arcs): bandwidth-trivial, latency-bound; rounds are separate small launches.
+// This file: palace_match_greedy (one matching, CSR lists, arc ids = ranks), the host glue that ranks arcs
+// (palace_match_arcs_from_edges) and palace_match_decompose[_ex], which hands the arc-bearing sub-graph to the
+// device-resident decomposition of decomp.hip and expands its result.
+//
+// palace_match_greedy: a vertex owns two slots, "out" (its successor) and "in" (its predecessor).  Per round every
+// free out-slot proposes the lowest-id arc whose head's in-slot is free, every free in-slot the lowest-id arc whose
+// tail's out-slot is free; an arc proposed from both sides is taken.  The globally best remaining arc is always
+// taken, and any arc taken this way is one the sequential greedy pass would also take, so the fixed point is the
+// greedy matching -- independent of scheduling.
 #include "common.hpp"
+#include "decomp.hpp"
 #include <algorithm>
 #include <map>
 #include <memory>
@@ -132,7 +135,7 @@ extern "C" int palace_match_greedy(palace_ctx *ctx, int32_t n_vertices, int64_t 
     return PALACE_OK;
 }
 
-// ---- whole decomposition: GPU matching per round + host read-off ------------------------------
+// ---- whole decomposition: the arc-bearing sub-graph on the device, bare segments merged in on the host ----
 struct SubResult {                      // components of the arc-bearing sub-graph (small)
     std::vector<int64_t> off{0};
     std::vector<int32_t> verts, iter, open_at;
@@ -180,15 +183,12 @@ private:
 };
 static BlockPool g_result_pool;
 
-struct Head { int32_t first; int64_t begin, end; uint8_t cycle; int32_t open; };
-
-// Host temporaries of palace_match_decompose, kept in the context between calls for the same reason.
+// Host temporaries of palace_match_decompose, kept in the context between calls (fresh megabyte-sized vectors cost a page
+// fault per 4 KiB).
 struct MatchScratch {
-    std::vector<int32_t> new_id, old_id, ssrc, sdst, owner, pool, live;
-    std::vector<int64_t> sub_copies, po, pi, left;
-    std::vector<uint8_t> seen;
+    std::vector<int32_t> new_id, old_id, ssrc, sdst;
+    std::vector<int64_t> sub_copies;
     std::vector<uint64_t> has_arc;
-    std::vector<Head> heads, ordered;
     SubResult sub;
 };
 void free_match_scratch(MatchScratch *m) { delete m; }
@@ -206,6 +206,14 @@ struct Borrowed {
     Borrowed &operator=(const Borrowed &) = delete;
 };
 
+__global__ void iota_keys_kernel(uint64_t *__restrict__ khi, uint64_t *__restrict__ klo, int64_t n)
+{
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        khi[i] = static_cast<uint64_t>(i);                       // arcs arrive in rank order: the rank is the key
+        klo[i] = 0;
+    }
+}
+
 }  // namespace palace
 
 struct palace_match_result {            // final result: arrays from the block pool, written exactly once
@@ -215,221 +223,92 @@ struct palace_match_result {            // final result: arrays from the block p
     uint8_t *kind = nullptr;
     uint64_t *bare = nullptr;            // compact results: bit s set = segment s has no arc (bare path of round 0 [+ the aggressive round])
     int64_t n_bare = 0;
+    bool borrowed = false;               // the arrays belong to somebody else (the resident stage-04 object): nothing to give back
     ~palace_match_result()
     {
+        if (borrowed) return;
         for (void *p : {(void *)off, (void *)verts, (void *)iter, (void *)open_at, (void *)kind, (void *)bare}) palace::g_result_pool.give(p);
     }
 };
 
-namespace palace {
-// Device arrays of one decomposition live in the context's grow-only workspace, behind the two
-// want arrays palace_match_greedy keeps at its start: hipMalloc/hipFree per call would wait for every
-// stream of the device (the eref stream runs beside this one).
-struct Arena {
-    char *base;
-    size_t used;
-    template <class T>
-    T *take(size_t n)
-    {
-        T *p = reinterpret_cast<T *>(base + used);
-        used += (std::max<size_t>(1, n) * sizeof(T) + 255) / 256 * 256;
-        return p;
-    }
-};
-template <class T>
-static int dev_copy(palace_ctx *ctx, Arena &ar, const T *h, size_t n, T **d)
+// The decomposition of the arc-bearing sub-graph, all of it on the device (decomp.hip): arcs, copy numbers and the segment
+// ids of the caller's graph go up, the component arrays come back -- one synchronisation in the middle of nothing: the host
+// enqueues everything, then waits once for the counters and once for the arrays.
+static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, const int32_t *orig, int64_t n_arcs,
+                          const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive, SubResult *res)
 {
-    *d = ar.take<T>(n);
-    if (n) PALACE_HIP_TRY(hipMemcpyAsync(*d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    return PALACE_OK;
-}
-}  // namespace palace
-
-using palace::dev_copy;
-
-static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
-                          const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
-                          palace::MatchScratch &ms, SubResult *res)
-{
-    const int32_t V = 2 * n_segs;
-    const int64_t E = n_arcs;
-    // Host staging in pinned memory (grow-only, owned by the context): the link arrays that come back every round,
-    // laid out like the three device arrays so that one copy fetches them all, the liveness bytes, the `changed`
-    // word, and the CSR of the arcs, so that every upload is a true asynchronous copy.
-    const size_t v4 = (static_cast<size_t>(V) * 4 + 255) / 256 * 256, v1 = (static_cast<size_t>(V) + 255) / 256 * 256;
-    const size_t o8 = (static_cast<size_t>(V + 1) * 8 + 255) / 256 * 256, e4 = (static_cast<size_t>(E) * 4 + 255) / 256 * 256;
-    {
-        int rc = palace::ensure_pinned(ctx, 3 * v4 + v1 + 256 + 2 * o8 + 4 * e4);
-        if (rc) return rc;
-    }
-    char *pin = static_cast<char *>(ctx->pin.ptr);
-    int32_t *next = reinterpret_cast<int32_t *>(pin), *prev = next + v4 / 4, *narc = prev + v4 / 4;
-    uint8_t *alive = reinterpret_cast<uint8_t *>(pin + 3 * v4);
-    unsigned int *changed = reinterpret_cast<unsigned int *>(pin + 3 * v4 + v1);
-    int64_t *out_off = reinterpret_cast<int64_t *>(pin + 3 * v4 + v1 + 256), *in_off = out_off + o8 / 8;
-    int32_t *out_arcs = reinterpret_cast<int32_t *>(in_off + o8 / 8), *in_arcs = out_arcs + e4 / 4;
-    int32_t *p_src = in_arcs + e4 / 4, *p_dst = p_src + e4 / 4;
-    // CSR by tail and by head; arc ids ascend inside every list because arcs arrive in rank order
-    palace::Borrowed<std::vector<int64_t>> b_po(ms.po), b_pi(ms.pi), b_left(ms.left);
-    palace::Borrowed<std::vector<int32_t>> b_owner(ms.owner), b_pool(ms.pool);
-    palace::Borrowed<std::vector<uint8_t>> b_seen(ms.seen);
-    palace::Borrowed<std::vector<palace::Head>> b_heads(ms.heads), b_ordered(ms.ordered);
-    auto &po = b_po.v, &pi = b_pi.v;
-    std::fill(out_off, out_off + V + 1, 0); std::fill(in_off, in_off + V + 1, 0);
-    for (int64_t e = 0; e < E; e++) { out_off[src[e] + 1]++; in_off[dst[e] + 1]++; }
-    for (int32_t v = 0; v < V; v++) { out_off[v + 1] += out_off[v]; in_off[v + 1] += in_off[v]; }
-    po.assign(out_off, out_off + V); pi.assign(in_off, in_off + V);
-    for (int64_t e = 0; e < E; e++) { out_arcs[po[src[e]]++] = static_cast<int32_t>(e); in_arcs[pi[dst[e]]++] = static_cast<int32_t>(e); }
-    std::copy(src, src + E, p_src); std::copy(dst, dst + E, p_dst);
-    int32_t *d_src = nullptr, *d_dst = nullptr, *d_oa = nullptr, *d_ia = nullptr, *d_next = nullptr, *d_prev = nullptr, *d_narc = nullptr;
-    int64_t *d_oo = nullptr, *d_io = nullptr;
-    uint8_t *d_alive = nullptr;
-    const size_t greedy_bytes = (static_cast<size_t>(V) * 8 + 256 + 255) / 256 * 256;
-    const size_t arena_bytes = greedy_bytes + 4 * (static_cast<size_t>(E) * 4 + 256) + 2 * (static_cast<size_t>(V + 1) * 8 + 256) +
-                               3 * (static_cast<size_t>(V) * 4 + 256) + static_cast<size_t>(V) + 256;
-    {
-        int rc = palace::ensure_workspace(ctx, arena_bytes);
-        if (rc) return rc;
-    }
-    palace::Arena ar{static_cast<char *>(ctx->ws.ptr), greedy_bytes};
-    auto cleanup = [&] { (void)hipStreamSynchronize(ctx->stream); };   // host vectors must outlive the copies
-#define TRY_OR_CLEAN(expr) do { int rc__ = (expr); if (rc__) { cleanup(); return rc__; } } while (0)
-    TRY_OR_CLEAN(dev_copy(ctx, ar, p_src, E, &d_src)); TRY_OR_CLEAN(dev_copy(ctx, ar, p_dst, E, &d_dst));
-    TRY_OR_CLEAN(dev_copy(ctx, ar, out_arcs, E, &d_oa)); TRY_OR_CLEAN(dev_copy(ctx, ar, in_arcs, E, &d_ia));
-    TRY_OR_CLEAN(dev_copy(ctx, ar, out_off, V + 1, &d_oo)); TRY_OR_CLEAN(dev_copy(ctx, ar, in_off, V + 1, &d_io));
-    d_next = ar.take<int32_t>(V); d_prev = ar.take<int32_t>(V); d_narc = ar.take<int32_t>(V);   // written by match_init_kernel
-    if (reinterpret_cast<char *>(d_prev) - reinterpret_cast<char *>(d_next) != static_cast<ptrdiff_t>(v4) ||
-        reinterpret_cast<char *>(d_narc) - reinterpret_cast<char *>(d_prev) != static_cast<ptrdiff_t>(v4)) {
-        palace::set_error("decompose: arena layout"); cleanup(); return PALACE_ESTATE;
-    }
-    d_alive = ar.take<uint8_t>(V);
-    if (ar.used > arena_bytes) { palace::set_error("decompose: arena accounting"); cleanup(); return PALACE_ESTATE; }
-
-    using palace::Head;
-    auto &left = b_left.v;
-    auto &seen = b_seen.v;
-    auto &owner = b_owner.v, &pool = b_pool.v;
-    auto &heads = b_heads.v, &ordered = b_ordered.v;
-    left.assign(copies, copies + n_segs);
-    for (auto &c : left) c = std::max<int64_t>(1, c);
-    seen.assign(V, 0); owner.assign(V, -1);
-    heads.clear(); pool.clear();
-    palace::Borrowed<std::vector<int32_t>> b_live(ms.live);
-    auto &live = b_live.v;
-    res->off.assign(1, 0); res->verts.clear(); res->iter.clear(); res->open_at.clear(); res->kind.clear();
+    using namespace palace;
+    const int64_t S = n_segs, E = n_arcs;
     const int rounds = iterations + (aggressive ? 1 : 0);
-    for (int t = 0; t < rounds; t++) {
-        if (aggressive && t == rounds - 1) std::fill(left.begin(), left.end(), 1);
-        live.clear();
-        for (int32_t s = 0; s < n_segs; s++) {
-            const bool on = left[s] > 0;
-            alive[2 * s] = alive[2 * s + 1] = on;
-            if (on) { live.push_back(2 * s); live.push_back(2 * s + 1); }
+    PALACE_REQUIRE(rounds <= kMaxRounds, "too many iterations");
+    // output room: a segment is alive in at most min(iterations, copies) rounds (it pays at least one copy per round) plus the
+    // aggressive one; a round lists a live segment once, twice on a component that is its own conjugate
+    int64_t live_rounds = 0;
+    for (int64_t s = 0; s < S; s++) live_rounds += std::min<int64_t>(iterations, std::max<int64_t>(1, copies[s]));
+    if (aggressive) live_rounds += S;
+    const int64_t comp_cap = live_rounds, vert_cap = 2 * live_rounds;
+    const int iters = ctx->match_iters > 0 ? std::min(ctx->match_iters, kMaxIters) : 12;
+    const size_t dev_bytes = decomp_bytes(S, E, comp_cap, vert_cap, rounds, std::max(iters, 16));
+    int rc = ensure_workspace(ctx, dev_bytes);
+    if (rc) return rc;
+    DecompBufs b;
+    decomp_carve(b, static_cast<char *>(ctx->ws.ptr), S, E, comp_cap, vert_cap, rounds, std::max(iters, 16));
+    // staging in pinned memory so that every upload is a true asynchronous copy
+    const size_t e4 = (static_cast<size_t>(E) * 4 + 255) / 256 * 256, s8 = (static_cast<size_t>(S) * 8 + 255) / 256 * 256,
+                 s4 = (static_cast<size_t>(S) * 4 + 255) / 256 * 256;
+    rc = ensure_pinned(ctx, 2 * e4 + s8 + s4 + 512);
+    if (rc) return rc;
+    char *pin = static_cast<char *>(ctx->pin.ptr);
+    int32_t *p_src = reinterpret_cast<int32_t *>(pin), *p_dst = reinterpret_cast<int32_t *>(pin + e4);
+    int64_t *p_left = reinterpret_cast<int64_t *>(pin + 2 * e4);
+    int32_t *p_orig = reinterpret_cast<int32_t *>(pin + 2 * e4 + s8);
+    DecompState *p_st = reinterpret_cast<DecompState *>(pin + 2 * e4 + s8 + s4);
+    DecompState *p_back = p_st + 1;
+    std::copy(src, src + E, p_src); std::copy(dst, dst + E, p_dst);
+    for (int64_t s = 0; s < S; s++) p_left[s] = std::max<int64_t>(1, copies[s]);
+    std::copy(orig, orig + S, p_orig);
+    std::memset(p_st, 0, sizeof *p_st);
+    p_st->S = n_segs; p_st->V = 2 * n_segs; p_st->E = E;
+    hipStream_t st = ctx->stream;
+    auto upload = [&]() -> int {
+        PALACE_HIP_TRY(hipMemcpyAsync(b.st, p_st, sizeof *p_st, hipMemcpyHostToDevice, st));
+        if (E) {
+            PALACE_HIP_TRY(hipMemcpyAsync(b.src, p_src, static_cast<size_t>(E) * 4, hipMemcpyHostToDevice, st));
+            PALACE_HIP_TRY(hipMemcpyAsync(b.dst, p_dst, static_cast<size_t>(E) * 4, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(iota_keys_kernel, dim3(kDecompGrid), dim3(kDecompBlock), 0, st, b.khi, b.klo, E);
         }
-        if (live.empty()) continue;                           // nothing left this round (an `aggressive` round may follow)
-        // Late rounds often have no arc left between two live segments: then there is nothing to match (every live
-        // vertex is a path of its own) and no reason to visit the GPU.
-        bool arcs_alive = t == 0;
-        for (int64_t e = 0; e < E && !arcs_alive; e++) arcs_alive = alive[src[e]] && alive[dst[e]];
-        if (!arcs_alive) {
-            for (const int32_t v : live) { next[v] = -1; prev[v] = -1; narc[v] = -1; }
-        } else {
-        // One stream round trip per outer round: liveness up (pinned, stream-ordered), a batch of matching rounds,
-        // the `changed` word and the three link arrays (side by side) down; more batches only if it had not settled.
-            MatchArgs a{};
-            a.n_vertices = V; a.n_arcs = E; a.src = d_src; a.dst = d_dst;
-            a.out_off = d_oo; a.in_off = d_io; a.out_arcs = d_oa; a.in_arcs = d_ia;
-            a.alive = d_alive; a.next = d_next; a.prev = d_prev; a.next_arc = d_narc;
-            a.want_out = static_cast<int32_t *>(ctx->ws.ptr);
-            a.want_in = a.want_out + V;
-            a.changed = reinterpret_cast<unsigned int *>(ctx->d_small);
-            hipError_t e = hipMemcpyAsync(d_alive, alive, static_cast<size_t>(V), hipMemcpyHostToDevice, ctx->stream);
-            if (e != hipSuccess) { palace::set_error("decompose: %s", hipGetErrorString(e)); cleanup(); return PALACE_EHIP; }
-            hipLaunchKernelGGL(match_init_kernel, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, ctx->stream, a);
-            for (int done = 0;; done += kRoundsPerCheck) {
-                int rc = enqueue_rounds(ctx, a, kRoundsPerCheck);
-                if (rc) { cleanup(); return rc; }
-                e = hipMemcpyAsync(changed, ctx->d_small, 4, hipMemcpyDeviceToHost, ctx->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(next, d_next, 3 * v4, hipMemcpyDeviceToHost, ctx->stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-                if (e != hipSuccess) { palace::set_error("decompose: %s", hipGetErrorString(e)); cleanup(); return PALACE_EHIP; }
-                if (!*changed) break;
-                if (done > V + 2) { palace::set_error("decompose: no fixed point"); cleanup(); return PALACE_ESTATE; }
-            }
-        }
-        // Host read-off over the vertices that are alive this round only (after round 0 that is a small part of the
-        // graph); `seen` and `owner` entries are reset for exactly those vertices afterwards.
-        heads.clear();
-        pool.clear();
-        for (const int32_t v : live) {                        // open paths, one representative per conjugate pair
-            if (seen[v] || prev[v] >= 0) continue;
-            const int64_t b = static_cast<int64_t>(pool.size());
-            for (int32_t x = v; x >= 0; x = next[x]) { pool.push_back(x); seen[x] = 1; }
-            const int64_t e = static_cast<int64_t>(pool.size());
-            for (int64_t k = b; k < e; k++) seen[pool[k] ^ 1] = 1;
-            if ((pool[e - 1] ^ 1) < pool[b]) {
-                std::reverse(pool.begin() + b, pool.begin() + e);
-                for (int64_t k = b; k < e; k++) pool[k] ^= 1;
-            }
-            heads.push_back({pool[b], b, e, 0, 0});
-        }
-        for (const int32_t v : live) {                        // closed walks
-            if (seen[v]) continue;
-            const int64_t b = static_cast<int64_t>(pool.size());
-            for (int32_t x = v; !seen[x]; x = next[x]) { pool.push_back(x); seen[x] = 1; }
-            const int64_t e = static_cast<int64_t>(pool.size());
-            int32_t lo = pool[b], lo_conj = pool[b] ^ 1;
-            for (int64_t k = b; k < e; k++) { seen[pool[k] ^ 1] = 1; lo = std::min(lo, pool[k]); lo_conj = std::min(lo_conj, pool[k] ^ 1); }
-            if (lo_conj < lo) {
-                std::reverse(pool.begin() + b, pool.begin() + e);
-                for (int64_t k = b; k < e; k++) pool[k] ^= 1;
-            }
-            std::rotate(pool.begin() + b, std::min_element(pool.begin() + b, pool.begin() + e), pool.begin() + e);
-            int64_t worst = b;
-            for (int64_t k = b + 1; k < e; k++)
-                if (narc[pool[k]] > narc[pool[worst]]) worst = k;
-            heads.push_back({pool[b], b, e, 1, static_cast<int32_t>((worst + 1 - b) % (e - b))});
-        }
-        {   // emission order = ascending first vertex; first vertices are distinct, so place instead of sorting
-            // (`live` ascends, and a first vertex is a live vertex)
-            for (size_t c = 0; c < heads.size(); c++) owner[heads[c].first] = static_cast<int32_t>(c);
-            ordered.clear();
-            ordered.reserve(heads.size());
-            for (const int32_t v : live)
-                if (owner[v] >= 0) { ordered.push_back(heads[owner[v]]); owner[v] = -1; }
-            heads.swap(ordered);
-        }
-        for (size_t c = 0; c < heads.size(); c++)
-            for (int64_t k = heads[c].begin; k < heads[c].end; k++) owner[pool[k]] = static_cast<int32_t>(c);
-        const size_t v_at = res->verts.size(), c_at = res->kind.size();
-        res->verts.resize(v_at + pool.size());
-        res->off.resize(c_at + 1 + heads.size());
-        res->kind.resize(c_at + heads.size()); res->iter.resize(c_at + heads.size()); res->open_at.resize(c_at + heads.size());
-        int32_t *ev = res->verts.data() + v_at;
-        for (size_t c = 0; c < heads.size(); c++) {
-            const Head &h = heads[c];
-            // copies paid = min over segments of floor(left / uses); a segment is used twice when both
-            // of its orientations lie on this component
-            const int32_t me = static_cast<int32_t>(c);
-            int64_t pay = -1;
-            for (int64_t k = h.begin; k < h.end; k++) {
-                const int64_t uses = 1 + (owner[pool[k] ^ 1] == me);
-                const int64_t q = left[pool[k] >> 1] / uses;
-                pay = pay < 0 ? q : std::min(pay, q);
-            }
-            pay = std::max<int64_t>(1, pay);
-            for (int64_t k = h.begin; k < h.end; k++) { int64_t &l = left[pool[k] >> 1]; l = std::max<int64_t>(0, l - pay); }
-            ev = std::copy(pool.begin() + h.begin, pool.begin() + h.end, ev);
-            res->off[c_at + 1 + c] = static_cast<int64_t>(ev - res->verts.data());
-            res->kind[c_at + c] = h.cycle;
-            res->iter[c_at + c] = t;
-            res->open_at[c_at + c] = h.open;
-        }
-        for (const int32_t v : pool) { owner[v] = -1; }       // leave the scratch clean for the next round
-        for (const int32_t v : live) seen[v] = 0;
+        PALACE_HIP_TRY(hipMemcpyAsync(b.left, p_left, static_cast<size_t>(S) * 8, hipMemcpyHostToDevice, st));
+        PALACE_HIP_TRY(hipMemcpyAsync(b.orig, p_orig, static_cast<size_t>(S) * 4, hipMemcpyHostToDevice, st));
+        return PALACE_OK;
+    };
+    auto fail = [&](int code) { (void)hipStreamSynchronize(st); return code; };      // the pinned staging must outlive the copies
+    if ((rc = upload())) return fail(rc);
+    if ((rc = decomp_enqueue(ctx, b, rounds, aggressive, iters, true, comp_cap, vert_cap))) return fail(rc);
+    hipError_t e = hipMemcpyAsync(p_back, b.st, sizeof *p_back, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("decompose: %s", hipGetErrorString(e)); return fail(PALACE_EHIP); }
+    if (p_back->unsettled) {
+        // a round needed more matching iterations than were enqueued (long chains of ascending weights): once more, with the
+        // host watching every round's fixed point
+        if ((rc = upload())) return fail(rc);
+        if ((rc = decomp_run_checked(ctx, b, rounds, aggressive, true, comp_cap, vert_cap, 2 * E + 64))) return fail(rc);
+        e = hipMemcpyAsync(p_back, b.st, sizeof *p_back, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("decompose: %s", hipGetErrorString(e)); return fail(PALACE_EHIP); }
     }
-    cleanup();
-#undef TRY_OR_CLEAN
+    if (p_back->overflow || p_back->n_comp > comp_cap || p_back->n_vert > vert_cap) {
+        set_error("decompose: component arrays too small (%lld components, %lld vertices)", (long long)p_back->n_comp, (long long)p_back->n_vert);
+        return PALACE_ESTATE;
+    }
+    const size_t nc = static_cast<size_t>(p_back->n_comp), nv = static_cast<size_t>(p_back->n_vert);
+    res->off.resize(nc + 1); res->verts.resize(nv); res->iter.resize(nc); res->open_at.resize(nc); res->kind.resize(nc);
+    e = hipMemcpyAsync(res->off.data(), b.o_off, (nc + 1) * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && nv) e = hipMemcpyAsync(res->verts.data(), b.o_verts, nv * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && nc) e = hipMemcpyAsync(res->iter.data(), b.o_iter, nc * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && nc) e = hipMemcpyAsync(res->open_at.data(), b.o_open, nc * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && nc) e = hipMemcpyAsync(res->kind.data(), b.o_kind, nc, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("decompose: %s", hipGetErrorString(e)); return fail(PALACE_EHIP); }
     return PALACE_OK;
 }
 
@@ -516,6 +395,19 @@ int palace_match_arcs_from_edges(const int32_t *cn, int32_t n_segs, const palace
     return PALACE_OK;
 }
 
+int palace_match_set_option(palace_ctx *ctx, const char *name, int64_t value)
+{
+    PALACE_REQUIRE(ctx && name, "null argument");
+    if (!std::strcmp(name, "iters_per_round")) {
+        PALACE_REQUIRE(value >= 0 && value <= palace::kMaxIters, "iters_per_round out of range");
+        ctx->match_iters = static_cast<int>(value);
+    } else {
+        palace::set_error("palace_match_set_option: unknown option '%s'", name);
+        return PALACE_EINVAL;
+    }
+    return PALACE_OK;
+}
+
 int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
                            const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
                            palace_match_result **out)
@@ -578,10 +470,9 @@ int palace_match_decompose_ex(palace_ctx *ctx, int32_t n_segs, const int64_t *co
         sdst[e] = 2 * sub_rank(dst[e] >> 1) + (dst[e] & 1);
     }
     sub.off.assign(1, 0); sub.verts.clear(); sub.iter.clear(); sub.open_at.clear(); sub.kind.clear();
-    int rc = n_sub ? decompose_core(ctx, n_sub, sub_copies.data(), n_arcs, ssrc.data(), sdst.data(), iterations, aggressive, ms, &sub)
-                   : PALACE_OK;
+    int rc = n_sub ? decompose_core(ctx, n_sub, sub_copies.data(), old_id.data(), n_arcs, ssrc.data(), sdst.data(), iterations, aggressive, &sub)
+                   : PALACE_OK;                            // (vertices come back as ids of the caller's graph)
     if (rc) return rc;
-    for (int32_t &v : sub.verts) v = 2 * old_id[v >> 1] + (v & 1);
     const int64_t n_sub_comp = static_cast<int64_t>(sub.kind.size());
     const int last_round = iterations + (aggressive ? 1 : 0) - 1;
     const int64_t n_bare = static_cast<int64_t>(n_segs) - n_sub;

@@ -81,31 +81,18 @@ def test_bench_shaped_sample_equals_oracle(tmp_path):
     assert want.count("JUNC") > 50
 
 
-@pytest.mark.parametrize("n,aggressive", [(30000, False), (300000, False), (300000, True)])
-def test_bench_matching_stage_equals_oracle(tmp_path, n, aggressive):
-    """bench.py's glue (graph_to_arcs) + palace_match_decompose, formatted the way matching_main.cpp formats,
-    equal the oracle's linear/cycle files for the same SEG/JUNC text.  (n = 300000: above 2^17 segments the bare
-    segments are merged back by several threads.)"""
-    import bench
-    from oracle import binding as orc
-    from palace_amd import capi
-
-    rng = np.random.Generator(np.random.PCG64(4))
-    names = [f"EDGE_{i + 1}_length_{int(rng.integers(60, 5000))}_cov_{rng.random() * 20:.4f}" for i in range(n)]
-    cn = rng.integers(0, 4, size=n).astype(np.int32)
-    e = np.zeros(40000, dtype=capi.EDGE_DTYPE)
-    e["left"] = rng.integers(0, n, len(e)); e["right"] = rng.integers(0, n, len(e))
-    e["oL"] = rng.integers(0, 2, len(e)); e["oR"] = rng.integers(0, 2, len(e))
-    e["counts"] = rng.integers(0, 6, size=(len(e), 4))
-    ring = np.arange(3000)                                    # planted heavy 10-rings so that cycles are certain
-    e["left"][:3000] = ring; e["right"][:3000] = (ring // 10) * 10 + (ring + 1) % 10
-    e["oL"][:3000] = 0; e["oR"][:3000] = 0; e["counts"][:3000] = 50
-    # canonical, unique edge keys as generateGraph would hand them over
+def _unique_edges(e):
+    """canonical, unique edge keys as generateGraph would hand them over"""
     key = (e["left"].astype(np.int64) << 34) | (e["right"].astype(np.int64) << 2) | (e["oL"] << 1) | e["oR"]
-    e = e[np.unique(key, return_index=True)[1]]
-    copies, src, dst, w = bench.graph_to_arcs(cn, n, e)
-    with capi.Ctx(0) as ctx:
-        off, verts, kind, it, open_at = capi.match_decompose(ctx, copies, src, dst, 10, aggressive)
+    return e[np.unique(key, return_index=True)[1]]
+
+
+def _decompose_as_text(ctx, names, cn, e, aggressive):
+    """bench.py's glue (graph_to_arcs) + palace_match_decompose, formatted the way matching_main.cpp formats"""
+    import bench
+    from palace_amd import capi
+    copies, src, dst, w = bench.graph_to_arcs(cn, len(names), e)
+    off, verts, kind, it, open_at = capi.match_decompose(ctx, copies, src, dst, 10, aggressive)
     tok = lambda v: names[v >> 1] + "+-"[v & 1]
     lin, cyc, seen_l, seen_c = [], [], set(), set()
     for c in range(len(kind)):
@@ -118,6 +105,11 @@ def test_bench_matching_stage_equals_oracle(tmp_path, n, aggressive):
                 seen_l.add(body); lin.append(body)
         elif body not in seen_c:
             seen_c.add(body); cyc.append(f"iter {it[c]}\n" + body)
+    return "".join(lin).encode(), "".join(cyc).encode()
+
+
+def _oracle_text(tmp_path, names, cn, e, aggressive):
+    from oracle import binding as orc
     g = str(tmp_path / "g.txt")
     tot = e["counts"].sum(axis=1)
     with open(g, "w") as f:
@@ -125,10 +117,64 @@ def test_bench_matching_stage_equals_oracle(tmp_path, n, aggressive):
         f.write("".join(f"JUNC {names[l]} {'+-'[a]} {names[r]} {'+-'[b]} {t} 0\n"
                         for l, r, a, b, t in zip(e["left"].tolist(), e["right"].tolist(), e["oL"].tolist(), e["oR"].tolist(), tot.tolist())
                         if t >= 5))
-    want_lin, want_cyc = orc.match_run(g, None, 10, aggressive=aggressive, cap=256 * 1024 * 1024)
-    assert "".join(lin).encode() == want_lin
-    assert "".join(cyc).encode() == want_cyc
+    return orc.match_run(g, None, 10, aggressive=aggressive, cap=256 * 1024 * 1024)
+
+
+@pytest.mark.parametrize("n,aggressive", [(30000, False), (300000, False), (300000, True)])
+def test_bench_matching_stage_equals_oracle(tmp_path, n, aggressive):
+    """bench.py's glue (graph_to_arcs) + palace_match_decompose equal the oracle's linear/cycle files for the same SEG/JUNC
+    text.  (n = 300000: above 2^17 segments the bare segments are merged back by several threads.)"""
+    from palace_amd import capi
+
+    rng = np.random.Generator(np.random.PCG64(4))
+    names = [f"EDGE_{i + 1}_length_{int(rng.integers(60, 5000))}_cov_{rng.random() * 20:.4f}" for i in range(n)]
+    cn = rng.integers(0, 4, size=n).astype(np.int32)
+    e = np.zeros(40000, dtype=capi.EDGE_DTYPE)
+    e["left"] = rng.integers(0, n, len(e)); e["right"] = rng.integers(0, n, len(e))
+    e["oL"] = rng.integers(0, 2, len(e)); e["oR"] = rng.integers(0, 2, len(e))
+    e["counts"] = rng.integers(0, 6, size=(len(e), 4))
+    ring = np.arange(3000)                                    # planted heavy 10-rings so that cycles are certain
+    e["left"][:3000] = ring; e["right"][:3000] = (ring // 10) * 10 + (ring + 1) % 10
+    e["oL"][:3000] = 0; e["oR"][:3000] = 0; e["counts"][:3000] = 50
+    e = _unique_edges(e)
+    with capi.Ctx(0) as ctx:
+        lin, cyc = _decompose_as_text(ctx, names, cn, e, aggressive)
+    want_lin, want_cyc = _oracle_text(tmp_path, names, cn, e, aggressive)
+    assert lin == want_lin
+    assert cyc == want_cyc
     assert want_cyc.count(b"iter") > 0
+
+
+@pytest.mark.parametrize("aggressive", [False, True])
+def test_decomposition_with_the_host_checking_fixed_points(tmp_path, aggressive):
+    """The decomposition enqueues a fixed number of matching iterations per round and only looks at the end; a round that
+    needed more is redone with the host watching every fixed point.  Forced here two ways: a zig-zag of ascending weights
+    (a_i -> b_i < a_(i+1) -> b_i < a_(i+1) -> b_(i+1) ...: one arc per iteration can be taken, hundreds of iterations), and
+    iters_per_round = 1 on a random graph.  Both must equal the oracle and the default setting."""
+    from palace_amd import capi
+    rng = np.random.Generator(np.random.PCG64(21))
+    k = 400
+    n = 2 * k + 2000
+    names = [f"EDGE_{i + 1}_length_{int(rng.integers(60, 5000))}_cov_{rng.random() * 20:.4f}" for i in range(n)]
+    cn = rng.integers(0, 4, size=n).astype(np.int32)
+    zig = np.zeros(2 * k - 1, dtype=capi.EDGE_DTYPE)          # a_i = segment i, b_i = segment k + i
+    for j in range(2 * k - 1):
+        i = j // 2
+        zig[j]["left"] = i + (j & 1); zig[j]["right"] = k + i
+        zig[j]["counts"] = (5 + j, 0, 0, 0)
+    rnd = np.zeros(3000, dtype=capi.EDGE_DTYPE)
+    rnd["left"] = rng.integers(2 * k, n, len(rnd)); rnd["right"] = rng.integers(2 * k, n, len(rnd))
+    rnd["oL"] = rng.integers(0, 2, len(rnd)); rnd["oR"] = rng.integers(0, 2, len(rnd))
+    rnd["counts"] = rng.integers(0, 6, size=(len(rnd), 4))
+    rnd = _unique_edges(rnd)
+    e = np.concatenate([zig, rnd])
+    want = _oracle_text(tmp_path, names, cn, e, aggressive)
+    with capi.Ctx(0) as ctx:
+        assert _decompose_as_text(ctx, names, cn, e, aggressive) == want           # default: 12 iterations do not settle the zig-zag
+        ctx.match_set_option("iters_per_round", 1)
+        assert _decompose_as_text(ctx, names, cn, rnd, aggressive) == _oracle_text(tmp_path, names, cn, rnd, aggressive)
+        ctx.match_set_option("iters_per_round", 64)
+        assert _decompose_as_text(ctx, names, cn, e, aggressive) == want
 
 
 def test_compact_decomposition_equals_full():
@@ -141,8 +187,7 @@ def test_compact_decomposition_equals_full():
     e["left"] = rng.integers(0, n, len(e)); e["right"] = rng.integers(0, n, len(e))
     e["oL"] = rng.integers(0, 2, len(e)); e["oR"] = rng.integers(0, 2, len(e))
     e["counts"] = rng.integers(0, 6, size=(len(e), 4))
-    key = (e["left"].astype(np.int64) << 34) | (e["right"].astype(np.int64) << 2) | (e["oL"] << 1) | e["oR"]
-    e = e[np.unique(key, return_index=True)[1]]
+    e = _unique_edges(e)
     import bench
     copies, src, dst, w = bench.graph_to_arcs(cn, n, e)
     for aggressive in (False, True):
