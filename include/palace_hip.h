@@ -229,6 +229,14 @@ int palace_graph_classify(palace_ctx *ctx, const palace_bam_cols *cols, const pa
                           int64_t ord_base, uint64_t *d_consumed, palace_graph_cand *d_cands,
                           int64_t cand_cap, int64_t *n_cands_out);
 
+/* The same, also returning how many of the candidates fall into the exp() underflow zone (cls == 2): the two counters
+ * come back in one copy behind one wait, and palace_graph_resolve_ex needs no round trip of its own to learn the second. */
+int palace_graph_classify_ex(palace_ctx *ctx, const palace_bam_cols *cols, const palace_sa_item *d_sa,
+                             int32_t n_targets, const int32_t *d_tlen, const int32_t *d_trank,
+                             const uint64_t *d_fastg, int64_t n_fastg, const palace_graph_params *prm,
+                             int64_t ord_base, uint64_t *d_consumed, palace_graph_cand *d_cands,
+                             int64_t cand_cap, int64_t *n_cands_out, int64_t *n_border_out);
+
 /* Second half: decide host-side borderline scores, apply the order-dependent rules
  * (hasSupplementEvidence gating :881-888, processedPairedReads "first in file order wins" and its
  * mate-contig depth quirk :890-893, :938), aggregate per canonical edge (:866-872, :1002-1008).
@@ -236,6 +244,14 @@ int palace_graph_classify(palace_ctx *ctx, const palace_bam_cols *cols, const pa
 int palace_graph_resolve(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_cands,
                          int64_t n_records_total, const palace_graph_params *prm, uint64_t *d_consumed,
                          palace_graph_edge *d_edges, int64_t edge_cap, int64_t *n_edges_out);
+
+/* The same without the host in the loop.  n_border: number of candidates with cls == 2 (from palace_graph_classify_ex; summed
+ * over the ranks whose candidates were gathered), 0 = none, so nothing is copied to the host; < 0 = unknown, look.
+ * d_n_edges (device, 8 bytes, optional) receives the edge count in stream order; n_edges_out may be NULL, and then the call
+ * only enqueues: no synchronisation (a count above edge_cap is then the reader's to detect: edges beyond it are dropped). */
+int palace_graph_resolve_ex(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_cands, int64_t n_border,
+                            int64_t n_records_total, const palace_graph_params *prm, uint64_t *d_consumed,
+                            palace_graph_edge *d_edges, int64_t edge_cap, int64_t *d_n_edges, int64_t *n_edges_out);
 
 /* G6 epilogue numbers (generate_graph.cpp:1029-1031): depth = consumed / max(1, len) and
  * cn = (int)floor(depth / avg_depth + 0.5) (0 when avg_depth <= 0), per target, in IEEE double. */
@@ -323,6 +339,56 @@ const uint8_t *palace_match_result_kind(const palace_match_result *r);
 const int32_t *palace_match_result_iter(const palace_match_result *r);
 const int32_t *palace_match_result_open_at(const palace_match_result *r);
 void palace_match_result_free(palace_match_result *r);
+
+/* ---- stage 04 resident in HBM: filter_graph.py + matching without the text files in between ----------------------- */
+
+/* What the pipeline does between generateGraph's numbers and `all_result` (palace:566-600) is a selection on the graph
+ * (share/palace/scripts/filter_graph.py) and `matching` on what the selection leaves.  For a sample whose edges are already
+ * in HBM (palace_graph_resolve) both run on the device; the host formats.  Per-sample inputs, parsed once like the BAM
+ * columns (host arrays; create copies them to the device): */
+typedef struct {
+    int32_t n_segs;            /* contigs = BAM targets */
+    int32_t min_count;         /* MIN_COUNT (generate_graph.cpp:40): a JUNC line exists for an edge whose counters sum to >= it (:1061) */
+    const uint8_t *seed;       /* per contig: bit 0 in blast_segs (filter_graph.py:66-94), bit 1 in gene_res (:99-102), bit 2 score > threshold (:104-112) */
+    const int32_t *tlen;       /* target lengths: a contig has a SEG line iff its length is > 0 (generate_graph.cpp:1019-1050) */
+    const int32_t *rank;       /* dense rank of the names in byte order = order of the SEG lines of `_graph.txt` */
+    const int32_t *name_len;   /* the length token of each name (get_edge_len, filter_graph.py:50-52) */
+    int64_t n_paths;           /* lines of contigs.paths that are not NODE headers */
+    const int64_t *path_off;   /* n_paths + 1 offsets into path_tok */
+    const int32_t *path_tok;   /* 2 * contig + (orientation == '-'); -1 = an id no contig has */
+} palace_stage04_inputs;
+
+typedef struct palace_stage04 palace_stage04;
+int palace_stage04_create(palace_ctx *ctx, const palace_stage04_inputs *in, palace_stage04 **out);
+int palace_stage04_destroy(palace_ctx *ctx, palace_stage04 *s);
+
+/* B2 in memory (filter_graph.py:201-264): which junctions and which SEG lines `_filtered_graph.txt` holds.  d_edges and
+ * d_n_edges (device, 8 bytes) are what palace_graph_resolve_ex leaves; edge_bound is a bound on the count the host knows
+ * (the number of candidates): it sizes the tables.  Only enqueues.  Per edge a flag byte: 1 = the JUNC line exists,
+ * 2 = kept by pass 2 (:223-233), 4 = kept by pass 3 (:237-245); per contig: 1 = its SEG line is selected (seed, or end
+ * of a kept junction), 2 = rescued through contigs.paths only (:126-151, written with the ` 0 1.0 0` tail), 4 = core seed.
+ * The file lists the selected SEG lines, then the rescued ones, then the pass-2 junctions and the pass-3 junctions that are
+ * not pass-2 ones, each group in `_graph.txt` order. */
+int palace_stage04_filter(palace_ctx *ctx, palace_stage04 *s, const palace_graph_edge *d_edges, const int64_t *d_n_edges,
+                          int64_t edge_bound);
+/* the flags on the host (waits for the stream); n_edges <= edge_bound entries of the edge flags */
+int palace_stage04_flags(palace_ctx *ctx, palace_stage04 *s, uint8_t *h_seg_flags, uint8_t *h_edge_flags, int64_t n_edges);
+/* counts[8] = edges, JUNC lines, junctions kept by pass 2, further junctions kept by pass 3, selected SEG lines, rescued SEG
+ * lines, merged arcs (-1 before palace_stage04_match), segments of the filtered graph (waits for the stream); also reports
+ * what the reference script dies on: a contigs.paths id that names no contig, a rescued contig without SEG line */
+int palace_stage04_counts(palace_ctx *ctx, palace_stage04 *s, int64_t counts[8]);
+
+/* M1 on the filtered graph: `matching -g <filtered graph> -i <iterations> [-l contigs.paths] [--aggressive]` (palace:587-590)
+ * on the device.  Segments are numbered as the filtered file lists them; copies = max(1, d_cn[contig]); arcs = kept junctions
+ * (weight n1 + n2) + conjugates, and with use_paths the path-backed arcs.  Only enqueues (at most 10 iterations +
+ * aggressive per filter call's reservation). */
+int palace_stage04_match(palace_ctx *ctx, palace_stage04 *s, const palace_graph_edge *d_edges, const int32_t *d_cn,
+                         int32_t iterations, int32_t aggressive, int32_t use_paths);
+/* Waits and hands out the result in the compact form of palace_match_decompose_ex (vertices 2 * segment + orientation,
+ * segments = ids of the filtered graph; bare segments as bits), owned by `s` (valid until the next match call or destroy;
+ * palace_match_result_free on it does nothing), and contig_of[filtered segment] -> contig (n_segs_filtered entries). */
+int palace_stage04_result(palace_ctx *ctx, palace_stage04 *s, palace_match_result **out, const int32_t **contig_of_out,
+                          int64_t *n_segs_filtered_out);
 
 #ifdef __cplusplus
 }

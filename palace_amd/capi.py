@@ -46,6 +46,12 @@ class BamCols(C.Structure):
                                       "flag", "mapq", "qkey", "sa_off")]
 
 
+class Stage04Inputs(C.Structure):
+    """palace_stage04_inputs"""
+    _fields_ = [("n_segs", C.c_int32), ("min_count", C.c_int32), ("seed", C.c_void_p), ("tlen", C.c_void_p), ("rank", C.c_void_p),
+                ("name_len", C.c_void_p), ("n_paths", C.c_int64), ("path_off", C.c_void_p), ("path_tok", C.c_void_p)]
+
+
 SA_ITEM_DTYPE = np.dtype([(k, np.int32) for k in ("tid2", "pos2", "mapq2", "nm2", "clip_s2", "clip_e2", "len2", "rev2")])
 CAND_DTYPE = np.dtype([("ord", np.int64), ("qkey", np.uint64), ("left", np.int32), ("right", np.int32),
                        ("mtid", np.int32), ("ref_len", np.int32), ("dL", np.int32), ("dR", np.int32),
@@ -114,6 +120,18 @@ _SIGS = {
                                   C.c_int32, C.c_int32, C.POINTER(C.c_void_p)],
     "palace_graph_resolve": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(GraphParams), C.c_void_p,
                              C.c_void_p, C.c_int64, C.POINTER(C.c_int64)],
+    "palace_graph_classify_ex": [C.c_void_p, C.POINTER(BamCols), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int64, C.POINTER(GraphParams), C.c_int64, C.c_void_p, C.c_void_p,
+                                 C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+    "palace_graph_resolve_ex": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(GraphParams), C.c_void_p,
+                                C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)],
+    "palace_stage04_create": [C.c_void_p, C.POINTER(Stage04Inputs), C.POINTER(C.c_void_p)],
+    "palace_stage04_destroy": [C.c_void_p, C.c_void_p],
+    "palace_stage04_filter": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64],
+    "palace_stage04_flags": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64],
+    "palace_stage04_counts": [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],
+    "palace_stage04_match": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32],
+    "palace_stage04_result": [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)],
 }
 
 
@@ -389,6 +407,59 @@ def match_decompose(ctx: "Ctx", copies: np.ndarray, src: np.ndarray, dst: np.nda
     """palace_match_decompose -> (offsets, verts, kind, iter, open_at) as numpy copies."""
     with match_decompose_views(ctx, copies, src, dst, iterations, aggressive) as r:
         return r.off.copy(), r.verts.copy(), r.kind.copy(), r.iter.copy(), r.open_at.copy()
+
+
+class Stage04:
+    """The resident stage-04 object (palace_stage04_*): filter_graph.py's selection + matching on the device."""
+    COUNT_NAMES = ("edges", "juncs", "kept_pass2", "kept_pass3_more", "segs_selected", "segs_rescued", "arcs", "segs_filtered")
+
+    def __init__(self, ctx: "Ctx", seed, tlen, rank, name_len, path_off, path_tok, min_count: int = 5):
+        self.ctx = ctx
+        self._keep = [np.ascontiguousarray(seed, np.uint8), np.ascontiguousarray(tlen, np.int32), np.ascontiguousarray(rank, np.int32),
+                      np.ascontiguousarray(name_len, np.int32), np.ascontiguousarray(path_off, np.int64),
+                      np.ascontiguousarray(path_tok, np.int32)]
+        sd, tl, rk, nl, po, pt = self._keep
+        assert len(sd) == len(tl) == len(rk) == len(nl) and len(po) >= 1
+        inp = Stage04Inputs(len(sd), min_count, sd.ctypes.data, tl.ctypes.data, rk.ctypes.data, nl.ctypes.data, len(po) - 1,
+                            po.ctypes.data, pt.ctypes.data if len(pt) else None)
+        h = C.c_void_p()
+        _check(lib().palace_stage04_create(ctx.h, C.byref(inp), C.byref(h)), "palace_stage04_create")
+        self.h, self.n_segs = h, len(sd)
+
+    def filter(self, d_edges_ptr: int, d_n_edges_ptr: int, edge_bound: int):
+        _check(lib().palace_stage04_filter(self.ctx.h, self.h, d_edges_ptr, d_n_edges_ptr, edge_bound), "palace_stage04_filter")
+
+    def counts(self) -> dict:
+        out = (C.c_int64 * 8)()
+        _check(lib().palace_stage04_counts(self.ctx.h, self.h, out), "palace_stage04_counts")
+        return dict(zip(self.COUNT_NAMES, (int(v) for v in out)))
+
+    def flags(self, n_edges: int):
+        seg = np.zeros(self.n_segs, np.uint8)
+        edge = np.zeros(n_edges, np.uint8)
+        _check(lib().palace_stage04_flags(self.ctx.h, self.h, seg.ctypes.data, edge.ctypes.data if n_edges else None, n_edges),
+               "palace_stage04_flags")
+        return seg, edge
+
+    def match(self, d_edges_ptr: int, d_cn_ptr: int, iterations: int = 10, aggressive: bool = False, use_paths: bool = True):
+        _check(lib().palace_stage04_match(self.ctx.h, self.h, d_edges_ptr, d_cn_ptr, iterations, int(aggressive), int(use_paths)),
+               "palace_stage04_match")
+
+    def result(self):
+        """-> (MatchResult view with .bare / .n_bare, contig_of array view); valid until the next match() / close()"""
+        res, cof, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        _check(lib().palace_stage04_result(self.ctx.h, self.h, C.byref(res), C.byref(cof), C.byref(n)), "palace_stage04_result")
+        r = MatchResult(res)
+        r.n_bare = int(lib().palace_match_result_bare_count(res))
+        words = (n.value + 63) // 64
+        r.bare = np.ctypeslib.as_array(lib().palace_match_result_bare(res), shape=(max(1, words),))[:words]
+        contig_of = np.ctypeslib.as_array(C.cast(cof, C.POINTER(C.c_int32)), shape=(max(1, n.value),))[: n.value]
+        return r, contig_of
+
+    def close(self):
+        if self.h:
+            lib().palace_stage04_destroy(self.ctx.h, self.h)
+            self.h = None
 
 
 def window_minimums(hit_ratio: float, perfect_ratio: float):

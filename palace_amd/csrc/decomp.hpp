@@ -4,6 +4,19 @@
 #pragma once
 #include "common.hpp"
 
+// the result object of the C ABI (palace_match_result_* accessors, match.hip); the resident stage-04 object (filter.hip) hands
+// out one whose arrays it owns itself
+struct palace_match_result {
+    int64_t n = 0;
+    int64_t *off = nullptr;
+    int32_t *verts = nullptr, *iter = nullptr, *open_at = nullptr;
+    uint8_t *kind = nullptr;
+    uint64_t *bare = nullptr;            // compact results: bit s set = segment s has no arc (bare path of round 0 [+ the aggressive round])
+    int64_t n_bare = 0;
+    bool borrowed = false;               // the arrays (and this object) belong to somebody else: nothing to give back
+    ~palace_match_result();              // match.hip (block pool)
+};
+
 namespace palace {
 
 constexpr int kDecompGrid = 256;           // every kernel of the decomposition is grid-stride over a count it reads from device

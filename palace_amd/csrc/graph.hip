@@ -99,6 +99,7 @@ __device__ __forceinline__ void emit(const GraphArgs &a, const palace_graph_cand
 {
     unsigned long long i = atomicAdd(a.n_cands, 1ull);
     if (static_cast<int64_t>(i) < a.cap) a.cands[i] = c;
+    if (c.found && c.cls == 2) atomicAdd(a.n_cands + 1, 1ull);      // exp() underflow zone: the host decides these (rare)
 }
 
 __global__ __launch_bounds__(256) void graph_classify_kernel(GraphArgs a)
@@ -252,12 +253,6 @@ struct ResolveArgs {
     unsigned long long *counters;   // [0] edges, [1] border
 };
 
-__global__ void count_border_kernel(ResolveArgs a)
-{
-    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < a.n && a.cands[i].found && a.cands[i].cls == 2) atomicAdd(&a.counters[1], 1ull);
-}
-
 __device__ __forceinline__ void count_edge(const ResolveArgs &a, const palace_graph_cand &c)
 {
     uint64_t s = slot_for(a.e_keys, a.e_mask, edge_key(c));
@@ -353,9 +348,20 @@ int palace_graph_classify(palace_ctx *ctx, const palace_bam_cols *cols, const pa
                           int64_t ord_base, uint64_t *d_consumed, palace_graph_cand *d_cands,
                           int64_t cand_cap, int64_t *n_cands_out)
 {
+    return palace_graph_classify_ex(ctx, cols, d_sa, n_targets, d_tlen, d_trank, d_fastg, n_fastg, prm, ord_base, d_consumed,
+                                    d_cands, cand_cap, n_cands_out, nullptr);
+}
+
+int palace_graph_classify_ex(palace_ctx *ctx, const palace_bam_cols *cols, const palace_sa_item *d_sa,
+                             int32_t n_targets, const int32_t *d_tlen, const int32_t *d_trank,
+                             const uint64_t *d_fastg, int64_t n_fastg, const palace_graph_params *prm,
+                             int64_t ord_base, uint64_t *d_consumed, palace_graph_cand *d_cands,
+                             int64_t cand_cap, int64_t *n_cands_out, int64_t *n_border_out)
+{
     PALACE_REQUIRE(ctx && cols && prm && n_cands_out, "null argument");
     PALACE_REQUIRE(cols->n >= 0 && n_targets >= 0 && n_fastg >= 0 && cand_cap >= 0, "negative size");
     *n_cands_out = 0;
+    if (n_border_out) *n_border_out = 0;
     if (cols->n == 0) return PALACE_OK;
     PALACE_REQUIRE(cols->tid && cols->pos && cols->mtid && cols->mpos && cols->nm && cols->ref_len &&
                        cols->read_len && cols->clip_s && cols->clip_e && cols->flag && cols->mapq &&
@@ -363,6 +369,8 @@ int palace_graph_classify(palace_ctx *ctx, const palace_bam_cols *cols, const pa
                    "null device pointer");
     PALACE_REQUIRE(n_fastg == 0 || d_fastg, "null FASTG key array");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_pinned(ctx, 256);
+    if (rc) return rc;
     GraphArgs a{};
     a.c = *cols; a.sa = d_sa; a.n_targets = n_targets; a.tlen = d_tlen; a.trank = d_trank;
     a.fastg = d_fastg; a.n_fastg = n_fastg; a.p = *prm; a.ord_base = ord_base;
@@ -371,17 +379,21 @@ int palace_graph_classify(palace_ctx *ctx, const palace_bam_cols *cols, const pa
     a.consumed = reinterpret_cast<unsigned long long *>(d_consumed);
     a.cands = d_cands; a.cap = cand_cap;
     a.n_cands = reinterpret_cast<unsigned long long *>(ctx->d_small);
-    PALACE_HIP_TRY(hipMemsetAsync(ctx->d_small, 0, 8, ctx->stream));
+    PALACE_HIP_TRY(hipMemsetAsync(ctx->d_small, 0, 16, ctx->stream));
     int64_t blocks = (cols->n + 255) / 256;
     PALACE_REQUIRE(blocks < (1ll << 31), "too many records for one launch");
     hipLaunchKernelGGL(graph_classify_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, a);
     PALACE_HIP_TRY(hipGetLastError());
-    unsigned long long n = 0;
-    PALACE_HIP_TRY(hipMemcpyAsync(&n, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+    // both counters come back in one copy into pinned memory, behind one wait (no second round trip in resolve)
+    unsigned long long *n = static_cast<unsigned long long *>(ctx->pin.ptr);
+    PALACE_HIP_TRY(hipMemcpyAsync(n, ctx->d_small, 16, hipMemcpyDeviceToHost, ctx->stream));
     PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    *n_cands_out = static_cast<int64_t>(n);
-    if (static_cast<int64_t>(n) > cand_cap) {
-        set_error("palace_graph_classify: %llu candidates exceed capacity %lld", n, (long long)cand_cap);
+    *n_cands_out = static_cast<int64_t>(n[0]);
+    if (n_border_out) *n_border_out = static_cast<int64_t>(n[1]);
+    ctx->graph_border = static_cast<int64_t>(n[1]);
+    ctx->graph_border_cands = d_cands;
+    if (static_cast<int64_t>(n[0]) > cand_cap) {
+        set_error("palace_graph_classify: %llu candidates exceed capacity %lld", n[0], (long long)cand_cap);
         return PALACE_EINVAL;
     }
     return PALACE_OK;
@@ -404,10 +416,24 @@ int palace_graph_resolve(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_
                          int64_t n_records_total, const palace_graph_params *prm, uint64_t *d_consumed,
                          palace_graph_edge *d_edges, int64_t edge_cap, int64_t *n_edges_out)
 {
-    PALACE_REQUIRE(ctx && prm && n_edges_out, "null argument");
+    PALACE_REQUIRE(n_edges_out, "null argument");
+    // candidates of this very classify call carry its border count; anything else (gathered from several ranks) is counted
+    const int64_t n_border = (ctx && d_cands == ctx->graph_border_cands) ? ctx->graph_border : -1;
+    return palace_graph_resolve_ex(ctx, d_cands, n_cands, n_border, n_records_total, prm, d_consumed, d_edges, edge_cap, nullptr,
+                                   n_edges_out);
+}
+
+int palace_graph_resolve_ex(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_cands, int64_t n_border,
+                            int64_t n_records_total, const palace_graph_params *prm, uint64_t *d_consumed,
+                            palace_graph_edge *d_edges, int64_t edge_cap, int64_t *d_n_edges, int64_t *n_edges_out)
+{
+    PALACE_REQUIRE(ctx && prm, "null argument");
     PALACE_REQUIRE(n_cands >= 0 && n_records_total >= 0 && edge_cap >= 0, "negative size");
-    *n_edges_out = 0;
-    if (n_cands == 0) return PALACE_OK;
+    if (n_edges_out) *n_edges_out = 0;
+    if (n_cands == 0) {
+        if (d_n_edges) PALACE_HIP_TRY(hipMemsetAsync(d_n_edges, 0, 8, ctx->stream));
+        return PALACE_OK;
+    }
     PALACE_REQUIRE(d_cands && d_consumed && (d_edges || edge_cap == 0), "null device pointer");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     const uint64_t qcap = pow2_at_least(2 * static_cast<uint64_t>(n_cands));
@@ -432,17 +458,17 @@ int palace_graph_resolve(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_
     PALACE_HIP_TRY(hipMemsetAsync(a.q_keys, 0xff, up256(qcap * 8) * 3, ctx->stream));   // keys, mins, edge keys
     PALACE_HIP_TRY(hipMemsetAsync(a.e_counts, 0, up256(qcap * 16), ctx->stream));
     const unsigned blocks = static_cast<unsigned>((n_cands + 255) / 256);
-    hipLaunchKernelGGL(count_border_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
-    PALACE_HIP_TRY(hipGetLastError());
-    unsigned long long cnt[2] = {0, 0};
-    PALACE_HIP_TRY(hipMemcpyAsync(cnt, ctx->d_small, 16, hipMemcpyDeviceToHost, ctx->stream));
-    PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (cnt[1] > 0) {       // exp() underflow zone: decide with the host's libm (:432-461)
+    if (n_border != 0) {    // exp() underflow zone: decide with the host's libm (:432-461).  n_border < 0: not known, look
         std::vector<palace_graph_cand> h(static_cast<size_t>(n_cands));
-        PALACE_HIP_TRY(hipMemcpy(h.data(), d_cands, h.size() * sizeof(palace_graph_cand), hipMemcpyDeviceToHost));
+        PALACE_HIP_TRY(hipMemcpyAsync(h.data(), d_cands, h.size() * sizeof(palace_graph_cand), hipMemcpyDeviceToHost, ctx->stream));
+        PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        bool any = false;
         for (auto &c : h)
-            if (c.found && c.cls == 2) c.cls = host_score_positive(c, *prm) ? 1 : 0;
-        PALACE_HIP_TRY(hipMemcpy(d_cands, h.data(), h.size() * sizeof(palace_graph_cand), hipMemcpyHostToDevice));
+            if (c.found && c.cls == 2) { c.cls = host_score_positive(c, *prm) ? 1 : 0; any = true; }
+        if (any) {
+            PALACE_HIP_TRY(hipMemcpyAsync(d_cands, h.data(), h.size() * sizeof(palace_graph_cand), hipMemcpyHostToDevice, ctx->stream));
+            PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));     // h leaves scope
+        }
     }
     hipLaunchKernelGGL(resolve_split_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(resolve_pair_insert_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
@@ -450,6 +476,11 @@ int palace_graph_resolve(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_
     hipLaunchKernelGGL(compact_edges_kernel, dim3(static_cast<unsigned>((qcap + 255) / 256)), dim3(256), 0,
                        ctx->stream, a);
     PALACE_HIP_TRY(hipGetLastError());
+    if (d_n_edges) PALACE_HIP_TRY(hipMemcpyAsync(d_n_edges, ctx->d_small, 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (!n_edges_out) return PALACE_OK;              // the count stays on the device: nothing to wait for
+    rc = ensure_pinned(ctx, 256);
+    if (rc) return rc;
+    unsigned long long *cnt = static_cast<unsigned long long *>(ctx->pin.ptr);
     PALACE_HIP_TRY(hipMemcpyAsync(cnt, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
     PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
     *n_edges_out = static_cast<int64_t>(cnt[0]);

@@ -216,20 +216,11 @@ __global__ void iota_keys_kernel(uint64_t *__restrict__ khi, uint64_t *__restric
 
 }  // namespace palace
 
-struct palace_match_result {            // final result: arrays from the block pool, written exactly once
-    int64_t n = 0;
-    int64_t *off = nullptr;
-    int32_t *verts = nullptr, *iter = nullptr, *open_at = nullptr;
-    uint8_t *kind = nullptr;
-    uint64_t *bare = nullptr;            // compact results: bit s set = segment s has no arc (bare path of round 0 [+ the aggressive round])
-    int64_t n_bare = 0;
-    bool borrowed = false;               // the arrays belong to somebody else (the resident stage-04 object): nothing to give back
-    ~palace_match_result()
-    {
-        if (borrowed) return;
-        for (void *p : {(void *)off, (void *)verts, (void *)iter, (void *)open_at, (void *)kind, (void *)bare}) palace::g_result_pool.give(p);
-    }
-};
+palace_match_result::~palace_match_result()
+{
+    if (borrowed) return;
+    for (void *p : {(void *)off, (void *)verts, (void *)iter, (void *)open_at, (void *)kind, (void *)bare}) palace::g_result_pool.give(p);
+}
 
 // The decomposition of the arc-bearing sub-graph, all of it on the device (decomp.hip): arcs, copy numbers and the segment
 // ids of the caller's graph go up, the component arrays come back -- one synchronisation in the middle of nothing: the host
@@ -594,6 +585,6 @@ const int32_t *palace_match_result_iter(const palace_match_result *r) { return r
 const int32_t *palace_match_result_open_at(const palace_match_result *r) { return r ? r->open_at : nullptr; }
 const uint64_t *palace_match_result_bare(const palace_match_result *r) { return r ? r->bare : nullptr; }
 int64_t palace_match_result_bare_count(const palace_match_result *r) { return r ? r->n_bare : 0; }
-void palace_match_result_free(palace_match_result *r) { delete r; }
+void palace_match_result_free(palace_match_result *r) { if (r && !r->borrowed) delete r; }
 
 }  // extern "C"

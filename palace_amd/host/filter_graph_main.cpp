@@ -297,7 +297,9 @@ int main(int argc, char **argv)
     { Mapped unused(fastg_fai); }                                                 // opened like the reference does (l.114-120)
 
     Mapped graph(graph_path);
-    std::string seg_block;                                                        // SEG texts in first-selection order
+    std::string seg_block;                                                        // SEG texts as they are selected ...
+    struct Piece { const char *src; size_t at, len; };                           // ... written in the order of the SEG lines they
+    std::vector<Piece> pieces;                                                    // were made from (src), as the script sorts them
     auto flags_of = [&](const Facts &f) {
         std::string s;
         if (f.blast) s += "ref+";
@@ -319,7 +321,7 @@ int main(int argc, char **argv)
         text += f.has_score ? f.score_text : std::string("0.000");
         text += f.blast ? " 1\n" : " 0\n";
     };
-    auto emit = [&](Facts &f, sv text) {                      // select() of the script: a text is written once
+    auto emit = [&](Facts &f, sv text, const char *src) {     // select() of the script: a text is written once
         if (f.text_len) {
             if (sv(seg_block).substr(f.text_at, f.text_len) == text) return;
             for (const std::string &e : f.more_texts)
@@ -329,6 +331,7 @@ int main(int argc, char **argv)
             f.text_at = seg_block.size();
             f.text_len = text.size();
         }
+        pieces.push_back(Piece{src, seg_block.size(), text.size()});
         seg_block.append(text);
         // `already` of the script: the second space-separated token of every selected text
         const size_t a = text.find(' ');
@@ -346,7 +349,7 @@ int main(int argc, char **argv)
         if (f.text_of == f.raw.data()) return;                // the text of this very line is out already
         f.text_of = f.raw.data();
         render(f, f.raw, toks, text);
-        emit(f, text);
+        emit(f, text, f.raw.data());
     };
 
     struct End { sv line; int left, right; };
@@ -399,7 +402,7 @@ int main(int argc, char **argv)
                 if (r.text_len) {                             // a seed
                     f.seed = true;
                     f.text_of = r.line.data();
-                    emit(f, sv(texts[k]).substr(r.text_at, r.text_len));
+                    emit(f, sv(texts[k]).substr(r.text_at, r.text_len), r.line.data());
                     if (hit_listed.size() < facts.size()) hit_listed.resize(facts.size(), 0);
                     if (!hit_listed[static_cast<size_t>(id)]) { hit_listed[static_cast<size_t>(id)] = 1; hit_rows.emplace_back(id, flags_of(f)); }
                 }
@@ -469,11 +472,18 @@ int main(int argc, char **argv)
     trace.lap("paths rescue");
     FILE *out = std::fopen(out_path, "wb");
     if (!out) die(std::string("cannot write ") + out_path);
-    std::fwrite(seg_block.data(), 1, seg_block.size(), out);
+    std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &a, const Piece &b) { return a.src < b.src; });
+    for (const Piece &pc : pieces) std::fwrite(seg_block.data() + pc.at, 1, pc.len, out);
+    std::vector<int> tail;
     for (int m : rescued) {
         const Facts &f = facts[static_cast<size_t>(m)];
         if (f.in_already) continue;
         if (!f.has_raw) die("contigs.paths names a contig without a SEG line: " + std::string(names.names[static_cast<size_t>(m)]));
+        tail.push_back(m);
+    }
+    std::sort(tail.begin(), tail.end(), [&](int a, int b) { return facts[static_cast<size_t>(a)].raw.data() < facts[static_cast<size_t>(b)].raw.data(); });
+    for (int m : tail) {
+        const Facts &f = facts[static_cast<size_t>(m)];
         const sv raw = strip(f.raw);
         std::fwrite(raw.data(), 1, raw.size(), out);
         std::fputs(" 0 1.0 0\n", out);

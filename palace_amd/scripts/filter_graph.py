@@ -8,9 +8,12 @@ same 13 positional arguments, the same output grammar:
   JUNC ...                                                          copied verbatim, first occurrence only
 
 and `all_hit_segs.txt` (SAMPLE<TAB>name<TAB>ref+score+gene+ flags) in SEG order of the input graph.
-The reference emits its SEG block by iterating Python sets, i.e. in a PYTHONHASHSEED-dependent
-order (filter_graph.py:41, 253-258); this implementation emits SEG lines in first-selection order,
-which is one of the orders the reference can produce.  The JUNC block order is identical.
+The reference emits its SEG block by iterating two Python sets, i.e. in a PYTHONHASHSEED-dependent
+order (filter_graph.py:41, 253-258): the selected SEG lines, then the path-rescued ones.  This
+implementation emits each of the two groups in the order of the SEG lines of the input graph -- one
+of the orders the reference can produce, and the one the in-memory filter of the HIP library
+(palace_stage04_filter) numbers the segments by, so that `matching` sees the same graph either way.
+The JUNC block order is identical to the reference's.
 
 argv: fastg.fai graph.txt out.txt depth f_th hit_seqs.out node_scores.out contigs.blast blast_ratio
       contigs.fasta.fai all_hit_segs.txt contigs.paths score_threshold
@@ -152,23 +155,25 @@ def run(argv):
         lines = f.readlines()
 
     raw_seg = {}
+    raw_at = {}                                               # name -> line number of its latest SEG line
     hit_rows = []
-    out_segs, out_seg_lines = set(), []
+    out_segs, out_seg_lines = set(), []                       # (line number of the SEG line a text was made from, text)
 
     def select(name):
         text = flt.seg_line(name, raw_seg[name])
         if text not in out_segs:
             out_segs.add(text)
-            out_seg_lines.append(text)
+            out_seg_lines.append((raw_at[name], text))
 
     juncs = []
     seeds = set()
-    for line in lines:                                        # pass 1: SEG lines, seeds
+    for at, line in enumerate(lines):                         # pass 1: SEG lines, seeds
         cols = line.rstrip().split(" ")
         if cols[0] != "SEG":
             continue
         name = cols[1]
         raw_seg[name] = line
+        raw_at[name] = at
         flags = flt.hit_flags(name)
         if flags:
             seeds.add(name)
@@ -193,12 +198,12 @@ def run(argv):
 
     support = flt.blast_hit | set(flt.gene_hit) | flt.score_hit
     rescued = flt.rescued_by_paths(paths_file, support)
-    already = {text.split(" ")[1] for text in out_seg_lines}
+    out_seg_lines.sort(key=lambda x: x[0])                    # graph order (stable: texts of one line keep their order)
+    already = {text.split(" ")[1] for _, text in out_seg_lines}
     with open(out_path, "w") as out:
-        out.writelines(out_seg_lines)
-        for name in rescued:
-            if name not in already:
-                out.write(f"{raw_seg[name].strip()} 0 1.0 0\n")
+        out.writelines(text for _, text in out_seg_lines)
+        for name in sorted((n for n in rescued if n not in already), key=lambda n: raw_at[n]):
+            out.write(f"{raw_seg[name].strip()} 0 1.0 0\n")
         emitted = set()
         for j in juncs:
             if j not in emitted:

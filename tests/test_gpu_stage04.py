@@ -1,0 +1,142 @@
+"""The resident stage 04 (palace_stage04_*: filter_graph.py's selection and `matching`, both on the device) against
+  * the outputs of the REFERENCE's filter_graph.py (tests/golden/filter_cases.npz): kept SEG set as a sorted multiset, JUNC list in order;
+  * this repository's own file chain (scripts/filter_graph.py -> uniq -> bin/matching -l contigs.paths): byte-identical linear / cycle files.
+matching itself stays "parity unpinned" (the reference binary is absent): the second check pins the in-memory
+path to the file path, not to the reference."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from palace_amd import capi, stage04_io, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRIPTS = os.path.join(ROOT, "palace_amd", "scripts")
+BIN = os.path.join(ROOT, "palace_amd", "bin")
+G = np.load(os.path.join(ROOT, "tests", "golden", "filter_cases.npz"))
+
+
+def _script_filter():
+    sys.path.insert(0, SCRIPTS)
+    import filter_graph
+    return filter_graph
+
+
+def _load_case(files, tmp_path, blast_ratio=0.7, score_threshold=0.7):
+    """the text inputs of filter_graph.py -> the arrays of palace_stage04_inputs + the edges of the graph text"""
+    P = lambda n: str(tmp_path / n)
+    for k in ("fasta_fai", "blast", "hit_seqs", "node_scores"):
+        open(P(k), "w").write(files[k])
+    flt = _script_filter().GraphFilter(blast_ratio, score_threshold)      # (the script's own readers of the side files)
+    flt.load_fasta_index(P("fasta_fai")); flt.load_blast(P("blast")); flt.load_gene_hits(P("hit_seqs")); flt.load_scores(P("node_scores"))
+    names = [l.split("\t")[0] for l in files["fasta_fai"].splitlines()]
+    index = {n: i for i, n in enumerate(names)}
+    seed = np.array([(n in flt.blast_hit) | ((n in flt.gene_hit) << 1) | ((n in flt.score_hit) << 2) for n in names], np.uint8)
+    raw_seg, cn, tlen = {}, np.zeros(len(names), np.int32), np.zeros(len(names), np.int32)
+    junc_lines, edges, seen = [], [], set()
+    for line in files["graph"].splitlines(keepends=True):
+        c = line.split()
+        if c[0] == "SEG":
+            raw_seg[c[1]] = line
+            cn[index[c[1]]] = int(float(c[3]))
+            tlen[index[c[1]]] = 1
+        else:
+            key = (index[c[1]], c[2] == "-", index[c[3]], c[4] == "-")
+            if key in seen:
+                continue                                     # the aggregated edge exists once; the file's duplicate line is dropped on output anyway
+            seen.add(key)
+            junc_lines.append(line)
+            edges.append((key[0], key[2], (int(c[5]), 0, 0, int(c[6])), key[1], key[3], (0,) * 6))
+    e = np.array(edges, dtype=capi.EDGE_DTYPE) if edges else np.zeros(0, capi.EDGE_DTYPE)
+    off, tok = stage04_io.paths_csr(files["contigs_paths"], names)
+    return dict(names=names, seed=seed, tlen=tlen, rank=stage04_io.name_ranks(names), name_len=stage04_io.name_lengths(names),
+                path_off=off, path_tok=tok, edges=e, junc_lines=junc_lines, raw_seg=raw_seg, cn=cn, flt=flt)
+
+
+def _run_filter(ctx, case, min_count):
+    st = capi.Stage04(ctx, case["seed"], case["tlen"], case["rank"], case["name_len"], case["path_off"], case["path_tok"], min_count)
+    e = case["edges"]
+    d_e = ctx.upload(e.view(np.uint8).reshape(-1) if len(e) else np.zeros(32, np.uint8))
+    d_n = ctx.upload(np.array([len(e)], np.int64))
+    st.filter(d_e.ptr, d_n.ptr, max(1, len(e)))
+    return st, d_e, d_n
+
+
+@pytest.mark.parametrize("case_no", [0, 1, 2])
+def test_in_memory_filter_equals_reference_outputs(tmp_path, case_no):
+    files = {k: G[f"case{case_no}_{k}"].tobytes().decode() for k in ("graph", "fasta_fai", "blast", "hit_seqs", "node_scores", "contigs_paths", "pre")}
+    case = _load_case(files, tmp_path)
+    with capi.Ctx(0) as ctx:
+        st, d_e, d_n = _run_filter(ctx, case, min_count=0)           # every JUNC line of the text is an edge here
+        seg_flags, edge_flags = st.flags(len(case["edges"]))
+        counts = st.counts()
+        st.close()
+    names, flt = case["names"], case["flt"]
+    got_seg = sorted([flt.seg_line(names[i], case["raw_seg"][names[i]]) for i in np.flatnonzero(seg_flags & 1)] +
+                     [case["raw_seg"][names[i]].strip() + " 0 1.0 0\n" for i in np.flatnonzero((seg_flags & 3) == 2)])
+    got_junc = [l for l, f in zip(case["junc_lines"], edge_flags) if f & 2] + [l for l, f in zip(case["junc_lines"], edge_flags) if (f & 6) == 4]
+    want = files["pre"].splitlines(keepends=True)
+    assert got_seg == sorted(l for l in want if l.startswith("SEG"))
+    assert got_junc == [l for l in want if not l.startswith("SEG")]
+    assert counts["segs_selected"] + counts["segs_rescued"] == len(got_seg) and counts["kept_pass2"] + counts["kept_pass3_more"] == len(got_junc)
+    assert len(got_junc) > 3 and counts["segs_rescued"] >= 0
+
+
+def _file_chain(tmp_path, files, avg, flags):
+    """scripts/filter_graph.py (native core) -> uniq -> bin/matching, as palace:566-591 runs them"""
+    P = lambda n: str(tmp_path / n)
+    for k, v in files.items():
+        open(P(k), "w").write(v)
+    subprocess.run([sys.executable, os.path.join(SCRIPTS, "filter_graph.py"), P("fastg_fai"), P("graph"), P("pre.txt"), f"{avg:.6g}", "0",
+                    P("hit_seqs"), P("node_scores"), P("blast"), "0.7", P("fasta_fai"), P("hits.txt"), P("contigs_paths"), "0.7"], check=True)
+    with open(P("filt.txt"), "wb") as f:
+        subprocess.run(["uniq", P("pre.txt")], check=True, stdout=f)
+    subprocess.run([os.path.join(BIN, "matching"), "-g", P("filt.txt"), "-r", P("lin.txt"), "-c", P("cyc.txt"), "-i", "10", "-l", P("contigs_paths")] + flags,
+                   check=True)
+    return open(P("lin.txt")).read(), open(P("cyc.txt")).read(), open(P("filt.txt")).read()
+
+
+@pytest.mark.parametrize("seed,n_contigs,n_events,flags", [(5, 60, 4000, ["-s"]), (6, 400, 30000, ["-s"]), (7, 400, 30000, ["-b", "--aggressive"]),
+                                                             (8, 2500, 120000, ["-s"])])
+def test_in_memory_stage04_equals_the_file_chain(tmp_path, seed, n_contigs, n_events, flags):
+    from oracle import binding as orc
+    rng = synth.rng_for(seed)
+    targets, fai_text, recs, avg = synth.random_graph_case(rng, n_contigs, n_events)
+    names, lens = [t[0] for t in targets], [t[1] for t in targets]
+    open(tmp_path / "g.fastg.fai", "w").write(fai_text)
+    o = orc.graph_default_opts()
+    o.min_count = 2
+    graph = orc.graph_run(recs, targets, str(tmp_path / "g.fastg.fai"), avg, o).decode()      # a `_graph.txt` (the checker's; any would do)
+    files = dict(graph=graph, fastg_fai=fai_text, **synth.filter_side_files(rng, names, lens))
+    lin, cyc, filt = _file_chain(tmp_path, files, avg, flags)
+    case = _load_case(files, tmp_path)
+    with capi.Ctx(0) as ctx:
+        st, d_e, d_n = _run_filter(ctx, case, min_count=0)
+        d_cn = ctx.upload(case["cn"])
+        st.match(d_e.ptr, d_cn.ptr, 10, "--aggressive" in flags, True)
+        res, contig_of = st.result()
+        got_lin, got_cyc = stage04_io.matching_text(res, contig_of, names, self_loops="-s" in flags, break_cycles="-b" in flags)
+        seg_order = [names[c] for c in contig_of]              # (views into the object's pinned memory: read before close)
+        counts = st.counts()
+        st.close()
+    assert seg_order == [l.split(" ")[1] for l in filt.splitlines() if l.startswith("SEG")]     # the file's SEG order
+    assert got_lin == lin
+    assert got_cyc == cyc
+    assert lin.count("\t") > 5 and counts["arcs"] > 10
+
+
+def test_stage04_reports_what_the_reference_script_dies_on(tmp_path):
+    """an id in contigs.paths that names no contig: filter_graph.py:138 raises KeyError; the resident filter reports it"""
+    names = [f"EDGE_{i + 1}_length_{500 + i}_cov_3.0" for i in range(6)]
+    off, tok = stage04_io.paths_csr("NODE_1\n1+,99-,2+\n", names)
+    assert tok.tolist() == [0, -1, 2]
+    with capi.Ctx(0) as ctx:
+        st = capi.Stage04(ctx, np.ones(6, np.uint8), np.full(6, 500, np.int32), stage04_io.name_ranks(names), stage04_io.name_lengths(names), off, tok)
+        d_e, d_n = ctx.upload(np.zeros(32, np.uint8)), ctx.upload(np.zeros(1, np.int64))
+        st.filter(d_e.ptr, d_n.ptr, 1)
+        with pytest.raises(capi.PalaceError, match="unknown contig id"):
+            st.counts()
+        st.close()
