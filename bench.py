@@ -261,6 +261,41 @@ def make_graph_sample(torch, dev, n_contigs, n_pairs, rank=0, world=1, long_mode
                 names=names, lens=c_lens, link=link, avg_depth=None if total_ref is None else float(f"{total_ref / c_lens.sum():.6g}"))
 
 
+def make_side_inputs(gs):
+    """The per-sample side inputs of filter_graph.py: hit_seqs 3 % of the contigs, node_scores all of them
+    (uniform, some in e-05 notation), .blast for 2 %, one contigs.paths entry per 3 contigs -- once, as data: the files -> files
+    leg writes them out as text, the resident step gets them as the arrays of palace_stage04_inputs."""
+    rng = np.random.Generator(np.random.PCG64(SEED + 2))
+    names, lens = gs["names"], gs["lens"]
+    n = len(names)
+    hit = rng.choice(n, size=max(1, n * 3 // 100), replace=False)
+    hit_k = rng.integers(1, 9, size=len(hit))
+    sc = rng.random(n)
+    tiny = rng.random(n) < 0.05
+    score_text = [(f"{x * 9:.4f}e-05" if t else f"{x:.6f}") for x, t in zip(sc.tolist(), tiny.tolist())]
+    bl = rng.choice(n, size=max(1, n // 50), replace=False)
+    bl_ident = rng.choice([99.5, 85.0, 69.9], size=len(bl))
+    bl_frac = rng.choice([0.3, 0.8, 0.95], size=len(bl))
+    bl_ref = rng.integers(1, 200, size=len(bl))
+    k_paths = max(1, n // 3)
+    mem = rng.integers(0, n, size=(k_paths, 3))
+    sg = rng.integers(0, 2, size=(k_paths, 3))
+    # seed bits as filter_graph.py derives them from those files (:66-112), thresholds 0.7 / 0.7 as palace:568-579 passes them
+    seed = np.zeros(n, np.uint8)
+    al = np.maximum(30, (lens[bl] * bl_frac).astype(np.int64))
+    seed[bl[(bl_ident > 70.0) & ((al / lens[bl] > 0.7) | (al > 2000))]] |= 1
+    seed[hit] |= 2
+    score_hit = np.fromiter((0.0 if t else float(f"{float(s):.3f}") for s, t in zip(score_text, tiny.tolist())), dtype=np.float64, count=n) > 0.7
+    seed[score_hit] |= 4
+    # contigs.paths: every entry is two path lines (the path and its reverse complement)
+    fwd = 2 * mem + sg
+    rc = (2 * mem + (1 - sg))[:, ::-1]
+    tok = np.stack([fwd, rc], axis=1).reshape(-1).astype(np.int32)
+    off = np.arange(2 * k_paths + 1, dtype=np.int64) * 3
+    return dict(hit=hit, hit_k=hit_k, score_text=score_text, bl=bl, bl_ident=bl_ident, bl_frac=bl_frac, bl_ref=bl_ref, mem=mem, sg=sg,
+                seed=seed, path_off=off, path_tok=tok)
+
+
 def graph_to_arcs(cn, n_segs, edges, min_count=5):
     """host glue between generateGraph's numbers and matching's input (JUNC filter :1056-1061, arc + conjugate,
     arc ranking): the library's own host routine, the same one palace_amd/host/matching_main.cpp ranks with."""
@@ -337,43 +372,40 @@ def write_e2e_inputs(torch, sample, gs, hdr, work):
     with open(P["fastg_fai"], "w") as f:
         f.write("".join(f"{names[x]}{q if u else ''}:{names[y]}{q if (u ^ v) else ''};\t{lens[x]}\t0\t60\t61\n"
                         for x, y, u, v in zip(a.tolist(), b.tolist(), o1.tolist(), o2.tolist())))
-    # side inputs of filter_graph.py: hit_seqs 3 % of the contigs, node_scores all of them (uniform, some in
-    # e-05 notation), .blast for 2 %, one contigs.paths entry per 3 contigs
-    rng = np.random.Generator(np.random.PCG64(SEED + 2))
+    # side inputs of filter_graph.py: the same data the resident step's palace_stage04 object was built from (make_side_inputs)
+    sd = gs["side"]
     n = len(names)
     with open(P["fasta_fai"], "w") as f:
         f.write("".join(f"{nm}\t{l}\t{7 + 100 * i}\t60\t61\n" for i, (nm, l) in enumerate(zip(names, lens.tolist()))))
-    hit = rng.choice(n, size=max(1, n * 3 // 100), replace=False)
     with open(P["hit"], "w") as f:
-        f.write("".join(f"{names[i]}\t{k}\n" for i, k in zip(hit.tolist(), rng.integers(1, 9, size=len(hit)).tolist())))
-    sc = rng.random(n)
-    tiny = rng.random(n) < 0.05
+        f.write("".join(f"{names[i]}\t{k}\n" for i, k in zip(sd["hit"].tolist(), sd["hit_k"].tolist())))
     with open(P["score"], "w") as f:
-        f.write("".join(f"{nm}\t{(f'{x * 9:.4f}e-05' if t else f'{x:.6f}')}\n" for nm, x, t in zip(names, sc.tolist(), tiny.tolist())))
-    bl = rng.choice(n, size=max(1, n // 50), replace=False)
+        f.write("".join(f"{nm}\t{t}\n" for nm, t in zip(names, sd["score_text"])))
     with open(P["blast"], "w") as f:
-        for i, ident, frac, ref in zip(bl.tolist(), rng.choice([99.5, 85.0, 69.9], size=len(bl)).tolist(),
-                                       rng.choice([0.3, 0.8, 0.95], size=len(bl)).tolist(), rng.integers(1, 200, size=len(bl)).tolist()):
+        for i, ident, frac, ref in zip(sd["bl"].tolist(), sd["bl_ident"].tolist(), sd["bl_frac"].tolist(), sd["bl_ref"].tolist()):
             L = int(lens[i]); al = max(30, int(L * frac))
             f.write(f"{names[i]}\tphage_{ref}\t{ident:.3f}\t{al}\t3\t0\t1\t{al}\t100\t{100 + al}\t1e-50\t200\t{L}\t40000\n")
-    ids = [nm.split("_")[1] for nm in names]
-    k_paths = max(1, n // 3)
-    mem = rng.integers(0, n, size=(k_paths, 3))
-    sg = rng.integers(0, 2, size=(k_paths, 3))
     with open(P["paths"], "w") as f:
-        out = []
-        for k in range(k_paths):
-            fwd = [ids[j] + "+-"[t] for j, t in zip(mem[k].tolist(), sg[k].tolist())]
-            rc = [t[:-1] + ("-" if t[-1] == "+" else "+") for t in reversed(fwd)]
-            tot = int(lens[mem[k]].sum())
-            out.append(f"NODE_{k + 1}_length_{tot}_cov_9.5\n{','.join(fwd)}\nNODE_{k + 1}_length_{tot}_cov_9.5'\n{','.join(rc)}\n")
-        f.write("".join(out))
+        f.write(paths_text(names, lens, sd))
     P["gen_s"] = time.perf_counter() - t0
     P["bytes"] = {k: os.path.getsize(P[k]) for k in ("fq1", "fq2", "fa", "bam", "fastg_fai")}
     return P
 
 
-def run_e2e(P, avg_depth, n_contigs, rows_host, n_junc_expected):
+def paths_text(names, lens, sd):
+    """contigs.paths (SPAdes): NODE header, the path, NODE' header, its reverse complement"""
+    ids = [nm.split("_")[1] for nm in names]
+    mem, sg = sd["mem"], sd["sg"]
+    out = []
+    for k in range(len(mem)):
+        fwd = [ids[j] + "+-"[t] for j, t in zip(mem[k].tolist(), sg[k].tolist())]
+        rc = [t[:-1] + ("-" if t[-1] == "+" else "+") for t in reversed(fwd)]
+        tot = int(lens[mem[k]].sum())
+        out.append(f"NODE_{k + 1}_length_{tot}_cov_9.5\n{','.join(fwd)}\nNODE_{k + 1}_length_{tot}_cov_9.5'\n{','.join(rc)}\n")
+    return "".join(out)
+
+
+def run_e2e(P, avg_depth, n_contigs, rows_host, n_junc_expected, result_text_expected=None):
     """The chain of palace:473-480 and 555-600 on the files, one process per stage as the driver runs them.  Returns wall
     seconds per stage.  eref is run twice: the first run builds <db>.k32.index.dat (once per DB, extract_ref.cpp:1245-1251),
     the second finds it -- the steady state of a DB shared by many samples and the one that enters `seconds`."""
@@ -412,8 +444,10 @@ def run_e2e(P, avg_depth, n_contigs, rows_host, n_junc_expected):
     got = {tuple(int(x) for x in l.split("\t")[1:4]) for l in open(P["refnames"]).read().splitlines()}
     n_junc = sum(1 for l in open(P["graph"]) if l.startswith("JUNC"))
     total = sum(v for k, v in st.items() if k != "eref_first_run_builds_index")
+    same_result = None if result_text_expected is None else bool(open(P["result"]).read() == result_text_expected)
     return dict(seconds=total, contigs_per_s=n_contigs / total, stage_s={k: round(v, 3) for k, v in st.items()},
-                agrees_with_resident_step=bool(got == want and n_junc == n_junc_expected),
+                agrees_with_resident_step=bool(got == want and n_junc == n_junc_expected and same_result is not False),
+                all_result_identical_to_resident_step=same_result,
                 refs_reported=len(got), junc_lines=n_junc, result_lines=sum(1 for _ in open(P["result"])),
                 input_bytes=P["bytes"], input_generation_s=round(P["gen_s"], 1),
                 note="wall clock of eref + generateGraph + filter_graph.py + uniq + matching + remove_cycle_dup.py + cat, one process "
@@ -537,17 +571,19 @@ def cpu_baseline(torch, sample, gs, header, frac, graph_out):
     gin.run(os.path.join(tmp, "g.fastg.fai"), gs["avg_depth"])
     t_graph_s = time.perf_counter() - t0
     t_graph = t_graph_s * gs["n_total"] / m
-    # ---- matching: the whole graph this run produced, through the oracle's own text parser ----
-    copies, src, dst, w = graph_out
-    gpath = os.path.join(tmp, "graph.txt")
+    # ---- matching: the whole FILTERED graph this run produced (what palace:587-590 hands to `matching`), through the oracle's
+    # own text parser, with contigs.paths ----
+    gpath, ppath = os.path.join(tmp, "graph.txt"), os.path.join(tmp, "contigs.paths")
+    e = graph_out["edges"][(graph_out["edge_flags"] & 6) != 0]
     with open(gpath, "w") as f:
-        f.write("".join(f"SEG {n} 1 {k} 0 0.000 0\n" for n, k in zip(names, copies.tolist())))
-        keep = src <= (dst ^ 1)                      # one line per conjugate pair
-        f.write("".join(f"JUNC {names[u >> 1]} {'+-'[u & 1]} {names[v >> 1]} {'+-'[v & 1]} {x} 0\n"
-                        for u, v, x in zip(src[keep].tolist(), dst[keep].tolist(), w[keep].tolist())))
+        f.write("".join(f"SEG {names[c]} 1 {graph_out['cn'][c]} 0 0.000 0\n" for c in graph_out["contig_of"].tolist()))
+        f.write("".join(f"JUNC {names[l]} {'+-'[a]} {names[r_]} {'+-'[b]} {x} 0\n"
+                        for l, r_, a, b, x in zip(e["left"].tolist(), e["right"].tolist(), e["oL"].tolist(), e["oR"].tolist(),
+                                                  e["counts"].astype(np.int64).sum(axis=1).tolist())))
+    open(ppath, "w").write(paths_text(names, gs["lens"], gs["side"]))
     cap = 128 * len(names) + (1 << 20)
     t0 = time.perf_counter()
-    orc.match_run(gpath, None, 10, cap=cap)
+    orc.match_run(gpath, ppath, 10, cap=cap)
     t_match = time.perf_counter() - t0
     t_full, t_full_mt = t_eref + t_graph + t_match, t_eref_mt + t_graph + t_match
     # the COMPILED reference, when it travels with the repo, on a small part of the same reads: a cross-check of the port's rate
@@ -562,8 +598,8 @@ def cpu_baseline(torch, sample, gs, header, frac, graph_out):
                sample=(f"oracle/ at threads=1. eref: {2 * n_side} of {total_reads} reads x{READ_LEN} bp ({t_reads:.1f} s) + 4 GiB table "
                        f"memset ({t_clear:.1f} s, fixed) + scan of {n_ref_s} of {sample['n_refs']} refs ({t_refs:.2f} s) -> {t_eref:.0f} s "
                        f"extrapolated; generateGraph: first {m} of {gs['n_total']} decoded records ({t_graph_s:.1f} s; BGZF/BAM decode and "
-                       f"full .fai parse excluded) -> {t_graph:.0f} s; matching: whole graph ({t_match:.1f} s; own algorithm, reference "
-                       f"absent)."),
+                       f"full .fai parse excluded) -> {t_graph:.0f} s; matching: the whole filtered graph with contigs.paths ({t_match:.1f} s; own "
+                       f"algorithm, reference absent); filter_graph.py itself (Python glue) is not in the sum."),
                stage_s=dict(eref=t_eref, generateGraph=t_graph, matching=t_match), port_reads_per_s=2 * n_side / t_reads,
                multi_thread=dict(value=nc / t_full_mt, unit="contigs/s", cores=cores, kind="port",
                                  note=f"read counting and ref scan on {cores} threads (same sample: {t_reads_mt:.1f} s and {t_refs_mt:.2f} s); "
@@ -637,7 +673,9 @@ def main():
 
     hdr = coder.header_from_picks(np.random.Generator(np.random.PCG64(SEED)).integers(0, 6, size=32))
     ctx = capi.Ctx(local)                      # eref stream
-    ctx_g = capi.Ctx(local, high_priority=True)   # generateGraph + matching stream (independent of eref until the end)
+    ctx_g = capi.Ctx(local, high_priority=os.environ.get("PALACE_BENCH_PRIO", "1") == "1")   # generateGraph + matching stream (independent of eref until the end)
+    if os.environ.get("PALACE_OPT_ITERS_PER_ROUND"):         # tuning runs only
+        ctx_g.match_set_option("iters_per_round", int(os.environ["PALACE_OPT_ITERS_PER_ROUND"]))
     ctx.eref_set_coder(hdr)
     for opt in ("slab_bases", "bin1_ppl"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
         if os.environ.get("PALACE_OPT_" + opt.upper()):
@@ -669,17 +707,21 @@ def main():
     cand_cap = gs["n"] + gs["n_sa"] + 1
     cands = torch.zeros((cand_cap, 64), dtype=torch.uint8, device=dev)
     edges = torch.zeros((cand_cap, 32), dtype=torch.uint8, device=dev)
-    edges_host = torch.zeros((min(cand_cap, 1 << 21), 32), dtype=torch.uint8).pin_memory()
     cols = capi.BamCols(gs["n"], *(P(gs["col"][k]) for k in ("tid", "pos", "mtid", "mpos", "nm", "ref_len", "read_len",
                                                            "clip_s", "clip_e", "flag", "mapq", "qkey")), P(gs["sa_off"]))
     prm = capi.GraphParams.default()
+    # stage 04 resident: the per-sample inputs of filter_graph.py and matching -l, parsed once like the BAM columns
+    gs["side"] = make_side_inputs(gs)
+    stage04 = None
+    if rank == 0:
+        stage04 = capi.Stage04(ctx_g, gs["side"]["seed"], gs["lens"].astype(np.int32), gs["trank"].cpu().numpy(), gs["lens"].astype(np.int32),
+                               gs["side"]["path_off"], gs["side"]["path_tok"], 5)
+    n_edges_dev = torch.zeros(1, dtype=torch.int64, device=dev)
     exch = multigpu.Exchange(torch, dist, rank, world) if (world > 1 or force_exchange) else None
     # torch ops and collectives run on torch's current stream, the library's kernels on the two context streams; the
     # hand-over points wait for exactly the stream that produced the data (a device-wide synchronize here would make the
     # generateGraph exchange wait for the eref counting kernels and vice versa)
     tsync = lambda: torch.cuda.current_stream().synchronize()
-    from concurrent.futures import ThreadPoolExecutor
-    match_thread = ThreadPoolExecutor(max_workers=1) if exch else None
     if exch:
         planes = [torch.zeros(1 << 29, dtype=torch.uint8, device=dev) for _ in range(3)]   # torch-owned so RCCL
         ctx.eref_table_attach([t.data_ptr() for t in planes])                                # can address them
@@ -718,8 +760,10 @@ def main():
             # both FASTQ sides as one read set: one binning pass, the plane slices are loaded and stored once
             capi._check(L.palace_eref_count_reads(ctx.h, P(sample["r12"]), P(sample["read_off"]), 2 * n_side, None, 2 * tot_b), "count")
             if timed: ctx.mark(m + 1)
+            ctx.mark(4095)                             # "the counting kernels are done" (stage 04 waits for it, see below)
 
-        if not exch:
+        skip_eref = os.environ.get("PALACE_BENCH_SKIP_EREF") == "1"      # tuning runs only: stream B alone on the device
+        if not exch and not skip_eref:
             eref_head()                                # one GPU: launched first, generateGraph + matching overlap it
 
         def eref_tail():
@@ -736,82 +780,90 @@ def main():
                 exch.gather_ranges(rows, ref_ranges)
                 tsync()
 
-        if not exch:
+        if not exch and not skip_eref:
             eref_tail()                                # one GPU: queue Phase B right behind the counting kernels
-        # ---------------- generateGraph (second stream; overlaps the eref kernels) ----------------
+        # ---------------- generateGraph + filter + matching (second stream; overlaps the eref kernels) ----------------
+        # One wait in the middle (the candidate count sizes the tables of what follows), one at the end; everything else is
+        # enqueued: classify -> resolve (edge count stays on the device) -> copy numbers -> filter_graph.py's selection ->
+        # matching on the filtered graph, all in HBM.
         g = ctx_g
+        th0 = time.perf_counter()
         if timed: g.mark(m)
         capi._check(L.palace_memset(g.h, P(consumed), 0, nt * 8), "memset")
-        n_c = ctypes.c_int64()
-        capi._check(L.palace_graph_classify(g.h, ctypes.byref(cols), P(gs["sa"]), nt, P(gs["tlen"]), P(gs["trank"]),
-                                            P(gs["fastg"]), gs["n_fastg"], ctypes.byref(prm), gs["ord_base"], P(consumed),
-                                            P(cands), cand_cap, ctypes.byref(n_c)), "classify")
+        n_c, n_b = ctypes.c_int64(), ctypes.c_int64()
+        capi._check(L.palace_graph_classify_ex(g.h, ctypes.byref(cols), P(gs["sa"]), nt, P(gs["tlen"]), P(gs["trank"]),
+                                               P(gs["fastg"]), gs["n_fastg"], ctypes.byref(prm), gs["ord_base"], P(consumed),
+                                               P(cands), cand_cap, ctypes.byref(n_c), ctypes.byref(n_b)), "classify")
         if timed: g.mark(m + 1)
-        all_c, n_cands, e_buf, cons_for_quirk = cands, n_c.value, edges, consumed
+        all_c, n_cands, n_border, e_buf, cons_for_quirk = cands, n_c.value, n_b.value, edges, consumed
         if exch:                                   # every rank resolves the same gathered candidates;
             all_c, n_cands = exch.gather_varlen(cands, n_cands)          # only rank 0's quirk sums join the reduce
+            nb = torch.tensor([n_border], device=dev, dtype=torch.int64)
+            dist.all_reduce(nb)
+            n_border = int(nb.item())
             e_buf = edges if n_cands <= cand_cap else torch.zeros((n_cands, 32), dtype=torch.uint8, device=dev)
             if rank != 0:
                 scratch_consumed.zero_()
                 cons_for_quirk = scratch_consumed
             tsync()
-        n_e = ctypes.c_int64()
-        capi._check(L.palace_graph_resolve(g.h, P(all_c), n_cands, gs["n_total"], ctypes.byref(prm), P(cons_for_quirk),
-                                           P(e_buf), max(1, n_cands), ctypes.byref(n_e)), "resolve")
+        capi._check(L.palace_graph_resolve_ex(g.h, P(all_c), n_cands, n_border, gs["n_total"], ctypes.byref(prm), P(cons_for_quirk),
+                                              P(e_buf), max(1, n_cands), P(n_edges_dev), None), "resolve")
         if exch:
             g.sync()
             exch.reduce_sum(consumed)
             tsync()
         capi._check(L.palace_graph_copy_numbers(g.h, P(consumed), P(gs["tlen"]), nt, gs["avg_depth"], P(cn_dev)), "cn")
         if timed: g.mark(m + 2)
-        th0 = time.perf_counter()
-        capi._check(L.palace_d2h(g.h, cn_host.data_ptr(), P(cn_dev), nt * 4), "d2h")
-        h_cn = cn_host.numpy()
-        if n_e.value <= edges_host.shape[0]:
-            capi._check(L.palace_d2h(g.h, edges_host.data_ptr(), P(e_buf), n_e.value * 32), "d2h")
-            h_edges = edges_host.numpy()[: n_e.value].view(capi.EDGE_DTYPE).reshape(-1)
-        else:
-            g.sync()
-            h_edges = e_buf[: n_e.value].cpu().numpy().view(capi.EDGE_DTYPE).reshape(-1)
+        if stage04 is not None:                     # rank 0 owns the (small) stage; its result is what the sample's all_result holds
+            # Stage 04 is a few hundred small latency-bound launches: beside the bandwidth-bound counting kernels each of them
+            # costs those kernels a few microseconds (kernel boundaries write back the L2 lines the partition kernels combine their
+            # stores in) -- 1.3 ms per step, measured; beside Phase B's small kernels it costs nothing.  So the selection and the
+            # arcs are done at once, and the rounds of the decomposition start when the counting kernels of this step are done
+            # (ordered on the device, no host wait).
+            late = not exch and not skip_eref and os.environ.get("PALACE_BENCH_STAGE04_EARLY") != "1"
+            stage04.filter(P(e_buf), P(n_edges_dev), max(1, n_cands))
+            stage04.match(P(e_buf), P(cn_dev), 10, False, True, after=(ctx, 4095) if late else None)
+        if timed: g.mark(m + 3)
         th1 = time.perf_counter()
-        # ---------------- matching (small; rank 0 owns it, components are independent) ----------------
-        def matching():
-            if rank != 0:                               # rank 0 owns the (small) matching stage
-                last.update(n_edges=int(n_e.value), n_cands=int(n_cands))
+        if timed:
+            host_ms["graph_enqueue_incl_classify_wait"] = host_ms.get("graph_enqueue_incl_classify_wait", 0.0) + 1e3 * (th1 - th0) / args.steps
+        last.update(n_cands=int(n_cands))
+
+        def finish_graph():
+            """the end of stream B: wait for the decomposition, take the result views; on untimed steps also the bookkeeping
+            (counts, result digest) that the JSON line reports"""
+            if stage04 is None:
                 return
-            copies, src, dst, w = graph_to_arcs(h_cn, nt, h_edges)
-            th2 = time.perf_counter()
-            h_last["edges"] = h_edges                     # (a view of the pinned buffer: read right after the last step)
-            if rank == 0:
-                # compact result: components that hold an arc-bearing segment + one bit per bare segment (views, no copies)
-                res = capi.match_decompose_views(g, copies, src, dst, 10, False, compact=True)
-                th3 = time.perf_counter()
-                if not timed or "n_comp" not in last:                                          # bookkeeping for the JSON line only
-                    last.update(n_comp=res.n + res.n_bare, n_cycles=int(res.kind.sum()), n_multi=int(((res.off[1:] - res.off[:-1]) > 1).sum()))
-                    # digest of the step's results: the lines of an N-GPU run and of the 1-GPU run must carry the same one
-                    e64 = np.ascontiguousarray(h_edges).view(np.uint64).reshape(-1, 4)
-                    e64 = e64[np.lexsort((e64[:, 3], e64[:, 2], e64[:, 1], e64[:, 0]))]
-                    hsh = hashlib.sha256()
-                    for arr in (e64, h_cn, np.asarray(res.off), np.asarray(res.verts), np.asarray(res.kind), np.asarray(res.iter), np.asarray(res.bare)):
-                        hsh.update(np.ascontiguousarray(arr).tobytes())
-                    last["digest_graph"] = hsh.hexdigest()[:16]
-                res.free()
-                if timed:
-                    for k_, v_ in (("d2h_graph", th1 - th0), ("glue", th2 - th1), ("match_decompose", th3 - th2)):
-                        host_ms[k_] = host_ms.get(k_, 0.0) + 1e3 * v_ / args.steps
-            last.update(graph=(copies, src, dst, w), n_edges=int(n_e.value), n_cands=int(n_cands), n_arcs=len(src))
+            t0_ = time.perf_counter()
+            res, contig_of = stage04.result()
+            if timed:
+                host_ms["stage04_result_wait_and_copy"] = host_ms.get("stage04_result_wait_and_copy", 0.0) + 1e3 * (time.perf_counter() - t0_) / args.steps
+            if not timed or "n_comp" not in last:
+                cnt = stage04.counts()
+                n_e = int(n_edges_dev.item())
+                capi._check(L.palace_d2h(g.h, cn_host.data_ptr(), P(cn_dev), nt * 4), "d2h")
+                h_edges = e_buf[:n_e].cpu().numpy().view(capi.EDGE_DTYPE).reshape(-1)
+                h_last.update(edges=h_edges, cn=cn_host.numpy().copy())
+                last.update(n_edges=n_e, n_junc=cnt["juncs"], n_kept_junc=cnt["kept_pass2"] + cnt["kept_pass3_more"], n_arcs=cnt["arcs"],
+                            n_segs_filtered=cnt["segs_filtered"], n_segs_rescued=cnt["segs_rescued"],
+                            n_comp=res.n + res.n_bare, n_cycles=int(np.asarray(res.kind).sum()),
+                            n_multi=int(((np.asarray(res.off)[1:] - np.asarray(res.off)[:-1]) > 1).sum()))
+                # digest of the step's results: the lines of an N-GPU run and of the 1-GPU run must carry the same one
+                e64 = np.ascontiguousarray(h_edges).view(np.uint64).reshape(-1, 4)
+                e64 = e64[np.lexsort((e64[:, 3], e64[:, 2], e64[:, 1], e64[:, 0]))]
+                hsh = hashlib.sha256()
+                for arr in (e64, h_last["cn"], np.asarray(res.off), np.asarray(res.verts), np.asarray(res.kind), np.asarray(res.iter),
+                            np.asarray(res.bare), np.asarray(contig_of)):
+                    hsh.update(np.ascontiguousarray(arr).tobytes())
+                last["digest_graph"] = hsh.hexdigest()[:16]
+            h_last["result"] = (res, contig_of)                   # views, valid until the next match call
 
         if exch:
-            # N GPUs: the count-table exchange and Phase B need every rank's host thread for the collectives, so
-            # the host-side matching runs beside them in a second thread (ctypes and numpy release the GIL)
-            # Order on N GPUs: generateGraph's small collectives first (behind a saturating count launch they would
-            # wait for it), then rank 0's host matching in its thread, and beside it counting + exchange + Phase B.
-            worker = match_thread.submit(matching)      # one long-lived thread: the library keeps per-thread scratch
+            # N GPUs: generateGraph's small collectives went first (behind a saturating count launch they would wait for it);
+            # rank 0's stage 04 now runs on its device beside counting + exchange + Phase B
             eref_head()
             eref_tail()
-            worker.result()
-        else:
-            matching()
+        finish_graph()
         # ---------------- join: eref results to the host ----------------
         capi._check(L.palace_d2h(ctx.h, rows_host.data_ptr(), P(rows), rows.numel() * 4), "d2h")
 
@@ -849,12 +901,16 @@ def main():
         soak = dict(steps=n_soak, seconds=time.perf_counter() - t1, ms_per_step=1e3 * (time.perf_counter() - t1) / max(1, n_soak),
                     note="untimed steps also lexsort and sha256 the results for `result_digest` (bookkeeping): not comparable with ms_per_step")
     K = range(args.steps)
-    count_each = [ctx.mark_elapsed(8 * i, 8 * i + 1) for i in K]
-    count_ms = np.mean(count_each)                                                  # one launch per step (both FASTQ sides)
-    merge_ms = np.mean([ctx.mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
-    scan_ms = np.mean([ctx.mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
+    if os.environ.get("PALACE_BENCH_SKIP_EREF") == "1":
+        count_each, count_ms, merge_ms, scan_ms = [1.0], 1.0, 0.0, 0.0
+    else:
+        count_each = [ctx.mark_elapsed(8 * i, 8 * i + 1) for i in K]
+        count_ms = np.mean(count_each)                                              # one launch per step (both FASTQ sides)
+        merge_ms = np.mean([ctx.mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
+        scan_ms = np.mean([ctx.mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
     classify_ms = np.mean([ctx_g.mark_elapsed(8 * i, 8 * i + 1) for i in K])
     resolve_ms = np.mean([ctx_g.mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
+    stage04_ms = np.mean([ctx_g.mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
     r = rows_host.numpy()
     reported = int(((r[:, 1] > 0) & (r[:, 1].astype(np.float32) / r[:, 2].astype(np.float32) > 0.75)).sum())
 
@@ -878,7 +934,10 @@ def main():
                        "result_digest": {"eref_rows": hashlib.sha256(np.ascontiguousarray(r).tobytes()).hexdigest()[:16],
                                          "graph_and_components": last.get("digest_graph"),
                                          "note": "sha256 prefixes of the last step's results; equal for every --gpus N"},
-                       "graph": {k: last[k] for k in ("n_cands", "n_edges", "n_arcs", "n_comp", "n_cycles", "n_multi")}},
+                       "graph": {k: last.get(k) for k in ("n_cands", "n_edges", "n_junc", "n_kept_junc", "n_segs_filtered", "n_segs_rescued", "n_arcs",
+                                                          "n_comp", "n_cycles", "n_multi")},
+                       "stage04": "filter_graph.py's selection (seeds, 1- and 2-hop junctions, contigs.paths rescue) and matching -i 10 -l contigs.paths "
+                                  "on the filtered graph, both on the device (palace_stage04_*), as palace:566-591 runs them on files"},
             "roofline": {"bound": "hbm", "kernel": "eref count_reads (streams + bin1 + bin2 + lds_count kernels of one launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # PMC (separate rocprofv3 passes, profiles/r01q_end_state_fused_launch.md): FETCH_SIZE x2 + WRITE_SIZE of
@@ -886,7 +945,7 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "avg_launch_ms": count_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "stage_ms": {"eref_count_each_step": [round(float(x), 3) for x in count_each], "eref_count_both_sides": count_ms, "eref_table_merge": merge_ms, "eref_scan_refs": scan_ms,
-                         "graph_classify": classify_ms, "graph_resolve": resolve_ms,
+                         "graph_classify": classify_ms, "graph_resolve": resolve_ms, "graph_filter_and_matching_on_device": stage04_ms,
                          **{"host_" + k: v for k, v in host_ms.items()},
                          "note": "eref runs on one HIP stream, generateGraph + matching on another; they overlap"},
         }
@@ -899,14 +958,22 @@ def main():
             try:
                 paths = write_e2e_inputs(torch, sample, gs, hdr, work)
                 n_junc = int((h_last["edges"]["counts"].sum(axis=1) >= 5).sum())
-                out["e2e"] = run_e2e(paths, gs["avg_depth"], args.contigs, r, n_junc)
+                # what the resident step's result reads as text: linear ++ cycles without duplicates (palace:594-600)
+                from palace_amd import stage04_io
+                lin, cyc = stage04_io.matching_text(*h_last["result"], gs["names"], self_loops=True, break_cycles=False)
+                cl = cyc.splitlines(keepends=True)
+                pairs = list(dict.fromkeys(zip(cl[0::2], cl[1::2] + (["\n"] if len(cl) % 2 else []))))      # remove_cycle_dup.py:3-30
+                out["e2e"] = run_e2e(paths, gs["avg_depth"], args.contigs, r, n_junc, lin + "".join(a + b for a, b in pairs))
             except Exception as e:                   # never let this leg break the headline line
                 out["e2e"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             finally:
                 if not os.environ.get("PALACE_BENCH_KEEP"):      # (tools/eref_cli_repeat.sh re-runs the executables on these files)
                     shutil.rmtree(work, ignore_errors=True)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(torch, sample, gs, hdr, args.cpu_sample_frac, last["graph"])
+            res_v, contig_of = h_last["result"]
+            seg_flags, edge_flags = stage04.flags(len(h_last["edges"]))
+            out["cpu_baseline"] = cpu_baseline(torch, sample, gs, hdr, args.cpu_sample_frac,
+                                               dict(contig_of=np.asarray(contig_of).copy(), cn=h_last["cn"], edges=h_last["edges"], edge_flags=edge_flags))
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     capi._check(L.palace_eref_probe_index_free(ctx.h, probe_index), "probe index free")

@@ -65,6 +65,9 @@ int palace_timer_end(palace_ctx *ctx, float *ms_out);
 int palace_mark(palace_ctx *ctx, int i);
 int palace_mark_elapsed(palace_ctx *ctx, int a, int b, float *ms_out);
 int palace_mark_wait(palace_ctx *ctx, int i);
+/* Orders two contexts on the device without the host: work enqueued on `ctx` after this call starts only when mark i of
+ * `other` (recorded before this call) has been reached on other's stream. */
+int palace_wait_for_mark(palace_ctx *ctx, palace_ctx *other, int i);
 
 /* ---- eref: k-mer screening of reads against the phage DB (bin/extract_ref.cpp) ---------- */
 
@@ -313,10 +316,11 @@ int palace_match_arcs_from_edges(const int32_t *cn, int32_t n_segs, const palace
  * open_at[c] = position after the cycle's weakest arc (where -b opens it; 0 for paths).
  * Duplicate and later-round singleton components are NOT filtered here (the caller formats). */
 typedef struct palace_match_result palace_match_result;
-/* Tuning knob (results are identical for every setting): "iters_per_round" = matching iterations enqueued per round before
- * the host looks (0 = default 12, at most 64).  The decomposition runs on the device without the host in the loop; a round
- * that needs more iterations than were enqueued is detected at the end and the whole decomposition is redone with the host
- * checking every round's fixed point. */
+/* Tuning knob (results are identical for every setting).  The decomposition runs on the device, one launch per phase, enqueued
+ * a group of rounds at a time with a fixed number of matching iterations per round (7 in the first round, 4 later; the
+ * iterations behind a round's fixed point return at once); the host looks at the state after each group, stops as soon as no
+ * segment keeps a copy, and redoes the decomposition with a check after every batch of iterations should a round not have
+ * settled.  "iters_per_round" overrides the number of iterations (0 = defaults, at most 64; 1 forces the checked path). */
 int palace_match_set_option(palace_ctx *ctx, const char *name, int64_t value);
 int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
                            const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
@@ -384,6 +388,12 @@ int palace_stage04_counts(palace_ctx *ctx, palace_stage04 *s, int64_t counts[8])
  * aggressive per filter call's reservation). */
 int palace_stage04_match(palace_ctx *ctx, palace_stage04 *s, const palace_graph_edge *d_edges, const int32_t *d_cn,
                          int32_t iterations, int32_t aggressive, int32_t use_paths);
+/* The same, with the rounds of the decomposition -- a few hundred small, latency-bound launches -- starting only when mark
+ * `mark` of context `other` has been reached on the device (palace_wait_for_mark); the arcs are built at once.  For a caller
+ * that runs bandwidth-bound kernels on another stream (eref's counting kernels): every kernel boundary beside them costs
+ * them microseconds, beside small kernels it costs nothing. */
+int palace_stage04_match_after(palace_ctx *ctx, palace_stage04 *s, const palace_graph_edge *d_edges, const int32_t *d_cn,
+                               int32_t iterations, int32_t aggressive, int32_t use_paths, palace_ctx *other, int32_t mark);
 /* Waits and hands out the result in the compact form of palace_match_decompose_ex (vertices 2 * segment + orientation,
  * segments = ids of the filtered graph; bare segments as bits), owned by `s` (valid until the next match call or destroy;
  * palace_match_result_free on it does nothing), and contig_of[filtered segment] -> contig (n_segs_filtered entries). */

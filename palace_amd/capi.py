@@ -77,6 +77,7 @@ _SIGS = {
     "palace_host_free": [C.c_void_p, C.c_void_p],
     "palace_h2d_async": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "palace_mark_wait": [C.c_void_p, C.c_int],
+    "palace_wait_for_mark": [C.c_void_p, C.c_void_p, C.c_int],
     "palace_timer_begin": [C.c_void_p],
     "palace_timer_end": [C.c_void_p, C.POINTER(C.c_float)],
     "palace_mark": [C.c_void_p, C.c_int],
@@ -131,6 +132,7 @@ _SIGS = {
     "palace_stage04_flags": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64],
     "palace_stage04_counts": [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],
     "palace_stage04_match": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32],
+    "palace_stage04_match_after": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32],
     "palace_stage04_result": [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)],
 }
 
@@ -241,6 +243,9 @@ class Ctx:
 
     def mark(self, i: int):
         _check(lib().palace_mark(self.h, i), "palace_mark")
+
+    def wait_for_mark(self, other: "Ctx", i: int):
+        _check(lib().palace_wait_for_mark(self.h, other.h, i), "palace_wait_for_mark")
 
     def mark_elapsed(self, a: int, b: int) -> float:
         ms = C.c_float()
@@ -441,9 +446,12 @@ class Stage04:
                "palace_stage04_flags")
         return seg, edge
 
-    def match(self, d_edges_ptr: int, d_cn_ptr: int, iterations: int = 10, aggressive: bool = False, use_paths: bool = True):
-        _check(lib().palace_stage04_match(self.ctx.h, self.h, d_edges_ptr, d_cn_ptr, iterations, int(aggressive), int(use_paths)),
-               "palace_stage04_match")
+    def match(self, d_edges_ptr: int, d_cn_ptr: int, iterations: int = 10, aggressive: bool = False, use_paths: bool = True,
+              after: "tuple[Ctx, int] | None" = None):
+        """after = (other context, mark): the decomposition's rounds start when that mark is reached on the device"""
+        other, mark = (after[0].h, after[1]) if after else (None, 0)
+        _check(lib().palace_stage04_match_after(self.ctx.h, self.h, d_edges_ptr, d_cn_ptr, iterations, int(aggressive), int(use_paths),
+                                                other, mark), "palace_stage04_match")
 
     def result(self):
         """-> (MatchResult view with .bare / .n_bare, contig_of array view); valid until the next match() / close()"""

@@ -255,6 +255,13 @@ int palace_mark(palace_ctx *ctx, int i)
     return PALACE_OK;
 }
 
+int palace_wait_for_mark(palace_ctx *ctx, palace_ctx *other, int i)
+{
+    PALACE_REQUIRE(ctx && other && i >= 0 && static_cast<size_t>(i) < other->marks.size() && other->marks[i], "mark not recorded");
+    PALACE_HIP_TRY(hipStreamWaitEvent(ctx->stream, other->marks[i], 0));
+    return PALACE_OK;
+}
+
 int palace_mark_elapsed(palace_ctx *ctx, int a, int b, float *ms_out)
 {
     PALACE_REQUIRE(ctx && ms_out && a >= 0 && b >= 0 && static_cast<size_t>(a) < ctx->marks.size() &&

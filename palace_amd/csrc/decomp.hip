@@ -20,6 +20,8 @@
 //                writes the vertices out and charges the copy numbers.
 #include "decomp.hpp"
 
+#include <algorithm>
+
 namespace palace {
 
 namespace {
@@ -28,8 +30,6 @@ constexpr uint64_t kNoKey = ~0ull;
 constexpr int kStampShift = 42;                        // khi < 2^42; the iteration stamp lives above
 constexpr uint64_t kLenMask = (1ull << 40) - 1;
 
-__device__ __forceinline__ int tid_global() { return static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x); }
-__device__ __forceinline__ int n_threads() { return static_cast<int>(gridDim.x * blockDim.x); }
 
 // ---- exclusive scan over u64, count on the device -------------------------------------------------------------------
 __device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, int lane)
@@ -42,28 +42,32 @@ __device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, int lane)
     return v;
 }
 
-__global__ __launch_bounds__(kDecompBlock) void scan_partials_kernel(const uint64_t *__restrict__ in, const int32_t *__restrict__ n_dev,
-                                                                     uint64_t *__restrict__ partials)
+constexpr int kMaxWaves = 16;                          // workgroups of up to 1024 threads
+
+// the three steps of an exclusive scan over `n` values by `nblk` workgroups (this one is number `blk`): chunk sums, their
+// prefix (one workgroup, nblk <= its size), the chunks
+__device__ void scan_partials_body(const uint64_t *__restrict__ in, int64_t n, uint64_t *__restrict__ partials, int blk, int nblk)
 {
-    __shared__ uint64_t part[kDecompBlock / 64];
-    const int64_t n = *n_dev, chunk = (n + gridDim.x - 1) / gridDim.x;
-    const int64_t a = min(n, static_cast<int64_t>(blockIdx.x) * chunk), e = min(n, a + chunk);
+    __shared__ uint64_t part[kMaxWaves];
+    const int64_t chunk = (n + nblk - 1) / nblk;
+    const int64_t a = min(n, static_cast<int64_t>(blk) * chunk), e = min(n, a + chunk);
     uint64_t s = 0;
     for (int64_t i = a + threadIdx.x; i < e; i += blockDim.x) s += in[i];
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, waves = static_cast<int>(blockDim.x >> 6);
     s = wave_incl_scan(s, lane);
     if (lane == 63) part[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint64_t t = 0;
-        for (int w = 0; w < kDecompBlock / 64; w++) t += part[w];
-        partials[blockIdx.x] = t;
+        for (int w = 0; w < waves; w++) t += part[w];
+        partials[blk] = t;
     }
+    __syncthreads();
 }
 
-__global__ __launch_bounds__(kDecompBlock) void scan_prefix_kernel(uint64_t *__restrict__ partials, int n_parts, uint64_t *__restrict__ total)
+__device__ void scan_prefix_body(uint64_t *__restrict__ partials, int n_parts, uint64_t *__restrict__ total)
 {
-    __shared__ uint64_t part[kDecompBlock / 64];
+    __shared__ uint64_t part[kMaxWaves];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t x = static_cast<int>(threadIdx.x) < n_parts ? partials[threadIdx.x] : 0;
     const uint64_t incl = wave_incl_scan(x, lane);
@@ -72,17 +76,18 @@ __global__ __launch_bounds__(kDecompBlock) void scan_prefix_kernel(uint64_t *__r
     uint64_t before = 0;
     for (int w = 0; w < wv; w++) before += part[w];
     if (static_cast<int>(threadIdx.x) < n_parts) partials[threadIdx.x] = before + incl - x;
-    if (threadIdx.x == kDecompBlock - 1) *total = before + incl;
+    if (threadIdx.x == blockDim.x - 1) *total = before + incl;
+    __syncthreads();
 }
 
-__global__ __launch_bounds__(kDecompBlock) void scan_apply_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
-                                                                  const int32_t *__restrict__ n_dev, const uint64_t *__restrict__ partials)
+__device__ void scan_apply_body(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, int64_t n, const uint64_t *__restrict__ partials,
+                                int blk, int nblk)
 {
-    __shared__ uint64_t part[kDecompBlock / 64];
-    const int64_t n = *n_dev, chunk = (n + gridDim.x - 1) / gridDim.x;
-    const int64_t a = min(n, static_cast<int64_t>(blockIdx.x) * chunk), e = min(n, a + chunk);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint64_t carry = partials[blockIdx.x];
+    __shared__ uint64_t part[kMaxWaves];
+    const int64_t chunk = (n + nblk - 1) / nblk;
+    const int64_t a = min(n, static_cast<int64_t>(blk) * chunk), e = min(n, a + chunk);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = static_cast<int>(blockDim.x >> 6);
+    uint64_t carry = partials[blk];
     for (int64_t base = a; base < e; base += blockDim.x) {
         const int64_t i = base + threadIdx.x;
         const uint64_t x = i < e ? in[i] : 0;
@@ -90,31 +95,52 @@ __global__ __launch_bounds__(kDecompBlock) void scan_apply_kernel(const uint64_t
         if (lane == 63) part[wv] = incl;
         __syncthreads();
         uint64_t before = 0, all = 0;
-        for (int w = 0; w < kDecompBlock / 64; w++) { if (w < wv) before += part[w]; all += part[w]; }
+        for (int w = 0; w < waves; w++) { if (w < wv) before += part[w]; all += part[w]; }
         if (i < e) out[i] = carry + before + incl - x;
         carry += all;
         __syncthreads();
     }
 }
 
-// ---- decomposition -----------------------------------------------------------------------------------------------------
-__global__ void dec_init_kernel(DecompBufs b, int64_t comp_cap, int64_t vert_cap, int n_flags)
+__global__ __launch_bounds__(kDecompBlock) void scan_partials_kernel(const uint64_t *__restrict__ in, const int32_t *__restrict__ n_dev,
+                                                                     uint64_t *__restrict__ partials)
+{
+    scan_partials_body(in, *n_dev, partials, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+}
+__global__ __launch_bounds__(kDecompBlock) void scan_prefix_kernel(uint64_t *__restrict__ partials, int n_parts, uint64_t *__restrict__ total)
+{
+    scan_prefix_body(partials, n_parts, total);
+}
+__global__ __launch_bounds__(kDecompBlock) void scan_apply_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                                  const int32_t *__restrict__ n_dev, const uint64_t *__restrict__ partials)
+{
+    scan_apply_body(in, out, *n_dev, partials, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+}
+
+// ---- decomposition: the phases as device functions over a span of threads (T.tid of T.n), launched as
+// one kernel per phase ----
+struct Span { int tid, n; };
+__device__ __forceinline__ Span whole_grid() { return Span{static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x), static_cast<int>(gridDim.x * blockDim.x)}; }
+
+__device__ void ph_init(const DecompBufs &b, Span T, int64_t comp_cap, int64_t vert_cap, int n_flags)
 {
     DecompState *st = b.st;
     const int V = st->V;
-    for (int i = tid_global(); i < V; i += n_threads()) { b.bo_hi[i] = kNoKey; b.bi_hi[i] = kNoKey; b.on_path[i] = 0; }
-    for (int i = tid_global(); i < n_flags; i += n_threads()) b.changed[i] = 0;
-    if (tid_global() == 0) {
+    for (int i = T.tid; i < V; i += T.n) { b.bo_hi[i] = kNoKey; b.bi_hi[i] = kNoKey; b.on_path[i] = 0; }
+    for (int i = T.tid; i < n_flags; i += T.n) b.changed[i] = 0;
+    if (T.tid == 0) {
         st->n_comp = 0; st->n_vert = 0; st->comp_cap = comp_cap; st->vert_cap = vert_cap;
-        st->unsettled = 0; st->overflow = 0; st->scan_total = 0;
+        st->unsettled = 0; st->overflow = 0; st->bad = 0; st->dead = 0; st->scan_total = 0; st->alive_after = 0;
         if (comp_cap >= 0) b.o_off[0] = 0;
     }
 }
 
-__global__ void dec_round_begin_kernel(DecompBufs b, int reset_left)
+__device__ void ph_round_begin(const DecompBufs &b, Span T, int reset_left)
 {
     const int V = b.st->V;
-    for (int i = tid_global(); i < V; i += n_threads()) {
+    if (!reset_left && b.st->dead) return;                     // nobody kept a copy: this round is empty (the aggressive round hands out new ones)
+    if (T.tid == 0) { b.st->alive_after = 0; if (reset_left) b.st->dead = 0; }
+    for (int i = T.tid; i < V; i += T.n) {
         const int s = i >> 1;
         const int64_t l = reset_left ? 1 : b.left[s];          // the aggressive round: every segment gets one more copy
         if (reset_left && !(i & 1)) b.left[s] = 1;
@@ -139,13 +165,14 @@ __device__ __forceinline__ bool arc_open(const DecompBufs &b, int u, int v)
 
 // pass 1: stamped khi into both slots; the klo halves of the OTHER parity (written one iteration ago, needed again in the
 // next one) are reset here, where nothing writes next / prev and "open" is the same for every thread that looks
-__global__ void dec_propose_hi_kernel(DecompBufs b, IterArgs a)
+__device__ void ph_propose_hi(const DecompBufs &b, Span T, const IterArgs &a)
 {
+    if (b.st->dead) return;
     if (a.prev_flag >= 0 && !b.changed[a.prev_flag]) return;           // the round reached its fixed point
     const int64_t E = b.st->E;
     const int V = b.st->V;
     const int other = (a.parity ^ 1) * V;
-    for (int64_t e = tid_global(); e < E; e += n_threads()) {
+    for (int64_t e = T.tid; e < E; e += T.n) {
         const int u = b.src[e], v = b.dst[e];
         if (!arc_open(b, u, v)) continue;
         const uint64_t k = a.stamp | b.khi[e];
@@ -156,12 +183,13 @@ __global__ void dec_propose_hi_kernel(DecompBufs b, IterArgs a)
 }
 
 // pass 2: among the arcs that tie on khi in a slot, the smallest klo
-__global__ void dec_propose_lo_kernel(DecompBufs b, IterArgs a)
+__device__ void ph_propose_lo(const DecompBufs &b, Span T, const IterArgs &a)
 {
+    if (b.st->dead) return;
     if (a.prev_flag >= 0 && !b.changed[a.prev_flag]) return;
     const int64_t E = b.st->E;
     const int mine = a.parity * b.st->V;
-    for (int64_t e = tid_global(); e < E; e += n_threads()) {
+    for (int64_t e = T.tid; e < E; e += T.n) {
         const int u = b.src[e], v = b.dst[e];
         if (!arc_open(b, u, v)) continue;
         const uint64_t k = a.stamp | b.khi[e], lo = b.klo[e];
@@ -171,12 +199,19 @@ __global__ void dec_propose_lo_kernel(DecompBufs b, IterArgs a)
 }
 
 // pass 3: an arc that is the best of both its slots is taken (slot owners are unique: keys are distinct)
-__global__ void dec_commit_kernel(DecompBufs b, IterArgs a)
+__device__ void ph_commit_flag(const DecompBufs &b, Span T, const IterArgs &a, volatile unsigned int *took);
+__device__ void ph_commit(const DecompBufs &b, Span T, const IterArgs &a)
 {
+    if (b.st->dead) return;
     if (a.prev_flag >= 0 && !b.changed[a.prev_flag]) return;
+    ph_commit_flag(b, T, a, b.changed + a.flag);
+}
+__device__ void ph_commit_flag(const DecompBufs &b, Span T, const IterArgs &a, volatile unsigned int *took)
+{
+    bool any = false;
     const int64_t E = b.st->E;
     const int mine = a.parity * b.st->V;
-    for (int64_t e = tid_global(); e < E; e += n_threads()) {
+    for (int64_t e = T.tid; e < E; e += T.n) {
         const int u = b.src[e], v = b.dst[e];
         if (!arc_open(b, u, v)) continue;            // (a slot taken a moment ago by another arc of this pass reads as closed: that arc held the slot's best key, not this one)
         const uint64_t k = a.stamp | b.khi[e], lo = b.klo[e];
@@ -184,18 +219,20 @@ __global__ void dec_commit_kernel(DecompBufs b, IterArgs a)
         if (!a.unique_hi && (b.bo_lo[mine + u] != lo || b.bi_lo[mine + v] != lo)) continue;
         b.next[u] = v; b.prev[v] = u;
         b.nhi[u] = b.khi[e]; b.nlo[u] = lo;
-        b.changed[a.flag] = 1u;
+        any = true;
     }
+    if (__syncthreads_or(any) && threadIdx.x == 0) *took = 1u;         // one store per workgroup, not one per arc, to the one word
 }
 
 // open walks: every live vertex without predecessor walks to the end of its path; the walker whose first vertex is the smaller
 // one of {P, conj P} reports
-__global__ void dec_heads_kernel(DecompBufs b, int round, int last_flag)
+__device__ void ph_heads(const DecompBufs &b, Span T, int round, int last_flag)
 {
     DecompState *st = b.st;
-    if (tid_global() == 0 && last_flag >= 0 && b.changed[last_flag]) st->unsettled = 1;
+    if (st->dead) return;
+    if (T.tid == 0 && last_flag >= 0 && b.changed[last_flag]) st->unsettled = 1;
     const int V = st->V;
-    for (int v = tid_global(); v < V; v += n_threads()) {
+    for (int v = T.tid; v < V; v += T.n) {
         if (!b.alive[v] || b.prev[v] >= 0) continue;
         int len = 0, last = v;
         int64_t least = b.left[v >> 1];
@@ -217,10 +254,11 @@ __global__ void dec_heads_kernel(DecompBufs b, int round, int last_flag)
 
 // closed walks: a live vertex no open walk reached lies on a cycle; it walks until it meets a smaller vertex (then it is not
 // the cycle's first vertex) or itself
-__global__ void dec_cycles_kernel(DecompBufs b, int round)
+__device__ void ph_cycles(const DecompBufs &b, Span T, int round)
 {
     const int V = b.st->V;
-    for (int v = tid_global(); v < V; v += n_threads()) {
+    if (b.st->dead) return;
+    for (int v = T.tid; v < V; v += T.n) {
         if (!b.alive[v] || b.on_path[v] == round + 1) continue;
         int len = 1, twin_least = v ^ 1, worst = 0;
         uint64_t whi = b.nhi[v], wlo = b.nlo[v];
@@ -244,12 +282,13 @@ __global__ void dec_cycles_kernel(DecompBufs b, int round)
 }
 
 // second walk of the reporting vertices: the component into the output arrays, copies charged
-__global__ void dec_emit_kernel(DecompBufs b, int round)
+__device__ void ph_emit(const DecompBufs &b, Span T, int round, int64_t c0, int64_t v0)
 {
     DecompState *st = b.st;
     const int V = st->V;
-    const int64_t c0 = st->n_comp, v0 = st->n_vert;
-    for (int v = tid_global(); v < V; v += n_threads()) {
+    if (st->dead) return;
+    int64_t alive = 0;
+    for (int v = T.tid; v < V; v += T.n) {
         const uint64_t la = b.len_a[v];
         if (!la) continue;
         const int64_t len = static_cast<int64_t>(la & kLenMask);
@@ -260,19 +299,41 @@ __global__ void dec_emit_kernel(DecompBufs b, int round)
         if (!room) st->overflow = 1;
         else { b.o_off[c] = at; b.o_kind[c] = b.kind[v]; b.o_iter[c] = round; b.o_open[c] = b.open_at[v]; }
         int x = v;
+        int64_t still = 0;                                         // vertices of this component whose segment keeps copies
         for (int64_t k = 0; k < len; k++) {
             if (room) b.o_verts[at + k] = 2 * b.orig[x >> 1] + (x & 1);
             const int64_t l = b.left[x >> 1];
             b.left[x >> 1] = max(static_cast<int64_t>(0), l - pay);
+            still += l - pay > 0;
             x = b.next[x];
         }
+        alive += still;
     }
+    // one add per workgroup
+    __shared__ unsigned long long wg_alive;
+    if (threadIdx.x == 0) wg_alive = 0;
+    __syncthreads();
+    if (alive) atomicAdd(&wg_alive, static_cast<unsigned long long>(alive));
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_alive) atomicAdd(reinterpret_cast<unsigned long long *>(&st->alive_after), wg_alive);
 }
+
+
+// one kernel per phase
+__global__ void dec_init_kernel(DecompBufs b, int64_t comp_cap, int64_t vert_cap, int n_flags) { ph_init(b, whole_grid(), comp_cap, vert_cap, n_flags); }
+__global__ void dec_round_begin_kernel(DecompBufs b, int reset_left) { ph_round_begin(b, whole_grid(), reset_left); }
+__global__ void dec_propose_hi_kernel(DecompBufs b, IterArgs a) { ph_propose_hi(b, whole_grid(), a); }
+__global__ void dec_propose_lo_kernel(DecompBufs b, IterArgs a) { ph_propose_lo(b, whole_grid(), a); }
+__global__ void dec_commit_kernel(DecompBufs b, IterArgs a) { ph_commit(b, whole_grid(), a); }
+__global__ void dec_heads_kernel(DecompBufs b, int round, int last_flag) { ph_heads(b, whole_grid(), round, last_flag); }
+__global__ void dec_cycles_kernel(DecompBufs b, int round) { ph_cycles(b, whole_grid(), round); }
+__global__ void dec_emit_kernel(DecompBufs b, int round) { ph_emit(b, whole_grid(), round, b.st->n_comp, b.st->n_vert); }
 
 __global__ void dec_round_end_kernel(DecompBufs b)
 {
     DecompState *st = b.st;
-    if (tid_global() != 0) return;
+    if (blockIdx.x || threadIdx.x || st->dead) return;
+    st->dead = st->alive_after == 0;
     st->n_comp += static_cast<int64_t>(st->scan_total >> 40);
     st->n_vert += static_cast<int64_t>(st->scan_total & kLenMask);
     if (st->n_comp <= st->comp_cap) b.o_off[st->n_comp] = st->n_vert;       // (o_off has comp_cap + 1 entries)
@@ -371,17 +432,23 @@ int enqueue_read_off(palace_ctx *ctx, const DecompBufs &b, int round, int last_f
 
 }  // namespace
 
-int decomp_enqueue(palace_ctx *ctx, const DecompBufs &b, int rounds, int aggressive, int iters, bool unique_hi,
-                   int64_t comp_cap, int64_t vert_cap)
+int decomp_begin(palace_ctx *ctx, const DecompBufs &b, int rounds, int64_t comp_cap, int64_t vert_cap)
 {
-    PALACE_REQUIRE(rounds >= 1 && rounds <= kMaxRounds && iters >= 1 && iters <= kMaxIters, "round / iteration count out of range");
+    PALACE_REQUIRE(rounds >= 1 && rounds <= kMaxRounds, "round count out of range");
     static_assert(kDecompGrid <= kDecompBlock, "scan_prefix_kernel scans the block sums with one workgroup");
-    hipLaunchKernelGGL(dec_init_kernel, kGrid, kBlock, 0, ctx->stream, b, comp_cap, vert_cap, rounds * iters);
-    uint64_t count = 0;                                                     // < 2^16: the stamp fits above bit 42
-    for (int t = 0; t < rounds; t++) {
+    hipLaunchKernelGGL(dec_init_kernel, kGrid, kBlock, 0, ctx->stream, b, comp_cap, vert_cap, rounds * kMaxIters);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+int decomp_rounds(palace_ctx *ctx, const DecompBufs &b, int t0, int t1, int rounds, int aggressive, int iters, bool unique_hi,
+                  uint64_t *count)
+{
+    PALACE_REQUIRE(0 <= t0 && t0 <= t1 && t1 <= rounds && rounds <= kMaxRounds && iters >= 1 && iters <= kMaxIters, "round / iteration count out of range");
+    for (int t = t0; t < t1; t++) {
         hipLaunchKernelGGL(dec_round_begin_kernel, kGrid, kBlock, 0, ctx->stream, b, (aggressive && t == rounds - 1) ? 1 : 0);
-        enqueue_iterations(ctx, b, 0, iters, &count, t * iters, unique_hi);
-        int rc = enqueue_read_off(ctx, b, t, t * iters + iters - 1);
+        enqueue_iterations(ctx, b, 0, iters, count, t * kMaxIters, unique_hi);       // stamps descend over the whole decomposition
+        int rc = enqueue_read_off(ctx, b, t, t * kMaxIters + iters - 1);
         if (rc) return rc;
     }
     PALACE_HIP_TRY(hipGetLastError());
@@ -417,6 +484,46 @@ int decomp_run_checked(palace_ctx *ctx, const DecompBufs &b, int rounds, int agg
         if (rc) return rc;
     }
     return PALACE_OK;
+}
+
+int decomp_group(palace_ctx *ctx, const DecompBufs &b, DecompRun &run, int rounds, int aggressive, bool unique_hi)
+{
+    const int t0 = run.next_round, t1 = std::min(rounds, t0 + kRoundsPerGroup);
+    for (int t = t0; t < t1; t++) {
+        const int iters = ctx->match_iters > 0 ? std::min(ctx->match_iters, kMaxIters) : (t == 0 ? kFirstRoundIters : kLaterRoundIters);
+        int rc = decomp_rounds(ctx, b, t, t + 1, rounds, aggressive, iters, unique_hi, &run.count);
+        if (rc) return rc;
+    }
+    run.next_round = t1;
+    return PALACE_OK;
+}
+
+int decomp_finish(palace_ctx *ctx, const DecompBufs &b, DecompRun &run, int rounds, int aggressive, bool unique_hi, int64_t comp_cap,
+                  int64_t vert_cap, int64_t max_iterations, DecompState *h_state, const std::function<int()> &reset_left)
+{
+    for (;;) {
+        PALACE_HIP_TRY(hipMemcpyAsync(h_state, b.st, sizeof *h_state, hipMemcpyDeviceToHost, ctx->stream));
+        PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (h_state->unsettled) {
+            // a round was still taking arcs in its last enqueued iteration (long chains of ascending weights): the whole
+            // decomposition once more, with the host watching every round's fixed point
+            int rc = reset_left();
+            if (rc) return rc;
+            rc = decomp_run_checked(ctx, b, rounds, aggressive, unique_hi, comp_cap, vert_cap, max_iterations);
+            if (rc) return rc;
+            PALACE_HIP_TRY(hipMemcpyAsync(h_state, b.st, sizeof *h_state, hipMemcpyDeviceToHost, ctx->stream));
+            PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            return PALACE_OK;
+        }
+        if (run.next_round >= rounds) return PALACE_OK;
+        if (h_state->alive_after == 0) {
+            // nobody keeps a copy: every further round is empty -- except an aggressive last round, which hands every segment one
+            if (!aggressive) return PALACE_OK;
+            run.next_round = rounds - 1;
+        }
+        int rc = decomp_group(ctx, b, run, rounds, aggressive, unique_hi);
+        if (rc) return rc;
+    }
 }
 
 }  // namespace palace

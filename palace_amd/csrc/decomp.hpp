@@ -2,6 +2,8 @@
 // feed it: palace_match_decompose[_ex] (arcs ranked by the host, match.hip) and the resident stage-04 path (arcs built on the
 // device from the filtered graph, filter.hip).  Not part of the C ABI.
 #pragma once
+#include <functional>
+
 #include "common.hpp"
 
 // the result object of the C ABI (palace_match_result_* accessors, match.hip); the resident stage-04 object (filter.hip) hands
@@ -32,9 +34,10 @@ struct DecompState {
     int64_t comp_cap, vert_cap;            // room in the output arrays
     uint32_t unsettled;                    // a round ran out of enqueued matching iterations before its fixed point
     uint32_t overflow;                     // output arrays too small
-    uint32_t bad;                          // inconsistent input (filter path: unknown contig in contigs.paths, ...)
-    uint32_t pad;
+    uint32_t bad;                          // (unused)
+    uint32_t dead;                         // no segment kept a copy in the last round: the kernels of further ordinary rounds return at once
     uint64_t scan_total;                   // last scan: sum of all inputs
+    int64_t alive_after;                   // vertices reported in the last round whose segment still has copies (0: later rounds are empty)
 };
 
 struct DecompBufs {
@@ -65,11 +68,24 @@ struct DecompBufs {
 size_t decomp_bytes(int64_t s_cap, int64_t e_cap, int64_t comp_cap, int64_t vert_cap, int rounds, int iters);
 // lays the arrays of `b` out in [base, base + decomp_bytes(...))
 void decomp_carve(DecompBufs &b, char *base, int64_t s_cap, int64_t e_cap, int64_t comp_cap, int64_t vert_cap, int rounds, int iters);
-// Enqueue the whole decomposition on the context's stream (no host synchronisation): `rounds` rounds of at most `iters`
-// matching iterations each.  b.st->S/V/E, the arcs, left and orig must be in place (stream order); comp_cap / vert_cap are
-// stored into the state.  When `unique_hi`, khi alone ranks the arcs (the second proposal pass is skipped).
-int decomp_enqueue(palace_ctx *ctx, const DecompBufs &b, int rounds, int aggressive, int iters, bool unique_hi,
-                   int64_t comp_cap, int64_t vert_cap);
+// The decomposition is enqueued in pieces, none of which waits for the host: decomp_begin (state, slot arrays), then
+// decomp_rounds for rounds [t0, t1) with `iters` matching iterations each (the ones behind a round's fixed point return at
+// once; a round that was still taking arcs in its last enqueued iteration sets st->unsettled).  b.st->S/V/E, the arcs, left
+// and orig must be in place (stream order).  `count` carries the iteration stamp from call to call.  When `unique_hi`, khi
+// alone ranks the arcs (the second proposal pass is skipped).  After a group of rounds the caller reads the state back:
+// alive_after == 0 means every later round is empty (all but an `aggressive` last one can be skipped).
+constexpr int kFirstRoundIters = 7, kLaterRoundIters = 4, kRoundsPerGroup = 5;
+int decomp_begin(palace_ctx *ctx, const DecompBufs &b, int rounds, int64_t comp_cap, int64_t vert_cap);
+int decomp_rounds(palace_ctx *ctx, const DecompBufs &b, int t0, int t1, int rounds, int aggressive, int iters, bool unique_hi,
+                  uint64_t *count);
+
+// The usual way through: decomp_begin, decomp_group (the next kRoundsPerGroup rounds; only enqueues), then decomp_finish, which
+// reads the state back after every group, enqueues further groups while segments keep copies, and redoes the decomposition
+// with decomp_run_checked (after `reset_left` has put the copy numbers back) should a round not have settled.  h_state: pinned.
+struct DecompRun { int next_round = 0; uint64_t count = 0; };
+int decomp_group(palace_ctx *ctx, const DecompBufs &b, DecompRun &run, int rounds, int aggressive, bool unique_hi);
+int decomp_finish(palace_ctx *ctx, const DecompBufs &b, DecompRun &run, int rounds, int aggressive, bool unique_hi, int64_t comp_cap,
+                  int64_t vert_cap, int64_t max_iterations, DecompState *h_state, const std::function<int()> &reset_left);
 
 // The same with the host checking for each round's fixed point (any number of iterations); synchronises the stream.
 int decomp_run_checked(palace_ctx *ctx, const DecompBufs &b, int rounds, int aggressive, bool unique_hi, int64_t comp_cap,

@@ -13,7 +13,9 @@
 // Every kernel is grid-stride with a fixed grid and reads its counts from device memory: the call sequence is the same for
 // every sample, nothing waits for the host, and the host reads results back once.
 #include <algorithm>
+#include <cstdlib>
 #include <memory>
+#include <vector>
 
 #include "common.hpp"
 #include "decomp.hpp"
@@ -27,6 +29,8 @@ constexpr uint64_t kWeightTop = 1ull << 40;           // arc weights are below t
 struct FilterState {                                  // device scalars
     int32_t n_segs, S_f, n_sel, n_resc;
     int64_t n_edges, n_junc, n_kept2, n_kept3, n_arcs;
+    int64_t n_static, n_dyn;                          // arcs backed by contigs.paths / junction arcs beside them
+    int64_t n_path_arcs;                              // (create) distinct arcs of contigs.paths
     uint32_t bad, pad;
     uint64_t scan_total;
 };
@@ -38,6 +42,18 @@ struct ArcTable {
     uint32_t *backed;
     uint64_t mask;
     int64_t *list, list_cap;                          // slots in insertion order
+};
+
+// contigs.paths as matching -l uses it, once per sample: the distinct arcs (and conjugates) its consecutive tokens back, as
+// oriented CONTIG vertices (2 * contig + minus), in a hash table for look-up plus a list; which of them exist in a filtered
+// graph is a matter of which contigs that graph keeps
+struct PathArcs {
+    uint64_t *key;                                    // hash: (u << 32 | v), kEmptyKey = free
+    int32_t *idx;                                     //       -> position in the list
+    uint64_t mask;
+    int32_t *u, *v;                                   // the list
+    int32_t *arc_of;                                  // per step: arc number the entry got in the filtered graph, -1 = not in it
+    int64_t n, cap;
 };
 
 struct F {                                            // what the kernels see
@@ -53,8 +69,13 @@ struct F {                                            // what the kernels see
     int32_t *fid, *contig_of;
     uint64_t *scan_in, *scan_out;
     int64_t edge_bound;
-    ArcTable t;
+    ArcTable t;                                       // junction arcs that no path backs (per step)
+    PathArcs pa;
     int32_t *arc_u, *arc_v;                           // filtered-graph vertex ids of the merged arcs
+    unsigned long long *arc_w;                        // their weights
+    uint8_t *arc_backed;
+    int64_t arc_cap;
+    int use_paths;
     uint64_t *bare;
 };
 
@@ -77,7 +98,7 @@ __global__ void st4_begin_kernel(F f, const int64_t *__restrict__ d_n_edges)
         const int64_t n = *d_n_edges;
         fs->n_segs = f.n_segs; fs->S_f = 0; fs->n_sel = 0; fs->n_resc = 0;
         fs->n_edges = n < 0 ? 0 : (n > f.edge_bound ? f.edge_bound : n);
-        fs->n_junc = 0; fs->n_kept2 = 0; fs->n_kept3 = 0; fs->n_arcs = 0;
+        fs->n_junc = 0; fs->n_kept2 = 0; fs->n_kept3 = 0; fs->n_arcs = 0; fs->n_static = 0; fs->n_dyn = 0;
         fs->bad = n > f.edge_bound ? kBadEdgeBound : 0u;
         fs->scan_total = 0;
     }
@@ -183,8 +204,96 @@ __device__ __forceinline__ uint64_t mix(uint64_t x)
     return x;
 }
 
-__device__ void bump_arc(const F &f, int32_t u, int32_t v, int64_t w, bool backed)
+// create(): the distinct arcs of contigs.paths (consecutive tokens of a line; an unknown id breaks the chain) and their conjugates
+__device__ void path_arc_insert(const F &f, int32_t u, int32_t v)
 {
+    const PathArcs &pa = f.pa;
+    const uint64_t key = (static_cast<uint64_t>(static_cast<uint32_t>(u)) << 32) | static_cast<uint32_t>(v);
+    uint64_t s = mix(key) & pa.mask;
+    for (uint64_t probes = 0; probes <= pa.mask; probes++) {
+        const uint64_t cur = pa.key[s];
+        if (cur == key) return;
+        if (cur == kEmptyKey) {
+            const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(&pa.key[s]), kEmptyKey, key);
+            if (old == kEmptyKey) {
+                const int64_t at = static_cast<int64_t>(atomicAdd(reinterpret_cast<unsigned long long *>(&f.fs->n_path_arcs), 1ull));
+                if (at < pa.cap) { pa.u[at] = u; pa.v[at] = v; pa.idx[s] = static_cast<int32_t>(at); }
+                return;
+            }
+            if (old == key) return;
+        }
+        s = (s + 1) & pa.mask;
+    }
+}
+__global__ void st4_path_arcs_kernel(F f)
+{
+    for (int64_t p = gtid(); p < f.n_paths; p += gsize()) {
+        int32_t before = -1;
+        for (int64_t k = f.path_off[p]; k < f.path_off[p + 1]; k++) {
+            const int32_t here = f.path_tok[k];
+            if (before >= 0 && here >= 0) {
+                path_arc_insert(f, before, here);
+                if ((here ^ 1) != before) path_arc_insert(f, here ^ 1, before ^ 1);       // the conjugate (make_final_fa.py:20-34)
+            }
+            before = here;
+        }
+    }
+}
+__device__ __forceinline__ int32_t path_arc_find(const PathArcs &pa, int32_t u, int32_t v)
+{
+    const uint64_t key = (static_cast<uint64_t>(static_cast<uint32_t>(u)) << 32) | static_cast<uint32_t>(v);
+    uint64_t s = mix(key) & pa.mask;
+    for (;;) {
+        const uint64_t cur = pa.key[s];
+        if (cur == key) return pa.idx[s];
+        if (cur == kEmptyKey) return -1;
+        s = (s + 1) & pa.mask;
+    }
+}
+
+// matching -l contigs.paths on the filtered graph: the path arcs both of whose contigs it keeps (weight 0, path-backed)
+__global__ void st4_arcs_static_kernel(F f)
+{
+    const PathArcs &pa = f.pa;
+    const int lane = threadIdx.x & 63;
+    for (int64_t p0 = static_cast<int64_t>(blockIdx.x) * blockDim.x; p0 < pa.n; p0 += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t p = p0 + threadIdx.x;
+        int32_t fu = -1, fv = -1;
+        if (p < pa.n) {                                            // the byte per contig first (1 MB, cache resident), the ids for the few that pass
+            const int32_t cu = pa.u[p] >> 1, cv = pa.v[p] >> 1;
+            if ((f.seg_flags[cu] & 3) && (f.seg_flags[cv] & 3)) { fu = f.fid[cu]; fv = f.fid[cv]; }
+        }
+        const bool in = fu >= 0 && fv >= 0;
+        const unsigned long long m = __ballot(in);                 // one counter add per wave
+        int64_t base = 0;
+        if (m && lane == __builtin_ctzll(m)) base = static_cast<int64_t>(atomicAdd(reinterpret_cast<unsigned long long *>(&f.fs->n_static),
+                                                                                   static_cast<unsigned long long>(__popcll(m))));
+        base = __shfl(base, m ? __builtin_ctzll(m) : 0);
+        if (p < pa.n) {
+            int32_t at = -1;
+            if (in) {
+                at = static_cast<int32_t>(base + __popcll(m & ((1ull << lane) - 1)));
+                if (at < f.arc_cap) {
+                    f.arc_u[at] = 2 * fu + (pa.u[p] & 1); f.arc_v[at] = 2 * fv + (pa.v[p] & 1);
+                    f.arc_w[at] = 0; f.arc_backed[at] = 1;
+                } else { atomicOr(&f.fs->bad, kBadArcTable); at = -1; }
+            }
+            pa.arc_of[p] = at;
+        }
+    }
+}
+
+// a junction arc: its weight goes to the path arc between the same two oriented contigs if the graph has one, else it is an arc
+// of its own (merged with equal ones in the table of this step)
+__device__ void bump_arc(const F &f, int32_t cu, int32_t cv, int32_t u, int32_t v, int64_t w)
+{
+    if (f.use_paths) {
+        const int32_t p = path_arc_find(f.pa, cu, cv);
+        if (p >= 0) {
+            const int32_t at = f.pa.arc_of[p];                   // (both contigs are kept, so the path arc is in the graph)
+            if (at >= 0) { atomicAdd(&f.arc_w[at], static_cast<unsigned long long>(w)); return; }
+        }
+    }
     const ArcTable &t = f.t;
     const uint64_t key = (static_cast<uint64_t>(static_cast<uint32_t>(u)) << 32) | static_cast<uint32_t>(v);
     uint64_t s = mix(key) & t.mask;
@@ -195,7 +304,7 @@ __device__ void bump_arc(const F &f, int32_t u, int32_t v, int64_t w, bool backe
         if (cur == kEmptyKey) {
             const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(&t.key[s]), kEmptyKey, key);
             if (old == kEmptyKey) {                          // this thread created the arc: it also lists it
-                const int64_t at = static_cast<int64_t>(atomicAdd(reinterpret_cast<unsigned long long *>(&f.fs->n_arcs), 1ull));
+                const int64_t at = static_cast<int64_t>(atomicAdd(reinterpret_cast<unsigned long long *>(&f.fs->n_dyn), 1ull));
                 if (at < t.list_cap) t.list[at] = static_cast<int64_t>(s);
                 else atomicOr(&f.fs->bad, kBadArcTable);
                 break;
@@ -205,14 +314,6 @@ __device__ void bump_arc(const F &f, int32_t u, int32_t v, int64_t w, bool backe
         s = (s + 1) & t.mask;
     }
     if (w) atomicAdd(&t.w[s], static_cast<unsigned long long>(w));
-    if (backed) atomicOr(&t.backed[s], 1u);
-}
-
-// the arc and its conjugate (make_final_fa.py:20-34); an arc that is its own conjugate once
-__device__ __forceinline__ void add_arc(const F &f, int32_t u, int32_t v, int64_t w, bool backed)
-{
-    bump_arc(f, u, v, w, backed);
-    if ((v ^ 1) != u) bump_arc(f, v ^ 1, u ^ 1, w, backed);
 }
 
 __global__ void st4_arcs_juncs_kernel(F f, const palace_graph_edge *__restrict__ edges)
@@ -222,46 +323,45 @@ __global__ void st4_arcs_juncs_kernel(F f, const palace_graph_edge *__restrict__
         if (!(f.edge_flags[i] & 6)) continue;
         const palace_graph_edge e = edges[i];
         const int64_t w = min(edge_total(e), static_cast<int64_t>(kWeightTop - 1));
-        add_arc(f, 2 * f.fid[e.left] + (e.oL & 1), 2 * f.fid[e.right] + (e.oR & 1), w, false);
+        const int32_t cu = 2 * e.left + (e.oL & 1), cv = 2 * e.right + (e.oR & 1);
+        const int32_t u = 2 * f.fid[e.left] + (e.oL & 1), v = 2 * f.fid[e.right] + (e.oR & 1);
+        bump_arc(f, cu, cv, u, v, w);
+        if ((v ^ 1) != u) bump_arc(f, cv ^ 1, cu ^ 1, v ^ 1, u ^ 1, w);          // the conjugate; an arc that is its own conjugate once
     }
 }
 
-// matching -l contigs.paths: consecutive tokens of a line back the arc between them (weight 0 if the arc is new); a token
-// whose contig is not in the filtered graph breaks the chain
-__global__ void st4_arcs_paths_kernel(F f)
+// the junction arcs of this step's table join the list behind the path arcs; the table is left clean for the next sample
+__global__ void st4_arcs_dyn_kernel(F f)
 {
-    for (int64_t p = gtid(); p < f.n_paths; p += gsize()) {
-        int32_t before = -1;
-        for (int64_t k = f.path_off[p]; k < f.path_off[p + 1]; k++) {
-            const int32_t t = f.path_tok[k];
-            int32_t here = -1;
-            if (t >= 0) {
-                const int32_t id = f.fid[t >> 1];
-                if (id >= 0) here = 2 * id + (t & 1);
-            }
-            if (before >= 0 && here >= 0) add_arc(f, before, here, 0, true);
-            before = here;
-        }
+    FilterState *fs = f.fs;
+    const int64_t n_static = min(fs->n_static, f.arc_cap), n = min(fs->n_dyn, f.t.list_cap);
+    for (int64_t a = gtid(); a < n; a += gsize()) {
+        const int64_t s = f.t.list[a];
+        const uint64_t key = f.t.key[s];
+        const int64_t at = n_static + a;
+        if (at < f.arc_cap) {
+            f.arc_u[at] = static_cast<int32_t>(key >> 32); f.arc_v[at] = static_cast<int32_t>(key & 0xffffffffu);
+            f.arc_w[at] = f.t.w[s]; f.arc_backed[at] = 0;
+        } else atomicOr(&fs->bad, kBadArcTable);
+        f.t.key[s] = kEmptyKey; f.t.w[s] = 0;
     }
+    if (gtid() == 0) fs->n_arcs = min(n_static + n, f.arc_cap);
 }
 
 // rank keys (lower = better): weight descending, path-backed first, class {arc, conjugate} ascending, the arc that equals
 // its class key first -- the order palace_amd/host/matching_main.cpp sorts by
-__global__ void st4_arc_list_kernel(F f, DecompBufs b)
+__global__ void st4_arc_keys_kernel(F f, DecompBufs b)
 {
-    const int64_t n = min(f.fs->n_arcs, f.t.list_cap);
-    for (int64_t a = gtid(); a < n; a += gsize()) {
-        const int64_t s = f.t.list[a];
-        const uint64_t key = f.t.key[s];
-        const int32_t u = static_cast<int32_t>(key >> 32), v = static_cast<int32_t>(key & 0xffffffffu);
-        const uint64_t w = min(static_cast<uint64_t>(f.t.w[s]), kWeightTop - 1);
-        f.arc_u[a] = u; f.arc_v[a] = v;
-        b.khi[a] = ((kWeightTop - w) << 1) | (f.t.backed[s] ? 0u : 1u);
+    const int64_t n = min(f.fs->n_static, f.arc_cap) + min(f.fs->n_dyn, f.t.list_cap);
+    for (int64_t a = gtid(); a < n && a < f.arc_cap; a += gsize()) {
+        const int32_t u = f.arc_u[a], v = f.arc_v[a];
+        const uint64_t w = min(static_cast<uint64_t>(f.arc_w[a]), kWeightTop - 1);
+        b.khi[a] = ((kWeightTop - w) << 1) | (f.arc_backed[a] ? 0u : 1u);
+        const uint64_t key = (static_cast<uint64_t>(static_cast<uint32_t>(u)) << 32) | static_cast<uint32_t>(v);
         const uint64_t twin = (static_cast<uint64_t>(static_cast<uint32_t>(v ^ 1)) << 32) | static_cast<uint32_t>(u ^ 1);
         const uint64_t cls = min(key, twin);
         b.klo[a] = (cls << 1) | (key != cls ? 1u : 0u);
         f.has_arc[u >> 1] = 1; f.has_arc[v >> 1] = 1;
-        f.t.key[s] = kEmptyKey; f.t.w[s] = 0; f.t.backed[s] = 0;        // the table is left clean for the next sample
     }
 }
 
@@ -283,7 +383,7 @@ __global__ void st4_sub_kernel(F f, DecompBufs b, const int32_t *__restrict__ cn
         b.orig[sub] = i;
         b.left[sub] = max(1, cn[f.contig_of[i]]);
     }
-    const int64_t n_arcs = min(fs->n_arcs, f.t.list_cap);
+    const int64_t n_arcs = min(fs->n_arcs, f.arc_cap);
     for (int64_t a = gtid(); a < n_arcs; a += gsize()) {
         const int32_t u = f.arc_u[a], v = f.arc_v[a];
         b.src[a] = 2 * static_cast<int32_t>(f.scan_out[u >> 1]) + (u & 1);
@@ -331,7 +431,8 @@ struct palace_stage04 {
     char *grown = nullptr;            // device block sized by the edge bound (grow-only)
     size_t grown_bytes = 0;
     int64_t n_tok = 0, edge_bound = 0, s_cap = 0, e_cap = 0, comp_cap = 0, vert_cap = 0;
-    int rounds = 0, aggressive = 0, iters = 0, last_rounds = 0;
+    int rounds = 0, aggressive = 0, last_rounds = 0;
+    palace::DecompRun run;
     bool filtered = false, matched = false;
     const int32_t *d_cn = nullptr;
     // pinned host
@@ -347,7 +448,7 @@ using namespace palace;
 
 namespace {
 
-const dim3 kG(kDecompGrid), kB(kDecompBlock);
+const dim3 kG(1024), kB(kDecompBlock);           // fixed grid of the grid-stride kernels over contigs / edges / path lines
 
 int grow_pinned(palace_ctx *ctx, palace_stage04 *s, size_t bytes)
 {
@@ -363,14 +464,14 @@ int grow_pinned(palace_ctx *ctx, palace_stage04 *s, size_t bytes)
 // the device block that depends on the edge bound: edge flags, the arc table and list, the decomposition's arrays
 int grow_device(palace_ctx *ctx, palace_stage04 *s, int64_t edge_bound, int rounds)
 {
-    const int64_t pairs = std::max<int64_t>(0, s->n_tok - s->f.n_paths);
-    const int64_t e_cap = 2 * (edge_bound + pairs) + 16;                       // arcs incl. conjugates
+    const int64_t e_dyn = 2 * edge_bound + 16;                                 // junction arcs incl. conjugates
+    const int64_t e_cap = e_dyn + s->f.pa.n + 16;                              // + the arcs contigs.paths backs
     const int64_t s_cap = std::min<int64_t>(s->f.n_segs, e_cap);               // arc-bearing segments: an arc has two ends, ends are shared
     const int64_t comp_cap = static_cast<int64_t>(rounds) * s_cap + 16, vert_cap = 2 * comp_cap;
-    const uint64_t slots = pow2_at_least(2 * static_cast<uint64_t>(e_cap));
+    const uint64_t slots = pow2_at_least(2 * static_cast<uint64_t>(e_dyn));
     const size_t dec = decomp_bytes(s_cap, e_cap, comp_cap, vert_cap, rounds, kMaxIters);
-    const size_t bytes = up(static_cast<size_t>(edge_bound) + 1) + up(slots * 8) * 2 + up(slots * 4) + up(static_cast<size_t>(e_cap) * 8) +
-                         2 * up(static_cast<size_t>(e_cap) * 4) + dec + 4096;
+    const size_t bytes = up(static_cast<size_t>(edge_bound) + 1) + up(slots * 8) * 2 + up(static_cast<size_t>(e_dyn) * 8) +
+                         2 * up(static_cast<size_t>(e_cap) * 4) + up(static_cast<size_t>(e_cap) * 8) + up(static_cast<size_t>(e_cap)) + dec + 8192;
     if (s->grown_bytes < bytes || s->edge_bound < edge_bound || s->rounds < rounds) {
         if (s->grown) { PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream)); PALACE_HIP_TRY(hipFree(s->grown)); s->grown = nullptr; s->grown_bytes = 0; }
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&s->grown), bytes);
@@ -380,16 +481,18 @@ int grow_device(palace_ctx *ctx, palace_stage04 *s, int64_t edge_bound, int roun
         s->f.edge_flags = carve<uint8_t>(p, static_cast<size_t>(edge_bound) + 1);
         s->f.t.key = carve<uint64_t>(p, slots);
         s->f.t.w = carve<unsigned long long>(p, slots);
-        s->f.t.backed = carve<uint32_t>(p, slots);
+        s->f.t.backed = nullptr;
         s->f.t.mask = slots - 1;
-        s->f.t.list = carve<int64_t>(p, static_cast<size_t>(e_cap));
-        s->f.t.list_cap = e_cap;
+        s->f.t.list = carve<int64_t>(p, static_cast<size_t>(e_dyn));
+        s->f.t.list_cap = e_dyn;
         s->f.arc_u = carve<int32_t>(p, static_cast<size_t>(e_cap));
         s->f.arc_v = carve<int32_t>(p, static_cast<size_t>(e_cap));
+        s->f.arc_w = carve<unsigned long long>(p, static_cast<size_t>(e_cap));
+        s->f.arc_backed = carve<uint8_t>(p, static_cast<size_t>(e_cap));
+        s->f.arc_cap = e_cap;
         decomp_carve(s->b, p, s_cap, e_cap, comp_cap, vert_cap, rounds, kMaxIters);
         PALACE_HIP_TRY(hipMemsetAsync(s->f.t.key, 0xff, slots * 8, ctx->stream));       // empty; every use leaves it empty again
         PALACE_HIP_TRY(hipMemsetAsync(s->f.t.w, 0, slots * 8, ctx->stream));
-        PALACE_HIP_TRY(hipMemsetAsync(s->f.t.backed, 0, slots * 4, ctx->stream));
         s->edge_bound = edge_bound; s->s_cap = s_cap; s->e_cap = e_cap; s->comp_cap = comp_cap; s->vert_cap = vert_cap; s->rounds = rounds;
     }
     s->f.edge_bound = s->edge_bound;
@@ -413,8 +516,11 @@ int palace_stage04_create(palace_ctx *ctx, const palace_stage04_inputs *in, pala
     for (int32_t i = 0; i < in->n_segs; i++) PALACE_REQUIRE(in->rank[i] >= 0 && in->rank[i] < in->n_segs, "rank out of range");
     for (int64_t k = 0; k < n_tok; k++) PALACE_REQUIRE(in->path_tok[k] < 2 * static_cast<int64_t>(in->n_segs), "path token out of range");
     std::unique_ptr<palace_stage04> s(new palace_stage04());
+    const int64_t pa_cap = 2 * std::max<int64_t>(0, n_tok - in->n_paths) + 16;          // consecutive pairs and their conjugates
+    const uint64_t pa_slots = pow2_at_least(2 * static_cast<uint64_t>(pa_cap));
     const size_t bytes = up(sizeof(FilterState)) + up(n) * 8 + up(n * 4) * 6 + up(n * 8) * 2 + up((static_cast<size_t>(in->n_paths) + 1) * 8) +
-                         up(static_cast<size_t>(n_tok) * 4 + 4) + up((n + 63) / 64 * 8 + 8) + 8192;
+                         up(static_cast<size_t>(n_tok) * 4 + 4) + up((n + 63) / 64 * 8 + 8) + up(pa_slots * 8) + up(pa_slots * 4) +
+                         3 * up(static_cast<size_t>(pa_cap) * 4) + 16384;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&s->fixed), bytes);
     if (e != hipSuccess) { set_error("stage04: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return PALACE_ENOMEM; }
     char *p = s->fixed;
@@ -430,6 +536,10 @@ int palace_stage04_create(palace_ctx *ctx, const palace_stage04_inputs *in, pala
     int64_t *path_off = carve<int64_t>(p, static_cast<size_t>(in->n_paths) + 1);
     int32_t *path_tok = carve<int32_t>(p, static_cast<size_t>(n_tok) + 1);
     f.bare = carve<uint64_t>(p, (n + 63) / 64 + 1);
+    f.pa.key = carve<uint64_t>(p, pa_slots); f.pa.idx = carve<int32_t>(p, pa_slots); f.pa.mask = pa_slots - 1;
+    f.pa.u = carve<int32_t>(p, static_cast<size_t>(pa_cap)); f.pa.v = carve<int32_t>(p, static_cast<size_t>(pa_cap));
+    f.pa.arc_of = carve<int32_t>(p, static_cast<size_t>(pa_cap));
+    f.pa.cap = pa_cap; f.pa.n = 0;
     f.seed = seed; f.tlen = tlen; f.rank = rank; f.name_len = name_len; f.path_off = path_off; f.path_tok = path_tok;
     s->n_tok = n_tok;
     auto fail = [&](hipError_t err) {
@@ -449,7 +559,15 @@ int palace_stage04_create(palace_ctx *ctx, const palace_stage04_inputs *in, pala
         if (n_tok && (e = hipMemcpyAsync(path_tok, in->path_tok, static_cast<size_t>(n_tok) * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
     } else if ((e = hipMemsetAsync(path_off, 0, 8, st)) != hipSuccess) return fail(e);
     hipLaunchKernelGGL(st4_by_rank_kernel, kG, kB, 0, st, f);
+    // the arcs contigs.paths backs, once per sample (what `matching -l` derives from the file every time it runs)
+    if ((e = hipMemsetAsync(f.fs, 0, sizeof(FilterState), st)) != hipSuccess) return fail(e);
+    if ((e = hipMemsetAsync(f.pa.key, 0xff, pa_slots * 8, st)) != hipSuccess) return fail(e);
+    hipLaunchKernelGGL(st4_path_arcs_kernel, kG, kB, 0, st, f);
+    FilterState h_fs{};
+    if ((e = hipMemcpyAsync(&h_fs, f.fs, sizeof h_fs, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e);
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e);          // the caller's arrays are free again
+    if (h_fs.n_path_arcs > pa_cap) { (void)hipFree(s->fixed); set_error("stage04: path arc table too small"); return PALACE_ESTATE; }
+    f.pa.n = h_fs.n_path_arcs;
     // the small pinned block the two state structs come back into
     e = hipHostMalloc(reinterpret_cast<void **>(&s->h_fs), up(sizeof(FilterState)) + up(sizeof(DecompState)), hipHostMallocDefault);
     if (e != hipSuccess) { (void)hipFree(s->fixed); set_error("stage04: hipHostMalloc failed: %s", hipGetErrorString(e)); return PALACE_ENOMEM; }
@@ -498,11 +616,13 @@ int palace_stage04_filter(palace_ctx *ctx, palace_stage04 *s, const palace_graph
 
 static int enqueue_match(palace_ctx *ctx, palace_stage04 *s, const palace_graph_edge *d_edges, bool use_paths)
 {
+    s->f.use_paths = use_paths ? 1 : 0;
     const F &f = s->f;
     hipStream_t st = ctx->stream;
+    if (use_paths) hipLaunchKernelGGL(st4_arcs_static_kernel, kG, kB, 0, st, f);
     hipLaunchKernelGGL(st4_arcs_juncs_kernel, kG, kB, 0, st, f, d_edges);
-    if (use_paths) hipLaunchKernelGGL(st4_arcs_paths_kernel, kG, kB, 0, st, f);
-    hipLaunchKernelGGL(st4_arc_list_kernel, kG, kB, 0, st, f, s->b);
+    hipLaunchKernelGGL(st4_arcs_dyn_kernel, kG, kB, 0, st, f);
+    hipLaunchKernelGGL(st4_arc_keys_kernel, kG, kB, 0, st, f, s->b);
     hipLaunchKernelGGL(st4_sub_in_kernel, kG, kB, 0, st, f);
     PALACE_HIP_TRY(hipGetLastError());
     int rc = scan_u64(ctx, f.scan_in, f.scan_out, &f.fs->S_f, s->b.partials, &f.fs->scan_total);
@@ -516,6 +636,12 @@ static int enqueue_match(palace_ctx *ctx, palace_stage04 *s, const palace_graph_
 int palace_stage04_match(palace_ctx *ctx, palace_stage04 *s, const palace_graph_edge *d_edges, const int32_t *d_cn,
                          int32_t iterations, int32_t aggressive, int32_t use_paths)
 {
+    return palace_stage04_match_after(ctx, s, d_edges, d_cn, iterations, aggressive, use_paths, nullptr, 0);
+}
+
+int palace_stage04_match_after(palace_ctx *ctx, palace_stage04 *s, const palace_graph_edge *d_edges, const int32_t *d_cn,
+                               int32_t iterations, int32_t aggressive, int32_t use_paths, palace_ctx *other, int32_t mark)
+{
     PALACE_REQUIRE(ctx && s && d_cn && iterations >= 1, "bad argument");
     PALACE_REQUIRE(s->filtered, "palace_stage04_filter has not run");
     const int rounds = iterations + (aggressive ? 1 : 0);
@@ -523,14 +649,18 @@ int palace_stage04_match(palace_ctx *ctx, palace_stage04 *s, const palace_graph_
     PALACE_REQUIRE(rounds <= s->rounds, "more rounds than the filter call reserved room for (at most 10 iterations + aggressive)");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     s->d_cn = d_cn; s->aggressive = aggressive ? 1 : 0;
-    s->iters = ctx->match_iters > 0 ? std::min(ctx->match_iters, kMaxIters) : 12;
     int rc = enqueue_match(ctx, s, d_edges, use_paths != 0);
     if (rc) return rc;
-    rc = decomp_enqueue(ctx, s->b, rounds, s->aggressive, s->iters, false, s->comp_cap, s->vert_cap);
-    if (rc) return rc;
-    // the two state blocks follow in stream order; palace_stage04_result waits for them
+    // the first group of rounds goes out now; palace_stage04_result looks at the state after it and continues while segments
+    // keep copies (a typical sample is done after the first group)
+    s->run = DecompRun{};
+    if (other) {                                             // the arcs are built; the rounds wait for the other stream's mark
+        rc = palace_wait_for_mark(ctx, other, mark);
+        if (rc) return rc;
+    }
+    if ((rc = decomp_begin(ctx, s->b, rounds, s->comp_cap, s->vert_cap))) return rc;
+    if ((rc = decomp_group(ctx, s->b, s->run, rounds, s->aggressive, false))) return rc;
     PALACE_HIP_TRY(hipMemcpyAsync(s->h_fs, s->f.fs, sizeof(FilterState), hipMemcpyDeviceToHost, ctx->stream));
-    PALACE_HIP_TRY(hipMemcpyAsync(s->h_ds, s->b.st, sizeof(DecompState), hipMemcpyDeviceToHost, ctx->stream));
     s->rounds = std::max(s->rounds, rounds);
     s->matched = true;
     s->last_rounds = rounds;
@@ -578,17 +708,15 @@ int palace_stage04_result(palace_ctx *ctx, palace_stage04 *s, palace_match_resul
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int rounds = s->last_rounds;
-    PALACE_HIP_TRY(hipStreamSynchronize(st));                             // the state blocks are in
-    int rc = check_filter_state(*s->h_fs);
-    if (rc) return rc;
-    if (s->h_ds->unsettled) {
-        // a round needed more matching iterations than were enqueued: once more with the host watching (arcs are still in place)
+    auto reset_left = [&]() -> int {
         hipLaunchKernelGGL(st4_left_kernel, kG, kB, 0, st, s->f, s->b, s->d_cn);
-        rc = decomp_run_checked(ctx, s->b, rounds, s->aggressive, false, s->comp_cap, s->vert_cap, 2 * s->h_fs->n_arcs + 64);
-        if (rc) return rc;
-        PALACE_HIP_TRY(hipMemcpyAsync(s->h_ds, s->b.st, sizeof(DecompState), hipMemcpyDeviceToHost, st));
-        PALACE_HIP_TRY(hipStreamSynchronize(st));
-    }
+        PALACE_HIP_TRY(hipGetLastError());
+        return PALACE_OK;
+    };
+    int rc = decomp_finish(ctx, s->b, s->run, rounds, s->aggressive, false, s->comp_cap, s->vert_cap, 2 * s->e_cap + 64, s->h_ds, reset_left);
+    if (rc) return rc;
+    rc = check_filter_state(*s->h_fs);                          // (in since the first wait of decomp_finish)
+    if (rc) return rc;
     const DecompState &ds = *s->h_ds;
     if (ds.overflow || ds.n_comp > s->comp_cap || ds.n_vert > s->vert_cap) { set_error("stage04: component arrays too small"); return PALACE_ESTATE; }
     const size_t nc = static_cast<size_t>(ds.n_comp), nv = static_cast<size_t>(ds.n_vert), sf = static_cast<size_t>(s->h_fs->S_f);

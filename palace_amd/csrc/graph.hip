@@ -299,8 +299,15 @@ __global__ void resolve_pair_apply_kernel(ResolveArgs a)
 __global__ void compact_edges_kernel(ResolveArgs a)
 {
     uint64_t s = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (s > a.e_mask || a.e_keys[s] == kEmpty) return;
-    unsigned long long i = atomicAdd(&a.counters[0], 1ull);
+    const bool have = s <= a.e_mask && a.e_keys[s] != kEmpty;
+    const unsigned long long m = __ballot(have);                  // one counter add per wave, not one per edge
+    if (!m) return;
+    const int lane = threadIdx.x & 63, first = __builtin_ctzll(m);
+    unsigned long long base = 0;
+    if (lane == first) base = atomicAdd(&a.counters[0], static_cast<unsigned long long>(__popcll(m)));
+    base = __shfl(base, first);
+    if (!have) return;
+    const unsigned long long i = base + __popcll(m & ((1ull << lane) - 1));
     if (static_cast<int64_t>(i) >= a.edge_cap) return;
     uint64_t k = a.e_keys[s];
     palace_graph_edge e{};

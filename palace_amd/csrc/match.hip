@@ -238,12 +238,11 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
     for (int64_t s = 0; s < S; s++) live_rounds += std::min<int64_t>(iterations, std::max<int64_t>(1, copies[s]));
     if (aggressive) live_rounds += S;
     const int64_t comp_cap = live_rounds, vert_cap = 2 * live_rounds;
-    const int iters = ctx->match_iters > 0 ? std::min(ctx->match_iters, kMaxIters) : 12;
-    const size_t dev_bytes = decomp_bytes(S, E, comp_cap, vert_cap, rounds, std::max(iters, 16));
+    const size_t dev_bytes = decomp_bytes(S, E, comp_cap, vert_cap, rounds, kMaxIters);
     int rc = ensure_workspace(ctx, dev_bytes);
     if (rc) return rc;
     DecompBufs b;
-    decomp_carve(b, static_cast<char *>(ctx->ws.ptr), S, E, comp_cap, vert_cap, rounds, std::max(iters, 16));
+    decomp_carve(b, static_cast<char *>(ctx->ws.ptr), S, E, comp_cap, vert_cap, rounds, kMaxIters);
     // staging in pinned memory so that every upload is a true asynchronous copy
     const size_t e4 = (static_cast<size_t>(E) * 4 + 255) / 256 * 256, s8 = (static_cast<size_t>(S) * 8 + 255) / 256 * 256,
                  s4 = (static_cast<size_t>(S) * 4 + 255) / 256 * 256;
@@ -273,20 +272,16 @@ static int decompose_core(palace_ctx *ctx, int32_t n_segs, const int64_t *copies
         return PALACE_OK;
     };
     auto fail = [&](int code) { (void)hipStreamSynchronize(st); return code; };      // the pinned staging must outlive the copies
+    hipError_t e = hipSuccess;
     if ((rc = upload())) return fail(rc);
-    if ((rc = decomp_enqueue(ctx, b, rounds, aggressive, iters, true, comp_cap, vert_cap))) return fail(rc);
-    hipError_t e = hipMemcpyAsync(p_back, b.st, sizeof *p_back, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { set_error("decompose: %s", hipGetErrorString(e)); return fail(PALACE_EHIP); }
-    if (p_back->unsettled) {
-        // a round needed more matching iterations than were enqueued (long chains of ascending weights): once more, with the
-        // host watching every round's fixed point
-        if ((rc = upload())) return fail(rc);
-        if ((rc = decomp_run_checked(ctx, b, rounds, aggressive, true, comp_cap, vert_cap, 2 * E + 64))) return fail(rc);
-        e = hipMemcpyAsync(p_back, b.st, sizeof *p_back, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { set_error("decompose: %s", hipGetErrorString(e)); return fail(PALACE_EHIP); }
-    }
+    if ((rc = decomp_begin(ctx, b, rounds, comp_cap, vert_cap))) return fail(rc);
+    DecompRun run;
+    if ((rc = decomp_group(ctx, b, run, rounds, aggressive, true))) return fail(rc);
+    auto reset_left = [&]() -> int {                          // (the checked run starts over: copy numbers as uploaded)
+        PALACE_HIP_TRY(hipMemcpyAsync(b.left, p_left, static_cast<size_t>(S) * 8, hipMemcpyHostToDevice, st));
+        return PALACE_OK;
+    };
+    if ((rc = decomp_finish(ctx, b, run, rounds, aggressive, true, comp_cap, vert_cap, 2 * E + 64, p_back, reset_left))) return fail(rc);
     if (p_back->overflow || p_back->n_comp > comp_cap || p_back->n_vert > vert_cap) {
         set_error("decompose: component arrays too small (%lld components, %lld vertices)", (long long)p_back->n_comp, (long long)p_back->n_vert);
         return PALACE_ESTATE;
