@@ -815,12 +815,11 @@ def main():
         capi._check(L.palace_graph_copy_numbers(g.h, P(consumed), P(gs["tlen"]), nt, gs["avg_depth"], P(cn_dev)), "cn")
         if timed: g.mark(m + 2)
         if stage04 is not None:                     # rank 0 owns the (small) stage; its result is what the sample's all_result holds
-            # Stage 04 is a few hundred small latency-bound launches: beside the bandwidth-bound counting kernels each of them
-            # costs those kernels a few microseconds (kernel boundaries write back the L2 lines the partition kernels combine their
-            # stores in) -- 1.3 ms per step, measured; beside Phase B's small kernels it costs nothing.  So the selection and the
-            # arcs are done at once, and the rounds of the decomposition start when the counting kernels of this step are done
-            # (ordered on the device, no host wait).
-            late = not exch and not skip_eref and os.environ.get("PALACE_BENCH_STAGE04_EARLY") != "1"
+            # Stage 04 is ~150 small latency-bound launches beside the bandwidth-bound counting kernels; each costs those kernels a
+            # few microseconds (kernel boundaries write back the L2 lines the partition kernels combine their stores in): about
+            # 1 ms per step, measured.  Holding the rounds back until the counting kernels are done (PALACE_BENCH_STAGE04_LATE=1:
+            # palace_stage04_match_after) leaves those undisturbed but puts the rounds on the critical path -- 14.8 against 12.8 ms.
+            late = not exch and not skip_eref and os.environ.get("PALACE_BENCH_STAGE04_LATE") == "1"
             stage04.filter(P(e_buf), P(n_edges_dev), max(1, n_cands))
             stage04.match(P(e_buf), P(cn_dev), 10, False, True, after=(ctx, 4095) if late else None)
         if timed: g.mark(m + 3)
