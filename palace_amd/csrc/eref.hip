@@ -555,7 +555,17 @@ __device__ __forceinline__ uint64_t fine_region_base(const DensityCaps &c, uint3
 {
     return 2 * (c.prefix(b1) * kL2Rows + static_cast<uint64_t>(sub) * c.cap(b1));
 }
-__device__ __forceinline__ uint32_t fine_region_cap(const DensityCaps &c, uint32_t b1) { return 2 * c.cap(b1); }
+
+// A fine region is split eight ways, one sub-region per XCD: a workgroup appends its runs (~48 payloads, 2-byte granular)
+// to the sub-region of the XCD it runs on (read from the hardware, HW_REG_XCC_ID; any value 0..7 is correct).  Measured:
+// the kernel 4.09 -> 3.73 ms (eight times as many cursors share the reservations, and a sub-region's run ends meet in one
+// L2); the bytes written do NOT drop (6.0 -> 6.6 GB for 4.76 GB of payloads): the memory side writes 64-byte granules, and a
+// ~96-byte run at a 2-byte offset touches 2.4 of them wherever its neighbours come from.  Runs padded to whole 16-byte pieces
+// (pad value 0xffff, keys with that payload counted in a side array) were built, parity-green, and dropped: 6.9 GB written,
+// the same 3.75 ms, the count kernel 1.32 -> 1.50 ms for the pads it skips.  Only longer runs would help, i.e. more LDS.
+constexpr int kXcds = 8;
+__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }
+__host__ __device__ inline uint32_t fine_sub_cap(const DensityCaps &c, uint32_t b1) { return (2 * c.cap(b1) / kXcds) & ~7u; }   // keys; multiple of 8
 
 typedef uint16_t __attribute__((address_space(1))) global_u16;
 
@@ -618,16 +628,16 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
     constexpr int rows_per_wave = kL2Rows / (kBin2Threads / 64);
     const int lane = threadIdx.x & 63;
     const int row0 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) * rows_per_wave;
-    const uint32_t cap = fine_region_cap(o.caps, b1);
+    const uint32_t cap = fine_sub_cap(o.caps, b1), xcd = xcc_id();          // this XCD's share of every fine region
     uint32_t c = 0, g = 0, p_lo = 0, p_hi = 0;
     bool over = false;
     if (lane < rows_per_wave) {
         const uint32_t row = row0 + lane;
         const unsigned long long r = st.rows[row];
         c = min(static_cast<uint32_t>(r), static_cast<uint32_t>(r >> 32)) - row * kRowSlots;
-        if (c) g = atomicAdd(&o.cursor[b1 * kL2Rows + row], c);
+        if (c) g = atomicAdd(&o.cursor[(b1 * kL2Rows + row) * kXcds + xcd], c);
         over = static_cast<uint64_t>(g) + c > cap;
-        const uint64_t ptr = reinterpret_cast<uint64_t>(o.buf + fine_region_base(o.caps, b1, row) + min(g, cap));
+        const uint64_t ptr = reinterpret_cast<uint64_t>(o.buf + fine_region_base(o.caps, b1, row) + static_cast<uint64_t>(xcd) * cap + min(g, cap));
         p_lo = static_cast<uint32_t>(ptr); p_hi = static_cast<uint32_t>(ptr >> 32);
     }
     const unsigned long long over_rows = __ballot(over);
@@ -689,21 +699,40 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
 {
     __shared__ uint32_t l1[kFineWords], l2[kFineWords], l3[kFineWords];
     const uint32_t b = blockIdx.x, b1 = b / kL2Rows;
-    const uint32_t n = min(cursor[b], fine_region_cap(caps, b1));
-    if (n == 0) return;                                    // uniform for the whole workgroup
+    // the bucket's keys lie in eight sub-regions (one per XCD that wrote them); as one sequence of 16-byte vectors of eight
+    // keys: vector j belongs to sub-region x with first[x] <= j < first[x + 1]
+    const uint32_t sub_cap = fine_sub_cap(caps, b1);
+    uint32_t n_sub[kXcds], first[kXcds + 1];
+    first[0] = 0;
+#pragma unroll
+    for (int x = 0; x < kXcds; x++) {
+        n_sub[x] = min(cursor[b * kXcds + x], sub_cap);
+        first[x + 1] = first[x] + (n_sub[x] + 7) / 8;
+    }
+    const uint32_t n8 = first[kXcds];
+    if (n8 == 0) return;                                   // uniform for the whole workgroup
     const size_t w0 = static_cast<size_t>(b) * kFineWords;
     const uint4 *g1 = reinterpret_cast<const uint4 *>(p1 + w0), *g2 = reinterpret_cast<const uint4 *>(p2 + w0),
                 *g3 = reinterpret_cast<const uint4 *>(p3 + w0);
-    // keys eight at a time (regions start on 16-byte boundaries and capacities are multiples of 8 keys, so the last
-    // vector may run past n but not past the region); the first batch of key loads is issued together with the seeds
+    // (sub-regions start on 16-byte boundaries and their capacity is a multiple of 8 keys, so the last vector of one may run
+    // past its count but not past the sub-region); the first batch of key loads is issued together with the seeds
     const uint4 *keys = reinterpret_cast<const uint4 *>(binned + fine_region_base(caps, b1, b % kL2Rows));
-    const uint32_t n8 = (n + 7) / 8;
+    auto locate = [&](uint32_t j, uint32_t &valid) -> const uint4 * {      // vector j and how many of its 8 keys count
+        uint32_t x = 0;
+#pragma unroll
+        for (int k = 1; k < kXcds; k++) x += j >= first[k];
+        const uint32_t local = j - first[x];
+        valid = min(8u, n_sub[x] - 8 * local);
+        return keys + (static_cast<size_t>(x) * sub_cap) / 8 + local;
+    };
     constexpr int kBatch = 4;
     uint4 v[kBatch];
+    uint32_t ok[kBatch];
 #pragma unroll
     for (int u = 0; u < kBatch; u++) {
         const uint32_t i = threadIdx.x + u * kCountThreads;
-        v[u] = i < n8 ? keys[i] : uint4{0, 0, 0, 0};
+        ok[u] = 0; v[u] = uint4{0, 0, 0, 0};
+        if (i < n8) v[u] = *locate(i, ok[u]);
     }
     const bool seed = !CLEAN || ((touched[b >> 5] >> (b & 31)) & 1u);      // uniform for the workgroup
     for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) {
@@ -720,24 +749,24 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
     };
     for (uint32_t i0 = threadIdx.x; i0 < n8; i0 += kBatch * kCountThreads) {
         uint4 nx[kBatch];
+        uint32_t nok[kBatch];
 #pragma unroll
         for (int u = 0; u < kBatch; u++) {                 // the next batch is in flight while this one is applied
             const uint32_t i = i0 + (kBatch + u) * kCountThreads;
-            nx[u] = i < n8 ? keys[i] : uint4{0, 0, 0, 0};
+            nok[u] = 0; nx[u] = uint4{0, 0, 0, 0};
+            if (i < n8) nx[u] = *locate(i, nok[u]);
         }
 #pragma unroll
         for (int u = 0; u < kBatch; u++) {
-            const uint32_t i = i0 + u * kCountThreads;
-            if (i >= n8) break;
             const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                if (8 * i + 2 * e < n) apply(d[e] & 0xffffu);
-                if (8 * i + 2 * e + 1 < n) apply(d[e] >> 16);
+                if (2 * e < static_cast<int>(ok[u])) apply(d[e] & 0xffffu);
+                if (2 * e + 1 < static_cast<int>(ok[u])) apply(d[e] >> 16);
             }
         }
 #pragma unroll
-        for (int u = 0; u < kBatch; u++) v[u] = nx[u];
+        for (int u = 0; u < kBatch; u++) { v[u] = nx[u]; ok[u] = nok[u]; }
     }
     __syncthreads();
     uint4 *o1 = reinterpret_cast<uint4 *>(p1 + w0), *o2 = reinterpret_cast<uint4 *>(p2 + w0),
@@ -1447,7 +1476,7 @@ int plan_count(palace_ctx *ctx, int64_t total_bases, CountPlan *pl)
     }
     PALACE_REQUIRE(pl->caps1.cap(0) < (1u << 31) && pl->caps2.cap(0) < (1u << 30), "slab too large for 32-bit region cursors");
     pl->cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
-    pl->cur2_bytes = align_up(kFine * sizeof(unsigned int), 256);
+    pl->cur2_bytes = align_up(static_cast<size_t>(kFine) * kXcds * sizeof(unsigned int), 256);       // a cursor per fine bucket and XCD
     pl->buf1_bytes = align_up(static_cast<size_t>(pl->caps1.prefix(kL1Buckets)) * kL1Replicas * 4, 256);
     PALACE_REQUIRE(pl->buf1_bytes < (1ull << 36), "slab too large: level 1 addresses its regions as 2^32 groups of 16 bytes");
     pl->buf2_bytes = align_up(static_cast<size_t>(pl->caps2.prefix(kL1Buckets)) * kL2Rows * 4, 256);    // pairs of 2-byte keys
