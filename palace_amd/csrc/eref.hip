@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void eref_count_kernel(const uint8_t *__restri
 // and fine-bucket regions are therefore sized by that density (a constant pad plus a share proportional to 255-2b).
 // A key that finds its region (or, in level 2, its staging row) full goes straight to the planes with global atomics,
 // so the result stays exact for any input.
-// Traffic per key: 4 B written + 4 B read + 2 B written + 2 B read, instead of ~52 B of memory-side atomic requests.
+// Traffic per key: 3.2 B written + 3.2 B read (level-1 records of 25 bits, five to a 16-byte group) + 2 B written + 2 B read,
+// instead of ~52 B of memory-side atomic requests.
 // ------------------------------------------------------------------------------------------
 constexpr int kBucketBits = 14;                       // probe index of Phase B: 2^14 groups of 2^18 keys
 constexpr int kBuckets = 1 << kBucketBits;
@@ -347,14 +348,13 @@ __global__ __launch_bounds__(256) void eref_streams_kernel(const uint8_t *__rest
 // wrote one partial-wave store per row).
 //   1. the lane computes its keys (registers) and counts them per bucket in an LDS histogram; the returning add gives
 //      the key its rank in the row;
-//   2. one wave turns the histogram into row starts, every row padded to a multiple of 4 keys; the pad slots get a
-//      SENTINEL -- a key whose top 7 bits name another bucket, which level 2 skips -- so that rows, global runs and
-//      16-byte vectors all stay aligned;
-//   3. meanwhile 128 lanes of two other waves reserve the (padded) runs in the bucket regions: these global atomics are
+//   2. one wave turns the histogram into row starts, every row padded to a multiple of 5 slots (one 16-byte group of five
+//      25-bit records and a count, see pack_group: the pad slots are never written, the group's count says how many are keys);
+//   3. meanwhile 128 lanes of two other waves reserve the runs (in groups) in the bucket regions: these global atomics are
 //      in flight during 2. and 4.;
 //   4. every lane places its keys at row start + rank;
-//   5. the compact, bucket-sorted tile is swept with 16-byte loads from LDS and 16-byte stores: a lane's four keys belong
-//      to one row (rows are 4-aligned), the row is the keys' own top bits, its destination one LDS read.
+//   5. the compact, bucket-sorted tile is swept group by group: five LDS reads, the row from the first key's own top bits,
+//      its destination one LDS read, one 16-byte store.
 // What bounds it (kernel cut short after each step, 1M-contig set): launch + stream loads + keys 1.5 ms, + histogram and
 // row starts 1.7, + placement 2.6, + reservations and sweep without the stores 3.4, all of it 4.1 -- each workgroup is a
 // chain of latencies of ~11 us whatever its tile size (the same with 256 threads, with 10 positions per lane), so the
@@ -381,8 +381,29 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
     return v;
 }
 
-__host__ __device__ constexpr uint32_t l1_sentinel(uint32_t b) { return (b ^ 64u) << kL1Shift; }
-constexpr uint32_t kRunAlign = 4;                     // keys: every run of level 1 is padded to a multiple of this (16 bytes)
+// Level-1 records: the bucket implies the top 7 bits of a key, so a record keeps 25.  FIVE records and a 3-bit count share one
+// 16-byte group -- bits [25 i, 25 i + 25) = key i & 0x1ffffff, bits [125, 128) = how many of the five are keys (the rest of a
+// run's last group is padding) -- 3.2 bytes per key instead of 4, every group, run and region still 16-byte aligned, and no
+// sentinel keys: level 2 reads the count.  Region capacities, cursors and run sizes are counted in groups.
+constexpr uint32_t kGroupKeys = 5;
+constexpr uint32_t kKeyMask25 = (1u << kL1Shift) - 1;
+__device__ __forceinline__ uint4 pack_group(const uint32_t k[5], uint32_t count)
+{
+    const unsigned long long k0 = k[0] & kKeyMask25, k1 = k[1] & kKeyMask25, k2 = k[2] & kKeyMask25, k3 = k[3] & kKeyMask25, k4 = k[4] & kKeyMask25;
+    const unsigned long long lo = k0 | (k1 << 25) | (k2 << 50);
+    const unsigned long long hi = (k2 >> 14) | (k3 << 11) | (k4 << 36) | (static_cast<unsigned long long>(count) << 61);
+    return uint4{static_cast<uint32_t>(lo), static_cast<uint32_t>(lo >> 32), static_cast<uint32_t>(hi), static_cast<uint32_t>(hi >> 32)};
+}
+__device__ __forceinline__ uint32_t unpack_group(const uint4 &g, uint32_t k[5])          // -> count
+{
+    const unsigned long long lo = g.x | (static_cast<unsigned long long>(g.y) << 32), hi = g.z | (static_cast<unsigned long long>(g.w) << 32);
+    k[0] = static_cast<uint32_t>(lo) & kKeyMask25;
+    k[1] = static_cast<uint32_t>(lo >> 25) & kKeyMask25;
+    k[2] = static_cast<uint32_t>((lo >> 50) | (hi << 14)) & kKeyMask25;
+    k[3] = static_cast<uint32_t>(hi >> 11) & kKeyMask25;
+    k[4] = static_cast<uint32_t>(hi >> 36) & kKeyMask25;
+    return static_cast<uint32_t>(hi >> 61);
+}
 
 template <int P, int THREADS>
 __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t *__restrict__ s0,
@@ -391,11 +412,11 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
                                                                      int64_t pos_lo, int64_t pos_hi,
                                                                      CoderMasks masks, BinOut o)
 {
-    constexpr int kMaxKeys = THREADS * P * 3 + kL1Buckets * (kRunAlign - 1);     // every key of the tile + the pad slots of every row
+    constexpr int kMaxKeys = THREADS * P * 3 + kL1Buckets * (kGroupKeys - 1);    // every key of the tile + the pad slots of every row
     __shared__ __attribute__((aligned(16))) uint32_t tile[kMaxKeys];
     __shared__ uint32_t hist[kL1Buckets], start[kL1Buckets + 1], room[kL1Buckets];
-    __shared__ uint32_t dst[kL1Buckets];                 // 16-byte group index in o.buf of the row's compact slot 0, modulo 2^32 (regions,
-                                                         // runs and row starts are multiples of 4 keys; a slab's regions hold < 2^32 groups)
+    __shared__ uint32_t dst[kL1Buckets];                 // group index in o.buf of the row's first group minus the row's first group in the
+                                                         // tile, modulo 2^32 (row starts are multiples of 5 slots; a slab's regions hold < 2^32 groups)
     __shared__ uint32_t any_partial;                     // some run of this tile did not fit its region whole (rare): check `room`
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #ifdef PALACE_STAMPS
@@ -445,17 +466,15 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
     const bool reserver = threadIdx.x >= 64 && threadIdx.x < 64 + kL1Buckets;
     const uint32_t my_row = threadIdx.x - 64;
     uint32_t my_pc = 0, my_g = 0;
-    if (wave == 0) {
+    if (wave == 0) {                                     // rows start on multiples of 5 slots (a group); the pad slots stay unwritten
         const uint32_t c0 = hist[2 * lane], c1 = hist[2 * lane + 1];
-        const uint32_t pc0 = (c0 + kRunAlign - 1) & ~(kRunAlign - 1), pc1 = (c1 + kRunAlign - 1) & ~(kRunAlign - 1);
+        const uint32_t pc0 = (c0 + kGroupKeys - 1) / kGroupKeys * kGroupKeys, pc1 = (c1 + kGroupKeys - 1) / kGroupKeys * kGroupKeys;
         const uint32_t incl = wave_inclusive_scan(pc0 + pc1);
         const uint32_t a0 = incl - pc0 - pc1, a1 = a0 + pc0;
         start[2 * lane] = a0; start[2 * lane + 1] = a1;
         if (lane == 63) start[kL1Buckets] = incl;
-        for (uint32_t q = c0; q < pc0; q++) tile[a0 + q] = l1_sentinel(2 * lane);
-        for (uint32_t q = c1; q < pc1; q++) tile[a1 + q] = l1_sentinel(2 * lane + 1);
     } else if (reserver) {
-        my_pc = (hist[my_row] + kRunAlign - 1) & ~(kRunAlign - 1);
+        my_pc = (hist[my_row] + kGroupKeys - 1) / kGroupKeys;                    // groups of the run
         if (my_pc) my_g = atomicAdd(&o.cursor[l1_cursor(my_row, replica)], my_pc);
     }
     lds_barrier();
@@ -473,45 +492,49 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
     if (reserver) {
         const uint32_t cap = o.caps.cap(my_row);
         const bool whole = static_cast<uint64_t>(my_g) + my_pc <= cap;
-        room[my_row] = cap - min(cap, my_g);                      // keys of the run that fit (a multiple of 4)
-        dst[my_row] = static_cast<uint32_t>((l1_region_base(o.caps, my_row, replica) + my_g - start[my_row]) >> 2);
+        room[my_row] = cap - min(cap, my_g);                      // groups of the run that fit
+        dst[my_row] = static_cast<uint32_t>(l1_region_base(o.caps, my_row, replica) + my_g - start[my_row] / kGroupKeys);
         if (!whole) any_partial = 1;
     }
     lds_barrier();
     STAMP(stamps, 4);
-    // ---- 5. sweep: unrolled, the 16-byte stores of a lane go out back to back (as a loop the compiler made every
-    // iteration wait for the previous iteration's store to be acknowledged: three HBM round trips in a row per tile) ----
+    // ---- 5. sweep: a lane packs the five slots of a group into 16 bytes; unrolled, every LDS read of the lane first, then its
+    // 16-byte stores back to back (as a loop the compiler made every iteration wait for the previous iteration's store to
+    // be acknowledged: three HBM round trips in a row per tile) ----
     const uint32_t total = start[kL1Buckets];
     const bool check = any_partial != 0;                           // uniform
-    constexpr int kSweeps = (kMaxKeys + THREADS * 4 - 1) / (THREADS * 4);
+    constexpr int kSweeps = (kMaxKeys / static_cast<int>(kGroupKeys) + THREADS - 1) / THREADS;
     uint32_t slow = 0;
     uint4 k[kSweeps];
-    uint32_t to[kSweeps], live = 0;                                // 16-byte group index in o.buf; bit it of live: group it is stored
+    uint32_t to[kSweeps], live = 0;                                // group index in o.buf; bit it of live: group it is stored
 #pragma unroll
-    for (int it = 0; it < kSweeps; it++) {                         // every LDS read of the lane first ...
-        const uint32_t x = (it * THREADS + threadIdx.x) * 4;
+    for (int it = 0; it < kSweeps; it++) {
+        const uint32_t gi = it * THREADS + threadIdx.x, x = gi * kGroupKeys;
         to[it] = 0;
         k[it] = uint4{0, 0, 0, 0};
         if (x < total) {
-            k[it] = *reinterpret_cast<const uint4 *>(&tile[x]);
-            // the row of the group: its keys' own top bits (a group of four pads names row ^ 64: they are the tail of that row)
-            const uint32_t row = k[it].x >> kL1Shift;             // (the first key of an aligned group of four is never a pad)
-            if (!check || x - start[row] < room[row]) { to[it] = dst[row] + (x >> 2); live |= 1u << it; }
+            uint32_t s5[kGroupKeys];
+#pragma unroll
+            for (uint32_t e = 0; e < kGroupKeys; e++) s5[e] = tile[x + e];
+            const uint32_t row = s5[0] >> kL1Shift;                // the group's first slot is always a key: the row is its top bits
+            const uint32_t in_row = x - start[row];
+            k[it] = pack_group(s5, min(kGroupKeys, hist[row] - in_row));
+            if (!check || in_row / kGroupKeys < room[row]) { to[it] = dst[row] + gi; live |= 1u << it; }
             else slow |= 1u << it;
         }
     }
 #pragma unroll
-    for (int it = 0; it < kSweeps; it++)                           // ... then its stores, in distinct registers
+    for (int it = 0; it < kSweeps; it++)
         if (live & (1u << it)) reinterpret_cast<uint4 *>(o.buf)[to[it]] = k[it];
-    if (slow) {                                                    // the region is full: exact slow path, pads skipped
+    if (slow) {                                                    // the region is full: exact slow path
 #pragma unroll 1
         for (int it = 0; it < kSweeps; it++) {
             if (!((slow >> it) & 1u)) continue;
-            const uint32_t x = (it * THREADS + threadIdx.x) * 4;
+            const uint32_t x = (it * THREADS + threadIdx.x) * kGroupKeys;
             const uint32_t row = tile[x] >> kL1Shift;
+            const uint32_t n = min(kGroupKeys, hist[row] - (x - start[row]));
 #pragma unroll 1
-            for (int e = 0; e < 4; e++)
-                if ((tile[x + e] >> kL1Shift) == row) count_key_marked(tile[x + e], o.p1, o.p2, o.p3, o.touched);
+            for (uint32_t e = 0; e < n; e++) count_key_marked(tile[x + e], o.p1, o.p2, o.p3, o.touched);
         }
     }
     STAMP(stamps, 5);
@@ -523,7 +546,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
 #endif
 }
 
-// level 2: blockIdx.y = level-1 region (bucket b1, replica), blockIdx.x = tile of kTile2Keys of its keys.  The 25 low
+// level 2: a workgroup takes a tile of kTile2Groups groups of one level-1 region (bucket b1, replica).  The 25 low
 // bits of a key split into a fine row (bits 24..16: 512 rows) and a 16-bit payload, and only the payload is staged and
 // written: below this level a key costs 2 bytes, not 4.  The grid covers the largest region's capacity, so most
 // workgroups of the sparser buckets leave at once (a device-built list of the non-empty tiles was measured and cost
@@ -532,8 +555,8 @@ constexpr int kFineBits = 16;                         // fine bucket = key >> 16
 constexpr int kFine = 1 << kFineBits;
 constexpr int kL2Rows = kFine / kL1Buckets;           // 512 fine rows per level-1 bucket
 constexpr int kBin2Threads = 1024;                    // 16 waves; 78 KiB of LDS -> 2 workgroups per CU
-constexpr int kKeys2PerThread = 24;
-constexpr int kTile2Keys = kBin2Threads * kKeys2PerThread;   // 24576 keys: row mean 48 of 72 slots (+3.5 sigma)
+constexpr int kGroups2PerThread = 5;
+constexpr int kTile2Groups = kBin2Threads * kGroups2PerThread;   // 5120 groups <= 25600 keys (runs fill their groups to ~96 %): row mean 48 of 72 slots
 constexpr int kStage2Slots = kL2Rows * kRowSlots;
 
 struct Stage2 {
@@ -569,8 +592,8 @@ __host__ __device__ inline uint32_t fine_sub_cap(const DensityCaps &c, uint32_t 
 
 typedef uint16_t __attribute__((address_space(1))) global_u16;
 
-// tiles of kTile2Keys keys that cover the capacity of one region of level-1 bucket b
-__host__ __device__ inline uint32_t tiles_of_bucket(const DensityCaps &c, uint32_t b) { return (c.cap(b) + kTile2Keys - 1) / kTile2Keys; }
+// tiles of kTile2Groups groups that cover the capacity of one region of level-1 bucket b
+__host__ __device__ inline uint32_t tiles_of_bucket(const DensityCaps &c, uint32_t b) { return (c.cap(b) + kTile2Groups - 1) / kTile2Groups; }
 
 struct Bin2Grid { uint32_t first[kL1Buckets + 1]; };   // first[b] = workgroups in front of bucket b (tiles x replicas, prefix)
 
@@ -586,40 +609,35 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (grid.first[mid] <= blockIdx.x) lo = mid; else hi = mid; }
     const uint32_t b1 = lo, within = blockIdx.x - grid.first[b1], per_region = tiles_of_bucket(caps1, b1);
     const uint32_t replica = within / per_region, tile = within % per_region;
-    const uint32_t n1 = min(cursor1[l1_cursor(b1, replica)], caps1.cap(b1));
-    const uint32_t start = tile * kTile2Keys;
+    const uint32_t n1 = min(cursor1[l1_cursor(b1, replica)], caps1.cap(b1));       // groups
+    const uint32_t start = tile * kTile2Groups;
     if (start >= n1) return;                               // uniform for the workgroup
-    const uint32_t end = min(n1, start + kTile2Keys);
-    // all of a thread's keys are loaded (16 bytes at a time: regions and tiles start on 16-byte boundaries and
-    // capacities are multiples of 4 keys, so a vector may run past n1 but not past the region) before the first append
-    const uint4 *src = reinterpret_cast<const uint4 *>(buf1 + l1_region_base(caps1, b1, replica));
-    constexpr int kVecs = kKeys2PerThread / 4;
-    uint4 v[kVecs];
+    const uint32_t end = min(n1, start + kTile2Groups);
+    // all of a thread's groups are loaded (16 bytes each) before the first append
+    const uint4 *src = reinterpret_cast<const uint4 *>(buf1) + l1_region_base(caps1, b1, replica);
+    uint4 v[kGroups2PerThread];
 #pragma unroll
-    for (int it = 0; it < kVecs; it++) {
-        const uint32_t i = start + (it * kBin2Threads + threadIdx.x) * 4;
-        v[it] = i < end ? src[i >> 2] : uint4{0, 0, 0, 0};
+    for (int it = 0; it < kGroups2PerThread; it++) {
+        const uint32_t i = start + it * kBin2Threads + threadIdx.x;
+        v[it] = i < end ? src[i] : uint4{0, 0, 0, 0};     // (count 0: nothing to append)
     }
     if (threadIdx.x < kL2Rows)
         st.rows[threadIdx.x] = (static_cast<unsigned long long>((threadIdx.x + 1) * kRowSlots) << 32) | (threadIdx.x * kRowSlots);
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < kVecs; it++) {
-        const uint32_t i = start + (it * kBin2Threads + threadIdx.x) * 4;
-        const uint32_t k[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
-        unsigned long long r[4];
-        bool real[4];                                       // (level 1 pads its runs with keys of another bucket)
+    for (int it = 0; it < kGroups2PerThread; it++) {
+        uint32_t k[kGroupKeys];
+        const uint32_t n = unpack_group(v[it], k);
+        unsigned long long r[kGroupKeys];
 #pragma unroll
-        for (int e = 0; e < 4; e++) real[e] = i + e < end && (k[e] >> kL1Shift) == b1;
+        for (uint32_t e = 0; e < kGroupKeys; e++)
+            if (e < n) r[e] = atomicAdd(&st.rows[k[e] >> kFineBits], 1ull);         // (25-bit record: bits 24..16 are the fine row)
 #pragma unroll
-        for (int e = 0; e < 4; e++)
-            if (real[e]) r[e] = atomicAdd(&st.rows[(k[e] >> kFineBits) & (kL2Rows - 1)], 1ull);
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-            if (real[e]) {
+        for (uint32_t e = 0; e < kGroupKeys; e++)
+            if (e < n) {
                 const uint32_t at = static_cast<uint32_t>(r[e]);
                 if (at < static_cast<uint32_t>(r[e] >> 32)) st.slot[at] = static_cast<uint16_t>(k[e]);
-                else count_key_marked(k[e], o.p1, o.p2, o.p3, o.touched);   // row full: exact slow path
+                else count_key_marked((b1 << kL1Shift) | k[e], o.p1, o.p2, o.p3, o.touched);   // row full: exact slow path
             }
     }
     __syncthreads();
@@ -1467,17 +1485,18 @@ int plan_count(palace_ctx *ctx, int64_t total_bases, CountPlan *pl)
     // room, plus a flat pad of 1/8 of the mean and a constant
     const int64_t max_keys = 3 * slab_bases;
     // (level-1 runs are padded to 4 keys: on average 1.5 pad keys per run of ~48)
-    const int64_t mean1 = max_keys / kRegions * 25 / 24, mean2 = max_keys / kFine / 2;    // mean2: in pairs of 16-bit keys
-    pl->caps1 = DensityCaps{static_cast<uint64_t>(mean1 + mean1 / 5) / kRunAlign, static_cast<uint32_t>(mean1 / 8 + 4096) / kRunAlign, kRunAlign};   // per level-1 region
+    // (level-1 regions hold GROUPS of five keys; a run's last group is partly filled: ~2 pad slots per run of ~72)
+    const int64_t mean1 = max_keys / kRegions / kGroupKeys * 26 / 25 + 1, mean2 = max_keys / kFine / 2;    // mean1: groups; mean2: pairs of 16-bit keys
+    pl->caps1 = DensityCaps{static_cast<uint64_t>(mean1 + mean1 / 5), static_cast<uint32_t>(mean1 / 8 + 1024), 1};   // per level-1 region
     pl->caps2 = DensityCaps{static_cast<uint64_t>(mean2 + mean2 / 5) / 4, static_cast<uint32_t>(mean2 / 8 + 2048) / 4};   // per fine bucket
     if (ctx->bin_cap_override > 0) {                       // test hook: uniform, deliberately small regions
         pl->caps2 = DensityCaps{0, static_cast<uint32_t>((ctx->bin_cap_override + 3) / 4)};
-        pl->caps1 = DensityCaps{0, static_cast<uint32_t>(ctx->bin_cap_override), kRunAlign};
+        pl->caps1 = DensityCaps{0, static_cast<uint32_t>((ctx->bin_cap_override + kGroupKeys - 1) / kGroupKeys), 1};
     }
     PALACE_REQUIRE(pl->caps1.cap(0) < (1u << 31) && pl->caps2.cap(0) < (1u << 30), "slab too large for 32-bit region cursors");
     pl->cur1_bytes = align_up(kRegions * sizeof(unsigned int), 256);
     pl->cur2_bytes = align_up(static_cast<size_t>(kFine) * kXcds * sizeof(unsigned int), 256);       // a cursor per fine bucket and XCD
-    pl->buf1_bytes = align_up(static_cast<size_t>(pl->caps1.prefix(kL1Buckets)) * kL1Replicas * 4, 256);
+    pl->buf1_bytes = align_up(static_cast<size_t>(pl->caps1.prefix(kL1Buckets)) * kL1Replicas * 16, 256);
     PALACE_REQUIRE(pl->buf1_bytes < (1ull << 36), "slab too large: level 1 addresses its regions as 2^32 groups of 16 bytes");
     pl->buf2_bytes = align_up(static_cast<size_t>(pl->caps2.prefix(kL1Buckets)) * kL2Rows * 4, 256);    // pairs of 2-byte keys
     pl->n_chunks = (total_bases + 63) / 64;
@@ -1488,7 +1507,7 @@ int plan_count(palace_ctx *ctx, int64_t total_bases, CountPlan *pl)
     //      word of a stream must cover two more words, for the last tile of EVERY slab (inner slabs read real words);
     PALACE_REQUIRE(pl->words_bytes >= (static_cast<size_t>(total_bases >> 5) + 3) * 4, "stream pad does not cover the last tile's look-ahead");
     //  (b) destinations are 32-bit indices of 16-byte groups into buf1: base of the last region + its capacity < 2^32 groups;
-    PALACE_REQUIRE(pl->caps1.prefix(kL1Buckets) * kL1Replicas / 4 < (1ull << 32), "level-1 regions exceed 2^32 groups of 16 bytes");
+    PALACE_REQUIRE(pl->caps1.prefix(kL1Buckets) * kL1Replicas < (1ull << 32), "level-1 regions exceed 2^32 groups of 16 bytes");
     //  (c) a region cursor keeps counting when its region is full (the excess takes the exact path): it must not wrap even
     //      if every key of the slab's tiles of one replica lands in one bucket.
     PALACE_REQUIRE(3ull * static_cast<uint64_t>(slab_bases) / kL1Replicas + (1ull << 20) < (1ull << 32), "slab too large for 32-bit region cursors");
