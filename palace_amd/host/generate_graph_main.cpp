@@ -24,6 +24,7 @@
 #include "bam.hpp"
 #include "depth_host.hpp"
 #include "fastx.hpp"
+#include "stage04_fused.hpp"
 #include "trace.hpp"
 
 using namespace palace_host;
@@ -44,7 +45,12 @@ void usage(const char *prog)            // same option surface as generate_graph
               << "  --lib <FR|RF|FF>          Library type (accepted, unused as in the reference)\n"
               << "  --min-count <int>         Minimum supporting reads (default: 5)\n"
               << "  --min-score <double>      (accepted, unused as in the reference)\n"
-              << "  --debug                   (accepted; per-read traces are not produced)\n";
+              << "  --debug                   (accepted; per-read traces are not produced)\n"
+              << "Stage 04 in this process (optional; every file of palace:566-600, none read back):\n"
+              << "  --hit-seqs F --node-scores F --blast F --fasta-fai F --paths F   inputs of filter_graph.py (+ --blast-ratio, --score-threshold: 0.7)\n"
+              << "  --filtered-pre F --filtered F --all-hit-segs F                  its outputs (F after uniq)\n"
+              << "  --linear F --cycle F --cycle-nodup F --all-result F              matching / remove_cycle_dup.py / cat outputs\n"
+              << "  -s  -b  -i <int>  --aggressive                                   matching options (palace:587-590)\n";
 }
 
 #define CK(call)                                                                        \
@@ -176,9 +182,18 @@ int main(int argc, char **argv)
                                         {"min-count", required_argument, 0, 1003},
                                         {"min-score", required_argument, 0, 1004},
                                         {"debug", no_argument, 0, 1005},
+                                        {"hit-seqs", required_argument, 0, 1100}, {"node-scores", required_argument, 0, 1101},
+                                        {"blast", required_argument, 0, 1102}, {"fasta-fai", required_argument, 0, 1103},
+                                        {"paths", required_argument, 0, 1104}, {"blast-ratio", required_argument, 0, 1105},
+                                        {"score-threshold", required_argument, 0, 1106}, {"filtered-pre", required_argument, 0, 1107},
+                                        {"filtered", required_argument, 0, 1108}, {"all-hit-segs", required_argument, 0, 1109},
+                                        {"linear", required_argument, 0, 1110}, {"cycle", required_argument, 0, 1111},
+                                        {"cycle-nodup", required_argument, 0, 1112}, {"all-result", required_argument, 0, 1113},
+                                        {"aggressive", no_argument, 0, 1114},
                                         {0, 0, 0, 0}};
+    Stage04Options s4o;
     int opt, li = 0;
-    while ((opt = getopt_long(argc, argv, "e:q:n:p:P:", long_opts, &li)) != -1) {
+    while ((opt = getopt_long(argc, argv, "e:q:n:p:P:sbi:", long_opts, &li)) != -1) {
         switch (opt) {                                       // clamps as generate_graph.cpp:575-590
         case 'e': prm.max_end = std::max(1, std::atoi(optarg)); break;
         case 'q': prm.min_mapq = std::max(0, std::atoi(optarg)); break;
@@ -195,10 +210,32 @@ int main(int argc, char **argv)
         case 1003: min_count = std::max(1, std::atoi(optarg)); break;
         case 1004: break;
         case 1005: break;
+        case 1100: s4o.gene_file = optarg; break;
+        case 1101: s4o.score_file = optarg; break;
+        case 1102: s4o.blast_file = optarg; break;
+        case 1103: s4o.fasta_fai = optarg; break;
+        case 1104: s4o.paths_file = optarg; break;
+        case 1105: s4o.blast_ratio = std::atof(optarg); break;
+        case 1106: s4o.score_threshold = std::atof(optarg); break;
+        case 1107: s4o.pre_out = optarg; break;
+        case 1108: s4o.filtered_out = optarg; break;
+        case 1109: s4o.hit_segs_out = optarg; break;
+        case 1110: s4o.linear_out = optarg; break;
+        case 1111: s4o.cycle_out = optarg; break;
+        case 1112: s4o.nodup_out = optarg; break;
+        case 1113: s4o.result_out = optarg; break;
+        case 1114: s4o.aggressive = true; break;
+        case 's': s4o.self_loops = true; break;
+        case 'b': s4o.break_cycles = true; break;
+        case 'i': s4o.iterations = std::max(1, std::atoi(optarg)); break;
         default: usage(argv[0]); return 1;
         }
     }
     if (argc - optind < 4) { usage(argv[0]); return 1; }
+    if (s4o.enabled() && (s4o.gene_file.empty() || s4o.score_file.empty() || s4o.blast_file.empty() || s4o.fasta_fai.empty() || s4o.paths_file.empty())) {
+        std::cerr << "generateGraph: stage 04 needs --hit-seqs, --node-scores, --blast, --fasta-fai and --paths\n";
+        return 1;
+    }
     const std::string bam_path = argv[optind], fai_path = argv[optind + 1], out_path = argv[optind + 2];
     // <avgDepth> = "auto": the depth stage (palace:538-552) is done here, on the records this run decodes anyway; the value
     // goes through the same text the driver would have passed ("%.6g" of awk, then atof)
@@ -225,6 +262,10 @@ int main(int argc, char **argv)
     palace_ctx *ctx = nullptr;
     int ctx_rc = 0;
     std::string ctx_err;
+    Stage04Side s4side;
+    std::thread side04;
+    if (s4o.enabled()) side04 = std::thread([&] { stage04_read_side_files(s4o, c, s4side); });     // beside the inflate, like the rest
+    auto join04 = [&] { if (side04.joinable()) side04.join(); };
     std::thread side([&] { name_ranks(c.target_name, by_name, rank); });
     std::thread side2([&] { fkeys = fastg_keys(fai_path, c, 4); });
     std::thread hip_up([&] {
@@ -235,7 +276,7 @@ int main(int argc, char **argv)
         load_bam_finish(load, seed);
     } catch (const std::exception &e) {
         std::cerr << e.what() << "\n";
-        side.join(); side2.join(); hip_up.join();
+        side.join(); side2.join(); hip_up.join(); join04();
         return 1;
     }
     tr.lap("bam records");
@@ -243,7 +284,7 @@ int main(int argc, char **argv)
     side2.join();
     tr.lap("name ranks + fastg keys (joined)");
     hip_up.join();
-    if (ctx_rc) { std::cerr << "generateGraph: cannot set up the GPU: " << ctx_err << "\n"; return 1; }
+    if (ctx_rc) { std::cerr << "generateGraph: cannot set up the GPU: " << ctx_err << "\n"; join04(); return 1; }
     tr.lap("hip runtime up (joined)");
     if (auto_depth) {
         std::string text;
@@ -305,13 +346,16 @@ int main(int argc, char **argv)
     std::vector<palace_graph_edge> edges(static_cast<size_t>(n_edges));
     std::vector<int32_t> cn_dev(static_cast<size_t>(nt));
     CK(palace_malloc(ctx, std::max<size_t>(1, nt) * 4, &p));
-    CK(palace_graph_copy_numbers(ctx, d_consumed, d_tlen, nt, avg_depth, static_cast<int32_t *>(p)));
+    int32_t *d_cn = static_cast<int32_t *>(p);
+    CK(palace_graph_copy_numbers(ctx, d_consumed, d_tlen, nt, avg_depth, d_cn));
     CK(palace_d2h(ctx, cn_dev.data(), p, cn_dev.size() * 4));
     CK(palace_d2h(ctx, consumed.data(), d_consumed, consumed.size() * 8));
     CK(palace_d2h(ctx, edges.data(), d_edges, edges.size() * sizeof(palace_graph_edge)));
     tr.lap("resolve + d2h");
-    palace_ctx_destroy(ctx);
-    tr.lap("ctx destroy");
+    if (!s4o.enabled()) {
+        palace_ctx_destroy(ctx);
+        tr.lap("ctx destroy");
+    }
 
     // ---- text output (generate_graph.cpp:1019-1076) ----
     FILE *out = std::fopen(out_path.c_str(), "w");
@@ -320,6 +364,8 @@ int main(int argc, char **argv)
     std::setvbuf(out, big.data(), _IOFBF, big.size());
     // SEG lines in name order; formatted by all threads (a slice of the order each), written in order
     std::vector<std::string> seg_text(static_cast<size_t>(threads) * 4);
+    struct SegAt { int32_t tid; size_t at, len; };
+    std::vector<std::vector<SegAt>> seg_at(seg_text.size());
     pool_for(seg_text.size(), threads, [&](size_t part) {
         std::string &txt = seg_text[part];
         char line[512];
@@ -342,18 +388,25 @@ int main(int argc, char **argv)
             const double cnf = avg_depth > 0.0 ? depth / avg_depth : 0.0;
             const int cn = unique_name ? cn_dev[best] : static_cast<int>(std::floor(cnf + 0.5));   // device value; host only for duplicate names
             const std::string &nm = c.target_name[best];
+            const size_t at = txt.size();
             if (nm.size() < 400) txt.append(line, static_cast<size_t>(std::snprintf(line, sizeof line, "SEG %s %g %d\n", nm.c_str(), depth, cn)));
             else { txt += "SEG " + nm; txt.append(line, static_cast<size_t>(std::snprintf(line, sizeof line, " %g %d\n", depth, cn))); }
+            seg_at[part].push_back({best, at, txt.size() - at});
         }
     });
     for (const std::string &txt : seg_text) std::fwrite(txt.data(), 1, txt.size(), out);
-    std::sort(edges.begin(), edges.end(), [&](const palace_graph_edge &a, const palace_graph_edge &b) {
+    // `_graph.txt` order of the edges, as an index into the device order (stage 04 flags edges in device order)
+    std::vector<uint32_t> sorted_index(edges.size());
+    std::iota(sorted_index.begin(), sorted_index.end(), 0u);
+    std::sort(sorted_index.begin(), sorted_index.end(), [&](uint32_t ia, uint32_t ib) {
+        const palace_graph_edge &a = edges[ia], &b = edges[ib];
         if (rank[a.left] != rank[b.left]) return rank[a.left] < rank[b.left];
         if (rank[a.right] != rank[b.right]) return rank[a.right] < rank[b.right];
         if (a.oL != b.oL) return a.oL < b.oL;                          // '+' (43) < '-' (45)
         return a.oR < b.oR;
     });
-    for (const auto &e : edges) {
+    for (uint32_t ei : sorted_index) {
+        const palace_graph_edge &e = edges[ei];
         const uint32_t supp = e.counts[0], supp_nf = e.counts[1], span = e.counts[2], span_nf = e.counts[3];
         const uint32_t total = supp + supp_nf + span + span_nf;
         if (total == 0 || total < static_cast<uint32_t>(min_count)) continue;   // :1056-1061
@@ -365,6 +418,20 @@ int main(int argc, char **argv)
         return 1;
     }
     tr.lap("text output");
+    if (s4o.enabled()) {
+        join04();
+        bool unique_names = true;
+        for (int32_t k = 1; k < nt && unique_names; k++) unique_names = rank[by_name[k]] != rank[by_name[k - 1]];
+        if (!unique_names) { std::cerr << "generateGraph: stage 04 in this process needs distinct target names; run the stages separately\n"; return 1; }
+        std::vector<std::string_view> raw_seg(static_cast<size_t>(nt));
+        for (size_t part = 0; part < seg_text.size(); part++)
+            for (const SegAt &sg : seg_at[part]) raw_seg[static_cast<size_t>(sg.tid)] = std::string_view(seg_text[part]).substr(sg.at, sg.len);
+        std::string err;
+        if (stage04_run(ctx, s4o, c, s4side, rank, raw_seg, edges, sorted_index, min_count, d_edges, n_cands, d_cn, tr, err)) {
+            std::cerr << "generateGraph: stage 04: " << err << "\n";
+            return 1;
+        }
+    }
     std::fflush(nullptr);
     _exit(0);                   // the output is complete and closed: skip tearing down gigabytes of host containers
 }

@@ -1,0 +1,441 @@
+// Stage 04 inside generateGraph (optional): BAM -> `_graph.txt` -> `_filtered_graph_pre.txt` / `_filtered_graph.txt` ->
+// `linear` / `cycle` / `cycle_nodup` / `all_result` in ONE process, every named artefact of palace:555-600 written, none of
+// them read back.  The reference runs five processes here (generateGraph, filter_graph.py, uniq, matching,
+// remove_cycle_dup.py + cat) coupled by text files; this replacement's separate executables stay as they are for the
+// unchanged driver, and this path gives byte for byte the files that chain gives (tests/test_gpu_stage04.py) while the graph
+// stays in HBM: the selection and the decomposition are the library's palace_stage04_* (csrc/filter.hip, decomp.hip).
+//
+// Host work here: the side files of filter_graph.py (read by threads while the BAM is inflated), and text.
+// Line citations are to share/palace/scripts/filter_graph.py unless they name another file.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/palace_hip.h"
+#include "bam.hpp"
+#include "fastx.hpp"
+#include "textio.hpp"
+#include "trace.hpp"
+
+namespace palace_host {
+
+struct Stage04Options {
+    // inputs of filter_graph.py (argv 6-10, 12, 13; palace:568-579)
+    std::string gene_file, score_file, blast_file, fasta_fai, paths_file;
+    double blast_ratio = 0.7, score_threshold = 0.7;
+    // outputs
+    std::string pre_out, filtered_out, hit_segs_out, linear_out, cycle_out, nodup_out, result_out;
+    // matching options (palace:587-590)
+    int iterations = 10;
+    bool self_loops = false, break_cycles = false, aggressive = false;
+    bool enabled() const { return !pre_out.empty() || !filtered_out.empty() || !result_out.empty() || !linear_out.empty(); }
+};
+
+namespace s4 {
+
+inline bool has_e(sv s) { return s.find('e') != sv::npos || s.find('E') != sv::npos; }
+inline bool to_double(sv tok, double &v)                   // float(text): the whole (stripped) token must be a number
+{
+    const std::string t(strip(tok));
+    if (t.empty() || t.find('x') != std::string::npos || t.find('X') != std::string::npos) return false;
+    char *end = nullptr;
+    v = std::strtod(t.c_str(), &end);
+    return end == t.c_str() + t.size();
+}
+inline bool to_int(sv tok, long long &v)
+{
+    const sv t = strip(tok);
+    size_t i = 0;
+    bool neg = false;
+    if (i < t.size() && (t[i] == '+' || t[i] == '-')) neg = t[i++] == '-';
+    long long x = 0;
+    const size_t first = i;
+    for (; i < t.size() && t[i] >= '0' && t[i] <= '9'; i++) x = x * 10 + (t[i] - '0');
+    if (i == first || i != t.size() || i - first > 18) return false;
+    v = neg ? -x : x;
+    return true;
+}
+inline std::string fixed3(double v)
+{
+    char buf[400];
+    std::snprintf(buf, sizeof buf, "%.3f", v);
+    return buf;
+}
+// fields written in scientific notation become plain (l.178-188)
+inline std::string plain_number(sv tok)
+{
+    double v;
+    if (!has_e(tok) || !to_double(tok, v)) return std::string(tok);
+    char buf[400];
+    if (std::isfinite(v) && v == std::floor(v)) {
+        std::snprintf(buf, sizeof buf, "%.0f", v);
+        if (buf[0] == '-' && buf[1] == '0' && buf[2] == 0) return "0";
+        return buf;
+    }
+    std::string s = fixed3(v);
+    while (!s.empty() && s.back() == '0') s.pop_back();
+    if (!s.empty() && s.back() == '.') s.pop_back();
+    return s;
+}
+
+}  // namespace s4
+
+// what the side files say about every BAM target (names that are no target cannot have a SEG line and are ignored, as the
+// script ignores facts about names its graph does not list)
+struct Stage04Side {
+    std::vector<uint8_t> seed;                     // bit 0 blast (l.66-94), bit 1 gene (l.99-102), bit 2 score > threshold (l.104-112)
+    std::vector<std::string> score_text;           // "%.3f" text or "0.0"; empty = no line ("0.000" in the SEG text)
+    std::vector<int32_t> name_len;                 // get_edge_len (l.50-52); -1 = the name has no such token
+    std::vector<int64_t> path_off{0};
+    std::vector<int32_t> path_tok;
+    std::string error;                             // first thing the script would have died on
+};
+
+inline void stage04_read_side_files(const Stage04Options &o, const BamColumns &c, Stage04Side &out)
+{
+    const size_t nt = c.target_name.size();
+    out.seed.assign(nt, 0);
+    out.score_text.assign(nt, std::string());
+    out.name_len.assign(nt, -1);
+    std::vector<long long> fai_len(nt, -1);
+    Names tokens;                                  // id token (EDGE_<token>_...) -> target, from the fasta index as the script builds it
+    std::vector<int32_t> token_tid;
+    std::string err_fai, err_blast, err_gene, err_score, err_paths;
+    // name lengths: every target, not only those the fasta index lists
+    for (size_t t = 0; t < nt; t++) {
+        const std::string &nm = c.target_name[t];
+        size_t a = 0;
+        int k = 0;
+        for (; k < 3; k++) { a = nm.find('_', a); if (a == std::string::npos) break; a++; }
+        if (k == 3) {
+            const size_t b = nm.find('_', a);
+            long long v;
+            if (s4::to_int(sv(nm).substr(a, b == std::string::npos ? std::string::npos : b - a), v) && v < (1ll << 31)) out.name_len[t] = static_cast<int32_t>(v);
+        }
+    }
+    std::unique_ptr<MappedText> fai, blast, genes, scores, paths;
+    auto open = [](const std::string &p, std::unique_ptr<MappedText> &m, std::string &err) {
+        try { m.reset(new MappedText(p)); } catch (const std::exception &e) { err = e.what(); }
+    };
+    open(o.fasta_fai, fai, err_fai); open(o.blast_file, blast, err_blast); open(o.gene_file, genes, err_gene);
+    open(o.score_file, scores, err_score); open(o.paths_file, paths, err_paths);
+    for (const std::string *e : {&err_fai, &err_blast, &err_gene, &err_score, &err_paths})
+        if (!e->empty()) { out.error = *e; return; }
+
+    // fasta index first: lengths (the BLAST rule divides by them) and the id tokens (contigs.paths speaks in them)
+    {
+        std::vector<sv> cols, parts;
+        tokens.reserve(nt + 16);
+        for_each_line(fai->data, fai->size, [&](sv line) {
+            if (!err_fai.empty()) return;
+            split_on(strip(line), '\t', cols);
+            long long len;
+            if (cols.size() < 2 || !s4::to_int(cols[1], len)) { err_fai = "short or non-numeric line in the fasta index"; return; }
+            split_on(cols[0], '_', parts);
+            if (parts.size() < 2) { err_fai = "fasta index name without an id token: " + std::string(cols[0]); return; }
+            const int32_t tid = c.tid_of(cols[0]);
+            if (tid >= 0) fai_len[static_cast<size_t>(tid)] = len;
+            const int t = tokens.intern(parts[1]);
+            if (static_cast<size_t>(t) >= token_tid.size()) token_tid.resize(static_cast<size_t>(t) + 1, -1);
+            token_tid[static_cast<size_t>(t)] = tid;                   // a later line with the same token wins, as in a dict (-1: no target)
+        });
+    }
+    std::thread t_blast([&] {                      // consecutive rows of one (query, subject) pair form a group (l.66-94)
+        std::vector<sv> cols;
+        sv cur_q, cur_s;
+        long long aligned = 0;
+        const double cut = o.blast_ratio * 100;
+        auto group_done = [&](sv q, bool last) {
+            const int32_t tid = c.tid_of(q);
+            if (tid < 0 || fai_len[static_cast<size_t>(tid)] < 0) {
+                // (the script looks the query up in the fasta index; a query that is no BAM target cannot have a SEG line)
+                if (tid >= 0 && !last) err_blast = "BLAST query not in the fasta index: " + std::string(q);
+                return;
+            }
+            const long long len = fai_len[static_cast<size_t>(tid)];
+            if (len == 0) { err_blast = "contig of length 0 in the fasta index: " + std::string(q); return; }
+            if (static_cast<double>(aligned) / static_cast<double>(len) > o.blast_ratio || aligned > 2000) out.seed[static_cast<size_t>(tid)] |= 1;
+        };
+        for_each_line(blast->data, blast->size, [&](sv line) {
+            if (!err_blast.empty()) return;
+            split_on(strip(line), '\t', cols);
+            double ident;
+            long long alen;
+            if (cols.size() < 4 || !s4::to_double(cols[2], ident) || !s4::to_int(cols[3], alen)) { err_blast = "malformed line in the BLAST table"; return; }
+            const sv q = cols[0], s = cols[1];
+            const bool new_group = (cur_q != q && !cur_q.empty()) || (cur_s != s && !cur_s.empty());
+            if (new_group) { group_done(cur_q, false); aligned = ident > cut ? alen : 0; }
+            else if (ident > cut) aligned += alen;
+            cur_q = q; cur_s = s;
+        });
+        if (err_blast.empty() && !cur_q.empty()) group_done(cur_q, true);
+    });
+    std::vector<uint8_t> gene_hit(nt, 0);          // (its own bytes: the BLAST thread is writing `seed` meanwhile)
+    std::thread t_gene([&] {                       // first column, untrimmed (l.101)
+        for_each_line(genes->data, genes->size, [&](sv line) {
+            const size_t t = line.find('\t');
+            const int32_t tid = c.tid_of(t == sv::npos ? line : line.substr(0, t));
+            if (tid >= 0) gene_hit[static_cast<size_t>(tid)] = 1;
+        });
+    });
+    t_blast.join();
+    t_gene.join();
+    for (size_t t = 0; t < nt; t++) if (gene_hit[t]) out.seed[t] |= 2;
+    std::thread t_score([&] {                      // l.104-112
+        const std::vector<size_t> cut = line_cuts(scores->data, scores->size, 8);
+        std::vector<std::string> errs(cut.size() - 1);
+        for_parts(cut, [&](size_t k, size_t a, size_t b) {
+            std::vector<sv> cols;
+            for_each_line(scores->data + a, b - a, [&](sv line) {
+                if (!errs[k].empty()) return;
+                split_on(strip(line), '\t', cols);
+                double v = 0;
+                if (cols.size() < 2 || (!s4::has_e(cols[1]) && !s4::to_double(cols[1], v))) { errs[k] = "malformed line in the score table"; return; }
+                const int32_t tid = c.tid_of(cols[0]);
+                if (tid < 0) return;
+                std::string text = s4::has_e(cols[1]) ? std::string("0.0") : s4::fixed3(v);
+                const double rounded = std::strtod(text.c_str(), nullptr);
+                // (distinct targets per line; a repeated name: the later line wins, parts are in file order only per part --
+                //  a name listed twice in the score file is not something the pipeline produces)
+                out.score_text[static_cast<size_t>(tid)] = std::move(text);
+                if (rounded > o.score_threshold) out.seed[static_cast<size_t>(tid)] |= 4; else out.seed[static_cast<size_t>(tid)] &= static_cast<uint8_t>(~4);
+            });
+        });
+        for (const auto &e : errs) if (!e.empty() && err_score.empty()) err_score = e;
+    });
+    std::thread t_paths([&] {                      // contigs.paths: every line that is no NODE header (l.126-137)
+        out.path_off.reserve(paths->size / 12 + 16);
+        out.path_tok.reserve(paths->size / 6 + 16);
+        std::string clean;
+        for_each_line(paths->data, paths->size, [&](sv raw) {
+            const sv s = strip(raw);
+            clean.clear();
+            for (char ch : s) if (ch != ';') clean += ch;
+            if (sv(clean).substr(0, 4) == "NODE") return;
+            size_t p = 0;
+            while (p <= clean.size()) {
+                const size_t comma = clean.find(',', p);
+                const sv tok = sv(clean).substr(p, comma == std::string::npos ? sv::npos : comma - p);
+                p = comma == std::string::npos ? clean.size() + 1 : comma + 1;
+                int32_t code = -1;
+                if (!tok.empty()) {
+                    const int t = tokens.find(tok.substr(0, tok.size() - 1));
+                    const int32_t tid = t < 0 ? -1 : token_tid[static_cast<size_t>(t)];
+                    if (tid >= 0) code = 2 * tid + (tok.back() == '-');
+                }
+                out.path_tok.push_back(code);
+            }
+            out.path_off.push_back(static_cast<int64_t>(out.path_tok.size()));
+        });
+    });
+    t_score.join();
+    t_paths.join();
+    for (const std::string *e : {&err_fai, &err_blast, &err_gene, &err_score, &err_paths})
+        if (!e->empty() && out.error.empty()) out.error = *e;
+}
+
+// remove_cycle_dup.py:3-30: pairs of lines (an odd last line is paired with "\n"), first occurrence of every pair kept
+inline std::string cycle_without_duplicates(const std::string &cyc)
+{
+    std::vector<sv> lines;
+    for_each_line(cyc.data(), cyc.size(), [&](sv l) { lines.push_back(l); });
+    std::string out;
+    std::unordered_set<std::string> seen;
+    for (size_t i = 0; i < lines.size(); i += 2) {
+        std::string pair(lines[i]);
+        pair += '\x01';
+        pair += i + 1 < lines.size() ? std::string(lines[i + 1]) : std::string("\n");
+        if (!seen.insert(pair).second) continue;
+        out.append(lines[i]);
+        out.append(i + 1 < lines.size() ? lines[i + 1] : sv("\n"));
+    }
+    return out;
+}
+
+inline bool write_file(const std::string &path, const std::string &text)
+{
+    if (path.empty()) return true;
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = std::fwrite(text.data(), 1, text.size(), f) == text.size();
+    return (std::fclose(f) == 0) && ok;
+}
+
+// `uniq`: a line equal to the one before it is dropped
+inline std::string uniq_lines(const std::string &text)
+{
+    std::string out;
+    out.reserve(text.size());
+    sv prev;
+    bool have = false;
+    for_each_line(text.data(), text.size(), [&](sv l) {
+        if (have && l == prev) return;
+        out.append(l);
+        prev = l; have = true;
+    });
+    return out;
+}
+
+// After generateGraph's resolve: selection, decomposition, every file.  raw_seg[t] = the SEG line of target t as `_graph.txt`
+// has it (empty: none); edges = the aggregated edges in DEVICE order (d_edges), sorted_index = their `_graph.txt` order.
+// Returns 0, or 1 with `err` set.
+inline int stage04_run(palace_ctx *ctx, const Stage04Options &o, const BamColumns &c, const Stage04Side &side,
+                       const std::vector<int32_t> &rank, const std::vector<sv> &raw_seg, const std::vector<palace_graph_edge> &edges,
+                       const std::vector<uint32_t> &sorted_index, int min_count, const palace_graph_edge *d_edges, int64_t n_cands,
+                       const int32_t *d_cn, Trace &tr, std::string &err)
+{
+    const int32_t nt = static_cast<int32_t>(c.target_name.size());
+    auto fail = [&](const std::string &what) { err = what; return 1; };
+    if (!side.error.empty()) return fail(side.error);
+    palace_stage04_inputs in{};
+    in.n_segs = nt; in.min_count = min_count;
+    in.seed = side.seed.data(); in.tlen = c.target_len.data(); in.rank = rank.data();
+    std::vector<int32_t> name_len(side.name_len);
+    for (int32_t &v : name_len) if (v < 0) v = 0;                         // (only read for members of contigs.paths lines, whose names have the token)
+    in.name_len = name_len.data();
+    in.n_paths = static_cast<int64_t>(side.path_off.size()) - 1;
+    in.path_off = side.path_off.data(); in.path_tok = side.path_tok.data();
+    palace_stage04 *st = nullptr;
+    if (palace_stage04_create(ctx, &in, &st)) return fail(palace_last_error());
+    void *p = nullptr;
+    if (palace_malloc(ctx, 8, &p)) return fail(palace_last_error());
+    const int64_t n_edges = static_cast<int64_t>(edges.size());
+    if (palace_h2d(ctx, p, &n_edges, 8)) return fail(palace_last_error());
+    if (palace_stage04_filter(ctx, st, d_edges, static_cast<const int64_t *>(p), std::max<int64_t>(1, std::max(n_cands, n_edges)))) return fail(palace_last_error());
+    if (palace_stage04_match(ctx, st, d_edges, d_cn, o.iterations, o.aggressive ? 1 : 0, 1)) return fail(palace_last_error());
+    std::vector<uint8_t> seg_flags(static_cast<size_t>(nt)), edge_flags(static_cast<size_t>(n_edges));
+    if (palace_stage04_flags(ctx, st, seg_flags.data(), edge_flags.data(), n_edges)) return fail(palace_last_error());
+    int64_t counts[8];
+    if (palace_stage04_counts(ctx, st, counts)) return fail(palace_last_error());   // (also what the script dies on)
+    tr.lap("stage 04: selection on the device");
+
+    // ---- `_filtered_graph_pre.txt` (l.252-264): selected SEG lines and rescued ones in graph order, the kept junctions ----
+    std::vector<int32_t> by_rank(static_cast<size_t>(nt));
+    for (int32_t t = 0; t < nt; t++) by_rank[static_cast<size_t>(rank[static_cast<size_t>(t)])] = t;
+    std::string pre, hits;
+    pre.reserve(static_cast<size_t>(counts[4] + counts[5]) * 72 + static_cast<size_t>(counts[2] + counts[3]) * 110);
+    std::vector<sv> toks;
+    for (int32_t r = 0; r < nt; r++) {
+        const int32_t t = by_rank[static_cast<size_t>(r)];
+        const uint8_t sd = side.seed[static_cast<size_t>(t)];
+        if (sd && !raw_seg[static_cast<size_t>(t)].empty()) {           // all_hit_segs.txt in SEG order (l.163-171, 266-269)
+            hits += "SAMPLE\t"; hits += c.target_name[static_cast<size_t>(t)]; hits += '\t';
+            if (sd & 1) hits += "ref+";
+            if (sd & 4) hits += "score+";
+            if (sd & 2) hits += "gene+";
+            hits += '\n';
+        }
+        if (!(seg_flags[static_cast<size_t>(t)] & 1)) continue;
+        split_ws(raw_seg[static_cast<size_t>(t)], toks);                  // l.173-197
+        for (size_t i = 0; i < toks.size(); i++) {
+            if (i) pre += ' ';
+            if (i < 2) pre.append(toks[i]); else pre += s4::plain_number(toks[i]);
+        }
+        pre += (sd & 2) ? " 1 " : " 0 ";
+        pre += side.score_text[static_cast<size_t>(t)].empty() ? std::string("0.000") : side.score_text[static_cast<size_t>(t)];
+        pre += (sd & 1) ? " 1\n" : " 0\n";
+    }
+    for (int32_t r = 0; r < nt; r++) {
+        const int32_t t = by_rank[static_cast<size_t>(r)];
+        if ((seg_flags[static_cast<size_t>(t)] & 3) != 2) continue;
+        pre.append(strip(raw_seg[static_cast<size_t>(t)]));
+        pre += " 0 1.0 0\n";
+    }
+    char line[1024];
+    auto junc_line = [&](const palace_graph_edge &e) {
+        const uint32_t supp = e.counts[0], supp_nf = e.counts[1], span = e.counts[2], span_nf = e.counts[3];
+        const std::string &l = c.target_name[static_cast<size_t>(e.left)], &r2 = c.target_name[static_cast<size_t>(e.right)];
+        if (l.size() + r2.size() < 900)
+            pre.append(line, static_cast<size_t>(std::snprintf(line, sizeof line, "JUNC %s %c %s %c %u %u\n", l.c_str(), e.oL ? '-' : '+', r2.c_str(),
+                                                               e.oR ? '-' : '+', supp + span + supp_nf, span_nf)));
+        else {
+            pre += "JUNC " + l + (e.oL ? " - " : " + ") + r2 + (e.oR ? " - " : " + ");
+            pre.append(line, static_cast<size_t>(std::snprintf(line, sizeof line, "%u %u\n", supp + span + supp_nf, span_nf)));
+        }
+    };
+    for (int pass = 0; pass < 2; pass++)
+        for (uint32_t i : sorted_index) {
+            const uint8_t f = edge_flags[i];
+            if (pass == 0 ? (f & 2) : ((f & 6) == 4)) junc_line(edges[i]);
+        }
+    if (!write_file(o.pre_out, pre)) return fail("cannot write " + o.pre_out);
+    if (!o.filtered_out.empty() && !write_file(o.filtered_out, uniq_lines(pre))) return fail("cannot write " + o.filtered_out);
+    if (!write_file(o.hit_segs_out, hits)) return fail("cannot write " + o.hit_segs_out);
+    tr.lap("stage 04: filtered graph text");
+
+    // ---- matching's two files, as palace_amd/host/matching_main.cpp writes them ----
+    palace_match_result *res = nullptr;
+    const int32_t *contig_of = nullptr;
+    int64_t n_f = 0;
+    if (palace_stage04_result(ctx, st, &res, &contig_of, &n_f)) return fail(palace_last_error());
+    tr.lap("stage 04: decomposition (waited)");
+    const int64_t n_comp = palace_match_result_count(res);
+    const int64_t *off = palace_match_result_offsets(res);
+    const int32_t *verts = palace_match_result_verts(res), *iter = palace_match_result_iter(res), *open_at = palace_match_result_open_at(res);
+    const uint8_t *kind = palace_match_result_kind(res);
+    const uint64_t *bare = palace_match_result_bare(res);
+    std::string lin, cyc, selfs;
+    std::unordered_set<std::string> lin_seen, cyc_seen;
+    auto name_of = [&](int32_t v) -> const std::string & { return c.target_name[static_cast<size_t>(contig_of[v >> 1])]; };
+    auto comp_line = [&](int64_t k, int64_t first) {
+        std::string s;
+        const int64_t n = off[k + 1] - off[k];
+        for (int64_t i = 0; i < n; i++) {
+            const int32_t v = verts[off[k] + (first + i) % n];
+            if (i) s += '\t';
+            s += name_of(v);
+            s += (v & 1) ? '-' : '+';
+        }
+        s += '\n';
+        return s;
+    };
+    // round 0 lists the bare segments (one-vertex paths) between the components, in first-vertex order; names are distinct,
+    // so a bare line can only repeat a line already written if a component consists of that one vertex -- which it cannot
+    // (a component vertex has an arc, a bare segment has none): bare lines need no look-up
+    int64_t k = 0;
+    int64_t next_bare = 0;                                              // next filtered segment id to test for bareness
+    auto bare_until = [&](int64_t seg_end) {                             // bare segments with id < seg_end
+        for (; next_bare < seg_end; next_bare++)
+            if ((bare[next_bare >> 6] >> (next_bare & 63)) & 1) { lin += c.target_name[static_cast<size_t>(contig_of[next_bare])]; lin += "+\n"; }
+    };
+    for (; k < n_comp && iter[k] == 0; k++) {
+        bare_until((static_cast<int64_t>(verts[off[k]]) + 1) >> 1);       // a component goes behind every bare s with 2 s < its first vertex
+        const int64_t n = off[k + 1] - off[k];
+        if (!kind[k]) { std::string s = comp_line(k, 0); if (lin_seen.insert(s).second) lin += s; continue; }
+        std::string s = comp_line(k, 0);
+        if (!cyc_seen.insert(s).second) continue;
+        if (n == 1 && o.self_loops) selfs += "self\n" + s; else cyc += "iter 0\n" + s;
+        if (o.break_cycles) { std::string op = comp_line(k, open_at[k]); if (lin_seen.insert(op).second) lin += op; }
+    }
+    bare_until(n_f);
+    for (; k < n_comp; k++) {
+        const int64_t n = off[k + 1] - off[k];
+        if (!kind[k]) {
+            if (n == 1) continue;                                         // a bare segment is reported once, in round 0
+            std::string s = comp_line(k, 0);
+            if (lin_seen.insert(s).second) lin += s;
+            continue;
+        }
+        std::string s = comp_line(k, 0);
+        if (!cyc_seen.insert(s).second) continue;
+        if (n == 1 && o.self_loops) selfs += "self\n" + s; else cyc += "iter " + std::to_string(iter[k]) + "\n" + s;
+        if (o.break_cycles) { std::string op = comp_line(k, open_at[k]); if (lin_seen.insert(op).second) lin += op; }
+    }
+    cyc += selfs;
+    const std::string nodup = cycle_without_duplicates(cyc);
+    if (!write_file(o.linear_out, lin) || !write_file(o.cycle_out, cyc) || !write_file(o.nodup_out, nodup) || !write_file(o.result_out, lin + nodup))
+        return fail("cannot write the matching outputs");
+    palace_stage04_destroy(ctx, st);
+    tr.lap("stage 04: result text");
+    return 0;
+}
+
+}  // namespace palace_host

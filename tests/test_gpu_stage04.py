@@ -142,3 +142,39 @@ def test_stage04_reports_what_the_reference_script_dies_on(tmp_path):
         with pytest.raises(capi.PalaceError, match="unknown contig id"):
             st.counts()
         st.close()
+
+
+@pytest.mark.parametrize("seed,n_contigs,n_events,flags", [(15, 80, 6000, ["-s"]), (16, 500, 40000, ["-s", "-b"]), (17, 500, 40000, ["--aggressive"])])
+def test_stage04_inside_generateGraph_writes_the_files_of_the_chain(tmp_path, seed, n_contigs, n_events, flags):
+    """generateGraph with the stage-04 options (one process, the graph never leaves HBM) writes byte for byte the files the
+    five-process chain of palace:555-600 writes: `_graph.txt`, `_filtered_graph_pre.txt`, `_filtered_graph.txt`,
+    all_hit_segs.txt, linear, cycle, cycle_nodup, all_result."""
+    rng = synth.rng_for(seed)
+    targets, fai_text, recs, avg = synth.random_graph_case(rng, n_contigs, n_events)
+    names, lens = [t[0] for t in targets], [t[1] for t in targets]
+    P = lambda n: str(tmp_path / n)
+    synth.write_bam(P("t.bam"), targets, recs, block=30000)
+    side = synth.filter_side_files(rng, names, lens)
+    for k, v in dict(fastg_fai=fai_text, **side).items():
+        open(P(k), "w").write(v)
+    common = ["--min-count", "2"]
+    # the chain
+    subprocess.run([os.path.join(BIN, "generateGraph"), *common, P("t.bam"), P("fastg_fai"), P("c_graph.txt"), f"{avg:.6g}"], check=True)
+    subprocess.run([sys.executable, os.path.join(SCRIPTS, "filter_graph.py"), P("fastg_fai"), P("c_graph.txt"), P("c_pre.txt"), f"{avg:.6g}", "0",
+                    P("hit_seqs"), P("node_scores"), P("blast"), "0.7", P("fasta_fai"), P("c_hits.txt"), P("contigs_paths"), "0.7"], check=True)
+    with open(P("c_filt.txt"), "wb") as f:
+        subprocess.run(["uniq", P("c_pre.txt")], check=True, stdout=f)
+    subprocess.run([os.path.join(BIN, "matching"), "-g", P("c_filt.txt"), "-r", P("c_lin.txt"), "-c", P("c_cyc.txt"), "-i", "10", "-l", P("contigs_paths")] + flags,
+                   check=True)
+    subprocess.run([sys.executable, os.path.join(SCRIPTS, "remove_cycle_dup.py"), P("c_cyc.txt"), P("c_nodup.txt")], check=True, stdout=subprocess.DEVNULL)
+    open(P("c_all.txt"), "wb").write(open(P("c_lin.txt"), "rb").read() + open(P("c_nodup.txt"), "rb").read())
+    # one process
+    p = subprocess.run([os.path.join(BIN, "generateGraph"), *common, "--hit-seqs", P("hit_seqs"), "--node-scores", P("node_scores"), "--blast", P("blast"),
+                        "--fasta-fai", P("fasta_fai"), "--paths", P("contigs_paths"), "--filtered-pre", P("f_pre.txt"), "--filtered", P("f_filt.txt"),
+                        "--all-hit-segs", P("f_hits.txt"), "--linear", P("f_lin.txt"), "--cycle", P("f_cyc.txt"), "--cycle-nodup", P("f_nodup.txt"),
+                        "--all-result", P("f_all.txt"), "-i", "10", *flags, P("t.bam"), P("fastg_fai"), P("f_graph.txt"), f"{avg:.6g}"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    for name in ("graph", "pre", "filt", "hits", "lin", "cyc", "nodup", "all"):
+        assert open(P(f"f_{name}.txt"), "rb").read() == open(P(f"c_{name}.txt"), "rb").read(), name
+    assert open(P("c_all.txt")).read().count("\t") > 5 and open(P("c_pre.txt")).read().count("JUNC") > 5
