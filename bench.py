@@ -437,6 +437,25 @@ def run_e2e(P, avg_depth, n_contigs, rows_host, n_junc_expected, result_text_exp
         for k in ("lin", "nodup"):
             f.write(open(P[k], "rb").read())
     st["cat"] = time.perf_counter() - t0
+    # the same files from ONE process: generateGraph with its stage-04 options (palace_amd/host/stage04_fused.hpp) -- the graph stays
+    # in HBM between the stages, every named artefact is still written; the separate executables above stay for the unchanged driver
+    fused = None
+    try:
+        fp = {k: P[k] + ".fused" for k in ("graph", "pre", "filt", "allhit", "lin", "cyc", "nodup", "result")}
+        t0 = time.perf_counter()
+        subprocess.run([os.path.join(B, "generateGraph"), "--hit-seqs", P["hit"], "--node-scores", P["score"], "--blast", P["blast"], "--fasta-fai", P["fasta_fai"],
+                        "--paths", P["paths"], "--filtered-pre", fp["pre"], "--filtered", fp["filt"], "--all-hit-segs", fp["allhit"], "--linear", fp["lin"],
+                        "--cycle", fp["cyc"], "--cycle-nodup", fp["nodup"], "--all-result", fp["result"], "-s", "-i", "10",
+                        P["bam"], P["fastg_fai"], fp["graph"], f"{avg_depth:.6g}"], check=True)
+        t_fused = time.perf_counter() - t0
+        same = all(open(fp[k], "rb").read() == open(P[k], "rb").read() for k in ("graph", "pre", "filt", "allhit", "lin", "cyc", "nodup", "result"))
+        fused = dict(seconds=st["eref"] + t_fused, contigs_per_s=n_contigs / (st["eref"] + t_fused),
+                     stage_s=dict(eref=round(st["eref"], 3), generateGraph_with_stage04=round(t_fused, 3)),
+                     files_identical_to_the_chain=bool(same),
+                     note="eref + ONE generateGraph process that also writes _filtered_graph_pre / _filtered_graph / all_hit_segs / linear / cycle / "
+                          "cycle_nodup / all_result (its --filtered-pre ... --all-result options)")
+    except Exception as e:
+        fused = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
     # cross-check against the HBM-resident step (same coder header, same sample): reported refs and kept junctions
     r = rows_host
     want = {(i + 1, int(r[i, 0]), int(r[i, 1])) for i in range(len(r))
@@ -447,7 +466,7 @@ def run_e2e(P, avg_depth, n_contigs, rows_host, n_junc_expected, result_text_exp
     same_result = None if result_text_expected is None else bool(open(P["result"]).read() == result_text_expected)
     return dict(seconds=total, contigs_per_s=n_contigs / total, stage_s={k: round(v, 3) for k, v in st.items()},
                 agrees_with_resident_step=bool(got == want and n_junc == n_junc_expected and same_result is not False),
-                all_result_identical_to_resident_step=same_result,
+                all_result_identical_to_resident_step=same_result, one_process_stage04=fused,
                 refs_reported=len(got), junc_lines=n_junc, result_lines=sum(1 for _ in open(P["result"])),
                 input_bytes=P["bytes"], input_generation_s=round(P["gen_s"], 1),
                 note="wall clock of eref + generateGraph + filter_graph.py + uniq + matching + remove_cycle_dup.py + cat, one process "

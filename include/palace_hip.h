@@ -366,6 +366,11 @@ typedef struct palace_stage04 palace_stage04;
 int palace_stage04_create(palace_ctx *ctx, const palace_stage04_inputs *in, palace_stage04 **out);
 int palace_stage04_destroy(palace_ctx *ctx, palace_stage04 *s);
 
+/* Optional: allocate now what a filter call with this edge bound will need (hundreds of MB for a million contigs; the
+ * allocation alone takes tens of milliseconds), e.g. while the caller is still decoding its BAM.  The object's memory belongs
+ * to the device: it may be created and reserved through one context and used through another. */
+int palace_stage04_reserve(palace_ctx *ctx, palace_stage04 *s, int64_t edge_bound);
+
 /* B2 in memory (filter_graph.py:201-264): which junctions and which SEG lines `_filtered_graph.txt` holds.  d_edges and
  * d_n_edges (device, 8 bytes) are what palace_graph_resolve_ex leaves; edge_bound is a bound on the count the host knows
  * (the number of candidates): it sizes the tables.  Only enqueues.  Per edge a flag byte: 1 = the JUNC line exists,

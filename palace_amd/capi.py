@@ -128,6 +128,7 @@ _SIGS = {
                                 C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)],
     "palace_stage04_create": [C.c_void_p, C.POINTER(Stage04Inputs), C.POINTER(C.c_void_p)],
     "palace_stage04_destroy": [C.c_void_p, C.c_void_p],
+    "palace_stage04_reserve": [C.c_void_p, C.c_void_p, C.c_int64],
     "palace_stage04_filter": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64],
     "palace_stage04_flags": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64],
     "palace_stage04_counts": [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],

@@ -589,6 +589,13 @@ int palace_stage04_destroy(palace_ctx *ctx, palace_stage04 *s)
     return PALACE_OK;
 }
 
+int palace_stage04_reserve(palace_ctx *ctx, palace_stage04 *s, int64_t edge_bound)
+{
+    PALACE_REQUIRE(ctx && s && edge_bound >= 0, "bad argument");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    return grow_device(ctx, s, std::max<int64_t>(edge_bound, s->edge_bound), std::max(s->rounds, 11));
+}
+
 int palace_stage04_filter(palace_ctx *ctx, palace_stage04 *s, const palace_graph_edge *d_edges, const int64_t *d_n_edges,
                           int64_t edge_bound)
 {

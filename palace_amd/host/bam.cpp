@@ -326,6 +326,8 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c)
     return L.release();
 }
 
+size_t load_bam_size_hint(const BamLoad *load) { return load->c->raw.size(); }
+
 void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumns &c)
 {
     load_bam_finish(load_bam_begin(path, threads, c), key_seed);

@@ -65,6 +65,7 @@ void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumn
 struct BamLoad;
 BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &out);
 void load_bam_finish(BamLoad *load, uint64_t key_seed);
+size_t load_bam_size_hint(const BamLoad *load);          // bytes of the inflated stream (known from the BGZF member trailers)
 
 // Re-key every read name with another seed (collision escape hatch).
 void rekey(BamColumns &cols, uint64_t key_seed);

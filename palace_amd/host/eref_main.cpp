@@ -164,11 +164,22 @@ int main(int argc, char **argv)
     SeqSet db_all, db;
     try {
         MappedText fa_txt(fasta);
-        parse_fasta(fa_txt.data, fa_txt.size, db_all);
+        parse_fasta_mt(fa_txt.data, fa_txt.size, db_all, static_cast<int>(std::max(1u, std::min(16u, std::thread::hardware_concurrency()))));
     } catch (const std::exception &e) { std::cerr << "eref: " << e.what() << "\n"; return 1; }
     std::vector<int64_t> cum(db_all.n() + 1, 0);
+    bool all_long = db_all.n() > 0 && db_all.len(0) == 0;          // the usual DB: nothing ahead of the first header, every record > 32 bases
     for (int64_t i = 0; i < db_all.n(); i++) {
         cum[i + 1] = cum[i] + db_all.len(i);
+        if (i > 0 && db_all.len(i) <= 32) all_long = false;
+    }
+    if (all_long) {                                                 // then the record set IS the reference set: no second copy of the bases
+        db.bases = std::move(db_all.bases);                         // (record i of db_all starts at the same offset in it: record 0 is empty)
+        db.offsets.assign(db_all.offsets.begin() + 1, db_all.offsets.end());
+        db.names.assign(db_all.names.begin() + 1, db_all.names.end());
+        db.ordinal.resize(static_cast<size_t>(db_all.n() - 1));
+        for (int64_t i = 1; i < db_all.n(); i++) db.ordinal[static_cast<size_t>(i - 1)] = i;
+    }
+    for (int64_t i = 0; i < db_all.n() && !all_long; i++) {
         if (db_all.len(i) > 32) {
             db.bases.insert(db.bases.end(), db_all.bases.begin() + db_all.offsets[i], db_all.bases.begin() + db_all.offsets[i + 1]);
             db.offsets.push_back(static_cast<int64_t>(db.bases.size()));
@@ -339,7 +350,8 @@ int main(int argc, char **argv)
             std::string pct = line;
             if (pct.find_first_of(".en") == std::string::npos) pct += ".0";      // float("1") prints as 1.0
             fa << '>' << db_all.ids[static_cast<size_t>(i)] << '\n';
-            std::string seq(reinterpret_cast<const char *>(db_all.bases.data() + db_all.offsets[i]), static_cast<size_t>(db_all.len(i)));
+            const uint8_t *all_bases = all_long ? db.bases.data() : db_all.bases.data();
+            std::string seq(reinterpret_cast<const char *>(all_bases + db_all.offsets[i]), static_cast<size_t>(db_all.len(i)));
             seq.erase(std::remove_if(seq.begin(), seq.end(), [](char ch) { return std::isspace(static_cast<unsigned char>(ch)); }), seq.end());
             fa << seq << '\n';                                                  // (Bio.SeqIO drops white space inside sequence lines)
             pc << db_all.ids[static_cast<size_t>(i)] << '\t' << pct << '\n';

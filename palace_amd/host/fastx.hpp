@@ -134,6 +134,61 @@ inline void parse_fasta(const char *txt, size_t N, SeqSet &out)
 }
 inline void parse_fasta(const std::vector<char> &txt, SeqSet &out) { parse_fasta(txt.data(), txt.size(), out); }
 
+// The same on threads: the text is cut at header lines, every part parsed on its own, the pieces joined (the copy of the bases
+// into their final place runs on the threads as well).  A 200-Mbase DB: 190 ms -> ~40 ms on 16 threads.
+inline void parse_fasta_mt(const char *txt, size_t N, SeqSet &out, int threads)
+{
+    if (threads <= 1 || N < (4u << 20)) { parse_fasta(txt, N, out); return; }
+    std::vector<size_t> cut{0};
+    for (int k = 1; k < threads; k++) {
+        size_t p = std::max(cut.back(), N / static_cast<size_t>(threads) * static_cast<size_t>(k));
+        size_t at = N;
+        while (p < N) {                                     // next line that starts with '>'
+            const void *nl = std::memchr(txt + p, '\n', N - p);
+            if (!nl) break;
+            p = static_cast<size_t>(static_cast<const char *>(nl) - txt) + 1;
+            if (p < N && txt[p] == '>') { at = p; break; }
+        }
+        if (at >= N) break;
+        if (at > cut.back()) cut.push_back(at);
+    }
+    cut.push_back(N);
+    const size_t n_parts = cut.size() - 1;
+    std::vector<SeqSet> piece(n_parts);
+    {
+        std::vector<std::thread> pool;
+        for (size_t k = 0; k < n_parts; k++) pool.emplace_back([&, k] { parse_fasta(txt + cut[k], cut[k + 1] - cut[k], piece[k]); });
+        for (auto &t : pool) t.join();
+    }
+    // every piece begins with the implicit record "start" (text ahead of its first header): real in piece 0, empty in the others
+    size_t n_rec = 0, n_bases = 0;
+    std::vector<size_t> rec0(n_parts), base0(n_parts);
+    for (size_t k = 0; k < n_parts; k++) {
+        rec0[k] = n_rec; base0[k] = n_bases;
+        n_rec += static_cast<size_t>(piece[k].n()) - (k ? 1 : 0);
+        n_bases += piece[k].bases.size();
+    }
+    out.bases.resize(n_bases);
+    out.offsets.assign(n_rec + 1, 0);
+    out.names.resize(n_rec); out.ids.resize(n_rec); out.ordinal.resize(n_rec);
+    {
+        std::vector<std::thread> pool;
+        for (size_t k = 0; k < n_parts; k++)
+            pool.emplace_back([&, k] {
+                const SeqSet &pc = piece[k];
+                if (!pc.bases.empty()) std::memcpy(out.bases.data() + base0[k], pc.bases.data(), pc.bases.size());
+                const size_t skip = k ? 1 : 0;
+                for (size_t i = skip; i < static_cast<size_t>(pc.n()); i++) {
+                    const size_t r = rec0[k] + i - skip;
+                    out.offsets[r + 1] = static_cast<int64_t>(base0[k]) + pc.offsets[i + 1];
+                    out.names[r] = pc.names[i]; out.ids[r] = pc.ids[i];
+                    out.ordinal[r] = static_cast<int64_t>(r);           // record 0 is "start" (ordinal 0), header n has ordinal n
+                }
+            });
+        for (auto &t : pool) t.join();
+    }
+}
+
 }  // namespace palace_host
 
 // ------------------------------------------------------------------------------------------------

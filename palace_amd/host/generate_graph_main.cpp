@@ -264,7 +264,6 @@ int main(int argc, char **argv)
     std::string ctx_err;
     Stage04Side s4side;
     std::thread side04;
-    if (s4o.enabled()) side04 = std::thread([&] { stage04_read_side_files(s4o, c, s4side); });     // beside the inflate, like the rest
     auto join04 = [&] { if (side04.joinable()) side04.join(); };
     std::thread side([&] { name_ranks(c.target_name, by_name, rank); });
     std::thread side2([&] { fkeys = fastg_keys(fai_path, c, 4); });
@@ -272,16 +271,29 @@ int main(int argc, char **argv)
         ctx_rc = palace_ctx_create(0, &ctx);
         if (ctx_rc) ctx_err = palace_last_error();
     });
+    palace_stage04 *s4obj = nullptr;
+    std::string s4err;
+    if (s4o.enabled())                                            // beside the inflate, like the rest: the side files, then (once the
+        side04 = std::thread([&] {                               // name ranks are there) the resident object and its scratch on the device
+            stage04_read_side_files(s4o, c, s4side);
+            side.join();
+            bool unique_names = true;
+            for (int32_t k = 1; k < nt && unique_names; k++) unique_names = rank[by_name[k]] != rank[by_name[k - 1]];
+            if (!unique_names) { s4err = "stage 04 in this process needs distinct target names; run the stages separately"; return; }
+            s4obj = stage04_prepare(s4o, c, s4side, rank, min_count, std::max<int64_t>(1 << 20, static_cast<int64_t>(load_bam_size_hint(load)) / 2400), s4err);
+        });
     try {
         load_bam_finish(load, seed);
     } catch (const std::exception &e) {
         std::cerr << e.what() << "\n";
-        side.join(); side2.join(); hip_up.join(); join04();
+        join04(); if (side.joinable()) side.join(); side2.join(); hip_up.join();
         return 1;
     }
     tr.lap("bam records");
-    side.join();
+    join04();                                                     // (it joined `side`)
+    if (side.joinable()) side.join();
     side2.join();
+    if (s4o.enabled() && !s4obj) { std::cerr << "generateGraph: stage 04: " << s4err << "\n"; hip_up.join(); return 1; }
     tr.lap("name ranks + fastg keys (joined)");
     hip_up.join();
     if (ctx_rc) { std::cerr << "generateGraph: cannot set up the GPU: " << ctx_err << "\n"; join04(); return 1; }
@@ -338,6 +350,10 @@ int main(int argc, char **argv)
         CK(palace_h2d(ctx, d_qkey, c.qkey.data(), c.qkey.size() * 8));
     }
     tr.lap("classify + name guard");
+    // The inflated stream (gigabytes) has served: read names were its last users.  Giving the pages back takes the kernel a few
+    // hundred milliseconds -- at process exit that is wall time the driver waits for, here it runs beside the rest of the work.
+    std::thread([buf = std::move(c.raw.p)]() mutable { buf.reset(); }).detach();
+    c.raw.n = 0;
     CK(palace_malloc(ctx, static_cast<size_t>(std::max<int64_t>(1, n_cands)) * sizeof(palace_graph_edge), &p));
     palace_graph_edge *d_edges = static_cast<palace_graph_edge *>(p);
     int64_t n_edges = 0;
@@ -419,15 +435,11 @@ int main(int argc, char **argv)
     }
     tr.lap("text output");
     if (s4o.enabled()) {
-        join04();
-        bool unique_names = true;
-        for (int32_t k = 1; k < nt && unique_names; k++) unique_names = rank[by_name[k]] != rank[by_name[k - 1]];
-        if (!unique_names) { std::cerr << "generateGraph: stage 04 in this process needs distinct target names; run the stages separately\n"; return 1; }
         std::vector<std::string_view> raw_seg(static_cast<size_t>(nt));
         for (size_t part = 0; part < seg_text.size(); part++)
             for (const SegAt &sg : seg_at[part]) raw_seg[static_cast<size_t>(sg.tid)] = std::string_view(seg_text[part]).substr(sg.at, sg.len);
         std::string err;
-        if (stage04_run(ctx, s4o, c, s4side, rank, raw_seg, edges, sorted_index, min_count, d_edges, n_cands, d_cn, tr, err)) {
+        if (stage04_run(ctx, s4obj, s4o, c, s4side, rank, raw_seg, edges, sorted_index, d_edges, n_cands, d_cn, threads, tr, err)) {
             std::cerr << "generateGraph: stage 04: " << err << "\n";
             return 1;
         }

@@ -2,7 +2,7 @@
 // Test tool for the CPU test suite:
 //   hostdump bam   <file.bam>          header + one line per record (decoded columns + parsed SA items)
 //   hostdump fastq <file.fq> <threads> [part_bytes]  one line per sequence line
-//   hostdump fasta <file.fa>           one line per record (ordinal, name, length, sequence)
+//   hostdump fasta <file.fa> [threads] one line per record (ordinal, name, length, sequence); with threads: parse_fasta_mt
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -47,7 +47,9 @@ int main(int argc, char **argv)
             }
         } else if (mode == "fasta") {
             SeqSet db;
-            parse_fasta(read_file(argv[2]), db);
+            const std::vector<char> txt = read_file(argv[2]);
+            if (argc > 3) parse_fasta_mt(txt.data(), txt.size(), db, std::atoi(argv[3]));     // the eref executable's threaded parser
+            else parse_fasta(txt, db);
             for (int64_t i = 0; i < db.n(); i++) {
                 std::printf("%lld\t%s\t%lld\t", (long long)db.ordinal[i], db.names[i].c_str(), (long long)db.len(i));
                 std::fwrite(db.bases.data() + db.offsets[i], 1, static_cast<size_t>(db.len(i)), stdout);

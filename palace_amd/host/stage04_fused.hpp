@@ -101,6 +101,7 @@ struct Stage04Side {
 
 inline void stage04_read_side_files(const Stage04Options &o, const BamColumns &c, Stage04Side &out)
 {
+    Trace tr("generateGraph/side");
     const size_t nt = c.target_name.size();
     out.seed.assign(nt, 0);
     out.score_text.assign(nt, std::string());
@@ -110,17 +111,20 @@ inline void stage04_read_side_files(const Stage04Options &o, const BamColumns &c
     std::vector<int32_t> token_tid;
     std::string err_fai, err_blast, err_gene, err_score, err_paths;
     // name lengths: every target, not only those the fasta index lists
-    for (size_t t = 0; t < nt; t++) {
-        const std::string &nm = c.target_name[t];
-        size_t a = 0;
-        int k = 0;
-        for (; k < 3; k++) { a = nm.find('_', a); if (a == std::string::npos) break; a++; }
-        if (k == 3) {
-            const size_t b = nm.find('_', a);
-            long long v;
-            if (s4::to_int(sv(nm).substr(a, b == std::string::npos ? std::string::npos : b - a), v) && v < (1ll << 31)) out.name_len[t] = static_cast<int32_t>(v);
+    constexpr int kSideThreads = 6;                // (the inflate threads have the cores; this work only has to end before they do)
+    pool_for(64, kSideThreads, [&](size_t part) {
+        for (size_t t = nt * part / 64; t < nt * (part + 1) / 64; t++) {
+            const std::string &nm = c.target_name[t];
+            size_t a = 0;
+            int k = 0;
+            for (; k < 3; k++) { a = nm.find('_', a); if (a == std::string::npos) break; a++; }
+            if (k == 3) {
+                const size_t b = nm.find('_', a);
+                long long v;
+                if (s4::to_int(sv(nm).substr(a, b == std::string::npos ? std::string::npos : b - a), v) && v < (1ll << 31)) out.name_len[t] = static_cast<int32_t>(v);
+            }
         }
-    }
+    });
     std::unique_ptr<MappedText> fai, blast, genes, scores, paths;
     auto open = [](const std::string &p, std::unique_ptr<MappedText> &m, std::string &err) {
         try { m.reset(new MappedText(p)); } catch (const std::exception &e) { err = e.what(); }
@@ -130,24 +134,39 @@ inline void stage04_read_side_files(const Stage04Options &o, const BamColumns &c
     for (const std::string *e : {&err_fai, &err_blast, &err_gene, &err_score, &err_paths})
         if (!e->empty()) { out.error = *e; return; }
 
-    // fasta index first: lengths (the BLAST rule divides by them) and the id tokens (contigs.paths speaks in them)
+    // fasta index first: lengths (the BLAST rule divides by them) and the id tokens (contigs.paths speaks in them).  Parsed in
+    // parts on threads (splitting, numbers, the name look-up); applied in file order by this thread
     {
-        std::vector<sv> cols, parts;
-        tokens.reserve(nt + 16);
-        for_each_line(fai->data, fai->size, [&](sv line) {
-            if (!err_fai.empty()) return;
-            split_on(strip(line), '\t', cols);
-            long long len;
-            if (cols.size() < 2 || !s4::to_int(cols[1], len)) { err_fai = "short or non-numeric line in the fasta index"; return; }
-            split_on(cols[0], '_', parts);
-            if (parts.size() < 2) { err_fai = "fasta index name without an id token: " + std::string(cols[0]); return; }
-            const int32_t tid = c.tid_of(cols[0]);
-            if (tid >= 0) fai_len[static_cast<size_t>(tid)] = len;
-            const int t = tokens.intern(parts[1]);
-            if (static_cast<size_t>(t) >= token_tid.size()) token_tid.resize(static_cast<size_t>(t) + 1, -1);
-            token_tid[static_cast<size_t>(t)] = tid;                   // a later line with the same token wins, as in a dict (-1: no target)
+        struct Row { sv token; uint64_t h_token; long long len; int32_t tid; };
+        const std::vector<size_t> cut = line_cuts(fai->data, fai->size, 24);
+        std::vector<std::vector<Row>> rows(cut.size() - 1);
+        std::vector<std::string> errs(cut.size() - 1);
+        pool_for(cut.size() - 1, kSideThreads, [&](size_t k) {
+            std::vector<sv> cols, parts;
+            rows[k].reserve((cut[k + 1] - cut[k]) / 40 + 16);
+            for_each_line(fai->data + cut[k], cut[k + 1] - cut[k], [&](sv line) {
+                if (!errs[k].empty()) return;
+                split_on(strip(line), '\t', cols);
+                long long len;
+                if (cols.size() < 2 || !s4::to_int(cols[1], len)) { errs[k] = "short or non-numeric line in the fasta index"; return; }
+                split_on(cols[0], '_', parts);
+                if (parts.size() < 2) { errs[k] = "fasta index name without an id token: " + std::string(cols[0]); return; }
+                rows[k].push_back(Row{parts[1], hash_bytes(parts[1]), len, c.tid_of(cols[0])});
+            });
         });
+        size_t n_rows = 0;
+        for (size_t k = 0; k < rows.size(); k++) { n_rows += rows[k].size(); if (!errs[k].empty() && err_fai.empty()) err_fai = errs[k]; }
+        tokens.reserve(n_rows + 16);
+        token_tid.reserve(n_rows + 16);
+        for (const auto &part : rows)
+            for (const Row &r : part) {
+                if (r.tid >= 0) fai_len[static_cast<size_t>(r.tid)] = r.len;
+                const int t = tokens.intern_hashed(r.token, r.h_token);
+                if (static_cast<size_t>(t) >= token_tid.size()) token_tid.resize(static_cast<size_t>(t) + 1, -1);
+                token_tid[static_cast<size_t>(t)] = r.tid;             // a later line with the same token wins, as in a dict (-1: no target)
+            }
     }
+    tr.lap("name lengths + fasta index");
     std::thread t_blast([&] {                      // consecutive rows of one (query, subject) pair form a group (l.66-94)
         std::vector<sv> cols;
         sv cur_q, cur_s;
@@ -189,6 +208,7 @@ inline void stage04_read_side_files(const Stage04Options &o, const BamColumns &c
     t_blast.join();
     t_gene.join();
     for (size_t t = 0; t < nt; t++) if (gene_hit[t]) out.seed[t] |= 2;
+    tr.lap("blast + gene hits");
     std::thread t_score([&] {                      // l.104-112
         const std::vector<size_t> cut = line_cuts(scores->data, scores->size, 8);
         std::vector<std::string> errs(cut.size() - 1);
@@ -211,33 +231,47 @@ inline void stage04_read_side_files(const Stage04Options &o, const BamColumns &c
         });
         for (const auto &e : errs) if (!e.empty() && err_score.empty()) err_score = e;
     });
-    std::thread t_paths([&] {                      // contigs.paths: every line that is no NODE header (l.126-137)
-        out.path_off.reserve(paths->size / 12 + 16);
-        out.path_tok.reserve(paths->size / 6 + 16);
-        std::string clean;
-        for_each_line(paths->data, paths->size, [&](sv raw) {
-            const sv s = strip(raw);
-            clean.clear();
-            for (char ch : s) if (ch != ';') clean += ch;
-            if (sv(clean).substr(0, 4) == "NODE") return;
-            size_t p = 0;
-            while (p <= clean.size()) {
-                const size_t comma = clean.find(',', p);
-                const sv tok = sv(clean).substr(p, comma == std::string::npos ? sv::npos : comma - p);
-                p = comma == std::string::npos ? clean.size() + 1 : comma + 1;
-                int32_t code = -1;
-                if (!tok.empty()) {
-                    const int t = tokens.find(tok.substr(0, tok.size() - 1));
-                    const int32_t tid = t < 0 ? -1 : token_tid[static_cast<size_t>(t)];
-                    if (tid >= 0) code = 2 * tid + (tok.back() == '-');
+    std::thread t_paths([&] {                      // contigs.paths: every line that is no NODE header (l.126-137); in parts
+        const std::vector<size_t> cut = line_cuts(paths->data, paths->size, 16);
+        std::vector<std::vector<int32_t>> tok(cut.size() - 1), ends(cut.size() - 1);
+        pool_for(cut.size() - 1, kSideThreads - 2, [&](size_t k) {
+            std::string clean;
+            tok[k].reserve((cut[k + 1] - cut[k]) / 6 + 16);
+            for_each_line(paths->data + cut[k], cut[k + 1] - cut[k], [&](sv raw) {
+                const sv s = strip(raw);
+                clean.clear();
+                for (char ch : s) if (ch != ';') clean += ch;
+                if (sv(clean).substr(0, 4) == "NODE") return;
+                size_t p = 0;
+                while (p <= clean.size()) {
+                    const size_t comma = clean.find(',', p);
+                    const sv t = sv(clean).substr(p, comma == std::string::npos ? sv::npos : comma - p);
+                    p = comma == std::string::npos ? clean.size() + 1 : comma + 1;
+                    int32_t code = -1;
+                    if (!t.empty()) {
+                        const int id = tokens.find(t.substr(0, t.size() - 1));
+                        const int32_t tid = id < 0 ? -1 : token_tid[static_cast<size_t>(id)];
+                        if (tid >= 0) code = 2 * tid + (t.back() == '-');
+                    }
+                    tok[k].push_back(code);
                 }
-                out.path_tok.push_back(code);
-            }
-            out.path_off.push_back(static_cast<int64_t>(out.path_tok.size()));
+                ends[k].push_back(static_cast<int32_t>(tok[k].size()));
+            });
         });
+        size_t n_tok = 0, n_lines = 0;
+        for (size_t k = 0; k < tok.size(); k++) { n_tok += tok[k].size(); n_lines += ends[k].size(); }
+        out.path_tok.reserve(n_tok + 1);
+        out.path_off.reserve(n_lines + 1);
+        for (size_t k = 0; k < tok.size(); k++) {
+            const int64_t base = static_cast<int64_t>(out.path_tok.size());
+            out.path_tok.insert(out.path_tok.end(), tok[k].begin(), tok[k].end());
+            for (int32_t e : ends[k]) out.path_off.push_back(base + e);
+        }
     });
     t_score.join();
+    tr.lap("scores (joined)");
     t_paths.join();
+    tr.lap("paths (joined)");
     for (const std::string *e : {&err_fai, &err_blast, &err_gene, &err_score, &err_paths})
         if (!e->empty() && out.error.empty()) out.error = *e;
 }
@@ -284,19 +318,19 @@ inline std::string uniq_lines(const std::string &text)
     return out;
 }
 
-// After generateGraph's resolve: selection, decomposition, every file.  raw_seg[t] = the SEG line of target t as `_graph.txt`
-// has it (empty: none); edges = the aggregated edges in DEVICE order (d_edges), sorted_index = their `_graph.txt` order.
-// Returns 0, or 1 with `err` set.
-inline int stage04_run(palace_ctx *ctx, const Stage04Options &o, const BamColumns &c, const Stage04Side &side,
-                       const std::vector<int32_t> &rank, const std::vector<sv> &raw_seg, const std::vector<palace_graph_edge> &edges,
-                       const std::vector<uint32_t> &sorted_index, int min_count, const palace_graph_edge *d_edges, int64_t n_cands,
-                       const int32_t *d_cn, Trace &tr, std::string &err)
+// The resident object (side arrays on the device, the path-arc table, the big scratch blocks) can be set up while the BAM is
+// still being inflated: on a context of its own, from the thread that read the side files.  edge_guess sizes the scratch (it
+// grows later if the real bound is larger).
+inline palace_stage04 *stage04_prepare(const Stage04Options &o, const BamColumns &c, const Stage04Side &side, const std::vector<int32_t> &rank,
+                                       int min_count, int64_t edge_guess, std::string &err)
 {
-    const int32_t nt = static_cast<int32_t>(c.target_name.size());
-    auto fail = [&](const std::string &what) { err = what; return 1; };
-    if (!side.error.empty()) return fail(side.error);
+    if (!side.error.empty()) { err = side.error; return nullptr; }
+    Trace tr("generateGraph/prepare");
+    palace_ctx *ctx = nullptr;
+    if (palace_ctx_create(0, &ctx)) { err = palace_last_error(); return nullptr; }
+    tr.lap("context");
     palace_stage04_inputs in{};
-    in.n_segs = nt; in.min_count = min_count;
+    in.n_segs = static_cast<int32_t>(c.target_name.size()); in.min_count = min_count;
     in.seed = side.seed.data(); in.tlen = c.target_len.data(); in.rank = rank.data();
     std::vector<int32_t> name_len(side.name_len);
     for (int32_t &v : name_len) if (v < 0) v = 0;                         // (only read for members of contigs.paths lines, whose names have the token)
@@ -304,7 +338,25 @@ inline int stage04_run(palace_ctx *ctx, const Stage04Options &o, const BamColumn
     in.n_paths = static_cast<int64_t>(side.path_off.size()) - 1;
     in.path_off = side.path_off.data(); in.path_tok = side.path_tok.data();
     palace_stage04 *st = nullptr;
-    if (palace_stage04_create(ctx, &in, &st)) return fail(palace_last_error());
+    if (palace_stage04_create(ctx, &in, &st)) { err = palace_last_error(); st = nullptr; }
+    tr.lap("create");
+    if (st && (palace_stage04_reserve(ctx, st, edge_guess) || palace_sync(ctx))) { err = palace_last_error(); st = nullptr; }
+    tr.lap("reserve");
+    palace_ctx_destroy(ctx);                                              // (the object's memory belongs to the device, not to the context)
+    (void)o;
+    return st;
+}
+
+// After generateGraph's resolve: selection, decomposition, every file.  raw_seg[t] = the SEG line of target t as `_graph.txt`
+// has it (empty: none); edges = the aggregated edges in DEVICE order (d_edges), sorted_index = their `_graph.txt` order.
+// Returns 0, or 1 with `err` set.
+inline int stage04_run(palace_ctx *ctx, palace_stage04 *st, const Stage04Options &o, const BamColumns &c, const Stage04Side &side,
+                       const std::vector<int32_t> &rank, const std::vector<sv> &raw_seg, const std::vector<palace_graph_edge> &edges,
+                       const std::vector<uint32_t> &sorted_index, const palace_graph_edge *d_edges, int64_t n_cands,
+                       const int32_t *d_cn, int threads, Trace &tr, std::string &err)
+{
+    const int32_t nt = static_cast<int32_t>(c.target_name.size());
+    auto fail = [&](const std::string &what) { err = what; return 1; };
     void *p = nullptr;
     if (palace_malloc(ctx, 8, &p)) return fail(palace_last_error());
     const int64_t n_edges = static_cast<int64_t>(edges.size());
@@ -321,33 +373,45 @@ inline int stage04_run(palace_ctx *ctx, const Stage04Options &o, const BamColumn
     std::vector<int32_t> by_rank(static_cast<size_t>(nt));
     for (int32_t t = 0; t < nt; t++) by_rank[static_cast<size_t>(rank[static_cast<size_t>(t)])] = t;
     std::string pre, hits;
-    pre.reserve(static_cast<size_t>(counts[4] + counts[5]) * 72 + static_cast<size_t>(counts[2] + counts[3]) * 110);
-    std::vector<sv> toks;
-    for (int32_t r = 0; r < nt; r++) {
-        const int32_t t = by_rank[static_cast<size_t>(r)];
-        const uint8_t sd = side.seed[static_cast<size_t>(t)];
-        if (sd && !raw_seg[static_cast<size_t>(t)].empty()) {           // all_hit_segs.txt in SEG order (l.163-171, 266-269)
-            hits += "SAMPLE\t"; hits += c.target_name[static_cast<size_t>(t)]; hits += '\t';
-            if (sd & 1) hits += "ref+";
-            if (sd & 4) hits += "score+";
-            if (sd & 2) hits += "gene+";
-            hits += '\n';
-        }
-        if (!(seg_flags[static_cast<size_t>(t)] & 1)) continue;
-        split_ws(raw_seg[static_cast<size_t>(t)], toks);                  // l.173-197
-        for (size_t i = 0; i < toks.size(); i++) {
-            if (i) pre += ' ';
-            if (i < 2) pre.append(toks[i]); else pre += s4::plain_number(toks[i]);
-        }
-        pre += (sd & 2) ? " 1 " : " 0 ";
-        pre += side.score_text[static_cast<size_t>(t)].empty() ? std::string("0.000") : side.score_text[static_cast<size_t>(t)];
-        pre += (sd & 1) ? " 1\n" : " 0\n";
-    }
-    for (int32_t r = 0; r < nt; r++) {
-        const int32_t t = by_rank[static_cast<size_t>(r)];
-        if ((seg_flags[static_cast<size_t>(t)] & 3) != 2) continue;
-        pre.append(strip(raw_seg[static_cast<size_t>(t)]));
-        pre += " 0 1.0 0\n";
+    {
+        const size_t n_parts = static_cast<size_t>(std::max(1, threads)) * 2;
+        std::vector<std::string> sel_part(n_parts), resc_part(n_parts), hit_part(n_parts);
+        pool_for(n_parts, threads, [&](size_t part) {
+            std::string &sel = sel_part[part], &resc = resc_part[part], &hit = hit_part[part];
+            std::vector<sv> toks;
+            const int32_t r0 = static_cast<int32_t>(static_cast<int64_t>(nt) * part / n_parts), r1 = static_cast<int32_t>(static_cast<int64_t>(nt) * (part + 1) / n_parts);
+            for (int32_t r = r0; r < r1; r++) {
+                const int32_t t = by_rank[static_cast<size_t>(r)];
+                const uint8_t sd = side.seed[static_cast<size_t>(t)];
+                if (sd && !raw_seg[static_cast<size_t>(t)].empty()) {   // all_hit_segs.txt in SEG order (l.163-171, 266-269)
+                    hit += "SAMPLE\t"; hit += c.target_name[static_cast<size_t>(t)]; hit += '\t';
+                    if (sd & 1) hit += "ref+";
+                    if (sd & 4) hit += "score+";
+                    if (sd & 2) hit += "gene+";
+                    hit += '\n';
+                }
+                const uint8_t fl = seg_flags[static_cast<size_t>(t)];
+                if (fl & 1) {
+                    split_ws(raw_seg[static_cast<size_t>(t)], toks);    // l.173-197
+                    for (size_t i = 0; i < toks.size(); i++) {
+                        if (i) sel += ' ';
+                        if (i < 2) sel.append(toks[i]); else sel += s4::plain_number(toks[i]);
+                    }
+                    sel += (sd & 2) ? " 1 " : " 0 ";
+                    sel += side.score_text[static_cast<size_t>(t)].empty() ? std::string("0.000") : side.score_text[static_cast<size_t>(t)];
+                    sel += (sd & 1) ? " 1\n" : " 0\n";
+                } else if ((fl & 3) == 2) {
+                    resc.append(strip(raw_seg[static_cast<size_t>(t)]));
+                    resc += " 0 1.0 0\n";
+                }
+            }
+        });
+        size_t total = static_cast<size_t>(counts[2] + counts[3]) * 110;
+        for (size_t k = 0; k < n_parts; k++) total += sel_part[k].size() + resc_part[k].size();
+        pre.reserve(total);
+        for (const std::string &x : sel_part) pre += x;                   // selected SEG lines in graph order, then the rescued ones
+        for (const std::string &x : resc_part) pre += x;
+        for (const std::string &x : hit_part) hits += x;
     }
     char line[1024];
     auto junc_line = [&](const palace_graph_edge &e) {
@@ -385,8 +449,7 @@ inline int stage04_run(palace_ctx *ctx, const Stage04Options &o, const BamColumn
     std::string lin, cyc, selfs;
     std::unordered_set<std::string> lin_seen, cyc_seen;
     auto name_of = [&](int32_t v) -> const std::string & { return c.target_name[static_cast<size_t>(contig_of[v >> 1])]; };
-    auto comp_line = [&](int64_t k, int64_t first) {
-        std::string s;
+    auto comp_line = [&](int64_t k, int64_t first, std::string &s) {
         const int64_t n = off[k + 1] - off[k];
         for (int64_t i = 0; i < n; i++) {
             const int32_t v = verts[off[k] + (first + i) % n];
@@ -395,45 +458,52 @@ inline int stage04_run(palace_ctx *ctx, const Stage04Options &o, const BamColumn
             s += (v & 1) ? '-' : '+';
         }
         s += '\n';
-        return s;
+    };
+    // the lines of all components, formatted on threads (ranges of components; one buffer and the line ends per range)
+    const size_t n_parts = static_cast<size_t>(std::max(1, threads)) * 2;
+    std::vector<std::string> text(n_parts);
+    std::vector<std::vector<uint32_t>> ends(n_parts);                     // end offset of every component's line in its range's buffer
+    pool_for(n_parts, threads, [&](size_t part) {
+        const int64_t k0 = n_comp * static_cast<int64_t>(part) / static_cast<int64_t>(n_parts), k1 = n_comp * static_cast<int64_t>(part + 1) / static_cast<int64_t>(n_parts);
+        ends[part].reserve(static_cast<size_t>(k1 - k0));
+        for (int64_t k = k0; k < k1; k++) { comp_line(k, 0, text[part]); ends[part].push_back(static_cast<uint32_t>(text[part].size())); }
+    });
+    size_t part_of = 0;
+    int64_t part_first = 0;
+    auto line_of = [&](int64_t k) -> sv {                                  // (k ascends)
+        while (k >= n_comp * static_cast<int64_t>(part_of + 1) / static_cast<int64_t>(n_parts)) { part_of++; part_first = n_comp * static_cast<int64_t>(part_of) / static_cast<int64_t>(n_parts); }
+        const size_t i = static_cast<size_t>(k - part_first);
+        const uint32_t a0 = i ? ends[part_of][i - 1] : 0;
+        return sv(text[part_of]).substr(a0, ends[part_of][i] - a0);
     };
     // round 0 lists the bare segments (one-vertex paths) between the components, in first-vertex order; names are distinct,
-    // so a bare line can only repeat a line already written if a component consists of that one vertex -- which it cannot
-    // (a component vertex has an arc, a bare segment has none): bare lines need no look-up
-    int64_t k = 0;
+    // so a bare line cannot repeat another line (a component vertex has an arc, a bare segment has none)
     int64_t next_bare = 0;                                              // next filtered segment id to test for bareness
     auto bare_until = [&](int64_t seg_end) {                             // bare segments with id < seg_end
         for (; next_bare < seg_end; next_bare++)
             if ((bare[next_bare >> 6] >> (next_bare & 63)) & 1) { lin += c.target_name[static_cast<size_t>(contig_of[next_bare])]; lin += "+\n"; }
     };
-    for (; k < n_comp && iter[k] == 0; k++) {
-        bare_until((static_cast<int64_t>(verts[off[k]]) + 1) >> 1);       // a component goes behind every bare s with 2 s < its first vertex
+    bool past_round0 = false;
+    for (int64_t k = 0; k < n_comp; k++) {
+        if (!past_round0 && iter[k] != 0) { bare_until(n_f); past_round0 = true; }
+        if (!past_round0) bare_until((static_cast<int64_t>(verts[off[k]]) + 1) >> 1);   // a component goes behind every bare s with 2 s < its first vertex
         const int64_t n = off[k + 1] - off[k];
-        if (!kind[k]) { std::string s = comp_line(k, 0); if (lin_seen.insert(s).second) lin += s; continue; }
-        std::string s = comp_line(k, 0);
-        if (!cyc_seen.insert(s).second) continue;
-        if (n == 1 && o.self_loops) selfs += "self\n" + s; else cyc += "iter 0\n" + s;
-        if (o.break_cycles) { std::string op = comp_line(k, open_at[k]); if (lin_seen.insert(op).second) lin += op; }
-    }
-    bare_until(n_f);
-    for (; k < n_comp; k++) {
-        const int64_t n = off[k + 1] - off[k];
+        const sv s = line_of(k);
         if (!kind[k]) {
-            if (n == 1) continue;                                         // a bare segment is reported once, in round 0
-            std::string s = comp_line(k, 0);
-            if (lin_seen.insert(s).second) lin += s;
+            if (n == 1 && iter[k] > 0) continue;                          // a bare segment is reported once, in round 0
+            if (lin_seen.emplace(s).second) lin.append(s);
             continue;
         }
-        std::string s = comp_line(k, 0);
-        if (!cyc_seen.insert(s).second) continue;
-        if (n == 1 && o.self_loops) selfs += "self\n" + s; else cyc += "iter " + std::to_string(iter[k]) + "\n" + s;
-        if (o.break_cycles) { std::string op = comp_line(k, open_at[k]); if (lin_seen.insert(op).second) lin += op; }
+        if (!cyc_seen.emplace(s).second) continue;
+        if (n == 1 && o.self_loops) { selfs += "self\n"; selfs.append(s); }
+        else { cyc += "iter " + std::to_string(iter[k]) + "\n"; cyc.append(s); }
+        if (o.break_cycles) { std::string op; comp_line(k, open_at[k], op); if (lin_seen.insert(op).second) lin += op; }
     }
+    if (!past_round0) bare_until(n_f);
     cyc += selfs;
     const std::string nodup = cycle_without_duplicates(cyc);
     if (!write_file(o.linear_out, lin) || !write_file(o.cycle_out, cyc) || !write_file(o.nodup_out, nodup) || !write_file(o.result_out, lin + nodup))
         return fail("cannot write the matching outputs");
-    palace_stage04_destroy(ctx, st);
     tr.lap("stage 04: result text");
     return 0;
 }

@@ -188,3 +188,25 @@ def test_synthbam_round_trip(tmp_path):
             assert f[12:] == [f"SA:{tid2},{s[1]},{s[7]},{s[2]},{s[3]},90,0,150"], (i, f)
         else:
             assert len(f) == 12
+
+
+def test_threaded_fasta_parser_equals_the_serial_one(tmp_path):
+    """parse_fasta_mt (what eref reads its DB with): text ahead of the first header, empty records, records shorter than a
+    k-mer, long headers, no final newline -- the same records as the serial parser, for several thread counts."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    recs = [b"leading text without a header\nACGT\n"]
+    for i in range(3000):
+        n = int(rng.choice([0, 5, 31, 32, 33, 200, 4000, 9000]))
+        seq = bytes(rng.choice(list(b"ACGTNacgt"), size=n).astype(np.uint8))
+        hdr = b">ref%d/%d some text\twith a tab" % (i, i % 7) if i % 5 else b">r%d" % i
+        recs.append(hdr + b"\n" + b"\n".join(seq[k:k + 70] for k in range(0, len(seq), 70)) + (b"\n" if n else b""))
+    data = b"".join(recs)
+    data = data.rstrip(b"\n")                                           # no newline at the end of the file
+    assert len(data) > (4 << 20)
+    fa = tmp_path / "db.fa"
+    fa.write_bytes(data)
+    want = subprocess.run([HOSTDUMP, "fasta", str(fa)], stdout=subprocess.PIPE, check=True).stdout
+    assert want.count(b"\n") == 3001
+    for threads in ("2", "7", "16"):
+        assert subprocess.run([HOSTDUMP, "fasta", str(fa), threads], stdout=subprocess.PIPE, check=True).stdout == want
