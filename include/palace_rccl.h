@@ -1,0 +1,39 @@
+/*
+ * palace_rccl.h -- the multi-GPU exchange of the eref count table as a C entry point, for a C++ host that drives one
+ * process per GPU itself (libpalace_rccl.so: links libpalace_hip.so and RCCL; kept out of libpalace_hip.so so that the
+ * single-GPU executables do not load a collective library they never call).
+ *
+ * The reference shares ONE count table between std::threads of one process (bin/extract_ref.cpp:1269-1291); with the reads
+ * of a sample sharded over the GPUs of a node every rank counts into a private table and the tables are merged
+ * (SURVEY.md section 8(e)).  bench.py does this exchange through torch.distributed (palace_amd/multigpu.py); this is the same
+ * exchange without Python: every rank owns 1/world of the key space, peers send it their slice of TWO planes (the unary planes
+ * of a partial table carry two bits per key: palace_eref_table_pack_low), the owner folds the parts with the saturating
+ * bit-plane add (palace_eref_table_merge_slices_packed) and the merged ">= 3" plane -- the only one Phase B reads -- is
+ * all-gathered.  Point-to-point sends to every peer at once (all seven xGMI links of a GPU busy), no ring all-reduce of the
+ * whole table.
+ */
+#ifndef PALACE_RCCL_H
+#define PALACE_RCCL_H
+
+#include "palace_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* comm: an ncclComm_t of `world` ranks on which this process is `rank` (RCCL over xGMI inside a node); the calls are
+ * enqueued on the context's stream, behind the counting kernels, and nothing waits for the host.  On return (stream order)
+ * plane 3 of the context's table is the global "count >= 3" plane on every rank; planes 1 and 2 hold the merged values for
+ * this rank's slice only.  Needs 3 x 2^29 bytes of the context's scratch.  world must divide 2^25 (slices stay 16-byte
+ * aligned); world == 1 is allowed (the calls degenerate to copies). */
+int palace_eref_table_exchange(palace_ctx *ctx, void *comm, int rank, int world);
+
+/* Phase B rows: every rank scanned the refs [ref_lo[r], ref_hi[r]) and holds their rows (4 x int32 per ref) in d_rows;
+ * afterwards every rank holds all n_refs rows.  ref_lo / ref_hi: host arrays of `world` entries, the same on every rank. */
+int palace_eref_rows_allgather(palace_ctx *ctx, void *comm, int rank, int world, int32_t *d_rows, int64_t n_refs,
+                               const int64_t *ref_lo, const int64_t *ref_hi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PALACE_RCCL_H */

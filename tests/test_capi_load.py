@@ -36,3 +36,19 @@ def test_struct_layouts_match_header():
     """sizes the C side static-asserts too (csrc/graph.hip)"""
     assert ctypes.sizeof(capi.GraphParams) == 32
     assert ctypes.sizeof(capi.BamCols) == 8 + 13 * 8
+
+
+def test_rccl_library_exports_what_its_header_declares():
+    """include/palace_rccl.h -> libpalace_rccl.so (the multi-GPU exchange for a C++ host); loading it pulls RCCL in, which
+    needs no GPU.  No calls."""
+    import os
+    import re
+    capi.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "palace_rccl.h")).read()
+    names = sorted(set(re.findall(r"\b(palace_[a-z0-9_]+)\s*\(", text)) - {"palace_eref_table_pack_low", "palace_eref_table_merge_slices_packed"})
+    assert names == ["palace_eref_rows_allgather", "palace_eref_table_exchange"]
+    capi.lib()                                                   # libpalace_hip.so first: the rccl library links it by name
+    lib = ctypes.CDLL(os.path.join(root, "palace_amd", "libpalace_rccl.so"), mode=ctypes.RTLD_GLOBAL)
+    for n in names:
+        assert hasattr(lib, n), n

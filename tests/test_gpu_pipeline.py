@@ -94,3 +94,10 @@ def test_bench_starts_its_own_ranks():
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
     assert a["config"]["graph"] == b["config"]["graph"]
     assert a["config"]["result_digest"] == b["config"]["result_digest"] and a["config"]["result_digest"]["graph_and_components"]
+
+
+def test_c_abi_table_exchange_on_a_one_rank_communicator():
+    """include/palace_rccl.h driven from C++ (palace_amd/host/exchange_selftest_main.cpp): count -> pack -> grouped
+    send/recv -> merge -> all-gather on an ncclComm_t of one rank leaves the table as it was, the rows broadcast too."""
+    out = sh([os.path.join(BIN, "exchange_selftest"), "20000"]).decode()
+    assert out.startswith("ok:"), out

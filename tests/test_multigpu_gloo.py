@@ -1,4 +1,4 @@
-"""world_size-2 gloo run of palace_amd/multigpu.Exchange on CPU tensors: the byte movement of the
+"""world_size-2 and world_size-8 gloo runs of palace_amd/multigpu.Exchange on CPU tensors: the byte movement of the
 N>1 path (plane-slice all_to_all + owner merge + all_gather, padded row gathers, var-length candidate
 gather, depth reduce).  The merge arithmetic is the HIP library's in production; here a torch
 statement of the same bit-plane algebra stands in so the exchange can be checked end to end."""
@@ -83,8 +83,8 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2])
-def test_exchange_world2(world):
+@pytest.mark.parametrize("world", [2, 8])                 # 8 = the node the driver scales to, rehearsed over gloo
+def test_exchange_world(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
