@@ -96,6 +96,22 @@ int palace_eref_reserve(palace_ctx *ctx, int64_t total_bases);
 int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets,
                             int64_t n_reads, const uint8_t *d_keep, int64_t total_bases);
 
+/* E4 with the read set already packed (replaces the same loop, extract_ref.cpp:927-1004, for a caller that packs while it
+ * parses: 0.375 bytes per base cross PCIe instead of 1, and the kernels that derive the streams from ASCII do not run).
+ * Three bit streams over the positions 0 .. n_positions-1 of the read set (bit p & 31 of 32-bit word p >> 5, little endian):
+ *   P0[p] = base p is A or T,  P1[p] = base p is A or C   (either case; together the base itself -- what the reference's
+ *           generate_base tables project, extract_ref.cpp:1010-1046);
+ *   U[p]  = a 32-mer is counted at p: positions p .. p+31 lie in ONE read that is counted (E3 subsampling) and all are
+ *           A/C/G/T -- the `n`/read-end/short-read tests of extract_ref.cpp:963-996.
+ * Positions between reads that belong to no read (pads, e.g. to start every parser thread's part on a word) are allowed:
+ * U = 0 there and the other two streams are not looked at.  Each stream: palace_eref_packed_bytes(n_positions) bytes of
+ * device memory, 8-byte aligned (two words of look-ahead behind the last position are read, their content is ignored).
+ * n_reads_hint: number of reads if known (picks the tile shape for short-read sets), else 0.  Same table, same
+ * asynchrony as palace_eref_count_reads. */
+size_t palace_eref_packed_bytes(int64_t n_positions);
+int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const uint32_t *d_p1, const uint32_t *d_u,
+                                   int64_t n_positions, int64_t n_reads_hint);
+
 /* Tuning knobs of count_reads (no reference counterpart; results are identical for every setting, which is what the
  * tests use them for).  set_count_mode: mode 0 = automatic (partition + LDS counting for large inputs, direct global
  * atomics for tiny ones), 1 = always direct, 2 = always partitioned; bucket_cap > 0 overrides the per-bucket capacity

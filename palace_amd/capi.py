@@ -87,6 +87,7 @@ _SIGS = {
     "palace_eref_table_reset": [C.c_void_p],
     "palace_eref_reserve": [C.c_void_p, C.c_int64],
     "palace_eref_count_reads": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64],
+    "palace_eref_count_reads_packed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64],
     "palace_eref_set_count_mode": [C.c_void_p, C.c_int, C.c_int64],
     "palace_eref_set_option": [C.c_void_p, C.c_char_p, C.c_int64],
     "palace_eref_scan_refs": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
@@ -157,6 +158,8 @@ def lib() -> C.CDLL:
         _LIB.palace_version.restype = C.c_char_p
         _LIB.palace_stream.restype = C.c_void_p
         _LIB.palace_stream.argtypes = [C.c_void_p]
+        _LIB.palace_eref_packed_bytes.restype = C.c_size_t
+        _LIB.palace_eref_packed_bytes.argtypes = [C.c_int64]
         for nm, rt in (("count", C.c_int64), ("bare_count", C.c_int64), ("bare", C.POINTER(C.c_uint64)), ("offsets", C.POINTER(C.c_int64)), ("verts", C.POINTER(C.c_int32)),
                        ("kind", C.POINTER(C.c_uint8)), ("iter", C.POINTER(C.c_int32)), ("open_at", C.POINTER(C.c_int32))):
             fn = getattr(_LIB, "palace_match_result_" + nm)
@@ -270,6 +273,10 @@ class Ctx:
                          total_bases: int = -1):
         _check(lib().palace_eref_count_reads(self.h, d_bases.ptr, d_offsets.ptr, n_reads,
                                              d_keep.ptr if d_keep else None, total_bases), "palace_eref_count_reads")
+
+    def eref_count_reads_packed(self, d_p0: DevBuf, d_p1: DevBuf, d_u: DevBuf, n_positions: int, n_reads_hint: int = 0):
+        _check(lib().palace_eref_count_reads_packed(self.h, d_p0.ptr, d_p1.ptr, d_u.ptr, n_positions, n_reads_hint),
+               "palace_eref_count_reads_packed")
 
     def eref_set_count_mode(self, mode: int, bucket_cap: int = 0):
         _check(lib().palace_eref_set_count_mode(self.h, mode, bucket_cap), "palace_eref_set_count_mode")

@@ -205,6 +205,26 @@ __device__ __forceinline__ uint64_t l1_region_base(const DensityCaps &c, uint32_
     return c.prefix(b) * kL1Replicas + static_cast<uint64_t>(replica) * c.cap(b);
 }
 
+// Small packed read sets (palace_eref_count_reads_packed below the binning threshold): a lane per position, the windows of
+// the two projection streams straight from two words each, three atomics per marked position.
+__global__ __launch_bounds__(256) void eref_count_packed_kernel(const uint32_t *__restrict__ s0, const uint32_t *__restrict__ s1,
+                                                                const uint32_t *__restrict__ su, int64_t n, CoderMasks masks,
+                                                                uint32_t *__restrict__ p1, uint32_t *__restrict__ p2,
+                                                                uint32_t *__restrict__ p3)
+{
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < n; p += stride) {
+        const int64_t g = p >> 5;
+        const int sh = static_cast<int>(p & 31);
+        if (!((su[g] >> sh) & 1u)) continue;
+        const uint32_t a0 = __builtin_amdgcn_alignbit(s0[g + 1], s0[g], sh), a1 = __builtin_amdgcn_alignbit(s1[g + 1], s1[g], sh);
+        uint32_t key[3];
+        kmer_keys(masks, a0, a1, ~(a0 ^ a1), key);
+#pragma unroll
+        for (int i = 0; i < 3; i++) count_key(key[i], p1, p2, p3);
+    }
+}
+
 // Read ends as a bit per base position (bit p set <=> position p is the last base of a read), so
 // the kernels below need no per-read offset lookups: a 32-mer starting at p is inside one read
 // iff no end bit lies in [p, p+30].
@@ -1529,6 +1549,61 @@ int palace_eref_reserve(palace_ctx *ctx, int64_t total_bases)
     return ensure_workspace(ctx, pl.total());
 }
 
+}  // extern "C"
+
+// The read set as bit streams (P0, P1, U: see eref_streams_kernel) -> level-1 partition -> level-2 partition -> count in LDS,
+// slab by slab.  Shared by the ASCII entry (which builds the streams first) and the packed entry (whose caller did).
+static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const BinOut &o1, const Bin2Out &o2, const uint32_t *w0, const uint32_t *w1,
+                         const uint32_t *wu, int64_t total_bases, double keys_per_pos)
+{
+    const int64_t kSlabBases = pl.slab_bases_max, n_slabs = pl.n_slabs;
+    const DensityCaps caps1 = pl.caps1, caps2 = pl.caps2;
+    const size_t cur1_bytes = pl.cur1_bytes, cur2_bytes = pl.cur2_bytes;
+    unsigned int *cursor1 = o1.cursor, *cursor2 = o2.cursor, *touched = o1.touched;
+    uint32_t *buf1 = o1.buf;
+    uint16_t *buf2 = o2.buf;
+    // positions per lane of the level-1 kernel.  Its throughput is (key slots the CU's LDS holds) / (latency of a tile,
+    // ~11 us whatever the tile size): 6 positions x 3 keys x 512 lanes + pads = 39.5 KiB, the most that still fits four
+    // times into 160 KiB (5: +4 %, 4: +8 %, 8 -- three workgroups per CU --: +2 %).  Sparse sets (short reads) take 8.
+    const int ppl = ctx->bin1_ppl ? ctx->bin1_ppl : keys_per_pos > 1.6 ? 6 : 8;
+    for (int64_t slab = 0; slab < n_slabs; slab++) {
+        PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes + kTouchedBytes, ctx->stream));
+        const bool clean = ctx->table_clean && slab == 0;        // every plane bit is still zero: slices need no reading
+        const int64_t p_lo = slab * kSlabBases, p_hi = std::min(total_bases, (slab + 1) * kSlabBases);
+        const int64_t tile_pos = static_cast<int64_t>(kBinThreads) * ppl;
+        const int64_t tiles = (p_hi - p_lo + tile_pos - 1) / tile_pos;
+        PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
+        // one tile per workgroup, 8 waves.  Measured and dropped: workgroups that take several tiles with the next tile's
+        // words in flight -- five variants, DESIGN.md section 4 item 6; the last one (a loader wave with direct-to-LDS loads,
+        // LDS-only barriers, hand-placed waits: nothing of the previous tile is waited for) 4.4 ms against 4.07 at the same
+        // tile size; 256-thread workgroups (+3 %); 10 / 16 positions per lane (the same / +45 %).
+        const dim3 grid(static_cast<unsigned>(tiles)), block(kBinThreads);
+        switch (ppl) {
+        case 4: hipLaunchKernelGGL((eref_bin1_sort_kernel<4, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
+        case 5: hipLaunchKernelGGL((eref_bin1_sort_kernel<5, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
+        case 6: hipLaunchKernelGGL((eref_bin1_sort_kernel<6, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
+        default: hipLaunchKernelGGL((eref_bin1_sort_kernel<8, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
+        }
+        PALACE_HIP_TRY(hipGetLastError());
+        Bin2Grid g2;
+        g2.first[0] = 0;
+        for (uint32_t b = 0; b < kL1Buckets; b++) g2.first[b + 1] = g2.first[b] + tiles_of_bucket(caps1, b) * kL1Replicas;
+        hipLaunchKernelGGL(eref_bin2_kernel, dim3(g2.first[kL1Buckets]), dim3(kBin2Threads), 0, ctx->stream, cursor1, buf1, caps1, g2, o2);
+        PALACE_HIP_TRY(hipGetLastError());
+        if (clean)
+            hipLaunchKernelGGL(eref_lds_count_kernel<true>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, cursor2, buf2, caps2,
+                               ctx->plane[0], ctx->plane[1], ctx->plane[2], touched);
+        else
+            hipLaunchKernelGGL(eref_lds_count_kernel<false>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, cursor2, buf2, caps2,
+                               ctx->plane[0], ctx->plane[1], ctx->plane[2], touched);
+        PALACE_HIP_TRY(hipGetLastError());
+        ctx->table_clean = false;
+    }
+    return PALACE_OK;
+}
+
+extern "C" {
+
 int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets,
                             int64_t n_reads, const uint8_t *d_keep, int64_t total_bases)
 {
@@ -1564,11 +1639,9 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     CountPlan pl;
     rc = plan_count(ctx, total_bases, &pl);
     if (rc) return rc;
-    const int64_t kSlabBases = pl.slab_bases_max, n_slabs = pl.n_slabs, n_chunks = pl.n_chunks;
+    const int64_t n_chunks = pl.n_chunks;
     const DensityCaps caps1 = pl.caps1, caps2 = pl.caps2;
-    const size_t cur1_bytes = pl.cur1_bytes, cur2_bytes = pl.cur2_bytes, buf1_bytes = pl.buf1_bytes, buf2_bytes = pl.buf2_bytes,
-                 words_bytes = pl.words_bytes;
-    (void)buf2_bytes;
+    const size_t cur1_bytes = pl.cur1_bytes, cur2_bytes = pl.cur2_bytes, buf1_bytes = pl.buf1_bytes, words_bytes = pl.words_bytes;
     rc = ensure_workspace(ctx, pl.total());
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
@@ -1602,47 +1675,55 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
                            reinterpret_cast<uint16_t *>(strm[1]), reinterpret_cast<uint16_t *>(strm[2]));
         PALACE_HIP_TRY(hipGetLastError());
     }
-    // positions per lane of the level-1 kernel.  Its throughput is (key slots the CU's LDS holds) / (latency of a tile,
-    // ~11 us whatever the tile size): 6 positions x 3 keys x 512 lanes + pads = 39.5 KiB, the most that still fits four
-    // times into 160 KiB (5: +4 %, 4: +8 %, 8 -- three workgroups per CU --: +2 %).  Sparse sets (short reads) take 8.
     const double keys_per_pos = 3.0 * std::max(0.02, 1.0 - 31.0 * static_cast<double>(n_reads) / std::max<double>(1.0, static_cast<double>(total_bases)));
-    const int ppl = ctx->bin1_ppl ? ctx->bin1_ppl : keys_per_pos > 1.6 ? 6 : 8;
-    for (int64_t slab = 0; slab < n_slabs; slab++) {
-        PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes + kTouchedBytes, ctx->stream));
-        const bool clean = ctx->table_clean && slab == 0;        // every plane bit is still zero: slices need no reading
-        const int64_t p_lo = slab * kSlabBases, p_hi = std::min(total_bases, (slab + 1) * kSlabBases);
-        const int64_t tile_pos = static_cast<int64_t>(kBinThreads) * ppl;
-        const int64_t tiles = (p_hi - p_lo + tile_pos - 1) / tile_pos;
-        PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
-        const uint32_t *w0 = reinterpret_cast<const uint32_t *>(strm[0]), *w1 = reinterpret_cast<const uint32_t *>(strm[1]),
-                       *wu = reinterpret_cast<const uint32_t *>(strm[2]);
-        // one tile per workgroup, 8 waves.  Measured and dropped: workgroups that take several tiles with the next tile's
-        // words in flight -- five variants, DESIGN.md section 4 item 6; the last one (a loader wave with direct-to-LDS loads,
-        // LDS-only barriers, hand-placed waits: nothing of the previous tile is waited for) 4.4 ms against 4.07 at the same
-        // tile size; 256-thread workgroups (+3 %); 10 / 16 positions per lane (the same / +45 %).
-        const dim3 grid(static_cast<unsigned>(tiles)), block(kBinThreads);
-        switch (ppl) {
-        case 4: hipLaunchKernelGGL((eref_bin1_sort_kernel<4, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
-        case 5: hipLaunchKernelGGL((eref_bin1_sort_kernel<5, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
-        case 6: hipLaunchKernelGGL((eref_bin1_sort_kernel<6, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
-        default: hipLaunchKernelGGL((eref_bin1_sort_kernel<8, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
-        }
-        PALACE_HIP_TRY(hipGetLastError());
-        Bin2Grid g2;
-        g2.first[0] = 0;
-        for (uint32_t b = 0; b < kL1Buckets; b++) g2.first[b + 1] = g2.first[b] + tiles_of_bucket(caps1, b) * kL1Replicas;
-        hipLaunchKernelGGL(eref_bin2_kernel, dim3(g2.first[kL1Buckets]), dim3(kBin2Threads), 0, ctx->stream, cursor1, buf1, caps1, g2, o2);
-        PALACE_HIP_TRY(hipGetLastError());
-        if (clean)
-            hipLaunchKernelGGL(eref_lds_count_kernel<true>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, cursor2, buf2, caps2,
-                               ctx->plane[0], ctx->plane[1], ctx->plane[2], touched);
-        else
-            hipLaunchKernelGGL(eref_lds_count_kernel<false>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, cursor2, buf2, caps2,
-                               ctx->plane[0], ctx->plane[1], ctx->plane[2], touched);
+    return bin_and_count(ctx, pl, o1, o2, reinterpret_cast<const uint32_t *>(strm[0]), reinterpret_cast<const uint32_t *>(strm[1]),
+                         reinterpret_cast<const uint32_t *>(strm[2]), total_bases, keys_per_pos);
+}
+
+/* E4, packed input (include/palace_hip.h): the three bit streams come from the caller, the partition kernels read them where
+ * they lie -- no stream kernel, no read-end marks, no ASCII in HBM. */
+size_t palace_eref_packed_bytes(int64_t n_positions)
+{
+    return n_positions < 0 ? 0 : (static_cast<size_t>((n_positions + 63) / 64) + 2) * 8;
+}
+
+int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const uint32_t *d_p1, const uint32_t *d_u,
+                                   int64_t n_positions, int64_t n_reads_hint)
+{
+    PALACE_REQUIRE(ctx && n_positions >= 0 && n_reads_hint >= 0, "bad argument");
+    if (!ctx->coder_set) { set_error("palace_eref_count_reads_packed: coder not set"); return PALACE_ESTATE; }
+    if (n_positions == 0) return PALACE_OK;
+    PALACE_REQUIRE(d_p0 && d_p1 && d_u, "null device pointer");
+    PALACE_REQUIRE(((reinterpret_cast<uintptr_t>(d_p0) | reinterpret_cast<uintptr_t>(d_p1) | reinterpret_cast<uintptr_t>(d_u)) & 7) == 0,
+                   "the streams must be 8-byte aligned");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_table(ctx);
+    if (rc) return rc;
+    const bool binned = ctx->count_mode == 2 || (ctx->count_mode == 0 && n_positions >= (1ll << 22));
+    if (!binned) {
+        const int64_t blocks = std::min<int64_t>((n_positions + 255) / 256, static_cast<int64_t>(kCUs) * 8 * 8);
+        hipLaunchKernelGGL(eref_count_packed_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d_p0, d_p1, d_u,
+                           n_positions, ctx->masks, ctx->plane[0], ctx->plane[1], ctx->plane[2]);
         PALACE_HIP_TRY(hipGetLastError());
         ctx->table_clean = false;
+        return PALACE_OK;
     }
-    return PALACE_OK;
+    CountPlan pl;
+    rc = plan_count(ctx, n_positions, &pl);
+    if (rc) return rc;
+    // (palace_eref_packed_bytes covers what plan_count checks the look-ahead of the last tile against: (n >> 5) + 3 words of 4 bytes)
+    rc = ensure_workspace(ctx, pl.total() - 5 * pl.words_bytes);
+    if (rc) return rc;
+    char *ws = static_cast<char *>(ctx->ws.ptr);
+    unsigned int *cursor1 = reinterpret_cast<unsigned int *>(ws); ws += pl.cur1_bytes;
+    unsigned int *cursor2 = reinterpret_cast<unsigned int *>(ws); ws += pl.cur2_bytes;
+    unsigned int *touched = reinterpret_cast<unsigned int *>(ws); ws += kTouchedBytes;
+    uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += pl.buf1_bytes;
+    uint16_t *buf2 = reinterpret_cast<uint16_t *>(ws);
+    BinOut o1{cursor1, buf1, pl.caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], touched};
+    Bin2Out o2{cursor2, buf2, pl.caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2], touched};
+    const double keys_per_pos = n_reads_hint ? 3.0 * std::max(0.02, 1.0 - 31.0 * static_cast<double>(n_reads_hint) / static_cast<double>(n_positions)) : 3.0;
+    return bin_and_count(ctx, pl, o1, o2, d_p0, d_p1, d_u, n_positions, keys_per_pos);
 }
 
 /* Tuning knobs of count_reads (see include/palace_hip.h). */

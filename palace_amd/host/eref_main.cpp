@@ -252,57 +252,113 @@ int main(int argc, char **argv)
     if (const char *t = std::getenv("PALACE_EREF_SAMPLE_TARGET")) target = std::atol(t);   // test builds only (bin/eref_testhooks)
 #endif
     const int down_sam_ratio = sample > 0 ? static_cast<int>(100L * target / sample) : 100;
-    uint8_t *d_b = nullptr, *d_k = nullptr; int64_t *d_o = nullptr;
-    {
-        void *p = nullptr;
-        CK(palace_malloc(ctx, static_cast<size_t>(n_bases) + 64, &p)); d_b = static_cast<uint8_t *>(p);
-        CK(palace_malloc(ctx, static_cast<size_t>(n_reads + 1) * 8, &p)); d_o = static_cast<int64_t *>(p);
-    }
-    tr.lap("device buffers");
-    std::vector<int64_t> offsets(static_cast<size_t>(n_reads) + 1, 0);
-    constexpr int64_t kStage = 96ll << 20;
-    uint8_t *stage[2] = {nullptr, nullptr};
-    for (int k = 0; k < 2; k++) { void *p = nullptr; CK(palace_host_alloc(ctx, static_cast<size_t>(kStage), &p)); stage[k] = static_cast<uint8_t *>(p); }
-    tr.lap("pinned staging");
-    int n_sent = 0;
-    for (int side = 0; side < 2; side++) {
-        const FastqPlan &pl = plan[side];
-        const int64_t byte_base = side == 0 ? 0 : plan[0].n_bases, read_base = side == 0 ? 0 : plan[0].n_reads;
-        for (size_t i0 = 0; i0 < pl.parts.size();) {
-            size_t i1 = i0;                                                      // parts [i0, i1): as many as the buffer takes
-            const int64_t b0 = pl.parts[i0].byte0;
-            while (i1 < pl.parts.size() && pl.parts[i1].byte0 + pl.parts[i1].seq_bytes() - b0 <= kStage) i1++;
-            uint8_t *dst = stage[n_sent & 1];
-            std::vector<uint8_t> big;                                            // one part larger than the buffer (huge lines)
-            if (i1 == i0) { i1 = i0 + 1; big.resize(static_cast<size_t>(pl.parts[i0].seq_bytes())); dst = big.data(); }
-            else if (n_sent >= 2) CK(palace_mark_wait(ctx, 100 + ((n_sent - 2) & 1)));   // this buffer's previous copy has landed
-            pool_for(i1 - i0, threads, [&](size_t k) {
-                extract_fastq_part(pl, i0 + k, dst, b0, offsets.data() + read_base, byte_base);
-            });
-            const int64_t nb = pl.parts[i1 - 1].byte0 + pl.parts[i1 - 1].seq_bytes() - b0;
-            if (big.empty()) {
-                CK(palace_h2d_async(ctx, d_b + byte_base + b0, dst, static_cast<size_t>(nb)));
-                CK(palace_mark(ctx, 100 + (n_sent & 1)));
-                n_sent++;
-            } else {
-                CK(palace_h2d(ctx, d_b + byte_base + b0, dst, static_cast<size_t>(nb)));
-            }
-            i0 = i1;
-        }
-    }
-    tr.lap("fastq pass 2 + staged h2d");
-    CK(palace_h2d(ctx, d_o, offsets.data(), offsets.size() * 8));               // (also waits for the staged copies)
-    tr.lap("offsets h2d");
-    if (down_sam_ratio < 100) {                                                 // one draw per sequence line, file order (:955-960)
-        GlibcRand rng(1);                                                       // :1239-1240
-        std::vector<uint8_t> keep(static_cast<size_t>(n_reads));
+    // E3: one draw per sequence line, file order (:955-960, seeded :1239-1240)
+    std::vector<uint8_t> keep;
+    if (down_sam_ratio < 100) {
+        GlibcRand rng(1);
+        keep.resize(static_cast<size_t>(n_reads));
         for (int64_t i = 0; i < n_reads; i++) keep[static_cast<size_t>(i)] = (rng.next() % 100) < down_sam_ratio;
-        CK(upload(ctx, keep.data(), keep.size(), &d_k));
     }
-    if (n_reads) CK(palace_eref_count_reads(ctx, d_b, d_o, n_reads, d_k, n_bases));
-    tr.lap("count_reads enqueued");
-    for (int k = 0; k < 2; k++) CK(palace_host_free(ctx, stage[k]));
-    CK(palace_free(ctx, d_b)); CK(palace_free(ctx, d_o)); CK(palace_free(ctx, d_k));
+    const char *in_mode = std::getenv("PALACE_EREF_INPUT");                      // "ascii": the byte-per-base entry (kept, tested equal)
+    const bool packed = !(in_mode && std::strcmp(in_mode, "ascii") == 0);
+    if (packed) {
+        // The parser threads pack while they scan (fastx.hpp: pack_fastq_part): two bits per base and the 32-mer start mask
+        // go to the device, 0.375 bytes per base; the stream kernel and the read-end marks do not run.
+        std::vector<int64_t> pos0[2];
+        int64_t n_pos = 0;
+        for (int side = 0; side < 2; side++)
+            for (const FastqPart &pt : plan[side].parts) { pos0[side].push_back(n_pos); n_pos += packed_span(pt.seq_bytes()); }
+        const size_t stream_bytes = palace_eref_packed_bytes(n_pos);
+        uint64_t *d_s[3] = {nullptr, nullptr, nullptr};
+        for (int q = 0; q < 3; q++) { void *p = nullptr; CK(palace_malloc(ctx, stream_bytes, &p)); d_s[q] = static_cast<uint64_t *>(p); }
+        tr.lap("device buffers");
+        constexpr int64_t kStageWords = (32ll << 20) / 8;                        // per stream and buffer: 32 MiB = 256 M positions
+        uint64_t *stage[2] = {nullptr, nullptr};
+        for (int k = 0; k < 2; k++) { void *p = nullptr; CK(palace_host_alloc(ctx, static_cast<size_t>(3 * kStageWords * 8), &p)); stage[k] = static_cast<uint64_t *>(p); }
+        tr.lap("pinned staging");
+        int n_sent = 0;
+        for (int side = 0; side < 2; side++) {
+            const FastqPlan &pl = plan[side];
+            const int64_t read_base = side == 0 ? 0 : plan[0].n_reads;
+            const uint8_t *kp = keep.empty() ? nullptr : keep.data();
+            for (size_t i0 = 0; i0 < pl.parts.size();) {
+                size_t i1 = i0;                                                  // parts [i0, i1): as many as the buffer takes
+                const int64_t w0 = pos0[side][i0] / 64;
+                auto end_word = [&](size_t i) { return (pos0[side][i] + packed_span(pl.parts[i].seq_bytes())) / 64; };
+                while (i1 < pl.parts.size() && end_word(i1) - w0 <= kStageWords) i1++;
+                std::vector<uint64_t> big;                                       // one part larger than the buffer (huge lines)
+                uint64_t *dst = stage[n_sent & 1];
+                int64_t cap = kStageWords;
+                if (i1 == i0) { i1 = i0 + 1; cap = end_word(i0) - w0; big.resize(static_cast<size_t>(3 * cap)); dst = big.data(); }
+                else if (n_sent >= 2) CK(palace_mark_wait(ctx, 100 + ((n_sent - 2) & 1)));   // this buffer's previous copies have landed
+                pool_for(i1 - i0, threads, [&](size_t k) {
+                    const int64_t o = pos0[side][i0 + k] / 64 - w0;
+                    pack_fastq_part(pl, i0 + k, dst + o, dst + cap + o, dst + 2 * cap + o, kp, read_base);
+                });
+                const int64_t nw = end_word(i1 - 1) - w0;
+                for (int q = 0; q < 3; q++) {
+                    if (big.empty()) CK(palace_h2d_async(ctx, d_s[q] + w0, dst + q * cap, static_cast<size_t>(nw) * 8));
+                    else CK(palace_h2d(ctx, d_s[q] + w0, dst + q * cap, static_cast<size_t>(nw) * 8));
+                }
+                if (big.empty()) { CK(palace_mark(ctx, 100 + (n_sent & 1))); n_sent++; }
+                i0 = i1;
+            }
+        }
+        tr.lap("fastq pass 2 (packed) + staged h2d");
+        if (n_pos) CK(palace_eref_count_reads_packed(ctx, reinterpret_cast<const uint32_t *>(d_s[0]), reinterpret_cast<const uint32_t *>(d_s[1]),
+                                                     reinterpret_cast<const uint32_t *>(d_s[2]), n_pos, n_reads));
+        tr.lap("count_reads_packed enqueued");
+        CK(palace_sync(ctx));                                                    // the staging buffers are being read until the copies have landed
+        for (int k = 0; k < 2; k++) CK(palace_host_free(ctx, stage[k]));
+        for (int q = 0; q < 3; q++) CK(palace_free(ctx, d_s[q]));
+    } else {
+        uint8_t *d_b = nullptr, *d_k = nullptr; int64_t *d_o = nullptr;
+        {
+            void *p = nullptr;
+            CK(palace_malloc(ctx, static_cast<size_t>(n_bases) + 64, &p)); d_b = static_cast<uint8_t *>(p);
+            CK(palace_malloc(ctx, static_cast<size_t>(n_reads + 1) * 8, &p)); d_o = static_cast<int64_t *>(p);
+        }
+        tr.lap("device buffers");
+        std::vector<int64_t> offsets(static_cast<size_t>(n_reads) + 1, 0);
+        constexpr int64_t kStage = 96ll << 20;
+        uint8_t *stage[2] = {nullptr, nullptr};
+        for (int k = 0; k < 2; k++) { void *p = nullptr; CK(palace_host_alloc(ctx, static_cast<size_t>(kStage), &p)); stage[k] = static_cast<uint8_t *>(p); }
+        tr.lap("pinned staging");
+        int n_sent = 0;
+        for (int side = 0; side < 2; side++) {
+            const FastqPlan &pl = plan[side];
+            const int64_t byte_base = side == 0 ? 0 : plan[0].n_bases, read_base = side == 0 ? 0 : plan[0].n_reads;
+            for (size_t i0 = 0; i0 < pl.parts.size();) {
+                size_t i1 = i0;                                                      // parts [i0, i1): as many as the buffer takes
+                const int64_t b0 = pl.parts[i0].byte0;
+                while (i1 < pl.parts.size() && pl.parts[i1].byte0 + pl.parts[i1].seq_bytes() - b0 <= kStage) i1++;
+                uint8_t *dst = stage[n_sent & 1];
+                std::vector<uint8_t> big;                                            // one part larger than the buffer (huge lines)
+                if (i1 == i0) { i1 = i0 + 1; big.resize(static_cast<size_t>(pl.parts[i0].seq_bytes())); dst = big.data(); }
+                else if (n_sent >= 2) CK(palace_mark_wait(ctx, 100 + ((n_sent - 2) & 1)));   // this buffer's previous copy has landed
+                pool_for(i1 - i0, threads, [&](size_t k) {
+                    extract_fastq_part(pl, i0 + k, dst, b0, offsets.data() + read_base, byte_base);
+                });
+                const int64_t nb = pl.parts[i1 - 1].byte0 + pl.parts[i1 - 1].seq_bytes() - b0;
+                if (big.empty()) {
+                    CK(palace_h2d_async(ctx, d_b + byte_base + b0, dst, static_cast<size_t>(nb)));
+                    CK(palace_mark(ctx, 100 + (n_sent & 1)));
+                    n_sent++;
+                } else {
+                    CK(palace_h2d(ctx, d_b + byte_base + b0, dst, static_cast<size_t>(nb)));
+                }
+                i0 = i1;
+            }
+        }
+        tr.lap("fastq pass 2 + staged h2d");
+        CK(palace_h2d(ctx, d_o, offsets.data(), offsets.size() * 8));               // (also waits for the staged copies)
+        tr.lap("offsets h2d");
+        if (!keep.empty()) CK(upload(ctx, keep.data(), keep.size(), &d_k));
+        if (n_reads) CK(palace_eref_count_reads(ctx, d_b, d_o, n_reads, d_k, n_bases));
+        tr.lap("count_reads enqueued");
+        for (int k = 0; k < 2; k++) CK(palace_host_free(ctx, stage[k]));
+        CK(palace_free(ctx, d_b)); CK(palace_free(ctx, d_o)); CK(palace_free(ctx, d_k));
+    }
     for (int side = 0; side < 2; side++) plan[side].parts.clear();
 
     // ---- references: Phase B ----

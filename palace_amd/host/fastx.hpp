@@ -317,4 +317,74 @@ inline void extract_fastq_part(const FastqPlan &plan, size_t i, uint8_t *bases_d
     }
 }
 
+
+// ---- the packed form of a part (include/palace_hip.h: palace_eref_count_reads_packed) --------------------------------------
+// Pass 2 without the ASCII copy: the sequence lines of a part become bits of three streams -- P0 = {A,T}, P1 = {A,C}, and
+// U = "a 32-mer is counted here" -- which is what the device kernels read; 3 bits per base go over PCIe instead of 8.  Parts
+// start on multiples of 64 positions (the gaps are positions of no read, U = 0), so no two threads share a word.
+//
+// Eight bases per step: bit k of every byte is brought to bit 0 of its byte by a shift, the class tests are byte-parallel
+// boolean algebra on those (the same formulas as the device's class_bits4: A 0x41, C 0x43, G 0x47, T 0x54, case bit
+// ignored), and a multiply gathers the eight bit-0s into one byte.
+inline uint64_t gather_bit0_of_bytes(uint64_t y) { return ((y & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56; }
+
+inline int64_t packed_span(int64_t seq_bytes) { return (seq_bytes + 63) / 64 * 64; }     // positions a part occupies
+
+// Words [0, packed_span / 64) of p0 / p1 / u are written, all of them.  keep: one byte per read of the whole set (E3
+// subsampling, indexed read_base + the part's read numbers) or null.
+inline void pack_fastq_part(const FastqPlan &plan, size_t i, uint64_t *p0, uint64_t *p1, uint64_t *u, const uint8_t *keep, int64_t read_base)
+{
+    const FastqPart &pt = plan.parts[i];
+    const char *d = plan.txt->data;
+    const size_t nw = static_cast<size_t>(packed_span(pt.seq_bytes()) / 64);
+    std::vector<uint64_t> ok(nw + 1, 0), en(nw + 1, 0);
+    uint64_t a0 = 0, a1 = 0, ak = 0;                       // accumulators of the word being filled
+    int fill = 0;
+    size_t w = 0;
+    int64_t at = 0, r = pt.read0, l = pt.line0;            // position within the part
+    auto put = [&](uint64_t b0, uint64_t b1, uint64_t bk, int n) {          // n <= 8 bits each
+        a0 |= b0 << fill; a1 |= b1 << fill; ak |= bk << fill;
+        fill += n;
+        if (fill >= 64) {
+            p0[w] = a0; p1[w] = a1; ok[w] = ak; w++;
+            fill -= 64;
+            const int used = n - fill;                     // bits of this put that went into the finished word
+            a0 = fill ? b0 >> used : 0; a1 = fill ? b1 >> used : 0; ak = fill ? bk >> used : 0;
+        }
+    };
+    for (size_t p = pt.a; p < pt.b; l++) {
+        const void *nl = std::memchr(d + p, '\n', pt.b - p);
+        const size_t e = nl ? static_cast<const char *>(nl) - d : pt.b;
+        if ((l & 3) == 1) {
+            const bool counted = !keep || keep[read_base + r];
+            r++;
+            const size_t len = e - p;
+            for (size_t q = 0; q < len; q += 8) {
+                const int n = static_cast<int>(std::min<size_t>(8, len - q));
+                uint64_t x = 0;
+                std::memcpy(&x, d + p + q, static_cast<size_t>(n));             // (little endian: byte j = base q + j)
+                const uint64_t b0 = x, b1 = x >> 1, b2 = x >> 2, b3 = x >> 3, b4 = x >> 4, b6 = x >> 6, b7 = x >> 7;
+                const uint64_t t_like = b2 & ~b1 & ~b0, acg_like = b0 & (b1 | ~b2);
+                const uint64_t valid = gather_bit0_of_bytes(b6 & ~b7 & ~b3 & ((b4 & t_like) | (~b4 & acg_like)));
+                const uint64_t m = (1ull << n) - 1;        // (bytes beyond the line are zero = not a base, but keep it explicit)
+                put(gather_bit0_of_bytes(~b1) & m, gather_bit0_of_bytes(~b2) & m, counted ? (valid & m) : 0, n);
+            }
+            at += static_cast<int64_t>(len);
+            if (len) en[static_cast<size_t>((at - 1) >> 6)] |= 1ull << ((at - 1) & 63);
+        }
+        p = nl ? e + 1 : pt.b;
+    }
+    if (w < nw) { p0[w] = a0; p1[w] = a1; ok[w] = ak; w++; }
+    for (; w < nw; w++) { p0[w] = 0; p1[w] = 0; }
+    // U: bit t = the 32 positions from t on are bases of a counted read, and no read ends among the first 31 of them
+    for (size_t k = 0; k < nw; k++) {
+        unsigned __int128 a = (static_cast<unsigned __int128>(ok[k + 1]) << 64) | ok[k];
+        for (int sft = 1; sft < 32; sft <<= 1) a &= a >> sft;
+        unsigned __int128 x = (static_cast<unsigned __int128>(en[k + 1]) << 64) | en[k];
+        for (int sft = 1; sft < 16; sft <<= 1) x |= x >> sft;
+        x |= x >> 15;
+        u[k] = static_cast<uint64_t>(a) & ~static_cast<uint64_t>(x);
+    }
+}
+
 }  // namespace palace_host

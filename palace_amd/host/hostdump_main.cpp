@@ -2,6 +2,9 @@
 // Test tool for the CPU test suite:
 //   hostdump bam   <file.bam>          header + one line per record (decoded columns + parsed SA items)
 //   hostdump fastq <file.fq> <threads> [part_bytes]  one line per sequence line
+//   hostdump fastqpack <file.fq> <threads> <part_bytes> [keep_every]   the packed form of the sequence lines (pack_fastq_part):
+//                                      one line per part "pos0 n_words n_reads", then its words of P0, P1, U (hex, one line per stream);
+//                                      keep_every = k: read r is counted iff r % k != 0
 //   hostdump fasta <file.fa> [threads] one line per record (ordinal, name, length, sequence); with threads: parse_fasta_mt
 #include <cstdio>
 #include <cstring>
@@ -44,6 +47,31 @@ int main(int argc, char **argv)
             for (int64_t i = 0; i < plan.n_reads; i++) {
                 std::fwrite(bases.data() + off[i], 1, static_cast<size_t>(off[i + 1] - off[i]), stdout);
                 std::fputc('\n', stdout);
+            }
+        } else if (mode == "fastqpack") {
+            const int threads = argc > 3 ? std::atoi(argv[3]) : 1;
+            MappedText txt(argv[2]);
+            FastqPlan plan;
+            plan_fastq(txt, threads, plan, argc > 4 ? static_cast<size_t>(std::atol(argv[4])) : (4u << 20));
+            const int every = argc > 5 ? std::atoi(argv[5]) : 0;
+            std::vector<uint8_t> keep;
+            if (every > 0) { keep.resize(static_cast<size_t>(plan.n_reads)); for (size_t r = 0; r < keep.size(); r++) keep[r] = (r % static_cast<size_t>(every)) != 0; }
+            std::vector<int64_t> pos0;
+            int64_t n_pos = 0;
+            for (const FastqPart &pt : plan.parts) { pos0.push_back(n_pos); n_pos += packed_span(pt.seq_bytes()); }
+            std::vector<uint64_t> st[3];
+            for (auto &v : st) v.assign(static_cast<size_t>(n_pos / 64) + 1, 0xdeadbeefdeadbeefull);      // every word must be written
+            pool_for(plan.parts.size(), threads, [&](size_t i) {
+                const size_t o = static_cast<size_t>(pos0[i] / 64);
+                pack_fastq_part(plan, i, st[0].data() + o, st[1].data() + o, st[2].data() + o, keep.empty() ? nullptr : keep.data(), 0);
+            });
+            for (size_t i = 0; i < plan.parts.size(); i++) {
+                const size_t o = static_cast<size_t>(pos0[i] / 64), nw = static_cast<size_t>(packed_span(plan.parts[i].seq_bytes()) / 64);
+                std::printf("%lld %zu %lld\n", (long long)pos0[i], nw, (long long)plan.parts[i].n_seq());
+                for (int q = 0; q < 3; q++) {
+                    for (size_t k = 0; k < nw; k++) std::printf("%016llx%c", (unsigned long long)st[q][o + k], k + 1 < nw ? ' ' : '\n');
+                    if (!nw) std::fputc('\n', stdout);
+                }
             }
         } else if (mode == "fasta") {
             SeqSet db;

@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_every_declared_symbol_has_a_python_signature():
-    have = set(capi._SIGS) | {"palace_last_error", "palace_version", "palace_stream", "palace_match_result_free"}
+    have = set(capi._SIGS) | {"palace_last_error", "palace_version", "palace_stream", "palace_match_result_free", "palace_eref_packed_bytes"}
     have |= {"palace_match_result_" + k for k in ("count", "offsets", "verts", "kind", "iter", "open_at", "bare", "bare_count")}
     assert set(capi.declared_symbols()) <= have
 

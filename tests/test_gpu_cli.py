@@ -44,8 +44,9 @@ def test_eref_cached_index_equals_reference_stdout(eref_files, golden_eref, key,
     orc.build_index_file(fa, golden_eref["index_header"], fa + ".k32.index.dat", fa + ".genome.len.txt")
     tmp = str(d / "tmp.txt")
     open(tmp, "w").write("stale")
-    for threads in ("1", "8"):
-        p = run([os.path.join(BIN, "eref"), str(d / "r_1.fq"), str(d / "r_2.fq"), fa, tmp, hr, pr, threads])
+    for threads, reads_as in (("1", "packed"), ("8", "packed"), ("8", "ascii")):     # the parser threads pack the reads (default) or ship bytes
+        p = run([os.path.join(BIN, "eref"), str(d / "r_1.fq"), str(d / "r_2.fq"), fa, tmp, hr, pr, threads],
+                env=dict(os.environ, PALACE_EREF_INPUT=reads_as))
         assert p.returncode == 0, p.stderr
         assert p.stdout == golden_eref[key].tobytes()
         assert os.path.getsize(tmp) == 0                      # extract_ref.cpp:825, 899
@@ -234,10 +235,11 @@ def test_eref_subsampling_follows_glibc_rand_stream(eref_files, golden_eref):
     # bin/eref_testhooks = eref_main.cpp compiled with -DPALACE_TEST_HOOKS (a lowered sampling target; the shipped eref has
     # no such knob).  The same path at its real threshold (> 1 Gbase in fq1) is pinned by tests/test_gpu_configs.py against a
     # run of the compiled reference.
-    p = run([os.path.join(BIN, "eref_testhooks"), str(d / "r_1.fq"), str(d / "r_2.fq"), fa, str(d / "tmp.txt"), "0.8", "0.5", "2"],
-            env=dict(os.environ, PALACE_EREF_SAMPLE_TARGET=str(target)))
-    assert p.returncode == 0, p.stderr
-    assert p.stdout == want
+    for reads_as in ("packed", "ascii"):
+        p = run([os.path.join(BIN, "eref_testhooks"), str(d / "r_1.fq"), str(d / "r_2.fq"), fa, str(d / "tmp.txt"), "0.8", "0.5", "2"],
+                env=dict(os.environ, PALACE_EREF_SAMPLE_TARGET=str(target), PALACE_EREF_INPUT=reads_as))
+        assert p.returncode == 0, p.stderr
+        assert p.stdout == want
     assert want != g["stdout_080_050"].tobytes()              # sampling really changed the answer
 
 

@@ -445,3 +445,89 @@ def test_binned_slabs(ctx, with_keep):
     u, c = oracle_key_counts(kept.bases, kept.offsets, cc)
     assert_table_equals(ctx, u, c)
 
+
+
+def pack_reads(bases, offsets, keep=None, gap_every=0):
+    """a read set as the three bit streams of palace_eref_count_reads_packed (include/palace_hip.h), stated with numpy per
+    base; gap_every > 0 puts positions of no read between the reads now and then (what parser threads leave between their parts)"""
+    bases, offsets = np.asarray(bases, np.uint8), np.asarray(offsets, np.int64)
+    n = len(offsets) - 1
+    lens = offsets[1:] - offsets[:-1]
+    gaps = np.array([(37 if gap_every and r % gap_every == 0 else 0) for r in range(n)], np.int64)
+    start = np.concatenate([[0], np.cumsum(lens + gaps)[:-1]]) + gaps          # packed position of every read's first base
+    n_pos = int((lens + gaps).sum())
+    pos = np.repeat(start - (offsets[:-1] - offsets[0]), lens) + np.arange(offsets[0], offsets[-1]) - offsets[0]
+    up = bases[offsets[0]:offsets[-1]] & 0xDF
+    ok = np.isin(up, np.frombuffer(b"ACGT", np.uint8))
+    if keep is not None:
+        ok &= np.repeat(np.asarray(keep, bool), lens)
+    v0, v1, valid = (np.zeros(n_pos + 32, np.uint8) for _ in range(3))
+    v0[pos] = np.isin(up, np.frombuffer(b"AT", np.uint8)); v1[pos] = np.isin(up, np.frombuffer(b"AC", np.uint8)); valid[pos] = ok
+    cs = np.concatenate([[0], np.cumsum(1 - valid.astype(np.int64))])
+    all_ok = (cs[32:n_pos + 32] - cs[:n_pos]) == 0                              # the 32 positions from p on are counted bases ...
+    end = np.zeros(n_pos, np.int64); end[pos] = np.repeat(start + lens, lens)
+    u = all_ok & (np.arange(n_pos) + 32 <= end)                                 # ... of one read
+    n_bytes = int(capi.lib().palace_eref_packed_bytes(n_pos))
+    out = []
+    for bits in (v0[:n_pos], v1[:n_pos], u.astype(np.uint8)):
+        b = np.zeros(n_bytes, np.uint8)
+        pk = np.packbits(bits, bitorder="little")
+        b[:len(pk)] = pk
+        b[len(pk):] = 0xA5 if bits is not u else 0                              # look-ahead words: content is ignored
+        out.append(b)
+    return out, n_pos
+
+
+@pytest.mark.parametrize("mode", [1, 2])                                        # direct kernel / binned
+@pytest.mark.parametrize("with_keep,gap_every", [(False, 0), (True, 5)])
+def test_packed_entry_equals_ascii_entry(ctx, mode, with_keep, gap_every):
+    """palace_eref_count_reads_packed == palace_eref_count_reads == oracle on the same reads: ragged lengths (0, 31, 32, 33),
+    invalid bases, lower case, dropped reads, positions of no read between reads."""
+    rng = synth.rng_for(41)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    cc = orc.header_to_cc(hdr)
+    genome = synth.random_dna(rng, 60000)
+    with_n = genome[300:400].copy(); with_n[40] = ord("N")
+    reads = [np.zeros(0, np.uint8), np.full(31, ord("A"), np.uint8), genome[:32], genome[100:133], genome[200:300] | 0x20, with_n]
+    for _ in range(3000):
+        a, L = int(rng.integers(0, 59000)), int(rng.integers(20, 400))
+        s = genome[a:a + L].copy()
+        if rng.random() < 0.2:
+            s[int(rng.integers(0, len(s)))] = ord("N")
+        reads.append(s)
+    rs = synth.reads_from_list(reads)
+    keep = (rng.random(rs.n) < 0.6).astype(np.uint8) if with_keep else None
+    kept = synth.reads_from_list([rs.read(i) for i in range(rs.n) if keep is None or keep[i]])
+    u, c = oracle_key_counts(kept.bases, kept.offsets, cc)
+    streams, n_pos = pack_reads(rs.bases, rs.offsets, keep, gap_every)
+    try:
+        ctx.eref_set_count_mode(mode, 0)
+        if mode == 2:
+            ctx.eref_set_option("slab_bases", 64 * 1024)
+        ctx.eref_set_coder(hdr)
+        ctx.eref_table_reset()
+        d = [ctx.upload(s) for s in streams]
+        ctx.eref_count_reads_packed(d[0], d[1], d[2], n_pos, rs.n)
+        ctx.sync()
+        for b in d:
+            b.free()
+        assert_table_equals(ctx, u, c)
+        count_on_gpu(ctx, [(rs.bases, rs.offsets)], hdr, keep=[keep] if with_keep else None)
+        assert_table_equals(ctx, u, c)
+    finally:
+        ctx.eref_set_option("slab_bases", 0)
+        ctx.eref_set_count_mode(0, 0)
+
+
+def test_packed_entry_argument_checks(ctx):
+    hdr = orc.header_from_picks(np.zeros(32, np.int64))
+    ctx.eref_set_coder(hdr)
+    ctx.eref_table_reset()
+    d = ctx.upload(np.zeros(64, np.uint8))
+    ctx.eref_count_reads_packed(d, d, d, 0)                                     # nothing to count
+    with pytest.raises(capi.PalaceError):
+        capi._check(capi.lib().palace_eref_count_reads_packed(ctx.h, d.ptr + 4, d.ptr, d.ptr, 100, 0), "packed")   # misaligned stream
+    with pytest.raises(capi.PalaceError):
+        capi._check(capi.lib().palace_eref_count_reads_packed(ctx.h, None, d.ptr, d.ptr, 100, 0), "packed")
+    d.free()
+    assert capi.lib().palace_eref_packed_bytes(0) == 16 and capi.lib().palace_eref_packed_bytes(65) == 32

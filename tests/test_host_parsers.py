@@ -210,3 +210,54 @@ def test_threaded_fasta_parser_equals_the_serial_one(tmp_path):
     assert want.count(b"\n") == 3001
     for threads in ("2", "7", "16"):
         assert subprocess.run([HOSTDUMP, "fasta", str(fa), threads], stdout=subprocess.PIPE, check=True).stdout == want
+
+
+def packed_expectation(seqs, keep=None):
+    """What a read set is as P0 / P1 / U bit lists (include/palace_hip.h, palace_eref_count_reads_packed), stated per base:
+    a 32-mer is counted at p iff the 32 bytes from p on lie in one counted read and are all A/C/G/T in either case
+    (extract_ref.cpp:963-996)."""
+    p0, p1, u = [], [], []
+    for r, s in enumerate(seqs):
+        s = s.upper()
+        ok = [c in b"ACGT" and (keep is None or keep[r]) for c in s]
+        p0 += [int(c in b"AT") if c in b"ACGT" else None for c in s]
+        p1 += [int(c in b"AC") if c in b"ACGT" else None for c in s]
+        u += [int(i + 32 <= len(s) and all(ok[i:i + 32])) for i in range(len(s))]
+    return p0, p1, u
+
+
+def test_packed_fastq_parts_equal_the_per_base_statement(tmp_path):
+    """pack_fastq_part (fastx.hpp): the parser threads' packed output -- parts on 64-position boundaries, every word written,
+    invalid bases, short reads, CR, lower case, reads that are not counted (E3), many part sizes and line phases."""
+    rng = synth.rng_for(11)
+    seqs = [b"ACGT" * 20, b"acgtn" * 30, b"", b"A" * 31, b"C" * 32, b"G" * 33, b"T" * 64 + b"\r", b"ACGTRYKM" * 9, b"N" * 70]
+    for _ in range(40):
+        L = int(rng.integers(0, 200))
+        s = bytearray(synth.random_dna(rng, L)) if L else bytearray()
+        for _ in range(int(rng.integers(0, 3))):
+            if L:
+                s[int(rng.integers(0, L))] = rng.choice(list(b"NnXacgt-"))
+        seqs.append(bytes(s))
+    txt = b"".join(b"@r%d\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n" for i, s in enumerate(seqs))
+    p = str(tmp_path / "p.fq")
+    open(p, "wb").write(txt)
+    for threads, part_bytes, every in (("1", "4194304", 0), ("3", "300", 0), ("5", "64", 3), ("2", "1", 2), ("4", "1000", 0)):
+        keep = [r % every != 0 for r in range(len(seqs))] if every else None
+        want0, want1, want_u = packed_expectation(seqs, keep)
+        out = dump("fastqpack", p, threads, part_bytes, *([str(every)] if every else [])).decode().split("\n")
+        i, next_pos, r = 0, 0, 0
+        while i + 3 < len(out):
+            pos0, nw, n_reads = (int(x) for x in out[i].split())
+            assert pos0 == next_pos and pos0 % 64 == 0
+            next_pos += 64 * nw
+            mine = seqs[r:r + n_reads]
+            want0, want1, want_u = packed_expectation(mine, keep[r:r + n_reads] if keep else None)
+            assert nw == (len(want_u) + 63) // 64                          # the gap ends at the next multiple of 64
+            bits = [[(int(w, 16) >> b) & 1 for w in out[i + 1 + q].split() for b in range(64)] for q in range(3)]
+            assert all(len(b) == 64 * nw for b in bits)
+            assert bits[2] == want_u + [0] * (64 * nw - len(want_u))         # U, and U = 0 in the gap
+            for q, want in ((0, want0), (1, want1)):
+                assert all(w is None or bits[q][j] == w for j, w in enumerate(want))
+            r += n_reads
+            i += 4
+        assert r == len(seqs)
