@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <fstream>
 #include <future>
 #include <iostream>
@@ -143,8 +144,11 @@ int main(int argc, char **argv)
         } catch (const std::exception &e) { in_err = e.what(); }
     }).share();
     std::thread hip_up([&] {
+        Trace th("eref/hip");
         ctx_rc = palace_ctx_create(0, &ctx);
+        th.lap("context");
         if (!ctx_rc) ctx_rc = palace_eref_table_reset(ctx);
+        th.lap("table");
         // One-shot process: count in slabs of 2^28 positions (6.5 GB of scratch) instead of the library's 2^30 (26 GB).  The
         // driver hands out zeroed device memory, and zeroing what the previous process left behind was measured at up to
         // 1.1 s for 26 GB; the three extra passes over the planes cost ~3 ms.  PALACE_EREF_SLAB=<positions> overrides.
@@ -154,7 +158,9 @@ int main(int argc, char **argv)
         }
         if (!ctx_rc) {                                      // ... and the scratch memory of the count, as soon as its size is known
             scan_done.wait();
+            th.lap("fastq pass 1 (waited)");
             if (in_err.empty()) ctx_rc = palace_eref_reserve(ctx, plan[0].n_bases + plan[1].n_bases);
+            th.lap("scratch reserved");
         }
         if (ctx_rc) ctx_err = palace_last_error();          // (the message is per thread)
     });
@@ -272,7 +278,9 @@ int main(int argc, char **argv)
         uint64_t *d_s[3] = {nullptr, nullptr, nullptr};
         for (int q = 0; q < 3; q++) { void *p = nullptr; CK(palace_malloc(ctx, stream_bytes, &p)); d_s[q] = static_cast<uint64_t *>(p); }
         tr.lap("device buffers");
-        constexpr int64_t kStageWords = (32ll << 20) / 8;                        // per stream and buffer: 32 MiB = 256 M positions
+        // per stream and buffer 8 MiB = 64 M positions (a dozen parts per thread); page-locking the ASCII path's 2 x 96 MiB
+        // costs ~50 ms, these 2 x 24 MiB a quarter of it
+        constexpr int64_t kStageWords = (8ll << 20) / 8;
         uint64_t *stage[2] = {nullptr, nullptr};
         for (int k = 0; k < 2; k++) { void *p = nullptr; CK(palace_host_alloc(ctx, static_cast<size_t>(3 * kStageWords * 8), &p)); stage[k] = static_cast<uint64_t *>(p); }
         tr.lap("pinned staging");
@@ -414,5 +422,6 @@ int main(int argc, char **argv)
         }
     }
     tr.lap("stdout");
-    return 0;
+    std::fflush(nullptr);
+    _exit(0);                   // every output is complete: skip the teardown of the runtime and of gigabytes of mappings
 }

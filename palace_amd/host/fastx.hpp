@@ -197,6 +197,7 @@ inline void parse_fasta_mt(const char *txt, size_t N, SeqSet &out, int threads)
 // under each of the four possible line phases (so the parts can be placed without a serial pass), then to copy its
 // sequence lines to their final place in a staging buffer.  Same getline semantics as parse_fastq above.
 // ------------------------------------------------------------------------------------------------
+#include <emmintrin.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -323,11 +324,8 @@ inline void extract_fastq_part(const FastqPlan &plan, size_t i, uint8_t *bases_d
 // U = "a 32-mer is counted here" -- which is what the device kernels read; 3 bits per base go over PCIe instead of 8.  Parts
 // start on multiples of 64 positions (the gaps are positions of no read, U = 0), so no two threads share a word.
 //
-// Eight bases per step: bit k of every byte is brought to bit 0 of its byte by a shift, the class tests are byte-parallel
-// boolean algebra on those (the same formulas as the device's class_bits4: A 0x41, C 0x43, G 0x47, T 0x54, case bit
-// ignored), and a multiply gathers the eight bit-0s into one byte.
-inline uint64_t gather_bit0_of_bytes(uint64_t y) { return ((y & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56; }
-
+// Sixteen bases per step (SSE2, the x86-64 baseline): four byte-wise compares against A, C, G, T on the case-folded bytes,
+// and a movemask turns each class into 16 bits.
 inline int64_t packed_span(int64_t seq_bytes) { return (seq_bytes + 63) / 64 * 64; }     // positions a part occupies
 
 // Words [0, packed_span / 64) of p0 / p1 / u are written, all of them.  keep: one byte per read of the whole set (E3
@@ -342,7 +340,7 @@ inline void pack_fastq_part(const FastqPlan &plan, size_t i, uint64_t *p0, uint6
     int fill = 0;
     size_t w = 0;
     int64_t at = 0, r = pt.read0, l = pt.line0;            // position within the part
-    auto put = [&](uint64_t b0, uint64_t b1, uint64_t bk, int n) {          // n <= 8 bits each
+    auto put = [&](uint64_t b0, uint64_t b1, uint64_t bk, int n) {          // n <= 16 bits each
         a0 |= b0 << fill; a1 |= b1 << fill; ak |= bk << fill;
         fill += n;
         if (fill >= 64) {
@@ -359,15 +357,23 @@ inline void pack_fastq_part(const FastqPlan &plan, size_t i, uint64_t *p0, uint6
             const bool counted = !keep || keep[read_base + r];
             r++;
             const size_t len = e - p;
-            for (size_t q = 0; q < len; q += 8) {
-                const int n = static_cast<int>(std::min<size_t>(8, len - q));
-                uint64_t x = 0;
-                std::memcpy(&x, d + p + q, static_cast<size_t>(n));             // (little endian: byte j = base q + j)
-                const uint64_t b0 = x, b1 = x >> 1, b2 = x >> 2, b3 = x >> 3, b4 = x >> 4, b6 = x >> 6, b7 = x >> 7;
-                const uint64_t t_like = b2 & ~b1 & ~b0, acg_like = b0 & (b1 | ~b2);
-                const uint64_t valid = gather_bit0_of_bytes(b6 & ~b7 & ~b3 & ((b4 & t_like) | (~b4 & acg_like)));
-                const uint64_t m = (1ull << n) - 1;        // (bytes beyond the line are zero = not a base, but keep it explicit)
-                put(gather_bit0_of_bytes(~b1) & m, gather_bit0_of_bytes(~b2) & m, counted ? (valid & m) : 0, n);
+            const __m128i fold = _mm_set1_epi8(static_cast<char>(0xDF)), cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'),
+                          cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
+            for (size_t q = 0; q < len; q += 16) {
+                const int n = static_cast<int>(std::min<size_t>(16, len - q));
+                __m128i x;
+                if (n == 16) x = _mm_loadu_si128(reinterpret_cast<const __m128i *>(d + p + q));
+                else {                                                           // the line's tail: never read past it (the mapping may end there)
+                    alignas(16) char tail[16] = {0};
+                    std::memcpy(tail, d + p + q, static_cast<size_t>(n));
+                    x = _mm_load_si128(reinterpret_cast<const __m128i *>(tail));
+                }
+                x = _mm_and_si128(x, fold);
+                const __m128i isA = _mm_cmpeq_epi8(x, cA), isC = _mm_cmpeq_epi8(x, cC), isG = _mm_cmpeq_epi8(x, cG), isT = _mm_cmpeq_epi8(x, cT);
+                const uint64_t at_ = static_cast<uint64_t>(_mm_movemask_epi8(_mm_or_si128(isA, isT))),
+                               ac_ = static_cast<uint64_t>(_mm_movemask_epi8(_mm_or_si128(isA, isC))),
+                               gt_ = static_cast<uint64_t>(_mm_movemask_epi8(_mm_or_si128(isG, isT)));
+                put(at_, ac_, counted ? ((ac_ | gt_) & ((1ull << n) - 1)) : 0, n);      // (zero bytes of a tail match nothing anyway)
             }
             at += static_cast<int64_t>(len);
             if (len) en[static_cast<size_t>((at - 1) >> 6)] |= 1ull << ((at - 1) & 63);

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sys/mman.h>
 #include <fstream>
 #include <iostream>
 #include <numeric>
@@ -352,22 +353,36 @@ int main(int argc, char **argv)
     tr.lap("classify + name guard");
     // The inflated stream (gigabytes) has served: read names were its last users.  Giving the pages back takes the kernel a few
     // hundred milliseconds -- at process exit that is wall time the driver waits for, here it runs beside the rest of the work.
-    std::thread([buf = std::move(c.raw.p)]() mutable { buf.reset(); }).detach();
+    // Not with one munmap, though: that holds the address-space lock against every allocation of the other threads for its
+    // whole duration.  The pages go back piece by piece (MADV_DONTNEED takes the lock shared, and briefly); the empty mapping
+    // itself stays until exit.
+    {
+        uint8_t *raw = c.raw.p.release();
+        const size_t raw_n = c.raw.n;
+        std::thread([raw, raw_n] {
+            const uintptr_t page = 4096, piece = 32u << 20;
+            uintptr_t a = (reinterpret_cast<uintptr_t>(raw) + page - 1) / page * page, e = (reinterpret_cast<uintptr_t>(raw) + raw_n) / page * page;
+            for (; a < e; a += piece) ::madvise(reinterpret_cast<void *>(a), std::min<uintptr_t>(piece, e - a), MADV_DONTNEED);
+        }).detach();
+    }
     c.raw.n = 0;
     CK(palace_malloc(ctx, static_cast<size_t>(std::max<int64_t>(1, n_cands)) * sizeof(palace_graph_edge), &p));
     palace_graph_edge *d_edges = static_cast<palace_graph_edge *>(p);
     int64_t n_edges = 0;
+    tr.lap("edge buffer");
     CK(palace_graph_resolve(ctx, d_cands, n_cands, c.n(), &prm, d_consumed, d_edges, std::max<int64_t>(1, n_cands), &n_edges));
+    tr.lap("resolve");
     std::vector<uint64_t> consumed(static_cast<size_t>(nt));
     std::vector<palace_graph_edge> edges(static_cast<size_t>(n_edges));
     std::vector<int32_t> cn_dev(static_cast<size_t>(nt));
     CK(palace_malloc(ctx, std::max<size_t>(1, nt) * 4, &p));
     int32_t *d_cn = static_cast<int32_t *>(p);
+    tr.lap("host buffers");
     CK(palace_graph_copy_numbers(ctx, d_consumed, d_tlen, nt, avg_depth, d_cn));
     CK(palace_d2h(ctx, cn_dev.data(), p, cn_dev.size() * 4));
     CK(palace_d2h(ctx, consumed.data(), d_consumed, consumed.size() * 8));
     CK(palace_d2h(ctx, edges.data(), d_edges, edges.size() * sizeof(palace_graph_edge)));
-    tr.lap("resolve + d2h");
+    tr.lap("copy numbers + d2h");
     if (!s4o.enabled()) {
         palace_ctx_destroy(ctx);
         tr.lap("ctx destroy");
