@@ -44,6 +44,9 @@ def parse_args():
                          "(100k contigs, N50 ~ 50 kb, tail > 120 kb, evidence that reaches the exp-underflow gate)")
     ap.add_argument("--contigs", type=int, default=None)
     ap.add_argument("--refs", type=int, default=5000)
+    ap.add_argument("--reads", choices=("packed", "ascii"), default="packed",
+                    help="form of the reads resident in HBM: packed = two bits per base + 32-mer start mask (what the eref executable's "
+                         "parser threads produce; palace_eref_count_reads_packed), ascii = a byte per base (palace_eref_count_reads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files -> files leg (CLI chain on generated files)")
     ap.add_argument("--soak-seconds", type=float, default=2.0,
@@ -654,7 +657,7 @@ def phase_a_traffic(args, world):
         t = json.load(open(os.path.join(ROOT, "profiles", "phase_a_traffic.json")))
     except Exception:
         return None, None
-    if world != 1 or t.get("contigs") != args.contigs or t.get("workload", "default") != args.workload:
+    if world != 1 or t.get("contigs") != args.contigs or t.get("workload", "default") != args.workload or t.get("reads", "ascii") != args.reads:
         return None, None
     return t.get("bytes_per_launch"), t.get("source")
 
@@ -769,6 +772,19 @@ def main():
     capi._check(L.palace_eref_probe_index_build(ctx.h, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
                                                 sample["ref_total"], ctypes.byref(probe_index)), "probe index")
 
+    # the reads in the form the step counts them from (resident before the timed region, like every other input)
+    packed = None
+    if args.reads == "packed":
+        nb = int(L.palace_eref_packed_bytes(2 * n_side * READ_LEN))
+        packed = [torch.zeros(nb, dtype=torch.uint8, device=dev) for _ in range(3)]
+        capi._check(L.palace_eref_pack_reads(ctx.h, P(sample["r12"]), P(sample["read_off"]), 2 * n_side, None, 2 * n_side * READ_LEN,
+                                             *(P(t) for t in packed)), "pack")
+        ctx.sync()
+    # one GPU (and N GPUs that each count all reads): the count of a step is the only one between its reset and its scan, so the
+    # two lower planes of the table need not leave the LDS (include/palace_hip.h, option final_count)
+    final_count = not shard_reads
+    ctx.eref_set_option("final_count", 1 if final_count else 0)
+
     def step(i, timed):
         m = 8 * i
         tot_b = n_side * READ_LEN
@@ -777,7 +793,10 @@ def main():
             capi._check(L.palace_eref_table_reset(ctx.h), "reset")
             if timed: ctx.mark(m)
             # both FASTQ sides as one read set: one binning pass, the plane slices are loaded and stored once
-            capi._check(L.palace_eref_count_reads(ctx.h, P(sample["r12"]), P(sample["read_off"]), 2 * n_side, None, 2 * tot_b), "count")
+            if packed:
+                capi._check(L.palace_eref_count_reads_packed(ctx.h, *(P(t) for t in packed), 2 * tot_b, 2 * n_side), "count")
+            else:
+                capi._check(L.palace_eref_count_reads(ctx.h, P(sample["r12"]), P(sample["read_off"]), 2 * n_side, None, 2 * tot_b), "count")
             if timed: ctx.mark(m + 1)
             ctx.mark(4095)                             # "the counting kernels are done" (stage 04 waits for it, see below)
 
@@ -945,6 +964,8 @@ def main():
                                    f"{2 * sample['n_pairs_total']} reads x {READ_LEN} bp, {gs['n_total']} primary BAM records, "
                                    f"{gs['n_fastg']} FASTG links",
                        "stages": ["eref", "generateGraph", "matching"], "seed": SEED, "workload_kind": args.workload,
+                       "reads": ("packed in HBM: two bits per base + 32-mer start mask, 0.375 B/base (palace_eref_count_reads_packed)" if packed else
+                                 "ASCII in HBM, 1 B/base (palace_eref_count_reads)") + ("; count keeps only the '>= 3' plane (final_count)" if final_count else ""),
                        "parallelism": "1 GPU" if world == 1 else (f"reads/records/refs sharded over {world} GPUs (RCCL)" if shard_reads else
                                                                    f"records/refs sharded over {world} GPUs (RCCL), reads counted on every GPU"),
                        "ref_index": "per-DB probe index prebuilt, as the reference's cached <fasta>.k32.index.dat (8 B/position in HBM)",
@@ -956,7 +977,8 @@ def main():
                                                           "n_comp", "n_cycles", "n_multi")},
                        "stage04": "filter_graph.py's selection (seeds, 1- and 2-hop junctions, contigs.paths rescue) and matching -i 10 -l contigs.paths "
                                   "on the filtered graph, both on the device (palace_stage04_*), as palace:566-591 runs them on files"},
-            "roofline": {"bound": "hbm", "kernel": "eref count_reads (streams + bin1 + bin2 + lds_count kernels of one launch)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "eref count_reads_packed (bin1 + bin2 + lds_count kernels of one launch)" if packed else
+                                   "eref count_reads (streams + bin1 + bin2 + lds_count kernels of one launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # PMC (separate rocprofv3 passes, profiles/r01q_end_state_fused_launch.md): FETCH_SIZE x2 + WRITE_SIZE of
                          # bin1 + bin2 + lds_count per launch; only valid for the default workload on one GPU

@@ -109,6 +109,11 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
  * n_reads_hint: number of reads if known (picks the tile shape for short-read sets), else 0.  Same table, same
  * asynchrony as palace_eref_count_reads. */
 size_t palace_eref_packed_bytes(int64_t n_positions);
+/* The same three streams made on the device from a read set that is in HBM as ASCII (the arguments of
+ * palace_eref_count_reads; positions = bases, no gaps): for a caller that counts one read set more than once -- the streams
+ * do not depend on the coder, so one packing serves every DB -- or keeps its samples resident in the packed form. */
+int palace_eref_pack_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_reads,
+                           const uint8_t *d_keep, int64_t total_bases, uint32_t *d_p0, uint32_t *d_p1, uint32_t *d_u);
 int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const uint32_t *d_p1, const uint32_t *d_u,
                                    int64_t n_positions, int64_t n_reads_hint);
 
@@ -117,7 +122,14 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
  * atomics for tiny ones), 1 = always direct, 2 = always partitioned; bucket_cap > 0 overrides the per-bucket capacity
  * of the partitioned path (keys beyond it take the direct path).  set_option(name, value):
  *   "slab_bases"  positions per slab that large read sets are processed in (multiple of 64; 0 = default 2^30 / 2^31)
- *   "bin1_ppl"    read positions per lane of the first partition kernel (4, 5, 6 or 8; 0 = by key density) */
+ *   "bin1_ppl"    read positions per lane of the first partition kernel (4, 5, 6 or 8; 0 = by key density)
+ *   "final_count" 1: every count call from now on is the ONLY one between palace_eref_table_reset and the scan.  Phase B
+ *                 reads nothing but the "count >= 3" plane (the slide tests `== least_depth`, extract_ref.cpp:23, :531, of a count that
+ *                 saturates there, :995), so such a
+ *                 call keeps the two lower planes in LDS only: they are not written (1 GB less per call) and stay zero, and
+ *                 the next reset clears one plane instead of three.  Afterwards the table cannot take further counts,
+ *                 merges or lookups until it is reset (those calls fail); popcounts report 0, 0, n.  Applies to binned
+ *                 counts of one slab into a clean table, otherwise the call behaves as without the option.  0: off (default). */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap);
 int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value);
 

@@ -87,6 +87,7 @@ _SIGS = {
     "palace_eref_table_reset": [C.c_void_p],
     "palace_eref_reserve": [C.c_void_p, C.c_int64],
     "palace_eref_count_reads": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64],
+    "palace_eref_pack_reads": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
     "palace_eref_count_reads_packed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64],
     "palace_eref_set_count_mode": [C.c_void_p, C.c_int, C.c_int64],
     "palace_eref_set_option": [C.c_void_p, C.c_char_p, C.c_int64],
@@ -273,6 +274,10 @@ class Ctx:
                          total_bases: int = -1):
         _check(lib().palace_eref_count_reads(self.h, d_bases.ptr, d_offsets.ptr, n_reads,
                                              d_keep.ptr if d_keep else None, total_bases), "palace_eref_count_reads")
+
+    def eref_pack_reads(self, d_bases: DevBuf, d_offsets: DevBuf, n_reads: int, d_keep, total_bases: int, d_p0: DevBuf, d_p1: DevBuf, d_u: DevBuf):
+        _check(lib().palace_eref_pack_reads(self.h, d_bases.ptr, d_offsets.ptr, n_reads, d_keep.ptr if d_keep else None, total_bases,
+                                            d_p0.ptr, d_p1.ptr, d_u.ptr), "palace_eref_pack_reads")
 
     def eref_count_reads_packed(self, d_p0: DevBuf, d_p1: DevBuf, d_u: DevBuf, n_positions: int, n_reads_hint: int = 0):
         _check(lib().palace_eref_count_reads_packed(self.h, d_p0.ptr, d_p1.ptr, d_u.ptr, n_positions, n_reads_hint),

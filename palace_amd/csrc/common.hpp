@@ -64,6 +64,8 @@ struct palace_ctx {
     palace::CoderMasks masks{};
     uint32_t *plane[3] = {nullptr, nullptr, nullptr};
     bool planes_external = false;
+    bool want_final = false;        // option final_count: a count into a clean table may keep only the ">= 3" plane
+    bool final_only = false;        // ... and did: planes ">= 1" and ">= 2" are all zero, the table cannot take further counts
     bool table_clean = false;       // every plane bit is zero (set by reset, cleared by whatever writes the planes)
     int count_mode = 0;             // 0 auto, 1 direct atomics, 2 binned
     int64_t bin_cap_override = 0;

@@ -727,7 +727,10 @@ constexpr int kFineWords = kFine / 32;               // 2048 u32 per plane per f
 constexpr int kCountThreads = 256;
 // CLEAN: the planes were all zero when this launch began (first count after a reset), so a slice is only read when the
 // overflow path of the partition kernels has written into it (`touched`); otherwise it starts from zero in LDS.
-template <bool CLEAN>
+// FINAL (implies CLEAN): the caller reads nothing but the ">= 3" plane afterwards (Phase B does not) -- the two lower planes
+// are not written at all, and where the overflow path of the partition kernels put bits into them (touched buckets) they are
+// zeroed again: after the launch they are all zero, as after a reset.
+template <bool CLEAN, bool FINAL = false>
 __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const unsigned int *__restrict__ cursor,
                                                                        const uint16_t *__restrict__ binned,
                                                                        DensityCaps caps, uint32_t *__restrict__ p1,
@@ -748,8 +751,14 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
         first[x + 1] = first[x] + (n_sub[x] + 7) / 8;
     }
     const uint32_t n8 = first[kXcds];
-    if (n8 == 0) return;                                   // uniform for the whole workgroup
     const size_t w0 = static_cast<size_t>(b) * kFineWords;
+    if (n8 == 0) {                                         // uniform for the whole workgroup
+        if (FINAL && ((touched[b >> 5] >> (b & 31)) & 1u)) {       // only overflow keys: plane 3 is right as it is, the lower two go back to zero
+            uint4 *z1 = reinterpret_cast<uint4 *>(p1 + w0), *z2 = reinterpret_cast<uint4 *>(p2 + w0);
+            for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) z1[i] = z2[i] = uint4{0, 0, 0, 0};
+        }
+        return;
+    }
     const uint4 *g1 = reinterpret_cast<const uint4 *>(p1 + w0), *g2 = reinterpret_cast<const uint4 *>(p2 + w0),
                 *g3 = reinterpret_cast<const uint4 *>(p3 + w0);
     // (sub-regions start on 16-byte boundaries and their capacity is a multiple of 8 keys, so the last vector of one may run
@@ -810,8 +819,12 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
     uint4 *o1 = reinterpret_cast<uint4 *>(p1 + w0), *o2 = reinterpret_cast<uint4 *>(p2 + w0),
           *o3 = reinterpret_cast<uint4 *>(p3 + w0);
     for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) {
-        o1[i] = reinterpret_cast<const uint4 *>(l1)[i];
-        o2[i] = reinterpret_cast<const uint4 *>(l2)[i];
+        if (!FINAL) {
+            o1[i] = reinterpret_cast<const uint4 *>(l1)[i];
+            o2[i] = reinterpret_cast<const uint4 *>(l2)[i];
+        } else if (seed) {
+            o1[i] = o2[i] = uint4{0, 0, 0, 0};
+        }
         o3[i] = reinterpret_cast<const uint4 *>(l3)[i];
     }
 }
@@ -1471,8 +1484,10 @@ int palace_eref_table_reset(palace_ctx *ctx)
     int rc = ensure_table(ctx);
     if (rc) return rc;
     if (!fresh)
-        for (int p = 0; p < 3; p++) PALACE_HIP_TRY(hipMemsetAsync(ctx->plane[p], 0, kPlaneBytes, ctx->stream));
+        for (int p = ctx->final_only ? 2 : 0; p < 3; p++)       // (after a final count the two lower planes are zero already)
+            PALACE_HIP_TRY(hipMemsetAsync(ctx->plane[p], 0, kPlaneBytes, ctx->stream));
     ctx->table_clean = true;
+    ctx->final_only = false;
     return PALACE_OK;
 }
 
@@ -1551,6 +1566,33 @@ int palace_eref_reserve(palace_ctx *ctx, int64_t total_bases)
 
 }  // extern "C"
 
+// The read set as bit streams, once for the whole set: P0, P1, validity; read ends (and dropped reads) -> U.
+// ends / dropped: scratch of words_bytes each; strm[q]: (n_chunks + 2) 64-bit words each.
+static int build_streams(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_reads, const uint8_t *d_keep,
+                         int64_t total_bases, unsigned long long *ends, unsigned long long *dropped, unsigned long long *const strm[3],
+                         size_t words_bytes)
+{
+    const int64_t n_chunks = (total_bases + 63) / 64;
+    PALACE_HIP_TRY(hipMemsetAsync(ends, 0, words_bytes, ctx->stream));
+    if (d_keep) PALACE_HIP_TRY(hipMemsetAsync(dropped, 0, words_bytes, ctx->stream));
+    hipLaunchKernelGGL(mark_read_ends_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
+                       ctx->stream, d_offsets, n_reads, ends);
+    if (d_keep)
+        hipLaunchKernelGGL(mark_dropped_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
+                           ctx->stream, d_offsets, n_reads, d_keep, dropped);
+    PALACE_HIP_TRY(hipGetLastError());
+    for (int q = 0; q < 3; q++)                           // the last word of each stream may be partly written, and the
+        PALACE_HIP_TRY(hipMemsetAsync(strm[q] + n_chunks - 1, 0, 24, ctx->stream));   // two pad words behind it are read
+    const int64_t groups = (total_bases + 15) / 16, blocks = (groups + kStreamTile - 1) / kStreamTile;
+    PALACE_REQUIRE(blocks < (1ll << 31), "too many tiles for one launch");
+    hipLaunchKernelGGL(eref_streams_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d_bases,
+                       d_offsets, total_bases, reinterpret_cast<const uint16_t *>(ends),
+                       d_keep ? reinterpret_cast<const uint16_t *>(dropped) : nullptr, reinterpret_cast<uint16_t *>(strm[0]),
+                       reinterpret_cast<uint16_t *>(strm[1]), reinterpret_cast<uint16_t *>(strm[2]));
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
 // The read set as bit streams (P0, P1, U: see eref_streams_kernel) -> level-1 partition -> level-2 partition -> count in LDS,
 // slab by slab.  Shared by the ASCII entry (which builds the streams first) and the packed entry (whose caller did).
 static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const BinOut &o1, const Bin2Out &o2, const uint32_t *w0, const uint32_t *w1,
@@ -1590,7 +1632,11 @@ static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const BinOut &o1,
         for (uint32_t b = 0; b < kL1Buckets; b++) g2.first[b + 1] = g2.first[b] + tiles_of_bucket(caps1, b) * kL1Replicas;
         hipLaunchKernelGGL(eref_bin2_kernel, dim3(g2.first[kL1Buckets]), dim3(kBin2Threads), 0, ctx->stream, cursor1, buf1, caps1, g2, o2);
         PALACE_HIP_TRY(hipGetLastError());
-        if (clean)
+        if (clean && n_slabs == 1 && ctx->want_final) {
+            hipLaunchKernelGGL((eref_lds_count_kernel<true, true>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, cursor2, buf2, caps2,
+                               ctx->plane[0], ctx->plane[1], ctx->plane[2], touched);
+            ctx->final_only = true;
+        } else if (clean)
             hipLaunchKernelGGL(eref_lds_count_kernel<true>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, cursor2, buf2, caps2,
                                ctx->plane[0], ctx->plane[1], ctx->plane[2], touched);
         else
@@ -1611,6 +1657,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     if (!ctx->coder_set) { set_error("palace_eref_count_reads: coder not set"); return PALACE_ESTATE; }
     if (n_reads == 0) return PALACE_OK;
     PALACE_REQUIRE(d_bases && d_offsets, "null device pointer");
+    PALACE_REQUIRE(!ctx->final_only, "the table holds only its \">= 3\" plane (option final_count): reset it first");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
@@ -1639,7 +1686,6 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     CountPlan pl;
     rc = plan_count(ctx, total_bases, &pl);
     if (rc) return rc;
-    const int64_t n_chunks = pl.n_chunks;
     const DensityCaps caps1 = pl.caps1, caps2 = pl.caps2;
     const size_t cur1_bytes = pl.cur1_bytes, cur2_bytes = pl.cur2_bytes, buf1_bytes = pl.buf1_bytes, words_bytes = pl.words_bytes;
     rc = ensure_workspace(ctx, pl.total());
@@ -1656,25 +1702,8 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     uint16_t *buf2 = reinterpret_cast<uint16_t *>(ws);
     BinOut o1{cursor1, buf1, caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], touched};
     Bin2Out o2{cursor2, buf2, caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2], touched};
-    // the read set as bit streams, once for the whole set: P0, P1, P2, validity; read ends (and dropped reads) -> U
-    PALACE_HIP_TRY(hipMemsetAsync(ends, 0, (d_keep ? 2 : 1) * words_bytes, ctx->stream));
-    hipLaunchKernelGGL(mark_read_ends_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
-                       ctx->stream, d_offsets, n_reads, ends);
-    if (d_keep)
-        hipLaunchKernelGGL(mark_dropped_kernel, dim3(static_cast<unsigned>((n_reads + 255) / 256)), dim3(256), 0,
-                           ctx->stream, d_offsets, n_reads, d_keep, dropped);
-    PALACE_HIP_TRY(hipGetLastError());
-    for (int q = 0; q < 3; q++)                           // the last word of each stream may be partly written, and the
-        PALACE_HIP_TRY(hipMemsetAsync(strm[q] + n_chunks - 1, 0, 24, ctx->stream));   // two pad words behind it are read
-    {
-        const int64_t groups = (total_bases + 15) / 16, blocks = (groups + kStreamTile - 1) / kStreamTile;
-        PALACE_REQUIRE(blocks < (1ll << 31), "too many tiles for one launch");
-        hipLaunchKernelGGL(eref_streams_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d_bases,
-                           d_offsets, total_bases, reinterpret_cast<const uint16_t *>(ends),
-                           d_keep ? reinterpret_cast<const uint16_t *>(dropped) : nullptr, reinterpret_cast<uint16_t *>(strm[0]),
-                           reinterpret_cast<uint16_t *>(strm[1]), reinterpret_cast<uint16_t *>(strm[2]));
-        PALACE_HIP_TRY(hipGetLastError());
-    }
+    rc = build_streams(ctx, d_bases, d_offsets, n_reads, d_keep, total_bases, ends, dropped, strm, words_bytes);
+    if (rc) return rc;
     const double keys_per_pos = 3.0 * std::max(0.02, 1.0 - 31.0 * static_cast<double>(n_reads) / std::max<double>(1.0, static_cast<double>(total_bases)));
     return bin_and_count(ctx, pl, o1, o2, reinterpret_cast<const uint32_t *>(strm[0]), reinterpret_cast<const uint32_t *>(strm[1]),
                          reinterpret_cast<const uint32_t *>(strm[2]), total_bases, keys_per_pos);
@@ -1687,6 +1716,24 @@ size_t palace_eref_packed_bytes(int64_t n_positions)
     return n_positions < 0 ? 0 : (static_cast<size_t>((n_positions + 63) / 64) + 2) * 8;
 }
 
+int palace_eref_pack_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_reads, const uint8_t *d_keep,
+                           int64_t total_bases, uint32_t *d_p0, uint32_t *d_p1, uint32_t *d_u)
+{
+    PALACE_REQUIRE(ctx && n_reads >= 0 && total_bases >= 0, "bad argument");
+    if (n_reads == 0 || total_bases == 0) return PALACE_OK;
+    PALACE_REQUIRE(d_bases && d_offsets && d_p0 && d_p1 && d_u, "null device pointer");
+    PALACE_REQUIRE(((reinterpret_cast<uintptr_t>(d_p0) | reinterpret_cast<uintptr_t>(d_p1) | reinterpret_cast<uintptr_t>(d_u)) & 7) == 0,
+                   "the streams must be 8-byte aligned");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    const size_t words_bytes = align_up(palace_eref_packed_bytes(total_bases), 256);
+    int rc = ensure_workspace(ctx, 2 * words_bytes);
+    if (rc) return rc;
+    unsigned long long *ends = static_cast<unsigned long long *>(ctx->ws.ptr), *dropped = ends + words_bytes / 8;
+    unsigned long long *const strm[3] = {reinterpret_cast<unsigned long long *>(d_p0), reinterpret_cast<unsigned long long *>(d_p1),
+                                         reinterpret_cast<unsigned long long *>(d_u)};
+    return build_streams(ctx, d_bases, d_offsets, n_reads, d_keep, total_bases, ends, dropped, strm, words_bytes);
+}
+
 int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const uint32_t *d_p1, const uint32_t *d_u,
                                    int64_t n_positions, int64_t n_reads_hint)
 {
@@ -1696,6 +1743,7 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
     PALACE_REQUIRE(d_p0 && d_p1 && d_u, "null device pointer");
     PALACE_REQUIRE(((reinterpret_cast<uintptr_t>(d_p0) | reinterpret_cast<uintptr_t>(d_p1) | reinterpret_cast<uintptr_t>(d_u)) & 7) == 0,
                    "the streams must be 8-byte aligned");
+    PALACE_REQUIRE(!ctx->final_only, "the table holds only its \">= 3\" plane (option final_count): reset it first");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
@@ -1741,6 +1789,9 @@ int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value)
     if (!std::strcmp(name, "slab_bases")) {
         PALACE_REQUIRE(value >= 0 && value % 64 == 0, "slab size must be a non-negative multiple of 64");
         ctx->slab_override = value;
+    } else if (!std::strcmp(name, "final_count")) {          // the count calls that follow are each the only one between a reset and Phase B
+        PALACE_REQUIRE(value == 0 || value == 1, "final_count must be 0 or 1");
+        ctx->want_final = value != 0;
     } else if (!std::strcmp(name, "bin1_ppl")) {              // 0: by key density, else positions per lane of level 1 (4, 5, 6, 8)
         PALACE_REQUIRE(value == 0 || value == 4 || value == 5 || value == 6 || value == 8, "bin1_ppl must be 0, 4, 5, 6 or 8");
         ctx->bin1_ppl = static_cast<int>(value);
@@ -1992,6 +2043,7 @@ int palace_eref_table_attach(palace_ctx *ctx, void *const d_planes3[3])
     }
     ctx->planes_external = true;
     ctx->table_clean = false;                              // caller-owned memory: contents unknown
+    ctx->final_only = false;
     return PALACE_OK;
 }
 
@@ -1999,6 +2051,7 @@ int palace_eref_table_invalidate(palace_ctx *ctx)
 {
     PALACE_REQUIRE(ctx, "ctx is null");
     ctx->table_clean = false;
+    ctx->final_only = false;
     return PALACE_OK;
 }
 
@@ -2007,6 +2060,7 @@ static int merge_slices_impl(palace_ctx *ctx, const void *d_parts, int n_parts, 
     PALACE_REQUIRE(ctx && d_parts && n_parts > 0, "bad argument");
     PALACE_REQUIRE(slice_off % 16 == 0 && slice_bytes % 16 == 0 && slice_off + slice_bytes <= kPlaneBytes,
                    "slice must be 16-byte aligned and inside the plane");
+    PALACE_REQUIRE(!ctx->final_only, "the table holds only its \">= 3\" plane (option final_count): reset it first");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
@@ -2045,6 +2099,7 @@ int palace_eref_table_pack_low(palace_ctx *ctx, void *d_low)
 {
     PALACE_REQUIRE(ctx && d_low, "null argument");
     PALACE_REQUIRE(reinterpret_cast<uintptr_t>(d_low) % 16 == 0, "buffer must be 16-byte aligned");
+    PALACE_REQUIRE(!ctx->final_only, "the table holds only its \">= 3\" plane (option final_count): reset it first");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
@@ -2061,6 +2116,7 @@ int palace_eref_table_lookup(palace_ctx *ctx, const uint32_t *d_keys, int64_t n,
     PALACE_REQUIRE(ctx && n >= 0, "bad argument");
     if (n == 0) return PALACE_OK;
     PALACE_REQUIRE(d_keys && d_counts, "null device pointer");
+    PALACE_REQUIRE(!ctx->final_only, "the table holds only its \">= 3\" plane (option final_count): reset it first");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;

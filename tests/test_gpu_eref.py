@@ -531,3 +531,75 @@ def test_packed_entry_argument_checks(ctx):
         capi._check(capi.lib().palace_eref_count_reads_packed(ctx.h, None, d.ptr, d.ptr, 100, 0), "packed")
     d.free()
     assert capi.lib().palace_eref_packed_bytes(0) == 16 and capi.lib().palace_eref_packed_bytes(65) == 32
+
+
+@pytest.mark.parametrize("with_keep", [False, True])
+def test_pack_reads_on_the_device_equals_the_per_base_statement(ctx, with_keep):
+    """palace_eref_pack_reads: the streams the ASCII entry makes for itself, handed out -- bit-identical to the numpy statement
+    (U everywhere; P0 / P1 at every valid base)."""
+    rng = synth.rng_for(43)
+    genome = synth.random_dna(rng, 30000)
+    reads = [np.zeros(0, np.uint8), genome[:31], genome[:32], genome[50:83] | 0x20]
+    for _ in range(1500):
+        a, L = int(rng.integers(0, 29000)), int(rng.integers(1, 300))
+        s = genome[a:a + L].copy()
+        if rng.random() < 0.3:
+            s[int(rng.integers(0, len(s)))] = rng.choice(list(b"NnX.-"))
+        reads.append(s)
+    rs = synth.reads_from_list(reads)
+    keep = (rng.random(rs.n) < 0.5).astype(np.uint8) if with_keep else None
+    want, n_pos = pack_reads(rs.bases, rs.offsets, keep)
+    assert n_pos == len(rs.bases)
+    db, do = ctx.upload(rs.bases), ctx.upload(rs.offsets)
+    dk = ctx.upload(keep) if with_keep else None
+    out = [ctx.upload(np.full(len(want[0]), 0x5A, np.uint8)) for _ in range(3)]
+    ctx.eref_pack_reads(db, do, rs.n, dk, n_pos, out[0], out[1], out[2])
+    ctx.sync()
+    got = [np.unpackbits(o.to_host(), bitorder="little")[:n_pos] for o in out]
+    exp = [np.unpackbits(w, bitorder="little")[:n_pos] for w in want]
+    valid = np.isin(rs.bases & 0xDF, np.frombuffer(b"ACGT", np.uint8))
+    assert np.array_equal(got[2], exp[2])
+    assert np.array_equal(got[0][valid], exp[0][valid]) and np.array_equal(got[1][valid], exp[1][valid])
+    for b in [db, do] + out + ([dk] if dk else []):
+        b.free()
+
+
+@pytest.mark.parametrize("cap", [0, 64, 1])                                    # 64 / 1: most keys take the overflow path of the partition kernels
+def test_final_count_keeps_only_the_top_plane_and_leaves_the_others_zero(ctx, cap):
+    """option final_count (include/palace_hip.h): plane ">= 3" as without the option, the two lower planes all zero -- also
+    where overflow keys had written into them --, further counts / lookups refused until the reset, and the reset (which now
+    clears one plane only) gives a table that counts exactly again."""
+    rng = synth.rng_for(47)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    cc = orc.header_to_cc(hdr)
+    rs = synth.vector_reads(rng, synth.random_dna(rng, 40000), 4000, 120)      # ~12x coverage: many keys reach 3
+    u, c = oracle_key_counts(rs.bases, rs.offsets, cc)
+    top = u[c >= 3]
+    assert len(top) > 1000 and (c == 1).sum() > 100
+    db, do = ctx.upload(rs.bases), ctx.upload(rs.offsets)
+    try:
+        ctx.eref_set_count_mode(2, cap)
+        ctx.eref_set_option("final_count", 1)
+        ctx.eref_set_coder(hdr)
+        ctx.eref_table_reset()
+        ctx.eref_count_reads(db, do, rs.n)
+        assert ctx.eref_table_popcounts() == [0, 0, len(top)]
+        ptrs, nbytes = ctx.eref_table_planes()
+        plane3 = capi.DevBuf.__new__(capi.DevBuf)                               # a view of the context's plane, not owned
+        plane3.ctx, plane3.ptr, plane3.nbytes, plane3.dtype, plane3.shape = ctx, ptrs[2], nbytes, np.dtype(np.uint32), (nbytes // 4,)
+        words = plane3.to_host()
+        assert np.all((words[top >> 5] >> (top & 31)) & 1)                      # popcount equal + every expected bit set = the same set
+        with pytest.raises(capi.PalaceError):
+            ctx.eref_count_reads(db, do, rs.n)
+        with pytest.raises(capi.PalaceError):
+            ctx.eref_table_lookup(u[:10])
+        ctx.eref_set_option("final_count", 0)
+        ctx.eref_table_reset()                                                  # clears plane 3 only
+        ctx.eref_count_reads(db, do, rs.n)
+        ctx.sync()
+        assert_table_equals(ctx, u, c)
+    finally:
+        ctx.eref_set_option("final_count", 0)
+        ctx.eref_set_count_mode(0, 0)
+        ctx.eref_table_reset()
+        db.free(); do.free()

@@ -6,6 +6,12 @@ import csv
 import sys
 
 
+def short(name):
+    """kernel name without its parameter list; kernels of an unnamed namespace keep their own name"""
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+
+
+
 def main():
     out, args = sys.argv[1], sys.argv[2:]
     lines = []
@@ -19,7 +25,7 @@ def main():
             rows = list(csv.DictReader(open(args[i + 1])))
             keep = [r for r in rows if "palace::" in r["Name"]] + [r for r in rows if "palace::" not in r["Name"]][:4]
             for r in keep:
-                nm = r["Name"].split("(")[0].replace("void ", "")[:70]
+                nm = short(r["Name"])[:70]
                 lines.append(f"| {nm} | {r['Calls']} | {float(r['AverageNs'])/1e6:.4f} | "
                              f"{float(r['TotalDurationNs'])/1e6:.3f} | {float(r['Percentage']):.2f} |")
             lines.append("")
@@ -29,7 +35,7 @@ def main():
             import statistics
             dur = collections.defaultdict(list)
             for r in csv.DictReader(open(args[i + 1])):
-                dur[r["Kernel_Name"].split("(")[0].replace("void ", "")[:70]].append(
+                dur[short(r["Kernel_Name"])[:70]].append(
                     (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
             lines.append("## rocprofv3 --kernel-trace: per-kernel duration (palace kernels)\n")
             lines.append("| kernel | calls | median ms | mean ms | max ms |\n|---|---|---|---|---|")
@@ -42,7 +48,7 @@ def main():
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(path)):
                 if r["Counter_Name"] == name and "palace::" in r["Kernel_Name"]:
-                    agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+                    agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
             lines.append(f"## rocprofv3 --pmc {name} (own pass; per-dispatch mean, counter unit = KiB)\n")
             lines.append("| kernel | dispatches | mean value (KiB) | mean GB |\n|---|---|---|---|")
             for k, v in agg.items():
