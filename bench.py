@@ -782,7 +782,7 @@ def main():
         ctx.sync()
     # one GPU (and N GPUs that each count all reads): the count of a step is the only one between its reset and its scan, so the
     # two lower planes of the table need not leave the LDS (include/palace_hip.h, option final_count)
-    final_count = not shard_reads
+    final_count = not shard_reads and os.environ.get("PALACE_BENCH_FINAL", "1") == "1"      # (=0: A/B runs)
     ctx.eref_set_option("final_count", 1 if final_count else 0)
 
     def step(i, timed):

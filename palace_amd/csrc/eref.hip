@@ -643,6 +643,7 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
     }
     if (threadIdx.x < kL2Rows)
         st.rows[threadIdx.x] = (static_cast<unsigned long long>((threadIdx.x + 1) * kRowSlots) << 32) | (threadIdx.x * kRowSlots);
+    const uint32_t cap = fine_sub_cap(o.caps, b1), xcd = xcc_id();          // this XCD's share of every fine region
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < kGroups2PerThread; it++) {
@@ -657,7 +658,16 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
             if (e < n) {
                 const uint32_t at = static_cast<uint32_t>(r[e]);
                 if (at < static_cast<uint32_t>(r[e] >> 32)) st.slot[at] = static_cast<uint16_t>(k[e]);
-                else count_key_marked((b1 << kL1Shift) | k[e], o.p1, o.p2, o.p3, o.touched);   // row full: exact slow path
+                else {
+                    // Row full (a row holds 72 of the tile's keys, mean 50: about one key in a thousand): the key goes to its
+                    // fine region as a run of its own.  It used to take the direct-atomic path, which marks the fine bucket
+                    // `touched` -- and with ~50 000 such keys per launch 38 % of the 65 536 count workgroups then began by
+                    // seeding their 24 KiB of plane slices from HBM (0.6 GB per launch, PMC) for the sake of one or two keys.
+                    const uint32_t row = k[e] >> kFineBits;
+                    const uint32_t gg = atomicAdd(&o.cursor[(b1 * kL2Rows + row) * kXcds + xcd], 1u);
+                    if (gg < cap) o.buf[fine_region_base(o.caps, b1, row) + static_cast<uint64_t>(xcd) * cap + gg] = static_cast<uint16_t>(k[e]);
+                    else count_key_marked((b1 << kL1Shift) | k[e], o.p1, o.p2, o.p3, o.touched);   // region full as well: exact slow path
+                }
             }
     }
     __syncthreads();
@@ -666,7 +676,6 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
     constexpr int rows_per_wave = kL2Rows / (kBin2Threads / 64);
     const int lane = threadIdx.x & 63;
     const int row0 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) * rows_per_wave;
-    const uint32_t cap = fine_sub_cap(o.caps, b1), xcd = xcc_id();          // this XCD's share of every fine region
     uint32_t c = 0, g = 0, p_lo = 0, p_hi = 0;
     bool over = false;
     if (lane < rows_per_wave) {
