@@ -434,7 +434,11 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
 {
     constexpr int kMaxKeys = THREADS * P * 3 + kL1Buckets * (kGroupKeys - 1);    // every key of the tile + the pad slots of every row
     __shared__ __attribute__((aligned(16))) uint32_t tile[kMaxKeys];
-    __shared__ uint32_t hist[kL1Buckets], start[kL1Buckets + 1], room[kL1Buckets];
+    __shared__ uint32_t hist[kL1Buckets], room[kL1Buckets];
+    __shared__ uint16_t start[kL1Buckets + 2];           // (16 bits: with 32 the P = 6 tile is 40 976 bytes, 16 more than a quarter of the CU's LDS)
+    static_assert(kMaxKeys < 65536, "row starts are kept in 16 bits");
+    static_assert(P != 6 || THREADS != 512 || sizeof(uint32_t) * (kMaxKeys + 3 * kL1Buckets + 1) + sizeof(uint16_t) * (kL1Buckets + 2) <= 160 * 1024 / 4,
+                  "the 6-position tile must fit four times into the LDS of a CU");
     __shared__ uint32_t dst[kL1Buckets];                 // group index in o.buf of the row's first group minus the row's first group in the
                                                          // tile, modulo 2^32 (row starts are multiples of 5 slots; a slab's regions hold < 2^32 groups)
     __shared__ uint32_t any_partial;                     // some run of this tile did not fit its region whole (rare): check `room`
@@ -774,11 +778,16 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
     // past its count but not past the sub-region); the first batch of key loads is issued together with the seeds
     const uint4 *keys = reinterpret_cast<const uint4 *>(binned + fine_region_base(caps, b1, b % kL2Rows));
     auto locate = [&](uint32_t j, uint32_t &valid) -> const uint4 * {      // vector j and how many of its 8 keys count
-        uint32_t x = 0;
+        // first[x] and n_sub[x] by multiply-adds over the eight (uniform) entries: indexed with x, or picked by a chain of
+        // selects, the compiler puts the arrays into scratch memory and every vector's address waits for two scratch loads
+        uint32_t x = 0, f = 0, ns = n_sub[0];
 #pragma unroll
-        for (int k = 1; k < kXcds; k++) x += j >= first[k];
-        const uint32_t local = j - first[x];
-        valid = min(8u, n_sub[x] - 8 * local);
+        for (int k = 1; k < kXcds; k++) {
+            const uint32_t ge = j >= first[k] ? 1u : 0u;
+            x += ge; f += ge * (first[k] - first[k - 1]); ns += ge * (n_sub[k] - n_sub[k - 1]);
+        }
+        const uint32_t local = j - f;
+        valid = min(8u, ns - 8 * local);
         return keys + (static_cast<size_t>(x) * sub_cap) / 8 + local;
     };
     constexpr int kBatch = 4;
@@ -791,11 +800,17 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
         if (i < n8) v[u] = *locate(i, ok[u]);
     }
     const bool seed = !CLEAN || ((touched[b >> 5] >> (b & 31)) & 1u);      // uniform for the workgroup
-    for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) {
-        const uint4 z{0, 0, 0, 0};
-        reinterpret_cast<uint4 *>(l1)[i] = seed ? g1[i] : z;
-        reinterpret_cast<uint4 *>(l2)[i] = seed ? g2[i] : z;
-        reinterpret_cast<uint4 *>(l3)[i] = seed ? g3[i] : z;
+    // (two loops, not `seed ? g[i] : zero` in one: for that the compiler selects between the global ADDRESS and the address of
+    // a zero it keeps in scratch memory, and the clean case pays three flat loads per lane and round all the same)
+    if (seed) {
+        for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) {
+            reinterpret_cast<uint4 *>(l1)[i] = g1[i];
+            reinterpret_cast<uint4 *>(l2)[i] = g2[i];
+            reinterpret_cast<uint4 *>(l3)[i] = g3[i];
+        }
+    } else {
+        for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads)
+            reinterpret_cast<uint4 *>(l1)[i] = reinterpret_cast<uint4 *>(l2)[i] = reinterpret_cast<uint4 *>(l3)[i] = uint4{0, 0, 0, 0};
     }
     __syncthreads();
     auto apply = [&](uint32_t k) {
