@@ -777,6 +777,7 @@ def main():
     if args.reads == "packed":
         nb = int(L.palace_eref_packed_bytes(2 * n_side * READ_LEN))
         packed = [torch.zeros(nb, dtype=torch.uint8, device=dev) for _ in range(3)]
+        torch.cuda.synchronize()                     # torch fills them on ITS stream; the library writes them on the context's
         capi._check(L.palace_eref_pack_reads(ctx.h, P(sample["r12"]), P(sample["read_off"]), 2 * n_side, None, 2 * n_side * READ_LEN,
                                              *(P(t) for t in packed)), "pack")
         ctx.sync()
@@ -912,6 +913,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    torch.cuda.synchronize()                         # every buffer torch made above is filled before a library stream touches it
     for _ in range(args.warmup):
         step(0, False)
     barrier()
