@@ -1109,11 +1109,14 @@ __global__ __launch_bounds__(1024) void eref_bucket_prefix_kernel(const unsigned
     if (threadIdx.x == 1023) first[kBuckets] = run;
 }
 
-// one workgroup per fine bucket: its slice of plane 3 in LDS, its positions tested against it
-__global__ __launch_bounds__(1024) void eref_probe_kernel(const unsigned long long *__restrict__ first,
-                                                          const unsigned long long *__restrict__ entries,
-                                                          const uint32_t *__restrict__ p3,
-                                                          unsigned long long *__restrict__ hit_words)
+// one workgroup per fine bucket: its slice of plane 3 in LDS, its positions tested against it.
+// 512 threads (four workgroups per CU by LDS and by waves; with 1024 there were two, each alone with its load latency between
+// its batches), the next batch of entry loads always in flight while the current one is tested.
+constexpr int kProbeThreads = 512;
+__global__ __launch_bounds__(kProbeThreads) void eref_probe_kernel(const unsigned long long *__restrict__ first,
+                                                                   const unsigned long long *__restrict__ entries,
+                                                                   const uint32_t *__restrict__ p3,
+                                                                   uint8_t *__restrict__ hit_bytes)
 {
     __shared__ uint32_t l3[kSliceWords];
     const uint32_t b = blockIdx.x;
@@ -1124,42 +1127,52 @@ __global__ __launch_bounds__(1024) void eref_probe_kernel(const unsigned long lo
     const unsigned long long lo = e0 & ~1ull, hi = e0 + n;            // entries [lo, hi) are loaded, [e0, hi) tested
     const unsigned long long n2 = (hi - lo + 1) / 2;                  // pairs (the array is padded by one entry: see the builder)
     const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(entries + lo);
-    constexpr int kFirst = 8;                              // pair loads in flight per thread ahead of the slice
-    ulonglong2 e[kFirst];
+    constexpr int kBatch = 4;                              // pair loads per thread and batch
+    constexpr unsigned long long kStride = static_cast<unsigned long long>(kBatch) * kProbeThreads;
+    ulonglong2 cur[kBatch];
 #pragma unroll
-    for (int u = 0; u < kFirst; u++) {
-        const unsigned long long i = threadIdx.x + static_cast<unsigned long long>(u) * blockDim.x;
-        e[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
+    for (int u = 0; u < kBatch; u++) {
+        const unsigned long long i = threadIdx.x + static_cast<unsigned long long>(u) * kProbeThreads;
+        cur[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
     }
     const uint4 *g3 = reinterpret_cast<const uint4 *>(p3 + static_cast<size_t>(b) * kSliceWords);
-    for (int i = threadIdx.x; i < kSliceWords / 4; i += blockDim.x) reinterpret_cast<uint4 *>(l3)[i] = g3[i];
+    for (int i = threadIdx.x; i < kSliceWords / 4; i += kProbeThreads) reinterpret_cast<uint4 *>(l3)[i] = g3[i];
     __syncthreads();
     auto test = [&](unsigned long long ent, unsigned long long at) {  // at: global index of the entry
         if (at < e0 || at >= hi) return;
         const uint32_t k = static_cast<uint32_t>(ent) & ((1u << kBucketShift) - 1);
-        if ((l3[k >> 5] >> (k & 31)) & 1u) {
-            const unsigned long long pos = ent >> kBucketShift;
-            atomicOr(&hit_words[pos >> 6], 1ull << (pos & 63));
-        }
+        // a hit is a BYTE store, not an atomicOr into the bit array: the ~8 M hits of a step are random over 200 M positions, and
+        // as 64-bit atomics they were 0.6 ms of this kernel's 1.04 (measured by leaving them out); eref_hits_to_bits_kernel packs
+        // the bytes afterwards
+        if ((l3[k >> 5] >> (k & 31)) & 1u) hit_bytes[ent >> kBucketShift] = 1;
     };
+    for (unsigned long long i0 = threadIdx.x; i0 < n2; i0 += kStride) {
+        ulonglong2 nxt[kBatch];
 #pragma unroll
-    for (int u = 0; u < kFirst; u++) {
-        const unsigned long long i = threadIdx.x + static_cast<unsigned long long>(u) * blockDim.x;
-        if (i < n2) { test(e[u].x, lo + 2 * i); test(e[u].y, lo + 2 * i + 1); }
+        for (int u = 0; u < kBatch; u++) {
+            const unsigned long long i = i0 + kStride + static_cast<unsigned long long>(u) * kProbeThreads;
+            nxt[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            const unsigned long long i = i0 + static_cast<unsigned long long>(u) * kProbeThreads;
+            if (i < n2) { test(cur[u].x, lo + 2 * i); test(cur[u].y, lo + 2 * i + 1); }
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) cur[u] = nxt[u];
     }
-    constexpr int kBatch = 4;                              // the rest (buckets of more than 16384 entries), four loads at a time
-    for (unsigned long long i0 = threadIdx.x + static_cast<unsigned long long>(kFirst) * blockDim.x; i0 < n2; i0 += kBatch * blockDim.x) {
-        ulonglong2 r[kBatch];
-#pragma unroll
-        for (int u = 0; u < kBatch; u++) {
-            const unsigned long long i = i0 + u * blockDim.x;
-            r[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; u++) {
-            const unsigned long long i = i0 + u * blockDim.x;
-            if (i < n2) { test(r[u].x, lo + 2 * i); test(r[u].y, lo + 2 * i + 1); }
-        }
+}
+
+// hit bytes of the probe kernel -> the bit words everything downstream reads: a lane packs 16 positions (bit 0 of each byte
+// gathered by a multiply, 8 at a time) into a 16-bit piece of the word array
+__global__ __launch_bounds__(256) void eref_hits_to_bits_kernel(const uint4 *__restrict__ hit_bytes, int64_t n16, uint16_t *__restrict__ words16)
+{
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const uint4 v = hit_bytes[i];
+        const unsigned long long a = v.x | (static_cast<unsigned long long>(v.y) << 32), b = v.z | (static_cast<unsigned long long>(v.w) << 32);
+        const unsigned long long m = 0x0101010101010101ull, g = 0x0102040810204080ull;
+        words16[i] = static_cast<uint16_t>((((a & m) * g) >> 56) | ((((b & m) * g) >> 56) << 8));
     }
 }
 
@@ -1882,10 +1895,11 @@ struct ScanBuffers {
     uint64_t *any_w, *all_w, *good_w;
     uint32_t *any_p, *all_p;
     uint8_t *need, *active;                 // per chunk / per ref flags of eref_need_kernel
+    uint8_t *hit_bytes;                     // indexed scan: a byte per position (64 per word of any_w), see eref_probe_kernel
     int64_t max_tiles, max_words;
 };
 
-int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int64_t total_bases, ScanBuffers *b)
+int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int64_t total_bases, ScanBuffers *b, bool with_hit_bytes = false)
 {
     b->max_tiles = total_bases / kTilePos + n_refs;
     b->max_words = total_bases / 64 + n_refs + 1;
@@ -1893,7 +1907,8 @@ int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int6
     const size_t pre_bytes = align_up((n_refs + 1) * 8, 256);
     const size_t w64 = align_up(b->max_words * 8, 256), w32 = align_up(b->max_words * 4, 256);
     const size_t w8 = align_up(b->max_words, 256);
-    int rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32 + w8 + align_up(n_refs + 1, 256));
+    const size_t hb = with_hit_bytes ? align_up(static_cast<size_t>(b->max_words) * 64, 256) : 0;
+    int rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32 + w8 + align_up(n_refs + 1, 256) + hb);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
     b->tile_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
@@ -1904,7 +1919,8 @@ int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int6
     b->any_p = reinterpret_cast<uint32_t *>(ws); ws += w32;
     b->all_p = reinterpret_cast<uint32_t *>(ws); ws += w32;
     b->need = reinterpret_cast<uint8_t *>(ws); ws += w8;
-    b->active = reinterpret_cast<uint8_t *>(ws);
+    b->active = reinterpret_cast<uint8_t *>(ws); ws += align_up(n_refs + 1, 256);
+    b->hit_bytes = with_hit_bytes ? reinterpret_cast<uint8_t *>(ws) : nullptr;
     return launch_prefix(ctx, d_offsets, n_refs, b->tile_pre, b->word_pre);
 }
 
@@ -2034,11 +2050,13 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     rc = ensure_table(ctx);
     if (rc) return rc;
     ScanBuffers b;
-    rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b);
+    rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b, true);
     if (rc) return rc;
-    PALACE_HIP_TRY(hipMemsetAsync(b.any_w, 0, static_cast<size_t>(b.max_words) * 8, ctx->stream));
-    hipLaunchKernelGGL(eref_probe_kernel, dim3(kBuckets), dim3(1024), 0, ctx->stream, ix->first, ix->entries, ctx->plane[2],
-                       reinterpret_cast<unsigned long long *>(b.any_w));
+    PALACE_HIP_TRY(hipMemsetAsync(b.hit_bytes, 0, static_cast<size_t>(b.max_words) * 64, ctx->stream));
+    hipLaunchKernelGGL(eref_probe_kernel, dim3(kBuckets), dim3(kProbeThreads), 0, ctx->stream, ix->first, ix->entries, ctx->plane[2], b.hit_bytes);
+    PALACE_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(eref_hits_to_bits_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(b.hit_bytes),
+                       b.max_words * 4, reinterpret_cast<uint16_t *>(b.any_w));
     PALACE_HIP_TRY(hipGetLastError());
     return scan_tail(ctx, b, d_bases, d_offsets, n_refs, one_min, three_min, d_rows);
 }

@@ -1,4 +1,5 @@
 #include "bam.hpp"
+#include "trace.hpp"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -337,6 +338,7 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
 {
     std::unique_ptr<BamLoad> L(load);
     BamColumns &c = *L->c;
+    Trace tr("bam");
     const int32_t n_ref = L->n_ref;
     int threads = L->threads;
     const uint8_t *d = c.raw.data();
@@ -357,7 +359,9 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
         rec_at.push_back(p + 4);
         p += 4 + bs;
     }
+    tr.lap("record boundaries (behind the inflate front)");
     for (auto &t : L->workers) t.join();                          // (members behind a malformed record are still inflated)
+    tr.lap("inflate threads joined");
     if (L->bad) throw std::runtime_error("BGZF inflate failed");
     L->file.reset();
     const size_t n = rec_at.size();
@@ -469,6 +473,7 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
             }
         }
     });
+    tr.lap("columns decoded");
     for (size_t i = 0; i < n; i++) c.sa_off[i + 1] = c.sa_off[i] + sa_cnt[i];
     c.sa.clear();
     c.sa.reserve(static_cast<size_t>(c.sa_off[n]) + 1);
@@ -478,6 +483,7 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
     c.mseg_tid.reserve(n_ms); c.mseg_pos.reserve(n_ms); c.mseg_len.reserve(n_ms);
     for (auto &part : ms_part)
         for (size_t k = 0; k + 2 < part.size(); k += 3) { c.mseg_tid.push_back(part[k]); c.mseg_pos.push_back(part[k + 1]); c.mseg_len.push_back(part[k + 2]); }
+    tr.lap("SA items + match segments joined");
 }
 
 }  // namespace palace_host

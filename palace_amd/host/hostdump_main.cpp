@@ -1,6 +1,7 @@
 // hostdump -- prints what the host-side parsers hand to the GPU, as text (no GPU needed).
 // Test tool for the CPU test suite:
 //   hostdump bam   <file.bam>          header + one line per record (decoded columns + parsed SA items)
+//   hostdump bamtime <file.bam> <threads>   load only, prints the record count (PALACE_TRACE=1: laps of the loader)
 //   hostdump fastq <file.fq> <threads> [part_bytes]  one line per sequence line
 //   hostdump fastqpack <file.fq> <threads> <part_bytes> [keep_every]   the packed form of the sequence lines (pack_fastq_part):
 //                                      one line per part "pos0 n_words n_reads", then its words of P0, P1, U (hex, one line per stream);
@@ -34,6 +35,10 @@ int main(int argc, char **argv)
                 }
                 std::printf("\n");
             }
+        } else if (mode == "bamtime") {
+            BamColumns c;
+            load_bam(argv[2], argc > 3 ? std::atoi(argv[3]) : 4, 1, c);
+            std::printf("%lld records, %zu SA items, %zu match segments\n", (long long)c.n(), c.sa.size(), c.mseg_tid.size());
         } else if (mode == "fastq") {
             // the executable's own ingest path: mapped file, parts, two passes (fastx.hpp); optional 4th argument =
             // part size in bytes, so that tests can force many parts on a small file
