@@ -1,4 +1,5 @@
 #include "bam.hpp"
+#include "inflate_fast.hpp"
 #include "trace.hpp"
 
 #include <fcntl.h>
@@ -258,9 +259,12 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c)
             z_stream zs{};
             if (inflateInit2(&zs, -15) != Z_OK) { ld->bad = true; return; }
             uint8_t *out = ld->c->raw.data();
+            const bool use_fast = std::getenv("PALACE_BAM_ZLIB") == nullptr;          // PALACE_BAM_ZLIB=1: zlib for every member (A/B, tests)
             for (size_t i = static_cast<size_t>(t); i < nb && !ld->bad; i += static_cast<size_t>(threads)) {
                 const Block &k = ld->blocks[i];
-                if (k.out_len) {
+                // the member decoder written for this loader first (inflate_fast.hpp); whatever it does not take, zlib decides
+                if (k.out_len && !(use_fast && inflate_fast(ld->file->data + k.in_off, k.in_len, ld->file->size - (k.in_off + k.in_len),
+                                                            out + k.out_off, k.out_len))) {
                     if (inflateReset(&zs) != Z_OK) { ld->bad = true; break; }
                     zs.next_in = const_cast<Bytef *>(ld->file->data + k.in_off);
                     zs.avail_in = static_cast<uInt>(k.in_len);

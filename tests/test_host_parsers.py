@@ -261,3 +261,30 @@ def test_packed_fastq_parts_equal_the_per_base_statement(tmp_path):
             r += n_reads
             i += 4
         assert r == len(seqs)
+
+
+def test_own_inflate_agrees_with_zlib_or_refuses():
+    """host/inflate_fast.hpp, the loader's DEFLATE decoder: ~22 000 streams (every zlib strategy / level, multi-block, stored,
+    fixed and dynamic codes, truncated, bit-flipped, noise) -- it either refuses (the loader then asks zlib) or gives zlib's
+    bytes, never writes outside its output; and a BAM loads to the same columns through either."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "palace_amd", "host"), os.path.join("..", "bin", "inflate_selftest")], check=True,
+                   stdout=subprocess.DEVNULL)
+    p = subprocess.run([os.path.join(ROOT, "palace_amd", "bin", "inflate_selftest")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and p.stdout.startswith(b"ok "), p.stderr
+    assert int(p.stdout.split()[4]) > 5000                          # ... and it does decode the valid ones itself ("ok N streams checked, M decoded ...")
+
+
+def test_bam_loads_the_same_through_own_inflate_and_zlib(tmp_path):
+    rng = synth.rng_for(5)
+    targets = [("c%d" % i, 3000 + 17 * i) for i in range(40)]
+    recs = []
+    for i in range(6000):
+        t = int(rng.integers(0, 40))
+        recs.append(synth.BamRecord("q%d" % (i // 2), 99 if i % 2 == 0 else 147, t, int(rng.integers(0, 2800)), 60, "100M",
+                                    mtid=t, mpos=int(rng.integers(0, 2800)), nm=int(rng.integers(0, 4)),
+                                    sa="c%d,%d,+,60S40M,60,1;" % (int(rng.integers(0, 40)), int(rng.integers(1, 2000))) if i % 7 == 0 else None))
+    bam = str(tmp_path / "t.bam")
+    synth.write_bam(bam, targets, recs, block=20000)
+    a = dump("bam", bam, "4")
+    p = subprocess.run([HOSTDUMP, "bam", bam, "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, PALACE_BAM_ZLIB="1"))
+    assert p.returncode == 0 and p.stdout == a and a.count(b"\n") == 40 + 6000
