@@ -369,15 +369,17 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
     if (L->bad) throw std::runtime_error("BGZF inflate failed");
     L->file.reset();
     const size_t n = rec_at.size();
+    // (not zero-filled: every element is written below, by the thread that owns its record)
     for (auto *v : {&c.tid, &c.pos, &c.mtid, &c.mpos, &c.nm, &c.ref_len, &c.read_len, &c.clip_s, &c.clip_e})
-        v->assign(n, 0);
-    c.sa_off.assign(n + 1, 0);
-    c.flag.assign(n, 0); c.mapq.assign(n, 0); c.qkey.assign(n, 0);
-    c.qname_at.assign(n, 0); c.qname_len.assign(n, 0);
+        v->resize(n);
+    c.sa_off.resize(n + 1);
+    c.sa_off[0] = 0;
+    c.flag.resize(n); c.mapq.resize(n); c.qkey.resize(n);
+    c.qname_at.resize(n); c.qname_len.resize(n);
     threads = std::max(1, threads);
     std::vector<std::vector<palace_sa_item>> sa_part(static_cast<size_t>(threads));
     std::vector<std::vector<int32_t>> ms_part(static_cast<size_t>(threads));        // (tid, pos, len) triples
-    std::vector<int32_t> sa_cnt(n, 0);
+    Column<int32_t> sa_cnt(n);
     parallel_for(n, threads, [&](size_t a, size_t b, int t) {
         static const char opchr[] = "MIDNSHP=XB??????";
         for (size_t i = a; i < b; i++) {
@@ -385,6 +387,8 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
             const uint8_t *end = r + le32(r - 4);
             const int32_t tid = static_cast<int32_t>(le32(r));
             c.tid[i] = tid;
+            c.nm[i] = 0;
+            sa_cnt[i] = 0;
             c.pos[i] = static_cast<int32_t>(le32(r + 4));
             const size_t l_name = r[8];
             c.mapq[i] = r[9];

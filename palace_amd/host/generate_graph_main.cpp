@@ -63,8 +63,8 @@ void usage(const char *prog)            // same option surface as generate_graph
         }                                                                               \
     } while (0)
 
-template <class T>
-int upload(palace_ctx *ctx, const std::vector<T> &v, T **d)
+template <class T, class A>
+int upload(palace_ctx *ctx, const std::vector<T, A> &v, T **d)
 {
     void *p = nullptr;
     int rc = palace_malloc(ctx, std::max<size_t>(1, v.size()) * sizeof(T), &p);
