@@ -351,26 +351,41 @@ int main(int argc, char **argv)
         CK(palace_h2d(ctx, d_qkey, c.qkey.data(), c.qkey.size() * 8));
     }
     tr.lap("classify + name guard");
-    // The inflated stream (gigabytes) has served: read names were its last users.  Giving the pages back takes the kernel a few
-    // hundred milliseconds -- at process exit that is wall time the driver waits for, here it runs beside the rest of the work.
-    // Not with one munmap, though: that holds the address-space lock against every allocation of the other threads for its
-    // whole duration.  The pages go back piece by piece (MADV_DONTNEED takes the lock shared, and briefly); the empty mapping
+    // The inflated stream (gigabytes) and the per-record columns (350 MB at 6.7 M records) have served: read names were their
+    // last users.  Giving the pages back takes the kernel a few hundred milliseconds -- at process exit that is wall time the
+    // driver waits for (measured: 15 to 250 ms after the last output byte, depending on how far a single helper had come);
+    // here it runs beside the rest of the work, on four helpers.  Not with one munmap of the stream, though: that holds the
+    // address-space lock against every allocation of the other threads for its whole duration ("resolve + d2h" took 220 ms
+    // instead of 9).  The pages go back piece by piece (MADV_DONTNEED takes the lock shared, and briefly); the empty mapping
     // itself stays until exit.
+    const int64_t n_records = c.n();
     {
         uint8_t *raw = c.raw.p.release();
         const size_t raw_n = c.raw.n;
-        std::thread([raw, raw_n] {
-            const uintptr_t page = 4096, piece = 32u << 20;
-            uintptr_t a = (reinterpret_cast<uintptr_t>(raw) + page - 1) / page * page, e = (reinterpret_cast<uintptr_t>(raw) + raw_n) / page * page;
-            for (; a < e; a += piece) ::madvise(reinterpret_cast<void *>(a), std::min<uintptr_t>(piece, e - a), MADV_DONTNEED);
-        }).detach();
+        constexpr int kHelpers = 4;
+        const uintptr_t page = 4096, piece = 32u << 20;
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(raw) + page - 1) / page * page, hi = (reinterpret_cast<uintptr_t>(raw) + raw_n) / page * page;
+        for (int h = 0; h < kHelpers && hi > lo; h++) {
+            const uintptr_t a0 = lo + (hi - lo) / page * static_cast<uintptr_t>(h) / kHelpers * page,
+                            a1 = h + 1 == kHelpers ? hi : lo + (hi - lo) / page * static_cast<uintptr_t>(h + 1) / kHelpers * page;
+            std::thread([a0, a1, piece] {
+                for (uintptr_t a = a0; a < a1; a += piece) ::madvise(reinterpret_cast<void *>(a), std::min<uintptr_t>(piece, a1 - a), MADV_DONTNEED);
+            }).detach();
+        }
+        auto *dead = new BamColumns;                                   // the columns the device has taken over
+        std::swap(dead->tid, c.tid); std::swap(dead->pos, c.pos); std::swap(dead->mtid, c.mtid); std::swap(dead->mpos, c.mpos);
+        std::swap(dead->nm, c.nm); std::swap(dead->ref_len, c.ref_len); std::swap(dead->read_len, c.read_len); std::swap(dead->clip_s, c.clip_s);
+        std::swap(dead->clip_e, c.clip_e); std::swap(dead->sa_off, c.sa_off); std::swap(dead->flag, c.flag); std::swap(dead->mapq, c.mapq);
+        std::swap(dead->qkey, c.qkey); std::swap(dead->qname_at, c.qname_at); std::swap(dead->qname_len, c.qname_len); std::swap(dead->sa, c.sa);
+        std::swap(dead->mseg_tid, c.mseg_tid); std::swap(dead->mseg_pos, c.mseg_pos); std::swap(dead->mseg_len, c.mseg_len);
+        std::thread([dead] { delete dead; }).detach();
     }
     c.raw.n = 0;
     CK(palace_malloc(ctx, static_cast<size_t>(std::max<int64_t>(1, n_cands)) * sizeof(palace_graph_edge), &p));
     palace_graph_edge *d_edges = static_cast<palace_graph_edge *>(p);
     int64_t n_edges = 0;
     tr.lap("edge buffer");
-    CK(palace_graph_resolve(ctx, d_cands, n_cands, c.n(), &prm, d_consumed, d_edges, std::max<int64_t>(1, n_cands), &n_edges));
+    CK(palace_graph_resolve(ctx, d_cands, n_cands, n_records, &prm, d_consumed, d_edges, std::max<int64_t>(1, n_cands), &n_edges));
     tr.lap("resolve");
     std::vector<uint64_t> consumed(static_cast<size_t>(nt));
     std::vector<palace_graph_edge> edges(static_cast<size_t>(n_edges));
