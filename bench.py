@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--reads", choices=("packed", "ascii"), default="packed",
                     help="form of the reads resident in HBM: packed = two bits per base + 32-mer start mask (what the eref executable's "
                          "parser threads produce; palace_eref_count_reads_packed), ascii = a byte per base (palace_eref_count_reads)")
+    ap.add_argument("--batches-in-flight", type=int, choices=(1, 2), default=2,
+                    help="one GPU: 2 = the k-mer table is double-buffered and the counting kernels of a step are enqueued while Phase B "
+                         "of the step before is still running (its rows are fetched one step later); 1 = every step drains before the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files -> files leg (CLI chain on generated files)")
     ap.add_argument("--soak-seconds", type=float, default=2.0,
@@ -698,10 +701,14 @@ def main():
     ctx_g = capi.Ctx(local, high_priority=os.environ.get("PALACE_BENCH_PRIO", "1") == "1")   # generateGraph + matching stream (independent of eref until the end)
     if os.environ.get("PALACE_OPT_ITERS_PER_ROUND"):         # tuning runs only
         ctx_g.match_set_option("iters_per_round", int(os.environ["PALACE_OPT_ITERS_PER_ROUND"]))
-    ctx.eref_set_coder(hdr)
-    for opt in ("slab_bases", "bin1_ppl"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
-        if os.environ.get("PALACE_OPT_" + opt.upper()):
-            ctx.eref_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
+    # one GPU: a second eref context (own stream, own count table, own scratch) so that consecutive batches overlap
+    depth = args.batches_in_flight if (world == 1 and not force_exchange) else 1
+    ectx = [ctx] + [capi.Ctx(local) for _ in range(depth - 1)]
+    for e in ectx:
+        e.eref_set_coder(hdr)
+        for opt in ("slab_bases", "bin1_ppl"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
+            if os.environ.get("PALACE_OPT_" + opt.upper()):
+                e.eref_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
     # Phase A across ranks.  Sharding the reads costs a count-table exchange: every rank ships (W-1)/W of three 512 MiB
     # planes and receives the merged ">= 3" plane, about 1.4 GB each way whatever W is, over W-1 xGMI links -- one link
     # at W = 2 (~15 ms, more than the ~7 ms the split saves), seven at W = 8 (~3.5 ms).  Below four ranks every rank
@@ -784,11 +791,19 @@ def main():
     # one GPU (and N GPUs that each count all reads): the count of a step is the only one between its reset and its scan, so the
     # two lower planes of the table need not leave the LDS (include/palace_hip.h, option final_count)
     final_count = not shard_reads and os.environ.get("PALACE_BENCH_FINAL", "1") == "1"      # (=0: A/B runs)
-    ctx.eref_set_option("final_count", 1 if final_count else 0)
+    for e in ectx:
+        e.eref_set_option("final_count", 1 if final_count else 0)
+    rows_l = [rows] + [torch.zeros_like(rows) for _ in range(depth - 1)]
+    rows_host_l = [rows_host] + [torch.zeros((n_refs, 4), dtype=torch.int32).pin_memory() for _ in range(depth - 1)]
+    seq = {"n": 0, "pending": None, "last": 0, "of_timed": {}}           # running batch number; the batch whose rows are still on their way
 
     def step(i, timed):
         m = 8 * i
         tot_b = n_side * READ_LEN
+        slot = seq["n"] % depth                        # which eref context / rows buffers this batch uses
+        seq["n"] += 1
+        ctx, rows, rows_host = ectx[slot], rows_l[slot], rows_host_l[slot]
+        if timed: seq["of_timed"][i] = slot
         # ---------------- eref: runs asynchronously on its own stream ----------------
         def eref_head():
             capi._check(L.palace_eref_table_reset(ctx.h), "reset")
@@ -903,10 +918,22 @@ def main():
             eref_tail()
         finish_graph()
         # ---------------- join: eref results to the host ----------------
-        capi._check(L.palace_d2h(ctx.h, rows_host.data_ptr(), P(rows), rows.numel() * 4), "d2h")
+        # the rows of THIS batch are requested; with two batches in flight the ones waited for are the previous batch's (whose
+        # Phase B ran beside this batch's counting kernels), with one they are this batch's
+        capi._check(L.palace_d2h_async(ctx.h, rows_host.data_ptr(), P(rows), rows.numel() * 4), "d2h")
+        ctx.mark(4094)
+        if depth == 1:
+            ctx.mark_wait(4094)
+        else:
+            if seq["pending"] is not None:
+                ectx[seq["pending"]].mark_wait(4094)
+            seq["pending"] = slot
+        seq["last"] = slot
 
     def barrier():
-        ctx.sync()
+        for e in ectx:
+            e.sync()
+        seq["pending"] = None
         ctx_g.sync()
         torch.cuda.synchronize()
         if dist is not None:
@@ -943,14 +970,15 @@ def main():
     if os.environ.get("PALACE_BENCH_SKIP_EREF") == "1":
         count_each, count_ms, merge_ms, scan_ms = [1.0], 1.0, 0.0, 0.0
     else:
-        count_each = [ctx.mark_elapsed(8 * i, 8 * i + 1) for i in K]
+        E = lambda i: ectx[seq["of_timed"][i]]                                      # the context timed step i ran on
+        count_each = [E(i).mark_elapsed(8 * i, 8 * i + 1) for i in K]
         count_ms = np.mean(count_each)                                              # one launch per step (both FASTQ sides)
-        merge_ms = np.mean([ctx.mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
-        scan_ms = np.mean([ctx.mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
+        merge_ms = np.mean([E(i).mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
+        scan_ms = np.mean([E(i).mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
     classify_ms = np.mean([ctx_g.mark_elapsed(8 * i, 8 * i + 1) for i in K])
     resolve_ms = np.mean([ctx_g.mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
     stage04_ms = np.mean([ctx_g.mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
-    r = rows_host.numpy()
+    r = rows_host_l[seq["last"]].numpy()
     reported = int(((r[:, 1] > 0) & (r[:, 1].astype(np.float32) / r[:, 2].astype(np.float32) > 0.75)).sum())
 
     if rank == 0:
@@ -966,6 +994,7 @@ def main():
                                    f"{2 * sample['n_pairs_total']} reads x {READ_LEN} bp, {gs['n_total']} primary BAM records, "
                                    f"{gs['n_fastg']} FASTG links",
                        "stages": ["eref", "generateGraph", "matching"], "seed": SEED, "workload_kind": args.workload,
+                       "batches_in_flight": depth,
                        "reads": ("packed in HBM: two bits per base + 32-mer start mask, 0.375 B/base (palace_eref_count_reads_packed)" if packed else
                                  "ASCII in HBM, 1 B/base (palace_eref_count_reads)") + ("; count keeps only the '>= 3' plane (final_count)" if final_count else ""),
                        "parallelism": "1 GPU" if world == 1 else (f"reads/records/refs sharded over {world} GPUs (RCCL)" if shard_reads else
@@ -1019,6 +1048,8 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     capi._check(L.palace_eref_probe_index_free(ctx.h, probe_index), "probe index free")
+    for e in ectx[1:]:
+        e.close()
     ctx.close()
     ctx_g.close()
     if dist is not None:

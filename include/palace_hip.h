@@ -57,6 +57,9 @@ int palace_d2d(palace_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 int palace_host_alloc(palace_ctx *ctx, size_t bytes, void **h_out);
 int palace_host_free(palace_ctx *ctx, void *h_ptr);
 int palace_h2d_async(palace_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+/* ... and the other way (results of one batch fetched while the next batch is being enqueued): h_dst page-locked, its
+ * content is there once a later palace_mark() on the stream has been waited for. */
+int palace_d2h_async(palace_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 /* HIP-event timing on the context's stream: begin/end bracket, elapsed in milliseconds. */
 int palace_timer_begin(palace_ctx *ctx);
 int palace_timer_end(palace_ctx *ctx, float *ms_out);

@@ -75,6 +75,7 @@ _SIGS = {
     "palace_d2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "palace_host_alloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
     "palace_host_free": [C.c_void_p, C.c_void_p],
+    "palace_d2h_async": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "palace_h2d_async": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "palace_mark_wait": [C.c_void_p, C.c_int],
     "palace_wait_for_mark": [C.c_void_p, C.c_void_p, C.c_int],
@@ -248,6 +249,10 @@ class Ctx:
 
     def mark(self, i: int):
         _check(lib().palace_mark(self.h, i), "palace_mark")
+
+    def mark_wait(self, i: int):
+        """the host waits for mark i of this context's stream"""
+        _check(lib().palace_mark_wait(self.h, i), "palace_mark_wait")
 
     def wait_for_mark(self, other: "Ctx", i: int):
         _check(lib().palace_wait_for_mark(self.h, other.h, i), "palace_wait_for_mark")

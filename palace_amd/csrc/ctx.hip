@@ -206,6 +206,13 @@ int palace_h2d_async(palace_ctx *ctx, void *d_dst, const void *h_src, size_t byt
     return PALACE_OK;
 }
 
+int palace_d2h_async(palace_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    PALACE_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "null argument");
+    if (bytes) PALACE_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return PALACE_OK;
+}
+
 int palace_mark_wait(palace_ctx *ctx, int i)
 {
     PALACE_REQUIRE(ctx && i >= 0 && static_cast<size_t>(i) < ctx->marks.size() && ctx->marks[i], "mark not recorded");

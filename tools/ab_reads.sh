@@ -16,3 +16,5 @@ BENCH_ARGS="--reads packed" run packed_all_planes PALACE_BENCH_FINAL=0 &&
 BENCH_ARGS="--reads packed" run packed_final PALACE_BENCH_FINAL=1
 [ -n "$AB_PPL" ] && for p in $AB_PPL; do BENCH_ARGS="--reads packed" run packed_final_ppl$p PALACE_BENCH_FINAL=1 PALACE_OPT_BIN1_PPL=$p; done
 true
+[ -n "$AB_DEPTH" ] && { BENCH_ARGS="--reads packed --batches-in-flight 1" run packed_final_depth1 PALACE_BENCH_FINAL=1; BENCH_ARGS="--reads packed --batches-in-flight 2" run packed_final_depth2 PALACE_BENCH_FINAL=1; }
+true
