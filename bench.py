@@ -795,7 +795,7 @@ def main():
         e.eref_set_option("final_count", 1 if final_count else 0)
     rows_l = [rows] + [torch.zeros_like(rows) for _ in range(depth - 1)]
     rows_host_l = [rows_host] + [torch.zeros((n_refs, 4), dtype=torch.int32).pin_memory() for _ in range(depth - 1)]
-    seq = {"n": 0, "pending": None, "last": 0, "of_timed": {}}           # running batch number; the batch whose rows are still on their way
+    seq = {"n": 0, "pending": None, "counted": None, "last": 0, "of_timed": {}}           # running batch number; the batch whose rows are still on their way
 
     def step(i, timed):
         m = 8 * i
@@ -807,6 +807,10 @@ def main():
         # ---------------- eref: runs asynchronously on its own stream ----------------
         def eref_head():
             capi._check(L.palace_eref_table_reset(ctx.h), "reset")
+            if depth > 1 and seq["counted"] is not None:
+                # this batch's counting kernels start when the previous batch's are done (two count launches side by side would
+                # only share the device); what then runs beside them is the previous batch's Phase B
+                ctx.wait_for_mark(ectx[seq["counted"]], 4095)
             if timed: ctx.mark(m)
             # both FASTQ sides as one read set: one binning pass, the plane slices are loaded and stored once
             if packed:
@@ -814,7 +818,8 @@ def main():
             else:
                 capi._check(L.palace_eref_count_reads(ctx.h, P(sample["r12"]), P(sample["read_off"]), 2 * n_side, None, 2 * tot_b), "count")
             if timed: ctx.mark(m + 1)
-            ctx.mark(4095)                             # "the counting kernels are done" (stage 04 waits for it, see below)
+            ctx.mark(4095)                             # "the counting kernels are done" (the next batch's, and a held-back stage 04, wait for it)
+            seq["counted"] = slot
 
         skip_eref = os.environ.get("PALACE_BENCH_SKIP_EREF") == "1"      # tuning runs only: stream B alone on the device
         if not exch and not skip_eref:
