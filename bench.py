@@ -47,9 +47,11 @@ def parse_args():
     ap.add_argument("--reads", choices=("packed", "ascii"), default="packed",
                     help="form of the reads resident in HBM: packed = two bits per base + 32-mer start mask (what the eref executable's "
                          "parser threads produce; palace_eref_count_reads_packed), ascii = a byte per base (palace_eref_count_reads)")
-    ap.add_argument("--batches-in-flight", type=int, choices=(1, 2), default=2,
-                    help="one GPU: 2 = the k-mer table is double-buffered and the counting kernels of a step are enqueued while Phase B "
-                         "of the step before is still running (its rows are fetched one step later); 1 = every step drains before the next")
+    ap.add_argument("--batches-in-flight", type=int, choices=(1, 2), default=1,
+                    help="one GPU: 2 = the k-mer table is double-buffered and the counting kernels of a step run beside Phase B of the step "
+                         "before (its rows are fetched one step later): 10.4 instead of 11.1 ms per step, but the count launch then shares the "
+                         "device and its own duration -- the roofline figure -- grows from 9.2 to 10.3 ms; 1 (default) = every step drains "
+                         "before the next, the count launch is timed with only this step's generateGraph stream beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files -> files leg (CLI chain on generated files)")
     ap.add_argument("--soak-seconds", type=float, default=2.0,
