@@ -708,7 +708,7 @@ def main():
     ectx = [ctx] + [capi.Ctx(local) for _ in range(depth - 1)]
     for e in ectx:
         e.eref_set_coder(hdr)
-        for opt in ("slab_bases", "bin1_ppl"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
+        for opt in ("slab_bases", "bin1_ppl", "level1_parts"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
             if os.environ.get("PALACE_OPT_" + opt.upper()):
                 e.eref_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
     # Phase A across ranks.  Sharding the reads costs a count-table exchange: every rank ships (W-1)/W of three 512 MiB

@@ -124,6 +124,9 @@ int palace_ctx_destroy(palace_ctx *ctx)
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     for (hipEvent_t e : ctx->marks)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_part)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -1533,9 +1533,11 @@ namespace {
 constexpr size_t kTouchedBytes = 8192 + 256;             // one bit per fine bucket (2^16 bits), padded
 struct CountPlan {
     int64_t slab_bases_max = 0, n_slabs = 0, n_chunks = 0;
+    int64_t part_bases = 0;              // level 1 works through a slab in parts of this many positions (level-1 regions hold one part)
+    int n_buf1 = 1;                      // 2: parts alternate between two sets of level-1 regions
     DensityCaps caps1{}, caps2{};
     size_t cur1_bytes = 0, cur2_bytes = 0, buf1_bytes = 0, buf2_bytes = 0, words_bytes = 0;
-    size_t total() const { return cur1_bytes + cur2_bytes + kTouchedBytes + 5 * words_bytes + buf1_bytes + buf2_bytes; }
+    size_t total() const { return n_buf1 * (cur1_bytes + buf1_bytes) + cur2_bytes + kTouchedBytes + 5 * words_bytes + buf2_bytes; }
 };
 constexpr int64_t kRegions = static_cast<int64_t>(kL1Buckets) * kL1Replicas;
 
@@ -1555,10 +1557,16 @@ int plan_count(palace_ctx *ctx, int64_t total_bases, CountPlan *pl)
     const int64_t slab_bases = std::min(total_bases, pl->slab_bases_max);
     // capacities: the key upper bound of one slab (a position range) shared out by the key density with 20 % head
     // room, plus a flat pad of 1/8 of the mean and a constant
-    const int64_t max_keys = 3 * slab_bases;
+    // Level 1 takes a slab in parts, level 2 follows part by part on the other stream (bin_and_count): the level-1 regions
+    // hold one part, twice.  Small slabs: one part, one stream.
+    int parts = ctx->level1_parts > 0 ? ctx->level1_parts : slab_bases >= (1ll << 27) ? 4 : 1;
+    pl->part_bases = ((slab_bases + parts - 1) / parts + 63) / 64 * 64;
+    if (pl->part_bases >= slab_bases) { pl->part_bases = slab_bases; parts = 1; }
+    pl->n_buf1 = parts > 1 ? 2 : 1;
+    const int64_t max_keys = 3 * slab_bases, max_keys1 = 3 * pl->part_bases;
     // (level-1 runs are padded to 4 keys: on average 1.5 pad keys per run of ~48)
     // (level-1 regions hold GROUPS of five keys; a run's last group is partly filled: ~2 pad slots per run of ~72)
-    const int64_t mean1 = max_keys / kRegions / kGroupKeys * 26 / 25 + 1, mean2 = max_keys / kFine / 2;    // mean1: groups; mean2: pairs of 16-bit keys
+    const int64_t mean1 = max_keys1 / kRegions / kGroupKeys * 26 / 25 + 1, mean2 = max_keys / kFine / 2;    // mean1: groups; mean2: pairs of 16-bit keys
     pl->caps1 = DensityCaps{static_cast<uint64_t>(mean1 + mean1 / 5), static_cast<uint32_t>(mean1 / 8 + 1024), 1};   // per level-1 region
     pl->caps2 = DensityCaps{static_cast<uint64_t>(mean2 + mean2 / 5) / 4, static_cast<uint32_t>(mean2 / 8 + 2048) / 4};   // per fine bucket
     if (ctx->bin_cap_override > 0) {                       // test hook: uniform, deliberately small regions
@@ -1582,7 +1590,7 @@ int plan_count(palace_ctx *ctx, int64_t total_bases, CountPlan *pl)
     PALACE_REQUIRE(pl->caps1.prefix(kL1Buckets) * kL1Replicas < (1ull << 32), "level-1 regions exceed 2^32 groups of 16 bytes");
     //  (c) a region cursor keeps counting when its region is full (the excess takes the exact path): it must not wrap even
     //      if every key of the slab's tiles of one replica lands in one bucket.
-    PALACE_REQUIRE(3ull * static_cast<uint64_t>(slab_bases) / kL1Replicas + (1ull << 20) < (1ull << 32), "slab too large for 32-bit region cursors");
+    PALACE_REQUIRE(3ull * static_cast<uint64_t>(pl->part_bases) / kL1Replicas + (1ull << 20) < (1ull << 32), "slab too large for 32-bit region cursors");
     return PALACE_OK;
 }
 }  // namespace
@@ -1630,55 +1638,105 @@ static int build_streams(palace_ctx *ctx, const uint8_t *d_bases, const int64_t 
     return PALACE_OK;
 }
 
+// Scratch of one count call, carved out of the context's workspace (sizes: CountPlan).
+struct CountBufs {
+    unsigned int *cursor2 = nullptr, *touched = nullptr, *cursor1[2] = {nullptr, nullptr};
+    unsigned long long *words = nullptr;                 // 5 x words_bytes (ASCII entry: read ends, dropped, three streams) or nothing
+    uint32_t *buf1[2] = {nullptr, nullptr};
+    uint16_t *buf2 = nullptr;
+};
+static void carve_count(const CountPlan &pl, char *ws, bool with_words, CountBufs *b)
+{
+    b->cursor2 = reinterpret_cast<unsigned int *>(ws); ws += pl.cur2_bytes;
+    b->touched = reinterpret_cast<unsigned int *>(ws); ws += kTouchedBytes;
+    for (int k = 0; k < pl.n_buf1; k++) { b->cursor1[k] = reinterpret_cast<unsigned int *>(ws); ws += pl.cur1_bytes; }
+    if (with_words) { b->words = reinterpret_cast<unsigned long long *>(ws); ws += 5 * pl.words_bytes; }
+    for (int k = 0; k < pl.n_buf1; k++) { b->buf1[k] = reinterpret_cast<uint32_t *>(ws); ws += pl.buf1_bytes; }
+    b->buf2 = reinterpret_cast<uint16_t *>(ws);
+}
+
+static int launch_bin1(palace_ctx *ctx, hipStream_t stream, int ppl, const uint32_t *w0, const uint32_t *w1, const uint32_t *wu, int64_t p_lo,
+                       int64_t p_hi, const BinOut &o1)
+{
+    const int64_t tile_pos = static_cast<int64_t>(kBinThreads) * ppl;
+    const int64_t tiles = (p_hi - p_lo + tile_pos - 1) / tile_pos;
+    PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
+    // one tile per workgroup, 8 waves.  Measured and dropped: workgroups that take several tiles with the next tile's
+    // words in flight -- five variants; the last one (a loader wave with direct-to-LDS loads,
+    // LDS-only barriers, hand-placed waits: nothing of the previous tile is waited for) 4.4 ms against 4.07 at the same
+    // tile size; 256-thread workgroups (+3 %); 10 / 16 positions per lane (the same / +45 %).
+    const dim3 grid(static_cast<unsigned>(tiles)), block(kBinThreads);
+    switch (ppl) {
+    case 4: hipLaunchKernelGGL((eref_bin1_sort_kernel<4, kBinThreads>), grid, block, 0, stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
+    case 5: hipLaunchKernelGGL((eref_bin1_sort_kernel<5, kBinThreads>), grid, block, 0, stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
+    case 6: hipLaunchKernelGGL((eref_bin1_sort_kernel<6, kBinThreads>), grid, block, 0, stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
+    default: hipLaunchKernelGGL((eref_bin1_sort_kernel<8, kBinThreads>), grid, block, 0, stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
+    }
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
 // The read set as bit streams (P0, P1, U: see eref_streams_kernel) -> level-1 partition -> level-2 partition -> count in LDS,
 // slab by slab.  Shared by the ASCII entry (which builds the streams first) and the packed entry (whose caller did).
-static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const BinOut &o1, const Bin2Out &o2, const uint32_t *w0, const uint32_t *w1,
+//
+// Inside a slab level 1 works in PARTS, on a second stream: level 1 of part p + 1 runs beside level 2 of part p (two sets of
+// level-1 regions), all parts append to the same fine regions, one count kernel per slab.  The two kernels load different
+// units -- level 1 the LDS and the VALU (it moves 1.9 TB/s), level 2 HBM (3.9 TB/s) -- and neither fills the device's
+// latency on its own.
+static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &b, const uint32_t *w0, const uint32_t *w1,
                          const uint32_t *wu, int64_t total_bases, double keys_per_pos)
 {
     const int64_t kSlabBases = pl.slab_bases_max, n_slabs = pl.n_slabs;
-    const DensityCaps caps1 = pl.caps1, caps2 = pl.caps2;
-    const size_t cur1_bytes = pl.cur1_bytes, cur2_bytes = pl.cur2_bytes;
-    unsigned int *cursor1 = o1.cursor, *cursor2 = o2.cursor, *touched = o1.touched;
-    uint32_t *buf1 = o1.buf;
-    uint16_t *buf2 = o2.buf;
     // positions per lane of the level-1 kernel.  Its throughput is (key slots the CU's LDS holds) / (latency of a tile,
-    // ~11 us whatever the tile size): 6 positions x 3 keys x 512 lanes + pads = 39.5 KiB, the most that still fits four
+    // ~11 us whatever the tile size): 6 positions x 3 keys x 512 lanes + pads = 39.8 KiB, the most that still fits four
     // times into 160 KiB (5: +4 %, 4: +8 %, 8 -- three workgroups per CU --: +2 %).  Sparse sets (short reads) take 8.
     const int ppl = ctx->bin1_ppl ? ctx->bin1_ppl : keys_per_pos > 1.6 ? 6 : 8;
+    const bool overlap = pl.n_buf1 > 1;
+    if (overlap && !ctx->side) {
+        PALACE_HIP_TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        for (hipEvent_t &e : ctx->ev_part) PALACE_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    hipEvent_t ev_start = ctx->ev_part[0], *ev_l1 = ctx->ev_part + 1, *ev_l2 = ctx->ev_part + 3;
+    Bin2Grid g2;
+    g2.first[0] = 0;
+    for (uint32_t bk = 0; bk < kL1Buckets; bk++) g2.first[bk + 1] = g2.first[bk] + tiles_of_bucket(pl.caps1, bk) * kL1Replicas;
+    const Bin2Out o2{b.cursor2, b.buf2, pl.caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched};
     for (int64_t slab = 0; slab < n_slabs; slab++) {
-        PALACE_HIP_TRY(hipMemsetAsync(cursor1, 0, cur1_bytes + cur2_bytes + kTouchedBytes, ctx->stream));
+        PALACE_HIP_TRY(hipMemsetAsync(b.cursor2, 0, pl.cur2_bytes + kTouchedBytes, ctx->stream));
         const bool clean = ctx->table_clean && slab == 0;        // every plane bit is still zero: slices need no reading
-        const int64_t p_lo = slab * kSlabBases, p_hi = std::min(total_bases, (slab + 1) * kSlabBases);
-        const int64_t tile_pos = static_cast<int64_t>(kBinThreads) * ppl;
-        const int64_t tiles = (p_hi - p_lo + tile_pos - 1) / tile_pos;
-        PALACE_REQUIRE(tiles < (1ll << 31), "too many tiles for one launch");
-        // one tile per workgroup, 8 waves.  Measured and dropped: workgroups that take several tiles with the next tile's
-        // words in flight -- five variants; the last one (a loader wave with direct-to-LDS loads,
-        // LDS-only barriers, hand-placed waits: nothing of the previous tile is waited for) 4.4 ms against 4.07 at the same
-        // tile size; 256-thread workgroups (+3 %); 10 / 16 positions per lane (the same / +45 %).
-        const dim3 grid(static_cast<unsigned>(tiles)), block(kBinThreads);
-        switch (ppl) {
-        case 4: hipLaunchKernelGGL((eref_bin1_sort_kernel<4, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
-        case 5: hipLaunchKernelGGL((eref_bin1_sort_kernel<5, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
-        case 6: hipLaunchKernelGGL((eref_bin1_sort_kernel<6, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
-        default: hipLaunchKernelGGL((eref_bin1_sort_kernel<8, kBinThreads>), grid, block, 0, ctx->stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1); break;
+        const int64_t s_lo = slab * kSlabBases, s_hi = std::min(total_bases, (slab + 1) * kSlabBases);
+        hipStream_t l1 = overlap ? ctx->side : ctx->stream;
+        if (overlap) {                                           // level 1 starts behind whatever the stream holds so far
+            PALACE_HIP_TRY(hipEventRecord(ev_start, ctx->stream));
+            PALACE_HIP_TRY(hipStreamWaitEvent(ctx->side, ev_start, 0));
         }
-        PALACE_HIP_TRY(hipGetLastError());
-        Bin2Grid g2;
-        g2.first[0] = 0;
-        for (uint32_t b = 0; b < kL1Buckets; b++) g2.first[b + 1] = g2.first[b] + tiles_of_bucket(caps1, b) * kL1Replicas;
-        hipLaunchKernelGGL(eref_bin2_kernel, dim3(g2.first[kL1Buckets]), dim3(kBin2Threads), 0, ctx->stream, cursor1, buf1, caps1, g2, o2);
-        PALACE_HIP_TRY(hipGetLastError());
+        int part = 0;
+        for (int64_t p_lo = s_lo; p_lo < s_hi; p_lo += pl.part_bases, part++) {
+            const int64_t p_hi = std::min(s_hi, p_lo + pl.part_bases);
+            const int k = overlap ? part & 1 : 0;
+            if (overlap && part >= 2) PALACE_HIP_TRY(hipStreamWaitEvent(ctx->side, ev_l2[k], 0));   // level 2 has read this set of regions
+            PALACE_HIP_TRY(hipMemsetAsync(b.cursor1[k], 0, pl.cur1_bytes, l1));
+            const BinOut o1{b.cursor1[k], b.buf1[k], pl.caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched};
+            int rc = launch_bin1(ctx, l1, ppl, w0, w1, wu, p_lo, p_hi, o1);
+            if (rc) return rc;
+            if (overlap) {
+                PALACE_HIP_TRY(hipEventRecord(ev_l1[k], ctx->side));
+                PALACE_HIP_TRY(hipStreamWaitEvent(ctx->stream, ev_l1[k], 0));
+            }
+            hipLaunchKernelGGL(eref_bin2_kernel, dim3(g2.first[kL1Buckets]), dim3(kBin2Threads), 0, ctx->stream, b.cursor1[k], b.buf1[k], pl.caps1, g2, o2);
+            PALACE_HIP_TRY(hipGetLastError());
+            if (overlap) PALACE_HIP_TRY(hipEventRecord(ev_l2[k], ctx->stream));
+        }
         if (clean && n_slabs == 1 && ctx->want_final) {
-            hipLaunchKernelGGL((eref_lds_count_kernel<true, true>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, cursor2, buf2, caps2,
-                               ctx->plane[0], ctx->plane[1], ctx->plane[2], touched);
+            hipLaunchKernelGGL((eref_lds_count_kernel<true, true>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
+                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched);
             ctx->final_only = true;
         } else if (clean)
-            hipLaunchKernelGGL(eref_lds_count_kernel<true>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, cursor2, buf2, caps2,
-                               ctx->plane[0], ctx->plane[1], ctx->plane[2], touched);
+            hipLaunchKernelGGL(eref_lds_count_kernel<true>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
+                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched);
         else
-            hipLaunchKernelGGL(eref_lds_count_kernel<false>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, cursor2, buf2, caps2,
-                               ctx->plane[0], ctx->plane[1], ctx->plane[2], touched);
+            hipLaunchKernelGGL(eref_lds_count_kernel<false>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
+                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched);
         PALACE_HIP_TRY(hipGetLastError());
         ctx->table_clean = false;
     }
@@ -1723,26 +1781,18 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     CountPlan pl;
     rc = plan_count(ctx, total_bases, &pl);
     if (rc) return rc;
-    const DensityCaps caps1 = pl.caps1, caps2 = pl.caps2;
-    const size_t cur1_bytes = pl.cur1_bytes, cur2_bytes = pl.cur2_bytes, buf1_bytes = pl.buf1_bytes, words_bytes = pl.words_bytes;
+    const size_t words_bytes = pl.words_bytes;
     rc = ensure_workspace(ctx, pl.total());
     if (rc) return rc;
-    char *ws = static_cast<char *>(ctx->ws.ptr);
-    unsigned int *cursor1 = reinterpret_cast<unsigned int *>(ws); ws += cur1_bytes;
-    unsigned int *cursor2 = reinterpret_cast<unsigned int *>(ws); ws += cur2_bytes;
-    unsigned int *touched = reinterpret_cast<unsigned int *>(ws); ws += kTouchedBytes;
-    unsigned long long *ends = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes;
-    unsigned long long *dropped = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes;
+    CountBufs cb;
+    carve_count(pl, static_cast<char *>(ctx->ws.ptr), true, &cb);
+    unsigned long long *ends = cb.words, *dropped = cb.words + words_bytes / 8;
     unsigned long long *strm[3];                           // P0, P1, U
-    for (int q = 0; q < 3; q++) { strm[q] = reinterpret_cast<unsigned long long *>(ws); ws += words_bytes; }
-    uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += buf1_bytes;
-    uint16_t *buf2 = reinterpret_cast<uint16_t *>(ws);
-    BinOut o1{cursor1, buf1, caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], touched};
-    Bin2Out o2{cursor2, buf2, caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2], touched};
+    for (int q = 0; q < 3; q++) strm[q] = cb.words + (2 + q) * (words_bytes / 8);
     rc = build_streams(ctx, d_bases, d_offsets, n_reads, d_keep, total_bases, ends, dropped, strm, words_bytes);
     if (rc) return rc;
     const double keys_per_pos = 3.0 * std::max(0.02, 1.0 - 31.0 * static_cast<double>(n_reads) / std::max<double>(1.0, static_cast<double>(total_bases)));
-    return bin_and_count(ctx, pl, o1, o2, reinterpret_cast<const uint32_t *>(strm[0]), reinterpret_cast<const uint32_t *>(strm[1]),
+    return bin_and_count(ctx, pl, cb, reinterpret_cast<const uint32_t *>(strm[0]), reinterpret_cast<const uint32_t *>(strm[1]),
                          reinterpret_cast<const uint32_t *>(strm[2]), total_bases, keys_per_pos);
 }
 
@@ -1799,16 +1849,10 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
     // (palace_eref_packed_bytes covers what plan_count checks the look-ahead of the last tile against: (n >> 5) + 3 words of 4 bytes)
     rc = ensure_workspace(ctx, pl.total() - 5 * pl.words_bytes);
     if (rc) return rc;
-    char *ws = static_cast<char *>(ctx->ws.ptr);
-    unsigned int *cursor1 = reinterpret_cast<unsigned int *>(ws); ws += pl.cur1_bytes;
-    unsigned int *cursor2 = reinterpret_cast<unsigned int *>(ws); ws += pl.cur2_bytes;
-    unsigned int *touched = reinterpret_cast<unsigned int *>(ws); ws += kTouchedBytes;
-    uint32_t *buf1 = reinterpret_cast<uint32_t *>(ws); ws += pl.buf1_bytes;
-    uint16_t *buf2 = reinterpret_cast<uint16_t *>(ws);
-    BinOut o1{cursor1, buf1, pl.caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], touched};
-    Bin2Out o2{cursor2, buf2, pl.caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2], touched};
+    CountBufs cb;
+    carve_count(pl, static_cast<char *>(ctx->ws.ptr), false, &cb);
     const double keys_per_pos = n_reads_hint ? 3.0 * std::max(0.02, 1.0 - 31.0 * static_cast<double>(n_reads_hint) / static_cast<double>(n_positions)) : 3.0;
-    return bin_and_count(ctx, pl, o1, o2, d_p0, d_p1, d_u, n_positions, keys_per_pos);
+    return bin_and_count(ctx, pl, cb, d_p0, d_p1, d_u, n_positions, keys_per_pos);
 }
 
 /* Tuning knobs of count_reads (see include/palace_hip.h). */
@@ -1829,6 +1873,9 @@ int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value)
     } else if (!std::strcmp(name, "final_count")) {          // the count calls that follow are each the only one between a reset and Phase B
         PALACE_REQUIRE(value == 0 || value == 1, "final_count must be 0 or 1");
         ctx->want_final = value != 0;
+    } else if (!std::strcmp(name, "level1_parts")) {         // 0: by size; n: level 1 takes a slab in n parts beside level 2 (1: one stream)
+        PALACE_REQUIRE(value >= 0 && value <= 64, "level1_parts must be 0 .. 64");
+        ctx->level1_parts = static_cast<int>(value);
     } else if (!std::strcmp(name, "bin1_ppl")) {              // 0: by key density, else positions per lane of level 1 (4, 5, 6, 8)
         PALACE_REQUIRE(value == 0 || value == 4 || value == 5 || value == 6 || value == 8, "bin1_ppl must be 0, 4, 5, 6 or 8");
         ctx->bin1_ppl = static_cast<int>(value);

@@ -18,3 +18,5 @@ BENCH_ARGS="--reads packed" run packed_final PALACE_BENCH_FINAL=1
 true
 [ -n "$AB_DEPTH" ] && { BENCH_ARGS="--reads packed --batches-in-flight 1" run packed_final_depth1 PALACE_BENCH_FINAL=1; BENCH_ARGS="--reads packed --batches-in-flight 2" run packed_final_depth2 PALACE_BENCH_FINAL=1; }
 true
+[ -n "$AB_PARTS" ] && for p in $AB_PARTS; do BENCH_ARGS="--reads packed" run packed_final_parts$p PALACE_BENCH_FINAL=1 PALACE_OPT_LEVEL1_PARTS=$p; done
+true
