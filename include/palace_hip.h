@@ -127,8 +127,8 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
  *   "slab_bases"  positions per slab that large read sets are processed in (multiple of 64; 0 = default 2^30 / 2^31)
  *   "bin1_ppl"    read positions per lane of the first partition kernel (4, 5, 6 or 8; 0 = by key density)
  *   "level1_parts" parts per slab in which the first partition kernel works, on a second stream, beside the second partition
- *                 kernel of the part before (0 = by size: 4 from 2^27 positions on, else 1; 1 = everything on the context's
- *                 stream).  The call stays stream-ordered: what follows it on the context's stream sees the finished table.
+ *                 kernel of the part before (0 or 1 = one part, everything on the context's stream: the default, and the faster
+ *                 choice where measured).  The call stays stream-ordered: what follows it on the context's stream sees the finished table.
  *   "final_count" 1: every count call from now on is the ONLY one between palace_eref_table_reset and the scan.  Phase B
  *                 reads nothing but the "count >= 3" plane (the slide tests `== least_depth`, extract_ref.cpp:23, :531, of a count that
  *                 saturates there, :995), so such a

@@ -1557,9 +1557,12 @@ int plan_count(palace_ctx *ctx, int64_t total_bases, CountPlan *pl)
     const int64_t slab_bases = std::min(total_bases, pl->slab_bases_max);
     // capacities: the key upper bound of one slab (a position range) shared out by the key density with 20 % head
     // room, plus a flat pad of 1/8 of the mean and a constant
-    // Level 1 takes a slab in parts, level 2 follows part by part on the other stream (bin_and_count): the level-1 regions
-    // hold one part, twice.  Small slabs: one part, one stream.
-    int parts = ctx->level1_parts > 0 ? ctx->level1_parts : slab_bases >= (1ll << 27) ? 4 : 1;
+    // Option level1_parts: level 1 takes a slab in parts, level 2 follows part by part on the other stream (bin_and_count); the
+    // level-1 regions then hold one part, twice.  Default: one part, one stream -- the overlap was measured and LOSES (1M-contig
+    // step, count launch: 1 part 9.24 ms, 2 parts 9.49, 4 parts 9.87, 8 parts 13.1): the two kernels do load different units,
+    // but side by side they split the CUs' LDS (a level-2 workgroup needs the room of two level-1 workgroups) and each part
+    // adds a kernel tail.
+    int parts = ctx->level1_parts > 0 ? ctx->level1_parts : 1;
     pl->part_bases = ((slab_bases + parts - 1) / parts + 63) / 64 * 64;
     if (pl->part_bases >= slab_bases) { pl->part_bases = slab_bases; parts = 1; }
     pl->n_buf1 = parts > 1 ? 2 : 1;
@@ -1679,10 +1682,9 @@ static int launch_bin1(palace_ctx *ctx, hipStream_t stream, int ppl, const uint3
 // The read set as bit streams (P0, P1, U: see eref_streams_kernel) -> level-1 partition -> level-2 partition -> count in LDS,
 // slab by slab.  Shared by the ASCII entry (which builds the streams first) and the packed entry (whose caller did).
 //
-// Inside a slab level 1 works in PARTS, on a second stream: level 1 of part p + 1 runs beside level 2 of part p (two sets of
-// level-1 regions), all parts append to the same fine regions, one count kernel per slab.  The two kernels load different
-// units -- level 1 the LDS and the VALU (it moves 1.9 TB/s), level 2 HBM (3.9 TB/s) -- and neither fills the device's
-// latency on its own.
+// With the option level1_parts > 1 level 1 works through a slab in PARTS, on a second stream: level 1 of part p + 1 runs beside
+// level 2 of part p (two sets of level-1 regions), all parts append to the same fine regions, one count kernel per slab.
+// (Measured slower than one part on one stream, see plan_count; kept as an option, exact either way.)
 static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &b, const uint32_t *w0, const uint32_t *w1,
                          const uint32_t *wu, int64_t total_bases, double keys_per_pos)
 {
