@@ -1047,7 +1047,7 @@ def main():
             finally:
                 if not os.environ.get("PALACE_BENCH_KEEP"):      # (tools/eref_cli_repeat.sh re-runs the executables on these files)
                     shutil.rmtree(work, ignore_errors=True)
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:             # (rank 0 at N = 1 only: the contract; the other ranks would wait for it)
             res_v, contig_of = h_last["result"]
             seg_flags, edge_flags = stage04.flags(len(h_last["edges"]))
             out["cpu_baseline"] = cpu_baseline(torch, sample, gs, hdr, args.cpu_sample_frac,
