@@ -701,8 +701,9 @@ def main():
     hdr = coder.header_from_picks(np.random.Generator(np.random.PCG64(SEED)).integers(0, 6, size=32))
     ctx = capi.Ctx(local)                      # eref stream
     ctx_g = capi.Ctx(local, high_priority=os.environ.get("PALACE_BENCH_PRIO", "1") == "1")   # generateGraph + matching stream (independent of eref until the end)
-    if os.environ.get("PALACE_OPT_ITERS_PER_ROUND"):         # tuning runs only
-        ctx_g.match_set_option("iters_per_round", int(os.environ["PALACE_OPT_ITERS_PER_ROUND"]))
+    for opt in ("iters_per_round", "first_group_rounds"):    # tuning runs only
+        if os.environ.get("PALACE_OPT_" + opt.upper()):
+            ctx_g.match_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
     # one GPU: a second eref context (own stream, own count table, own scratch) so that consecutive batches overlap
     depth = args.batches_in_flight if (world == 1 and not force_exchange) else 1
     ectx = [ctx] + [capi.Ctx(local) for _ in range(depth - 1)]

@@ -354,7 +354,9 @@ typedef struct palace_match_result palace_match_result;
  * a group of rounds at a time with a fixed number of matching iterations per round (7 in the first round, 4 later; the
  * iterations behind a round's fixed point return at once); the host looks at the state after each group, stops as soon as no
  * segment keeps a copy, and redoes the decomposition with a check after every batch of iterations should a round not have
- * settled.  "iters_per_round" overrides the number of iterations (0 = defaults, at most 64; 1 forces the checked path). */
+ * settled.  "iters_per_round" overrides the number of iterations (0 = defaults, at most 64; 1 forces the checked path);
+ * "first_group_rounds" the rounds enqueued before the first look at the state (0 = default 5; fewer launches beside other
+ * work, one host round trip more when a second round is needed: no effect on the step time where measured). */
 int palace_match_set_option(palace_ctx *ctx, const char *name, int64_t value);
 int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
                            const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,

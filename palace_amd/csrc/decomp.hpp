@@ -74,7 +74,7 @@ void decomp_carve(DecompBufs &b, char *base, int64_t s_cap, int64_t e_cap, int64
 // and orig must be in place (stream order).  `count` carries the iteration stamp from call to call.  When `unique_hi`, khi
 // alone ranks the arcs (the second proposal pass is skipped).  After a group of rounds the caller reads the state back:
 // alive_after == 0 means every later round is empty (all but an `aggressive` last one can be skipped).
-constexpr int kFirstRoundIters = 7, kLaterRoundIters = 4, kRoundsPerGroup = 5;
+constexpr int kFirstRoundIters = 7, kLaterRoundIters = 4, kRoundsPerGroup = 5, kFirstGroupRounds = 5;
 int decomp_begin(palace_ctx *ctx, const DecompBufs &b, int rounds, int64_t comp_cap, int64_t vert_cap);
 int decomp_rounds(palace_ctx *ctx, const DecompBufs &b, int t0, int t1, int rounds, int aggressive, int iters, bool unique_hi,
                   uint64_t *count);

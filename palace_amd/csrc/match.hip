@@ -387,6 +387,9 @@ int palace_match_set_option(palace_ctx *ctx, const char *name, int64_t value)
     if (!std::strcmp(name, "iters_per_round")) {
         PALACE_REQUIRE(value >= 0 && value <= palace::kMaxIters, "iters_per_round out of range");
         ctx->match_iters = static_cast<int>(value);
+    } else if (!std::strcmp(name, "first_group_rounds")) {
+        PALACE_REQUIRE(value >= 0 && value <= palace::kMaxRounds, "first_group_rounds out of range");
+        ctx->match_first_group = static_cast<int>(value);
     } else {
         palace::set_error("palace_match_set_option: unknown option '%s'", name);
         return PALACE_EINVAL;
