@@ -712,11 +712,13 @@ def main():
         for opt in ("slab_bases", "bin1_ppl", "level1_parts"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
             if os.environ.get("PALACE_OPT_" + opt.upper()):
                 e.eref_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
-    # Phase A across ranks.  Sharding the reads costs a count-table exchange: every rank ships (W-1)/W of three 512 MiB
-    # planes and receives the merged ">= 3" plane, about 1.4 GB each way whatever W is, over W-1 xGMI links -- one link
-    # at W = 2 (~15 ms, more than the ~7 ms the split saves), seven at W = 8 (~3.5 ms).  Below four ranks every rank
-    # therefore counts ALL reads (no exchange) and only Phase B, generateGraph and the gathers are sharded.
-    shard_reads = world >= 4 or force_exchange
+    # Phase A across ranks.  Sharding the reads costs a count-table exchange: every rank ships (W-1)/W of two 512 MiB planes
+    # (low bit + ">= 2") to their owners and receives the merged ">= 3" plane, 0.5-0.9 GB out and 0.26-0.45 GB in whatever W is,
+    # over W-1 xGMI links of ~50 GB/s usable each way, plus ~1.1 ms of reset / pack / merge passes: ~16 ms at W = 2, ~8 ms at
+    # W = 4, ~4 ms at W = 8 -- against the (W-1)/W of the 9.3 ms count launch that the split saves (4.6, 7.0, 8.1 ms).  Only at
+    # eight ranks does it pay: below that every rank counts ALL reads (no exchange) and only Phase B,
+    # generateGraph and the gathers are sharded.  PALACE_BENCH_SHARD_READS=1 forces the exchange (rehearsals).
+    shard_reads = world >= 8 or force_exchange or (world > 1 and os.environ.get("PALACE_BENCH_SHARD_READS") == "1")
     long_mode = args.workload == "long"
     sample = make_sample(torch, dev, args.contigs, args.refs, rank if shard_reads else 0, world if shard_reads else 1, long_mode)
     gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world, long_mode)

@@ -73,9 +73,11 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(world, port):
     a = json.loads(sh([sys.executable, os.path.join(ROOT, "bench.py")] + size).decode().strip().splitlines()[-1])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + size
-    out = sh(cmd, env=dict(os.environ, PALACE_BENCH_ONE_DEVICE="1", PALACE_BENCH_BACKEND="gloo")).decode()
+    # (the bench shards the reads from eight ranks on; the 4-rank rehearsal forces it so that the exchange is exercised)
+    out = sh(cmd, env=dict(os.environ, PALACE_BENCH_ONE_DEVICE="1", PALACE_BENCH_BACKEND="gloo", PALACE_BENCH_SHARD_READS="1" if world == 4 else "0")).decode()
     b = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
     assert b["n_gpus"] == world
+    assert ("reads/records/refs sharded" in b["config"]["parallelism"]) == (world == 4)
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
     assert a["config"]["graph"] == b["config"]["graph"]
     assert a["config"]["result_digest"] == b["config"]["result_digest"] and a["config"]["result_digest"]["graph_and_components"]
