@@ -712,13 +712,16 @@ def main():
         for opt in ("slab_bases", "bin1_ppl", "level1_parts"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
             if os.environ.get("PALACE_OPT_" + opt.upper()):
                 e.eref_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
-    # Phase A across ranks.  Sharding the reads costs a count-table exchange: every rank ships (W-1)/W of two 512 MiB planes
-    # (low bit + ">= 2") to their owners and receives the merged ">= 3" plane, 0.5-0.9 GB out and 0.26-0.45 GB in whatever W is,
-    # over W-1 xGMI links of ~50 GB/s usable each way, plus ~1.1 ms of reset / pack / merge passes: ~16 ms at W = 2, ~8 ms at
-    # W = 4, ~4 ms at W = 8 -- against the (W-1)/W of the 9.3 ms count launch that the split saves (4.6, 7.0, 8.1 ms).  Only at
-    # eight ranks does it pay: below that every rank counts ALL reads (no exchange) and only Phase B,
-    # generateGraph and the gathers are sharded.  PALACE_BENCH_SHARD_READS=1 forces the exchange (rehearsals).
-    shard_reads = world >= 8 or force_exchange or (world > 1 and os.environ.get("PALACE_BENCH_SHARD_READS") == "1")
+    # Phase A across ranks.  Three ways, modelled from the 1-GPU kernel times and ~50 GB/s usable per xGMI link and direction
+    # (none measured on more than one GPU yet):
+    #  * every rank counts ALL reads, nothing is exchanged (what two ranks do: anything else crosses ONE link);
+    #  * every rank counts all reads but only ITS 1/W of the key space, the ">= 3" plane slices are all-gathered (from four ranks
+    #    on, see key_split below): 512 MiB / W per rank and link pair, ~2.5 ms at W = 4, ~1.3 ms at W = 8, and the partition
+    #    kernels shrink to the key arithmetic plus 1/W of the sorting and the bytes;
+    #  * the reads are sharded and the partial count tables exchanged (two planes to their owners, merge, all-gather): 0.5-0.9 GB
+    #    out per rank whatever W is, ~8 ms at W = 4, ~4 ms at W = 8 plus ~1.1 ms of passes -- slower than the key split at every
+    #    W in this model; kept behind PALACE_BENCH_SHARD_READS=1 (the library's exchange entry points, and the rehearsals).
+    shard_reads = force_exchange or (world > 1 and os.environ.get("PALACE_BENCH_SHARD_READS") == "1")
     long_mode = args.workload == "long"
     sample = make_sample(torch, dev, args.contigs, args.refs, rank if shard_reads else 0, world if shard_reads else 1, long_mode)
     gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world, long_mode)
@@ -796,6 +799,14 @@ def main():
     # one GPU (and N GPUs that each count all reads): the count of a step is the only one between its reset and its scan, so the
     # two lower planes of the table need not leave the LDS (include/palace_hip.h, option final_count)
     final_count = not shard_reads and os.environ.get("PALACE_BENCH_FINAL", "1") == "1"      # (=0: A/B runs)
+    # Four ranks and more that each hold all reads: rank r counts only the keys of ITS 1/W of the key space (they are dropped
+    # where they are made: the partition kernels move 1/W of the bytes, the key arithmetic stays) and the ">= 3" plane slices
+    # are all-gathered -- one collective of 512 MiB / W per rank instead of the table exchange.  (Two ranks: the slice would
+    # cross ONE link, ~5 ms: every rank counts everything.)
+    key_split = bool(exch) and not shard_reads and world >= 4 and 128 % world == 0 and os.environ.get("PALACE_BENCH_KEY_SPLIT", "1") == "1"
+    if key_split:
+        ctx.eref_set_option("key_buckets_lo", rank * (128 // world))
+        ctx.eref_set_option("key_buckets_n", 128 // world)
     for e in ectx:
         e.eref_set_option("final_count", 1 if final_count else 0)
     rows_l = [rows] + [torch.zeros_like(rows) for _ in range(depth - 1)]
@@ -834,6 +845,12 @@ def main():
             if exch and shard_reads:                   # count-table exchange (RCCL), then Phase B on this rank's refs
                 ctx.sync()
                 exch.merge_planes(planes, merge_fn, pack_fn)
+                tsync()
+            elif key_split:                            # every rank counted its range of the key space: gather the ">= 3" plane
+                ctx.sync()
+                S = planes[2].numel() // world
+                mine = planes[2][rank * S:(rank + 1) * S].clone()
+                dist.all_gather_into_tensor(planes[2], mine)
                 tsync()
             if timed: ctx.mark(m + 2)
             capi._check(L.palace_eref_scan_refs_indexed(ctx.h, probe_index, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
@@ -1008,6 +1025,7 @@ def main():
                        "reads": ("packed in HBM: two bits per base + 32-mer start mask, 0.375 B/base (palace_eref_count_reads_packed)" if packed else
                                  "ASCII in HBM, 1 B/base (palace_eref_count_reads)") + ("; count keeps only the '>= 3' plane (final_count)" if final_count else ""),
                        "parallelism": "1 GPU" if world == 1 else (f"reads/records/refs sharded over {world} GPUs (RCCL)" if shard_reads else
+                                                                   f"records/refs and the key space sharded over {world} GPUs (RCCL): every GPU counts its 1/{world} of the keys of all reads, the '>= 3' plane is all-gathered" if key_split else
                                                                    f"records/refs sharded over {world} GPUs (RCCL), reads counted on every GPU"),
                        "ref_index": "per-DB probe index prebuilt, as the reference's cached <fasta>.k32.index.dat (8 B/position in HBM)",
                        "refs_reported": reported, "refs_present": int(len(sample["present"])),

@@ -126,6 +126,10 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
  * of the partitioned path (keys beyond it take the direct path).  set_option(name, value):
  *   "slab_bases"  positions per slab that large read sets are processed in (multiple of 64; 0 = default 2^30 / 2^31)
  *   "bin1_ppl"    read positions per lane of the first partition kernel (4, 5, 6 or 8; 0 = by key density)
+ *   "key_buckets_lo", "key_buckets_n"  count calls take in only the keys whose top 7 bits lie in [lo, lo + n) (default 0, 128: all).
+ *                 For N GPUs that each hold all reads: rank r counts the keys of its 1/N of the key space -- the ">= 3" plane
+ *                 of that range is exact -- and the plane slices are all-gathered (no table exchange, no merge); the other
+ *                 keys are dropped where they are made, so the partition kernels move 1/N of the bytes.
  *   "level1_parts" parts per slab in which the first partition kernel works, on a second stream, beside the second partition
  *                 kernel of the part before (0 or 1 = one part, everything on the context's stream: the default, and the faster
  *                 choice where measured).  The call stays stream-ordered: what follows it on the context's stream sees the finished table.

@@ -609,3 +609,56 @@ def test_final_count_keeps_only_the_top_plane_and_leaves_the_others_zero(ctx, ca
         ctx.eref_set_count_mode(0, 0)
         ctx.eref_table_reset()
         db.free(); do.free()
+
+
+@pytest.mark.parametrize("mode", [1, 2])                                        # direct kernels / partition kernels
+def test_key_range_counts_exactly_its_share_of_the_key_space(ctx, mode):
+    """options key_buckets_lo / key_buckets_n: four calls over the same reads, a quarter of the key space each, give four
+    tables that are exact on their quarter and empty elsewhere (what four GPUs that each hold all reads would all-gather),
+    through the ASCII and the packed entry, with final_count as the bench uses it"""
+    rng = synth.rng_for(53)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    cc = orc.header_to_cc(hdr)
+    rs = synth.vector_reads(rng, synth.random_dna(rng, 50000), 4000, 110)
+    u, c = oracle_key_counts(rs.bases, rs.offsets, cc)
+    streams, n_pos = pack_reads(rs.bases, rs.offsets)
+    db, do = ctx.upload(rs.bases), ctx.upload(rs.offsets)
+    ds = [ctx.upload(x) for x in streams]
+    try:
+        ctx.eref_set_count_mode(mode, 0)
+        ctx.eref_set_coder(hdr)
+        total3 = 0
+        for q in range(4):
+            mine = (u >> 25) // 32 == q
+            ctx.eref_set_option("key_buckets_lo", 32 * q)
+            ctx.eref_set_option("key_buckets_n", 32)
+            ctx.eref_table_reset()
+            ctx.eref_count_reads(db, do, rs.n)
+            ctx.sync()
+            assert_table_equals(ctx, u[mine], c[mine])                         # its keys exactly, and nothing else is set
+            ctx.eref_table_reset()
+            ctx.eref_count_reads_packed(ds[0], ds[1], ds[2], n_pos, rs.n)
+            ctx.sync()
+            assert_table_equals(ctx, u[mine], c[mine])
+            if mode == 2:
+                ctx.eref_set_option("final_count", 1)
+                ctx.eref_table_reset()
+                ctx.eref_count_reads_packed(ds[0], ds[1], ds[2], n_pos, rs.n)
+                pops = ctx.eref_table_popcounts()
+                assert pops[:2] == [0, 0] and pops[2] == int((c[mine] >= 3).sum())
+                total3 += pops[2]
+                ctx.eref_set_option("final_count", 0)
+                ctx.eref_table_reset()
+        if mode == 2:
+            assert total3 == int((c >= 3).sum())
+        with pytest.raises(capi.PalaceError):
+            ctx.eref_set_option("key_buckets_lo", 120)
+            ctx.eref_count_reads(db, do, rs.n)                                  # 120 + 32 runs past the 128 buckets
+    finally:
+        ctx.eref_set_option("key_buckets_lo", 0)
+        ctx.eref_set_option("key_buckets_n", 128)
+        ctx.eref_set_option("final_count", 0)
+        ctx.eref_set_count_mode(0, 0)
+        ctx.eref_table_reset()
+        for b in [db, do] + ds:
+            b.free()

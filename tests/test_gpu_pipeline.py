@@ -64,8 +64,8 @@ def test_bench_exchange_path_rehearsal():
     assert a["config"]["graph"]["n_edges"] > 0
 
 
-@pytest.mark.parametrize("world,port", [(2, 29521), (4, 29522)])
-def test_bench_multi_rank_rehearsal_on_one_gpu(world, port):
+@pytest.mark.parametrize("world,port,shard", [(2, 29521, "0"), (4, 29522, "1"), (4, 29523, "0")])
+def test_bench_multi_rank_rehearsal_on_one_gpu(world, port, shard):
     """The N-rank step (world 2: every rank counts all reads, Phase B / generateGraph / gathers sharded; world 4: reads
     sharded too, count-table exchange + merge) with all ranks on GPU 0 and the collectives over gloo (RCCL refuses two
     ranks on one device): the same refs and the same graph as the single-process run."""
@@ -73,11 +73,13 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(world, port):
     a = json.loads(sh([sys.executable, os.path.join(ROOT, "bench.py")] + size).decode().strip().splitlines()[-1])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + size
-    # (the bench shards the reads from eight ranks on; the 4-rank rehearsal forces it so that the exchange is exercised)
-    out = sh(cmd, env=dict(os.environ, PALACE_BENCH_ONE_DEVICE="1", PALACE_BENCH_BACKEND="gloo", PALACE_BENCH_SHARD_READS="1" if world == 4 else "0")).decode()
+    # (two flavours of four ranks: the reads sharded with the count-table exchange -- forced here, the bench itself never picks it --
+    # and of four: the key space split with an all-gather of the plane slices -- what the bench does from four ranks on)
+    out = sh(cmd, env=dict(os.environ, PALACE_BENCH_ONE_DEVICE="1", PALACE_BENCH_BACKEND="gloo", PALACE_BENCH_SHARD_READS=shard)).decode()
     b = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
     assert b["n_gpus"] == world
-    assert ("reads/records/refs sharded" in b["config"]["parallelism"]) == (world == 4)
+    assert ("reads/records/refs sharded" in b["config"]["parallelism"]) == (shard == "1")
+    assert ("key space sharded" in b["config"]["parallelism"]) == (world == 4 and shard == "0")
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
     assert a["config"]["graph"] == b["config"]["graph"]
     assert a["config"]["result_digest"] == b["config"]["result_digest"] and a["config"]["result_digest"]["graph_and_components"]
