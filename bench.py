@@ -712,6 +712,8 @@ def main():
         for opt in ("slab_bases", "bin1_ppl", "level1_parts"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
             if os.environ.get("PALACE_OPT_" + opt.upper()):
                 e.eref_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
+        if os.environ.get("PALACE_OPT_KEY_SHARE"):    # tuning runs only: count the share rank 0 of N would (results are then partial)
+            e.eref_set_key_buckets(multigpu.key_buckets_of(0, int(os.environ["PALACE_OPT_KEY_SHARE"])))
     # Phase A across ranks.  Three ways, modelled from the 1-GPU kernel times and ~50 GB/s usable per xGMI link and direction
     # (none measured on more than one GPU yet):
     #  * every rank counts ALL reads, nothing is exchanged (what two ranks do: anything else crosses ONE link);
@@ -803,10 +805,9 @@ def main():
     # where they are made: the partition kernels move 1/W of the bytes, the key arithmetic stays) and the ">= 3" plane slices
     # are all-gathered -- one collective of 512 MiB / W per rank instead of the table exchange.  (Two ranks: the slice would
     # cross ONE link, ~5 ms: every rank counts everything.)
-    key_split = bool(exch) and not shard_reads and world >= 4 and 128 % world == 0 and os.environ.get("PALACE_BENCH_KEY_SPLIT", "1") == "1"
+    key_split = bool(exch) and not shard_reads and world >= 4 and 64 % world == 0 and os.environ.get("PALACE_BENCH_KEY_SPLIT", "1") == "1"
     if key_split:
-        ctx.eref_set_option("key_buckets_lo", rank * (128 // world))
-        ctx.eref_set_option("key_buckets_n", 128 // world)
+        ctx.eref_set_key_buckets(multigpu.key_buckets_of(rank, world))       # mirrored pairs of buckets: equal key mass per rank
     for e in ectx:
         e.eref_set_option("final_count", 1 if final_count else 0)
     rows_l = [rows] + [torch.zeros_like(rows) for _ in range(depth - 1)]
@@ -848,9 +849,7 @@ def main():
                 tsync()
             elif key_split:                            # every rank counted its range of the key space: gather the ">= 3" plane
                 ctx.sync()
-                S = planes[2].numel() // world
-                mine = planes[2][rank * S:(rank + 1) * S].clone()
-                dist.all_gather_into_tensor(planes[2], mine)
+                exch.gather_key_buckets(planes[2])
                 tsync()
             if timed: ctx.mark(m + 2)
             capi._check(L.palace_eref_scan_refs_indexed(ctx.h, probe_index, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,

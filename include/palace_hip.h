@@ -126,10 +126,6 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
  * of the partitioned path (keys beyond it take the direct path).  set_option(name, value):
  *   "slab_bases"  positions per slab that large read sets are processed in (multiple of 64; 0 = default 2^30 / 2^31)
  *   "bin1_ppl"    read positions per lane of the first partition kernel (4, 5, 6 or 8; 0 = by key density)
- *   "key_buckets_lo", "key_buckets_n"  count calls take in only the keys whose top 7 bits lie in [lo, lo + n) (default 0, 128: all).
- *                 For N GPUs that each hold all reads: rank r counts the keys of its 1/N of the key space -- the ">= 3" plane
- *                 of that range is exact -- and the plane slices are all-gathered (no table exchange, no merge); the other
- *                 keys are dropped where they are made, so the partition kernels move 1/N of the bytes.
  *   "level1_parts" parts per slab in which the first partition kernel works, on a second stream, beside the second partition
  *                 kernel of the part before (0 or 1 = one part, everything on the context's stream: the default, and the faster
  *                 choice where measured).  The call stays stream-ordered: what follows it on the context's stream sees the finished table.
@@ -141,6 +137,13 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
  *                 merges or lookups until it is reset (those calls fail); popcounts report 0, 0, n.  Applies to binned
  *                 counts of one slab into a clean table, otherwise the call behaves as without the option.  0: off (default). */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap);
+/* The count calls that follow take in only the keys whose top 7 bits -- one of 128 buckets of the key space -- are in the set
+ * (bit b of mask128 = bucket b; default all).  For N GPUs that each hold all reads (the reference's threads share one table,
+ * extract_ref.cpp:1269-1291): rank r counts the keys of its buckets -- its slices of the ">= 3" plane (4 MiB per bucket) are
+ * then exact -- and the slices are gathered: no table exchange, no merge; the other keys are dropped where they are made, so
+ * the partition kernels move the rank's share of the bytes.  Canonical keys thin out linearly over the key space (bucket b
+ * holds (255 - 2b) / 16384 of them), so equal shares take buckets in mirrored pairs, e.g. {r, 2N-1-r} of every 2N. */
+int palace_eref_set_key_buckets(palace_ctx *ctx, const uint32_t mask128[4]);
 int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value);
 
 /* E5 + E6. For each ref: look the three indices of every position up in the table and run the

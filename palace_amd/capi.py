@@ -91,6 +91,7 @@ _SIGS = {
     "palace_eref_pack_reads": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
     "palace_eref_count_reads_packed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64],
     "palace_eref_set_count_mode": [C.c_void_p, C.c_int, C.c_int64],
+    "palace_eref_set_key_buckets": [C.c_void_p, C.c_void_p],
     "palace_eref_set_option": [C.c_void_p, C.c_char_p, C.c_int64],
     "palace_eref_scan_refs": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
                               C.c_void_p],
@@ -290,6 +291,13 @@ class Ctx:
 
     def eref_set_count_mode(self, mode: int, bucket_cap: int = 0):
         _check(lib().palace_eref_set_count_mode(self.h, mode, bucket_cap), "palace_eref_set_count_mode")
+
+    def eref_set_key_buckets(self, buckets=None):
+        """the level-1 buckets (0..127) count calls take in; None = all"""
+        m = (C.c_uint32 * 4)(*([0xFFFFFFFF] * 4 if buckets is None else [0] * 4))
+        for b in ([] if buckets is None else buckets):
+            m[b >> 5] |= 1 << (b & 31)
+        _check(lib().palace_eref_set_key_buckets(self.h, m), "palace_eref_set_key_buckets")
 
     def eref_set_option(self, name: str, value: int):
         _check(lib().palace_eref_set_option(self.h, name.encode(), value), "palace_eref_set_option")

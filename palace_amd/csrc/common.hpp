@@ -61,7 +61,7 @@ struct palace_ctx {
     // eref count_reads: level 1 of the next part of a slab runs on `side` beside level 2 of the current one (eref.hip, bin_and_count)
     hipStream_t side = nullptr;
     hipEvent_t ev_part[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // start, level 1 done [2], level 2 done [2]
-    uint32_t key_lo = 0, key_n = 128;   // option: the level-1 buckets (key >> 25) count calls take in
+    uint32_t key_buckets[4] = {~0u, ~0u, ~0u, ~0u};   // palace_eref_set_key_buckets: the level-1 buckets (key >> 25) count calls take in
     int level1_parts = 0;           // option: parts per slab (0 = by size, 1 = no overlap)
     std::vector<hipEvent_t> marks;   // lazily created
     // eref

@@ -103,18 +103,20 @@ __device__ __forceinline__ void count_key(uint32_t key, uint32_t *__restrict__ p
         if (atomicOr(&p2[word], bit) & bit) atomicOr(&p3[word], bit);
 }
 
-// Option key range (multi-GPU: every rank counts ALL reads but only the keys of its 1/W of the key space, the ">= 3" plane is
-// all-gathered): keys whose top 7 bits -- the level-1 bucket -- lie outside [lo, lo + n) are dropped where they are made.
-struct KeyRange {
-    uint32_t lo, n;                                   // level-1 buckets; the whole space: 0, 128
-    __device__ __forceinline__ bool has(uint32_t key) const { return (key >> 25) - lo < n; }
+// Option key buckets (multi-GPU: every rank counts ALL reads but only the keys of its share of the key space, the ">= 3" plane
+// is gathered): keys whose top 7 bits -- the level-1 bucket -- are not in the set are dropped where they are made.  A set, not
+// a range: the key density falls linearly over the key space (DensityCaps), so equal shares pair a dense bucket with a sparse one.
+struct KeyBuckets {
+    uint32_t m[4];                                    // bit b: level-1 bucket b is counted; all ones: the whole space
+    __host__ __device__ __forceinline__ bool bucket(uint32_t b) const { return (m[b >> 5] >> (b & 31)) & 1u; }
+    __device__ __forceinline__ bool has(uint32_t key) const { return bucket(key >> 25); }
 };
 
 __global__ __launch_bounds__(256) void eref_count_kernel(const uint8_t *__restrict__ bases,
                                                          const int64_t *__restrict__ offsets,
                                                          int64_t n_reads,
                                                          const uint8_t *__restrict__ keep,
-                                                         CoderMasks masks, KeyRange range, uint32_t *__restrict__ p1,
+                                                         CoderMasks masks, KeyBuckets range, uint32_t *__restrict__ p1,
                                                          uint32_t *__restrict__ p2,
                                                          uint32_t *__restrict__ p3)
 {
@@ -202,7 +204,7 @@ struct BinOut {
     DensityCaps caps;              // capacity of a destination region of level-1 bucket b
     uint32_t *p1, *p2, *p3;        // overflow path
     unsigned int *touched;         // one bit per fine bucket: the overflow path wrote into its plane slices
-    uint32_t key_lo, key_n;        // level-1 buckets this call counts (0, 128: all)
+    KeyBuckets keys;               // level-1 buckets this call counts
 };
 
 // Level-1 cursors are laid out replica-major: the 128 reservations of a tile (one per bucket, lanes 0..127) fall into
@@ -218,7 +220,7 @@ __device__ __forceinline__ uint64_t l1_region_base(const DensityCaps &c, uint32_
 // the two projection streams straight from two words each, three atomics per marked position.
 __global__ __launch_bounds__(256) void eref_count_packed_kernel(const uint32_t *__restrict__ s0, const uint32_t *__restrict__ s1,
                                                                 const uint32_t *__restrict__ su, int64_t n, CoderMasks masks,
-                                                                KeyRange range, uint32_t *__restrict__ p1, uint32_t *__restrict__ p2,
+                                                                KeyBuckets range, uint32_t *__restrict__ p1, uint32_t *__restrict__ p2,
                                                                 uint32_t *__restrict__ p3)
 {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(THREADS) void eref_bin1_sort_kernel(const uint32_t 
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
                     const uint32_t bk = key[t][i] >> kL1Shift;
-                    rank[t][i] = bk - o.key_lo < o.key_n ? atomicAdd(&hist[bk], 1u) : ~0u;              // its rank in the row; ~0: not this call's key
+                    rank[t][i] = o.keys.bucket(bk) ? atomicAdd(&hist[bk], 1u) : ~0u;                    // its rank in the row; ~0: not this call's key
                 }
             }
         }
@@ -763,10 +765,11 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
                                                                        DensityCaps caps, uint32_t *__restrict__ p1,
                                                                        uint32_t *__restrict__ p2,
                                                                        uint32_t *__restrict__ p3,
-                                                                       const unsigned int *__restrict__ touched, uint32_t first_bucket)
+                                                                       const unsigned int *__restrict__ touched, KeyBuckets share)
 {
     __shared__ uint32_t l1[kFineWords], l2[kFineWords], l3[kFineWords];
-    const uint32_t b = blockIdx.x + first_bucket, b1 = b / kL2Rows;       // (first_bucket: a call that counts a range of the key space)
+    const uint32_t b = blockIdx.x, b1 = b / kL2Rows;
+    if (!share.bucket(b1)) return;                          // a call that counts a share of the key space: not its bucket
     // the bucket's keys lie in eight sub-regions (one per XCD that wrote them); as one sequence of 16-byte vectors of eight
     // keys: vector j belongs to sub-region x with first[x] <= j < first[x + 1]
     const uint32_t sub_cap = fine_sub_cap(caps, b1);
@@ -1655,6 +1658,13 @@ static int build_streams(palace_ctx *ctx, const uint8_t *d_bases, const int64_t 
     return PALACE_OK;
 }
 
+static KeyBuckets ctx_buckets(const palace_ctx *ctx)
+{
+    KeyBuckets k;
+    for (int i = 0; i < 4; i++) k.m[i] = ctx->key_buckets[i];
+    return k;
+}
+
 // Scratch of one count call, carved out of the context's workspace (sizes: CountPlan).
 struct CountBufs {
     unsigned int *cursor2 = nullptr, *touched = nullptr, *cursor1[2] = {nullptr, nullptr};
@@ -1713,12 +1723,12 @@ static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &
         for (hipEvent_t &e : ctx->ev_part) PALACE_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     hipEvent_t ev_start = ctx->ev_part[0], *ev_l1 = ctx->ev_part + 1, *ev_l2 = ctx->ev_part + 3;
+    const KeyBuckets keys = ctx_buckets(ctx);
     Bin2Grid g2;
     g2.first[0] = 0;
     for (uint32_t bk = 0; bk < kL1Buckets; bk++)                                                 // (level 2 only where level 1 wrote)
-        g2.first[bk + 1] = g2.first[bk] + (bk - ctx->key_lo < ctx->key_n ? tiles_of_bucket(pl.caps1, bk) * kL1Replicas : 0);
+        g2.first[bk + 1] = g2.first[bk] + (keys.bucket(bk) ? tiles_of_bucket(pl.caps1, bk) * kL1Replicas : 0);
     const Bin2Out o2{b.cursor2, b.buf2, pl.caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched};
-    const uint32_t first_fine = ctx->key_lo * kL2Rows, n_fine = ctx->key_n * kL2Rows;            // the fine buckets this call counts
     for (int64_t slab = 0; slab < n_slabs; slab++) {
         PALACE_HIP_TRY(hipMemsetAsync(b.cursor2, 0, pl.cur2_bytes + kTouchedBytes, ctx->stream));
         const bool clean = ctx->table_clean && slab == 0;        // every plane bit is still zero: slices need no reading
@@ -1734,7 +1744,7 @@ static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &
             const int k = overlap ? part & 1 : 0;
             if (overlap && part >= 2) PALACE_HIP_TRY(hipStreamWaitEvent(ctx->side, ev_l2[k], 0));   // level 2 has read this set of regions
             PALACE_HIP_TRY(hipMemsetAsync(b.cursor1[k], 0, pl.cur1_bytes, l1));
-            const BinOut o1{b.cursor1[k], b.buf1[k], pl.caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, ctx->key_lo, ctx->key_n};
+            const BinOut o1{b.cursor1[k], b.buf1[k], pl.caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys};
             int rc = launch_bin1(ctx, l1, ppl, w0, w1, wu, p_lo, p_hi, o1);
             if (rc) return rc;
             if (overlap) {
@@ -1746,15 +1756,15 @@ static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &
             if (overlap) PALACE_HIP_TRY(hipEventRecord(ev_l2[k], ctx->stream));
         }
         if (clean && n_slabs == 1 && ctx->want_final) {
-            hipLaunchKernelGGL((eref_lds_count_kernel<true, true>), dim3(n_fine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
-                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, first_fine);
+            hipLaunchKernelGGL((eref_lds_count_kernel<true, true>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
+                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys);
             ctx->final_only = true;
         } else if (clean)
-            hipLaunchKernelGGL(eref_lds_count_kernel<true>, dim3(n_fine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
-                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, first_fine);
+            hipLaunchKernelGGL(eref_lds_count_kernel<true>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
+                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys);
         else
-            hipLaunchKernelGGL(eref_lds_count_kernel<false>, dim3(n_fine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
-                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, first_fine);
+            hipLaunchKernelGGL(eref_lds_count_kernel<false>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
+                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys);
         PALACE_HIP_TRY(hipGetLastError());
         ctx->table_clean = false;
     }
@@ -1770,7 +1780,6 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     if (!ctx->coder_set) { set_error("palace_eref_count_reads: coder not set"); return PALACE_ESTATE; }
     if (n_reads == 0) return PALACE_OK;
     PALACE_REQUIRE(d_bases && d_offsets, "null device pointer");
-    PALACE_REQUIRE(ctx->key_lo + ctx->key_n <= static_cast<uint32_t>(kL1Buckets), "key range (options key_buckets_lo / key_buckets_n) runs past the key space");
     PALACE_REQUIRE(!ctx->final_only, "the table holds only its \">= 3\" plane (option final_count): reset it first");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
@@ -1791,7 +1800,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         int64_t cap = static_cast<int64_t>(kCUs) * 8 * 8;   // grid-stride beyond 16 Ki blocks
         if (blocks > cap) blocks = cap;
         hipLaunchKernelGGL(eref_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream,
-                           d_bases, d_offsets, n_reads, d_keep, ctx->masks, KeyRange{ctx->key_lo, ctx->key_n}, ctx->plane[0], ctx->plane[1],
+                           d_bases, d_offsets, n_reads, d_keep, ctx->masks, ctx_buckets(ctx), ctx->plane[0], ctx->plane[1],
                            ctx->plane[2]);
         PALACE_HIP_TRY(hipGetLastError());
         ctx->table_clean = false;
@@ -1849,7 +1858,6 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
     PALACE_REQUIRE(d_p0 && d_p1 && d_u, "null device pointer");
     PALACE_REQUIRE(((reinterpret_cast<uintptr_t>(d_p0) | reinterpret_cast<uintptr_t>(d_p1) | reinterpret_cast<uintptr_t>(d_u)) & 7) == 0,
                    "the streams must be 8-byte aligned");
-    PALACE_REQUIRE(ctx->key_lo + ctx->key_n <= static_cast<uint32_t>(kL1Buckets), "key range (options key_buckets_lo / key_buckets_n) runs past the key space");
     PALACE_REQUIRE(!ctx->final_only, "the table holds only its \">= 3\" plane (option final_count): reset it first");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
@@ -1858,7 +1866,7 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
     if (!binned) {
         const int64_t blocks = std::min<int64_t>((n_positions + 255) / 256, static_cast<int64_t>(kCUs) * 8 * 8);
         hipLaunchKernelGGL(eref_count_packed_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d_p0, d_p1, d_u,
-                           n_positions, ctx->masks, KeyRange{ctx->key_lo, ctx->key_n}, ctx->plane[0], ctx->plane[1], ctx->plane[2]);
+                           n_positions, ctx->masks, ctx_buckets(ctx), ctx->plane[0], ctx->plane[1], ctx->plane[2]);
         PALACE_HIP_TRY(hipGetLastError());
         ctx->table_clean = false;
         return PALACE_OK;
@@ -1873,6 +1881,14 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
     carve_count(pl, static_cast<char *>(ctx->ws.ptr), false, &cb);
     const double keys_per_pos = n_reads_hint ? 3.0 * std::max(0.02, 1.0 - 31.0 * static_cast<double>(n_reads_hint) / static_cast<double>(n_positions)) : 3.0;
     return bin_and_count(ctx, pl, cb, d_p0, d_p1, d_u, n_positions, keys_per_pos);
+}
+
+int palace_eref_set_key_buckets(palace_ctx *ctx, const uint32_t mask128[4])
+{
+    PALACE_REQUIRE(ctx && mask128, "null argument");
+    PALACE_REQUIRE((mask128[0] | mask128[1] | mask128[2] | mask128[3]) != 0, "the set of key buckets is empty");
+    for (int i = 0; i < 4; i++) ctx->key_buckets[i] = mask128[i];
+    return PALACE_OK;
 }
 
 /* Tuning knobs of count_reads (see include/palace_hip.h). */
@@ -1893,12 +1909,6 @@ int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value)
     } else if (!std::strcmp(name, "final_count")) {          // the count calls that follow are each the only one between a reset and Phase B
         PALACE_REQUIRE(value == 0 || value == 1, "final_count must be 0 or 1");
         ctx->want_final = value != 0;
-    } else if (!std::strcmp(name, "key_buckets_lo") || !std::strcmp(name, "key_buckets_n")) {
-        // the 1/128ths of the key space (key >> 25) the count calls that follow take in: [lo, lo + n)
-        const bool is_lo = name[12] == 'l';
-        const int64_t lo = is_lo ? value : ctx->key_lo, n = is_lo ? ctx->key_n : value;
-        PALACE_REQUIRE(value >= 0 && lo <= kL1Buckets && n >= 1 && n <= kL1Buckets, "key range must lie inside the 128 buckets");
-        if (is_lo) ctx->key_lo = static_cast<uint32_t>(value); else ctx->key_n = static_cast<uint32_t>(value);
     } else if (!std::strcmp(name, "level1_parts")) {         // 0: by size; n: level 1 takes a slab in n parts beside level 2 (1: one stream)
         PALACE_REQUIRE(value >= 0 && value <= 64, "level1_parts must be 0 .. 64");
         ctx->level1_parts = static_cast<int>(value);

@@ -33,6 +33,18 @@ def split_by_weight(weights, rank: int, world: int):
     return cuts[rank], cuts[rank + 1]
 
 
+def key_buckets_of(rank: int, world: int):
+    """The level-1 buckets (key >> 25, 0..127) rank `rank` of `world` counts when the key space is split (every rank holds all
+    reads; palace_eref_set_key_buckets).  Canonical keys thin out linearly over the key space -- bucket b holds (255 - 2b) / 16384
+    of them -- so every block of 2 * world buckets gives a rank its r-th bucket and its mirror: equal key mass, 128 / world
+    buckets, i.e. 128 / world slices of 4 MiB of every plane.  world must divide 64."""
+    assert 64 % world == 0 and 0 <= rank < world
+    out = []
+    for base in range(0, 128, 2 * world):
+        out += [base + rank, base + 2 * world - 1 - rank]
+    return sorted(out)
+
+
 class Exchange:
     def __init__(self, torch, dist, rank: int, world: int):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
@@ -67,6 +79,22 @@ class Exchange:
             merge_fn(self._recv, W, self.rank * S, S, packed=True)
         mine = planes[2][self.rank * S:(self.rank + 1) * S].clone()
         dist.all_gather_into_tensor(planes[2], mine)
+
+    def gather_key_buckets(self, plane):
+        """plane: 1-D uint8 tensor of 2^29 bytes (the '>= 3' plane) of which this rank holds the 4 MiB slices of its buckets
+        (key_buckets_of); afterwards every rank holds all of it.  One all_gather of 512 MiB / world per rank: the slices are
+        packed into one buffer, gathered, and put back in place."""
+        torch, dist, W = self.torch, self.dist, self.world
+        rows = plane.view(128, -1)
+        idx = [torch.tensor(key_buckets_of(r, W), device=plane.device) for r in range(W)]
+        mine = rows.index_select(0, idx[self.rank]).contiguous()
+        if self._recv is None or self._recv.numel() != plane.numel():
+            self._recv = torch.empty(plane.numel(), dtype=torch.uint8, device=plane.device)
+        allp = self._recv.view(W, 128 // W, -1)
+        dist.all_gather_into_tensor(allp.view(-1), mine.view(-1))
+        for r in range(W):
+            if r != self.rank:
+                rows.index_copy_(0, idx[r], allp[r])
 
     # ---- small tables ------------------------------------------------------------------------------
     def gather_ranges(self, table, ranges):

@@ -612,10 +612,11 @@ def test_final_count_keeps_only_the_top_plane_and_leaves_the_others_zero(ctx, ca
 
 
 @pytest.mark.parametrize("mode", [1, 2])                                        # direct kernels / partition kernels
-def test_key_range_counts_exactly_its_share_of_the_key_space(ctx, mode):
-    """options key_buckets_lo / key_buckets_n: four calls over the same reads, a quarter of the key space each, give four
-    tables that are exact on their quarter and empty elsewhere (what four GPUs that each hold all reads would all-gather),
-    through the ASCII and the packed entry, with final_count as the bench uses it"""
+def test_key_buckets_count_exactly_their_share_of_the_key_space(ctx, mode):
+    """palace_eref_set_key_buckets: four calls over the same reads, each with the buckets a rank of four takes (mirrored pairs
+    {r, 7 - r} of every 8: equal key mass), give four tables that are exact on their buckets and empty elsewhere -- what four
+    GPUs that each hold all reads would gather --, through the ASCII and the packed entry, with final_count as the bench uses it"""
+    from palace_amd import multigpu
     rng = synth.rng_for(53)
     hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
     cc = orc.header_to_cc(hdr)
@@ -624,14 +625,18 @@ def test_key_range_counts_exactly_its_share_of_the_key_space(ctx, mode):
     streams, n_pos = pack_reads(rs.bases, rs.offsets)
     db, do = ctx.upload(rs.bases), ctx.upload(rs.offsets)
     ds = [ctx.upload(x) for x in streams]
+    shares = [multigpu.key_buckets_of(r, 4) for r in range(4)]
+    assert sorted(b for sh in shares for b in sh) == list(range(128))
+    mass = [sum(255 - 2 * b for b in sh) for sh in shares]
+    assert max(mass) == min(mass)                                               # the linear key density folds exactly
     try:
         ctx.eref_set_count_mode(mode, 0)
         ctx.eref_set_coder(hdr)
         total3 = 0
         for q in range(4):
-            mine = (u >> 25) // 32 == q
-            ctx.eref_set_option("key_buckets_lo", 32 * q)
-            ctx.eref_set_option("key_buckets_n", 32)
+            mine = np.isin(u >> 25, shares[q])
+            assert 0.2 < mine.mean() < 0.3
+            ctx.eref_set_key_buckets(shares[q])
             ctx.eref_table_reset()
             ctx.eref_count_reads(db, do, rs.n)
             ctx.sync()
@@ -652,11 +657,9 @@ def test_key_range_counts_exactly_its_share_of_the_key_space(ctx, mode):
         if mode == 2:
             assert total3 == int((c >= 3).sum())
         with pytest.raises(capi.PalaceError):
-            ctx.eref_set_option("key_buckets_lo", 120)
-            ctx.eref_count_reads(db, do, rs.n)                                  # 120 + 32 runs past the 128 buckets
+            ctx.eref_set_key_buckets([])                                        # an empty share is refused
     finally:
-        ctx.eref_set_option("key_buckets_lo", 0)
-        ctx.eref_set_option("key_buckets_n", 128)
+        ctx.eref_set_key_buckets(None)
         ctx.eref_set_option("final_count", 0)
         ctx.eref_set_count_mode(0, 0)
         ctx.eref_table_reset()

@@ -73,7 +73,16 @@ def worker(rank, world, port, q):
         t = torch.full((9,), rank + 1, dtype=torch.int64)
         ex.reduce_sum(t)
         ok_sum = bool((t == sum(range(1, world + 1))).all())
-        q.put((rank, ok_planes, ok_rows, ok_var, ok_sum))
+        # key-space split: a rank holds the plane slices of its buckets (mirrored pairs), afterwards everybody holds the plane
+        full_plane = torch.from_numpy(rng.integers(0, 256, size=128 * 64).astype(np.uint8))
+        plane = torch.zeros_like(full_plane)
+        for b in multigpu.key_buckets_of(rank, world):
+            plane.view(128, -1)[b] = full_plane.view(128, -1)[b]
+        ex.gather_key_buckets(plane)
+        ok_keys = bool(torch.equal(plane, full_plane))
+        shares = [multigpu.key_buckets_of(r, world) for r in range(world)]
+        ok_keys &= sorted(b for sh in shares for b in sh) == list(range(128)) and len({sum(255 - 2 * b for b in sh) for sh in shares}) == 1
+        q.put((rank, ok_planes, ok_rows, ok_var, ok_sum, ok_keys))
     finally:
         dist.destroy_process_group()
 
