@@ -28,6 +28,15 @@ extern "C" {
  * aligned); world == 1 is allowed (the calls degenerate to copies). */
 int palace_eref_table_exchange(palace_ctx *ctx, void *comm, int rank, int world);
 
+/* The other way to spread Phase A over the GPUs of a node, and the cheaper one when every rank can hold all reads (they are
+ * 0.375 bytes per base packed): every rank counts ALL reads but only the keys of its share of the key space
+ * (palace_eref_set_key_buckets with the mask palace_eref_key_share gives: mirrored pairs {r, 2W-1-r} of every 2W of the 128
+ * buckets -- equal key mass, since canonical keys thin out linearly over the key space); its 4 MiB slices of the ">= 3"
+ * plane are then exact, and palace_eref_key_share_gather completes the plane on every rank (each slice from its owner, in
+ * place, stream-ordered).  No partial tables, no merge.  world must divide 64. */
+int palace_eref_key_share(int rank, int world, uint32_t mask128[4]);
+int palace_eref_key_share_gather(palace_ctx *ctx, void *comm, int rank, int world);
+
 /* Phase B rows: every rank scanned the refs [ref_lo[r], ref_hi[r]) and holds their rows (4 x int32 per ref) in d_rows;
  * afterwards every rank holds all n_refs rows.  ref_lo / ref_hi: host arrays of `world` entries, the same on every rank. */
 int palace_eref_rows_allgather(palace_ctx *ctx, void *comm, int rank, int world, int32_t *d_rows, int64_t n_refs,

@@ -54,6 +54,37 @@ int palace_eref_table_exchange(palace_ctx *ctx, void *comm_, int rank, int world
     return PALACE_OK;
 }
 
+// ---- the key space split instead of the reads ----
+int palace_eref_key_share(int rank, int world, uint32_t mask128[4])
+{
+    PALACE_REQUIRE(mask128 && world >= 1 && rank >= 0 && rank < world && 64 % world == 0, "world must divide 64");
+    for (int i = 0; i < 4; i++) mask128[i] = 0;
+    for (int base = 0; base < 128; base += 2 * world)
+        for (int b : {base + rank, base + 2 * world - 1 - rank}) mask128[b >> 5] |= 1u << (b & 31);
+    return PALACE_OK;
+}
+
+int palace_eref_key_share_gather(palace_ctx *ctx, void *comm_, int rank, int world)
+{
+    PALACE_REQUIRE(ctx && comm_ && world >= 1 && rank >= 0 && rank < world && 64 % world == 0, "world must divide 64");
+    ncclComm_t comm = static_cast<ncclComm_t>(comm_);
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    void *planes[3];
+    size_t plane_bytes = 0;
+    int rc = palace_eref_table_planes(ctx, planes, &plane_bytes);
+    if (rc) return rc;
+    const size_t slice = plane_bytes / 128;                  // a level-1 bucket's 2^25 keys: 4 MiB of a plane
+    char *p3 = static_cast<char *>(planes[2]);
+    // every bucket's slice from its owner to everybody, in place, all of them in flight at once
+    PALACE_NCCL_TRY(ncclGroupStart());
+    for (int b = 0; b < 128; b++) {
+        const int x = b % (2 * world), owner = x < world ? x : 2 * world - 1 - x;
+        PALACE_NCCL_TRY(ncclBroadcast(p3 + b * slice, p3 + b * slice, slice, ncclUint8, owner, comm, ctx->stream));
+    }
+    PALACE_NCCL_TRY(ncclGroupEnd());
+    return PALACE_OK;
+}
+
 int palace_eref_rows_allgather(palace_ctx *ctx, void *comm_, int rank, int world, int32_t *d_rows, int64_t n_refs,
                                const int64_t *ref_lo, const int64_t *ref_hi)
 {

@@ -56,6 +56,15 @@ int main(int argc, char **argv)
                      (unsigned long long)after[2]);
         return 1;
     }
+    // the key space split one way: the share is everything, the gather leaves the plane as it is
+    uint32_t share[4];
+    CK(palace_eref_key_share(0, 1, share));
+    if ((share[0] & share[1] & share[2] & share[3]) != ~0u) { std::fprintf(stderr, "exchange_selftest: a one-rank share is not the whole key space\n"); return 1; }
+    CK(palace_eref_set_key_buckets(ctx, share));
+    CK(palace_eref_key_share_gather(ctx, comm, 0, 1));
+    CK(palace_sync(ctx));
+    CK(palace_eref_table_popcounts(ctx, after));
+    if (std::memcmp(before, after, sizeof before) != 0) { std::fprintf(stderr, "exchange_selftest: the share gather changed the planes\n"); return 1; }
     // rows: 5 refs, all owned by rank 0
     std::vector<int32_t> rows(20);
     for (int i = 0; i < 20; i++) rows[static_cast<size_t>(i)] = i * 3 + 1;

@@ -47,8 +47,16 @@ def test_rccl_library_exports_what_its_header_declares():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     text = open(os.path.join(root, "include", "palace_rccl.h")).read()
     names = sorted(set(re.findall(r"\b(palace_[a-z0-9_]+)\s*\(", text)) - {"palace_eref_table_pack_low", "palace_eref_table_merge_slices_packed"})
-    assert names == ["palace_eref_rows_allgather", "palace_eref_table_exchange"]
+    names = [n for n in names if n != "palace_eref_set_key_buckets"]                  # (libpalace_hip.so's, named in a comment)
+    assert names == ["palace_eref_key_share", "palace_eref_key_share_gather", "palace_eref_rows_allgather", "palace_eref_table_exchange"]
     capi.lib()                                                   # libpalace_hip.so first: the rccl library links it by name
     lib = ctypes.CDLL(os.path.join(root, "palace_amd", "libpalace_rccl.so"), mode=ctypes.RTLD_GLOBAL)
     for n in names:
         assert hasattr(lib, n), n
+    # the C and the Python statement of a rank's share agree
+    from palace_amd import multigpu
+    for world in (1, 2, 4, 8, 16):
+        for rank in range(world):
+            m = (ctypes.c_uint32 * 4)()
+            assert lib.palace_eref_key_share(rank, world, m) == 0
+            assert [b for b in range(128) if (m[b >> 5] >> (b & 31)) & 1] == multigpu.key_buckets_of(rank, world)
