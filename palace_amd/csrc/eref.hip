@@ -607,8 +607,8 @@ constexpr int kTile2Groups = kBin2Threads * kGroups2PerThread;   // 5120 groups 
 constexpr int kStage2Slots = kL2Rows * kRowSlots;
 
 struct Stage2 {
-    uint16_t slot[kStage2Slots];                      // 72 KiB
-    unsigned long long rows[kL2Rows];                 // (row end << 32) | next free slot
+    uint16_t slot[kStage2Slots + 2];                  // 72 KiB; [kStage2Slots]: where the appends that are none land
+    uint32_t rows[kL2Rows];                           // next free slot of the row (row r owns slots [r * kRowSlots, (r + 1) * kRowSlots))
 };
 
 struct Bin2Out {
@@ -668,34 +668,35 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
         const uint32_t i = start + it * kBin2Threads + threadIdx.x;
         v[it] = i < end ? src[i] : uint4{0, 0, 0, 0};     // (count 0: nothing to append)
     }
-    if (threadIdx.x < kL2Rows)
-        st.rows[threadIdx.x] = (static_cast<unsigned long long>((threadIdx.x + 1) * kRowSlots) << 32) | (threadIdx.x * kRowSlots);
+    if (threadIdx.x < kL2Rows) st.rows[threadIdx.x] = threadIdx.x * kRowSlots;
     const uint32_t cap = fine_sub_cap(o.caps, b1), xcd = xcc_id();          // this XCD's share of every fine region
     __syncthreads();
+    // The appends carry no branches: the kernel is bound by its vector and scalar instruction issue (~45 vector instructions
+    // per key before this form, 77 % of the kernel's time at full issue rate), and every `if` around an LDS operation costs an
+    // exec-mask round.  A slot of a group that holds no key (only a run's last group has such) adds 0 to a row; a key
+    // that finds no room, and a slot that is none, write to the spare slot behind the rows.
 #pragma unroll
     for (int it = 0; it < kGroups2PerThread; it++) {
         uint32_t k[kGroupKeys];
         const uint32_t n = unpack_group(v[it], k);
-        unsigned long long r[kGroupKeys];
+        uint32_t at[kGroupKeys];
 #pragma unroll
-        for (uint32_t e = 0; e < kGroupKeys; e++)
-            if (e < n) r[e] = atomicAdd(&st.rows[k[e] >> kFineBits], 1ull);         // (25-bit record: bits 24..16 are the fine row)
+        for (uint32_t e = 0; e < kGroupKeys; e++) at[e] = atomicAdd(&st.rows[k[e] >> kFineBits], e < n ? 1u : 0u);   // (25-bit record: bits 24..16 are the fine row)
 #pragma unroll
-        for (uint32_t e = 0; e < kGroupKeys; e++)
-            if (e < n) {
-                const uint32_t at = static_cast<uint32_t>(r[e]);
-                if (at < static_cast<uint32_t>(r[e] >> 32)) st.slot[at] = static_cast<uint16_t>(k[e]);
-                else {
-                    // Row full (a row holds 72 of the tile's keys, mean 50: about one key in a thousand): the key goes to its
-                    // fine region as a run of its own.  It used to take the direct-atomic path, which marks the fine bucket
-                    // `touched` -- and with ~50 000 such keys per launch 38 % of the 65 536 count workgroups then began by
-                    // seeding their 24 KiB of plane slices from HBM (0.6 GB per launch, PMC) for the sake of one or two keys.
-                    const uint32_t row = k[e] >> kFineBits;
-                    const uint32_t gg = atomicAdd(&o.cursor[(b1 * kL2Rows + row) * kXcds + xcd], 1u);
-                    if (gg < cap) o.buf[fine_region_base(o.caps, b1, row) + static_cast<uint64_t>(xcd) * cap + gg] = static_cast<uint16_t>(k[e]);
-                    else count_key_marked((b1 << kL1Shift) | k[e], o.p1, o.p2, o.p3, o.touched);   // region full as well: exact slow path
-                }
+        for (uint32_t e = 0; e < kGroupKeys; e++) {
+            const uint32_t row = k[e] >> kFineBits;
+            const bool is_key = e < n, fits = at[e] < (row + 1) * kRowSlots;
+            st.slot[is_key && fits ? at[e] : kStage2Slots] = static_cast<uint16_t>(k[e]);
+            if (is_key && !fits) {
+                // Row full (a row holds 72 of the tile's keys, mean 50: about one key in a thousand): the key goes to its
+                // fine region as a run of its own.  It used to take the direct-atomic path, which marks the fine bucket
+                // `touched` -- and with ~50 000 such keys per launch 38 % of the 65 536 count workgroups then began by
+                // seeding their 24 KiB of plane slices from HBM (0.6 GB per launch, PMC) for the sake of one or two keys.
+                const uint32_t gg = atomicAdd(&o.cursor[(b1 * kL2Rows + row) * kXcds + xcd], 1u);
+                if (gg < cap) o.buf[fine_region_base(o.caps, b1, row) + static_cast<uint64_t>(xcd) * cap + gg] = static_cast<uint16_t>(k[e]);
+                else count_key_marked((b1 << kL1Shift) | k[e], o.p1, o.p2, o.p3, o.touched);   // region full as well: exact slow path
             }
+        }
     }
     __syncthreads();
     // flush: a wave owns 32 rows; the first 32 lanes reserve the runs (one 128-byte piece of the cursor array) and work
@@ -707,8 +708,7 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
     bool over = false;
     if (lane < rows_per_wave) {
         const uint32_t row = row0 + lane;
-        const unsigned long long r = st.rows[row];
-        c = min(static_cast<uint32_t>(r), static_cast<uint32_t>(r >> 32)) - row * kRowSlots;
+        c = min(st.rows[row], (row + 1) * kRowSlots) - row * kRowSlots;
         if (c) g = atomicAdd(&o.cursor[(b1 * kL2Rows + row) * kXcds + xcd], c);
         over = static_cast<uint64_t>(g) + c > cap;
         const uint64_t ptr = reinterpret_cast<uint64_t>(o.buf + fine_region_base(o.caps, b1, row) + static_cast<uint64_t>(xcd) * cap + min(g, cap));
