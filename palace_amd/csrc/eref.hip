@@ -675,6 +675,7 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
     // per key before this form, 77 % of the kernel's time at full issue rate), and every `if` around an LDS operation costs an
     // exec-mask round.  A slot of a group that holds no key (only a run's last group has such) adds 0 to a row; a key
     // that finds no room, and a slot that is none, write to the spare slot behind the rows.
+    uint32_t homeless = 0;                                 // bit 5 * it + e: that key found its row full
 #pragma unroll
     for (int it = 0; it < kGroups2PerThread; it++) {
         uint32_t k[kGroupKeys];
@@ -687,11 +688,25 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
             const uint32_t row = k[e] >> kFineBits;
             const bool is_key = e < n, fits = at[e] < (row + 1) * kRowSlots;
             st.slot[is_key && fits ? at[e] : kStage2Slots] = static_cast<uint16_t>(k[e]);
-            if (is_key && !fits) {
-                // Row full (a row holds 72 of the tile's keys, mean 50: about one key in a thousand): the key goes to its
-                // fine region as a run of its own.  It used to take the direct-atomic path, which marks the fine bucket
-                // `touched` -- and with ~50 000 such keys per launch 38 % of the 65 536 count workgroups then began by
-                // seeding their 24 KiB of plane slices from HBM (0.6 GB per launch, PMC) for the sake of one or two keys.
+            homeless |= (is_key && !fits ? 1u : 0u) << (kGroupKeys * it + e);
+        }
+    }
+    if (homeless) {
+        // Row full (a row holds 72 of the tile's keys, mean 50: about one key in a thousand): the key goes to its fine region
+        // as a run of its own.  It used to take the direct-atomic path, which marks the fine bucket `touched` -- and with
+        // ~50 000 such keys per launch 38 % of the 65 536 count workgroups then began by seeding their 24 KiB of plane slices
+        // from HBM (0.6 GB per launch, PMC) for the sake of one or two keys.
+        // (unrolled: v[] and k[] indexed by a loop variable would live in scratch memory)
+#pragma unroll
+        for (int it = 0; it < kGroups2PerThread; it++) {
+            if (!((homeless >> (kGroupKeys * it)) & 31u)) continue;
+            uint32_t k[kGroupKeys];
+            unpack_group(src[start + it * kBin2Threads + threadIdx.x], k);        // (loaded again: keeping v[] alive until here costs 20 registers,
+                                                                                  //  and with them the second workgroup of the CU)
+#pragma unroll
+            for (uint32_t e = 0; e < kGroupKeys; e++) {
+                if (!((homeless >> (kGroupKeys * it + e)) & 1u)) continue;
+                const uint32_t row = k[e] >> kFineBits;
                 const uint32_t gg = atomicAdd(&o.cursor[(b1 * kL2Rows + row) * kXcds + xcd], 1u);
                 if (gg < cap) o.buf[fine_region_base(o.caps, b1, row) + static_cast<uint64_t>(xcd) * cap + gg] = static_cast<uint16_t>(k[e]);
                 else count_key_marked((b1 << kL1Shift) | k[e], o.p1, o.p2, o.p3, o.touched);   // region full as well: exact slow path
@@ -715,6 +730,8 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
         p_lo = static_cast<uint32_t>(ptr); p_hi = static_cast<uint32_t>(ptr >> 32);
     }
     const unsigned long long over_rows = __ballot(over);
+    const uint32_t c_fast = over ? 0u : c;                  // (a run that does not fit is left to the pass below: no lane stores it here --
+                                                            //  cheaper than a scalar test per row: the flush is bound by the CU's scalar unit)
     // rows in batches of 16: all LDS reads of a batch first, then its stores back to back (a row holds at most 72 slots:
     // one more, short pass for the fullest rows)
 #pragma unroll
@@ -724,10 +741,9 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
         for (int j = 0; j < 16; j++) k[j] = st.slot[(row0 + j0 + j) * kRowSlots + lane];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            const uint32_t cj = __builtin_amdgcn_readlane(c, j0 + j);
+            const uint32_t cj = __builtin_amdgcn_readlane(c_fast, j0 + j);
             const uint32_t bl = __builtin_amdgcn_readlane(p_lo, j0 + j), bh = __builtin_amdgcn_readlane(p_hi, j0 + j);
             global_u16 *dst = reinterpret_cast<global_u16 *>((static_cast<uint64_t>(bh) << 32) | bl);
-            if ((over_rows >> (j0 + j)) & 1ull) continue;          // wave-uniform; handled below
             if (lane < cj) dst[lane] = k[j];
         }
     }
