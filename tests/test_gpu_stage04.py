@@ -178,3 +178,78 @@ def test_stage04_inside_generateGraph_writes_the_files_of_the_chain(tmp_path, se
     for name in ("graph", "pre", "filt", "hits", "lin", "cyc", "nodup", "all"):
         assert open(P(f"f_{name}.txt"), "rb").read() == open(P(f"c_{name}.txt"), "rb").read(), name
     assert open(P("c_all.txt")).read().count("\t") > 5 and open(P("c_pre.txt")).read().count("JUNC") > 5
+
+
+# ---- hypothesis: the device selection against the script on adversarial graphs ---------------------------------------------------
+from hypothesis import HealthCheck, given, settings, strategies as hst
+
+
+@hst.composite
+def filter_cases(draw):
+    """small graphs chosen to break the selection: self loops, junctions listed twice and in both directions, seeds that touch
+    nothing, chains seed - a - b - c (pass 3 must stop after two hops), paths whose supported share sits at the 0.5 / 2000-base
+    edges, paths with ';' and with NODE header lines, a contig on several paths, scores in e-notation and just at the threshold"""
+    n = draw(hst.integers(3, 14))
+    lens = [draw(hst.sampled_from([56, 100, 999, 1000, 1001, 2000, 2001, 4000])) for _ in range(n)]
+    names = ["EDGE_%d_length_%d_cov_%d.5" % (i + 1, lens[i], i + 1) for i in range(n)]
+    blast = draw(hst.sets(hst.integers(0, n - 1), max_size=3))
+    gene = draw(hst.sets(hst.integers(0, n - 1), max_size=2))
+    score = [draw(hst.sampled_from(["0.100", "0.700", "0.701", "0.999", "1e-05", "7.01e-01", "0.5"])) for _ in range(n)]
+    order = draw(hst.permutations(range(n)))                              # SEG order in the graph file != fai order
+    juncs, keys = [], set()
+    for _ in range(draw(hst.integers(0, 18))):
+        a, b = draw(hst.integers(0, n - 1)), draw(hst.integers(0, n - 1))
+        j = (a, draw(hst.sampled_from("+-")), b, draw(hst.sampled_from("+-")), draw(hst.integers(5, 40)), draw(hst.integers(0, 3)))
+        if j[:4] not in keys:                                             # (generateGraph aggregates: one line per oriented pair)
+            keys.add(j[:4])
+            juncs.append(j)
+    if juncs and draw(hst.booleans()):
+        juncs.append(juncs[0])                                            # the same JUNC line twice
+    paths = []
+    for _ in range(draw(hst.integers(0, 5))):
+        members = [draw(hst.integers(0, n - 1)) for _ in range(draw(hst.integers(1, 5)))]
+        paths.append(",".join("%d%s" % (m + 1, draw(hst.sampled_from("+-"))) for m in members) + draw(hst.sampled_from(["", ";"])))
+    return n, lens, names, blast, gene, score, order, juncs, paths
+
+
+@settings(max_examples=120, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(filter_cases())
+def test_device_selection_equals_the_script_on_adversarial_graphs(case):
+    import tempfile
+    from pathlib import Path
+    n, lens, names, blast, gene, score, order, juncs, paths = case
+    files = dict(
+        fasta_fai="".join("%s\t%d\t0\t60\t61\n" % (names[i], lens[i]) for i in range(n)),
+        # one blast hit row per seed: full-length, 99 % identity (cumulative aligned length / length > 0.7)
+        blast="".join("%s\tref1\t99.0\t%d\t0\t0\t1\t%d\t1\t%d\t0.0\t100\n" % (names[i], lens[i], lens[i], lens[i]) for i in sorted(blast)),
+        hit_seqs="".join(">%s\n" % names[i] for i in sorted(gene)),
+        node_scores="".join("%s\t%s\n" % (names[i], score[i]) for i in range(n)),
+        contigs_paths="".join("NODE_%d_length_9_cov_1\n%s\n" % (k + 1, p) for k, p in enumerate(paths)),
+        graph="".join("SEG %s %g %d\n" % (names[i], 3.5 + i, 1 + i % 3) for i in order) +
+              "".join("JUNC %s %s %s %s %d %d\n" % (names[a], oa, names[b], ob, c1, c2) for a, oa, b, ob, c1, c2 in juncs),
+    )
+    with tempfile.TemporaryDirectory(prefix="palace_s4fuzz_") as d:
+        tmp = Path(d)
+        for k, v in files.items():
+            (tmp / k).write_text(v)
+        (tmp / "fastg_fai").write_text("x\t1\t0\t60\t61\n")
+        rc = _script_filter().run([str(tmp / "fastg_fai"), str(tmp / "graph"), str(tmp / "pre"), "5.0", "0", str(tmp / "hit_seqs"), str(tmp / "node_scores"),
+                                   str(tmp / "blast"), "0.7", str(tmp / "fasta_fai"), str(tmp / "hits"), str(tmp / "contigs_paths"), "0.7"])
+        assert rc == 0
+        want = (tmp / "pre").read_text().splitlines(keepends=True)
+        case_arrays = _load_case(files, tmp)
+    # the graph file lists SEG lines in `order`: that is the rank the device orders the selected segments by
+    rank = np.empty(n, np.int32)
+    rank[list(order)] = np.arange(n, dtype=np.int32)
+    case_arrays["rank"] = rank
+    with capi.Ctx(0) as ctx:
+        st, d_e, d_n = _run_filter(ctx, case_arrays, min_count=0)
+        seg_flags, edge_flags = st.flags(len(case_arrays["edges"]))
+        st.close()
+    flt, nm = case_arrays["flt"], case_arrays["names"]
+    got_seg = sorted([flt.seg_line(nm[i], case_arrays["raw_seg"][nm[i]]) for i in np.flatnonzero(seg_flags & 1)] +
+                     [case_arrays["raw_seg"][nm[i]].strip() + " 0 1.0 0\n" for i in np.flatnonzero((seg_flags & 3) == 2)])
+    jl = case_arrays["junc_lines"]
+    got_junc = [l for l, f in zip(jl, edge_flags) if f & 2] + [l for l, f in zip(jl, edge_flags) if (f & 6) == 4]
+    assert got_seg == sorted(l for l in want if l.startswith("SEG"))
+    assert got_junc == [l for l in want if not l.startswith("SEG")]
