@@ -253,3 +253,40 @@ def test_device_selection_equals_the_script_on_adversarial_graphs(case):
     got_junc = [l for l, f in zip(jl, edge_flags) if f & 2] + [l for l, f in zip(jl, edge_flags) if (f & 6) == 4]
     assert got_seg == sorted(l for l in want if l.startswith("SEG"))
     assert got_junc == [l for l in want if not l.startswith("SEG")]
+
+
+@settings(max_examples=50, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(filter_cases(), hst.sampled_from([["-s"], ["-s", "-b"], ["--aggressive"], []]))
+def test_device_stage04_equals_the_file_chain_on_adversarial_graphs(case, flags):
+    """the same adversarial graphs through selection + decomposition on the device against scripts/filter_graph.py -> uniq ->
+    bin/matching on files: SEG order of the filtered graph, linear and cycle files byte for byte (copy numbers 1..3, self
+    loops, junctions in both directions, path arcs between kept and dropped contigs)"""
+    import tempfile
+    from pathlib import Path
+    n, lens, names, blast, gene, score, order, juncs, paths = case
+    files = dict(
+        fasta_fai="".join("%s\t%d\t0\t60\t61\n" % (names[i], lens[i]) for i in range(n)),
+        blast="".join("%s\tref1\t99.0\t%d\t0\t0\t1\t%d\t1\t%d\t0.0\t100\n" % (names[i], lens[i], lens[i], lens[i]) for i in sorted(blast)),
+        hit_seqs="".join(">%s\n" % names[i] for i in sorted(gene)),
+        node_scores="".join("%s\t%s\n" % (names[i], score[i]) for i in range(n)),
+        contigs_paths="".join("NODE_%d_length_9_cov_1\n%s\n" % (k + 1, p) for k, p in enumerate(paths)),
+        fastg_fai="x\t1\t0\t60\t61\n",
+        # (SEG lines in name order, as generateGraph writes them: the device's segment order is the name rank)
+        graph="".join("SEG %s %g %d\n" % (names[i], 3.5 + i, 1 + i % 3) for i in sorted(range(n), key=lambda i: names[i].encode())) +
+              "".join("JUNC %s %s %s %s %d %d\n" % (names[a], oa, names[b], ob, c1, c2) for a, oa, b, ob, c1, c2 in juncs),
+    )
+    with tempfile.TemporaryDirectory(prefix="palace_s4fuzz_") as d:
+        tmp = Path(d)
+        lin, cyc, filt = _file_chain(tmp, files, 5.0, flags)
+        case_arrays = _load_case(files, tmp)
+    with capi.Ctx(0) as ctx:
+        st, d_e, d_n = _run_filter(ctx, case_arrays, min_count=0)
+        d_cn = ctx.upload(case_arrays["cn"])
+        st.match(d_e.ptr, d_cn.ptr, 10, "--aggressive" in flags, True)
+        res, contig_of = st.result()
+        got_lin, got_cyc = stage04_io.matching_text(res, contig_of, case_arrays["names"], self_loops="-s" in flags, break_cycles="-b" in flags)
+        seg_order = [case_arrays["names"][c] for c in contig_of]
+        st.close()
+    assert seg_order == [l.split(" ")[1] for l in filt.splitlines() if l.startswith("SEG")]
+    assert got_lin == lin
+    assert got_cyc == cyc
