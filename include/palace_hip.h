@@ -362,6 +362,10 @@ typedef struct palace_match_result palace_match_result;
  * iterations behind a round's fixed point return at once); the host looks at the state after each group, stops as soon as no
  * segment keeps a copy, and redoes the decomposition with a check after every batch of iterations should a round not have
  * settled.  "iters_per_round" overrides the number of iterations (0 = defaults, at most 64; 1 forces the checked path);
+ * "launch_graphs" 1: palace_stage04_filter / _match capture their launch sequences (about 10 and 160 kernels with fixed grids
+ * that read their counts from device memory) as hipGraphs at the first call with a set of arguments and replay them while the
+ * arguments -- edge array, copy numbers, iterations, flags -- stay the same: for a resident caller that runs sample after
+ * sample through the same buffers.  0 (default): plain launches (a one-shot process would only pay for the capture).
  * "first_group_rounds" the rounds enqueued before the first look at the state (0 = default 5; fewer launches beside other
  * work, one host round trip more when a second round is needed: no effect on the step time where measured). */
 int palace_match_set_option(palace_ctx *ctx, const char *name, int64_t value);

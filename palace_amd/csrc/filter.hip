@@ -442,6 +442,10 @@ struct palace_stage04 {
     palace::DecompState *h_ds = nullptr;
     palace_match_result res;
     int32_t *h_contig_of = nullptr;
+    // option launch_graphs: the launch sequences of filter / match as hipGraphs, captured at the first call with a set of
+    // arguments and replayed while they stay the same (kernels have fixed grids and read their counts from device memory)
+    struct Captured { hipGraphExec_t exec = nullptr; uint64_t key = 0; } g_filter, g_match;
+    uint64_t generation = 0;          // bumped whenever a device block moves: graphs of an older generation are stale
 };
 
 using namespace palace;
@@ -449,6 +453,35 @@ using namespace palace;
 namespace {
 
 const dim3 kG(1024), kB(kDecompBlock);           // fixed grid of the grid-stride kernels over contigs / edges / path lines
+
+uint64_t mix_key(uint64_t h, uint64_t v) { return (h ^ v) * 0x9E3779B97F4A7C15ull + (h >> 29); }
+
+// Runs `enqueue` (asynchronous launches on ctx->stream only) -- directly, or, with the option launch_graphs, as a hipGraph
+// captured once per `key` and replayed: ~10 / ~160 kernel launches become one graph launch per call.
+template <class Fn>
+int run_maybe_captured(palace_ctx *ctx, palace_stage04::Captured &g, uint64_t key, Fn &&enqueue)
+{
+    if (!ctx->launch_graphs) return enqueue();
+    if (g.exec && g.key != key) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    if (!g.exec) {
+        PALACE_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue();
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);            // (always: the stream must leave capture mode)
+        if (rc || e != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            if (rc) return rc;
+            set_error("stage04: hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            return PALACE_EHIP;
+        }
+        const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) { g.exec = nullptr; set_error("stage04: hipGraphInstantiate failed: %s", hipGetErrorString(ei)); return PALACE_EHIP; }
+        g.key = key;
+    }
+    PALACE_HIP_TRY(hipGraphLaunch(g.exec, ctx->stream));
+    return PALACE_OK;
+}
 
 int grow_pinned(palace_ctx *ctx, palace_stage04 *s, size_t bytes)
 {
@@ -494,6 +527,7 @@ int grow_device(palace_ctx *ctx, palace_stage04 *s, int64_t edge_bound, int roun
         PALACE_HIP_TRY(hipMemsetAsync(s->f.t.key, 0xff, slots * 8, ctx->stream));       // empty; every use leaves it empty again
         PALACE_HIP_TRY(hipMemsetAsync(s->f.t.w, 0, slots * 8, ctx->stream));
         s->edge_bound = edge_bound; s->s_cap = s_cap; s->e_cap = e_cap; s->comp_cap = comp_cap; s->vert_cap = vert_cap; s->rounds = rounds;
+        s->generation++;                                                               // captured launch sequences point into the old block
     }
     s->f.edge_bound = s->edge_bound;
     return PALACE_OK;
@@ -581,6 +615,8 @@ int palace_stage04_destroy(palace_ctx *ctx, palace_stage04 *s)
 {
     if (!s) return PALACE_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    if (s->g_filter.exec) (void)hipGraphExecDestroy(s->g_filter.exec);
+    if (s->g_match.exec) (void)hipGraphExecDestroy(s->g_match.exec);
     if (s->fixed) (void)hipFree(s->fixed);
     if (s->grown) (void)hipFree(s->grown);
     if (s->pin) (void)hipHostFree(s->pin);
@@ -604,18 +640,23 @@ int palace_stage04_filter(palace_ctx *ctx, palace_stage04 *s, const palace_graph
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = grow_device(ctx, s, std::max<int64_t>(edge_bound, s->edge_bound), std::max(s->rounds, 11));
     if (rc) return rc;
-    const F &f = s->f;
-    hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(st4_begin_kernel, kG, kB, 0, st, f, d_n_edges);
-    hipLaunchKernelGGL(st4_pass2_kernel, kG, kB, 0, st, f, d_edges);
-    hipLaunchKernelGGL(st4_pass3_kernel, kG, kB, 0, st, f, d_edges);
-    hipLaunchKernelGGL(st4_paths_kernel, kG, kB, 0, st, f);
-    hipLaunchKernelGGL(st4_order_kernel, kG, kB, 0, st, f);
-    PALACE_HIP_TRY(hipGetLastError());
-    rc = scan_u64(ctx, f.scan_in, f.scan_out, &f.fs->n_segs, s->b.partials, &f.fs->scan_total);
+    uint64_t key = mix_key(mix_key(mix_key(s->generation, reinterpret_cast<uint64_t>(d_edges)), reinterpret_cast<uint64_t>(d_n_edges)), 1);
+    rc = run_maybe_captured(ctx, s->g_filter, key, [&]() -> int {
+        const F &f = s->f;
+        hipStream_t st = ctx->stream;
+        hipLaunchKernelGGL(st4_begin_kernel, kG, kB, 0, st, f, d_n_edges);
+        hipLaunchKernelGGL(st4_pass2_kernel, kG, kB, 0, st, f, d_edges);
+        hipLaunchKernelGGL(st4_pass3_kernel, kG, kB, 0, st, f, d_edges);
+        hipLaunchKernelGGL(st4_paths_kernel, kG, kB, 0, st, f);
+        hipLaunchKernelGGL(st4_order_kernel, kG, kB, 0, st, f);
+        PALACE_HIP_TRY(hipGetLastError());
+        int rc2 = scan_u64(ctx, f.scan_in, f.scan_out, &f.fs->n_segs, s->b.partials, &f.fs->scan_total);
+        if (rc2) return rc2;
+        hipLaunchKernelGGL(st4_ids_kernel, kG, kB, 0, st, f);
+        PALACE_HIP_TRY(hipGetLastError());
+        return PALACE_OK;
+    });
     if (rc) return rc;
-    hipLaunchKernelGGL(st4_ids_kernel, kG, kB, 0, st, f);
-    PALACE_HIP_TRY(hipGetLastError());
     s->filtered = true;
     s->matched = false;
     return PALACE_OK;
@@ -656,18 +697,40 @@ int palace_stage04_match_after(palace_ctx *ctx, palace_stage04 *s, const palace_
     PALACE_REQUIRE(rounds <= s->rounds, "more rounds than the filter call reserved room for (at most 10 iterations + aggressive)");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     s->d_cn = d_cn; s->aggressive = aggressive ? 1 : 0;
-    int rc = enqueue_match(ctx, s, d_edges, use_paths != 0);
-    if (rc) return rc;
     // the first group of rounds goes out now; palace_stage04_result looks at the state after it and continues while segments
     // keep copies (a typical sample is done after the first group)
     s->run = DecompRun{};
-    if (other) {                                             // the arcs are built; the rounds wait for the other stream's mark
-        rc = palace_wait_for_mark(ctx, other, mark);
-        if (rc) return rc;
+    s->f.use_paths = use_paths ? 1 : 0;
+    auto enqueue = [&]() -> int {
+        int rc2 = enqueue_match(ctx, s, d_edges, use_paths != 0);
+        if (rc2) return rc2;
+        if (other) {                                         // the arcs are built; the rounds wait for the other stream's mark
+            rc2 = palace_wait_for_mark(ctx, other, mark);
+            if (rc2) return rc2;
+        }
+        s->run = DecompRun{};
+        if ((rc2 = decomp_begin(ctx, s->b, rounds, s->comp_cap, s->vert_cap))) return rc2;
+        if ((rc2 = decomp_group(ctx, s->b, s->run, rounds, s->aggressive, false))) return rc2;
+        PALACE_HIP_TRY(hipMemcpyAsync(s->h_fs, s->f.fs, sizeof(FilterState), hipMemcpyDeviceToHost, ctx->stream));
+        return PALACE_OK;
+    };
+    int rc;
+    if (other) rc = enqueue();                               // (a wait for another stream's event is not captured)
+    else {
+        uint64_t key = mix_key(mix_key(mix_key(s->generation, reinterpret_cast<uint64_t>(d_edges)), reinterpret_cast<uint64_t>(d_cn)), 2);
+        key = mix_key(key, (static_cast<uint64_t>(rounds) << 32) | (s->aggressive << 2) | (use_paths ? 2 : 0));
+        key = mix_key(key, (static_cast<uint64_t>(ctx->match_iters) << 32) | static_cast<uint32_t>(ctx->match_first_group));
+        rc = run_maybe_captured(ctx, s->g_match, key, enqueue);
+        if (!rc && ctx->launch_graphs) {                     // a replay did not run the host side of decomp_group: the state it leaves
+            DecompRun r{};
+            const int first = ctx->match_first_group > 0 ? ctx->match_first_group : kFirstGroupRounds;
+            r.next_round = std::min(rounds, first);
+            for (int t = 0; t < r.next_round; t++)
+                r.count += ctx->match_iters > 0 ? std::min(ctx->match_iters, kMaxIters) : (t == 0 ? kFirstRoundIters : kLaterRoundIters);
+            s->run = r;
+        }
     }
-    if ((rc = decomp_begin(ctx, s->b, rounds, s->comp_cap, s->vert_cap))) return rc;
-    if ((rc = decomp_group(ctx, s->b, s->run, rounds, s->aggressive, false))) return rc;
-    PALACE_HIP_TRY(hipMemcpyAsync(s->h_fs, s->f.fs, sizeof(FilterState), hipMemcpyDeviceToHost, ctx->stream));
+    if (rc) return rc;
     s->rounds = std::max(s->rounds, rounds);
     s->matched = true;
     s->last_rounds = rounds;

@@ -387,6 +387,9 @@ int palace_match_set_option(palace_ctx *ctx, const char *name, int64_t value)
     if (!std::strcmp(name, "iters_per_round")) {
         PALACE_REQUIRE(value >= 0 && value <= palace::kMaxIters, "iters_per_round out of range");
         ctx->match_iters = static_cast<int>(value);
+    } else if (!std::strcmp(name, "launch_graphs")) {
+        PALACE_REQUIRE(value == 0 || value == 1, "launch_graphs must be 0 or 1");
+        ctx->launch_graphs = value != 0;
     } else if (!std::strcmp(name, "first_group_rounds")) {
         PALACE_REQUIRE(value >= 0 && value <= palace::kMaxRounds, "first_group_rounds out of range");
         ctx->match_first_group = static_cast<int>(value);
