@@ -701,8 +701,8 @@ def main():
     hdr = coder.header_from_picks(np.random.Generator(np.random.PCG64(SEED)).integers(0, 6, size=32))
     ctx = capi.Ctx(local)                      # eref stream
     ctx_g = capi.Ctx(local, high_priority=os.environ.get("PALACE_BENCH_PRIO", "1") == "1")   # generateGraph + matching stream (independent of eref until the end)
-    if os.environ.get("PALACE_BENCH_GRAPHS", "1") == "1":     # the step runs sample after sample through the same buffers: stage 04 as two hipGraph launches
-        ctx_g.match_set_option("launch_graphs", 1)
+    if os.environ.get("PALACE_BENCH_GRAPHS", "0") == "1":     # stage 04 as two hipGraph launches per step (measured: host enqueue 1.25 -> 0.96 ms,
+        ctx_g.match_set_option("launch_graphs", 1)            # the step 10.95 -> 11.08 ms: back to back the small kernels disturb the counting kernels more)
     for opt in ("iters_per_round", "first_group_rounds"):    # tuning runs only
         if os.environ.get("PALACE_OPT_" + opt.upper()):
             ctx_g.match_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
