@@ -743,10 +743,8 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
         for (int j = 0; j < 16; j++) {
             const uint32_t cj = __builtin_amdgcn_readlane(c_fast, j0 + j);
             const uint32_t bl = __builtin_amdgcn_readlane(p_lo, j0 + j), bh = __builtin_amdgcn_readlane(p_hi, j0 + j);
-            // a buffer store whose descriptor ends behind the run: the hardware drops the lanes >= cj, no exec-mask round per row
-            const __amdgpu_buffer_rsrc_t run = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>((static_cast<uint64_t>(bh) << 32) | bl), 0,
-                                                                                   static_cast<int>(2 * cj), 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b16(static_cast<short>(k[j]), run, 2 * lane, 0, 0);
+            global_u16 *dst = reinterpret_cast<global_u16 *>((static_cast<uint64_t>(bh) << 32) | bl);
+            if (lane < cj) dst[lane] = k[j];
         }
     }
     unsigned long long more = __ballot(lane < rows_per_wave && (c > 64 || over));
