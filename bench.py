@@ -685,8 +685,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    force_exchange = os.environ.get("PALACE_FORCE_EXCHANGE") == "1"      # rehearse the N>1 code path on one GPU
-    if world > 1 or force_exchange:
+    force_exchange = os.environ.get("PALACE_FORCE_EXCHANGE") == "1"      # rehearse the N>1 code path on one GPU (reads sharded, table exchange)
+    force_key_split = os.environ.get("PALACE_FORCE_KEY_SPLIT") == "1"    # ... and the key-space split with its gather (one rank: its share is everything)
+    collectives = world > 1 or force_exchange or force_key_split
+    if collectives:
         import torch.distributed as dist
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -707,7 +709,7 @@ def main():
         if os.environ.get("PALACE_OPT_" + opt.upper()):
             ctx_g.match_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
     # one GPU: a second eref context (own stream, own count table, own scratch) so that consecutive batches overlap
-    depth = args.batches_in_flight if (world == 1 and not force_exchange) else 1
+    depth = args.batches_in_flight if not collectives else 1
     ectx = [ctx] + [capi.Ctx(local) for _ in range(depth - 1)]
     for e in ectx:
         e.eref_set_coder(hdr)
@@ -729,7 +731,7 @@ def main():
     long_mode = args.workload == "long"
     sample = make_sample(torch, dev, args.contigs, args.refs, rank if shard_reads else 0, world if shard_reads else 1, long_mode)
     gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world, long_mode)
-    if world > 1 or force_exchange:                 # avgDepth is a pipeline input: computed once from all shards
+    if collectives:                                 # avgDepth is a pipeline input: computed once from all shards
         tot = torch.tensor([float(gs["col"]["ref_len"].sum().item())], device=dev, dtype=torch.float64)
         dist.all_reduce(tot)
         gs["avg_depth"] = float(f"{tot.item() / gs['lens'].sum():.6g}")
@@ -758,7 +760,7 @@ def main():
         stage04 = capi.Stage04(ctx_g, gs["side"]["seed"], gs["lens"].astype(np.int32), gs["trank"].cpu().numpy(), gs["lens"].astype(np.int32),
                                gs["side"]["path_off"], gs["side"]["path_tok"], 5)
     n_edges_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-    exch = multigpu.Exchange(torch, dist, rank, world) if (world > 1 or force_exchange) else None
+    exch = multigpu.Exchange(torch, dist, rank, world) if collectives else None
     # torch ops and collectives run on torch's current stream, the library's kernels on the two context streams; the
     # hand-over points wait for exactly the stream that produced the data (a device-wide synchronize here would make the
     # generateGraph exchange wait for the eref counting kernels and vice versa)
@@ -807,7 +809,7 @@ def main():
     # where they are made: the partition kernels move 1/W of the bytes, the key arithmetic stays) and the ">= 3" plane slices
     # are all-gathered -- one collective of 512 MiB / W per rank instead of the table exchange.  (Two ranks: the slice would
     # cross ONE link, ~5 ms: every rank counts everything.)
-    key_split = bool(exch) and not shard_reads and world >= 4 and 64 % world == 0 and os.environ.get("PALACE_BENCH_KEY_SPLIT", "1") == "1"
+    key_split = bool(exch) and not shard_reads and (world >= 4 or force_key_split) and 64 % world == 0 and os.environ.get("PALACE_BENCH_KEY_SPLIT", "1") == "1"
     if key_split:
         ctx.eref_set_key_buckets(multigpu.key_buckets_of(rank, world))       # mirrored pairs of buckets: equal key mass per rank
     for e in ectx:

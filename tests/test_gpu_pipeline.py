@@ -58,9 +58,11 @@ def test_bench_exchange_path_rehearsal():
             "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--soak-seconds", "0"]
     a = json.loads(sh(base).decode().strip().splitlines()[-1])
     b = json.loads(sh(base, env=dict(os.environ, PALACE_FORCE_EXCHANGE="1")).decode().strip().splitlines()[-1])
-    assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
-    assert a["config"]["graph"] == b["config"]["graph"]
-    assert a["config"]["result_digest"] == b["config"]["result_digest"] and a["config"]["result_digest"]["graph_and_components"]
+    c = json.loads(sh(base, env=dict(os.environ, PALACE_FORCE_KEY_SPLIT="1")).decode().strip().splitlines()[-1])     # the key-space split's gather over RCCL
+    for x in (b, c):
+        assert a["config"]["refs_reported"] == x["config"]["refs_reported"] > 0
+        assert a["config"]["graph"] == x["config"]["graph"]
+        assert a["config"]["result_digest"] == x["config"]["result_digest"] and a["config"]["result_digest"]["graph_and_components"]
     assert a["config"]["graph"]["n_edges"] > 0
 
 
