@@ -1046,6 +1046,9 @@ def main():
                          # bin1 + bin2 + lds_count per launch; only valid for the default workload on one GPU
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "avg_launch_ms": count_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            # eref's unit is a read, generateGraph's a BAM record -- the same step in those units
+            "rates": {"reads_per_s": 2 * sample["n_pairs_total"] / (ms_step * 1e-3), "bam_records_per_s": gs["n_total"] / (ms_step * 1e-3),
+                      "read_bases_per_s": 2 * sample["n_pairs_total"] * READ_LEN / (ms_step * 1e-3)},
             "stage_ms": {"eref_count_each_step": [round(float(x), 3) for x in count_each], "eref_count_both_sides": count_ms, "eref_table_merge": merge_ms, "eref_scan_refs": scan_ms,
                          "graph_classify": classify_ms, "graph_resolve": resolve_ms, "graph_filter_and_matching_on_device": stage04_ms,
                          **{"host_" + k: v for k, v in host_ms.items()},
