@@ -1059,7 +1059,11 @@ def main():
         if world == 1 and not args.no_e2e:
             import shutil
             import tempfile
-            work = tempfile.mkdtemp(prefix="palace_e2e_", dir=os.environ.get("PALACE_BENCH_TMP", "/tmp"))
+            work = os.environ.get("PALACE_BENCH_WORK_DIR")          # (tools/e2e_repeat.sh: the directory it made for this run)
+            if work:
+                os.makedirs(work, exist_ok=True)
+            else:
+                work = tempfile.mkdtemp(prefix="palace_e2e_", dir=os.environ.get("PALACE_BENCH_TMP", "/tmp"))
             try:
                 paths = write_e2e_inputs(torch, sample, gs, hdr, work)
                 n_junc = int((h_last["edges"]["counts"].sum(axis=1) >= 5).sum())

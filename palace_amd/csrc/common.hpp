@@ -82,6 +82,7 @@ struct palace_ctx {
     palace::MatchScratch *match_scratch = nullptr;
     int64_t graph_border = -1;      // candidates of the last classify call that the host's libm has to score, and whose they are
     const void *graph_border_cands = nullptr;
+    int64_t graph_border_n = -1;    // ... and how many candidates that call left there (a buffer that was appended to is not that call's)
     bool launch_graphs = false;     // option: stage 04 replays its launch sequences as hipGraphs
     int match_first_group = 0;      // rounds enqueued before the first look at the state (0 = default)
     int match_iters = 0;            // matching iterations enqueued per round (0 = defaults; tests lower it to force the checked path)

@@ -87,7 +87,7 @@ __global__ void st4_by_rank_kernel(F f)
     for (int s = gtid(); s < f.n_segs; s += gsize()) f.by_rank[f.rank[s]] = s;
 }
 
-__global__ void st4_begin_kernel(F f, const int64_t *__restrict__ d_n_edges)
+__global__ void st4_begin_kernel(F f, const int64_t *__restrict__ d_n_edges, int64_t call_bound)
 {
     for (int s = gtid(); s < f.n_segs; s += gsize()) {
         const uint8_t c = f.seed[s] != 0 && f.tlen[s] > 0;          // a seed with a SEG line (filter_graph.py:210-218)
@@ -97,9 +97,10 @@ __global__ void st4_begin_kernel(F f, const int64_t *__restrict__ d_n_edges)
         FilterState *fs = f.fs;
         const int64_t n = *d_n_edges;
         fs->n_segs = f.n_segs; fs->S_f = 0; fs->n_sel = 0; fs->n_resc = 0;
-        fs->n_edges = n < 0 ? 0 : (n > f.edge_bound ? f.edge_bound : n);
+        const int64_t bound = call_bound < f.edge_bound ? call_bound : f.edge_bound;     // this call's edge array, and the flags' room
+        fs->n_edges = n < 0 ? 0 : (n > bound ? bound : n);
         fs->n_junc = 0; fs->n_kept2 = 0; fs->n_kept3 = 0; fs->n_arcs = 0; fs->n_static = 0; fs->n_dyn = 0;
-        fs->bad = n > f.edge_bound ? kBadEdgeBound : 0u;
+        fs->bad = n > bound ? kBadEdgeBound : 0u;
         fs->scan_total = 0;
     }
 }
@@ -444,7 +445,7 @@ struct palace_stage04 {
     int32_t *h_contig_of = nullptr;
     // option launch_graphs: the launch sequences of filter / match as hipGraphs, captured at the first call with a set of
     // arguments and replayed while they stay the same (kernels have fixed grids and read their counts from device memory)
-    struct Captured { hipGraphExec_t exec = nullptr; uint64_t key = 0; } g_filter, g_match;
+    struct Captured { hipGraphExec_t exec = nullptr; uint64_t key = 0; palace::DecompRun run_after; } g_filter, g_match;
     uint64_t generation = 0;          // bumped whenever a device block moves: graphs of an older generation are stale
 };
 
@@ -547,10 +548,16 @@ int palace_stage04_create(palace_ctx *ctx, const palace_stage04_inputs *in, pala
     const size_t n = static_cast<size_t>(in->n_segs);
     const int64_t n_tok = in->n_paths ? in->path_off[in->n_paths] : 0;
     PALACE_REQUIRE(n_tok >= 0 && (in->n_paths == 0 || in->path_off[0] == 0), "path offsets must start at 0 and ascend");
+    int64_t n_pairs = 0;                                     // consecutive token pairs over all path lines (a line may be empty)
+    for (int64_t k = 0; k < in->n_paths; k++) {
+        const int64_t len = in->path_off[k + 1] - in->path_off[k];
+        PALACE_REQUIRE(len >= 0 && in->path_off[k + 1] <= n_tok, "path offsets must start at 0 and ascend");
+        n_pairs += len > 1 ? len - 1 : 0;
+    }
     for (int32_t i = 0; i < in->n_segs; i++) PALACE_REQUIRE(in->rank[i] >= 0 && in->rank[i] < in->n_segs, "rank out of range");
     for (int64_t k = 0; k < n_tok; k++) PALACE_REQUIRE(in->path_tok[k] < 2 * static_cast<int64_t>(in->n_segs), "path token out of range");
     std::unique_ptr<palace_stage04> s(new palace_stage04());
-    const int64_t pa_cap = 2 * std::max<int64_t>(0, n_tok - in->n_paths) + 16;          // consecutive pairs and their conjugates
+    const int64_t pa_cap = 2 * n_pairs + 16;                                             // consecutive pairs and their conjugates
     const uint64_t pa_slots = pow2_at_least(2 * static_cast<uint64_t>(pa_cap));
     const size_t bytes = up(sizeof(FilterState)) + up(n) * 8 + up(n * 4) * 6 + up(n * 8) * 2 + up((static_cast<size_t>(in->n_paths) + 1) * 8) +
                          up(static_cast<size_t>(n_tok) * 4 + 4) + up((n + 63) / 64 * 8 + 8) + up(pa_slots * 8) + up(pa_slots * 4) +
@@ -641,10 +648,11 @@ int palace_stage04_filter(palace_ctx *ctx, palace_stage04 *s, const palace_graph
     int rc = grow_device(ctx, s, std::max<int64_t>(edge_bound, s->edge_bound), std::max(s->rounds, 11));
     if (rc) return rc;
     uint64_t key = mix_key(mix_key(mix_key(s->generation, reinterpret_cast<uint64_t>(d_edges)), reinterpret_cast<uint64_t>(d_n_edges)), 1);
+    key = mix_key(key, static_cast<uint64_t>(edge_bound));
     rc = run_maybe_captured(ctx, s->g_filter, key, [&]() -> int {
         const F &f = s->f;
         hipStream_t st = ctx->stream;
-        hipLaunchKernelGGL(st4_begin_kernel, kG, kB, 0, st, f, d_n_edges);
+        hipLaunchKernelGGL(st4_begin_kernel, kG, kB, 0, st, f, d_n_edges, edge_bound);
         hipLaunchKernelGGL(st4_pass2_kernel, kG, kB, 0, st, f, d_edges);
         hipLaunchKernelGGL(st4_pass3_kernel, kG, kB, 0, st, f, d_edges);
         hipLaunchKernelGGL(st4_paths_kernel, kG, kB, 0, st, f);
@@ -720,14 +728,13 @@ int palace_stage04_match_after(palace_ctx *ctx, palace_stage04 *s, const palace_
         uint64_t key = mix_key(mix_key(mix_key(s->generation, reinterpret_cast<uint64_t>(d_edges)), reinterpret_cast<uint64_t>(d_cn)), 2);
         key = mix_key(key, (static_cast<uint64_t>(rounds) << 32) | (s->aggressive << 2) | (use_paths ? 2 : 0));
         key = mix_key(key, (static_cast<uint64_t>(ctx->match_iters) << 32) | static_cast<uint32_t>(ctx->match_first_group));
+        const bool replay = ctx->launch_graphs && s->g_match.exec && s->g_match.key == key;
         rc = run_maybe_captured(ctx, s->g_match, key, enqueue);
-        if (!rc && ctx->launch_graphs) {                     // a replay did not run the host side of decomp_group: the state it leaves
-            DecompRun r{};
-            const int first = ctx->match_first_group > 0 ? ctx->match_first_group : kFirstGroupRounds;
-            r.next_round = std::min(rounds, first);
-            for (int t = 0; t < r.next_round; t++)
-                r.count += ctx->match_iters > 0 ? std::min(ctx->match_iters, kMaxIters) : (t == 0 ? kFirstRoundIters : kLaterRoundIters);
-            s->run = r;
+        if (!rc && ctx->launch_graphs) {
+            // a replay does not run the host side of decomp_group: the state that enqueue left when it was captured (rounds
+            // enqueued, iteration stamp) is kept with the graph and put back
+            if (replay) s->run = s->g_match.run_after;
+            else s->g_match.run_after = s->run;
         }
     }
     if (rc) return rc;

@@ -399,6 +399,7 @@ int palace_graph_classify_ex(palace_ctx *ctx, const palace_bam_cols *cols, const
     if (n_border_out) *n_border_out = static_cast<int64_t>(n[1]);
     ctx->graph_border = static_cast<int64_t>(n[1]);
     ctx->graph_border_cands = d_cands;
+    ctx->graph_border_n = static_cast<int64_t>(n[0]);
     if (static_cast<int64_t>(n[0]) > cand_cap) {
         set_error("palace_graph_classify: %llu candidates exceed capacity %lld", n[0], (long long)cand_cap);
         return PALACE_EINVAL;
@@ -424,8 +425,12 @@ int palace_graph_resolve(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_
                          palace_graph_edge *d_edges, int64_t edge_cap, int64_t *n_edges_out)
 {
     PALACE_REQUIRE(n_edges_out, "null argument");
-    // candidates of this very classify call carry its border count; anything else (gathered from several ranks) is counted
-    const int64_t n_border = (ctx && d_cands == ctx->graph_border_cands) ? ctx->graph_border : -1;
+    // Exactly the candidates the last classify call left (same buffer AND same count) carry its border count, once; anything
+    // else -- other ranks' candidates gathered in place behind them, a buffer classified into twice -- is looked at (-1).
+    // Callers that know the count pass it to palace_graph_resolve_ex themselves.
+    int64_t n_border = -1;
+    if (ctx && d_cands == ctx->graph_border_cands && n_cands == ctx->graph_border_n) n_border = ctx->graph_border;
+    if (ctx) { ctx->graph_border_cands = nullptr; ctx->graph_border_n = -1; }
     return palace_graph_resolve_ex(ctx, d_cands, n_cands, n_border, n_records_total, prm, d_consumed, d_edges, edge_cap, nullptr,
                                    n_edges_out);
 }

@@ -11,6 +11,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -392,7 +393,7 @@ int main(int argc, char **argv)
             out.append(line, std::snprintf(line, sizeof line, "ref_index\t%d\t%d\t%d\t%d\t%g\n", static_cast<int>(r + 1), n_int, el, len,
                                            static_cast<double>(ratio)));
     }
-    std::fwrite(out.data(), 1, out.size(), stdout);
+    bool wrote = std::fwrite(out.data(), 1, out.size(), stdout) == out.size();      // the ref list is a data channel (palace:477)
     if (argc >= 10) {
         // get_ref_by_index.py:6-89: the first integer of a stdout line is taken as the 1-based ROW of <db>.fai, i.e. the
         // record number among ALL records of the FASTA (a DB with records of <= 32 bases therefore names the wrong
@@ -420,8 +421,16 @@ int main(int argc, char **argv)
             fa << seq << '\n';                                                  // (Bio.SeqIO drops white space inside sequence lines)
             pc << db_all.ids[static_cast<size_t>(i)] << '\t' << pct << '\n';
         }
+        fa.close(); pc.close();
+        if (!fa.good() || !pc.good()) { std::cerr << "eref: write to " << argv[8] << " / " << argv[9] << " failed\n"; wrote = false; }
     }
     tr.lap("stdout");
+    if (std::fflush(stdout) != 0 || std::ferror(stdout)) wrote = false;
+    if (!wrote) {                                            // disk full, closed pipe: a cut-off ref list must not look like success
+        std::cerr << "eref: writing the results failed: " << std::strerror(errno) << "\n";
+        std::fflush(nullptr);
+        _exit(1);
+    }
     std::fflush(nullptr);
     _exit(0);                   // every output is complete: skip the teardown of the runtime and of gigabytes of mappings
 }

@@ -156,6 +156,23 @@ def test_config3_5m_contig_scale_slab_path():
 # ------------------------------------------------------------------------------------------------
 # configs[4]: long contigs
 # ------------------------------------------------------------------------------------------------
+def classify_part(ctx, gs, a, b, ord_base, consumed, out, cap, prm):
+    """palace_graph_classify on records [a, b) of the sample, candidates to `out` (a view of a candidate buffer); their number"""
+    L, P = capi.lib(), (lambda t: t.data_ptr())
+    sa_lo = int(gs["sa_off"][a].item())
+    sa_local = (gs["sa_off"][a:b + 1] - sa_lo).contiguous()
+    cols = capi.BamCols(b - a, *(P(gs["col"][k][a:b]) for k in ("tid", "pos", "mtid", "mpos", "nm", "ref_len", "read_len",
+                                                             "clip_s", "clip_e", "flag", "mapq", "qkey")), P(sa_local))
+    n_c = ctypes.c_int64()
+    import torch
+    torch.cuda.synchronize()                                  # sa_local was made on torch's stream
+    capi._check(L.palace_graph_classify(ctx.h, ctypes.byref(cols), P(gs["sa"][sa_lo:]), len(gs["names"]), P(gs["tlen"]), P(gs["trank"]),
+                                        P(gs["fastg"]), gs["n_fastg"], ctypes.byref(prm), ord_base, P(consumed),
+                                        P(out), cap, ctypes.byref(n_c)), "classify")
+    ctx.sync()                                                # (cols and sa_local stay alive until the call has finished)
+    return n_c.value
+
+
 def graph_on_gpu(ctx, gs, lo, hi, shards=1):
     """classify records [lo, hi) of the sample (in `shards` shards with their ordinal bases), resolve, copy numbers."""
     import torch
@@ -168,22 +185,12 @@ def graph_on_gpu(ctx, gs, lo, hi, shards=1):
     cands = torch.zeros((cap, 64), dtype=torch.uint8, device=dev)
     edges = torch.zeros((cap, 32), dtype=torch.uint8, device=dev)
     cn = torch.zeros(nt, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()              # torch zero-fills on ITS stream; the library's kernels run on the context's
     prm = capi.GraphParams.default()
     n_total = 0
     for s in range(shards):
         a, b = lo + n * s // shards, lo + n * (s + 1) // shards
-        sa_lo = int(gs["sa_off"][a].item())
-        sa_local = (gs["sa_off"][a:b + 1] - sa_lo).contiguous()   # (kept alive until the call has finished)
-        cols = capi.BamCols(b - a, *(P(gs["col"][k][a:b]) for k in ("tid", "pos", "mtid", "mpos", "nm", "ref_len", "read_len",
-                                                                 "clip_s", "clip_e", "flag", "mapq", "qkey")), P(sa_local))
-        keep = [cols, sa_local]
-        n_c = ctypes.c_int64()
-        capi._check(L.palace_graph_classify(ctx.h, ctypes.byref(cols), P(gs["sa"][sa_lo:]), nt, P(gs["tlen"]), P(gs["trank"]),
-                                            P(gs["fastg"]), gs["n_fastg"], ctypes.byref(prm), a - lo, P(consumed),
-                                            P(cands[n_total:]), cap - n_total, ctypes.byref(n_c)), "classify")
-        ctx.sync()
-        n_total += n_c.value
-        del keep
+        n_total += classify_part(ctx, gs, a, b, a - lo, consumed, cands[n_total:], cap - n_total, prm)
     h_cands = cands[:n_total].cpu().numpy().view(capi.CAND_DTYPE).reshape(-1).copy()
     n_e = ctypes.c_int64()
     capi._check(L.palace_graph_resolve(ctx.h, P(cands), n_total, n, ctypes.byref(prm), P(consumed), P(edges), cap, ctypes.byref(n_e)), "resolve")
@@ -234,6 +241,40 @@ def test_config4_long_contigs_full_size_and_oracle_sample(tmp_path):
         lo = max(0, min(lo, gs["n"] - m))
         cons, cn, edges, cs = graph_on_gpu(ctx, gs, lo, lo + m)
         assert (cs["cls"] == 2).sum() > 0
+        # ---- candidates of ANOTHER call appended behind the last classify call's (what an in-place all-gather leaves on rank 0):
+        # the legacy resolve entry must look at them instead of trusting the count it cached for that buffer ----
+        L, P = capi.lib(), (lambda t: t.data_ptr())
+        prm = capi.GraphParams.default()
+        nt = len(names)
+        cap = m + 4000 + gs["n_sa"] + 1
+        buf = torch.zeros((cap, 64), dtype=torch.uint8, device=dev)
+        other = torch.zeros((cap, 64), dtype=torch.uint8, device=dev)
+        cons_ab = torch.zeros(nt, dtype=torch.int64, device=dev)
+        edges_ab = torch.zeros((cap, 32), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        n_b = classify_part(ctx, gs, lo, lo + m, 2000, cons_ab, other, cap, prm)         # part B: holds gate candidates
+        a0 = None
+        for start in range(0, 40000, 2000):                                                # part A: 2000 records without any
+            if start + 2000 > lo and start < lo + m:
+                continue
+            cons_try = torch.zeros(nt, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            n_a = classify_part(ctx, gs, start, start + 2000, 0, cons_try, buf, cap, prm)
+            if n_a > 0 and (buf[:n_a].cpu().numpy().view(capi.CAND_DTYPE)["cls"] == 2).sum() == 0:
+                a0 = start
+                break
+        assert a0 is not None
+        cons_ab += cons_try
+        buf[n_a:n_a + n_b] = other[:n_b]                                                   # "gathered in place" behind A's
+        torch.cuda.synchronize()
+        n_e = ctypes.c_int64()
+        capi._check(L.palace_graph_resolve(ctx.h, P(buf), n_a + n_b, 2000 + m, ctypes.byref(prm), P(cons_ab), P(edges_ab), cap,
+                                           ctypes.byref(n_e)), "resolve")
+        ctx.sync()
+        got_c = buf[:n_a + n_b].cpu().numpy().view(capi.CAND_DTYPE).reshape(-1)
+        was_b = other[:n_b].cpu().numpy().view(capi.CAND_DTYPE).reshape(-1)
+        assert ((was_b["cls"] == 2) & (was_b["found"] != 0)).sum() > 0
+        assert ((got_c["cls"] == 2) & (got_c["found"] != 0)).sum() == 0, "gate candidates behind the cached count were not decided by the host"
     c = {k: v[lo:lo + m].cpu().numpy() for k, v in gs["col"].items()}
     so = gs["sa_off"][lo:lo + m + 1].cpu().numpy()
     sa = gs["sa"].cpu().numpy()

@@ -34,6 +34,7 @@ def test_bench_shaped_sample_equals_oracle(tmp_path):
         cands = torch.zeros((cap, 64), dtype=torch.uint8, device=dev)
         edges = torch.zeros((cap, 32), dtype=torch.uint8, device=dev)
         cn = torch.zeros(n_contigs, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()          # torch zero-fills on ITS stream; the library's kernels run on the context's
         n_c, n_e = ctypes.c_int64(), ctypes.c_int64()
         capi._check(L.palace_graph_classify(ctx.h, ctypes.byref(cols), P(gs["sa"]), n_contigs, P(gs["tlen"]), P(gs["trank"]),
                                             P(gs["fastg"]), gs["n_fastg"], ctypes.byref(prm), 0, P(consumed), P(cands), cap,

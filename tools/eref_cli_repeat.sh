@@ -2,8 +2,9 @@
 : "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it)}"
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out /tmp/e2e_keep
-PALACE_BENCH_TMP=/tmp/e2e_keep PALACE_BENCH_KEEP=1 timeout -k 10 600 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --soak-seconds 0 > gpurun_out/rep_bench.json 2> gpurun_out/rep_bench.err
-d=$(ls -d /tmp/e2e_keep/palace_e2e_* | head -1)
+d=$(mktemp -d /tmp/e2e_keep/palace_e2e_repeat.XXXXXX) || exit 1
+[ -n "$d" ] && [ -d "$d" ] || { echo "no work dir"; exit 1; }
+PALACE_BENCH_WORK_DIR="$d" PALACE_BENCH_KEEP=1 timeout -k 10 600 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --soak-seconds 0 > gpurun_out/rep_bench.json 2> gpurun_out/rep_bench.err
 echo "inputs in $d"; ls $d | head -20
 for slab in 268435456 1073741824 268435456 1073741824; do
   for i in 1 2 3; do
