@@ -677,6 +677,7 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
     import torch
+    from types import SimpleNamespace
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -687,17 +688,50 @@ def main():
     dist = None
     force_exchange = os.environ.get("PALACE_FORCE_EXCHANGE") == "1"      # rehearse the N>1 code path on one GPU (reads sharded, table exchange)
     force_key_split = os.environ.get("PALACE_FORCE_KEY_SPLIT") == "1"    # ... and the key-space split with its gather (one rank: its share is everything)
-    collectives = world > 1 or force_exchange or force_key_split
-    if collectives:
+    if world > 1 or force_exchange or force_key_split:
         import torch.distributed as dist
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("PALACE_BENCH_BACKEND", "nccl")           # "nccl" is RCCL; gloo only for rehearsals
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            # the collectives of a step are small and sit between kernels of the two context streams: RCCL's own stream at high
+            # priority, so that they are not queued behind the workgroups of a saturating count launch
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, pg_options=opts)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    E = SimpleNamespace(torch=torch, dev=dev, local=local, dist=dist, rank=rank, world=world,
+                        force_exchange=force_exchange, force_key_split=force_key_split)
+    out, failures = measure(args, E, "strong" if world > 1 else "single")
+    if world > 1 and os.environ.get("PALACE_BENCH_WEAK", "1") == "1":
+        # the other reading of "N GPUs": one independent sample per GPU, no collective in the data path.  Every rank runs the
+        # whole 1-GPU step on the (same) full sample; aggregate = N samples per max-over-ranks time.
+        weak, _ = measure(args, E, "weak")
+        if rank == 0:
+            out["weak"] = weak
+    if rank == 0:
+        if failures:
+            out["failed_checks"] = failures
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist is not None:
+        dist.destroy_process_group()
+    if failures:
+        print("bench.py: FAILED CHECKS: " + "; ".join(failures), file=sys.stderr)
+        sys.exit(3)
+
+
+def measure(args, E, leg):
+    """One measured configuration.  leg = "single" (one GPU), "strong" (one sample over E.world GPUs: `value` of the N > 1 line)
+    or "weak" (after the strong steps: every rank runs the whole one-GPU step on a full sample of its own, no collective in
+    the data path; only the barrier and the max-over-ranks time use the process group).  Returns (dict, failed checks)."""
+    torch, dev, local = E.torch, E.dev, E.local
+    solo = leg == "weak"
+    rank, world, dist = (0, 1, None) if solo else (E.rank, E.world, E.dist)
+    sync_dist, sync_world = E.dist, E.world                               # barrier + max over ranks: always the real group
+    force_exchange, force_key_split = (E.force_exchange and not solo), (E.force_key_split and not solo)
+    collectives = world > 1 or force_exchange or force_key_split
     from palace_amd import capi, coder, multigpu       # (oracle/ is imported by the cpu_baseline leg only)
 
     hdr = coder.header_from_picks(np.random.Generator(np.random.PCG64(SEED)).integers(0, 6, size=32))
@@ -718,17 +752,31 @@ def main():
                 e.eref_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
         if os.environ.get("PALACE_OPT_KEY_SHARE"):    # tuning runs only: count the share rank 0 of N would (results are then partial)
             e.eref_set_key_buckets(multigpu.key_buckets_of(0, int(os.environ["PALACE_OPT_KEY_SHARE"])))
-    # Phase A across ranks.  Three ways, modelled from the 1-GPU kernel times and ~50 GB/s usable per xGMI link and direction
-    # (none measured on more than one GPU yet):
-    #  * every rank counts ALL reads, nothing is exchanged (what two ranks do: anything else crosses ONE link);
-    #  * every rank counts all reads but only ITS 1/W of the key space, the ">= 3" plane slices are all-gathered (from four ranks
-    #    on, see key_split below): 512 MiB / W per rank and link pair, ~2.5 ms at W = 4, ~1.3 ms at W = 8, and the partition
-    #    kernels shrink to the key arithmetic plus 1/W of the sorting and the bytes;
-    #  * the reads are sharded and the partial count tables exchanged (two planes to their owners, merge, all-gather): 0.5-0.9 GB
-    #    out per rank whatever W is, ~8 ms at W = 4, ~4 ms at W = 8 plus ~1.1 ms of passes -- slower than the key split at every
-    #    W in this model; kept behind PALACE_BENCH_SHARD_READS=1 (the library's exchange entry points, and the rehearsals).
-    shard_reads = force_exchange or (world > 1 and os.environ.get("PALACE_BENCH_SHARD_READS") == "1")
+    # Phase A across ranks, three schemes (palace_amd/multigpu.py phase_a_model; none measured on more than
+    # one GPU yet): "replicate" -- every rank counts ALL reads, nothing is exchanged; "key_split" -- every rank holds all reads
+    # and counts ITS 1/W of the key space, the ">= 3" plane slices are all-gathered (the partition kernels shrink to the key
+    # arithmetic plus 1/W of the sorting and the bytes); "shard_reads" -- the reads are sharded and the partial count tables
+    # exchanged (two planes to their owners, merge, all-gather): 0.5-0.9 GB out per rank whatever W is, but the counting itself
+    # shards, which wins once a sample is large (5M contigs on 8 GPUs: ~11 ms against ~22 ms for the key split).  The scheme is
+    # picked per run from the model; PALACE_BENCH_SCHEME=replicate|key_split|shard_reads forces one (rehearsals, A/B runs).
     long_mode = args.workload == "long"
+    n_reads_total = 2 * (int(5e8 * (1.0 if long_mode else args.contigs / 1_000_000)) // READ_LEN)
+    model = multigpu.phase_a_model(n_reads_total, world)
+    scheme, forced = model["choice"], None
+    if force_exchange:
+        forced = "shard_reads"
+    elif force_key_split:
+        forced = "key_split"
+    elif world > 1 and os.environ.get("PALACE_BENCH_SCHEME", "auto") != "auto":
+        forced = os.environ["PALACE_BENCH_SCHEME"]
+        if forced not in ("replicate", "key_split", "shard_reads") or (forced == "key_split" and 64 % world):
+            raise SystemExit(f"PALACE_BENCH_SCHEME={forced}: not a scheme for {world} ranks")
+    if forced:
+        scheme = forced
+    if not collectives:
+        scheme = "replicate"
+    model.update(choice_in_force=scheme, forced=bool(forced))
+    shard_reads = scheme == "shard_reads"
     sample = make_sample(torch, dev, args.contigs, args.refs, rank if shard_reads else 0, world if shard_reads else 1, long_mode)
     gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world, long_mode)
     if collectives:                                 # avgDepth is a pipeline input: computed once from all shards
@@ -783,6 +831,7 @@ def main():
             ctx.eref_table_merge_slices(parts.data_ptr(), n_parts, slice_off, slice_bytes, packed)
             ctx.sync()
     last = {}
+    seen = {"graph": set(), "rows": set(), "steps": 0}     # result digests of the untimed steps (warm-up, soak): one value each, or the step is not repeatable
     h_last = {}
     host_ms = {}
     ref_off_local = sample["ref_off"][r_lo:r_hi + 1].contiguous()
@@ -805,11 +854,10 @@ def main():
     # one GPU (and N GPUs that each count all reads): the count of a step is the only one between its reset and its scan, so the
     # two lower planes of the table need not leave the LDS (include/palace_hip.h, option final_count)
     final_count = not shard_reads and os.environ.get("PALACE_BENCH_FINAL", "1") == "1"      # (=0: A/B runs)
-    # Four ranks and more that each hold all reads: rank r counts only the keys of ITS 1/W of the key space (they are dropped
-    # where they are made: the partition kernels move 1/W of the bytes, the key arithmetic stays) and the ">= 3" plane slices
-    # are all-gathered -- one collective of 512 MiB / W per rank instead of the table exchange.  (Two ranks: the slice would
-    # cross ONE link, ~5 ms: every rank counts everything.)
-    key_split = bool(exch) and not shard_reads and (world >= 4 or force_key_split) and 64 % world == 0 and os.environ.get("PALACE_BENCH_KEY_SPLIT", "1") == "1"
+    # key split: rank r counts only the keys of ITS 1/W of the key space (they are dropped where they are made: the partition
+    # kernels move 1/W of the bytes, the key arithmetic stays) and the ">= 3" plane slices are all-gathered -- one collective of
+    # 512 MiB / W per rank instead of the table exchange
+    key_split = bool(exch) and scheme == "key_split"
     if key_split:
         ctx.eref_set_key_buckets(multigpu.key_buckets_of(rank, world))       # mirrored pairs of buckets: equal key mass per rank
     for e in ectx:
@@ -939,6 +987,7 @@ def main():
                             np.asarray(res.bare), np.asarray(contig_of)):
                     hsh.update(np.ascontiguousarray(arr).tobytes())
                 last["digest_graph"] = hsh.hexdigest()[:16]
+                seen["graph"].add(last["digest_graph"])
             h_last["result"] = (res, contig_of)                   # views, valid until the next match call
 
         if exch:
@@ -954,6 +1003,9 @@ def main():
         ctx.mark(4094)
         if depth == 1:
             ctx.mark_wait(4094)
+            if not timed:
+                seen["rows"].add(hashlib.sha256(rows_host.numpy().tobytes()).hexdigest()[:16])
+                seen["steps"] += 1
         else:
             if seq["pending"] is not None:
                 ectx[seq["pending"]].mark_wait(4094)
@@ -1011,6 +1063,7 @@ def main():
     r = rows_host_l[seq["last"]].numpy()
     reported = int(((r[:, 1] > 0) & (r[:, 1].astype(np.float32) / r[:, 2].astype(np.float32) > 0.75)).sum())
 
+    failures = []
     if rank == 0:
         traffic, traffic_src = phase_a_traffic(args, world)
         alg_bytes = (READ_LEN + 6 * (READ_LEN - 31)) * 2 * n_side        # per launch (both FASTQ sides of this rank)
@@ -1034,6 +1087,8 @@ def main():
                        "refs_reported": reported, "refs_present": int(len(sample["present"])),
                        "result_digest": {"eref_rows": hashlib.sha256(np.ascontiguousarray(r).tobytes()).hexdigest()[:16],
                                          "graph_and_components": last.get("digest_graph"),
+                                         "identical_over_untimed_steps": (len(seen["graph"]) <= 1 and len(seen["rows"]) <= 1) if seen["steps"] else None,
+                                         "untimed_steps_compared": seen["steps"],
                                          "note": "sha256 prefixes of the last step's results; equal for every --gpus N"},
                        "graph": {k: last.get(k) for k in ("n_cands", "n_edges", "n_junc", "n_kept_junc", "n_segs_filtered", "n_segs_rescued", "n_arcs",
                                                           "n_comp", "n_cycles", "n_multi")},
@@ -1083,6 +1138,25 @@ def main():
             seg_flags, edge_flags = stage04.flags(len(h_last["edges"]))
             out["cpu_baseline"] = cpu_baseline(torch, sample, gs, hdr, args.cpu_sample_frac,
                                                dict(contig_of=np.asarray(contig_of).copy(), cn=h_last["cn"], edges=h_last["edges"], edge_flags=edge_flags))
+        # a line whose own cross-checks failed is still printed, but the run does not pass: wrong refs, the executables on the
+        # files disagreeing with the resident step (or the leg raising), results that differ from step to step
+        e2e = out.get("e2e")
+        if reported != len(sample["present"]) and args.contigs >= 1_000_000 and args.refs == 5000:     # (below 1M contigs the read depth leaves a few present refs short)
+            failures.append(f"refs_reported {reported} != refs_present {len(sample['present'])}")
+        if out["config"]["result_digest"]["identical_over_untimed_steps"] is False:
+            failures.append("result digests differ between untimed steps")
+        if e2e is not None:
+            if "error" in e2e:
+                failures.append("e2e leg raised: " + e2e["error"])
+            else:
+                for k in ("agrees_with_resident_step", "all_result_identical_to_resident_step"):
+                    if e2e.get(k) is not True:
+                        failures.append(f"e2e.{k} is {e2e.get(k)}")
+                one = e2e.get("one_process_stage04") or {}
+                if one.get("files_identical_to_the_chain") is not True:
+                    failures.append("e2e.one_process_stage04: " + str(one.get("error", "files differ from the chain's")))
+        if failures:
+            out["failed_checks"] = failures
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     capi._check(L.palace_eref_probe_index_free(ctx.h, probe_index), "probe index free")
@@ -1092,6 +1166,9 @@ def main():
     ctx_g.close()
     if dist is not None:
         dist.destroy_process_group()
+    if failures:
+        print("bench.py: FAILED CHECKS: " + "; ".join(failures), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -297,6 +297,14 @@ int palace_graph_resolve_ex(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t
                             int64_t n_records_total, const palace_graph_params *prm, uint64_t *d_consumed,
                             palace_graph_edge *d_edges, int64_t edge_cap, int64_t *d_n_edges, int64_t *n_edges_out);
 
+/* The host-libm decision alone (computeLayoutScore's exp() underflow gate, :432-461) on the candidates of ONE classify call:
+ * every found candidate with cls == 2 becomes cls 0 or 1 in place.  A rank of a multi-GPU run calls it on its own candidates
+ * (n_border from palace_graph_classify_ex; 0 = nothing to do, nothing is copied) before they are gathered, so that what every
+ * rank resolves carries no undecided candidate and palace_graph_resolve_ex can be given n_border = 0 without an exchange of
+ * counts.  Synchronises the stream when n_border != 0. */
+int palace_graph_score_border(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_cands, int64_t n_border,
+                              const palace_graph_params *prm);
+
 /* G6 epilogue numbers (generate_graph.cpp:1029-1031): depth = consumed / max(1, len) and
  * cn = (int)floor(depth / avg_depth + 0.5) (0 when avg_depth <= 0), per target, in IEEE double. */
 int palace_graph_copy_numbers(palace_ctx *ctx, const uint64_t *d_consumed, const int32_t *d_tlen,

@@ -435,6 +435,26 @@ int palace_graph_resolve(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_
                                    n_edges_out);
 }
 
+int palace_graph_score_border(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_cands, int64_t n_border,
+                              const palace_graph_params *prm)
+{
+    PALACE_REQUIRE(ctx && prm && n_cands >= 0, "bad argument");
+    if (n_cands == 0 || n_border == 0) return PALACE_OK;
+    PALACE_REQUIRE(d_cands, "null device pointer");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<palace_graph_cand> h(static_cast<size_t>(n_cands));
+    PALACE_HIP_TRY(hipMemcpyAsync(h.data(), d_cands, h.size() * sizeof(palace_graph_cand), hipMemcpyDeviceToHost, ctx->stream));
+    PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    bool any = false;
+    for (auto &c : h)
+        if (c.found && c.cls == 2) { c.cls = host_score_positive(c, *prm) ? 1 : 0; any = true; }
+    if (any) {
+        PALACE_HIP_TRY(hipMemcpyAsync(d_cands, h.data(), h.size() * sizeof(palace_graph_cand), hipMemcpyHostToDevice, ctx->stream));
+        PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));     // h leaves scope
+    }
+    return PALACE_OK;
+}
+
 int palace_graph_resolve_ex(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t n_cands, int64_t n_border,
                             int64_t n_records_total, const palace_graph_params *prm, uint64_t *d_consumed,
                             palace_graph_edge *d_edges, int64_t edge_cap, int64_t *d_n_edges, int64_t *n_edges_out)
@@ -471,16 +491,8 @@ int palace_graph_resolve_ex(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t
     PALACE_HIP_TRY(hipMemsetAsync(a.e_counts, 0, up256(qcap * 16), ctx->stream));
     const unsigned blocks = static_cast<unsigned>((n_cands + 255) / 256);
     if (n_border != 0) {    // exp() underflow zone: decide with the host's libm (:432-461).  n_border < 0: not known, look
-        std::vector<palace_graph_cand> h(static_cast<size_t>(n_cands));
-        PALACE_HIP_TRY(hipMemcpyAsync(h.data(), d_cands, h.size() * sizeof(palace_graph_cand), hipMemcpyDeviceToHost, ctx->stream));
-        PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        bool any = false;
-        for (auto &c : h)
-            if (c.found && c.cls == 2) { c.cls = host_score_positive(c, *prm) ? 1 : 0; any = true; }
-        if (any) {
-            PALACE_HIP_TRY(hipMemcpyAsync(d_cands, h.data(), h.size() * sizeof(palace_graph_cand), hipMemcpyHostToDevice, ctx->stream));
-            PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));     // h leaves scope
-        }
+        rc = palace_graph_score_border(ctx, d_cands, n_cands, n_border, prm);
+        if (rc) return rc;
     }
     hipLaunchKernelGGL(resolve_split_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(resolve_pair_insert_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);

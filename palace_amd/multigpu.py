@@ -45,6 +45,39 @@ def key_buckets_of(rank: int, world: int):
     return sorted(out)
 
 
+# ---- which Phase-A scheme for this many reads on this many GPUs ---------------------------------------------------------
+# Constants measured on ONE MI355X with the current kernels, 1M-contig workload = 6.67 M reads x 150 bp (DESIGN.md section 6;
+# tools/kr_diag.sh, profiles/): the count launch over all keys; the count launch of a 1/W key share of ALL reads
+# (3.35 + 5.95 / W ms: the key arithmetic over every read does not shard); the passes of the table exchange (pack the low
+# plane, fold the parts on the owner); repacking gathered plane slices.  Everything else is interconnect arithmetic:
+# xGMI is point to point, a rank reaches each peer over its own link, `link_gbs` is what one link and direction sustains.
+MODEL = dict(reads_measured=6_666_666, count_all_ms=9.1, key_fixed_ms=3.35, key_shared_ms=5.95, three_planes_factor=1.03,
+             exchange_passes_ms=1.1, repack_ms=0.25, collective_latency_ms=0.05, link_gbs=50.0, plane_bytes=1 << 29)
+
+
+def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None) -> dict:
+    """Modelled milliseconds of eref Phase A (count launch + what it takes to have the '>= 3' plane complete on every rank) per
+    step for the three schemes, and the cheapest.  n_reads: reads of the whole sample (both FASTQ sides).
+      replicate    every rank counts all reads, nothing moves
+      key_split    every rank holds all reads and counts its 1/W of the key space; all-gather of the plane slices
+      shard_reads  reads sharded; two planes to their key-range owners, merge, all-gather of the merged '>= 3' plane"""
+    m = dict(MODEL)
+    if link_gbs:
+        m["link_gbs"] = float(link_gbs)
+    W, x = max(1, world), n_reads / m["reads_measured"]
+    per_link_ms = lambda nbytes: nbytes / (m["link_gbs"] * 1e9) * 1e3 + m["collective_latency_ms"]
+    out = {"replicate": m["count_all_ms"] * x}
+    if W > 1:
+        gather = per_link_ms(m["plane_bytes"] / W)                      # each rank pulls one slice per peer, all links at once
+        if 64 % W == 0:
+            out["key_split"] = (m["key_fixed_ms"] + m["key_shared_ms"] / W) * x + gather + m["repack_ms"]
+        out["shard_reads"] = (m["count_all_ms"] * m["three_planes_factor"] * x / W + per_link_ms(2 * m["plane_bytes"] / W)
+                              + m["exchange_passes_ms"] + gather)
+    choice = min(out, key=out.get)
+    return dict(ms={k: round(v, 2) for k, v in out.items()}, choice=choice, link_gbs=m["link_gbs"], n_reads=int(n_reads), world=W,
+                note="modelled from 1-GPU kernel times and per-link xGMI arithmetic; no N > 1 hardware measurement behind it")
+
+
 class Exchange:
     def __init__(self, torch, dist, rank: int, world: int):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
@@ -124,6 +157,20 @@ class Exchange:
         dist.all_gather_into_tensor(out.view(-1), part.view(-1))
         allrows = torch.cat([out[r, :c] for r, c in enumerate(counts)], dim=0).contiguous()
         return allrows, sum(counts)
+
+    def gather_padded(self, rows, n_dev, width: int, out=None):
+        """The same gather with nothing read back: rows (cap, k), of which the first *n_dev (a 1-element int64 device tensor)
+        are valid, are gathered as `width` rows per rank -- rows beyond a rank's count arrive as zeros (a zero candidate is
+        one that resolve ignores).  Returns ((world * width, k) tensor, (world,) int64 device tensor of the counts); the
+        caller checks counts <= width afterwards (a count above it means rows were cut off: redo with a wider gather)."""
+        torch, dist, W = self.torch, self.dist, self.world
+        counts = torch.empty(W, dtype=torch.int64, device=rows.device)
+        dist.all_gather_into_tensor(counts, n_dev)
+        part = rows[:width] * (torch.arange(width, device=rows.device) < n_dev).to(rows.dtype)[:, None]
+        if out is None or out.shape[0] != W * width:
+            out = torch.empty((W * width, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        dist.all_gather_into_tensor(out.view(-1), part.contiguous().view(-1))
+        return out, counts
 
     def reduce_sum(self, t):
         self.dist.all_reduce(t)

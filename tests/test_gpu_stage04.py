@@ -292,6 +292,35 @@ def test_device_stage04_equals_the_file_chain_on_adversarial_graphs(case, flags)
     assert got_cyc == cyc
 
 
+def test_stage04_paths_with_empty_lines_bad_offsets_and_the_call_s_own_edge_bound():
+    """(review of round 3) many empty path lines beside one long line: the path arc table is sized by the token PAIRS, not by
+    tokens minus lines; offsets that do not ascend are refused; a later filter call with a SMALLER edge array is held to that
+    call's bound, not to the largest bound the object has seen"""
+    names = [f"EDGE_{i + 1}_length_{500 + i}_cov_3.0" for i in range(80)]
+    n = len(names)
+    long_line = np.arange(0, 2 * 60, 2, dtype=np.int32)                       # 60 tokens, 59 consecutive pairs (+ conjugates = 118 arcs)
+    off = np.concatenate([np.zeros(101, np.int64), [len(long_line)]])          # 100 empty lines in front of it
+    with capi.Ctx(0) as ctx:
+        st = capi.Stage04(ctx, np.ones(n, np.uint8), np.full(n, 500, np.int32), stage04_io.name_ranks(names), stage04_io.name_lengths(names), off, long_line)
+        e = np.zeros(64, capi.EDGE_DTYPE)
+        e["left"] = np.arange(64) % n; e["right"] = (np.arange(64) + 1) % n; e["counts"][:, 0] = 9
+        d_e, d_n, d_cn = ctx.upload(e.view(np.uint8).reshape(-1)), ctx.upload(np.array([64], np.int64)), ctx.upload(np.ones(n, np.int32))
+        st.filter(d_e.ptr, d_n.ptr, 64)
+        st.match(d_e.ptr, d_cn.ptr, 10, False, True)
+        res, contig_of = st.result()
+        c = st.counts()
+        assert c["juncs"] == 64 and c["arcs"] >= 118
+        # the same object, a smaller edge array whose device-side count says more than the array holds
+        small = ctx.upload(e[:8].view(np.uint8).reshape(-1))
+        st.filter(small.ptr, d_n.ptr, 8)                                        # *d_n_edges is still 64 > 8
+        with pytest.raises(capi.PalaceError, match="more edges on the device than the bound"):
+            st.counts()
+        st.close()
+        bad = off.copy(); bad[50] = 7                                           # 0 ... 7 0 ...: descends
+        with pytest.raises(capi.PalaceError, match="ascend"):
+            capi.Stage04(ctx, np.ones(n, np.uint8), np.full(n, 500, np.int32), stage04_io.name_ranks(names), stage04_io.name_lengths(names), bad, long_line)
+
+
 def test_launch_graphs_replay_gives_what_plain_launches_give(tmp_path):
     """option launch_graphs: filter / match captured as hipGraphs at the first call and replayed -- on NEW contents of the same
     buffers (the kernels read counts and data from device memory) the replay must give what plain launches give"""
