@@ -522,7 +522,31 @@ def reference_eref_check(b1, b2, off, rb, ro, n_ref_s, tmp):
         return dict(error=str(e)[:200])
 
 
-def cpu_baseline(torch, sample, gs, header, frac, graph_out):
+def bam_decode_seconds(bam_path, cores):
+    """BGZF inflate + BAM record decode of the WHOLE BAM of the workload on the host, through this repo's loader (hostdump
+    bamtime: the same code path generateGraph loads with, no GPU): with zlib's inflate() on one thread -- what htslib's
+    sam_read1 does for the reference's single-threaded loop (generate_graph.cpp:611-669) --, with zlib on `cores` threads, and
+    as shipped (the loader's own DEFLATE decoder on `cores` threads).  Seconds each; the file is in the page cache."""
+    import subprocess
+    exe = os.path.join(ROOT, "palace_amd", "bin", "hostdump")
+    if not (bam_path and os.path.exists(bam_path) and os.path.exists(exe)):
+        return None
+    def run(threads, zlib):
+        env = dict(os.environ)
+        env.pop("PALACE_BAM_ZLIB", None)
+        if zlib:
+            env["PALACE_BAM_ZLIB"] = "1"
+        t0 = time.perf_counter()
+        subprocess.run([exe, "bamtime", bam_path, str(threads)], check=True, stdout=subprocess.DEVNULL, env=env, timeout=600)
+        return time.perf_counter() - t0
+    try:
+        return dict(zlib_1_thread=run(1, True), zlib_threads=run(cores, True), own_decoder_threads=run(cores, False), threads=cores,
+                    bam_bytes=os.path.getsize(bam_path))
+    except Exception as e:
+        return dict(error=f"{type(e).__name__}: {str(e)[:200]}")
+
+
+def cpu_baseline(torch, sample, gs, header, frac, graph_out, bam_path=None):
     """The oracle (CPU restatement of the reference algorithm) on a bounded sample of every stage, extrapolated linearly to
     the whole workload: at threads = 1 (the only configuration in which the reference's semantics are defined, SURVEY.md
     F5) -> `value`; with the read counting on min(nproc, 16) threads (race-free: saturating increment by compare-and-swap)
@@ -598,6 +622,10 @@ def cpu_baseline(torch, sample, gs, header, frac, graph_out):
     gin.run(os.path.join(tmp, "g.fastg.fai"), gs["avg_depth"])
     t_graph_s = time.perf_counter() - t0
     t_graph = t_graph_s * gs["n_total"] / m
+    # ... and what the reference's loop spends inside sam_read1: BGZF inflate + record decode of the whole BAM (not a sample)
+    dec = bam_decode_seconds(bam_path, cores)
+    t_decode = dec["zlib_1_thread"] if dec and "error" not in dec else None
+    t_decode_mt = dec["zlib_threads"] if t_decode is not None else None
     # ---- matching: the whole FILTERED graph this run produced (what palace:587-590 hands to `matching`), through the oracle's
     # own text parser, with contigs.paths ----
     gpath, ppath = os.path.join(tmp, "graph.txt"), os.path.join(tmp, "contigs.paths")
@@ -612,7 +640,7 @@ def cpu_baseline(torch, sample, gs, header, frac, graph_out):
     t0 = time.perf_counter()
     orc.match_run(gpath, ppath, 10, cap=cap)
     t_match = time.perf_counter() - t0
-    t_full, t_full_mt = t_eref + t_graph + t_match, t_eref_mt + t_graph + t_match
+    t_full, t_full_mt = t_eref + t_graph + t_match + (t_decode or 0.0), t_eref_mt + t_graph + t_match + (t_decode_mt or 0.0)
     # the COMPILED reference, when it travels with the repo, on a small part of the same reads: a cross-check of the port's rate
     k = min(n_side, 20000)
     ref_check = reference_eref_check(b1[: k * READ_LEN], b2[: k * READ_LEN], off[: k + 1], rb, ro, n_ref_s, tmp)
@@ -624,19 +652,33 @@ def cpu_baseline(torch, sample, gs, header, frac, graph_out):
     out = dict(value=nc / t_full, unit="contigs/s", cores=1, kind="port",
                sample=(f"oracle/ at threads=1. eref: {2 * n_side} of {total_reads} reads x{READ_LEN} bp ({t_reads:.1f} s) + 4 GiB table "
                        f"memset ({t_clear:.1f} s, fixed) + scan of {n_ref_s} of {sample['n_refs']} refs ({t_refs:.2f} s) -> {t_eref:.0f} s "
-                       f"extrapolated; generateGraph: first {m} of {gs['n_total']} decoded records ({t_graph_s:.1f} s; BGZF/BAM decode and "
-                       f"full .fai parse excluded) -> {t_graph:.0f} s; matching: the whole filtered graph with contigs.paths ({t_match:.1f} s; own "
+                       f"extrapolated; generateGraph: first {m} of {gs['n_total']} decoded records ({t_graph_s:.1f} s; full .fai parse excluded) -> {t_graph:.0f} s, "
+                       + (f"plus BGZF inflate + BAM decode of the whole {dec['bam_bytes'] / 1e6:.0f} MB BAM with zlib on one thread, as htslib's sam_read1 "
+                          f"does ({t_decode:.1f} s, measured, not extrapolated)" if t_decode is not None else "BGZF/BAM decode NOT included (no BAM file in this run: --no-e2e)")
+                       + f"; matching: the whole filtered graph with contigs.paths ({t_match:.1f} s; own "
                        f"algorithm, reference absent); filter_graph.py itself (Python glue) is not in the sum."),
-               stage_s=dict(eref=t_eref, generateGraph=t_graph, matching=t_match), port_reads_per_s=2 * n_side / t_reads,
+               stage_s=dict(eref=t_eref, generateGraph=t_graph, generateGraph_bam_decode=t_decode, matching=t_match), port_reads_per_s=2 * n_side / t_reads,
+               extrapolated="eref and generateGraph's record loop are timed on the sample named in `sample` and scaled linearly; table memset, BAM decode and matching are whole",
+               bam_decode_s=dec,
                multi_thread=dict(value=nc / t_full_mt, unit="contigs/s", cores=cores, kind="port",
                                  note=f"read counting and ref scan on {cores} threads (same sample: {t_reads_mt:.1f} s and {t_refs_mt:.2f} s); "
-                                      "generateGraph and matching single-threaded, as the reference's are",
-                                 stage_s=dict(eref=t_eref_mt, generateGraph=t_graph, matching=t_match)),
+                                      "generateGraph's record loop and matching single-threaded, as the reference's are; BGZF inflate on the same threads (htslib can: bgzf_mt)",
+                                 stage_s=dict(eref=t_eref_mt, generateGraph=t_graph, generateGraph_bam_decode=t_decode_mt, matching=t_match)),
                reference_eref=ref_check)
     if t_dead is not None:
         out["as_shipped"] = dict(value=nc / (t_full + t_dead), unit="contigs/s", cores=1, kind="port",
                                  note=f"threads=1 plus the reference's never-read Peaks arrays: 16 GiB + 300 MB allocated and zeroed "
                                       f"({t_dead:.1f} s on this host, fixed per run; extract_ref.cpp:1296-1299)")
+    return out
+
+
+def roofline_stages(stages, traffic):
+    """{stage: (algorithmic bytes per step, live ms per step, what the bytes are)} -> the per-stage roofline objects"""
+    out = {}
+    for k, (alg, ms, what) in stages.items():
+        ach = alg / (ms * 1e-3) / 1e9 if ms and ms > 0 else None
+        out[k] = {"bound": "hbm", "algorithmic_bytes_per_step": int(alg), "ms_per_step": float(ms), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": None if ach is None else ach / HBM_PEAK_GBS, "traffic": traffic.get(k), "bytes": what}
     return out
 
 
@@ -654,17 +696,20 @@ def launch_ranks(args) -> int:
     return subprocess.run(cmd).returncode
 
 
-def phase_a_traffic(args, world):
-    """HBM bytes per count_reads launch from the committed PMC profile of the CURRENT kernels (profiles/phase_a_traffic.json,
-    written by tools/prof_full.sh + tools/traffic_json.py): FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE over the
-    launch's kernels.  Only quoted for the workload it was measured on; otherwise null."""
+def profiled_traffic(args, world, version):
+    """HBM bytes per step from the committed PMC profile (profiles/phase_a_traffic.json, written by tools/prof_full.sh +
+    tools/traffic_json.py): FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, per count launch and per stage.  Only quoted for
+    the workload AND the library build (palace_version(): a digest of the kernel sources) it was measured on; otherwise null.
+    -> (bytes per count launch, source, {stage: bytes})"""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "phase_a_traffic.json")))
     except Exception:
-        return None, None
+        return None, None, {}
     if world != 1 or t.get("contigs") != args.contigs or t.get("workload", "default") != args.workload or t.get("reads", "ascii") != args.reads:
-        return None, None
-    return t.get("bytes_per_launch"), t.get("source")
+        return None, "profiles/phase_a_traffic.json is of another workload", {}
+    if t.get("build") != version:
+        return None, f"profiles/phase_a_traffic.json was measured on another build ({t.get('build')}); this is {version}", {}
+    return t.get("bytes_per_launch"), t.get("source"), {k: v.get("bytes") for k, v in (t.get("stages") or {}).items()}
 
 
 def main():
@@ -735,13 +780,30 @@ def measure(args, E, leg):
     from palace_amd import capi, coder, multigpu       # (oracle/ is imported by the cpu_baseline leg only)
 
     hdr = coder.header_from_picks(np.random.Generator(np.random.PCG64(SEED)).integers(0, 6, size=32))
-    ctx = capi.Ctx(local)                      # eref stream
-    ctx_g = capi.Ctx(local, high_priority=os.environ.get("PALACE_BENCH_PRIO", "1") == "1")   # generateGraph + matching stream (independent of eref until the end)
+    # Streams.  A: eref (count + scan).  B: generateGraph (classify, resolve, copy numbers), high priority.  S: stage 04 (selection +
+    # matching: ~150 small latency-bound launches), confined to ONE XCD's compute units (hipExtStreamCreateWithCUMask, the first
+    # 32 CUs): beside the saturating counting kernels those launches otherwise land on all 256 CUs and cost the count launch ~1 ms
+    # (measured, tools/cu_mask_ab.sh: count 9.12 -> 7.9 ms with stream B + S confined to 32 CUs -- but classify, one wide kernel,
+    # then takes 4.5 ms instead of 0.9, hence the split of B and S).  PALACE_BENCH_STAGE04_CUS=0: stage 04 on stream B as before.
+    # With collectives (N GPUs) A and B are torch streams the contexts run on (palace_ctx_create_on_stream), so that
+    # torch.distributed's collectives are stream-ordered with the library's kernels and nothing waits on the host.
+    mask_of = lambda k: int(os.environ[k], 16) if os.environ.get(k) else None      # tuning runs: PALACE_BENCH_CU_MASK_A / _B (hex)
+    s04_cus = int(os.environ.get("PALACE_BENCH_STAGE04_CUS", "32"))
+    if collectives:
+        sA, sB = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1)
+        ctx, ctx_g = capi.Ctx(local, stream=sA.cuda_stream), capi.Ctx(local, stream=sB.cuda_stream)
+    else:
+        mask_a = mask_of("PALACE_BENCH_CU_MASK_A")
+        if mask_a is None and 0 < s04_cus < 256 and os.environ.get("PALACE_BENCH_EXCLUDE_A", "1") == "1":
+            mask_a = ((1 << 256) - 1) ^ ((1 << s04_cus) - 1)         # the eref stream keeps off stage 04's compute units
+        ctx = capi.Ctx(local, cu_mask=mask_a)
+        ctx_g = capi.Ctx(local, high_priority=os.environ.get("PALACE_BENCH_PRIO", "1") == "1", cu_mask=mask_of("PALACE_BENCH_CU_MASK_B"))
+    ctx_s = capi.Ctx(local, cu_mask=(1 << s04_cus) - 1) if 0 < s04_cus < 256 else ctx_g
     if os.environ.get("PALACE_BENCH_GRAPHS", "0") == "1":     # stage 04 as two hipGraph launches per step (measured: host enqueue 1.25 -> 0.96 ms,
-        ctx_g.match_set_option("launch_graphs", 1)            # the step 10.95 -> 11.08 ms: back to back the small kernels disturb the counting kernels more)
+        ctx_s.match_set_option("launch_graphs", 1)            # the step 10.95 -> 11.08 ms: back to back the small kernels disturb the counting kernels more)
     for opt in ("iters_per_round", "first_group_rounds"):    # tuning runs only
         if os.environ.get("PALACE_OPT_" + opt.upper()):
-            ctx_g.match_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
+            ctx_s.match_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
     # one GPU: a second eref context (own stream, own count table, own scratch) so that consecutive batches overlap
     depth = args.batches_in_flight if not collectives else 1
     ectx = [ctx] + [capi.Ctx(local) for _ in range(depth - 1)]
@@ -805,31 +867,31 @@ def measure(args, E, leg):
     gs["side"] = make_side_inputs(gs)
     stage04 = None
     if rank == 0:
-        stage04 = capi.Stage04(ctx_g, gs["side"]["seed"], gs["lens"].astype(np.int32), gs["trank"].cpu().numpy(), gs["lens"].astype(np.int32),
+        stage04 = capi.Stage04(ctx_s, gs["side"]["seed"], gs["lens"].astype(np.int32), gs["trank"].cpu().numpy(), gs["lens"].astype(np.int32),
                                gs["side"]["path_off"], gs["side"]["path_tok"], 5)
     n_edges_dev = torch.zeros(1, dtype=torch.int64, device=dev)
     exch = multigpu.Exchange(torch, dist, rank, world) if collectives else None
-    # torch ops and collectives run on torch's current stream, the library's kernels on the two context streams; the
-    # hand-over points wait for exactly the stream that produced the data (a device-wide synchronize here would make the
-    # generateGraph exchange wait for the eref counting kernels and vice versa)
-    tsync = lambda: torch.cuda.current_stream().synchronize()
+    # N GPUs: torch ops and collectives are issued with a CONTEXT's stream as torch's current stream (the library's streams
+    # wrapped as torch.cuda.ExternalStream): the collectives of eref are stream-ordered behind the counting kernels on stream A,
+    # those of generateGraph behind classify on stream B, and the host waits for nothing between them -- no synchronize at the
+    # hand-overs, no count read back to size a gather (rows travel padded to a width the previous step established)
     if exch:
+        on_a, on_b = (lambda: torch.cuda.stream(sA)), (lambda: torch.cuda.stream(sB))
         planes = [torch.zeros(1 << 29, dtype=torch.uint8, device=dev) for _ in range(3)]   # torch-owned so RCCL
         ctx.eref_table_attach([t.data_ptr() for t in planes])                                # can address them
         ref_ranges = [multigpu.split_by_weight(sample["ref_lens"], r, world) for r in range(world)]
         scratch_consumed = torch.zeros(nt, dtype=torch.int64, device=dev)
-
         low_plane = torch.zeros(1 << 29, dtype=torch.uint8, device=dev)
+        n_c_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        counts_host = torch.zeros(world, dtype=torch.int64).pin_memory()
+        gat = {"width": 0, "rows": None, "edges": None}          # padded gather of the candidates: rows per rank, buffers
 
-        def pack_fn():                              # two planes per peer instead of three (include/palace_hip.h)
+        def pack_fn():                              # two planes per peer instead of three (include/palace_hip.h); stream A
             ctx.eref_table_pack_low(low_plane.data_ptr())
-            ctx.sync()
             return low_plane
 
-        def merge_fn(parts, n_parts, slice_off, slice_bytes, packed=False):
-            tsync()
+        def merge_fn(parts, n_parts, slice_off, slice_bytes, packed=False):      # stream A, behind the all-to-all issued on it
             ctx.eref_table_merge_slices(parts.data_ptr(), n_parts, slice_off, slice_bytes, packed)
-            ctx.sync()
     last = {}
     seen = {"graph": set(), "rows": set(), "steps": 0}     # result digests of the untimed steps (warm-up, soak): one value each, or the step is not repeatable
     h_last = {}
@@ -841,6 +903,11 @@ def measure(args, E, leg):
     probe_index = ctypes.c_void_p()
     capi._check(L.palace_eref_probe_index_build(ctx.h, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
                                                 sample["ref_total"], ctypes.byref(probe_index)), "probe index")
+    # the count launch of a step is its final count (below): channel 0 of Phase B rides along in the count kernel while each fine
+    # bucket's ">= 3" slice is in LDS (palace_eref_attach_probe_index); PALACE_BENCH_FUSED_PROBE=0: the probe kernel does it (A/B runs)
+    fused_probe = depth == 1 and os.environ.get("PALACE_BENCH_FUSED_PROBE", "1") == "1"
+    if fused_probe:
+        capi._check(L.palace_eref_attach_probe_index(ctx.h, probe_index), "attach probe index")
 
     # the reads in the form the step counts them from (resident before the timed region, like every other input)
     packed = None
@@ -891,26 +958,24 @@ def measure(args, E, leg):
             seq["counted"] = slot
 
         skip_eref = os.environ.get("PALACE_BENCH_SKIP_EREF") == "1"      # tuning runs only: stream B alone on the device
-        if not exch and not skip_eref:
-            eref_head()                                # one GPU: launched first, generateGraph + matching overlap it
+        if not skip_eref:
+            eref_head()                                # launched first: generateGraph + matching (and, on N GPUs, their small collectives at
+                                                       # RCCL's high-priority stream) overlap the counting kernels
 
         def eref_tail():
-            if exch and shard_reads:                   # count-table exchange (RCCL), then Phase B on this rank's refs
-                ctx.sync()
-                exch.merge_planes(planes, merge_fn, pack_fn)
-                tsync()
+            if exch and shard_reads:                   # count-table exchange (RCCL) on stream A, then Phase B on this rank's refs
+                with on_a():
+                    exch.merge_planes(planes, merge_fn, pack_fn)
             elif key_split:                            # every rank counted its range of the key space: gather the ">= 3" plane
-                ctx.sync()
-                exch.gather_key_buckets(planes[2])
-                tsync()
+                with on_a():
+                    exch.gather_key_buckets(planes[2])
             if timed: ctx.mark(m + 2)
             capi._check(L.palace_eref_scan_refs_indexed(ctx.h, probe_index, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
                                                         sample["ref_total"], one_min, three_min, P(rows) + 16 * r_lo), "scan")
             if timed: ctx.mark(m + 3)
             if exch:
-                ctx.sync()
-                exch.gather_ranges(rows, ref_ranges)
-                tsync()
+                with on_a():
+                    exch.gather_ranges(rows, ref_ranges)
 
         if not exch and not skip_eref:
             eref_tail()                                # one GPU: queue Phase B right behind the counting kernels
@@ -928,24 +993,43 @@ def measure(args, E, leg):
                                                P(cands), cand_cap, ctypes.byref(n_c), ctypes.byref(n_b)), "classify")
         if timed: g.mark(m + 1)
         all_c, n_cands, n_border, e_buf, cons_for_quirk = cands, n_c.value, n_b.value, edges, consumed
-        if exch:                                   # every rank resolves the same gathered candidates;
-            all_c, n_cands = exch.gather_varlen(cands, n_cands)          # only rank 0's quirk sums join the reduce
-            nb = torch.tensor([n_border], device=dev, dtype=torch.int64)
-            dist.all_reduce(nb)
-            n_border = int(nb.item())
-            e_buf = edges if n_cands <= cand_cap else torch.zeros((n_cands, 32), dtype=torch.uint8, device=dev)
-            if rank != 0:
-                scratch_consumed.zero_()
-                cons_for_quirk = scratch_consumed
-            tsync()
+        n_cands_sample = n_cands
+        if exch:
+            # every rank resolves the same gathered candidates (only rank 0's quirk sums join the reduce).  A rank decides ITS
+            # candidates of the exp-underflow zone before they travel (host libm; none in the default workload), so no count of
+            # them is exchanged.  The gather itself: rows padded to `width` per rank, zero rows are candidates resolve ignores;
+            # the width is what the step before saw (+ 1/8), the per-rank counts come back with the step's results and are
+            # checked then.  The first step (and one whose counts outgrew the width) takes the exact gather, which reads them.
+            if n_border:
+                capi._check(L.palace_graph_score_border(g.h, P(cands), n_cands, n_border, ctypes.byref(prm)), "score border")
+                n_border = 0
+            with on_b():
+                if gat["width"] <= 0:
+                    all_c, n_cands = exch.gather_varlen(cands, n_cands)
+                    n_cands_sample = n_cands
+                    gat["learn"] = True
+                else:
+                    n_c_dev.fill_(n_cands)
+                    gat["rows"], counts_dev = exch.gather_padded(cands, n_c_dev, gat["width"], gat["rows"])
+                    counts_host.copy_(counts_dev, non_blocking=True)
+                    all_c, n_cands = gat["rows"], world * gat["width"]
+                    gat["learn"] = False
+                if gat["edges"] is None or gat["edges"].shape[0] < max(n_cands, cand_cap):
+                    gat["edges"] = torch.zeros((max(n_cands, cand_cap), 32), dtype=torch.uint8, device=dev)
+                e_buf = gat["edges"]
+                if rank != 0:
+                    scratch_consumed.zero_()
+                    cons_for_quirk = scratch_consumed
         capi._check(L.palace_graph_resolve_ex(g.h, P(all_c), n_cands, n_border, gs["n_total"], ctypes.byref(prm), P(cons_for_quirk),
                                               P(e_buf), max(1, n_cands), P(n_edges_dev), None), "resolve")
         if exch:
-            g.sync()
-            exch.reduce_sum(consumed)
-            tsync()
+            with on_b():
+                exch.reduce_sum(consumed)
         capi._check(L.palace_graph_copy_numbers(g.h, P(consumed), P(gs["tlen"]), nt, gs["avg_depth"], P(cn_dev)), "cn")
-        if timed: g.mark(m + 2)
+        if ctx_s is not g and stage04 is not None:  # stage 04 has a stream of its own: it starts when the copy numbers are there
+            g.mark(4092)
+            ctx_s.wait_for_mark(g, 4092)
+        if timed: g.mark(m + 2); ctx_s.mark(m + 2)
         if stage04 is not None:                     # rank 0 owns the (small) stage; its result is what the sample's all_result holds
             # Stage 04 is ~150 small latency-bound launches beside the bandwidth-bound counting kernels; each costs those kernels a
             # few microseconds (kernel boundaries write back the L2 lines the partition kernels combine their stores in): about
@@ -954,11 +1038,11 @@ def measure(args, E, leg):
             late = not exch and not skip_eref and os.environ.get("PALACE_BENCH_STAGE04_LATE") == "1"
             stage04.filter(P(e_buf), P(n_edges_dev), max(1, n_cands))
             stage04.match(P(e_buf), P(cn_dev), 10, False, True, after=(ctx, 4095) if late else None)
-        if timed: g.mark(m + 3)
+        if timed: ctx_s.mark(m + 3)
         th1 = time.perf_counter()
         if timed:
             host_ms["graph_enqueue_incl_classify_wait"] = host_ms.get("graph_enqueue_incl_classify_wait", 0.0) + 1e3 * (th1 - th0) / args.steps
-        last.update(n_cands=int(n_cands))
+        last.update(n_cands=int(n_cands_sample))
 
         def finish_graph():
             """the end of stream B: wait for the decomposition, take the result views; on untimed steps also the bookkeeping
@@ -990,11 +1074,8 @@ def measure(args, E, leg):
                 seen["graph"].add(last["digest_graph"])
             h_last["result"] = (res, contig_of)                   # views, valid until the next match call
 
-        if exch:
-            # N GPUs: generateGraph's small collectives went first (behind a saturating count launch they would wait for it);
-            # rank 0's stage 04 now runs on its device beside counting + exchange + Phase B
-            eref_head()
-            eref_tail()
+        if exch and not skip_eref:
+            eref_tail()                                # the plane exchange / gather, Phase B and the row gather, all enqueued on stream A
         finish_graph()
         # ---------------- join: eref results to the host ----------------
         # the rows of THIS batch are requested; with two batches in flight the ones waited for are the previous batch's (whose
@@ -1011,15 +1092,25 @@ def measure(args, E, leg):
                 ectx[seq["pending"]].mark_wait(4094)
             seq["pending"] = slot
         seq["last"] = slot
+        if exch:
+            g.mark(4093)
+            g.mark_wait(4093)                          # stream B has drained on every rank (only rank 0 waited for a stage-04 result)
+            cnt = exch.last_counts if gat["learn"] else [int(x) for x in counts_host.tolist()]
+            if not gat["learn"] and max(cnt) > gat["width"]:
+                gat["width"] = 0                       # a rank had more candidates than the padded gather carried: this step again, exactly
+                return step(i, timed)
+            last["n_cands"] = int(sum(cnt))
+            gat["width"] = max(gat["width"], (max(cnt) + max(cnt) // 8 + 256) // 256 * 256)
 
     def barrier():
         for e in ectx:
             e.sync()
         seq["pending"] = None
         ctx_g.sync()
+        ctx_s.sync()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if sync_dist is not None:
+            sync_dist.barrier()
             torch.cuda.synchronize()
 
     torch.cuda.synchronize()                         # every buffer torch made above is filled before a library stream touches it
@@ -1031,15 +1122,15 @@ def measure(args, E, leg):
         step(i, True)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sync_world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        sync_dist.all_reduce(tmax, op=sync_dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_step = 1e3 * dt / args.steps
     # soak: the K timed steps above are what `value` is computed from; when they took less than --soak-seconds the same
     # step keeps running (untimed for `value`) so that an outside GPU-activity sampler has something to see
     soak = None
-    if dt < args.soak_seconds and not exch:
+    if dt < args.soak_seconds and not exch and sync_world == 1:
         t1, n_soak = time.perf_counter(), 0
         while time.perf_counter() - t1 < args.soak_seconds - dt:
             for _ in range(10):
@@ -1059,13 +1150,15 @@ def measure(args, E, leg):
         scan_ms = np.mean([E(i).mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
     classify_ms = np.mean([ctx_g.mark_elapsed(8 * i, 8 * i + 1) for i in K])
     resolve_ms = np.mean([ctx_g.mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
-    stage04_ms = np.mean([ctx_g.mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
+    stage04_ms = np.mean([ctx_s.mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
     r = rows_host_l[seq["last"]].numpy()
     reported = int(((r[:, 1] > 0) & (r[:, 1].astype(np.float32) / r[:, 2].astype(np.float32) > 0.75)).sum())
 
-    failures = []
+    failures, out = [], None
     if rank == 0:
-        traffic, traffic_src = phase_a_traffic(args, world)
+        L.palace_version.restype = ctypes.c_char_p
+        version = L.palace_version().decode()
+        traffic, traffic_src, stage_traffic = profiled_traffic(args, world, version)
         alg_bytes = (READ_LEN + 6 * (READ_LEN - 31)) * 2 * n_side        # per launch (both FASTQ sides of this rank)
         achieved = alg_bytes / (count_ms * 1e-3) / 1e9
         out = {
@@ -1083,7 +1176,9 @@ def measure(args, E, leg):
                        "parallelism": "1 GPU" if world == 1 else (f"reads/records/refs sharded over {world} GPUs (RCCL)" if shard_reads else
                                                                    f"records/refs and the key space sharded over {world} GPUs (RCCL): every GPU counts its 1/{world} of the keys of all reads, the '>= 3' plane is all-gathered" if key_split else
                                                                    f"records/refs sharded over {world} GPUs (RCCL), reads counted on every GPU"),
-                       "ref_index": "per-DB probe index prebuilt, as the reference's cached <fasta>.k32.index.dat (8 B/position in HBM)",
+                       "parallelism_model": model,
+                       "ref_index": "per-DB probe index prebuilt, as the reference's cached <fasta>.k32.index.dat (8 B/position in HBM)"
+                                    + ("; its channel-0 probe rides along in the count kernel" if fused_probe and final_count and not key_split else ""),
                        "refs_reported": reported, "refs_present": int(len(sample["present"])),
                        "result_digest": {"eref_rows": hashlib.sha256(np.ascontiguousarray(r).tobytes()).hexdigest()[:16],
                                          "graph_and_components": last.get("digest_graph"),
@@ -1101,6 +1196,17 @@ def measure(args, E, leg):
                          # bin1 + bin2 + lds_count per launch; only valid for the default workload on one GPU
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "avg_launch_ms": count_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            # the other stages of the step against the same roofline (SURVEY.md section 8(d) algorithmic bytes; live event times of
+            # this run; PMC traffic of the committed profile when it is of this build and workload)
+            "roofline_stages": roofline_stages(dict(
+                phase_b=(sum(int(l) + 3 * (int(l) - 31) for l in sample["ref_lens"][r_lo:r_hi]), scan_ms,
+                         "l + 3(l - 31) B per ref: a byte per base, three 1-byte look-ups per position"),
+                classify=(52 * gs["n"] + 64 * gs["n_sa"], classify_ms, "52 B per primary record + 64 B per SA item"),
+                resolve=(64 * int(last.get("n_cands", 0)) + 16 * int(last.get("n_cands", 0)), resolve_ms,
+                         "64 B per candidate read + 16 B per evidence written"),
+                stage04=((32 * int(last.get("n_segs_filtered", 0)) + 24 * int(last.get("n_kept_junc", 0))) * 10, stage04_ms,
+                         "32 B per SEG + 24 B per JUNC of the filtered graph, read once per pass, -i 10 passes")), stage_traffic),
+            "library": version,
             # eref's unit is a read, generateGraph's a BAM record -- the same step in those units
             "rates": {"reads_per_s": 2 * sample["n_pairs_total"] / (ms_step * 1e-3), "bam_records_per_s": gs["n_total"] / (ms_step * 1e-3),
                       "read_bases_per_s": 2 * sample["n_pairs_total"] * READ_LEN / (ms_step * 1e-3)},
@@ -1111,7 +1217,7 @@ def measure(args, E, leg):
         }
         if soak:
             out["soak"] = soak
-        if world == 1 and not args.no_e2e:
+        if world == 1 and not solo and not args.no_e2e:
             import shutil
             import tempfile
             work = os.environ.get("PALACE_BENCH_WORK_DIR")          # (tools/e2e_repeat.sh: the directory it made for this run)
@@ -1130,14 +1236,20 @@ def measure(args, E, leg):
                 out["e2e"] = run_e2e(paths, gs["avg_depth"], args.contigs, r, n_junc, lin + "".join(a + b for a, b in pairs))
             except Exception as e:                   # never let this leg break the headline line
                 out["e2e"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
-            finally:
-                if not os.environ.get("PALACE_BENCH_KEEP"):      # (tools/eref_cli_repeat.sh re-runs the executables on these files)
-                    shutil.rmtree(work, ignore_errors=True)
-        if world == 1 and not args.no_cpu_baseline:             # (rank 0 at N = 1 only: the contract; the other ranks would wait for it)
-            res_v, contig_of = h_last["result"]
-            seg_flags, edge_flags = stage04.flags(len(h_last["edges"]))
-            out["cpu_baseline"] = cpu_baseline(torch, sample, gs, hdr, args.cpu_sample_frac,
-                                               dict(contig_of=np.asarray(contig_of).copy(), cn=h_last["cn"], edges=h_last["edges"], edge_flags=edge_flags))
+                paths = None
+        else:
+            work = paths = None
+        try:
+            if world == 1 and not solo and not args.no_cpu_baseline:         # (rank 0 at N = 1 only: the contract; the other ranks would wait for it)
+                res_v, contig_of = h_last["result"]
+                seg_flags, edge_flags = stage04.flags(len(h_last["edges"]))
+                out["cpu_baseline"] = cpu_baseline(torch, sample, gs, hdr, args.cpu_sample_frac,
+                                                   dict(contig_of=np.asarray(contig_of).copy(), cn=h_last["cn"], edges=h_last["edges"], edge_flags=edge_flags),
+                                                   bam_path=paths["bam"] if paths else None)
+        finally:
+            if work and not os.environ.get("PALACE_BENCH_KEEP"):              # (tools/eref_cli_repeat.sh re-runs the executables on these files)
+                import shutil
+                shutil.rmtree(work, ignore_errors=True)
         # a line whose own cross-checks failed is still printed, but the run does not pass: wrong refs, the executables on the
         # files disagreeing with the resident step (or the leg raising), results that differ from step to step
         e2e = out.get("e2e")
@@ -1155,20 +1267,23 @@ def measure(args, E, leg):
                 one = e2e.get("one_process_stage04") or {}
                 if one.get("files_identical_to_the_chain") is not True:
                     failures.append("e2e.one_process_stage04: " + str(one.get("error", "files differ from the chain's")))
-        if failures:
-            out["failed_checks"] = failures
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
     capi._check(L.palace_eref_probe_index_free(ctx.h, probe_index), "probe index free")
+    if stage04 is not None:
+        stage04.close()
     for e in ectx[1:]:
         e.close()
+    if ctx_s is not ctx_g:
+        ctx_s.close()
     ctx.close()
     ctx_g.close()
-    if dist is not None:
-        dist.destroy_process_group()
-    if failures:
-        print("bench.py: FAILED CHECKS: " + "; ".join(failures), file=sys.stderr)
-        sys.exit(3)
+    if solo:
+        # the weak record: N independent samples (one per GPU, the whole one-GPU step each), aggregate rate over the slowest rank
+        return dict(scaling="weak", n_gpus=sync_world, value=sync_world * args.contigs / (ms_step * 1e-3), unit="contigs/s",
+                    ms_per_step=ms_step, steps=args.steps, samples_per_step=sync_world,
+                    eref_count_ms=float(count_ms), result_digest=out["config"]["result_digest"],
+                    note="every rank runs the one-GPU step on a full sample of its own (here: the same synthetic sample on every rank), "
+                         "no collective in the data path; value = N x contigs / max-over-ranks time per step"), failures
+    return out, failures
 
 
 if __name__ == "__main__":

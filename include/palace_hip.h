@@ -40,6 +40,13 @@ int palace_ctx_create(int device, palace_ctx **out);
 /* same, with the context's stream at the device's highest priority when high_priority != 0 (for
  * small latency-bound work that runs beside bulk kernels of another context) */
 int palace_ctx_create_prio(int device, int high_priority, palace_ctx **out);
+/* The same with the stream confined to the compute units whose bit is set in cu_mask (n_words x 32 bits; NULL / 0 = no mask):
+ * a stream of many small latency-bound launches beside a saturating launch on another stream keeps CUs of its own. */
+int palace_ctx_create_masked(int device, int high_priority, const uint32_t *cu_mask, int n_words, palace_ctx **out);
+/* A context on the CALLER's stream (a hipStream_t): every call of the context enqueues there, so the caller's own work on that
+ * stream -- collectives, copies -- is ordered with the library's kernels without events or waits.  The stream is not
+ * destroyed with the context. */
+int palace_ctx_create_on_stream(int device, void *hip_stream, palace_ctx **out);
 int palace_ctx_destroy(palace_ctx *ctx);
 int palace_sync(palace_ctx *ctx);
 /* raw hipStream_t of the context (for callers that want to order their own work / events) */
@@ -168,6 +175,15 @@ int palace_eref_probe_index_free(palace_ctx *ctx, palace_eref_probe_index *ix);
 int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index *ix, const uint8_t *d_bases,
                                   const int64_t *d_offsets, int64_t n_refs, int64_t total_bases, int one_min,
                                   int three_min, int32_t *d_rows);
+
+/* Fuse Phase B's channel-0 probe of this DB into the count launch: while such an index is attached, a count call that runs as
+ * the FINAL count (option final_count, one slab, the whole key space) tests the DB's positions of every fine bucket against
+ * the bucket's final ">= 3" slice while that slice is still in LDS, and the next palace_eref_scan_refs_indexed with the same
+ * index starts from those hits: no probe kernel, no second read of the plane.  Results are identical either way (any other
+ * count call, a merge, an attach or a reset in between makes the scan probe for itself).  The index keeps one byte per DB
+ * position for the hits: attach it to ONE context at a time.  ix = NULL detaches. */
+int palace_eref_attach_probe_index(palace_ctx *ctx, const palace_eref_probe_index *ix);
+
 
 /* Multi-GPU exchange of the count table (no reference counterpart: the reference shares one
  * table between std::threads, extract_ref.cpp:1269-1291).  planes() exposes the three device

@@ -65,6 +65,8 @@ assert CAND_DTYPE.itemsize == 64 and EDGE_DTYPE.itemsize == 32 and SA_ITEM_DTYPE
 _SIGS = {
     "palace_ctx_create": [C.c_int, C.POINTER(C.c_void_p)],
     "palace_ctx_create_prio": [C.c_int, C.c_int, C.POINTER(C.c_void_p)],
+    "palace_ctx_create_masked": [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)],
+    "palace_ctx_create_on_stream": [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)],
     "palace_ctx_destroy": [C.c_void_p],
     "palace_sync": [C.c_void_p],
     "palace_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
@@ -96,6 +98,7 @@ _SIGS = {
     "palace_eref_scan_refs": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
                               C.c_void_p],
     "palace_eref_probe_index_build": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)],
+    "palace_eref_attach_probe_index": [C.c_void_p, C.c_void_p],
     "palace_eref_probe_index_free": [C.c_void_p, C.c_void_p],
     "palace_eref_scan_refs_indexed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                       C.c_void_p],
@@ -206,9 +209,17 @@ class DevBuf:
 class Ctx:
     """One device context (one HIP stream).  `calls` go straight to the C ABI."""
 
-    def __init__(self, device: int = 0, high_priority: bool = False):
+    def __init__(self, device: int = 0, high_priority: bool = False, cu_mask: int | None = None, stream: int | None = None):
+        """cu_mask: an integer whose bit i admits compute unit i to the context's stream (palace_ctx_create_masked);
+        stream: a hipStream_t of the caller's to run on instead of a stream of the context's own (palace_ctx_create_on_stream)"""
         h = C.c_void_p()
-        _check(lib().palace_ctx_create_prio(device, int(high_priority), C.byref(h)), "palace_ctx_create_prio")
+        if stream:
+            _check(lib().palace_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(h)), "palace_ctx_create_on_stream")
+        elif cu_mask:
+            words = (C.c_uint32 * 8)(*[(cu_mask >> (32 * k)) & 0xFFFFFFFF for k in range(8)])
+            _check(lib().palace_ctx_create_masked(device, int(high_priority), words, 8, C.byref(h)), "palace_ctx_create_masked")
+        else:
+            _check(lib().palace_ctx_create_prio(device, int(high_priority), C.byref(h)), "palace_ctx_create_prio")
         self.h = h
         self.device = device
 
@@ -314,6 +325,10 @@ class Ctx:
         _check(lib().palace_eref_probe_index_build(self.h, d_bases.ptr, d_offsets.ptr, n_refs, total_bases, C.byref(h)),
                "palace_eref_probe_index_build")
         return h
+
+    def eref_attach_probe_index(self, index):
+        """count calls that run as the final count also probe channel 0 of this DB (palace_eref_attach_probe_index); None detaches"""
+        _check(lib().palace_eref_attach_probe_index(self.h, index), "palace_eref_attach_probe_index")
 
     def eref_probe_index_free(self, index: C.c_void_p):
         _check(lib().palace_eref_probe_index_free(self.h, index), "palace_eref_probe_index_free")

@@ -57,6 +57,7 @@ void free_match_scratch(MatchScratch *m);
 struct palace_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;        // false: the caller's stream (palace_ctx_create_on_stream)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // eref count_reads: level 1 of the next part of a slab runs on `side` beside level 2 of the current one (eref.hip, bin_and_count)
     hipStream_t side = nullptr;
@@ -72,6 +73,10 @@ struct palace_ctx {
     bool want_final = false;        // option final_count: a count into a clean table may keep only the ">= 3" plane
     bool final_only = false;        // ... and did: planes ">= 1" and ">= 2" are all zero, the table cannot take further counts
     bool table_clean = false;       // every plane bit is zero (set by reset, cleared by whatever writes the planes)
+    // Phase B's channel-0 probe fused into the count launch (palace_eref_attach_probe_index): the attached per-DB index, and the
+    // index whose hit bytes the last count launch left complete (cleared by whatever changes the planes afterwards)
+    const struct palace_eref_probe_index *probe_ix = nullptr;
+    const struct palace_eref_probe_index *c0_hits_ix = nullptr;
     int count_mode = 0;             // 0 auto, 1 direct atomics, 2 binned
     int64_t bin_cap_override = 0;
     int64_t slab_override = 0;

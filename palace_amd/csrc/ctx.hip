@@ -75,11 +75,32 @@ using namespace palace;
 extern "C" {
 
 const char *palace_last_error(void) { return g_err; }
-const char *palace_version(void) { return "palace_hip 0.1 (gfx950)"; }
+#ifndef PALACE_BUILD_ID
+#define PALACE_BUILD_ID "unstamped"
+#endif
+const char *palace_version(void) { return "palace_hip 0.2 (gfx950) build " PALACE_BUILD_ID; }
 
 int palace_ctx_create(int device, palace_ctx **out) { return palace_ctx_create_prio(device, 0, out); }
 
 int palace_ctx_create_prio(int device, int high_priority, palace_ctx **out)
+{
+    return palace_ctx_create_masked(device, high_priority, nullptr, 0, out);
+}
+
+static int ctx_create(int device, int high_priority, const uint32_t *cu_mask, int n_words, hipStream_t given, palace_ctx **out);
+
+int palace_ctx_create_masked(int device, int high_priority, const uint32_t *cu_mask, int n_words, palace_ctx **out)
+{
+    return ctx_create(device, high_priority, cu_mask, n_words, nullptr, out);
+}
+
+int palace_ctx_create_on_stream(int device, void *hip_stream, palace_ctx **out)
+{
+    PALACE_REQUIRE(hip_stream != nullptr, "stream is null");
+    return ctx_create(device, 0, nullptr, 0, static_cast<hipStream_t>(hip_stream), out);
+}
+
+static int ctx_create(int device, int high_priority, const uint32_t *cu_mask, int n_words, hipStream_t given, palace_ctx **out)
 {
     PALACE_REQUIRE(out != nullptr, "out is null");
     int n = 0;
@@ -97,7 +118,12 @@ int palace_ctx_create_prio(int device, int high_priority, palace_ctx **out)
         palace_ctx_destroy(ctx);
         return PALACE_EHIP;
     };
-    if (high_priority) {
+    if (given) {                                           // the caller's stream: used, never destroyed
+        ctx->stream = given;
+        ctx->owns_stream = false;
+    } else if (cu_mask && n_words > 0) {                   // the stream's kernels only run on the CUs whose bit is set (no priority with it)
+        if ((e = hipExtStreamCreateWithCUMask(&ctx->stream, static_cast<uint32_t>(n_words), cu_mask)) != hipSuccess) return fail("hipExtStreamCreateWithCUMask", e);
+    } else if (high_priority) {
         int least = 0, greatest = 0;                       // numerically lower = more urgent
         if ((e = hipDeviceGetStreamPriorityRange(&least, &greatest)) != hipSuccess) return fail("hipDeviceGetStreamPriorityRange", e);
         if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest)) != hipSuccess) return fail("hipStreamCreateWithPriority", e);
@@ -129,7 +155,7 @@ int palace_ctx_destroy(palace_ctx *ctx)
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream && ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PALACE_OK;
 }

@@ -782,17 +782,36 @@ constexpr int kCountThreads = 256;
 // FINAL (implies CLEAN): the caller reads nothing but the ">= 3" plane afterwards (Phase B does not) -- the two lower planes
 // are not written at all, and where the overflow path of the partition kernels put bits into them (touched buckets) they are
 // zeroed again: after the launch they are all zero, as after a reset.
-template <bool CLEAN, bool FINAL = false>
+// PROBE (with FINAL, whole key space): Phase B's channel-0 probe of one DB rides along -- while the bucket's final ">= 3" slice
+// is in LDS, the DB positions whose channel-0 index falls into the bucket (the per-DB probe index, grouped by these very
+// buckets) are tested against it and their hit bytes set: the scan that follows needs neither the probe kernel nor its read
+// of the plane (palace_eref_attach_probe_index).
+struct ProbeArgs {
+    const unsigned long long *first, *entries;             // [65537] group starts, entries (position id << 18 | index & 0x3ffff)
+    uint8_t *hit_bytes;                                     // a byte per DB position, zero before the launch
+};
+template <int THREADS, int BATCH>
+__device__ __forceinline__ void probe_first_batch(const unsigned long long *__restrict__ entries, unsigned long long e0, unsigned long long hi,
+                                                  ulonglong2 (&cur)[BATCH]);
+template <int THREADS, int BATCH, bool DOUBLE>
+__device__ __forceinline__ void probe_group(const uint32_t *l3, uint32_t key_mask, const unsigned long long *__restrict__ entries,
+                                            unsigned long long e0, unsigned long long hi, ulonglong2 (&cur)[BATCH], uint8_t *__restrict__ hit_bytes);
+
+template <bool CLEAN, bool FINAL = false, bool PROBE = false>
 __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const unsigned int *__restrict__ cursor,
                                                                        const uint16_t *__restrict__ binned,
                                                                        DensityCaps caps, uint32_t *__restrict__ p1,
                                                                        uint32_t *__restrict__ p2,
                                                                        uint32_t *__restrict__ p3,
-                                                                       const unsigned int *__restrict__ touched, KeyBuckets share)
+                                                                       const unsigned int *__restrict__ touched, KeyBuckets share,
+                                                                       ProbeArgs pr)
 {
     __shared__ uint32_t l1[kFineWords], l2[kFineWords], l3[kFineWords];
     const uint32_t b = blockIdx.x, b1 = b / kL2Rows;
     if (!share.bucket(b1)) return;                          // a call that counts a share of the key space: not its bucket
+    constexpr int kProbeBatch = 6;                          // pair loads per thread and batch: a bucket's group (~3000 entries, ~12 per thread) is ONE batch
+    unsigned long long pe0 = 0, phi = 0;
+    if (PROBE) { pe0 = pr.first[b]; phi = pr.first[b + 1]; }
     // the bucket's keys lie in eight sub-regions (one per XCD that wrote them); as one sequence of 16-byte vectors of eight
     // keys: vector j belongs to sub-region x with first[x] <= j < first[x + 1]
     const uint32_t sub_cap = fine_sub_cap(caps, b1);
@@ -809,8 +828,16 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
         if (FINAL && ((touched[b >> 5] >> (b & 31)) & 1u)) {       // only overflow keys: plane 3 is right as it is, the lower two go back to zero
             uint4 *z1 = reinterpret_cast<uint4 *>(p1 + w0), *z2 = reinterpret_cast<uint4 *>(p2 + w0);
             for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) z1[i] = z2[i] = uint4{0, 0, 0, 0};
+            if (PROBE && phi > pe0) {                              // ... and is what the DB's positions of this bucket are tested against
+                ulonglong2 cur[kProbeBatch];
+                probe_first_batch<kCountThreads, kProbeBatch>(pr.entries, pe0, phi, cur);
+                const uint4 *s3 = reinterpret_cast<const uint4 *>(p3 + w0);
+                for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) reinterpret_cast<uint4 *>(l3)[i] = s3[i];
+                __syncthreads();
+                probe_group<kCountThreads, kProbeBatch, false>(l3, 0xffffu, pr.entries, pe0, phi, cur, pr.hit_bytes);
+            }
         }
-        return;
+        return;                                            // (no key at all: the slice is zero, no position of the DB hits)
     }
     const uint4 *g1 = reinterpret_cast<const uint4 *>(p1 + w0), *g2 = reinterpret_cast<const uint4 *>(p2 + w0),
                 *g3 = reinterpret_cast<const uint4 *>(p3 + w0);
@@ -879,7 +906,13 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
 #pragma unroll
         for (int u = 0; u < kBatch; u++) { v[u] = nx[u]; ok[u] = nok[u]; }
     }
+    // PROBE: the bucket's entries are requested before the barrier and tested right behind it, BEFORE the write-back: a wave's
+    // vmcnt counts loads and stores together, so with the slice's stores already in flight the tests would wait for those to be
+    // acknowledged as well
+    ulonglong2 pcur[kProbeBatch];
+    if (PROBE && phi > pe0) probe_first_batch<kCountThreads, kProbeBatch>(pr.entries, pe0, phi, pcur);
     __syncthreads();
+    if (PROBE && phi > pe0) probe_group<kCountThreads, kProbeBatch, false>(l3, 0xffffu, pr.entries, pe0, phi, pcur, pr.hit_bytes);
     uint4 *o1 = reinterpret_cast<uint4 *>(p1 + w0), *o2 = reinterpret_cast<uint4 *>(p2 + w0),
           *o3 = reinterpret_cast<uint4 *>(p3 + w0);
     for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) {
@@ -1116,7 +1149,7 @@ __global__ __launch_bounds__(256) void eref_probe_index_kernel(const uint8_t *__
                            w2 = window32(lo.p2, hi.p2, lane);
             const uint32_t key = canonical(masks, 0, w0, w1, w2, __brev(w0), __brev(w1), __brev(w2));
             if (key != 0) {                                   // index 0 means "none" (extract_ref.cpp:861)
-                const uint32_t b = key >> kBucketShift;
+                const uint32_t b = key >> 16;                    // fine bucket of the count kernel; four of them are one probe group
                 const unsigned long long at = atomicAdd(&count[b], 1ull);
                 if (PASS == 1)
                     entries[first[b] + at] = (static_cast<unsigned long long>((wbase + c) * 64 + lane) << kBucketShift) |
@@ -1127,14 +1160,15 @@ __global__ __launch_bounds__(256) void eref_probe_index_kernel(const uint8_t *__
     }
 }
 
-// exclusive prefix of the 16384 bucket counts (one workgroup, 16 buckets per thread); first[16384] = total
+// exclusive prefix of the 65536 fine-bucket counts (one workgroup, 64 buckets per thread); first[65536] = total
+constexpr int kIndexGroups = 1 << 16, kGroupsPerProbe = kIndexGroups / kBuckets;
 __global__ __launch_bounds__(1024) void eref_bucket_prefix_kernel(const unsigned long long *__restrict__ count,
                                                                   unsigned long long *__restrict__ first)
 {
     __shared__ unsigned long long part[1024];
-    unsigned long long v[16], sum = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) { v[i] = count[threadIdx.x * 16 + i]; sum += v[i]; }
+    constexpr int kPer = kIndexGroups / 1024;
+    unsigned long long sum = 0;
+    for (int i = 0; i < kPer; i++) sum += count[threadIdx.x * kPer + i];
     part[threadIdx.x] = sum;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
@@ -1144,9 +1178,63 @@ __global__ __launch_bounds__(1024) void eref_bucket_prefix_kernel(const unsigned
         __syncthreads();
     }
     unsigned long long run = part[threadIdx.x] - sum;
+    for (int i = 0; i < kPer; i++) { first[threadIdx.x * kPer + i] = run; run += count[threadIdx.x * kPer + i]; }
+    if (threadIdx.x == 1023) first[kIndexGroups] = run;
+}
+
+// the entries [e0, hi) of one group tested against a slice of plane 3 held in LDS (bit k & key_mask of the slice); a hit is a
+// BYTE store into the byte-per-position array (see eref_probe_kernel).  Entries two at a time: 16-byte loads, the group widened
+// to even entry indices and the strangers at its ends skipped (the array is padded by one entry); the next batch of loads is
+// always in flight.  `cur` must hold the first batch (probe_first_batch), which does not depend on the slice.
+template <int THREADS, int BATCH>
+__device__ __forceinline__ void probe_first_batch(const unsigned long long *__restrict__ entries, unsigned long long e0, unsigned long long hi,
+                                                  ulonglong2 (&cur)[BATCH])
+{
+    const unsigned long long lo = e0 & ~1ull, n2 = (hi - lo + 1) / 2;
+    const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(entries + lo);
 #pragma unroll
-    for (int i = 0; i < 16; i++) { first[threadIdx.x * 16 + i] = run; run += v[i]; }
-    if (threadIdx.x == 1023) first[kBuckets] = run;
+    for (int u = 0; u < BATCH; u++) {
+        const unsigned long long i = threadIdx.x + static_cast<unsigned long long>(u) * THREADS;
+        cur[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
+    }
+}
+template <int THREADS, int BATCH, bool DOUBLE>
+__device__ __forceinline__ void probe_group(const uint32_t *l3, uint32_t key_mask, const unsigned long long *__restrict__ entries,
+                                            unsigned long long e0, unsigned long long hi, ulonglong2 (&cur)[BATCH], uint8_t *__restrict__ hit_bytes)
+{
+    const unsigned long long lo = e0 & ~1ull, n2 = (hi - lo + 1) / 2;
+    const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(entries + lo);
+    constexpr unsigned long long kStride = static_cast<unsigned long long>(BATCH) * THREADS;
+    auto test = [&](unsigned long long ent, unsigned long long at) {  // at: global index of the entry
+        if (at < e0 || at >= hi) return;
+        const uint32_t k = static_cast<uint32_t>(ent) & key_mask;
+        if ((l3[k >> 5] >> (k & 31)) & 1u) hit_bytes[ent >> kBucketShift] = 1;
+    };
+    for (unsigned long long i0 = threadIdx.x; i0 < n2; i0 += kStride) {
+        ulonglong2 nxt[BATCH];
+        if (DOUBLE) {                                          // the next batch of loads is in flight while this one is tested
+#pragma unroll
+            for (int u = 0; u < BATCH; u++) {
+                const unsigned long long i = i0 + kStride + static_cast<unsigned long long>(u) * THREADS;
+                nxt[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+            const unsigned long long i = i0 + static_cast<unsigned long long>(u) * THREADS;
+            if (i < n2) { test(cur[u].x, lo + 2 * i); test(cur[u].y, lo + 2 * i + 1); }
+        }
+        if (DOUBLE) {
+#pragma unroll
+            for (int u = 0; u < BATCH; u++) cur[u] = nxt[u];
+        } else if (i0 - threadIdx.x + kStride < n2) {          // (uniform) a group larger than one batch: rare where DOUBLE is off
+#pragma unroll
+            for (int u = 0; u < BATCH; u++) {
+                const unsigned long long i = i0 + kStride + static_cast<unsigned long long>(u) * THREADS;
+                cur[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
+            }
+        }
+    }
 }
 
 // one workgroup per fine bucket: its slice of plane 3 in LDS, its positions tested against it.
@@ -1160,47 +1248,18 @@ __global__ __launch_bounds__(kProbeThreads) void eref_probe_kernel(const unsigne
 {
     __shared__ uint32_t l3[kSliceWords];
     const uint32_t b = blockIdx.x;
-    const unsigned long long e0 = first[b], n = first[b + 1] - e0;
-    if (n == 0) return;                                    // uniform for the workgroup
-    // Entries two at a time (16-byte loads; the group is widened to even entry indices and the strangers at its ends are
-    // skipped), the first batch requested before the slice is: it does not depend on it.
-    const unsigned long long lo = e0 & ~1ull, hi = e0 + n;            // entries [lo, hi) are loaded, [e0, hi) tested
-    const unsigned long long n2 = (hi - lo + 1) / 2;                  // pairs (the array is padded by one entry: see the builder)
-    const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(entries + lo);
+    const unsigned long long e0 = first[b * kGroupsPerProbe], hi = first[(b + 1) * kGroupsPerProbe];
+    if (hi == e0) return;                                  // uniform for the workgroup
+    // a hit is a BYTE store, not an atomicOr into the bit array: the ~8 M hits of a step are random over 200 M positions, and
+    // as 64-bit atomics they were 0.6 ms of this kernel's 1.04 (measured by leaving them out); eref_hits_to_bits_kernel packs
+    // the bytes afterwards
     constexpr int kBatch = 4;                              // pair loads per thread and batch
-    constexpr unsigned long long kStride = static_cast<unsigned long long>(kBatch) * kProbeThreads;
     ulonglong2 cur[kBatch];
-#pragma unroll
-    for (int u = 0; u < kBatch; u++) {
-        const unsigned long long i = threadIdx.x + static_cast<unsigned long long>(u) * kProbeThreads;
-        cur[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
-    }
+    probe_first_batch<kProbeThreads, kBatch>(entries, e0, hi, cur);       // requested before the slice is: it does not depend on it
     const uint4 *g3 = reinterpret_cast<const uint4 *>(p3 + static_cast<size_t>(b) * kSliceWords);
     for (int i = threadIdx.x; i < kSliceWords / 4; i += kProbeThreads) reinterpret_cast<uint4 *>(l3)[i] = g3[i];
     __syncthreads();
-    auto test = [&](unsigned long long ent, unsigned long long at) {  // at: global index of the entry
-        if (at < e0 || at >= hi) return;
-        const uint32_t k = static_cast<uint32_t>(ent) & ((1u << kBucketShift) - 1);
-        // a hit is a BYTE store, not an atomicOr into the bit array: the ~8 M hits of a step are random over 200 M positions, and
-        // as 64-bit atomics they were 0.6 ms of this kernel's 1.04 (measured by leaving them out); eref_hits_to_bits_kernel packs
-        // the bytes afterwards
-        if ((l3[k >> 5] >> (k & 31)) & 1u) hit_bytes[ent >> kBucketShift] = 1;
-    };
-    for (unsigned long long i0 = threadIdx.x; i0 < n2; i0 += kStride) {
-        ulonglong2 nxt[kBatch];
-#pragma unroll
-        for (int u = 0; u < kBatch; u++) {
-            const unsigned long long i = i0 + kStride + static_cast<unsigned long long>(u) * kProbeThreads;
-            nxt[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; u++) {
-            const unsigned long long i = i0 + static_cast<unsigned long long>(u) * kProbeThreads;
-            if (i < n2) { test(cur[u].x, lo + 2 * i); test(cur[u].y, lo + 2 * i + 1); }
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; u++) cur[u] = nxt[u];
-    }
+    probe_group<kProbeThreads, kBatch, true>(l3, (1u << kBucketShift) - 1, entries, e0, hi, cur, hit_bytes);
 }
 
 // hit bytes of the probe kernel -> the bit words everything downstream reads: a lane packs 16 positions (bit 0 of each byte
@@ -1565,6 +1624,7 @@ int palace_eref_table_reset(palace_ctx *ctx)
             PALACE_HIP_TRY(hipMemsetAsync(ctx->plane[p], 0, kPlaneBytes, ctx->stream));
     ctx->table_clean = true;
     ctx->final_only = false;
+    ctx->c0_hits_ix = nullptr;
     return PALACE_OK;
 }
 
@@ -1705,6 +1765,35 @@ static void carve_count(const CountPlan &pl, char *ws, bool with_words, CountBuf
     b->buf2 = reinterpret_cast<uint16_t *>(ws);
 }
 
+struct palace_eref_probe_index {
+    int64_t n_refs = 0, total_bases = 0;
+    palace::CoderMasks masks{};               // the coder the indices were computed with
+    unsigned long long n_entries = 0;
+    unsigned long long *first = nullptr;      // [kIndexGroups + 1]: entries grouped by index >> 16 (the count kernel's fine buckets;
+                                              //  four consecutive groups are one 2^18-key group of the stand-alone probe kernel)
+    unsigned long long *entries = nullptr;    // [n_entries] (position id << 18) | (index & 0x3ffff)
+    uint8_t *hit_bytes = nullptr;             // a byte per position id: the channel-0 hits a count launch leaves when the index is attached
+    size_t hit_bytes_size = 0;
+};
+
+static_assert(kIndexGroups == kFine, "the probe index is grouped by the count kernel's fine buckets");
+
+static bool probe_index_usable(const palace_ctx *ctx, const palace_eref_probe_index *ix)
+{
+    return ix->hit_bytes && std::memcmp(&ix->masks, &ctx->masks, sizeof(CoderMasks)) == 0;
+}
+
+// the final count kernel of a launch with Phase B's channel-0 probe riding along (eref_lds_count_kernel<true, true, true>)
+static int probe_index_launch_fused(palace_ctx *ctx, const palace_eref_probe_index *ix, const CountBufs &b, const CountPlan &pl, const KeyBuckets &keys)
+{
+    PALACE_HIP_TRY(hipMemsetAsync(ix->hit_bytes, 0, ix->hit_bytes_size, ctx->stream));
+    const ProbeArgs pr{ix->first, ix->entries, ix->hit_bytes};
+    hipLaunchKernelGGL((eref_lds_count_kernel<true, true, true>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
+                       ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, pr);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
 static int launch_bin1(palace_ctx *ctx, hipStream_t stream, int ppl, const uint32_t *w0, const uint32_t *w1, const uint32_t *wu, int64_t p_lo,
                        int64_t p_hi, const BinOut &o1)
 {
@@ -1746,6 +1835,7 @@ static int launch_bin1(palace_ctx *ctx, hipStream_t stream, int ppl, const uint3
 static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &b, const uint32_t *w0, const uint32_t *w1,
                          const uint32_t *wu, int64_t total_bases, double keys_per_pos)
 {
+    ctx->c0_hits_ix = nullptr;
     const int64_t kSlabBases = pl.slab_bases_max, n_slabs = pl.n_slabs;
     // positions per lane of the level-1 kernel.  Its throughput is (key slots the CU's LDS holds) / (latency of a tile,
     // ~11 us whatever the tile size): 6 positions x 3 keys x 512 lanes + pads = 39.8 KiB, the most that still fits four
@@ -1789,16 +1879,26 @@ static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &
             PALACE_HIP_TRY(hipGetLastError());
             if (overlap) PALACE_HIP_TRY(hipEventRecord(ev_l2[k], ctx->stream));
         }
+        const ProbeArgs no_probe{nullptr, nullptr, nullptr};
         if (clean && n_slabs == 1 && ctx->want_final) {
-            hipLaunchKernelGGL((eref_lds_count_kernel<true, true>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
-                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys);
+            const palace_eref_probe_index *ix = ctx->probe_ix;
+            const bool whole = (ctx->key_buckets[0] & ctx->key_buckets[1] & ctx->key_buckets[2] & ctx->key_buckets[3]) == ~0u;
+            if (ix && whole && probe_index_usable(ctx, ix)) {
+                // the final count of a whole key space with a probe index attached: channel 0 of Phase B rides along
+                int rc = probe_index_launch_fused(ctx, ix, b, pl, keys);
+                if (rc) return rc;
+                ctx->c0_hits_ix = ix;
+            } else {
+                hipLaunchKernelGGL((eref_lds_count_kernel<true, true>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
+                                   ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, no_probe);
+            }
             ctx->final_only = true;
         } else if (clean)
             hipLaunchKernelGGL(eref_lds_count_kernel<true>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
-                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys);
+                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, no_probe);
         else
             hipLaunchKernelGGL(eref_lds_count_kernel<false>, dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
-                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys);
+                               ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, no_probe);
         PALACE_HIP_TRY(hipGetLastError());
         ctx->table_clean = false;
     }
@@ -1833,6 +1933,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         int64_t blocks = (n_reads + 3) / 4;                 // 4 waves (reads) per 256-thread block
         int64_t cap = static_cast<int64_t>(kCUs) * 8 * 8;   // grid-stride beyond 16 Ki blocks
         if (blocks > cap) blocks = cap;
+        ctx->c0_hits_ix = nullptr;
         hipLaunchKernelGGL(eref_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream,
                            d_bases, d_offsets, n_reads, d_keep, ctx->masks, ctx_buckets(ctx), ctx->plane[0], ctx->plane[1],
                            ctx->plane[2]);
@@ -1899,6 +2000,7 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
     const bool binned = ctx->count_mode == 2 || (ctx->count_mode == 0 && n_positions >= (1ll << 22));
     if (!binned) {
         const int64_t blocks = std::min<int64_t>((n_positions + 255) / 256, static_cast<int64_t>(kCUs) * 8 * 8);
+        ctx->c0_hits_ix = nullptr;
         hipLaunchKernelGGL(eref_count_packed_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d_p0, d_p1, d_u,
                            n_positions, ctx->masks, ctx_buckets(ctx), ctx->plane[0], ctx->plane[1], ctx->plane[2]);
         PALACE_HIP_TRY(hipGetLastError());
@@ -1997,13 +2099,6 @@ int palace_eref_index_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_
 
 }  // extern "C"
 
-struct palace_eref_probe_index {
-    int64_t n_refs = 0, total_bases = 0;
-    palace::CoderMasks masks{};               // the coder the indices were computed with
-    unsigned long long n_entries = 0;
-    unsigned long long *first = nullptr;      // [kBuckets + 1]
-    unsigned long long *entries = nullptr;    // [n_entries]
-};
 
 namespace {
 
@@ -2119,23 +2214,25 @@ int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const
         hipError_t e__ = (expr);                                                                            \
         if (e__ != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(e__)); return done(PALACE_EHIP); } \
     } while (0)
-    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->first), (kBuckets + 1) * 8));
-    TRY_OR_DONE(hipMemsetAsync(ix->first, 0, (kBuckets + 1) * 8, ctx->stream));
+    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->first), (kIndexGroups + 1) * 8));
+    TRY_OR_DONE(hipMemsetAsync(ix->first, 0, (kIndexGroups + 1) * 8, ctx->stream));
     if (n_refs == 0) return done(PALACE_OK);
     ScanBuffers b;
     int rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b);     // tile_pre / word_pre exactly as the scans lay them out
     if (rc) return done(rc);
-    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&count), kBuckets * 8));
-    TRY_OR_DONE(hipMemsetAsync(count, 0, kBuckets * 8, ctx->stream));
+    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&count), kIndexGroups * 8));
+    TRY_OR_DONE(hipMemsetAsync(count, 0, kIndexGroups * 8, ctx->stream));
     hipLaunchKernelGGL(eref_probe_index_kernel<0>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
                        d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, count,
                        static_cast<const unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr));
     hipLaunchKernelGGL(eref_bucket_prefix_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, ix->first);
     TRY_OR_DONE(hipGetLastError());
-    TRY_OR_DONE(hipMemcpyAsync(&ix->n_entries, ix->first + kBuckets, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TRY_OR_DONE(hipMemcpyAsync(&ix->n_entries, ix->first + kIndexGroups, 8, hipMemcpyDeviceToHost, ctx->stream));
     TRY_OR_DONE(hipStreamSynchronize(ctx->stream));
     TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->entries), (ix->n_entries + 2) * 8));      // (+ pad: the probe kernel loads pairs)
-    TRY_OR_DONE(hipMemsetAsync(count, 0, kBuckets * 8, ctx->stream));
+    TRY_OR_DONE(hipMemsetAsync(count, 0, kIndexGroups * 8, ctx->stream));
+    ix->hit_bytes_size = static_cast<size_t>(b.max_words) * 64;                                     // (position ids run over the words of the hit bitmap)
+    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->hit_bytes), ix->hit_bytes_size));
     hipLaunchKernelGGL(eref_probe_index_kernel<1>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
                        d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, count, ix->first, ix->entries);
     TRY_OR_DONE(hipGetLastError());
@@ -2147,9 +2244,21 @@ int palace_eref_probe_index_free(palace_ctx *ctx, palace_eref_probe_index *ix)
 {
     if (!ix) return PALACE_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    if (ctx && ctx->probe_ix == ix) ctx->probe_ix = nullptr;
+    if (ctx && ctx->c0_hits_ix == ix) ctx->c0_hits_ix = nullptr;
     if (ix->first) (void)hipFree(ix->first);
     if (ix->entries) (void)hipFree(ix->entries);
+    if (ix->hit_bytes) (void)hipFree(ix->hit_bytes);
     delete ix;
+    return PALACE_OK;
+}
+
+int palace_eref_attach_probe_index(palace_ctx *ctx, const palace_eref_probe_index *ix)
+{
+    PALACE_REQUIRE(ctx, "ctx is null");
+    if (ix) PALACE_REQUIRE(std::memcmp(&ix->masks, &ctx->masks, sizeof(CoderMasks)) == 0 && ctx->coder_set, "probe index was built with another coder");
+    ctx->probe_ix = ix;
+    if (!ix) ctx->c0_hits_ix = nullptr;
     return PALACE_OK;
 }
 
@@ -2166,13 +2275,20 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     rc = ensure_table(ctx);
     if (rc) return rc;
+    // channel 0: the count launch has left the hit bytes when this index was attached to it and nothing has touched the planes
+    // since; otherwise the probe kernel makes them now
+    const bool fused = ctx->c0_hits_ix == ix && ix->hit_bytes;
     ScanBuffers b;
-    rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b, true);
+    rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b, !fused);
     if (rc) return rc;
-    PALACE_HIP_TRY(hipMemsetAsync(b.hit_bytes, 0, static_cast<size_t>(b.max_words) * 64, ctx->stream));
-    hipLaunchKernelGGL(eref_probe_kernel, dim3(kBuckets), dim3(kProbeThreads), 0, ctx->stream, ix->first, ix->entries, ctx->plane[2], b.hit_bytes);
-    PALACE_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(eref_hits_to_bits_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(b.hit_bytes),
+    const uint8_t *hits = ix->hit_bytes;
+    if (!fused) {
+        PALACE_HIP_TRY(hipMemsetAsync(b.hit_bytes, 0, static_cast<size_t>(b.max_words) * 64, ctx->stream));
+        hipLaunchKernelGGL(eref_probe_kernel, dim3(kBuckets), dim3(kProbeThreads), 0, ctx->stream, ix->first, ix->entries, ctx->plane[2], b.hit_bytes);
+        PALACE_HIP_TRY(hipGetLastError());
+        hits = b.hit_bytes;
+    }
+    hipLaunchKernelGGL(eref_hits_to_bits_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(hits),
                        b.max_words * 4, reinterpret_cast<uint16_t *>(b.any_w));
     PALACE_HIP_TRY(hipGetLastError());
     return scan_tail(ctx, b, d_bases, d_offsets, n_refs, one_min, three_min, d_rows);
@@ -2203,6 +2319,7 @@ int palace_eref_table_attach(palace_ctx *ctx, void *const d_planes3[3])
     ctx->planes_external = true;
     ctx->table_clean = false;                              // caller-owned memory: contents unknown
     ctx->final_only = false;
+    ctx->c0_hits_ix = nullptr;
     return PALACE_OK;
 }
 
@@ -2211,6 +2328,7 @@ int palace_eref_table_invalidate(palace_ctx *ctx)
     PALACE_REQUIRE(ctx, "ctx is null");
     ctx->table_clean = false;
     ctx->final_only = false;
+    ctx->c0_hits_ix = nullptr;
     return PALACE_OK;
 }
 

@@ -150,6 +150,7 @@ class Exchange:
         mine = torch.tensor([n], dtype=torch.int64, device=rows.device)
         dist.all_gather_into_tensor(counts, mine)
         counts = [int(x) for x in counts.tolist()]
+        self.last_counts = counts
         width = max(1, max(counts))
         part = torch.zeros((width, rows.shape[1]), dtype=rows.dtype, device=rows.device)
         part[:n] = rows[:n]

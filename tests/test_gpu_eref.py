@@ -225,6 +225,75 @@ def test_scan_matches_oracle_on_random_coverage(ctx):
     t.free()
 
 
+@pytest.mark.parametrize("cap", [0, 64])                                       # 64: most keys take the overflow path (touched buckets are seeded)
+def test_probe_fused_into_the_final_count_equals_the_probe_kernel_and_the_oracle(ctx, cap):
+    """palace_eref_attach_probe_index: a final count (option final_count, binned path, one slab, whole key space) leaves the
+    channel-0 hits of the attached DB, and the indexed scan that follows starts from them.  Rows must equal the scan that
+    probes for itself and the oracle's; any other count in between (not final, or a share of the key space) must make the
+    scan probe for itself again; a second sample through the same attached index must not see the first one's hits."""
+    rng = synth.rng_for(53)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    cc = orc.header_to_cc(hdr)
+    refs = [synth.random_dna(rng, L) for L in (40000, 6000, 33, 2500, 12345, 700)]
+    def sample(which, depth):
+        reads = []
+        for i in which:
+            s = refs[i]
+            for st in rng.integers(0, len(s) - 120, size=int(depth * len(s) / 120)):
+                reads.append(synth.mutate(rng, s[st:st + 120], 0.005))
+        return synth.reads_from_list(reads)
+    rs_refs = synth.reads_from_list(refs)
+    db, do = ctx.upload(rs_refs.bases), ctx.upload(rs_refs.offsets)
+    ix = None
+    try:
+        ctx.eref_set_coder(hdr)
+        ix = ctx.eref_probe_index_build(db, do, rs_refs.n, len(rs_refs.bases))
+        ctx.eref_set_count_mode(2, cap)
+        one_min, three_min = capi.window_minimums(0.9, 0.85)
+        rows_f, rows_p = ctx.empty((rs_refs.n, 4), np.int32), ctx.empty((rs_refs.n, 4), np.int32)
+        positives = 0
+        for which, depth in (((0, 3, 4), 14), ((1, 5), 12), ((0, 1, 2, 3, 4, 5), 2)):      # three samples through one attached index
+            rr = sample(which, depth)
+            rb, ro = ctx.upload(rr.bases), ctx.upload(rr.offsets)
+            t = orc.CountTable()
+            t.count(rr.bases, rr.offsets, cc)
+            want = [orc.scan_ref(orc.index_ref(s, cc), len(s), t, 0.9, 0.85)[1:3] for s in refs]
+            t.free()
+            # fused
+            ctx.eref_attach_probe_index(ix)
+            ctx.eref_set_option("final_count", 1)
+            ctx.eref_table_reset()
+            ctx.eref_count_reads(rb, ro, rr.n)
+            ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), one_min, three_min, rows_f)
+            got_f = rows_f.to_host()
+            # the same count without the index attached: the scan probes for itself
+            ctx.eref_attach_probe_index(None)
+            ctx.eref_table_reset()
+            ctx.eref_count_reads(rb, ro, rr.n)
+            ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), one_min, three_min, rows_p)
+            got_p = rows_p.to_host()
+            assert np.array_equal(got_f, got_p), which
+            assert [(int(a), int(b)) for a, b in got_f[:, :2]] == [(int(a), int(b)) for a, b in want], which
+            # attached, but the count is not a final one (three planes): nothing rides along, same rows
+            ctx.eref_attach_probe_index(ix)
+            ctx.eref_set_option("final_count", 0)
+            ctx.eref_table_reset()
+            ctx.eref_count_reads(rb, ro, rr.n)
+            ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), one_min, three_min, rows_p)
+            assert np.array_equal(rows_p.to_host(), got_f), which
+            rb.free(); ro.free()
+            positives += sum(1 for a, b in want if b > 0)
+        assert positives >= 4                                   # (the deep samples report their refs, the shallow third one none)
+    finally:
+        ctx.eref_attach_probe_index(None)
+        ctx.eref_set_option("final_count", 0)
+        ctx.eref_set_count_mode(0, 0)
+        if ix is not None:
+            ctx.eref_probe_index_free(ix)
+        ctx.eref_table_reset()
+        db.free(); do.free()
+
+
 def test_properties_full_size(ctx):
     """Size-independent properties at bench scale (2M reads): order independence, idempotence at
     saturation (x3 == x4), and the saturating merge of partial tables equals one-shot counting."""

@@ -62,29 +62,41 @@ def test_bench_exchange_path_rehearsal():
     for x in (b, c):
         assert a["config"]["refs_reported"] == x["config"]["refs_reported"] > 0
         assert a["config"]["graph"] == x["config"]["graph"]
-        assert a["config"]["result_digest"] == x["config"]["result_digest"] and a["config"]["result_digest"]["graph_and_components"]
+        for k in ("eref_rows", "graph_and_components"):
+            assert a["config"]["result_digest"][k] == x["config"]["result_digest"][k] is not None
     assert a["config"]["graph"]["n_edges"] > 0
 
 
-@pytest.mark.parametrize("world,port,shard", [(2, 29521, "0"), (4, 29522, "1"), (4, 29523, "0")])
-def test_bench_multi_rank_rehearsal_on_one_gpu(world, port, shard):
-    """The N-rank step (world 2: every rank counts all reads, Phase B / generateGraph / gathers sharded; world 4: reads
-    sharded too, count-table exchange + merge) with all ranks on GPU 0 and the collectives over gloo (RCCL refuses two
-    ranks on one device): the same refs and the same graph as the single-process run."""
-    size = ["--contigs", "20000", "--refs", "200", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--soak-seconds", "0"]
+@pytest.mark.parametrize("world,port,scheme", [(2, 29521, "replicate"), (4, 29522, "shard_reads"), (4, 29523, "key_split"), (2, 29524, "auto")])
+def test_bench_multi_rank_rehearsal_on_one_gpu(world, port, scheme):
+    """The N-rank step with all ranks on GPU 0 and the collectives over gloo (RCCL refuses two ranks on one device), under each
+    Phase-A scheme (replicate: every rank counts all reads; shard_reads: reads sharded, count-table exchange + merge; key_split:
+    the key space split, all-gather of the plane slices; auto: whatever the cost model picks for this size): the same refs and
+    the same graph as the single-process run, from the exact candidate gather (first step) and from the padded one (later
+    steps); and the weak record (every rank the whole one-GPU step) carries the same digest."""
+    size = ["--contigs", "20000", "--refs", "200", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--soak-seconds", "0"]
     a = json.loads(sh([sys.executable, os.path.join(ROOT, "bench.py")] + size).decode().strip().splitlines()[-1])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + size
-    # (two flavours of four ranks: the reads sharded with the count-table exchange -- forced here, the bench itself never picks it --
-    # and of four: the key space split with an all-gather of the plane slices -- what the bench does from four ranks on)
-    out = sh(cmd, env=dict(os.environ, PALACE_BENCH_ONE_DEVICE="1", PALACE_BENCH_BACKEND="gloo", PALACE_BENCH_SHARD_READS=shard)).decode()
+    out = sh(cmd, env=dict(os.environ, PALACE_BENCH_ONE_DEVICE="1", PALACE_BENCH_BACKEND="gloo", PALACE_BENCH_SCHEME=scheme)).decode()
     b = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
-    assert b["n_gpus"] == world
-    assert ("reads/records/refs sharded" in b["config"]["parallelism"]) == (shard == "1")
-    assert ("key space sharded" in b["config"]["parallelism"]) == (world == 4 and shard == "0")
+    assert b["n_gpus"] == world and b["scaling"] == "strong" and "failed_checks" not in b
+    pm = b["config"]["parallelism_model"]
+    assert set(pm["ms"]) == {"replicate", "key_split", "shard_reads"} and pm["world"] == world
+    if scheme == "auto":
+        assert pm["forced"] is False and pm["choice_in_force"] == pm["choice"] == min(pm["ms"], key=pm["ms"].get)
+        scheme = pm["choice"]
+    assert pm["choice_in_force"] == scheme
+    assert ("reads/records/refs sharded" in b["config"]["parallelism"]) == (scheme == "shard_reads")
+    assert ("key space sharded" in b["config"]["parallelism"]) == (scheme == "key_split")
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
     assert a["config"]["graph"] == b["config"]["graph"]
-    assert a["config"]["result_digest"] == b["config"]["result_digest"] and a["config"]["result_digest"]["graph_and_components"]
+    assert a["config"]["result_digest"]["eref_rows"] == b["config"]["result_digest"]["eref_rows"]
+    assert a["config"]["result_digest"]["graph_and_components"] == b["config"]["result_digest"]["graph_and_components"] is not None
+    w = b["weak"]
+    assert w["scaling"] == "weak" and w["n_gpus"] == world and w["value"] == pytest.approx(world * 20000 / (w["ms_per_step"] * 1e-3))
+    assert w["result_digest"]["eref_rows"] == a["config"]["result_digest"]["eref_rows"]
+    assert w["result_digest"]["graph_and_components"] == a["config"]["result_digest"]["graph_and_components"]
 
 
 def test_bench_starts_its_own_ranks():
@@ -99,7 +111,8 @@ def test_bench_starts_its_own_ranks():
     assert b["n_gpus"] == 2
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
     assert a["config"]["graph"] == b["config"]["graph"]
-    assert a["config"]["result_digest"] == b["config"]["result_digest"] and a["config"]["result_digest"]["graph_and_components"]
+    for k in ("eref_rows", "graph_and_components"):
+        assert a["config"]["result_digest"][k] == b["config"]["result_digest"][k] is not None
 
 
 def test_c_abi_table_exchange_on_a_one_rank_communicator():
@@ -116,4 +129,5 @@ def test_bench_two_batches_in_flight_gives_the_same_results():
     b = json.loads(sh([sys.executable, os.path.join(ROOT, "bench.py"), "--batches-in-flight", "2"] + size).decode().strip().splitlines()[-1])
     assert b["config"]["batches_in_flight"] == 2 and a["config"]["batches_in_flight"] == 1
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
-    assert a["config"]["result_digest"] == b["config"]["result_digest"]
+    for k in ("eref_rows", "graph_and_components"):
+        assert a["config"]["result_digest"][k] == b["config"]["result_digest"][k] is not None

@@ -70,6 +70,16 @@ def worker(rank, world, port, q):
         buf[:n_mine] = allc[rank]
         got, total = ex.gather_varlen(buf, n_mine)
         ok_var = total == sum(len(x) for x in allc) and bool(torch.equal(got, torch.cat(allc)))
+        # the same gather with nothing read back: rows padded to a width, zero rows beyond a rank's count, counts on the "device"
+        width = 12
+        buf[n_mine:] = 0xAB                                # stale rows behind the valid ones must not travel
+        padded, cnts = ex.gather_padded(buf, torch.tensor([n_mine], dtype=torch.int64), width)
+        want_pad = torch.zeros((world * width, 64), dtype=torch.uint8)
+        for r, x in enumerate(allc):
+            want_pad[r * width:r * width + len(x)] = x
+        ok_var &= bool(torch.equal(padded, want_pad)) and cnts.tolist() == [len(x) for x in allc] and ex.last_counts == cnts.tolist()
+        narrow, cnts = ex.gather_padded(buf, torch.tensor([n_mine], dtype=torch.int64), 4)      # too narrow: the counts say so
+        ok_var &= (max(cnts.tolist()) > 4) == (max(len(x) for x in allc) > 4) and narrow.shape[0] == 4 * world
         t = torch.full((9,), rank + 1, dtype=torch.int64)
         ex.reduce_sum(t)
         ok_sum = bool((t == sum(range(1, world + 1))).all())
@@ -106,6 +116,22 @@ def test_exchange_world(world):
         assert p.exitcode == 0
     for r in res:
         assert all(r[1:]), r
+
+
+def test_phase_a_scheme_model_picks_by_size():
+    """the cost model behind bench.py's scheme choice: 1M contigs on 4 or 8 GPUs -> key split, 5M contigs
+    on 8 -> read-sharded exchange, two GPUs -> every rank counts everything (a half plane would cross ONE link)"""
+    m = multigpu.phase_a_model
+    assert m(6_666_666, 8)["choice"] == "key_split" and m(6_666_666, 4)["choice"] == "key_split"
+    assert m(33_333_333, 8)["choice"] == "shard_reads" and m(33_333_333, 4)["choice"] == "shard_reads"
+    assert m(6_666_666, 2)["choice"] == "replicate" and m(6_666_666, 1)["choice"] == "replicate" and set(m(6_666_666, 1)["ms"]) == {"replicate"}
+    assert "key_split" not in m(6_666_666, 3)["ms"]                                   # shares are mirrored bucket pairs: W must divide 64
+    slow = m(6_666_666, 8, link_gbs=5.0)                                               # a slow interconnect: nothing beats counting everything
+    assert slow["choice"] == "replicate" and slow["link_gbs"] == 5.0
+    assert m(33_333_333, 8, link_gbs=5.0)["choice"] == "key_split"                     # ... until the sample is large: the one gather pays
+    for w in (2, 4, 8):
+        r = m(6_666_666, w)
+        assert r["ms"][r["choice"]] == min(r["ms"].values()) and r["world"] == w
 
 
 def test_split_by_weight_properties():
