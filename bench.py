@@ -780,15 +780,18 @@ def measure(args, E, leg):
     from palace_amd import capi, coder, multigpu       # (oracle/ is imported by the cpu_baseline leg only)
 
     hdr = coder.header_from_picks(np.random.Generator(np.random.PCG64(SEED)).integers(0, 6, size=32))
-    # Streams.  A: eref (count + scan).  B: generateGraph (classify, resolve, copy numbers), high priority.  S: stage 04 (selection +
-    # matching: ~150 small latency-bound launches), confined to ONE XCD's compute units (hipExtStreamCreateWithCUMask, the first
-    # 32 CUs): beside the saturating counting kernels those launches otherwise land on all 256 CUs and cost the count launch ~1 ms
-    # (measured, tools/cu_mask_ab.sh: count 9.12 -> 7.9 ms with stream B + S confined to 32 CUs -- but classify, one wide kernel,
-    # then takes 4.5 ms instead of 0.9, hence the split of B and S).  PALACE_BENCH_STAGE04_CUS=0: stage 04 on stream B as before.
+    # Streams.  A: eref (count + scan).  B: generateGraph (classify, resolve, copy numbers) and stage 04 (selection + matching: ~150
+    # small latency-bound launches), high priority.  Stage 04 beside the saturating counting kernels takes 5.4 ms instead of the
+    # 1.4 ms it takes alone and costs the count launch ~1 ms.  Measured in round 4 (tools/cu_mask_ab.sh, tools/r04c-e.sh; DESIGN.md
+    # section 4): confining stage 04 to a CU subset (hipExtStreamCreateWithCUMask; PALACE_BENCH_STAGE04_CUS=n puts it on a stream S
+    # of its own on the first n CUs, and keeps stream A off them) does not help -- on 32 CUs of its own it still takes 7.2 ms
+    # (it is slowed by the memory system the counting kernels saturate, not by the CUs they occupy), the step is 10.9 ms either
+    # way; holding it back behind the partition kernels or the whole count launch (PALACE_BENCH_STAGE04_LATE=l2|1) puts it on the
+    # critical path (11.3 / 11.7 ms).  Default: stage 04 on stream B.
     # With collectives (N GPUs) A and B are torch streams the contexts run on (palace_ctx_create_on_stream), so that
     # torch.distributed's collectives are stream-ordered with the library's kernels and nothing waits on the host.
     mask_of = lambda k: int(os.environ[k], 16) if os.environ.get(k) else None      # tuning runs: PALACE_BENCH_CU_MASK_A / _B (hex)
-    s04_cus = int(os.environ.get("PALACE_BENCH_STAGE04_CUS", "32"))
+    s04_cus = int(os.environ.get("PALACE_BENCH_STAGE04_CUS", "0"))
     if collectives:
         sA, sB = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1)
         ctx, ctx_g = capi.Ctx(local, stream=sA.cuda_stream), capi.Ctx(local, stream=sB.cuda_stream)
@@ -863,6 +866,11 @@ def measure(args, E, leg):
     cols = capi.BamCols(gs["n"], *(P(gs["col"][k]) for k in ("tid", "pos", "mtid", "mpos", "nm", "ref_len", "read_len",
                                                            "clip_s", "clip_e", "flag", "mapq", "qkey")), P(gs["sa_off"]))
     prm = capi.GraphParams.default()
+    # per-contig offsets into the sorted FASTG keys (once per sample, like the keys): the classify kernel's look-ups start there
+    fastg_first = torch.zeros(nt + 1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    capi._check(L.palace_graph_fastg_offsets(ctx_g.h, P(gs["fastg"]), gs["n_fastg"], nt, P(fastg_first)), "fastg offsets")
+    ctx_g.sync()
     # stage 04 resident: the per-sample inputs of filter_graph.py and matching -l, parsed once like the BAM columns
     gs["side"] = make_side_inputs(gs)
     stage04 = None
@@ -929,6 +937,8 @@ def measure(args, E, leg):
         ctx.eref_set_key_buckets(multigpu.key_buckets_of(rank, world))       # mirrored pairs of buckets: equal key mass per rank
     for e in ectx:
         e.eref_set_option("final_count", 1 if final_count else 0)
+        if os.environ.get("PALACE_BENCH_STAGE04_LATE") == "l2":
+            e.eref_set_option("mark_before_count_kernel", 4091)
     rows_l = [rows] + [torch.zeros_like(rows) for _ in range(depth - 1)]
     rows_host_l = [rows_host] + [torch.zeros((n_refs, 4), dtype=torch.int32).pin_memory() for _ in range(depth - 1)]
     seq = {"n": 0, "pending": None, "counted": None, "last": 0, "of_timed": {}}           # running batch number; the batch whose rows are still on their way
@@ -988,8 +998,8 @@ def measure(args, E, leg):
         if timed: g.mark(m)
         capi._check(L.palace_memset(g.h, P(consumed), 0, nt * 8), "memset")
         n_c, n_b = ctypes.c_int64(), ctypes.c_int64()
-        capi._check(L.palace_graph_classify_ex(g.h, ctypes.byref(cols), P(gs["sa"]), nt, P(gs["tlen"]), P(gs["trank"]),
-                                               P(gs["fastg"]), gs["n_fastg"], ctypes.byref(prm), gs["ord_base"], P(consumed),
+        capi._check(L.palace_graph_classify_ix(g.h, ctypes.byref(cols), P(gs["sa"]), nt, P(gs["tlen"]), P(gs["trank"]),
+                                               P(gs["fastg"]), gs["n_fastg"], P(fastg_first), ctypes.byref(prm), gs["ord_base"], P(consumed),
                                                P(cands), cand_cap, ctypes.byref(n_c), ctypes.byref(n_b)), "classify")
         if timed: g.mark(m + 1)
         all_c, n_cands, n_border, e_buf, cons_for_quirk = cands, n_c.value, n_b.value, edges, consumed
@@ -1035,9 +1045,11 @@ def measure(args, E, leg):
             # few microseconds (kernel boundaries write back the L2 lines the partition kernels combine their stores in): about
             # 1 ms per step, measured.  Holding the rounds back until the counting kernels are done (PALACE_BENCH_STAGE04_LATE=1:
             # palace_stage04_match_after) leaves those undisturbed but puts the rounds on the critical path -- 14.8 against 12.8 ms.
-            late = not exch and not skip_eref and os.environ.get("PALACE_BENCH_STAGE04_LATE") == "1"
+            late = os.environ.get("PALACE_BENCH_STAGE04_LATE", "0") if not exch and not skip_eref else "0"
             stage04.filter(P(e_buf), P(n_edges_dev), max(1, n_cands))
-            stage04.match(P(e_buf), P(cn_dev), 10, False, True, after=(ctx, 4095) if late else None)
+            # ("1": the rounds wait for the whole count launch; "l2": for its partition kernels -- they then run beside the count
+            # kernel and Phase B only)
+            stage04.match(P(e_buf), P(cn_dev), 10, False, True, after=(ctx, 4095) if late == "1" else (ctx, 4091) if late == "l2" else None)
         if timed: ctx_s.mark(m + 3)
         th1 = time.perf_counter()
         if timed:
@@ -1160,7 +1172,10 @@ def measure(args, E, leg):
         version = L.palace_version().decode()
         traffic, traffic_src, stage_traffic = profiled_traffic(args, world, version)
         alg_bytes = (READ_LEN + 6 * (READ_LEN - 31)) * 2 * n_side        # per launch (both FASTQ sides of this rank)
-        achieved = alg_bytes / (count_ms * 1e-3) / 1e9
+        # when Phase B's channel-0 probe rides along in the count kernel, its look-ups (1 B per ref position) are work of this launch
+        fused_now = fused_probe and final_count and not key_split
+        probe_bytes = sum(int(l) - 31 for l in sample["ref_lens"][r_lo:r_hi]) if fused_now else 0
+        achieved = (alg_bytes + probe_bytes) / (count_ms * 1e-3) / 1e9
         out = {
             "metric": "contigs/sec eref+generate_graph+matching, 1M-contig synth, 1/2/4/8 GPU",       # BASELINE.json, verbatim
             "value": args.contigs / (ms_step * 1e-3), "unit": "contigs/s", "n_gpus": world,
@@ -1189,18 +1204,21 @@ def measure(args, E, leg):
                                                           "n_comp", "n_cycles", "n_multi")},
                        "stage04": "filter_graph.py's selection (seeds, 1- and 2-hop junctions, contigs.paths rescue) and matching -i 10 -l contigs.paths "
                                   "on the filtered graph, both on the device (palace_stage04_*), as palace:566-591 runs them on files"},
-            "roofline": {"bound": "hbm", "kernel": "eref count_reads_packed (bin1 + bin2 + lds_count kernels of one launch)" if packed else
+            "roofline": {"bound": "hbm", "kernel": ("eref count_reads_packed (bin1 + bin2 + lds_count kernels of one launch" + (", Phase B's channel-0 probe fused into lds_count)" if fused_now else ")")) if packed else
                                    "eref count_reads (streams + bin1 + bin2 + lds_count kernels of one launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # PMC (separate rocprofv3 passes, profiles/r01q_end_state_fused_launch.md): FETCH_SIZE x2 + WRITE_SIZE of
                          # bin1 + bin2 + lds_count per launch; only valid for the default workload on one GPU
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                         "avg_launch_ms": count_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "avg_launch_ms": count_ms, "algorithmic_bytes_per_launch": alg_bytes + probe_bytes,
+                         "algorithmic_bytes_note": f"864 B per 150-bp read x {2 * n_side} reads" + (f" + {probe_bytes} B: the channel-0 look-ups of Phase B (1 B per ref "
+                                                   "position), which this launch's count kernel does while a bucket's slice is in LDS" if probe_bytes else "")},
             # the other stages of the step against the same roofline (SURVEY.md section 8(d) algorithmic bytes; live event times of
             # this run; PMC traffic of the committed profile when it is of this build and workload)
             "roofline_stages": roofline_stages(dict(
-                phase_b=(sum(int(l) + 3 * (int(l) - 31) for l in sample["ref_lens"][r_lo:r_hi]), scan_ms,
-                         "l + 3(l - 31) B per ref: a byte per base, three 1-byte look-ups per position"),
+                phase_b=(sum(int(l) + (2 if fused_now else 3) * (int(l) - 31) for l in sample["ref_lens"][r_lo:r_hi]), scan_ms,
+                         "l + 3(l - 31) B per ref: a byte per base, three 1-byte look-ups per position" +
+                         (" -- minus the channel-0 look-ups, which the count launch did" if fused_now else "")),
                 classify=(52 * gs["n"] + 64 * gs["n_sa"], classify_ms, "52 B per primary record + 64 B per SA item"),
                 resolve=(64 * int(last.get("n_cands", 0)) + 16 * int(last.get("n_cands", 0)), resolve_ms,
                          "64 B per candidate read + 16 B per evidence written"),

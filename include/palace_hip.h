@@ -142,7 +142,9 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
  *                 call keeps the two lower planes in LDS only: they are not written (1 GB less per call) and stay zero, and
  *                 the next reset clears one plane instead of three.  Afterwards the table cannot take further counts,
  *                 merges or lookups until it is reset (those calls fail); popcounts report 0, 0, n.  Applies to binned
- *                 counts of one slab into a clean table, otherwise the call behaves as without the option.  0: off (default). */
+ *                 counts of one slab into a clean table, otherwise the call behaves as without the option.  0: off (default).
+ *   "mark_before_count_kernel" i >= 0: a binned count call records palace_mark(ctx, i) between its partition kernels and its
+ *                 count kernel (another stream can hold work back until then: palace_wait_for_mark); -1: none (default). */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap);
 /* The count calls that follow take in only the keys whose top 7 bits -- one of 128 buckets of the key space -- are in the set
  * (bit b of mask128 = bucket b; default all).  For N GPUs that each hold all reads (the reference's threads share one table,
@@ -294,6 +296,17 @@ int palace_graph_classify(palace_ctx *ctx, const palace_bam_cols *cols, const pa
 int palace_graph_classify_ex(palace_ctx *ctx, const palace_bam_cols *cols, const palace_sa_item *d_sa,
                              int32_t n_targets, const int32_t *d_tlen, const int32_t *d_trank,
                              const uint64_t *d_fastg, int64_t n_fastg, const palace_graph_params *prm,
+                             int64_t ord_base, uint64_t *d_consumed, palace_graph_cand *d_cands,
+                             int64_t cand_cap, int64_t *n_cands_out, int64_t *n_border_out);
+
+/* The same with the FASTG search narrowed: d_fastg_first[t] (n_targets + 1 entries, made once per sample by
+ * palace_graph_fastg_offsets from the same sorted key array) = index of the first key whose left contig is >= t, so that a
+ * candidate's look-up starts inside its left contig's two or three links instead of bisecting the whole set (:863-864 is a
+ * std::set find per evidence; here ~22 dependent loads per candidate were most of the kernel's time).  NULL = bisect. */
+int palace_graph_fastg_offsets(palace_ctx *ctx, const uint64_t *d_fastg, int64_t n_fastg, int32_t n_targets, uint32_t *d_first);
+int palace_graph_classify_ix(palace_ctx *ctx, const palace_bam_cols *cols, const palace_sa_item *d_sa,
+                             int32_t n_targets, const int32_t *d_tlen, const int32_t *d_trank,
+                             const uint64_t *d_fastg, int64_t n_fastg, const uint32_t *d_fastg_first, const palace_graph_params *prm,
                              int64_t ord_base, uint64_t *d_consumed, palace_graph_cand *d_cands,
                              int64_t cand_cap, int64_t *n_cands_out, int64_t *n_border_out);
 

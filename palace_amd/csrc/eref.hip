@@ -807,6 +807,7 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
                                                                        ProbeArgs pr)
 {
     __shared__ uint32_t l1[kFineWords], l2[kFineWords], l3[kFineWords];
+    __shared__ uint32_t hit_n;
     const uint32_t b = blockIdx.x, b1 = b / kL2Rows;
     if (!share.bucket(b1)) return;                          // a call that counts a share of the key space: not its bucket
     constexpr int kProbeBatch = 6;                          // pair loads per thread and batch: a bucket's group (~3000 entries, ~12 per thread) is ONE batch
@@ -866,6 +867,9 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
         ok[u] = 0; v[u] = uint4{0, 0, 0, 0};
         if (i < n8) v[u] = *locate(i, ok[u]);
     }
+    // PROBE: the bucket's group of the DB's probe index is requested now and is in flight during the whole count phase
+    ulonglong2 pcur[kProbeBatch];
+    if (PROBE && phi > pe0) probe_first_batch<kCountThreads, kProbeBatch>(pr.entries, pe0, phi, pcur);
     const bool seed = !CLEAN || ((touched[b >> 5] >> (b & 31)) & 1u);      // uniform for the workgroup
     // (two loops, not `seed ? g[i] : zero` in one: for that the compiler selects between the global ADDRESS and the address of
     // a zero it keeps in scratch memory, and the clean case pays three flat loads per lane and round all the same)
@@ -906,13 +910,45 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
 #pragma unroll
         for (int u = 0; u < kBatch; u++) { v[u] = nx[u]; ok[u] = nok[u]; }
     }
-    // PROBE: the bucket's entries are requested before the barrier and tested right behind it, BEFORE the write-back: a wave's
-    // vmcnt counts loads and stores together, so with the slice's stores already in flight the tests would wait for those to be
-    // acknowledged as well
-    ulonglong2 pcur[kProbeBatch];
-    if (PROBE && phi > pe0) probe_first_batch<kCountThreads, kProbeBatch>(pr.entries, pe0, phi, pcur);
     __syncthreads();
-    if (PROBE && phi > pe0) probe_group<kCountThreads, kProbeBatch, false>(l3, 0xffffu, pr.entries, pe0, phi, pcur, pr.hit_bytes);
+    // PROBE: the entries are tested against the final slice; a hit goes to a list in LDS (plane 1's slice: dead in a final count),
+    // and the bytes are stored at the very end.  No global store is issued before the last entry load has come back: a wave's
+    // vmcnt counts loads and stores together and the compiler has to wait for ALL of them once both kinds are in flight, so a
+    // second batch of entries behind the first batch's hit stores would wait for those random byte stores to be acknowledged
+    uint32_t n_hits = 0;
+    if (PROBE && phi > pe0) {
+        static_assert(!PROBE || FINAL, "the hit list lives in the slice of plane 1");
+        if (threadIdx.x == 0) hit_n = 0;
+        __syncthreads();
+        const unsigned long long lo = pe0 & ~1ull, n2 = (phi - lo + 1) / 2;
+        const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(pr.entries + lo);
+        constexpr unsigned long long kStride = static_cast<unsigned long long>(kProbeBatch) * kCountThreads;
+        auto test = [&](unsigned long long ent, unsigned long long at) {
+            if (at < pe0 || at >= phi) return;
+            const uint32_t k = static_cast<uint32_t>(ent) & 0xffffu;
+            if ((l3[k >> 5] >> (k & 31)) & 1u) {
+                const uint32_t slot = atomicAdd(&hit_n, 1u);
+                if (slot < kFineWords) l1[slot] = static_cast<uint32_t>(ent >> kBucketShift);     // (position ids fit 32 bits: checked by the host)
+                else pr.hit_bytes[ent >> kBucketShift] = 1;                                     // list full (a bucket with > 2048 hits): directly
+            }
+        };
+        for (unsigned long long i0 = threadIdx.x; i0 < n2; i0 += kStride) {
+#pragma unroll
+            for (int u = 0; u < kProbeBatch; u++) {
+                const unsigned long long i = i0 + static_cast<unsigned long long>(u) * kCountThreads;
+                if (i < n2) { test(pcur[u].x, lo + 2 * i); test(pcur[u].y, lo + 2 * i + 1); }
+            }
+            if (i0 - threadIdx.x + kStride < n2) {             // (uniform) a group larger than one batch
+#pragma unroll
+                for (int u = 0; u < kProbeBatch; u++) {
+                    const unsigned long long i = i0 + kStride + static_cast<unsigned long long>(u) * kCountThreads;
+                    pcur[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
+                }
+            }
+        }
+        __syncthreads();
+        n_hits = min(hit_n, static_cast<uint32_t>(kFineWords));
+    }
     uint4 *o1 = reinterpret_cast<uint4 *>(p1 + w0), *o2 = reinterpret_cast<uint4 *>(p2 + w0),
           *o3 = reinterpret_cast<uint4 *>(p3 + w0);
     for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) {
@@ -924,6 +960,8 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
         }
         o3[i] = reinterpret_cast<const uint4 *>(l3)[i];
     }
+    if (PROBE)
+        for (uint32_t i = threadIdx.x; i < n_hits; i += kCountThreads) pr.hit_bytes[l1[i]] = 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1780,7 +1818,8 @@ static_assert(kIndexGroups == kFine, "the probe index is grouped by the count ke
 
 static bool probe_index_usable(const palace_ctx *ctx, const palace_eref_probe_index *ix)
 {
-    return ix->hit_bytes && std::memcmp(&ix->masks, &ctx->masks, sizeof(CoderMasks)) == 0;
+    // (the fused kernel keeps hit positions as 32-bit ids in LDS)
+    return ix->hit_bytes && ix->hit_bytes_size < (1ull << 32) && std::memcmp(&ix->masks, &ctx->masks, sizeof(CoderMasks)) == 0;
 }
 
 // the final count kernel of a launch with Phase B's channel-0 probe riding along (eref_lds_count_kernel<true, true, true>)
@@ -1878,6 +1917,12 @@ static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &
             hipLaunchKernelGGL(eref_bin2_kernel, dim3(g2.first[kL1Buckets]), dim3(kBin2Threads), 0, ctx->stream, b.cursor1[k], b.buf1[k], pl.caps1, g2, o2);
             PALACE_HIP_TRY(hipGetLastError());
             if (overlap) PALACE_HIP_TRY(hipEventRecord(ev_l2[k], ctx->stream));
+        }
+        // option mark_before_count_kernel: the partition kernels of the launch are done (what may run beside the count kernel
+        // and Phase B without slowing the partition kernels can be made to wait for this mark: palace_wait_for_mark)
+        if (ctx->mark_before_count >= 0 && slab + 1 == n_slabs) {
+            int rc = palace_mark(ctx, ctx->mark_before_count);
+            if (rc) return rc;
         }
         const ProbeArgs no_probe{nullptr, nullptr, nullptr};
         if (clean && n_slabs == 1 && ctx->want_final) {
@@ -2045,6 +2090,9 @@ int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value)
     } else if (!std::strcmp(name, "final_count")) {          // the count calls that follow are each the only one between a reset and Phase B
         PALACE_REQUIRE(value == 0 || value == 1, "final_count must be 0 or 1");
         ctx->want_final = value != 0;
+    } else if (!std::strcmp(name, "mark_before_count_kernel")) {   // -1: none; i: palace_mark(ctx, i) between the partition kernels and the count kernel
+        PALACE_REQUIRE(value >= -1 && value < 4096, "mark index out of range");
+        ctx->mark_before_count = static_cast<int>(value);
     } else if (!std::strcmp(name, "level1_parts")) {         // 0: by size; n: level 1 takes a slab in n parts beside level 2 (1: one stream)
         PALACE_REQUIRE(value >= 0 && value <= 64, "level1_parts must be 0 .. 64");
         ctx->level1_parts = static_cast<int>(value);

@@ -33,6 +33,7 @@ struct GraphArgs {
     const int32_t *tlen, *trank;
     const uint64_t *fastg;
     int64_t n_fastg;
+    const uint32_t *fastg_first;       // optional: fastg_first[t] = index of the first key whose left contig is >= t (n_targets + 1 entries)
     palace_graph_params p;
     double lambda, safe_dist;
     int64_t ord_base;
@@ -60,9 +61,12 @@ struct Side {
     int rev, reg, pos, len, tid, mapq, nm;
 };
 
-__device__ __forceinline__ bool fastg_has(const uint64_t *__restrict__ keys, int64_t n, uint64_t k)
+// membership in the sorted key array; with the per-contig offsets the search starts inside the left contig's few links (two or
+// three dependent loads instead of ~22 over the whole array: this search was most of the classify kernel's latency chain)
+__device__ __forceinline__ bool fastg_has(const uint64_t *__restrict__ keys, int64_t n, const uint32_t *__restrict__ first, uint64_t k)
 {
     int64_t lo = 0, hi = n;
+    if (first) { const uint32_t t = static_cast<uint32_t>(k >> 33); lo = first[t]; hi = first[t + 1]; }
     while (lo < hi) {
         int64_t mid = (lo + hi) >> 1;
         uint64_t v = keys[mid];
@@ -92,16 +96,43 @@ __device__ __forceinline__ void fill_evidence(const GraphArgs &a, const Side &l,
     }
     c.left = lt; c.right = rt; c.oL = static_cast<uint8_t>(kL); c.oR = static_cast<uint8_t>(kR);
     uint64_t fk = (static_cast<uint64_t>(lt) << 33) | (static_cast<uint64_t>(rt) << 2) | (oL << 1) | oR;   // :863
-    c.in_fastg = fastg_has(a.fastg, a.n_fastg, fk);
+    c.in_fastg = fastg_has(a.fastg, a.n_fastg, a.fastg_first, fk);
 }
 
-__device__ __forceinline__ void emit(const GraphArgs &a, const palace_graph_cand &c)
+// first[t] = index of the first key whose left contig (key >> 33) is >= t, t = 0 .. n_targets (a lower bound per thread)
+__global__ void fastg_offsets_kernel(const uint64_t *__restrict__ keys, int64_t n, int32_t n_targets, uint32_t *__restrict__ first)
 {
-    unsigned long long i = atomicAdd(a.n_cands, 1ull);
-    if (static_cast<int64_t>(i) < a.cap) a.cands[i] = c;
-    if (c.found && c.cls == 2) atomicAdd(a.n_cands + 1, 1ull);      // exp() underflow zone: the host decides these (rare)
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t > n_targets) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (static_cast<int64_t>(keys[mid] >> 33) < t) lo = mid + 1; else hi = mid;
+    }
+    first[t] = static_cast<uint32_t>(lo);
 }
 
+// Append the candidates of the lanes that have one (`has`; the call is made by all 64 lanes of the wave): ONE returning add on the
+// candidate counter per wave, not one per candidate -- ~420 000 adds on a single address were most of this kernel's time.
+__device__ __forceinline__ void emit_wave(const GraphArgs &a, bool has, const palace_graph_cand &c)
+{
+    const unsigned long long m = __ballot(has);
+    if (!m) return;                                                  // uniform
+    const int lane = threadIdx.x & 63, first = __builtin_ctzll(m);
+    const unsigned long long border = __ballot(has && c.found && c.cls == 2);      // exp() underflow zone: the host decides these (rare)
+    unsigned long long base = 0;
+    if (lane == first) {
+        base = atomicAdd(a.n_cands, static_cast<unsigned long long>(__popcll(m)));
+        if (border) atomicAdd(a.n_cands + 1, static_cast<unsigned long long>(__popcll(border)));
+    }
+    base = __shfl(base, first);
+    if (has) {
+        const unsigned long long i = base + __popcll(m & ((1ull << lane) - 1));
+        if (static_cast<int64_t>(i) < a.cap) a.cands[i] = c;
+    }
+}
+
+// One thread per record.  No lane leaves early: the wave stays whole so that candidates are appended per wave (emit_wave).
 __global__ __launch_bounds__(256) void graph_classify_kernel(GraphArgs a)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -135,55 +166,69 @@ __global__ __launch_bounds__(256) void graph_classify_kernel(GraphArgs a)
             atomicAdd(&a.consumed[key], static_cast<unsigned long long>(add));
         }
     }
-    if (!live) return;
-    const int mapq = a.c.mapq[i], nm = a.c.nm[i];
-    if (!(mapq >= a.p.min_mapq && nm <= a.p.max_nm)) return;           // :679
-    if (tid < 0 || tid >= a.n_targets) return;
+    int mapq = 0, nm = 0;
+    if (live) { mapq = a.c.mapq[i]; nm = a.c.nm[i]; }
+    // a record that can bear evidence: passes the flag filter, :679 and names a target
+    const bool pass = live && mapq >= a.p.min_mapq && nm <= a.p.max_nm && tid >= 0 && tid < a.n_targets;
     const int64_t ord = a.ord_base + i;
-    const int read_len = a.c.read_len[i];
-    Side s1{(flag & 0x10) != 0, 0, a.c.pos[i] + 1, a.tlen[tid], tid, mapq, nm};
-    s1.reg = region_of(s1.pos, s1.len, a.p.max_end);
+    int sa0 = 0, sa1 = 0, mtid = -1;
+    if (pass) { sa0 = a.c.sa_off[i]; sa1 = a.c.sa_off[i + 1]; mtid = a.c.mtid[i]; }
+    const bool pair = pass && a.p.enable_paired && (flag & 0x1) && !(flag & 0x8) && mtid >= 0 && mtid < a.n_targets && mtid != tid;
+    if (!__any(pair || sa1 > sa0)) return;                              // uniform: most waves of a sample end here
+    int read_len = 0;
+    Side s1{(flag & 0x10) != 0, kMiddle, 0, 0, tid, mapq, nm};
+    if (pair || sa1 > sa0) {
+        read_len = a.c.read_len[i];
+        s1.pos = a.c.pos[i] + 1; s1.len = a.tlen[tid];
+        s1.reg = region_of(s1.pos, s1.len, a.p.max_end);
+    }
 
-    // ---- split reads (:684-879) -----------------------------------------------------------------
-    const int sa0 = a.c.sa_off[i], sa1 = a.c.sa_off[i + 1];
+    // ---- split reads (:684-879): item r of every lane's SA list in step (lists are short; most lanes have none) ----------
+    int st1 = 0, en1 = 0;
     if (sa1 > sa0) {
-        const int clip_s = a.c.clip_s[i], clip_e = a.c.clip_e[i];
-        int st1, en1;                                                    // :369-380 (len == read_len)
+        const int clip_s = a.c.clip_s[i], clip_e = a.c.clip_e[i];     // :369-380 (len == read_len)
         if (clip_s < 0) { st1 = 0; en1 = 0; }                            // empty CIGAR text (:332)
         else if (s1.rev && read_len > 0) { st1 = read_len - (read_len - clip_e) + 1; en1 = read_len - clip_s; }
         else { st1 = clip_s + 1; en1 = read_len - clip_e; }
-        for (int k = sa0; k < sa1; k++) {
-            const palace_sa_item it = a.sa[k];
-            if (!(it.mapq2 >= a.p.min_mapq && it.nm2 <= a.p.max_nm)) continue;   // :724
-            if (it.tid2 < 0 || it.tid2 >= a.n_targets) continue;                 // :731-734
-            Side s2{it.rev2 != 0, 0, it.pos2, a.tlen[it.tid2], it.tid2, it.mapq2, it.nm2};
-            s2.reg = region_of(s2.pos, s2.len, a.p.max_end);
-            if (s1.reg == kMiddle || s2.reg == kMiddle) continue;                // :742
-            int st2, en2;
-            if (it.clip_s2 < 0) { st2 = 0; en2 = 0; }
-            else if (s2.rev && read_len > 0) { st2 = read_len - (it.len2 - it.clip_e2) + 1; en2 = read_len - it.clip_s2; }
-            else { st2 = it.clip_s2 + 1; en2 = it.len2 - it.clip_e2; }
-            bool first1, ok = false;                                             // :401-428, gap/overlap 150
-            if (en1 <= st2 && st2 - en1 - 1 <= 150) { first1 = true; ok = true; }
-            else if (en2 <= st1 && st1 - en2 - 1 <= 150) { first1 = false; ok = true; }
-            else if (st1 <= en2 && st2 <= en1) {
-                int ov = min(en1, en2) - max(st1, st2) + 1;
-                if (ov <= 150) { first1 = st1 <= st2; ok = true; }
+    }
+    for (int r = 0; __any(sa0 + r < sa1); r++) {
+        palace_graph_cand c{};
+        bool has = false;
+        if (sa0 + r < sa1) {
+            const palace_sa_item it = a.sa[sa0 + r];
+            bool ok = it.mapq2 >= a.p.min_mapq && it.nm2 <= a.p.max_nm && it.tid2 >= 0 && it.tid2 < a.n_targets;   // :724, :731-734
+            if (ok) {
+                Side s2{it.rev2 != 0, 0, it.pos2, a.tlen[it.tid2], it.tid2, it.mapq2, it.nm2};
+                s2.reg = region_of(s2.pos, s2.len, a.p.max_end);
+                ok = s1.reg != kMiddle && s2.reg != kMiddle;                         // :742
+                int st2, en2;
+                if (it.clip_s2 < 0) { st2 = 0; en2 = 0; }
+                else if (s2.rev && read_len > 0) { st2 = read_len - (it.len2 - it.clip_e2) + 1; en2 = read_len - it.clip_s2; }
+                else { st2 = it.clip_s2 + 1; en2 = it.len2 - it.clip_e2; }
+                bool first1 = false, stitch = false;                                 // :401-428, gap/overlap 150
+                if (en1 <= st2 && st2 - en1 - 1 <= 150) { first1 = true; stitch = true; }
+                else if (en2 <= st1 && st1 - en2 - 1 <= 150) { first1 = false; stitch = true; }
+                else if (st1 <= en2 && st2 <= en1) {
+                    int ov = min(en1, en2) - max(st1, st2) + 1;
+                    if (ov <= 150) { first1 = st1 <= st2; stitch = true; }
+                }
+                ok = ok && stitch;
+                if (ok) {
+                    const Side &l = first1 ? s1 : s2, &rr = first1 ? s2 : s1;
+                    const int oL = l.rev, oR = rr.rev;                               // both read forward (:524-527)
+                    if (l.reg == (oL ? kStart : kEnd) && rr.reg == (oR ? kEnd : kStart)) {   // :531-535
+                        c.ord = ord; c.kind = 0; c.found = 1;
+                        fill_evidence(a, l, rr, oL, oR, c);
+                        has = true;
+                    }
+                }
             }
-            if (!ok) continue;
-            const Side &l = first1 ? s1 : s2, &r = first1 ? s2 : s1;
-            const int oL = l.rev, oR = r.rev;                                    // both read forward (:524-527)
-            if (l.reg != (oL ? kStart : kEnd) || r.reg != (oR ? kEnd : kStart)) continue;   // :531-535
-            palace_graph_cand c{};
-            c.ord = ord; c.kind = 0; c.found = 1;
-            fill_evidence(a, l, r, oL, oR, c);
-            emit(a, c);
         }
+        emit_wave(a, has, c);
     }
     // ---- read pairs (:887-1011); the hasSupplementEvidence gate is applied in resolve -------------
-    const int mtid = a.c.mtid[i];
-    if (a.p.enable_paired && (flag & 0x1) && !(flag & 0x8) && mtid >= 0 && mtid < a.n_targets && mtid != tid) {
-        palace_graph_cand c{};
+    palace_graph_cand c{};
+    if (pair) {
         c.ord = ord; c.kind = 1; c.qkey = a.c.qkey[i]; c.mtid = mtid; c.ref_len = max(0, ref_len);
         Side s2{(flag & 0x20) != 0, 0, a.c.mpos[i] + 1, a.tlen[mtid], mtid, mapq, nm};   // mate mapq/nm := own (:950)
         s2.reg = region_of(s2.pos, s2.len, a.p.max_end);
@@ -201,8 +246,8 @@ __global__ __launch_bounds__(256) void graph_classify_kernel(GraphArgs a)
                 fill_evidence(a, l, r, oL, oR, c);
             }
         }
-        emit(a, c);
     }
+    emit_wave(a, pair, c);
 }
 
 // ---- resolve -----------------------------------------------------------------------------------
@@ -359,9 +404,30 @@ int palace_graph_classify(palace_ctx *ctx, const palace_bam_cols *cols, const pa
                                     d_cands, cand_cap, n_cands_out, nullptr);
 }
 
+int palace_graph_fastg_offsets(palace_ctx *ctx, const uint64_t *d_fastg, int64_t n_fastg, int32_t n_targets, uint32_t *d_first)
+{
+    PALACE_REQUIRE(ctx && d_first && n_fastg >= 0 && n_fastg < (1ll << 32) && n_targets >= 0, "bad argument");
+    PALACE_REQUIRE(n_fastg == 0 || d_fastg, "null FASTG key array");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    const unsigned blocks = static_cast<unsigned>((static_cast<int64_t>(n_targets) + 1 + 255) / 256);
+    hipLaunchKernelGGL(fastg_offsets_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_fastg, n_fastg, n_targets, d_first);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
 int palace_graph_classify_ex(palace_ctx *ctx, const palace_bam_cols *cols, const palace_sa_item *d_sa,
                              int32_t n_targets, const int32_t *d_tlen, const int32_t *d_trank,
                              const uint64_t *d_fastg, int64_t n_fastg, const palace_graph_params *prm,
+                             int64_t ord_base, uint64_t *d_consumed, palace_graph_cand *d_cands,
+                             int64_t cand_cap, int64_t *n_cands_out, int64_t *n_border_out)
+{
+    return palace_graph_classify_ix(ctx, cols, d_sa, n_targets, d_tlen, d_trank, d_fastg, n_fastg, nullptr, prm, ord_base, d_consumed,
+                                    d_cands, cand_cap, n_cands_out, n_border_out);
+}
+
+int palace_graph_classify_ix(palace_ctx *ctx, const palace_bam_cols *cols, const palace_sa_item *d_sa,
+                             int32_t n_targets, const int32_t *d_tlen, const int32_t *d_trank,
+                             const uint64_t *d_fastg, int64_t n_fastg, const uint32_t *d_fastg_first, const palace_graph_params *prm,
                              int64_t ord_base, uint64_t *d_consumed, palace_graph_cand *d_cands,
                              int64_t cand_cap, int64_t *n_cands_out, int64_t *n_border_out)
 {
@@ -380,7 +446,7 @@ int palace_graph_classify_ex(palace_ctx *ctx, const palace_bam_cols *cols, const
     if (rc) return rc;
     GraphArgs a{};
     a.c = *cols; a.sa = d_sa; a.n_targets = n_targets; a.tlen = d_tlen; a.trank = d_trank;
-    a.fastg = d_fastg; a.n_fastg = n_fastg; a.p = *prm; a.ord_base = ord_base;
+    a.fastg = d_fastg; a.n_fastg = n_fastg; a.fastg_first = n_fastg > 0 ? d_fastg_first : nullptr; a.p = *prm; a.ord_base = ord_base;
     a.lambda = std::max(50.0, static_cast<double>(prm->max_end) / 2.0);
     a.safe_dist = 600.0 * a.lambda;                 // exp(-600) ~ 2.6e-261: far above underflow
     a.consumed = reinterpret_cast<unsigned long long *>(d_consumed);

@@ -328,22 +328,34 @@ int main(int argc, char **argv)
     CK(palace_malloc(ctx, static_cast<size_t>(cand_cap) * sizeof(palace_graph_cand), &p));
     palace_graph_cand *d_cands = static_cast<palace_graph_cand *>(p);
 
+    // per-contig offsets into the sorted FASTG keys: a candidate's look-up starts inside its left contig's links
+    CK(palace_malloc(ctx, (static_cast<size_t>(nt) + 1) * 4, &p));
+    uint32_t *d_fk_first = static_cast<uint32_t *>(p);
+    CK(palace_graph_fastg_offsets(ctx, d_fk, static_cast<int64_t>(fkeys.size()), nt, d_fk_first));
     tr.lap("uploads");
     std::vector<palace_graph_cand> cands;
     int64_t n_cands = 0;
     for (int attempt = 0;; attempt++) {
         CK(palace_memset(ctx, d_consumed, 0, std::max<size_t>(1, nt) * 8));
-        CK(palace_graph_classify(ctx, &cols, d_sa, nt, d_tlen, d_rank, d_fk, static_cast<int64_t>(fkeys.size()), &prm,
-                                 0, d_consumed, d_cands, cand_cap, &n_cands));
+        CK(palace_graph_classify_ix(ctx, &cols, d_sa, nt, d_tlen, d_rank, d_fk, static_cast<int64_t>(fkeys.size()), d_fk_first, &prm,
+                                    0, d_consumed, d_cands, cand_cap, &n_cands, nullptr));
         // exactness guard: among pair candidates equal keys must mean equal read names
         cands.resize(static_cast<size_t>(n_cands));
         CK(palace_d2h(ctx, cands.data(), d_cands, cands.size() * sizeof(palace_graph_cand)));
-        std::unordered_map<uint64_t, int64_t> first;
+        // (a flat open-addressing table: the node-based map took ~30 ms for the 0.3 M pair candidates of a 1M-contig sample)
+        size_t n_pair = 0;
+        for (const auto &k : cands) n_pair += k.kind == 1;
+        size_t cap_t = 1024;
+        while (cap_t < 2 * n_pair) cap_t <<= 1;
+        std::vector<uint64_t> g_key(cap_t);
+        std::vector<int64_t> g_ord(cap_t, -1);                             // -1: empty slot
         bool collision = false;
         for (const auto &k : cands) {
             if (k.kind != 1) continue;
-            auto ins = first.emplace(k.qkey, k.ord);
-            if (!ins.second && ins.first->second != k.ord && c.qname(ins.first->second) != c.qname(k.ord)) { collision = true; break; }
+            size_t at = static_cast<size_t>((k.qkey * 0x9E3779B97F4A7C15ull) >> 20) & (cap_t - 1);
+            while (g_ord[at] >= 0 && g_key[at] != k.qkey) at = (at + 1) & (cap_t - 1);
+            if (g_ord[at] < 0) { g_key[at] = k.qkey; g_ord[at] = k.ord; }
+            else if (g_ord[at] != k.ord && c.qname(g_ord[at]) != c.qname(k.ord)) { collision = true; break; }
         }
         if (!collision) break;
         if (attempt == 8) { std::cerr << "generateGraph: read-name key collisions persist\n"; return 1; }
@@ -351,14 +363,32 @@ int main(int argc, char **argv)
         CK(palace_h2d(ctx, d_qkey, c.qkey.data(), c.qkey.size() * 8));
     }
     tr.lap("classify + name guard");
+    const int64_t n_records = c.n();
+    CK(palace_malloc(ctx, static_cast<size_t>(std::max<int64_t>(1, n_cands)) * sizeof(palace_graph_edge), &p));
+    palace_graph_edge *d_edges = static_cast<palace_graph_edge *>(p);
+    int64_t n_edges = 0;
+    tr.lap("edge buffer");
+    CK(palace_graph_resolve(ctx, d_cands, n_cands, n_records, &prm, d_consumed, d_edges, std::max<int64_t>(1, n_cands), &n_edges));
+    tr.lap("resolve");
+    std::vector<uint64_t> consumed(static_cast<size_t>(nt));
+    std::vector<palace_graph_edge> edges(static_cast<size_t>(n_edges));
+    std::vector<int32_t> cn_dev(static_cast<size_t>(nt));
+    CK(palace_malloc(ctx, std::max<size_t>(1, nt) * 4, &p));
+    int32_t *d_cn = static_cast<int32_t *>(p);
+    tr.lap("host buffers");
+    CK(palace_graph_copy_numbers(ctx, d_consumed, d_tlen, nt, avg_depth, d_cn));
+    CK(palace_d2h(ctx, cn_dev.data(), p, cn_dev.size() * 4));
+    CK(palace_d2h(ctx, consumed.data(), d_consumed, consumed.size() * 8));
+    CK(palace_d2h(ctx, edges.data(), d_edges, edges.size() * sizeof(palace_graph_edge)));
+    tr.lap("copy numbers + d2h");
     // The inflated stream (gigabytes) and the per-record columns (350 MB at 6.7 M records) have served: read names were their
     // last users.  Giving the pages back takes the kernel a few hundred milliseconds -- at process exit that is wall time the
     // driver waits for (measured: 15 to 250 ms after the last output byte, depending on how far a single helper had come);
-    // here it runs beside the rest of the work, on four helpers.  Not with one munmap of the stream, though: that holds the
+    // here it runs beside the rest of the work (the text outputs), on four helpers, once the last device buffer of this function is
+    // allocated (while the helpers ran beside them, "edge buffer" and "resolve" took 25 + 36 ms: allocations of the runtime wait for the same lock).  Not with one munmap of the stream, though: that holds the
     // address-space lock against every allocation of the other threads for its whole duration ("resolve + d2h" took 220 ms
     // instead of 9).  The pages go back piece by piece (MADV_DONTNEED takes the lock shared, and briefly); the empty mapping
     // itself stays until exit.
-    const int64_t n_records = c.n();
     {
         uint8_t *raw = c.raw.p.release();
         const size_t raw_n = c.raw.n;
@@ -381,23 +411,7 @@ int main(int argc, char **argv)
         std::thread([dead] { delete dead; }).detach();
     }
     c.raw.n = 0;
-    CK(palace_malloc(ctx, static_cast<size_t>(std::max<int64_t>(1, n_cands)) * sizeof(palace_graph_edge), &p));
-    palace_graph_edge *d_edges = static_cast<palace_graph_edge *>(p);
-    int64_t n_edges = 0;
-    tr.lap("edge buffer");
-    CK(palace_graph_resolve(ctx, d_cands, n_cands, n_records, &prm, d_consumed, d_edges, std::max<int64_t>(1, n_cands), &n_edges));
-    tr.lap("resolve");
-    std::vector<uint64_t> consumed(static_cast<size_t>(nt));
-    std::vector<palace_graph_edge> edges(static_cast<size_t>(n_edges));
-    std::vector<int32_t> cn_dev(static_cast<size_t>(nt));
-    CK(palace_malloc(ctx, std::max<size_t>(1, nt) * 4, &p));
-    int32_t *d_cn = static_cast<int32_t *>(p);
-    tr.lap("host buffers");
-    CK(palace_graph_copy_numbers(ctx, d_consumed, d_tlen, nt, avg_depth, d_cn));
-    CK(palace_d2h(ctx, cn_dev.data(), p, cn_dev.size() * 4));
-    CK(palace_d2h(ctx, consumed.data(), d_consumed, consumed.size() * 8));
-    CK(palace_d2h(ctx, edges.data(), d_edges, edges.size() * sizeof(palace_graph_edge)));
-    tr.lap("copy numbers + d2h");
+    tr.lap("pages handed back (helpers started)");
     if (!s4o.enabled()) {
         palace_ctx_destroy(ctx);
         tr.lap("ctx destroy");
@@ -440,7 +454,6 @@ int main(int argc, char **argv)
             seg_at[part].push_back({best, at, txt.size() - at});
         }
     });
-    for (const std::string &txt : seg_text) std::fwrite(txt.data(), 1, txt.size(), out);
     // `_graph.txt` order of the edges, as an index into the device order (stage 04 flags edges in device order)
     std::vector<uint32_t> sorted_index(edges.size());
     std::iota(sorted_index.begin(), sorted_index.end(), 0u);
@@ -451,19 +464,28 @@ int main(int argc, char **argv)
         if (a.oL != b.oL) return a.oL < b.oL;                          // '+' (43) < '-' (45)
         return a.oR < b.oR;
     });
-    for (uint32_t ei : sorted_index) {
-        const palace_graph_edge &e = edges[ei];
-        const uint32_t supp = e.counts[0], supp_nf = e.counts[1], span = e.counts[2], span_nf = e.counts[3];
-        const uint32_t total = supp + supp_nf + span + span_nf;
-        if (total == 0 || total < static_cast<uint32_t>(min_count)) continue;   // :1056-1061
-        std::fprintf(out, "JUNC %s %c %s %c %u %u\n", c.target_name[e.left].c_str(), e.oL ? '-' : '+',
-                     c.target_name[e.right].c_str(), e.oR ? '-' : '+', supp + span + supp_nf, span_nf);
-    }
-    if (std::ferror(out) | std::fclose(out)) {            // a short write must not exit 0
-        std::cerr << "Error: failed writing " << out_path << "\n";
-        return 1;
-    }
-    tr.lap("text output");
+    // The file itself (60 MB at a million contigs) is written by a thread of its own while stage 04 goes on: everything it reads
+    // (SEG text, edges, their order, names) is final
+    bool graph_ok = false;
+    std::thread graph_writer([&] {
+        for (const std::string &txt : seg_text) std::fwrite(txt.data(), 1, txt.size(), out);
+        for (uint32_t ei : sorted_index) {
+            const palace_graph_edge &e = edges[ei];
+            const uint32_t supp = e.counts[0], supp_nf = e.counts[1], span = e.counts[2], span_nf = e.counts[3];
+            const uint32_t total = supp + supp_nf + span + span_nf;
+            if (total == 0 || total < static_cast<uint32_t>(min_count)) continue;   // :1056-1061
+            std::fprintf(out, "JUNC %s %c %s %c %u %u\n", c.target_name[e.left].c_str(), e.oL ? '-' : '+',
+                         c.target_name[e.right].c_str(), e.oR ? '-' : '+', supp + span + supp_nf, span_nf);
+        }
+        graph_ok = !(std::ferror(out) | std::fclose(out));   // a short write must not exit 0
+    });
+    auto graph_written = [&]() -> bool {
+        if (graph_writer.joinable()) graph_writer.join();
+        if (!graph_ok) std::cerr << "Error: failed writing " << out_path << "\n";
+        return graph_ok;
+    };
+    if (!s4o.enabled() && !graph_written()) return 1;
+    tr.lap(s4o.enabled() ? "text output (SEG text; the file is being written)" : "text output");
     if (s4o.enabled()) {
         std::vector<std::string_view> raw_seg(static_cast<size_t>(nt));
         for (size_t part = 0; part < seg_text.size(); part++)
@@ -471,8 +493,11 @@ int main(int argc, char **argv)
         std::string err;
         if (stage04_run(ctx, s4obj, s4o, c, s4side, rank, raw_seg, edges, sorted_index, d_edges, n_cands, d_cn, threads, tr, err)) {
             std::cerr << "generateGraph: stage 04: " << err << "\n";
+            graph_written();
             return 1;
         }
+        if (!graph_written()) return 1;
+        tr.lap("_graph.txt written (joined)");
     }
     std::fflush(nullptr);
     _exit(0);                   // the output is complete and closed: skip tearing down gigabytes of host containers

@@ -368,6 +368,15 @@ inline int stage04_run(palace_ctx *ctx, palace_stage04 *st, const Stage04Options
     int64_t counts[8];
     if (palace_stage04_counts(ctx, st, counts)) return fail(palace_last_error());   // (also what the script dies on)
     tr.lap("stage 04: selection on the device");
+    // the decomposition is a few milliseconds of device work behind the selection: wait for it now, then the two text outputs
+    // (filtered graph; linear / cycle / all_result) are independent of each other and are made side by side
+    palace_match_result *res = nullptr;
+    const int32_t *contig_of = nullptr;
+    int64_t n_f = 0;
+    if (palace_stage04_result(ctx, st, &res, &contig_of, &n_f)) return fail(palace_last_error());
+    tr.lap("stage 04: decomposition (waited)");
+    std::string err_filtered;
+    std::thread filtered_text([&] {
 
     // ---- `_filtered_graph_pre.txt` (l.252-264): selected SEG lines and rescued ones in graph order, the kept junctions ----
     std::vector<int32_t> by_rank(static_cast<size_t>(nt));
@@ -430,17 +439,13 @@ inline int stage04_run(palace_ctx *ctx, palace_stage04 *st, const Stage04Options
             const uint8_t f = edge_flags[i];
             if (pass == 0 ? (f & 2) : ((f & 6) == 4)) junc_line(edges[i]);
         }
-    if (!write_file(o.pre_out, pre)) return fail("cannot write " + o.pre_out);
-    if (!o.filtered_out.empty() && !write_file(o.filtered_out, uniq_lines(pre))) return fail("cannot write " + o.filtered_out);
-    if (!write_file(o.hit_segs_out, hits)) return fail("cannot write " + o.hit_segs_out);
-    tr.lap("stage 04: filtered graph text");
+    if (!write_file(o.pre_out, pre)) { err_filtered = "cannot write " + o.pre_out; return; }
+    if (!o.filtered_out.empty() && !write_file(o.filtered_out, uniq_lines(pre))) { err_filtered = "cannot write " + o.filtered_out; return; }
+    if (!write_file(o.hit_segs_out, hits)) { err_filtered = "cannot write " + o.hit_segs_out; return; }
+    });
+    struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_filtered{filtered_text};
 
     // ---- matching's two files, as palace_amd/host/matching_main.cpp writes them ----
-    palace_match_result *res = nullptr;
-    const int32_t *contig_of = nullptr;
-    int64_t n_f = 0;
-    if (palace_stage04_result(ctx, st, &res, &contig_of, &n_f)) return fail(palace_last_error());
-    tr.lap("stage 04: decomposition (waited)");
     const int64_t n_comp = palace_match_result_count(res);
     const int64_t *off = palace_match_result_offsets(res);
     const int32_t *verts = palace_match_result_verts(res), *iter = palace_match_result_iter(res), *open_at = palace_match_result_open_at(res);
@@ -505,6 +510,9 @@ inline int stage04_run(palace_ctx *ctx, palace_stage04 *st, const Stage04Options
     if (!write_file(o.linear_out, lin) || !write_file(o.cycle_out, cyc) || !write_file(o.nodup_out, nodup) || !write_file(o.result_out, lin + nodup))
         return fail("cannot write the matching outputs");
     tr.lap("stage 04: result text");
+    filtered_text.join();
+    if (!err_filtered.empty()) return fail(err_filtered);
+    tr.lap("stage 04: filtered graph text (joined)");
     return 0;
 }
 

@@ -42,7 +42,15 @@ def check_line(line, contigs):
     assert e["refs_reported"] == c["refs_reported"] and e["junc_lines"] == c["graph"]["n_junc"] > 1000
     r = line["roofline"]
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
-    assert r["algorithmic_bytes_per_launch"] == 864 * int(c["workload"].split(", ")[1].split(" reads")[0])
+    n_reads = int(c["workload"].split(", ")[1].split(" reads")[0])
+    ref_bp = int(c["workload"].split("phage refs (")[1].split(" bp")[0])
+    # 864 B per 150-bp read; with Phase B's channel-0 probe fused into the count kernel, its 1 B per ref position too
+    assert r["algorithmic_bytes_per_launch"] in (864 * n_reads, 864 * n_reads + ref_bp - 31 * 5000)
+    st = line["roofline_stages"]
+    assert set(st) == {"phase_b", "classify", "resolve", "stage04"}
+    for v in st.values():
+        assert v["bound"] == "hbm" and v["ms_per_step"] > 0 and 0 < v["frac"] < 1 and v["algorithmic_bytes_per_step"] > 0
+    assert st["classify"]["algorithmic_bytes_per_step"] >= 52 * n_reads
     assert line["value"] == pytest.approx(contigs / (line["ms_per_step"] * 1e-3))
     return c
 

@@ -43,6 +43,30 @@ def test_bench_shaped_sample_equals_oracle(tmp_path):
                                            cap, ctypes.byref(n_e)), "resolve")
         capi._check(L.palace_graph_copy_numbers(ctx.h, P(consumed), P(gs["tlen"]), n_contigs, gs["avg_depth"], P(cn)), "cn")
         ctx.sync()
+        # the same classification with the FASTG look-ups narrowed by per-contig offsets (palace_graph_classify_ix): the same
+        # candidates (as a set: the append order is the waves'), the same depth sums
+        first = torch.zeros(n_contigs + 1, dtype=torch.int32, device=dev)
+        cands_ix, cons_ix = torch.zeros_like(cands), torch.zeros_like(consumed)
+        cands_plain, cons_plain = torch.zeros_like(cands), torch.zeros_like(consumed)
+        torch.cuda.synchronize()
+        capi._check(L.palace_graph_fastg_offsets(ctx.h, P(gs["fastg"]), gs["n_fastg"], n_contigs, P(first)), "offsets")
+        n_ix, n_pl, nb = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        capi._check(L.palace_graph_classify_ix(ctx.h, ctypes.byref(cols), P(gs["sa"]), n_contigs, P(gs["tlen"]), P(gs["trank"]), P(gs["fastg"]),
+                                               gs["n_fastg"], P(first), ctypes.byref(prm), 0, P(cons_ix), P(cands_ix), cap, ctypes.byref(n_ix),
+                                               ctypes.byref(nb)), "classify_ix")
+        capi._check(L.palace_graph_classify_ex(ctx.h, ctypes.byref(cols), P(gs["sa"]), n_contigs, P(gs["tlen"]), P(gs["trank"]), P(gs["fastg"]),
+                                               gs["n_fastg"], ctypes.byref(prm), 0, P(cons_plain), P(cands_plain), cap, ctypes.byref(n_pl),
+                                               ctypes.byref(nb)), "classify_ex")
+        ctx.sync()
+        assert n_ix.value == n_pl.value == n_c.value > 1000
+        def as_set(t, n):                                    # the 64-byte records in byte order
+            a = t[:n].cpu().numpy().reshape(-1, 64)
+            return a[np.lexsort(a.T[::-1])].tobytes()
+        assert as_set(cands_ix, n_ix.value) == as_set(cands_plain, n_pl.value)
+        fo = first.cpu().numpy().astype(np.int64)
+        fk_hi = (gs["fastg"].cpu().numpy().view(np.uint64) >> np.uint64(33)).astype(np.int64)
+        assert fo[0] == 0 and fo[-1] == gs["n_fastg"] and np.array_equal(fo, np.searchsorted(fk_hi, np.arange(n_contigs + 1), side="left"))
+        assert torch.equal(cons_ix, cons_plain)
         h_cons = consumed.cpu().numpy()
         h_cn = cn.cpu().numpy()
         h_edges = edges[: n_e.value].cpu().numpy().view(capi.EDGE_DTYPE).reshape(-1)
