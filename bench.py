@@ -75,7 +75,7 @@ def contig_lengths(n_contigs, long_mode):
     return np.maximum(56, rng.lognormal(np.log(800.0), 1.0, size=n_contigs)).astype(np.int64)
 
 
-def make_sample(torch, dev, n_contigs, n_refs, rank=0, world=1, long_mode=False):
+def make_sample(torch, dev, n_contigs, n_refs, rank=0, world=1, long_mode=False, read_weights=None):
     g = torch.Generator(device=dev)
     g.manual_seed(SEED)
     rng = np.random.Generator(np.random.PCG64(SEED))
@@ -136,8 +136,11 @@ def make_sample(torch, dev, n_contigs, n_refs, rank=0, world=1, long_mode=False)
     r2 = comp[torch.cat([r2_pool, r2_ph]).flip(1).long()]
     perm = torch.randperm(n_pairs, generator=g, device=dev)
     r1, r2 = r1[perm].contiguous(), r2[perm].contiguous()
-    if world > 1:                                  # reads shard by record range across ranks
-        lo, hi = n_pairs * rank // world, n_pairs * (rank + 1) // world
+    if world > 1:                                  # reads shard by record range across ranks (read_weights: relative shares, e.g. none for rank 0)
+        w = np.asarray(read_weights if read_weights is not None else [1.0] * world, dtype=np.float64)
+        cuts = np.concatenate([[0], np.floor(np.cumsum(w) / w.sum() * n_pairs + 1e-9).astype(np.int64)])
+        cuts[-1] = n_pairs
+        lo, hi = int(cuts[rank]), int(cuts[rank + 1])
         r1, r2 = r1[lo:hi].contiguous(), r2[lo:hi].contiguous()
     n_loc = r1.shape[0]
     read_off = torch.arange(2 * n_loc + 1, device=dev, dtype=torch.int64) * READ_LEN
@@ -827,7 +830,8 @@ def measure(args, E, leg):
     long_mode = args.workload == "long"
     n_reads_total = 2 * (int(5e8 * (1.0 if long_mode else args.contigs / 1_000_000)) // READ_LEN)
     model = multigpu.phase_a_model(n_reads_total, world)
-    scheme, forced = model["choice"], None
+    best = multigpu.best_step(args.contigs, n_reads_total, world)       # the whole step, serial terms included: scheme + whether rank 0 counts
+    scheme, forced = best["scheme"], None
     if force_exchange:
         forced = "shard_reads"
     elif force_key_split:
@@ -840,9 +844,21 @@ def measure(args, E, leg):
         scheme = forced
     if not collectives:
         scheme = "replicate"
-    model.update(choice_in_force=scheme, forced=bool(forced))
     shard_reads = scheme == "shard_reads"
-    sample = make_sample(torch, dev, args.contigs, args.refs, rank if shard_reads else 0, world if shard_reads else 1, long_mode)
+    # Stage 04 runs on rank 0.  Beside a count launch that saturates the device it takes 4-5x what it takes alone and grows with
+    # the sample (5M contigs: 27 ms), so for large samples under the read-sharded scheme rank 0 takes NO reads: ranks 1 .. W-1
+    # count 1/(W-1) each, rank 0's device has stage 04 (and its share of everything else) to itself.  PALACE_BENCH_RANK0_READS=0|1 forces.
+    rank0_counts = True
+    if shard_reads and world > 2:
+        env0 = os.environ.get("PALACE_BENCH_RANK0_READS", "auto")
+        rank0_counts = (env0 == "1") if env0 in ("0", "1") else (best["rank0_counts"] if scheme == best["scheme"] else
+                                                                  multigpu.step_model(args.contigs, n_reads_total, world, scheme, False)["step_ms"] >=
+                                                                  multigpu.step_model(args.contigs, n_reads_total, world, scheme, True)["step_ms"])
+    read_weights = None if (rank0_counts or not shard_reads) else [0.0] + [1.0] * (world - 1)
+    model.update(choice_in_force=scheme, forced=bool(forced), rank0_counts=bool(rank0_counts), choice=best["scheme"],
+                 step=multigpu.step_model(args.contigs, n_reads_total, world, scheme, rank0_counts),
+                 step_alternatives=[multigpu.step_model(args.contigs, n_reads_total, world, sch, True) for sch in model["ms"]])
+    sample = make_sample(torch, dev, args.contigs, args.refs, rank if shard_reads else 0, world if shard_reads else 1, long_mode, read_weights)
     gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world, long_mode)
     if collectives:                                 # avgDepth is a pipeline input: computed once from all shards
         tot = torch.tensor([float(gs["col"]["ref_len"].sum().item())], device=dev, dtype=torch.float64)
@@ -1175,7 +1191,7 @@ def measure(args, E, leg):
         # when Phase B's channel-0 probe rides along in the count kernel, its look-ups (1 B per ref position) are work of this launch
         fused_now = fused_probe and final_count and not key_split
         probe_bytes = sum(int(l) - 31 for l in sample["ref_lens"][r_lo:r_hi]) if fused_now else 0
-        achieved = (alg_bytes + probe_bytes) / (count_ms * 1e-3) / 1e9
+        achieved = (alg_bytes + probe_bytes) / (max(count_ms, 1e-6) * 1e-3) / 1e9          # (a rank 0 that takes no reads reports 0)
         out = {
             "metric": "contigs/sec eref+generate_graph+matching, 1M-contig synth, 1/2/4/8 GPU",       # BASELINE.json, verbatim
             "value": args.contigs / (ms_step * 1e-3), "unit": "contigs/s", "n_gpus": world,
@@ -1188,7 +1204,7 @@ def measure(args, E, leg):
                        "batches_in_flight": depth,
                        "reads": ("packed in HBM: two bits per base + 32-mer start mask, 0.375 B/base (palace_eref_count_reads_packed)" if packed else
                                  "ASCII in HBM, 1 B/base (palace_eref_count_reads)") + ("; count keeps only the '>= 3' plane (final_count)" if final_count else ""),
-                       "parallelism": "1 GPU" if world == 1 else (f"reads/records/refs sharded over {world} GPUs (RCCL)" if shard_reads else
+                       "parallelism": "1 GPU" if world == 1 else (f"reads/records/refs sharded over {world} GPUs (RCCL)" + ("" if rank0_counts else f"; rank 0 takes no reads: stage 04 has its device to itself, ranks 1-{world - 1} count") if shard_reads else
                                                                    f"records/refs and the key space sharded over {world} GPUs (RCCL): every GPU counts its 1/{world} of the keys of all reads, the '>= 3' plane is all-gathered" if key_split else
                                                                    f"records/refs sharded over {world} GPUs (RCCL), reads counted on every GPU"),
                        "parallelism_model": model,

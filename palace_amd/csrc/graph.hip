@@ -59,6 +59,7 @@ __device__ __forceinline__ int near_dist(int reg, int o_minus, int pos, int len)
 
 struct Side {
     int rev, reg, pos, len, tid, mapq, nm;
+    int rank;                       // dense rank of the contig's name (trank[tid]), fetched with the length
 };
 
 // membership in the sorted key array; with the per-contig offsets the search starts inside the left contig's few links (two or
@@ -81,7 +82,7 @@ __device__ __forceinline__ bool fastg_has(const uint64_t *__restrict__ keys, int
 __device__ __forceinline__ void fill_evidence(const GraphArgs &a, const Side &l, const Side &r, int oL, int oR,
                                               palace_graph_cand &c)
 {
-    const int rl = a.trank[l.tid], rr = a.trank[r.tid];
+    const int rl = l.rank, rr = r.rank;
     const bool left_is_a = rl <= rr;                                    // :802/:846 via name order
     const int eL = left_is_a ? oL : oR, eR = left_is_a ? oR : oL;       // :847-848 (orientations swap!)
     c.dL = near_dist(l.reg, eL, l.pos, l.len);
@@ -133,18 +134,21 @@ __device__ __forceinline__ void emit_wave(const GraphArgs &a, bool has, const pa
 }
 
 // One thread per record.  No lane leaves early: the wave stays whole so that candidates are appended per wave (emit_wave).
+// Loads go out in BATCHES, not one behind the test that needs it: every column of the record at once (nearly every record is
+// live, so gating them saved nothing and made a chain of ~11 dependent round trips per wave), then what the evidence-bearing
+// lanes need of the contig tables (lengths, name ranks, the read-name key) at once.
 __global__ __launch_bounds__(256) void graph_classify_kernel(GraphArgs a)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool in_range = i < a.c.n;
-    int flag = 0, tid = -1, ref_len = 0;
-    bool live = false;
-    if (in_range) {
-        flag = a.c.flag[i];
-        live = !(flag & (0x800 | 0x100 | 0x4));                         // :647-649
-        if (live) { tid = a.c.tid[i]; ref_len = a.c.ref_len[i]; }
+    int flag = 0x4, tid = -1, ref_len = 0, mapq = 0, nm = 0, sa0 = 0, sa1 = 0, mtid = -1, pos0 = 0, mpos0 = 0, read_len = 0;
+    if (in_range) {                                                     // batch 1: the record
+        flag = a.c.flag[i]; tid = a.c.tid[i]; ref_len = a.c.ref_len[i]; mapq = a.c.mapq[i]; nm = a.c.nm[i];
+        sa0 = a.c.sa_off[i]; sa1 = a.c.sa_off[i + 1]; mtid = a.c.mtid[i]; pos0 = a.c.pos[i]; mpos0 = a.c.mpos[i]; read_len = a.c.read_len[i];
     }
+    const bool live = in_range && !(flag & (0x800 | 0x100 | 0x4));      // :647-649
+    if (!live) { tid = -1; ref_len = 0; }
     // ---- depth (:654-662): combine runs of equal tid inside the wave, one atomic per run -------
     {
         int add = (live && tid >= 0 && tid < a.n_targets && ref_len > 0) ? ref_len : 0;
@@ -166,27 +170,27 @@ __global__ __launch_bounds__(256) void graph_classify_kernel(GraphArgs a)
             atomicAdd(&a.consumed[key], static_cast<unsigned long long>(add));
         }
     }
-    int mapq = 0, nm = 0;
-    if (live) { mapq = a.c.mapq[i]; nm = a.c.nm[i]; }
     // a record that can bear evidence: passes the flag filter, :679 and names a target
     const bool pass = live && mapq >= a.p.min_mapq && nm <= a.p.max_nm && tid >= 0 && tid < a.n_targets;
     const int64_t ord = a.ord_base + i;
-    int sa0 = 0, sa1 = 0, mtid = -1;
-    if (pass) { sa0 = a.c.sa_off[i]; sa1 = a.c.sa_off[i + 1]; mtid = a.c.mtid[i]; }
+    if (!pass) { sa0 = sa1 = 0; }
     const bool pair = pass && a.p.enable_paired && (flag & 0x1) && !(flag & 0x8) && mtid >= 0 && mtid < a.n_targets && mtid != tid;
-    if (!__any(pair || sa1 > sa0)) return;                              // uniform: most waves of a sample end here
-    int read_len = 0;
-    Side s1{(flag & 0x10) != 0, kMiddle, 0, 0, tid, mapq, nm};
-    if (pair || sa1 > sa0) {
-        read_len = a.c.read_len[i];
-        s1.pos = a.c.pos[i] + 1; s1.len = a.tlen[tid];
+    if (!__any(pair || sa1 > sa0)) return;                              // uniform
+    Side s1{(flag & 0x10) != 0, kMiddle, pos0 + 1, 0, tid, mapq, nm, 0};
+    Side sm{(flag & 0x20) != 0, kMiddle, mpos0 + 1, 0, mtid, mapq, nm, 0};  // the mate; its mapq/nm := own (:950)
+    unsigned long long qkey = 0;
+    int clip_s = 0, clip_e = 0;
+    if (pair || sa1 > sa0) {                                             // batch 2: the contig tables (and the rare columns)
+        s1.len = a.tlen[tid]; s1.rank = a.trank[tid];
+        if (pair) { sm.len = a.tlen[mtid]; sm.rank = a.trank[mtid]; qkey = a.c.qkey[i]; }
+        if (sa1 > sa0) { clip_s = a.c.clip_s[i]; clip_e = a.c.clip_e[i]; }
         s1.reg = region_of(s1.pos, s1.len, a.p.max_end);
+        if (pair) sm.reg = region_of(sm.pos, sm.len, a.p.max_end);
     }
 
     // ---- split reads (:684-879): item r of every lane's SA list in step (lists are short; most lanes have none) ----------
     int st1 = 0, en1 = 0;
-    if (sa1 > sa0) {
-        const int clip_s = a.c.clip_s[i], clip_e = a.c.clip_e[i];     // :369-380 (len == read_len)
+    if (sa1 > sa0) {                                                     // :369-380 (len == read_len)
         if (clip_s < 0) { st1 = 0; en1 = 0; }                            // empty CIGAR text (:332)
         else if (s1.rev && read_len > 0) { st1 = read_len - (read_len - clip_e) + 1; en1 = read_len - clip_s; }
         else { st1 = clip_s + 1; en1 = read_len - clip_e; }
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void graph_classify_kernel(GraphArgs a)
             const palace_sa_item it = a.sa[sa0 + r];
             bool ok = it.mapq2 >= a.p.min_mapq && it.nm2 <= a.p.max_nm && it.tid2 >= 0 && it.tid2 < a.n_targets;   // :724, :731-734
             if (ok) {
-                Side s2{it.rev2 != 0, 0, it.pos2, a.tlen[it.tid2], it.tid2, it.mapq2, it.nm2};
+                Side s2{it.rev2 != 0, 0, it.pos2, a.tlen[it.tid2], it.tid2, it.mapq2, it.nm2, a.trank[it.tid2]};
                 s2.reg = region_of(s2.pos, s2.len, a.p.max_end);
                 ok = s1.reg != kMiddle && s2.reg != kMiddle;                         // :742
                 int st2, en2;
@@ -229,9 +233,8 @@ __global__ __launch_bounds__(256) void graph_classify_kernel(GraphArgs a)
     // ---- read pairs (:887-1011); the hasSupplementEvidence gate is applied in resolve -------------
     palace_graph_cand c{};
     if (pair) {
-        c.ord = ord; c.kind = 1; c.qkey = a.c.qkey[i]; c.mtid = mtid; c.ref_len = max(0, ref_len);
-        Side s2{(flag & 0x20) != 0, 0, a.c.mpos[i] + 1, a.tlen[mtid], mtid, mapq, nm};   // mate mapq/nm := own (:950)
-        s2.reg = region_of(s2.pos, s2.len, a.p.max_end);
+        c.ord = ord; c.kind = 1; c.qkey = qkey; c.mtid = mtid; c.ref_len = max(0, ref_len);
+        const Side &s2 = sm;
         if (s1.reg != kMiddle && s2.reg != kMiddle) {                            // :910
             for (int order = 0; order < 2 && !c.found; order++) {                // :916-934
                 const Side &l = order == 0 ? s1 : s2, &r = order == 0 ? s2 : s1;

@@ -27,6 +27,7 @@
 #include "../../include/palace_hip.h"
 #include "fastx.hpp"
 #include "trace.hpp"
+#include "fast_exit.hpp"
 
 using namespace palace_host;
 
@@ -121,6 +122,7 @@ int main(int argc, char **argv)
         std::cerr << "Usage: " << argv[0] << " <fq1> <fq2> <phagedb.fa> <tmp.txt> <hit_ratio> <perfect_ratio> <threads>\n";
         return 1;
     }
+    palace_host::FastExit fast_exit = palace_host::fast_exit_begin();   // from here on this is the worker process (fast_exit.hpp)
     const std::string fq1 = argv[1], fq2 = argv[2], fasta = argv[3], interval_name = argv[4];
     const float hit_ratio = static_cast<float>(std::stod(argv[5]));            // :1228-1229
     const float perfect_ratio = static_cast<float>(std::stod(argv[6]));
@@ -431,6 +433,5 @@ int main(int argc, char **argv)
         std::fflush(nullptr);
         _exit(1);
     }
-    std::fflush(nullptr);
-    _exit(0);                   // every output is complete: skip the teardown of the runtime and of gigabytes of mappings
+    fast_exit.done(0);          // every output is complete: the caller goes on; runtime and gigabytes of mappings are torn down behind it
 }

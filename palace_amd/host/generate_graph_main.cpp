@@ -27,6 +27,7 @@
 #include "fastx.hpp"
 #include "stage04_fused.hpp"
 #include "trace.hpp"
+#include "fast_exit.hpp"
 
 using namespace palace_host;
 
@@ -243,6 +244,7 @@ int main(int argc, char **argv)
     const bool auto_depth = std::string(argv[optind + 3]) == "auto";
     double avg_depth = auto_depth ? 0.0 : std::atof(argv[optind + 3]);
 
+    FastExit fast_exit = fast_exit_begin();                    // from here on this is the worker process (fast_exit.hpp)
     Trace tr("generateGraph");
     BamColumns c;
     const int threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
@@ -381,37 +383,10 @@ int main(int argc, char **argv)
     CK(palace_d2h(ctx, consumed.data(), d_consumed, consumed.size() * 8));
     CK(palace_d2h(ctx, edges.data(), d_edges, edges.size() * sizeof(palace_graph_edge)));
     tr.lap("copy numbers + d2h");
-    // The inflated stream (gigabytes) and the per-record columns (350 MB at 6.7 M records) have served: read names were their
-    // last users.  Giving the pages back takes the kernel a few hundred milliseconds -- at process exit that is wall time the
-    // driver waits for (measured: 15 to 250 ms after the last output byte, depending on how far a single helper had come);
-    // here it runs beside the rest of the work (the text outputs), on four helpers, once the last device buffer of this function is
-    // allocated (while the helpers ran beside them, "edge buffer" and "resolve" took 25 + 36 ms: allocations of the runtime wait for the same lock).  Not with one munmap of the stream, though: that holds the
-    // address-space lock against every allocation of the other threads for its whole duration ("resolve + d2h" took 220 ms
-    // instead of 9).  The pages go back piece by piece (MADV_DONTNEED takes the lock shared, and briefly); the empty mapping
-    // itself stays until exit.
-    {
-        uint8_t *raw = c.raw.p.release();
-        const size_t raw_n = c.raw.n;
-        constexpr int kHelpers = 4;
-        const uintptr_t page = 4096, piece = 32u << 20;
-        const uintptr_t lo = (reinterpret_cast<uintptr_t>(raw) + page - 1) / page * page, hi = (reinterpret_cast<uintptr_t>(raw) + raw_n) / page * page;
-        for (int h = 0; h < kHelpers && hi > lo; h++) {
-            const uintptr_t a0 = lo + (hi - lo) / page * static_cast<uintptr_t>(h) / kHelpers * page,
-                            a1 = h + 1 == kHelpers ? hi : lo + (hi - lo) / page * static_cast<uintptr_t>(h + 1) / kHelpers * page;
-            std::thread([a0, a1, piece] {
-                for (uintptr_t a = a0; a < a1; a += piece) ::madvise(reinterpret_cast<void *>(a), std::min<uintptr_t>(piece, a1 - a), MADV_DONTNEED);
-            }).detach();
-        }
-        auto *dead = new BamColumns;                                   // the columns the device has taken over
-        std::swap(dead->tid, c.tid); std::swap(dead->pos, c.pos); std::swap(dead->mtid, c.mtid); std::swap(dead->mpos, c.mpos);
-        std::swap(dead->nm, c.nm); std::swap(dead->ref_len, c.ref_len); std::swap(dead->read_len, c.read_len); std::swap(dead->clip_s, c.clip_s);
-        std::swap(dead->clip_e, c.clip_e); std::swap(dead->sa_off, c.sa_off); std::swap(dead->flag, c.flag); std::swap(dead->mapq, c.mapq);
-        std::swap(dead->qkey, c.qkey); std::swap(dead->qname_at, c.qname_at); std::swap(dead->qname_len, c.qname_len); std::swap(dead->sa, c.sa);
-        std::swap(dead->mseg_tid, c.mseg_tid); std::swap(dead->mseg_pos, c.mseg_pos); std::swap(dead->mseg_len, c.mseg_len);
-        std::thread([dead] { delete dead; }).detach();
-    }
-    c.raw.n = 0;
-    tr.lap("pages handed back (helpers started)");
+    // (The inflated stream -- gigabytes -- and the per-record columns have served by now.  Rounds 2-3 handed their pages back
+    // from helper threads so that the process would exit faster; whatever ran beside those helpers paid for it (TLB shoot-downs,
+    // the address-space lock: hipMalloc 25 ms, SEG formatting +45 ms).  Now nothing is handed back: the caller's process leaves
+    // when the outputs are complete and this worker's address space is torn down behind it, fast_exit.hpp.)
     if (!s4o.enabled()) {
         palace_ctx_destroy(ctx);
         tr.lap("ctx destroy");
@@ -499,6 +474,5 @@ int main(int argc, char **argv)
         if (!graph_written()) return 1;
         tr.lap("_graph.txt written (joined)");
     }
-    std::fflush(nullptr);
-    _exit(0);                   // the output is complete and closed: skip tearing down gigabytes of host containers
+    fast_exit.done(0);          // the outputs are complete and closed: the caller goes on, gigabytes of host containers are torn down behind it
 }

@@ -27,6 +27,7 @@
 #include "fastx.hpp"
 #include "textio.hpp"
 #include "trace.hpp"
+#include "fast_exit.hpp"
 
 namespace {
 
@@ -207,6 +208,7 @@ int main(int argc, char **argv)
                      "       matching --batch <list of '<graph> <linear out> <cycle out>' lines> [-s] [-i <iterations>] [-b] [-l ...] [--aggressive]\n";
         return 1;
     }
+    palace_host::FastExit fast_exit = palace_host::fast_exit_begin();   // from here on this is the worker process (fast_exit.hpp)
     palace_host::Trace tr("matching");
     palace_ctx *ctx = nullptr;                                // the HIP runtime comes up while the graph text is read
     int ctx_rc = 0;
@@ -354,6 +356,5 @@ int main(int argc, char **argv)
         if (fl.fail() || fc.fail()) { std::cerr << "matching: failed writing the outputs of " << j.graph << "\n"; return 1; }
     }
     tr.lap("text output");
-    std::fflush(nullptr);
-    _exit(0);                   // outputs are complete and closed: skip the teardown of the host containers
+    fast_exit.done(0);          // outputs are complete and closed: the caller goes on, the teardown happens behind it
 }

@@ -78,6 +78,43 @@ def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None) -> di
                 note="modelled from 1-GPU kernel times and per-link xGMI arithmetic; no N > 1 hardware measurement behind it")
 
 
+# ---- the whole step of one rank, serial terms included ------------------------------------------------
+# One-GPU stage times of the 1M-contig workload (bench.py stage_ms, round 4) and how they scale: classify and resolve with the
+# records (= reads), Phase B with the refs (a constant DB) over the ranks, stage 04 (selection + matching, on rank 0) with the
+# contigs -- 1.4 ms alone on a device, 5.4 ms beside a count launch that saturates it (500k contigs: 2.9, 5M: 27, long: 1.6).
+STEP = dict(reset_ms=0.1, phase_b_fixed_ms=0.15, phase_b_ms=1.35, classify_ms=0.88, resolve_ms=0.37, small_collective_ms=0.1,
+            stage04_alone_ms=(0.9, 0.5), stage04_beside_count_ms=(1.0, 4.4))         # (fixed, per 1M contigs)
+
+
+def step_model(n_contigs: int, n_reads: int, world: int, scheme: str | None = None, rank0_counts: bool = True, link_gbs: float | None = None) -> dict:
+    """Modelled milliseconds per step of an N-GPU run: stream A of every rank (reset, Phase A under `scheme` -- default: the
+    cheapest --, Phase B on 1/W of the refs, row gather) against stream B of rank 0 (classify on 1/W of the records, candidate
+    gather, resolve, depth reduce, stage 04); the step is the longer of the two.  rank0_counts=False: the reads are sharded over
+    ranks 1 .. W-1 only (scheme shard_reads), so that stage 04 has rank 0's device to itself."""
+    W = max(1, world)
+    pa = phase_a_model(n_reads, W, link_gbs)
+    scheme = scheme or pa["choice"]
+    a_phase = pa["ms"].get(scheme, pa["ms"]["replicate"])            # (a scheme forced where the model has none for it: one rank, W not dividing 64)
+    if not rank0_counts and scheme == "shard_reads" and W > 2:
+        m, x = MODEL, n_reads / MODEL["reads_measured"]
+        a_phase += m["count_all_ms"] * m["three_planes_factor"] * x * (1.0 / (W - 1) - 1.0 / W)
+    xc, xr, t = n_contigs / 1e6, n_reads / MODEL["reads_measured"], STEP
+    coll = t["small_collective_ms"] if W > 1 else 0.0
+    stream_a = t["reset_ms"] + a_phase + t["phase_b_fixed_ms"] + t["phase_b_ms"] / W + coll
+    s04 = t["stage04_beside_count_ms"] if (rank0_counts or W == 1) else t["stage04_alone_ms"]
+    stream_b = t["classify_ms"] * xr / W + coll + t["resolve_ms"] * xr + coll + s04[0] + s04[1] * xc
+    return dict(scheme=scheme, rank0_counts=bool(rank0_counts), stream_a_ms=round(stream_a, 2), stream_b_rank0_ms=round(stream_b, 2),
+                step_ms=round(max(stream_a, stream_b), 2))
+
+
+def best_step(n_contigs: int, n_reads: int, world: int, link_gbs: float | None = None) -> dict:
+    """scheme and rank-0 read share with the shortest modelled step"""
+    cands = [step_model(n_contigs, n_reads, world, s, True, link_gbs) for s in phase_a_model(n_reads, world, link_gbs)["ms"]]
+    if world > 2:
+        cands.append(step_model(n_contigs, n_reads, world, "shard_reads", False, link_gbs))
+    return min(cands, key=lambda c: c["step_ms"])
+
+
 class Exchange:
     def __init__(self, torch, dist, rank: int, world: int):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world

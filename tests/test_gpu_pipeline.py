@@ -67,8 +67,9 @@ def test_bench_exchange_path_rehearsal():
     assert a["config"]["graph"]["n_edges"] > 0
 
 
-@pytest.mark.parametrize("world,port,scheme", [(2, 29521, "replicate"), (4, 29522, "shard_reads"), (4, 29523, "key_split"), (2, 29524, "auto")])
-def test_bench_multi_rank_rehearsal_on_one_gpu(world, port, scheme):
+@pytest.mark.parametrize("world,port,scheme,rank0", [(2, 29521, "replicate", "auto"), (4, 29522, "shard_reads", "1"), (4, 29525, "shard_reads", "0"),
+                                                    (4, 29523, "key_split", "auto"), (2, 29524, "auto", "auto")])
+def test_bench_multi_rank_rehearsal_on_one_gpu(world, port, scheme, rank0):
     """The N-rank step with all ranks on GPU 0 and the collectives over gloo (RCCL refuses two ranks on one device), under each
     Phase-A scheme (replicate: every rank counts all reads; shard_reads: reads sharded, count-table exchange + merge; key_split:
     the key space split, all-gather of the plane slices; auto: whatever the cost model picks for this size): the same refs and
@@ -78,7 +79,8 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(world, port, scheme):
     a = json.loads(sh([sys.executable, os.path.join(ROOT, "bench.py")] + size).decode().strip().splitlines()[-1])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + size
-    out = sh(cmd, env=dict(os.environ, PALACE_BENCH_ONE_DEVICE="1", PALACE_BENCH_BACKEND="gloo", PALACE_BENCH_SCHEME=scheme)).decode()
+    out = sh(cmd, env=dict(os.environ, PALACE_BENCH_ONE_DEVICE="1", PALACE_BENCH_BACKEND="gloo", PALACE_BENCH_SCHEME=scheme,
+                           PALACE_BENCH_RANK0_READS=rank0)).decode()
     b = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
     assert b["n_gpus"] == world and b["scaling"] == "strong" and "failed_checks" not in b
     pm = b["config"]["parallelism_model"]
@@ -86,7 +88,9 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(world, port, scheme):
     if scheme == "auto":
         assert pm["forced"] is False and pm["choice_in_force"] == pm["choice"] == min(pm["ms"], key=pm["ms"].get)
         scheme = pm["choice"]
-    assert pm["choice_in_force"] == scheme
+    assert pm["choice_in_force"] == scheme and pm["step"]["scheme"] == scheme and pm["step"]["step_ms"] > 0
+    if rank0 in ("0", "1"):
+        assert pm["rank0_counts"] == (rank0 == "1") and ("rank 0 takes no reads" in b["config"]["parallelism"]) == (rank0 == "0")
     assert ("reads/records/refs sharded" in b["config"]["parallelism"]) == (scheme == "shard_reads")
     assert ("key space sharded" in b["config"]["parallelism"]) == (scheme == "key_split")
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0

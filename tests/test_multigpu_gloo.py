@@ -134,6 +134,20 @@ def test_phase_a_scheme_model_picks_by_size():
         assert r["ms"][r["choice"]] == min(r["ms"].values()) and r["world"] == w
 
 
+def test_step_model_gives_rank_0_to_stage_04_for_large_samples():
+    """the whole-step model (serial terms included): at 5M contigs on 8 GPUs stage 04 beside a count launch would be rank 0's
+    critical path (27 ms on one GPU), so rank 0 takes no reads; at 1M contigs it is hidden and every rank counts"""
+    big = multigpu.best_step(5_000_000, 33_333_333, 8)
+    assert big["scheme"] == "shard_reads" and big["rank0_counts"] is False and big["stream_a_ms"] > big["stream_b_rank0_ms"]
+    with0 = multigpu.step_model(5_000_000, 33_333_333, 8, "shard_reads", True)
+    assert with0["step_ms"] > big["step_ms"] and with0["stream_b_rank0_ms"] > with0["stream_a_ms"]
+    small = multigpu.best_step(1_000_000, 6_666_666, 8)
+    assert small["scheme"] == "key_split" and small["rank0_counts"] is True
+    one = multigpu.best_step(1_000_000, 6_666_666, 1)
+    assert one["scheme"] == "replicate" and 9 < one["step_ms"] < 12
+    assert multigpu.best_step(5_000_000, 33_333_333, 8)["step_ms"] < multigpu.best_step(5_000_000, 33_333_333, 4)["step_ms"] < one["step_ms"] * 5
+
+
 def test_split_by_weight_properties():
     rng = np.random.Generator(np.random.PCG64(1))
     w = rng.integers(1, 100, size=1000)
