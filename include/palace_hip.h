@@ -339,6 +339,17 @@ int palace_graph_score_border(palace_ctx *ctx, palace_graph_cand *d_cands, int64
 int palace_graph_copy_numbers(palace_ctx *ctx, const uint64_t *d_consumed, const int32_t *d_tlen,
                               int32_t n_targets, double avg_depth, int32_t *d_cn);
 
+/* ---- N4: BGZF members inflated on the device ------------------------------------------------------------------------------ */
+
+/* What htslib's bgzf layer does inside sam_read1 (generate_graph.cpp:644), for n_members BGZF members at once, one wavefront
+ * each: member m's raw DEFLATE data are d_in[d_in_off[m] .. + d_in_len[m]) (behind the member's 18-byte header, in front of
+ * its CRC32 / ISIZE trailer), its d_out_len[m] (= ISIZE, <= 65536) bytes go to d_out + d_out_off[m].  d_status[m] = 0: exactly
+ * those bytes were written; non-zero: the decoder refused the member (malformed, or a size that does not fit) and the caller
+ * lets zlib decide it on the host, as the loader's CPU decoder does.  CRC32 is not checked (the loader never did; htslib does).
+ * The buffer behind d_in must extend at least 3 bytes past the last member's data (reads are whole dwords).  Enqueues only. */
+int palace_bgzf_inflate(palace_ctx *ctx, const uint8_t *d_in, int64_t n_members, const int64_t *d_in_off, const int32_t *d_in_len,
+                        const int64_t *d_out_off, const int32_t *d_out_len, uint8_t *d_out, int32_t *d_status);
+
 /* ---- depth stage: `samtools depth <bam> | awk '{sum+=$3} END {print sum/NR}'` (palace:538-552) ------------------ */
 
 /* The two numbers of that mean.  A match segment is one M / = / X CIGAR operation of a record whose UNMAP, SECONDARY,

@@ -133,54 +133,95 @@ __device__ __forceinline__ void emit_wave(const GraphArgs &a, bool has, const pa
     }
 }
 
-// One thread per record.  No lane leaves early: the wave stays whole so that candidates are appended per wave (emit_wave).
-// Loads go out in BATCHES, not one behind the test that needs it: every column of the record at once (nearly every record is
-// live, so gating them saved nothing and made a chain of ~11 dependent round trips per wave), then what the evidence-bearing
-// lanes need of the contig tables (lengths, name ranks, the read-name key) at once.
-__global__ __launch_bounds__(256) void graph_classify_kernel(GraphArgs a)
+// Pass 1, one thread per record, streaming: the filters, the per-contig depth sums (:654-662) and the SELECTION of the records
+// that can bear evidence at all -- an SA list or a mate on another contig: ~7 % of a sample -- whose indices are appended to
+// `list`, per wave.  Pass 2 runs the layout search on those only, with full waves.  (As one kernel, thread per record, 93 % of
+// the waves went down the whole chain of dependent loads -- contig tables, SA item, FASTG keys, two returning appends -- for
+// the four or five of their lanes that had a candidate: 0.84 ms for 6.67 M records, 5 % of the HBM rate.)
+constexpr int kSelectThreads = 1024;
+__global__ __launch_bounds__(kSelectThreads) void graph_depth_select_kernel(GraphArgs a, uint32_t *__restrict__ list, unsigned long long *__restrict__ n_list)
 {
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool in_range = i < a.c.n;
-    int flag = 0x4, tid = -1, ref_len = 0, mapq = 0, nm = 0, sa0 = 0, sa1 = 0, mtid = -1, pos0 = 0, mpos0 = 0, read_len = 0;
-    if (in_range) {                                                     // batch 1: the record
+    __shared__ uint32_t wave_n[kSelectThreads / 64];
+    __shared__ unsigned long long block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // a resident grid that strides over the records (two workgroups per CU): launched one workgroup per 1024 records the kernel
+    // took 0.68 ms however little it did -- 5 waves per CU in flight on average, the rest of the time went into getting waves started
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kSelectThreads;
+    for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * kSelectThreads; i0 < a.c.n; i0 += stride) {     // (uniform per workgroup)
+        const int64_t i = i0 + threadIdx.x;
+        const bool in_range = i < a.c.n;
+        int flag = 0x4, tid = -1, ref_len = 0, mapq = 0, nm = 0, sa0 = 0, sa1 = 0, mtid = -1;
+        if (in_range) {                                                     // every column this pass needs, at once
+            flag = a.c.flag[i]; tid = a.c.tid[i]; ref_len = a.c.ref_len[i]; mapq = a.c.mapq[i]; nm = a.c.nm[i];
+            sa0 = a.c.sa_off[i]; sa1 = a.c.sa_off[i + 1]; mtid = a.c.mtid[i];
+        }
+        const bool live = in_range && !(flag & (0x800 | 0x100 | 0x4));      // :647-649
+        if (!live) { tid = -1; ref_len = 0; }
+        // ---- depth (:654-662): combine runs of equal tid inside the wave, one atomic per run -------
+        {
+            int add = (live && tid >= 0 && tid < a.n_targets && ref_len > 0) ? ref_len : 0;
+            int key = (live && tid >= 0 && tid < a.n_targets) ? tid : -1;
+            int prev = __shfl_up(key, 1);
+            bool sorted = __all(lane == 0 || prev <= key);
+            if (sorted) {
+                long long v = add;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    long long u = __shfl_up(v, d);
+                    int k2 = __shfl_up(key, d);
+                    if (lane >= d && k2 == key) v += u;
+                }
+                int next = __shfl_down(key, 1);
+                if ((lane == 63 || next != key) && key >= 0 && v > 0)
+                    atomicAdd(&a.consumed[key], static_cast<unsigned long long>(v));
+            } else if (add > 0) {
+                atomicAdd(&a.consumed[key], static_cast<unsigned long long>(add));
+            }
+        }
+        // a record that can bear evidence: passes the flag filter, :679, names a target -- and has an SA list or a mate elsewhere
+        const bool pass = live && mapq >= a.p.min_mapq && nm <= a.p.max_nm && tid >= 0 && tid < a.n_targets;
+        const bool pair = pass && a.p.enable_paired && (flag & 0x1) && !(flag & 0x8) && mtid >= 0 && mtid < a.n_targets && mtid != tid;
+        const bool want = pass && (pair || sa1 > sa0);
+        // one returning add on the list counter per workgroup and round, not one per wave (adds on one address are taken one at a
+        // time by the memory side -- and while ~100 000 of them queued there, the counting kernels' own reservations on the other
+        // stream waited too: level 1 ran 4.47 ms beside the old classify kernel, 3.6 ms beside this one)
+        const unsigned long long m = __ballot(want);
+        if (lane == 0) wave_n[wave] = static_cast<uint32_t>(__popcll(m));
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (int w = 0; w < kSelectThreads / 64; w++) { const uint32_t c = wave_n[w]; wave_n[w] = total; total += c; }
+            block_base = total ? atomicAdd(n_list, static_cast<unsigned long long>(total)) : 0ull;
+        }
+        __syncthreads();
+        if (want) list[block_base + wave_n[wave] + __popcll(m & ((1ull << lane) - 1))] = static_cast<uint32_t>(i);
+        __syncthreads();                                                     // (wave_n / block_base are rewritten in the next round)
+    }
+}
+
+// Pass 2: a lane per SELECTED record (grid-stride over the list, whole waves: candidates are appended per wave, emit_wave).
+__global__ __launch_bounds__(256) void graph_classify_kernel(GraphArgs a, const uint32_t *__restrict__ list, const unsigned long long *__restrict__ n_list)
+{
+    const int64_t n = static_cast<int64_t>(*n_list);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t k0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) & ~63ll; k0 < n; k0 += stride) {   // k0: uniform per wave
+    const int64_t k = k0 + (threadIdx.x & 63);
+    const bool sel = k < n;
+    const int64_t i = sel ? list[k] : 0;
+    int flag = 0x4, tid = 0, ref_len = 0, mapq = 0, nm = 0, sa0 = 0, sa1 = 0, mtid = -1, pos0 = 0, mpos0 = 0, read_len = 0;
+    if (sel) {                                                          // batch 1: the record
         flag = a.c.flag[i]; tid = a.c.tid[i]; ref_len = a.c.ref_len[i]; mapq = a.c.mapq[i]; nm = a.c.nm[i];
         sa0 = a.c.sa_off[i]; sa1 = a.c.sa_off[i + 1]; mtid = a.c.mtid[i]; pos0 = a.c.pos[i]; mpos0 = a.c.mpos[i]; read_len = a.c.read_len[i];
     }
-    const bool live = in_range && !(flag & (0x800 | 0x100 | 0x4));      // :647-649
-    if (!live) { tid = -1; ref_len = 0; }
-    // ---- depth (:654-662): combine runs of equal tid inside the wave, one atomic per run -------
-    {
-        int add = (live && tid >= 0 && tid < a.n_targets && ref_len > 0) ? ref_len : 0;
-        int key = (live && tid >= 0 && tid < a.n_targets) ? tid : -1;
-        int prev = __shfl_up(key, 1);
-        bool sorted = __all(lane == 0 || prev <= key);
-        if (sorted) {
-            long long v = add;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                long long u = __shfl_up(v, d);
-                int k2 = __shfl_up(key, d);
-                if (lane >= d && k2 == key) v += u;
-            }
-            int next = __shfl_down(key, 1);
-            if ((lane == 63 || next != key) && key >= 0 && v > 0)
-                atomicAdd(&a.consumed[key], static_cast<unsigned long long>(v));
-        } else if (add > 0) {
-            atomicAdd(&a.consumed[key], static_cast<unsigned long long>(add));
-        }
-    }
-    // a record that can bear evidence: passes the flag filter, :679 and names a target
-    const bool pass = live && mapq >= a.p.min_mapq && nm <= a.p.max_nm && tid >= 0 && tid < a.n_targets;
+    if (!sel) { sa0 = sa1 = 0; }
     const int64_t ord = a.ord_base + i;
-    if (!pass) { sa0 = sa1 = 0; }
-    const bool pair = pass && a.p.enable_paired && (flag & 0x1) && !(flag & 0x8) && mtid >= 0 && mtid < a.n_targets && mtid != tid;
-    if (!__any(pair || sa1 > sa0)) return;                              // uniform
+    // (pass 1 selected the record: it is live, passes :679 and names a target)
+    const bool pair = sel && a.p.enable_paired && (flag & 0x1) && !(flag & 0x8) && mtid >= 0 && mtid < a.n_targets && mtid != tid;
     Side s1{(flag & 0x10) != 0, kMiddle, pos0 + 1, 0, tid, mapq, nm, 0};
     Side sm{(flag & 0x20) != 0, kMiddle, mpos0 + 1, 0, mtid, mapq, nm, 0};  // the mate; its mapq/nm := own (:950)
     unsigned long long qkey = 0;
     int clip_s = 0, clip_e = 0;
-    if (pair || sa1 > sa0) {                                             // batch 2: the contig tables (and the rare columns)
+    if (sel) {                                                           // batch 2: the contig tables (and the rare columns)
         s1.len = a.tlen[tid]; s1.rank = a.trank[tid];
         if (pair) { sm.len = a.tlen[mtid]; sm.rank = a.trank[mtid]; qkey = a.c.qkey[i]; }
         if (sa1 > sa0) { clip_s = a.c.clip_s[i]; clip_e = a.c.clip_e[i]; }
@@ -251,6 +292,7 @@ __global__ __launch_bounds__(256) void graph_classify_kernel(GraphArgs a)
         }
     }
     emit_wave(a, pair, c);
+    }
 }
 
 // ---- resolve -----------------------------------------------------------------------------------
@@ -344,18 +386,25 @@ __global__ void resolve_pair_apply_kernel(ResolveArgs a)
     }
     if (c.found && c.cls == 1) count_edge(a, c);
 }
-__global__ void compact_edges_kernel(ResolveArgs a)
+constexpr int kCompactThreads = 1024;
+__global__ __launch_bounds__(kCompactThreads) void compact_edges_kernel(ResolveArgs a)
 {
+    __shared__ uint32_t wave_n[kCompactThreads / 64];
+    __shared__ unsigned long long block_base;
     uint64_t s = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool have = s <= a.e_mask && a.e_keys[s] != kEmpty;
-    const unsigned long long m = __ballot(have);                  // one counter add per wave, not one per edge
-    if (!m) return;
-    const int lane = threadIdx.x & 63, first = __builtin_ctzll(m);
-    unsigned long long base = 0;
-    if (lane == first) base = atomicAdd(&a.counters[0], static_cast<unsigned long long>(__popcll(m)));
-    base = __shfl(base, first);
+    const unsigned long long m = __ballot(have);                  // one counter add per WORKGROUP (adds on one address are taken one at a time)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_n[wave] = static_cast<uint32_t>(__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < kCompactThreads / 64; w++) { const uint32_t c = wave_n[w]; wave_n[w] = total; total += c; }
+        block_base = total ? atomicAdd(&a.counters[0], static_cast<unsigned long long>(total)) : 0ull;
+    }
+    __syncthreads();
     if (!have) return;
-    const unsigned long long i = base + __popcll(m & ((1ull << lane) - 1));
+    const unsigned long long i = block_base + wave_n[wave] + __popcll(m & ((1ull << lane) - 1));
     if (static_cast<int64_t>(i) >= a.edge_cap) return;
     uint64_t k = a.e_keys[s];
     palace_graph_edge e{};
@@ -455,10 +504,17 @@ int palace_graph_classify_ix(palace_ctx *ctx, const palace_bam_cols *cols, const
     a.consumed = reinterpret_cast<unsigned long long *>(d_consumed);
     a.cands = d_cands; a.cap = cand_cap;
     a.n_cands = reinterpret_cast<unsigned long long *>(ctx->d_small);
-    PALACE_HIP_TRY(hipMemsetAsync(ctx->d_small, 0, 16, ctx->stream));
-    int64_t blocks = (cols->n + 255) / 256;
-    PALACE_REQUIRE(blocks < (1ll << 31), "too many records for one launch");
-    hipLaunchKernelGGL(graph_classify_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, a);
+    PALACE_HIP_TRY(hipMemsetAsync(ctx->d_small, 0, 24, ctx->stream));
+    const int64_t blocks = (cols->n + 255) / 256, sel_blocks = (cols->n + kSelectThreads - 1) / kSelectThreads;
+    PALACE_REQUIRE(blocks < (1ll << 31) && cols->n < (1ll << 32), "too many records for one launch");
+    // pass 1 over every record (depth, selection), pass 2 over the selected ones (their indices: 4 B per record of workspace)
+    rc = ensure_workspace(ctx, static_cast<size_t>(cols->n) * 4 + 256);
+    if (rc) return rc;
+    uint32_t *list = static_cast<uint32_t *>(ctx->ws.ptr);
+    unsigned long long *n_list = reinterpret_cast<unsigned long long *>(ctx->d_small) + 2;
+    hipLaunchKernelGGL(graph_depth_select_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(sel_blocks, 2 * kCUs))), dim3(kSelectThreads), 0, ctx->stream, a, list, n_list);
+    hipLaunchKernelGGL(graph_classify_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(blocks, kCUs * 8))), dim3(256), 0, ctx->stream, a, list,
+                       static_cast<const unsigned long long *>(n_list));
     PALACE_HIP_TRY(hipGetLastError());
     // both counters come back in one copy into pinned memory, behind one wait (no second round trip in resolve)
     unsigned long long *n = static_cast<unsigned long long *>(ctx->pin.ptr);
@@ -566,7 +622,7 @@ int palace_graph_resolve_ex(palace_ctx *ctx, palace_graph_cand *d_cands, int64_t
     hipLaunchKernelGGL(resolve_split_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(resolve_pair_insert_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(resolve_pair_apply_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL(compact_edges_kernel, dim3(static_cast<unsigned>((qcap + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(compact_edges_kernel, dim3(static_cast<unsigned>((qcap + kCompactThreads - 1) / kCompactThreads)), dim3(kCompactThreads), 0,
                        ctx->stream, a);
     PALACE_HIP_TRY(hipGetLastError());
     if (d_n_edges) PALACE_HIP_TRY(hipMemcpyAsync(d_n_edges, ctx->d_small, 8, hipMemcpyDeviceToDevice, ctx->stream));

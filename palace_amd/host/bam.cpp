@@ -241,8 +241,31 @@ struct BamLoad {
     }
 };
 
+std::vector<BgzfMember> bgzf_members(const uint8_t *file, size_t size, size_t *total_out)
+{
+    std::vector<BgzfMember> out;
+    for (const Block &b : index_bgzf(file, size, total_out)) out.push_back(BgzfMember{b.in_off, b.in_len, b.out_off, b.out_len});
+    return out;
+}
+
+bool inflate_member(const uint8_t *file, size_t size, const BgzfMember &m, uint8_t *out)
+{
+    if (m.out_len == 0) return true;
+    if (inflate_fast(file + m.in_off, m.in_len, size - (m.in_off + m.in_len), out, m.out_len)) return true;
+    z_stream zs{};
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef *>(file + m.in_off);
+    zs.avail_in = static_cast<uInt>(m.in_len);
+    zs.next_out = out;
+    zs.avail_out = static_cast<uInt>(m.out_len);
+    const bool ok = inflate(&zs, Z_FINISH) == Z_STREAM_END && zs.avail_out == 0;
+    inflateEnd(&zs);
+    return ok;
+}
+
 BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c)
 {
+    Trace trh("bam/header");
     std::unique_ptr<BamLoad> L(new BamLoad());
     L->c = &c;
     L->threads = threads = std::max(1, threads);
@@ -276,6 +299,7 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c)
             }
             inflateEnd(&zs);
         });
+    trh.lap("file mapped, members indexed, inflate threads started");
     // ---- header (BAM spec 4.2): magic, l_text, text, n_ref, then (l_name, name, l_ref) per reference ----
     const uint8_t *d = c.raw.data();
     auto need = [&](size_t upto) {
@@ -298,6 +322,7 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c)
         name_at.push_back(p);
         p += 8 + l;
     }
+    trh.lap("name offsets walked (behind the inflate front)");
     // names, lengths and name hashes on the threads; the index itself is filled by this thread (hashes in hand)
     const size_t nr = name_at.size();
     c.target_name.resize(nr);
@@ -318,6 +343,7 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c)
             });
         for (auto &th : pool) th.join();
     }
+    trh.lap("names, lengths, hashes (threads)");
     c.tid_names.reserve(nr + 16);
     c.tid_of_name.reserve(nr + 16);
     for (size_t i = 0; i < nr; i++) {
@@ -326,6 +352,7 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c)
         if (static_cast<size_t>(k) >= c.tid_of_name.size()) c.tid_of_name.resize(static_cast<size_t>(k) + 1);
         c.tid_of_name[static_cast<size_t>(k)] = static_cast<int32_t>(i);
     }
+    trh.lap("name index filled");
     L->first_record = p;
     L->n_ref = n_ref;
     return L.release();

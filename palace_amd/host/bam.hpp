@@ -79,6 +79,12 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &out);
 void load_bam_finish(BamLoad *load, uint64_t key_seed);
 size_t load_bam_size_hint(const BamLoad *load);          // bytes of the inflated stream (known from the BGZF member trailers)
 
+// The BGZF members of a mapped file (raw DEFLATE data and ISIZE of each; every field checked against the file) and the
+// loader's own inflate of one of them -- for tools that inflate members themselves (bin/gpuinflate).  Throw std::runtime_error.
+struct BgzfMember { uint64_t in_off, in_len, out_off, out_len; };
+std::vector<BgzfMember> bgzf_members(const uint8_t *file, size_t size, size_t *total_out);
+bool inflate_member(const uint8_t *file, size_t size, const BgzfMember &m, uint8_t *out);   // inflate_fast, then zlib; false: neither took it
+
 // Re-key every read name with another seed (collision escape hatch).
 void rekey(BamColumns &cols, uint64_t key_seed);
 
