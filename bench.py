@@ -52,6 +52,10 @@ def parse_args():
                          "before (its rows are fetched one step later): 10.4 instead of 11.1 ms per step, but the count launch then shares the "
                          "device and its own duration -- the roofline figure -- grows from 9.2 to 10.3 ms; 1 (default) = every step drains "
                          "before the next, the count launch is timed with only this step's generateGraph stream beside it")
+    ap.add_argument("--fused-probe", type=int, choices=(0, 1), default=0,
+                    help="1: Phase B's channel-0 probe rides along in the count kernel (palace_eref_attach_probe_index): the step is ~0.1 ms shorter "
+                         "(10.28 against 10.36 ms), the count launch 0.7 ms longer (9.19 against 8.46 ms) and Phase B 0.8 ms shorter; 0 (default): "
+                         "the count launch is Phase A alone, which is what `roofline` is about")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files -> files leg (CLI chain on generated files)")
     ap.add_argument("--soak-seconds", type=float, default=2.0,
@@ -699,7 +703,7 @@ def launch_ranks(args) -> int:
     return subprocess.run(cmd).returncode
 
 
-def profiled_traffic(args, world, version):
+def profiled_traffic(args, world, version, fused):
     """HBM bytes per step from the committed PMC profile (profiles/phase_a_traffic.json, written by tools/prof_full.sh +
     tools/traffic_json.py): FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, per count launch and per stage.  Only quoted for
     the workload AND the library build (palace_version(): a digest of the kernel sources) it was measured on; otherwise null.
@@ -710,6 +714,8 @@ def profiled_traffic(args, world, version):
         return None, None, {}
     if world != 1 or t.get("contigs") != args.contigs or t.get("workload", "default") != args.workload or t.get("reads", "ascii") != args.reads:
         return None, "profiles/phase_a_traffic.json is of another workload", {}
+    if bool(t.get("fused_probe", False)) != bool(fused):
+        return None, "profiles/phase_a_traffic.json was measured with" + ("out" if fused else "") + " the fused probe", {}
     if t.get("build") != version:
         return None, f"profiles/phase_a_traffic.json was measured on another build ({t.get('build')}); this is {version}", {}
     return t.get("bytes_per_launch"), t.get("source"), {k: v.get("bytes") for k, v in (t.get("stages") or {}).items()}
@@ -927,9 +933,9 @@ def measure(args, E, leg):
     probe_index = ctypes.c_void_p()
     capi._check(L.palace_eref_probe_index_build(ctx.h, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
                                                 sample["ref_total"], ctypes.byref(probe_index)), "probe index")
-    # the count launch of a step is its final count (below): channel 0 of Phase B rides along in the count kernel while each fine
-    # bucket's ">= 3" slice is in LDS (palace_eref_attach_probe_index); PALACE_BENCH_FUSED_PROBE=0: the probe kernel does it (A/B runs)
-    fused_probe = depth == 1 and os.environ.get("PALACE_BENCH_FUSED_PROBE", "1") == "1"
+    # the count launch of a step is its final count (below): with --fused-probe 1 (or PALACE_BENCH_FUSED_PROBE=1) channel 0 of Phase B
+    # rides along in the count kernel while each fine bucket's ">= 3" slice is in LDS (palace_eref_attach_probe_index)
+    fused_probe = depth == 1 and os.environ.get("PALACE_BENCH_FUSED_PROBE", str(args.fused_probe)) == "1"
     if fused_probe:
         capi._check(L.palace_eref_attach_probe_index(ctx.h, probe_index), "attach probe index")
 
@@ -1062,10 +1068,15 @@ def measure(args, E, leg):
             # 1 ms per step, measured.  Holding the rounds back until the counting kernels are done (PALACE_BENCH_STAGE04_LATE=1:
             # palace_stage04_match_after) leaves those undisturbed but puts the rounds on the critical path -- 14.8 against 12.8 ms.
             late = os.environ.get("PALACE_BENCH_STAGE04_LATE", "0") if not exch and not skip_eref else "0"
-            stage04.filter(P(e_buf), P(n_edges_dev), max(1, n_cands))
+            # (diagnosis only, timed steps only -- the line then fails its own checks on purpose: PALACE_BENCH_DIAG_SKIP=stage04|match
+            # leaves stage 04 / its matching rounds out, to see what they cost the counting kernels beside them)
+            diag_skip = os.environ.get("PALACE_BENCH_DIAG_SKIP") if timed else None
+            if diag_skip != "stage04":
+                stage04.filter(P(e_buf), P(n_edges_dev), max(1, n_cands))
             # ("1": the rounds wait for the whole count launch; "l2": for its partition kernels -- they then run beside the count
             # kernel and Phase B only)
-            stage04.match(P(e_buf), P(cn_dev), 10, False, True, after=(ctx, 4095) if late == "1" else (ctx, 4091) if late == "l2" else None)
+            if diag_skip is None:
+                stage04.match(P(e_buf), P(cn_dev), 10, False, True, after=(ctx, 4095) if late == "1" else (ctx, 4091) if late == "l2" else None)
         if timed: ctx_s.mark(m + 3)
         th1 = time.perf_counter()
         if timed:
@@ -1076,6 +1087,9 @@ def measure(args, E, leg):
             """the end of stream B: wait for the decomposition, take the result views; on untimed steps also the bookkeeping
             (counts, result digest) that the JSON line reports"""
             if stage04 is None:
+                return
+            if timed and os.environ.get("PALACE_BENCH_DIAG_SKIP"):
+                ctx_s.sync()
                 return
             t0_ = time.perf_counter()
             res, contig_of = stage04.result()
@@ -1186,10 +1200,10 @@ def measure(args, E, leg):
     if rank == 0:
         L.palace_version.restype = ctypes.c_char_p
         version = L.palace_version().decode()
-        traffic, traffic_src, stage_traffic = profiled_traffic(args, world, version)
+        fused_now = fused_probe and final_count and not key_split
+        traffic, traffic_src, stage_traffic = profiled_traffic(args, world, version, fused_now)
         alg_bytes = (READ_LEN + 6 * (READ_LEN - 31)) * 2 * n_side        # per launch (both FASTQ sides of this rank)
         # when Phase B's channel-0 probe rides along in the count kernel, its look-ups (1 B per ref position) are work of this launch
-        fused_now = fused_probe and final_count and not key_split
         probe_bytes = sum(int(l) - 31 for l in sample["ref_lens"][r_lo:r_hi]) if fused_now else 0
         achieved = (alg_bytes + probe_bytes) / (max(count_ms, 1e-6) * 1e-3) / 1e9          # (a rank 0 that takes no reads reports 0)
         out = {

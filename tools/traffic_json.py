@@ -19,7 +19,7 @@ SETUP = ("mark_read_ends_kernel", "mark_dropped_kernel", "eref_streams_kernel")
 STAGES = {
     "phase_a": SETUP + ("eref_usable_kernel", "eref_bin1_sort_kernel", "eref_bin2_kernel", "eref_lds_count_kernel"),
     "phase_b": ("eref_probe_kernel", "eref_hits_to_bits_kernel", "eref_need_kernel", "eref_ref_kernel", "eref_window_kernel", "seq_prefix_kernel"),
-    "classify": ("graph_classify_kernel",),
+    "classify": ("graph_depth_select_kernel", "graph_classify_kernel"),
     "resolve": ("resolve_split_kernel", "resolve_pair_insert_kernel", "resolve_pair_apply_kernel", "compact_edges_kernel", "copy_number_kernel"),
     "stage04": ("st4_", "dec_", "scan_apply_kernel", "scan_partials_kernel", "scan_prefix_kernel"),
 }
@@ -33,10 +33,15 @@ def kernel_of(name):
     return None
 
 
+FUSED = {"seen": False}                                     # the count kernel ran with Phase B's probe in it (its third template flag)
+
+
 def sums(path, counter):
     """kernel -> (sum over dispatches in bytes, dispatches)"""
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(path)):
+        if "eref_lds_count_kernel<true, true, true>" in r["Kernel_Name"].replace("(bool)1", "true"):
+            FUSED["seen"] = True
         if r["Counter_Name"] == counter:
             k = kernel_of(r["Kernel_Name"])
             if k:
@@ -78,7 +83,7 @@ def main():
     total = stages["phase_a"]["fetch_x2"] + stages["phase_a"]["write"]
     json.dump({"bytes_per_launch": total, "per_kernel_bytes": per_kernel, "once_at_setup": list(setup_only),
                "stages": {s: dict(v, bytes=v["fetch_x2"] + v["write"]) for s, v in stages.items()},
-               "source": tag, "contigs": contigs, "workload": workload, "reads": reads, "build": build_id(),
+               "source": tag, "contigs": contigs, "workload": workload, "reads": reads, "build": build_id(), "fused_probe": FUSED["seen"],
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of a one-step run; FETCH_SIZE x 2 + WRITE_SIZE "
                          "(KiB counters), summed over the dispatches of a stage"},
               open(out, "w"), indent=1)
