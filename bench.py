@@ -56,6 +56,13 @@ def parse_args():
                     help="1: Phase B's channel-0 probe rides along in the count kernel (palace_eref_attach_probe_index): the step is ~0.1 ms shorter "
                          "(10.28 against 10.36 ms), the count launch 0.7 ms longer (9.19 against 8.46 ms) and Phase B 0.8 ms shorter; 0 (default): "
                          "the count launch is Phase A alone, which is what `roofline` is about")
+    ap.add_argument("--graph-lag", type=int, choices=(0, 1), default=0,
+                    help="1: the graph result of a step (stage 04's decomposition) is collected at the START of the next step -- a two-deep "
+                         "pipeline of stream B, as a resident service would submit sample i+1 before it reads sample i's paths; with "
+                         "--stage04-hold l2 the matching rounds then run beside the count kernel and Phase B only and the step is stream A's "
+                         "length.  0 (default): every step collects its own result before it ends")
+    ap.add_argument("--stage04-hold", choices=("0", "l2", "1"), default="0",
+                    help="hold stage 04's matching rounds back until the count launch's partition kernels (l2) or the whole launch (1) are done")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files -> files leg (CLI chain on generated files)")
     ap.add_argument("--soak-seconds", type=float, default=2.0,
@@ -959,7 +966,7 @@ def measure(args, E, leg):
         ctx.eref_set_key_buckets(multigpu.key_buckets_of(rank, world))       # mirrored pairs of buckets: equal key mass per rank
     for e in ectx:
         e.eref_set_option("final_count", 1 if final_count else 0)
-        if os.environ.get("PALACE_BENCH_STAGE04_LATE") == "l2":
+        if os.environ.get("PALACE_BENCH_STAGE04_LATE", args.stage04_hold) == "l2":
             e.eref_set_option("mark_before_count_kernel", 4091)
     rows_l = [rows] + [torch.zeros_like(rows) for _ in range(depth - 1)]
     rows_host_l = [rows_host] + [torch.zeros((n_refs, 4), dtype=torch.int32).pin_memory() for _ in range(depth - 1)]
@@ -1016,6 +1023,8 @@ def measure(args, E, leg):
         # enqueued: classify -> resolve (edge count stays on the device) -> copy numbers -> filter_graph.py's selection ->
         # matching on the filtered graph, all in HBM.
         g = ctx_g
+        if seq.get("graph_pending"):                   # --graph-lag 1: the step before's decomposition is collected now, with this step's
+            seq.pop("graph_pending")()                 # counting kernels already enqueued (stage 04's buffers are then free for this step)
         th0 = time.perf_counter()
         if timed: g.mark(m)
         capi._check(L.palace_memset(g.h, P(consumed), 0, nt * 8), "memset")
@@ -1067,7 +1076,7 @@ def measure(args, E, leg):
             # few microseconds (kernel boundaries write back the L2 lines the partition kernels combine their stores in): about
             # 1 ms per step, measured.  Holding the rounds back until the counting kernels are done (PALACE_BENCH_STAGE04_LATE=1:
             # palace_stage04_match_after) leaves those undisturbed but puts the rounds on the critical path -- 14.8 against 12.8 ms.
-            late = os.environ.get("PALACE_BENCH_STAGE04_LATE", "0") if not exch and not skip_eref else "0"
+            late = os.environ.get("PALACE_BENCH_STAGE04_LATE", args.stage04_hold) if not exch and not skip_eref else "0"
             # (diagnosis only, timed steps only -- the line then fails its own checks on purpose: PALACE_BENCH_DIAG_SKIP=stage04|match
             # leaves stage 04 / its matching rounds out, to see what they cost the counting kernels beside them)
             diag_skip = os.environ.get("PALACE_BENCH_DIAG_SKIP") if timed else None
@@ -1118,7 +1127,10 @@ def measure(args, E, leg):
 
         if exch and not skip_eref:
             eref_tail()                                # the plane exchange / gather, Phase B and the row gather, all enqueued on stream A
-        finish_graph()
+        if args.graph_lag and not exch:
+            seq["graph_pending"] = finish_graph
+        else:
+            finish_graph()
         # ---------------- join: eref results to the host ----------------
         # the rows of THIS batch are requested; with two batches in flight the ones waited for are the previous batch's (whose
         # Phase B ran beside this batch's counting kernels), with one they are this batch's
@@ -1145,6 +1157,8 @@ def measure(args, E, leg):
             gat["width"] = max(gat["width"], (max(cnt) + max(cnt) // 8 + 256) // 256 * 256)
 
     def barrier():
+        if seq.get("graph_pending"):
+            seq.pop("graph_pending")()
         for e in ectx:
             e.sync()
         seq["pending"] = None
@@ -1215,7 +1229,7 @@ def measure(args, E, leg):
                                    f"{2 * sample['n_pairs_total']} reads x {READ_LEN} bp, {gs['n_total']} primary BAM records, "
                                    f"{gs['n_fastg']} FASTG links",
                        "stages": ["eref", "generateGraph", "matching"], "seed": SEED, "workload_kind": args.workload,
-                       "batches_in_flight": depth,
+                       "batches_in_flight": depth, "graph_lag": args.graph_lag, "stage04_hold": args.stage04_hold,
                        "reads": ("packed in HBM: two bits per base + 32-mer start mask, 0.375 B/base (palace_eref_count_reads_packed)" if packed else
                                  "ASCII in HBM, 1 B/base (palace_eref_count_reads)") + ("; count keeps only the '>= 3' plane (final_count)" if final_count else ""),
                        "parallelism": "1 GPU" if world == 1 else (f"reads/records/refs sharded over {world} GPUs (RCCL)" + ("" if rank0_counts else f"; rank 0 takes no reads: stage 04 has its device to itself, ranks 1-{world - 1} count") if shard_reads else
