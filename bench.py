@@ -1082,6 +1082,12 @@ def measure(args, E, leg):
             diag_skip = os.environ.get("PALACE_BENCH_DIAG_SKIP") if timed else None
             if diag_skip != "stage04":
                 stage04.filter(P(e_buf), P(n_edges_dev), max(1, n_cands))
+            if diag_skip and os.environ.get("PALACE_BENCH_DISTURB"):                  # "mode:ops:launches:slots:blocks"
+                dm, dops, dl, dslots, dblk = (int(x) for x in os.environ["PALACE_BENCH_DISTURB"].split(":"))
+                if "disturb_buf" not in seq:
+                    seq["disturb_buf"] = torch.full((dslots,), -1, dtype=torch.int64, device=dev)
+                    torch.cuda.synchronize()
+                capi._check(L.palace_diag_disturb(ctx_s.h, P(seq["disturb_buf"]), dslots, dops, dm, dl, dblk), "disturb")
             # ("1": the rounds wait for the whole count launch; "l2": for its partition kernels -- they then run beside the count
             # kernel and Phase B only)
             if diag_skip is None:

@@ -135,6 +135,7 @@ _SIGS = {
                                  C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(GraphParams), C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "palace_graph_fastg_offsets": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
+    "palace_diag_disturb": [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int],
     "palace_bgzf_inflate": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "palace_graph_score_border": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(GraphParams)],
     "palace_graph_resolve_ex": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(GraphParams), C.c_void_p,

@@ -160,6 +160,34 @@ int palace_ctx_destroy(palace_ctx *ctx)
     return PALACE_OK;
 }
 
+// ---- diagnosis: a stream of random memory operations of one kind, to see what they cost a kernel on another stream ----
+namespace {
+__global__ void diag_disturb_kernel(unsigned long long *buf, unsigned long long n_slots, unsigned long long n_ops, int mode, unsigned long long salt)
+{
+    unsigned long long acc = 0;
+    for (unsigned long long i = blockIdx.x * static_cast<unsigned long long>(blockDim.x) + threadIdx.x; i < n_ops; i += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
+        unsigned long long x = (i + salt) * 0x9E3779B97F4A7C15ull;
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        const unsigned long long idx = x % n_slots;
+        if (mode == 0) acc += buf[idx];                                        // gather, 8 bytes
+        else if (mode == 1) atomicMin(&buf[idx], x | (1ull << 63));            // 64-bit atomic, result unused
+        else if (mode == 2) buf[idx] = x;                                       // scattered store
+        else if (mode == 3) acc += reinterpret_cast<unsigned char *>(buf)[idx]; // gather, 1 byte
+    }
+    if (acc == 0x123456789abcdefull) buf[0] = acc;                             // (keeps the loads)
+}
+}  // namespace
+
+extern "C" int palace_diag_disturb(palace_ctx *ctx, void *d_buf, uint64_t n_slots, uint64_t n_ops, int mode, int launches, int blocks)
+{
+    PALACE_REQUIRE(ctx && d_buf && n_slots > 0 && launches > 0 && blocks > 0, "bad argument");
+    for (int l = 0; l < launches; l++)
+        hipLaunchKernelGGL(diag_disturb_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<unsigned long long *>(d_buf), n_slots, n_ops / launches, mode,
+                           static_cast<unsigned long long>(l) << 40);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
 int palace_sync(palace_ctx *ctx)
 {
     PALACE_REQUIRE(ctx, "ctx is null");
