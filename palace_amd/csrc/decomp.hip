@@ -140,6 +140,8 @@ __device__ void ph_round_begin(const DecompBufs &b, Span T, int reset_left)
     const int V = b.st->V;
     if (!reset_left && b.st->dead) return;                     // nobody kept a copy: this round is empty (the aggressive round hands out new ones)
     if (T.tid == 0) { b.st->alive_after = 0; if (reset_left) b.st->dead = 0; }
+    const int64_t E = b.st->E;
+    for (int64_t e = T.tid; e < E; e += T.n) b.done[e] = 0;    // every arc is looked at afresh in the round's first iteration
     for (int i = T.tid; i < V; i += T.n) {
         const int s = i >> 1;
         const int64_t l = reset_left ? 1 : b.left[s];          // the aggressive round: every segment gets one more copy
@@ -162,6 +164,14 @@ __device__ __forceinline__ bool arc_open(const DecompBufs &b, int u, int v)
 {
     return b.alive[u] && b.alive[v] && b.next[u] < 0 && b.prev[v] < 0;
 }
+// An arc that is closed stays closed until the round ends (vertices do not come back to life and slots are not given up inside
+// a round), so whoever sees it closed says so in `done`: from then on an iteration spends one sequential byte on it instead of
+// four random look-ups.  After the first iteration of a round most arcs are closed, and the decomposition's ~140 launches were
+// mostly such look-ups -- beside the counting kernels, which pay for every one of them.
+#define PALACE_OPEN_ARC_OR_CONTINUE(b, e, u, v)                 \
+    if ((b).done[e]) continue;                                  \
+    const int u = (b).src[e], v = (b).dst[e];                   \
+    if (!arc_open((b), u, v)) { (b).done[e] = 1; continue; }
 
 // pass 1: stamped khi into both slots; the klo halves of the OTHER parity (written one iteration ago, needed again in the
 // next one) are reset here, where nothing writes next / prev and "open" is the same for every thread that looks
@@ -173,8 +183,7 @@ __device__ void ph_propose_hi(const DecompBufs &b, Span T, const IterArgs &a)
     const int V = b.st->V;
     const int other = (a.parity ^ 1) * V;
     for (int64_t e = T.tid; e < E; e += T.n) {
-        const int u = b.src[e], v = b.dst[e];
-        if (!arc_open(b, u, v)) continue;
+        PALACE_OPEN_ARC_OR_CONTINUE(b, e, u, v)
         const uint64_t k = a.stamp | b.khi[e];
         atomicMin(reinterpret_cast<unsigned long long *>(&b.bo_hi[u]), static_cast<unsigned long long>(k));
         atomicMin(reinterpret_cast<unsigned long long *>(&b.bi_hi[v]), static_cast<unsigned long long>(k));
@@ -190,8 +199,7 @@ __device__ void ph_propose_lo(const DecompBufs &b, Span T, const IterArgs &a)
     const int64_t E = b.st->E;
     const int mine = a.parity * b.st->V;
     for (int64_t e = T.tid; e < E; e += T.n) {
-        const int u = b.src[e], v = b.dst[e];
-        if (!arc_open(b, u, v)) continue;
+        PALACE_OPEN_ARC_OR_CONTINUE(b, e, u, v)
         const uint64_t k = a.stamp | b.khi[e], lo = b.klo[e];
         if (b.bo_hi[u] == k) atomicMin(reinterpret_cast<unsigned long long *>(&b.bo_lo[mine + u]), static_cast<unsigned long long>(lo));
         if (b.bi_hi[v] == k) atomicMin(reinterpret_cast<unsigned long long *>(&b.bi_lo[mine + v]), static_cast<unsigned long long>(lo));
@@ -212,13 +220,13 @@ __device__ void ph_commit_flag(const DecompBufs &b, Span T, const IterArgs &a, v
     const int64_t E = b.st->E;
     const int mine = a.parity * b.st->V;
     for (int64_t e = T.tid; e < E; e += T.n) {
-        const int u = b.src[e], v = b.dst[e];
-        if (!arc_open(b, u, v)) continue;            // (a slot taken a moment ago by another arc of this pass reads as closed: that arc held the slot's best key, not this one)
+        PALACE_OPEN_ARC_OR_CONTINUE(b, e, u, v)      // (a slot taken a moment ago by another arc of this pass reads as closed: that arc held the slot's best key, not this one)
         const uint64_t k = a.stamp | b.khi[e], lo = b.klo[e];
         if (b.bo_hi[u] != k || b.bi_hi[v] != k) continue;
         if (!a.unique_hi && (b.bo_lo[mine + u] != lo || b.bi_lo[mine + v] != lo)) continue;
         b.next[u] = v; b.prev[v] = u;
         b.nhi[u] = b.khi[e]; b.nlo[u] = lo;
+        b.done[e] = 1;                               // (taken: both its slots are closed now)
         any = true;
     }
     if (__syncthreads_or(any) && threadIdx.x == 0) *took = 1u;         // one store per workgroup, not one per arc, to the one word
@@ -360,6 +368,7 @@ size_t carve_all(DecompBufs &b, char *base, int64_t s_cap, int64_t e_cap, int64_
     b.st = c.take<DecompState>(1);
     b.src = c.take<int32_t>(E); b.dst = c.take<int32_t>(E);
     b.khi = c.take<uint64_t>(E); b.klo = c.take<uint64_t>(E);
+    b.done = c.take<uint8_t>(E);
     b.left = c.take<int64_t>(S); b.orig = c.take<int32_t>(S);
     b.next = c.take<int32_t>(V); b.prev = c.take<int32_t>(V); b.on_path = c.take<int32_t>(V); b.open_at = c.take<int32_t>(V);
     b.nhi = c.take<uint64_t>(V); b.nlo = c.take<uint64_t>(V);

@@ -45,6 +45,7 @@ struct DecompBufs {
     // arcs [E]: tail, head (sub-graph vertex ids) and rank key -- lower (khi, klo) is better, keys are distinct
     int32_t *src = nullptr, *dst = nullptr;
     uint64_t *khi = nullptr, *klo = nullptr;
+    uint8_t *done = nullptr;                            // the arc was seen closed in this round (it stays closed until the round ends)
     // segments [S]: copies left, id of the segment in the caller's graph (vertices are reported as 2 * orig + orientation)
     int64_t *left = nullptr;
     int32_t *orig = nullptr;
