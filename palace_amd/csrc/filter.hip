@@ -253,11 +253,13 @@ __device__ __forceinline__ int32_t path_arc_find(const PathArcs &pa, int32_t u, 
 }
 
 // matching -l contigs.paths on the filtered graph: the path arcs both of whose contigs it keeps (weight 0, path-backed)
-__global__ void st4_arcs_static_kernel(F f)
+__global__ __launch_bounds__(kDecompBlock) void st4_arcs_static_kernel(F f)
 {
+    __shared__ uint32_t wave_n[kDecompBlock / 64];
+    __shared__ long long block_base;
     const PathArcs &pa = f.pa;
-    const int lane = threadIdx.x & 63;
-    for (int64_t p0 = static_cast<int64_t>(blockIdx.x) * blockDim.x; p0 < pa.n; p0 += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t p0 = static_cast<int64_t>(blockIdx.x) * blockDim.x; p0 < pa.n; p0 += static_cast<int64_t>(gridDim.x) * blockDim.x) {   // (uniform per workgroup)
         const int64_t p = p0 + threadIdx.x;
         int32_t fu = -1, fv = -1;
         if (p < pa.n) {                                            // the byte per contig first (1 MB, cache resident), the ids for the few that pass
@@ -265,22 +267,29 @@ __global__ void st4_arcs_static_kernel(F f)
             if ((f.seg_flags[cu] & 3) && (f.seg_flags[cv] & 3)) { fu = f.fid[cu]; fv = f.fid[cv]; }
         }
         const bool in = fu >= 0 && fv >= 0;
-        const unsigned long long m = __ballot(in);                 // one counter add per wave
-        int64_t base = 0;
-        if (m && lane == __builtin_ctzll(m)) base = static_cast<int64_t>(atomicAdd(reinterpret_cast<unsigned long long *>(&f.fs->n_static),
-                                                                                   static_cast<unsigned long long>(__popcll(m))));
-        base = __shfl(base, m ? __builtin_ctzll(m) : 0);
+        // one returning add on the arc counter per workgroup and round (adds on one address are a serial resource of the device)
+        const unsigned long long m = __ballot(in);
+        if (lane == 0) wave_n[wave] = static_cast<uint32_t>(__popcll(m));
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (int w = 0; w < kDecompBlock / 64; w++) { const uint32_t c = wave_n[w]; wave_n[w] = total; total += c; }
+            block_base = total ? static_cast<long long>(atomicAdd(reinterpret_cast<unsigned long long *>(&f.fs->n_static), static_cast<unsigned long long>(total))) : 0ll;
+        }
+        __syncthreads();
         if (p < pa.n) {
             int32_t at = -1;
             if (in) {
-                at = static_cast<int32_t>(base + __popcll(m & ((1ull << lane) - 1)));
-                if (at < f.arc_cap) {
+                const int64_t slot = block_base + wave_n[wave] + __popcll(m & ((1ull << lane) - 1));
+                if (slot < f.arc_cap) {
+                    at = static_cast<int32_t>(slot);
                     f.arc_u[at] = 2 * fu + (pa.u[p] & 1); f.arc_v[at] = 2 * fv + (pa.v[p] & 1);
                     f.arc_w[at] = 0; f.arc_backed[at] = 1;
-                } else { atomicOr(&f.fs->bad, kBadArcTable); at = -1; }
+                } else atomicOr(&f.fs->bad, kBadArcTable);
             }
             pa.arc_of[p] = at;
         }
+        __syncthreads();                                           // (wave_n / block_base are rewritten in the next round)
     }
 }
 
