@@ -73,9 +73,8 @@ bool parse_args(int argc, char **argv, Options &o)
 struct Arc { int32_t u, v; int64_t w; int32_t backed; uint64_t cls; };
 
 struct ConjGraph {
-    std::vector<std::string> name;
     std::vector<int64_t> copies;
-    palace_host::Names seg_of, seg_of_id;              // keys are views of the mapped graph text (kept by the job)
+    palace_host::Names seg_of, seg_of_id;              // keys are views of the mapped graph text (kept by the job); seg_of.names[s] = segment s's name
     std::vector<int32_t> id_seg;                       // seg_of_id's dense id -> segment (a later SEG with the same id wins)
     // (u << 32 | v) -> index in arcs: a flat open-addressing table (a node-based map took ~0.15 s for the 1.3 M arc look-ups of a
     // 1M-contig sample's contigs.paths)
@@ -97,17 +96,21 @@ struct ConjGraph {
     }
     std::vector<Arc> arcs;
 
-    int32_t seg(sv n)
+    static sv id_token(sv n)                           // EDGE_<id>_...: the token between the first two '_' ("" without a '_')
+    {
+        const size_t a = n.find('_');
+        if (a == sv::npos) return sv();
+        const size_t b = n.find('_', a + 1);
+        return n.substr(a + 1, b == sv::npos ? sv::npos : b - a - 1);
+    }
+    int32_t seg(sv n, uint64_t h)                      // h = hash_bytes(n)
     {
         const int before = static_cast<int>(seg_of.names.size());
-        const int32_t s = seg_of.intern(n);
+        const int32_t s = seg_of.intern_hashed(n, h);
         if (s < before) return s;
-        name.emplace_back(n);
         copies.push_back(1);
-        const size_t a = n.find('_');
-        if (a != sv::npos) {
-            const size_t b = n.find('_', a + 1);
-            const int t = seg_of_id.intern(n.substr(a + 1, b == sv::npos ? sv::npos : b - a - 1));
+        if (n.find('_') != sv::npos) {
+            const int t = seg_of_id.intern(id_token(n));
             if (static_cast<size_t>(t) >= id_seg.size()) id_seg.resize(static_cast<size_t>(t) + 1);
             id_seg[static_cast<size_t>(t)] = s;
         }
@@ -166,10 +169,10 @@ long int_prefix(sv tok)
 struct PathTok { sv id; bool minus; bool ok; };
 
 template <class F>
-void for_each_path_line(const palace_host::MappedText &txt, F f)      // f(tokens of one line)
+void for_each_path_line(const char *data, size_t size, F f)           // f(tokens of one line)
 {
     std::vector<PathTok> pl;
-    palace_host::for_each_line(txt.data, txt.size, [&](sv line) {
+    palace_host::for_each_line(data, size, [&](sv line) {
         if (!line.empty() && line.back() == '\n') line.remove_suffix(1);
         if (line.substr(0, 4) == "NODE") return;
         pl.clear();
@@ -187,7 +190,9 @@ void for_each_path_line(const palace_host::MappedText &txt, F f)      // f(token
     });
 }
 
-void apply_path(ConjGraph &g, const std::vector<PathTok> &line)
+// the arcs a path line backs in graph g (consecutive tokens the graph knows both of): f(tail, head); reads g only
+template <class F>
+void backed_by(const ConjGraph &g, const std::vector<PathTok> &line, F f)
 {
     int32_t before = -1;
     for (const PathTok &t : line) {
@@ -196,24 +201,50 @@ void apply_path(ConjGraph &g, const std::vector<PathTok> &line)
             const int32_t s = g.seg_by_id(t.id);
             if (s >= 0) here = 2 * s + (t.minus ? 1 : 0);
         }
-        if (before >= 0 && here >= 0) g.add(before, here, 0, 1);
+        if (before >= 0 && here >= 0) f(before, here);
         before = here;
     }
 }
+void apply_path(ConjGraph &g, const std::vector<PathTok> &line)
+{
+    backed_by(g, line, [&](int32_t u, int32_t v) { g.add(u, v, 0, 1); });
+}
 
+size_t host_threads(size_t bytes)
+{
+    if (const char *e = std::getenv("PALACE_HOST_THREADS")) return static_cast<size_t>(std::max(1, std::atoi(e)));
+    return bytes < (1u << 20) ? 1 : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+}
+
+// The lines of the graph text are split, hashed and their numbers read in parts on threads; segments and arcs are made from
+// them in file order by the caller's thread (a segment's number is the order of its first mention, SEG or JUNC).
 void load_graph_text(ConjGraph &g, const palace_host::MappedText &txt)
 {
-    std::vector<sv> t;
-    palace_host::for_each_line(txt.data, txt.size, [&](sv line) {
-        palace_host::split_ws(line, t);
-        if (t.size() >= 4 && t[0] == "SEG") {
-            const int32_t s = g.seg(t[1]);
-            g.copies[static_cast<size_t>(s)] = std::max<int64_t>(1, static_cast<int64_t>(num_prefix(t[3])));
-        } else if (t.size() >= 7 && t[0] == "JUNC") {
-            const int32_t a = g.seg(t[1]), b = g.seg(t[3]);
-            g.add(2 * a + (t[2] == "-"), 2 * b + (t[4] == "-"), int_prefix(t[5]) + int_prefix(t[6]), 0);
-        }
+    struct Rec { sv a, b; uint64_t ha, hb; int64_t w; uint8_t junc, minus_a, minus_b; };
+    const std::vector<size_t> cut = palace_host::line_cuts(txt.data, txt.size, host_threads(txt.size));
+    std::vector<std::vector<Rec>> recs(cut.size() - 1);
+    palace_host::for_parts(cut, [&](size_t k, size_t lo, size_t hi) {
+        std::vector<sv> t;
+        palace_host::for_each_line(txt.data + lo, hi - lo, [&](sv line) {
+            palace_host::split_ws(line, t);
+            if (t.size() >= 4 && t[0] == "SEG")
+                recs[k].push_back(Rec{t[1], sv(), palace_host::hash_bytes(t[1]), 0, std::max<int64_t>(1, static_cast<int64_t>(num_prefix(t[3]))), 0, 0, 0});
+            else if (t.size() >= 7 && t[0] == "JUNC")
+                recs[k].push_back(Rec{t[1], t[3], palace_host::hash_bytes(t[1]), palace_host::hash_bytes(t[3]), int_prefix(t[5]) + int_prefix(t[6]),
+                                      1, static_cast<uint8_t>(t[2] == "-"), static_cast<uint8_t>(t[4] == "-")});
+        });
     });
+    size_t n = 0;
+    for (const auto &part : recs) n += part.size();
+    g.seg_of.reserve(n + 16);
+    g.seg_of_id.reserve(n + 16);
+    g.copies.reserve(n + 16);
+    for (const auto &part : recs)
+        for (const Rec &r : part) {
+            if (!r.junc) { g.copies[static_cast<size_t>(g.seg(r.a, r.ha))] = r.w; continue; }
+            const int32_t a = g.seg(r.a, r.ha), b = g.seg(r.b, r.hb);
+            g.add(2 * a + r.minus_a, 2 * b + r.minus_b, r.w, 0);
+        }
 }
 
 }  // namespace
@@ -260,12 +291,24 @@ int main(int argc, char **argv)
             catch (const std::exception &) { throw std::runtime_error("cannot open graph " + j.graph); }
             load_graph_text(j.g, *j.text);
         }
+        tr.lap("graph text read");
         if (!opt.paths.empty()) {
             try { paths_text = std::make_unique<palace_host::MappedText>(opt.paths); }
             catch (const std::exception &) { paths_text.reset(); }                  // (an unreadable paths file backs nothing, as before)
         }
         if (paths_text && jobs.size() == 1) {
-            for_each_path_line(*paths_text, [&](const std::vector<PathTok> &pl) { apply_path(jobs[0].g, pl); });
+            // contigs.paths of a 1M-contig assembly is ~100 MB of which a filtered graph knows a few per cent of the ids: parts
+            // of the file on threads (tokens, look-ups in the graph: read-only), the arcs they back applied in file order here
+            const std::vector<size_t> cut = palace_host::line_cuts(paths_text->data, paths_text->size, host_threads(paths_text->size));
+            std::vector<std::vector<std::pair<int32_t, int32_t>>> backed(cut.size() - 1);
+            const ConjGraph &g = jobs[0].g;
+            palace_host::for_parts(cut, [&](size_t k, size_t a, size_t b) {
+                for_each_path_line(paths_text->data + a, b - a, [&](const std::vector<PathTok> &pl) {
+                    backed_by(g, pl, [&](int32_t u, int32_t v) { backed[k].emplace_back(u, v); });
+                });
+            });
+            for (const auto &part : backed)
+                for (const auto &uv : part) jobs[0].g.add(uv.first, uv.second, 0, 1);
         } else if (paths_text) {
             // which graphs know a contig id: a path line is applied, in file order, to every graph that knows one of its ids
             palace_host::Names ids;
@@ -277,7 +320,7 @@ int main(int argc, char **argv)
                     jobs_of[static_cast<size_t>(t)].push_back(ji);
                 }
             std::vector<uint32_t> touched;
-            for_each_path_line(*paths_text, [&](const std::vector<PathTok> &pl) {
+            for_each_path_line(paths_text->data, paths_text->size, [&](const std::vector<PathTok> &pl) {
                 touched.clear();
                 for (const PathTok &t : pl) {
                     if (!t.ok) continue;
@@ -290,12 +333,12 @@ int main(int argc, char **argv)
             });
         }
     } catch (const std::exception &e) { std::cerr << "matching: " << e.what() << "\n"; hip_up.join(); return 1; }
-    tr.lap("graphs + paths read");
+    tr.lap("contigs.paths applied");
     // The union of all graphs as one conjugate graph (vertex ids offset per graph).  Components never span two graphs and
     // come out in first-vertex order, and the arc order (weight, path-backed, class key, ends) compares two arcs of one
     // graph the same way with or without the offset, so every graph gets exactly the decomposition of a run of its own.
     int64_t S_total = 0, E = 0;
-    for (Job &j : jobs) { j.v0 = static_cast<int32_t>(2 * S_total); S_total += static_cast<int64_t>(j.g.name.size()); E += static_cast<int64_t>(j.g.arcs.size()); }
+    for (Job &j : jobs) { j.v0 = static_cast<int32_t>(2 * S_total); S_total += static_cast<int64_t>(j.g.seg_of.names.size()); E += static_cast<int64_t>(j.g.arcs.size()); }
     if (2 * S_total >= (1ll << 31)) { std::cerr << "matching: too many segments\n"; hip_up.join(); return 1; }
     const int32_t S = static_cast<int32_t>(S_total), V = 2 * S;
     std::vector<Arc> arcs;
@@ -343,7 +386,7 @@ int main(int argc, char **argv)
             for (int64_t i = 0; i < n; i++) {
                 const int32_t v = verts[off[c] + (first + i) % n] - j.v0;
                 if (i) s += '\t';
-                s += j.g.name[static_cast<size_t>(v >> 1)];
+                s += j.g.seg_of.names[static_cast<size_t>(v >> 1)];
                 s += (v & 1) ? '-' : '+';
             }
             s += '\n';
