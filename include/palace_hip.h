@@ -257,7 +257,9 @@ typedef struct {
 /* One piece of candidate evidence (classify output / resolve input).  kind 0 = split read,
  * 1 = cross-contig pair.  cls: 0 score is 0 (a mapq is 0), 1 score > 0, 2 decided on the host by
  * libm (exp underflow region of computeLayoutScore, :432-461).  found: a layout exists (:916-938).
- * left/right/oL/oR are already canonical (:855-861); in_fastg is the :863 lookup. */
+ * left/right/oL/oR are already canonical (:855-861); in_fastg is the :863 lookup.  sa_index: which item of
+ * the record's SA list a split candidate comes from (0 for pairs) -- with `ord` the order in which the
+ * reference meets the evidence (its --debug READS lists, :872, :1008, are in that order). */
 typedef struct {
     int64_t ord;
     uint64_t qkey;
@@ -267,7 +269,7 @@ typedef struct {
     int32_t nmL, nmR;
     int16_t mapqL, mapqR;
     uint8_t kind, cls, found, in_fastg, oL, oR, pad0, pad1;
-    int32_t pad2;
+    int32_t sa_index;
 } palace_graph_cand;
 
 /* Aggregated edge (AggStats, :300-306): counts[0..3] = supplementCount, supplementCountNoFastg,

@@ -172,7 +172,7 @@ class _OrcRecords(C.Structure):
 
 class GraphOpts(C.Structure):
     _fields_ = [("max_end", C.c_int), ("min_mapq", C.c_int), ("max_nm", C.c_int), ("enable_paired", C.c_int),
-                ("both_order", C.c_int), ("min_count", C.c_int), ("max_span_frac", C.c_double)]
+                ("both_order", C.c_int), ("min_count", C.c_int), ("max_span_frac", C.c_double), ("debug", C.c_int)]
 
 
 def graph_default_opts() -> GraphOpts:

@@ -181,7 +181,7 @@ std::set<PairKey> parse_fastg_fai(const char *path)
     return out;
 }
 
-struct Agg { int supp = 0, span = 0, supp_nf = 0, span_nf = 0; };
+struct Agg { int supp = 0, span = 0, supp_nf = 0, span_nf = 0; std::vector<std::pair<std::string, int>> reads; };   // AggStats :300-306 (supportingReads: name, flag)
 
 }  // namespace
 
@@ -202,12 +202,12 @@ struct OrcRecords {
     const uint8_t *has_sa;
 };
 
-struct OrcGraphOpts { int max_end, min_mapq, max_nm, enable_paired, both_order, min_count; double max_span_frac; };
+struct OrcGraphOpts { int max_end, min_mapq, max_nm, enable_paired, both_order, min_count; double max_span_frac; int debug; };   // debug: --debug (:44, :590)
 
 void orc_graph_default_opts(OrcGraphOpts *o)
 {
     Opts d;
-    *o = OrcGraphOpts{d.max_end, d.min_mapq, d.max_nm, d.enable_paired, d.both_order, d.min_count, d.max_span_frac};
+    *o = OrcGraphOpts{d.max_end, d.min_mapq, d.max_nm, d.enable_paired, d.both_order, d.min_count, d.max_span_frac, 0};
 }
 
 // generate_graph.cpp:644-1076.  Writes the SEG/JUNC text into out; returns its size or -1.
@@ -231,7 +231,7 @@ long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const
     static const char opchr[] = "MIDNSHP=XB";
 
     auto pass = [&](int mapq, int nm) { return mapq >= o.min_mapq && nm <= o.max_nm; };   // :246-248
-    auto add_edge = [&](std::string cL, char oL, std::string cR, char oR, bool split) {   // :855-872, :991-1008
+    auto add_edge = [&](std::string cL, char oL, std::string cR, char oR, bool split, const std::string &qname, int flag) {   // :855-872, :991-1008
         PairKey key{cL, cR, oL, oR};
         if (!o.both_order && cR < cL) {
             std::swap(cL, cR);
@@ -241,6 +241,7 @@ long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const
         Agg &a = agg[key];
         if (split) (in_fastg ? a.supp : a.supp_nf)++;
         else (in_fastg ? a.span : a.span_nf)++;
+        a.reads.emplace_back(qname, flag);                             // :872, :1008
     };
 
     for (int64_t i = 0; i < R->n; i++) {
@@ -295,7 +296,7 @@ long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const
                 int mqR = first1 ? it.mapq : mapq, nmR = first1 ? it.nm : nm;
                 bool left_is_a = cL <= cR;                                      // :802, :846
                 if (score_positive(l, mqL, nmL, left_is_a ? oL : oR, r, mqR, nmR, left_is_a ? oR : oL, o)) {
-                    add_edge(cL, oL, cR, oR, true);
+                    add_edge(cL, oL, cR, oR, true, qname, f);
                     has_supp = true;
                 }
             }
@@ -329,7 +330,7 @@ long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const
             const std::string &cL = first1 ? tname[tid] : tname[mtid], &cR = first1 ? tname[mtid] : tname[tid];
             bool left_is_a = cL <= cR;
             if (score_positive(l, mapq, nm, left_is_a ? oL : oR, r, mapq, nm, left_is_a ? oR : oL, o))   // :950-951, :990
-                add_edge(cL, oL, cR, oR, false);
+                add_edge(cL, oL, cR, oR, false, qname, f);
         }
     }
 
@@ -351,7 +352,12 @@ long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const
         int total = a.supp + a.span + a.supp_nf + a.span_nf;
         if (total == 0 || total < o.min_count) continue;
         os << "JUNC " << std::get<0>(kv.first) << " " << std::get<2>(kv.first) << " " << std::get<1>(kv.first) << " "
-           << std::get<3>(kv.first) << " " << (a.supp + a.span + a.supp_nf) << " " << a.span_nf << "\n";
+           << std::get<3>(kv.first) << " " << (a.supp + a.span + a.supp_nf) << " " << a.span_nf;
+        if (oo->debug) {                                                      // :1068-1073
+            os << " READS:";
+            for (const auto &r : a.reads) os << " " << r.first << "(" << r.second << ")";
+        }
+        os << "\n";
     }
     std::string s = os.str();
     if (s.size() > cap) return -1;

@@ -57,7 +57,7 @@ CAND_DTYPE = np.dtype([("ord", np.int64), ("qkey", np.uint64), ("left", np.int32
                        ("mtid", np.int32), ("ref_len", np.int32), ("dL", np.int32), ("dR", np.int32),
                        ("nmL", np.int32), ("nmR", np.int32), ("mapqL", np.int16), ("mapqR", np.int16),
                        ("kind", np.uint8), ("cls", np.uint8), ("found", np.uint8), ("in_fastg", np.uint8),
-                       ("oL", np.uint8), ("oR", np.uint8), ("pad0", np.uint8), ("pad1", np.uint8), ("pad2", np.int32)])
+                       ("oL", np.uint8), ("oR", np.uint8), ("pad0", np.uint8), ("pad1", np.uint8), ("sa_index", np.int32)])
 EDGE_DTYPE = np.dtype([("left", np.int32), ("right", np.int32), ("counts", np.uint32, 4), ("oL", np.uint8),
                        ("oR", np.uint8), ("pad", np.uint8, 6)])
 assert CAND_DTYPE.itemsize == 64 and EDGE_DTYPE.itemsize == 32 and SA_ITEM_DTYPE.itemsize == 32

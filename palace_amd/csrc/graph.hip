@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void graph_classify_kernel(GraphArgs a, const 
                     const Side &l = first1 ? s1 : s2, &rr = first1 ? s2 : s1;
                     const int oL = l.rev, oR = rr.rev;                               // both read forward (:524-527)
                     if (l.reg == (oL ? kStart : kEnd) && rr.reg == (oR ? kEnd : kStart)) {   // :531-535
-                        c.ord = ord; c.kind = 0; c.found = 1;
+                        c.ord = ord; c.kind = 0; c.found = 1; c.sa_index = r;
                         fill_evidence(a, l, rr, oL, oR, c);
                         has = true;
                     }

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <chrono>
 #include <memory>
 #include <cctype>
@@ -205,14 +206,19 @@ void rekey(BamColumns &c, uint64_t seed)
 }
 
 // The loader as a pipeline (the reference streams the file through htslib, generate_graph.cpp:644):
-//   inflate workers   take the BGZF members round-robin, so the inflated stream grows from the front;
+//   inflate workers   take the BGZF members one by one off the front, so the inflated stream grows from the front; helpers
+//                     (a device) take batches off the back;
 //   load_bam_begin    returns as soon as the members that hold the header are there and the header is parsed -- the caller
 //                     can start what depends on the target names only (name ranks, FASTG keys) beside the rest;
 //   load_bam_finish   walks the record boundaries behind the inflate front (that walk is serial: a record's size is its
 //                     first word), then decodes the records on all threads.
-struct BamLoad {
+struct BamLoad : BackMembers {
     std::unique_ptr<MappedFile> file;
     std::vector<Block> blocks;
+    std::vector<BgzfMember> as_members;  // the same, in the helpers' type (filled when there are helpers)
+    std::mutex claim_mu;                 // members [next_front, next_back) are nobody's yet
+    size_t next_front = 0, next_back = 0;
+    std::atomic<size_t> by_helpers{0};
     std::unique_ptr<std::atomic<uint8_t>[]> done;
     std::vector<std::thread> workers;
     std::atomic<bool> bad{false};
@@ -234,7 +240,33 @@ struct BamLoad {
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
     }
-    ~BamLoad()
+    bool claim_front(size_t *i)
+    {
+        std::lock_guard<std::mutex> g(claim_mu);
+        if (next_front >= next_back) return false;
+        *i = next_front++;
+        return true;
+    }
+    // A helper's batch comes back after its transfer and decode latency (a device: >= 12 ms for any batch size), in which the
+    // loader's threads get through some 1 000 members themselves: a third of what is left per claim, and nothing of the last 1 500
+    bool claim(size_t max, size_t *first, size_t *n) override
+    {
+        std::lock_guard<std::mutex> g(claim_mu);
+        const size_t left = next_back - next_front;
+        if (bad || left < 1500) return false;
+        *n = std::min(max, left / 3);
+        next_back -= *n;
+        *first = next_back;
+        return true;
+    }
+    const BgzfMember &member(size_t i) const override { return as_members[i]; }
+    void finished(size_t i, bool decoded) override
+    {
+        if (!decoded && !inflate_member(file->data, file->size, as_members[i], c->raw.data() + as_members[i].out_off)) bad = true;
+        if (decoded) by_helpers.fetch_add(1, std::memory_order_relaxed);
+        done[i].store(1, std::memory_order_release);
+    }
+    ~BamLoad() override
     {
         bad = true;                          // unwinding from a header / record error: the workers stop at their next member
         for (auto &t : workers) if (t.joinable()) t.join();
@@ -263,7 +295,7 @@ bool inflate_member(const uint8_t *file, size_t size, const BgzfMember &m, uint8
     return ok;
 }
 
-BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c)
+BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c, const std::vector<MemberHelper> &helpers)
 {
     Trace trh("bam/header");
     std::unique_ptr<BamLoad> L(new BamLoad());
@@ -277,13 +309,22 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c)
     L->done.reset(new std::atomic<uint8_t>[nb ? nb : 1]);
     for (size_t i = 0; i < nb; i++) L->done[i].store(0, std::memory_order_relaxed);
     BamLoad *ld = L.get();
+    L->next_back = nb;
+    if (!helpers.empty()) {
+        L->as_members.reserve(nb);
+        for (const Block &b : L->blocks) L->as_members.push_back(BgzfMember{b.in_off, b.in_len, b.out_off, b.out_len});
+        L->file_data = L->file->data;
+        L->file_size = L->file->size;
+        L->out = c.raw.data();
+        for (const MemberHelper &h : helpers) L->workers.emplace_back([ld, h] { h(*ld); });
+    }
     for (int t = 0; t < threads; t++)
-        L->workers.emplace_back([ld, t, threads, nb] {
+        L->workers.emplace_back([ld] {
             z_stream zs{};
             if (inflateInit2(&zs, -15) != Z_OK) { ld->bad = true; return; }
             uint8_t *out = ld->c->raw.data();
             const bool use_fast = std::getenv("PALACE_BAM_ZLIB") == nullptr;          // PALACE_BAM_ZLIB=1: zlib for every member (A/B, tests)
-            for (size_t i = static_cast<size_t>(t); i < nb && !ld->bad; i += static_cast<size_t>(threads)) {
+            for (size_t i = 0; !ld->bad && ld->claim_front(&i);) {
                 const Block &k = ld->blocks[i];
                 // the member decoder written for this loader first (inflate_fast.hpp); whatever it does not take, zlib decides
                 if (k.out_len && !(use_fast && inflate_fast(ld->file->data + k.in_off, k.in_len, ld->file->size - (k.in_off + k.in_len),
@@ -393,6 +434,8 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
     tr.lap("record boundaries (behind the inflate front)");
     for (auto &t : L->workers) t.join();                          // (members behind a malformed record are still inflated)
     tr.lap("inflate threads joined");
+    if (tr.on && !L->as_members.empty())
+        std::fprintf(stderr, "[bam] %zu of %zu members were inflated by helpers (device)\n", L->by_helpers.load(), L->blocks.size());
     if (L->bad) throw std::runtime_error("BGZF inflate failed");
     L->file.reset();
     const size_t n = rec_at.size();

@@ -4,6 +4,7 @@
 // (generate_graph.cpp:611-698); written against the SAM/BAM specification, not against htslib.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <string_view>
@@ -70,18 +71,38 @@ struct BamColumns {
 // 64-bit key of a read name (seeded so a collision can be escaped by re-keying).
 uint64_t name_key(const char *s, size_t n, uint64_t seed);
 
+// The BGZF members of a file: raw DEFLATE data [in_off, in_off + in_len) of the file, ISIZE = out_len bytes at out_off of the
+// inflated stream.
+struct BgzfMember { uint64_t in_off, in_len, out_off, out_len; };
+
+// A helper that inflates members somewhere else (a device: bam_device.hpp) while the loader's threads inflate from the front of
+// the file: it is handed members from the BACK, runs on a thread the loader starts for it, and returns when claim() says no.
+struct BackMembers {
+    const uint8_t *file_data = nullptr;            // the mapped file
+    size_t file_size = 0;
+    uint8_t *out = nullptr;                        // the inflated stream
+    virtual ~BackMembers() = default;
+    // members [first, first + n), 0 < n <= max, taken off the back of what nobody has claimed yet; false: what is left is for
+    // the loader's own threads (they would be done with it before a helper's batch came back)
+    virtual bool claim(size_t max, size_t *first, size_t *n) = 0;
+    virtual const BgzfMember &member(size_t i) const = 0;
+    // member i of a claimed range is in place (decoded) or was refused by the helper (then it is inflated here and now, by the
+    // loader's decoder with zlib behind it).  Every claimed member must be finished, whatever happens to the helper.
+    virtual void finished(size_t i, bool decoded) = 0;
+};
+using MemberHelper = std::function<void(BackMembers &)>;
+
 // Reads, inflates (threads) and decodes a whole BAM file.  Throws std::runtime_error.
 void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumns &out);
 // The same in two steps: begin() returns once the header (target names and lengths, the name index) is in `out`, with the
 // inflate threads still running; finish() delivers the records.  `out` must stay where it is in between.
 struct BamLoad;
-BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &out);
+BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &out, const std::vector<MemberHelper> &helpers = {});
 void load_bam_finish(BamLoad *load, uint64_t key_seed);
 size_t load_bam_size_hint(const BamLoad *load);          // bytes of the inflated stream (known from the BGZF member trailers)
 
 // The BGZF members of a mapped file (raw DEFLATE data and ISIZE of each; every field checked against the file) and the
 // loader's own inflate of one of them -- for tools that inflate members themselves (bin/gpuinflate).  Throw std::runtime_error.
-struct BgzfMember { uint64_t in_off, in_len, out_off, out_len; };
 std::vector<BgzfMember> bgzf_members(const uint8_t *file, size_t size, size_t *total_out);
 bool inflate_member(const uint8_t *file, size_t size, const BgzfMember &m, uint8_t *out);   // inflate_fast, then zlib; false: neither took it
 

@@ -1,0 +1,68 @@
+// BGZF members inflated on the device beside the loader's threads (palace_bgzf_inflate: one wavefront per
+// member).  Alone the device is slower than sixteen host threads (5.7 against 9 GB/s of output), but
+// it is idle while generateGraph reads its BAM: a helper thread takes batches of members off the BACK of the file (bam.hpp,
+// BackMembers), sends their compressed bytes up, and copies the inflated bytes straight into the loader's stream.  A member the
+// device decoder refuses goes to the loader's own decoder (zlib behind it), as a member the CPU decoder refuses does.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/palace_hip.h"
+#include "bam.hpp"
+
+namespace palace_host {
+
+// members per batch: the device holds ~1 000 of the decoder's wavefronts at a time (32 KiB of LDS each), and a batch takes the time
+// of its slowest member (~12 ms for 64 KiB) however small it is
+constexpr size_t kDeviceInflateBatch = 1024;
+
+inline MemberHelper device_inflate_helper(int device)
+{
+    return [device](BackMembers &bm) {
+        palace_ctx *ctx = nullptr;
+        if (palace_ctx_create(device, &ctx)) return;                           // no device: everything stays with the loader's threads
+        constexpr size_t B = kDeviceInflateBatch, kMember = 65536 + 64;
+        void *d_in = nullptr, *d_out = nullptr, *d_meta = nullptr;
+        // per member: in_off, out_off (int64), in_len, out_len, status (int32) -- one array each, one upload
+        const size_t meta_bytes = B * (8 + 8 + 4 + 4 + 4);
+        bool up = !palace_malloc(ctx, B * kMember + 64, &d_in) && !palace_malloc(ctx, B * kMember + 64, &d_out) && !palace_malloc(ctx, meta_bytes, &d_meta);
+        std::vector<uint8_t> meta(meta_bytes);
+        int64_t *in_off = reinterpret_cast<int64_t *>(meta.data()), *out_off = in_off + B;
+        int32_t *in_len = reinterpret_cast<int32_t *>(out_off + B), *out_len = in_len + B, *status = out_len + B;
+        uint8_t *dm = static_cast<uint8_t *>(d_meta);
+        size_t first = 0, n = 0;
+        while (up && bm.claim(B, &first, &n)) {
+            const BgzfMember &a = bm.member(first), &z = bm.member(first + n - 1);
+            const uint64_t in0 = a.in_off, in1 = z.in_off + z.in_len, out0 = a.out_off, out1 = z.out_off + z.out_len;
+            bool ok = in1 - in0 <= B * kMember && out1 - out0 <= B * kMember;
+            for (size_t k = 0; k < n; k++) {
+                const BgzfMember &m = bm.member(first + k);
+                in_off[k] = static_cast<int64_t>(m.in_off - in0); in_len[k] = static_cast<int32_t>(m.in_len);
+                out_off[k] = static_cast<int64_t>(m.out_off - out0); out_len[k] = static_cast<int32_t>(m.out_len);
+                status[k] = -1;
+            }
+            ok = ok && !palace_h2d_async(ctx, d_in, bm.file_data + in0, static_cast<size_t>(in1 - in0)) && !palace_h2d_async(ctx, d_meta, meta.data(), meta_bytes) &&
+                 !palace_bgzf_inflate(ctx, static_cast<const uint8_t *>(d_in), static_cast<int64_t>(n), reinterpret_cast<const int64_t *>(dm),
+                                      reinterpret_cast<const int32_t *>(dm + 16 * B), reinterpret_cast<const int64_t *>(dm + 8 * B),
+                                      reinterpret_cast<const int32_t *>(dm + 20 * B), static_cast<uint8_t *>(d_out), reinterpret_cast<int32_t *>(dm + 24 * B)) &&
+                 !palace_d2h_async(ctx, status, dm + 24 * B, 4 * n) && !palace_d2h(ctx, bm.out + out0, d_out, static_cast<size_t>(out1 - out0));
+            for (size_t k = 0; k < n; k++) bm.finished(first + k, ok && status[k] == 0);
+            if (!ok) break;                                                    // the device is out of the game; what is left goes to the threads
+        }
+        palace_free(ctx, d_in); palace_free(ctx, d_out); palace_free(ctx, d_meta);
+        palace_ctx_destroy(ctx);
+    };
+}
+
+// the helpers generateGraph and bamdepth start: PALACE_BAM_DEVICE=<n> helper threads (default 2: one's copies overlap the other's
+// kernel), 0 = the host alone
+inline std::vector<MemberHelper> device_inflate_helpers(int device)
+{
+    int n = 2;
+    if (const char *e = std::getenv("PALACE_BAM_DEVICE")) n = std::max(0, std::min(4, std::atoi(e)));
+    return std::vector<MemberHelper>(static_cast<size_t>(n), device_inflate_helper(device));
+}
+
+}  // namespace palace_host

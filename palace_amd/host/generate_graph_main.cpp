@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "bam.hpp"
+#include "bam_device.hpp"
 #include "depth_host.hpp"
 #include "fastx.hpp"
 #include "stage04_fused.hpp"
@@ -47,7 +48,8 @@ void usage(const char *prog)            // same option surface as generate_graph
               << "  --lib <FR|RF|FF>          Library type (accepted, unused as in the reference)\n"
               << "  --min-count <int>         Minimum supporting reads (default: 5)\n"
               << "  --min-score <double>      (accepted, unused as in the reference)\n"
-              << "  --debug                   (accepted; per-read traces are not produced)\n"
+              << "  --debug                   JUNC lines carry their supporting reads (' READS: name(flag) ...'); the per-read\n"
+              << "                            traces on stderr are not produced\n"
               << "Stage 04 in this process (optional; every file of palace:566-600, none read back):\n"
               << "  --hit-seqs F --node-scores F --blast F --fasta-fai F --paths F   inputs of filter_graph.py (+ --blast-ratio, --score-threshold: 0.7)\n"
               << "  --filtered-pre F --filtered F --all-hit-segs F                  its outputs (F after uniq)\n"
@@ -178,6 +180,7 @@ int main(int argc, char **argv)
 {
     palace_graph_params prm{300, 0, 5, 1, 0, 0, 0.80};
     int min_count = 5;
+    bool debug = false;
     static struct option long_opts[] = {{"max-span-frac", required_argument, 0, 1000},
                                         {"both-order", required_argument, 0, 1001},
                                         {"lib", required_argument, 0, 1002},
@@ -211,7 +214,7 @@ int main(int argc, char **argv)
         }
         case 1003: min_count = std::max(1, std::atoi(optarg)); break;
         case 1004: break;
-        case 1005: break;
+        case 1005: debug = true; break;
         case 1100: s4o.gene_file = optarg; break;
         case 1101: s4o.score_file = optarg; break;
         case 1102: s4o.blast_file = optarg; break;
@@ -238,6 +241,10 @@ int main(int argc, char **argv)
         std::cerr << "generateGraph: stage 04 needs --hit-seqs, --node-scores, --blast, --fasta-fai and --paths\n";
         return 1;
     }
+    if (s4o.enabled() && debug) {                 // (filter_graph.py copies JUNC lines as they are: the read lists would have to travel through stage 04)
+        std::cerr << "generateGraph: --debug goes with the plain four-argument call, not with the stage-04 outputs\n";
+        return 1;
+    }
     const std::string bam_path = argv[optind], fai_path = argv[optind + 1], out_path = argv[optind + 2];
     // <avgDepth> = "auto": the depth stage (palace:538-552) is done here, on the records this run decodes anyway; the value
     // goes through the same text the driver would have passed ("%.6g" of awk, then atof)
@@ -251,7 +258,8 @@ int main(int argc, char **argv)
     uint64_t seed = 1;
     BamLoad *load = nullptr;
     try {
-        load = load_bam_begin(bam_path, threads, c);             // header parsed, the rest of the file is being inflated
+        // header parsed, the rest of the file is being inflated -- by the threads, and by the device once its runtime is up (bam_device.hpp)
+        load = load_bam_begin(bam_path, threads, c, device_inflate_helpers(0));
     } catch (const std::exception &e) {
         std::cerr << e.what() << "\n";
         return 1;
@@ -372,6 +380,7 @@ int main(int argc, char **argv)
     tr.lap("edge buffer");
     CK(palace_graph_resolve(ctx, d_cands, n_cands, n_records, &prm, d_consumed, d_edges, std::max<int64_t>(1, n_cands), &n_edges));
     tr.lap("resolve");
+    if (debug) CK(palace_d2h(ctx, cands.data(), d_cands, cands.size() * sizeof(palace_graph_cand)));   // classes are final now (the host-scored ones too)
     std::vector<uint64_t> consumed(static_cast<size_t>(nt));
     std::vector<palace_graph_edge> edges(static_cast<size_t>(n_edges));
     std::vector<int32_t> cn_dev(static_cast<size_t>(nt));
@@ -390,6 +399,52 @@ int main(int argc, char **argv)
     if (!s4o.enabled()) {
         palace_ctx_destroy(ctx);
         tr.lap("ctx destroy");
+    }
+
+    // --debug (:1068-1073): the reads behind every junction.  The counting is the device's (palace_graph_resolve); which
+    // candidates it counted is restated here from its three rules (graph.hip, resolve_*_kernel) and checked against its counts.
+    // Order: as the reference meets the evidence -- records in file order, the SA items of a record in list order.
+    std::vector<std::string> reads_of(debug ? edges.size() : 0);
+    if (debug) {
+        std::vector<char> has_split(static_cast<size_t>(n_records) + 1, 0);
+        for (const auto &k : cands)
+            if (k.kind == 0 && k.cls == 1) has_split[static_cast<size_t>(k.ord)] = 1;          // :874
+        std::unordered_map<uint64_t, int64_t> first_of;                                        // read name (exact key) -> first record with a layout (:938)
+        for (const auto &k : cands)
+            if (k.kind == 1 && k.found && !has_split[static_cast<size_t>(k.ord)]) {
+                auto at = first_of.try_emplace(k.qkey, k.ord).first;
+                at->second = std::min(at->second, k.ord);
+            }
+        std::vector<uint32_t> counted;
+        for (size_t i = 0; i < cands.size(); i++) {
+            const auto &k = cands[i];
+            if (k.kind == 0) { if (k.cls == 1) counted.push_back(static_cast<uint32_t>(i)); continue; }
+            if (has_split[static_cast<size_t>(k.ord)]) continue;                               // :887
+            const auto at = first_of.find(k.qkey);
+            if (at != first_of.end() && at->second < k.ord) continue;                          // :890-893
+            if (k.found && k.cls == 1) counted.push_back(static_cast<uint32_t>(i));
+        }
+        std::sort(counted.begin(), counted.end(), [&](uint32_t a, uint32_t b) {
+            return cands[a].ord != cands[b].ord ? cands[a].ord < cands[b].ord : cands[a].sa_index < cands[b].sa_index;
+        });
+        auto key_of = [](int32_t l, int32_t r, int oL, int oR) {
+            return (static_cast<uint64_t>(static_cast<uint32_t>(l)) << 33) | (static_cast<uint64_t>(static_cast<uint32_t>(r)) << 2) | static_cast<uint64_t>((oL ? 2 : 0) | (oR ? 1 : 0));
+        };
+        std::unordered_map<uint64_t, uint32_t> edge_at;
+        for (size_t e = 0; e < edges.size(); e++) edge_at[key_of(edges[e].left, edges[e].right, edges[e].oL, edges[e].oR)] = static_cast<uint32_t>(e);
+        std::vector<uint32_t> listed(edges.size(), 0);
+        for (uint32_t i : counted) {
+            const auto &k = cands[i];
+            const auto at = edge_at.find(key_of(k.left, k.right, k.oL, k.oR));
+            if (at == edge_at.end()) { std::cerr << "generateGraph: --debug: evidence without an edge\n"; return 1; }
+            reads_of[at->second] += " " + c.qname(k.ord) + "(" + std::to_string(c.flag[static_cast<size_t>(k.ord)]) + ")";
+            listed[at->second]++;
+        }
+        for (size_t e = 0; e < edges.size(); e++)
+            if (listed[e] != edges[e].counts[0] + edges[e].counts[1] + edges[e].counts[2] + edges[e].counts[3]) {
+                std::cerr << "generateGraph: --debug: the read lists disagree with the device's counts\n";
+                return 1;
+            }
     }
 
     // ---- text output (generate_graph.cpp:1019-1076) ----
@@ -449,8 +504,10 @@ int main(int argc, char **argv)
             const uint32_t supp = e.counts[0], supp_nf = e.counts[1], span = e.counts[2], span_nf = e.counts[3];
             const uint32_t total = supp + supp_nf + span + span_nf;
             if (total == 0 || total < static_cast<uint32_t>(min_count)) continue;   // :1056-1061
-            std::fprintf(out, "JUNC %s %c %s %c %u %u\n", c.target_name[e.left].c_str(), e.oL ? '-' : '+',
+            std::fprintf(out, "JUNC %s %c %s %c %u %u", c.target_name[e.left].c_str(), e.oL ? '-' : '+',
                          c.target_name[e.right].c_str(), e.oR ? '-' : '+', supp + span + supp_nf, span_nf);
+            if (debug) { std::fputs(" READS:", out); std::fwrite(reads_of[ei].data(), 1, reads_of[ei].size(), out); }
+            std::fputc('\n', out);
         }
         graph_ok = !(std::ferror(out) | std::fclose(out));   // a short write must not exit 0
     });

@@ -33,6 +33,10 @@ def records():
 # ctgC = 500/400 = 1.25 -> floor(2.5+.5)=3
 EXPECTED = (b"SEG ctgA 1.36 3\nSEG ctgB 0.06 0\nSEG ctgC 1.25 3\n"
             b"JUNC ctgA + ctgB + 7 0\nJUNC ctgA + ctgC + 0 5\n")
+# --debug (generate_graph.cpp:1068-1073): supportingReads in the order the evidence is met (:872, :1008), `name(flag)`, flag in decimal
+EXPECTED_DEBUG = (b"SEG ctgA 1.36 3\nSEG ctgB 0.06 0\nSEG ctgC 1.25 3\n"
+                  b"JUNC ctgA + ctgB + 7 0 READS: s0(0) s1(0) s2(0) s3(0) s4(0) t0(16) t1(16)\n"
+                  b"JUNC ctgA + ctgC + 0 5 READS: p0(97) p1(97) p2(97) p3(97) p4(97)\n")
 
 
 # ---- depth stage (palace:538-552): samtools depth | awk '{sum+=$3} END {print sum/NR}', derived by hand -------------

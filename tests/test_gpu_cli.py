@@ -102,6 +102,8 @@ def graph_cli(tmp_path, targets, fai_text, recs, avg, extra=()):
 def test_graph_hand_case(tmp_path):
     got, _ = graph_cli(tmp_path, gc.TARGETS, gc.FASTG_FAI, gc.records(), gc.AVG_DEPTH)
     assert got == gc.EXPECTED
+    got, _ = graph_cli(tmp_path, gc.TARGETS, gc.FASTG_FAI, gc.records(), gc.AVG_DEPTH, ["--debug"])
+    assert got == gc.EXPECTED_DEBUG
 
 
 @pytest.mark.parametrize("seed,n_contigs,n_events", [(1, 40, 3000), (2, 12, 2000), (3, 300, 20000)])
@@ -126,6 +128,29 @@ def test_graph_options(tmp_path, extra, opt):
     for k, v in opt.items():
         setattr(o, k, v)
     assert got == orc.graph_run(recs, targets, fai, float(f"{avg:.6g}"), o)
+
+
+@pytest.mark.parametrize("seed,extra,opt", [(1, [], {}), (3, ["--min-count", "1"], dict(min_count=1)),
+                                            (5, ["--both-order", "1", "--min-count", "2"], dict(both_order=1, min_count=2))])
+def test_graph_debug_lists_the_supporting_reads(tmp_path, seed, extra, opt):
+    """--debug (generate_graph.cpp:1068-1073): every JUNC line ends in ' READS: name(flag) ...', the evidence in the order the
+    reference meets it (records in file order, the SA items of a record in list order)."""
+    targets, fai_text, recs, avg = synth.random_graph_case(synth.rng_for(seed), 40, 6000)
+    got, fai = graph_cli(tmp_path, targets, fai_text, recs, avg, ["--debug"] + extra)
+    o = orc.graph_default_opts()
+    o.debug = 1
+    for k, v in opt.items():
+        setattr(o, k, v)
+    want = orc.graph_run(recs, targets, fai, float(f"{avg:.6g}"), o)
+    assert got == want
+    juncs = [l for l in got.split(b"\n") if l.startswith(b"JUNC")]
+    assert len(juncs) > 3 and all(b" READS: " in l for l in juncs)
+    # the list of a junction is as long as its two counters say
+    for l in juncs:
+        t = l.split(b" READS:")[0].split()
+        assert len(l.split(b" READS:")[1].split()) == int(t[5]) + int(t[6])
+    plain, _ = graph_cli(tmp_path, targets, fai_text, recs, avg, extra)
+    assert plain == b"".join(l.split(b" READS:")[0] + b"\n" for l in got.split(b"\n") if l)
 
 
 def test_graph_long_contigs_underflow_gate(tmp_path):

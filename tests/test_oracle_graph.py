@@ -19,6 +19,10 @@ def test_hand_case(tmp_path):
     assert run(gc.records(), tmp_path) == gc.EXPECTED
 
 
+def test_debug_lists_the_supporting_reads(tmp_path):
+    assert run(gc.records(), tmp_path, debug=1) == gc.EXPECTED_DEBUG
+
+
 def test_min_count_and_flags(tmp_path):
     recs = gc.records()
     out = run(recs, tmp_path, min_count=6)
