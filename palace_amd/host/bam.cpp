@@ -199,6 +199,23 @@ uint64_t name_key(const char *s, size_t n, uint64_t seed)
     return h;
 }
 
+void RawBuf::release()
+{
+    if (p) ::munmap(p, mapped);
+    p = nullptr; n = mapped = 0;
+}
+void RawBuf::alloc(size_t bytes)
+{
+    release();
+    const size_t huge = size_t{2} << 20;
+    mapped = (bytes + huge) / huge * huge;
+    void *m = ::mmap(nullptr, mapped, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) { mapped = 0; throw std::bad_alloc(); }
+    p = static_cast<uint8_t *>(m);
+    n = bytes;
+    if (!std::getenv("PALACE_BAM_SMALL_PAGES")) ::madvise(p, mapped, MADV_HUGEPAGE);      // (a hint: refused or ignored, the stream is in 4 KiB pages as before)
+}
+
 void rekey(BamColumns &c, uint64_t seed)
 {
     for (int64_t i = 0; i < c.n(); i++)
@@ -240,12 +257,18 @@ struct BamLoad : BackMembers {
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
     }
+    std::atomic<int> helpers_running{0};
+    size_t hold_at = SIZE_MAX;           // tests (PALACE_BAM_HOST_SHARE=<per cent>): the threads stop there while a helper is at work
     bool claim_front(size_t *i)
     {
-        std::lock_guard<std::mutex> g(claim_mu);
-        if (next_front >= next_back) return false;
-        *i = next_front++;
-        return true;
+        for (;;) {
+            {
+                std::lock_guard<std::mutex> g(claim_mu);
+                if (next_front >= next_back) return false;
+                if (next_front < hold_at || helpers_running.load() == 0) { *i = next_front++; return true; }
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
     }
     // A helper's batch comes back after its transfer and decode latency (a device: >= 12 ms for any batch size), in which the
     // loader's threads get through some 1 000 members themselves: a third of what is left per claim, and nothing of the last 1 500
@@ -316,7 +339,9 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c, con
         L->file_data = L->file->data;
         L->file_size = L->file->size;
         L->out = c.raw.data();
-        for (const MemberHelper &h : helpers) L->workers.emplace_back([ld, h] { h(*ld); });
+        if (const char *e = std::getenv("PALACE_BAM_HOST_SHARE")) L->hold_at = nb * static_cast<size_t>(std::max(0, std::min(100, std::atoi(e)))) / 100;
+        L->helpers_running = static_cast<int>(helpers.size());
+        for (const MemberHelper &h : helpers) L->workers.emplace_back([ld, h] { h(*ld); ld->helpers_running.fetch_sub(1); });
     }
     for (int t = 0; t < threads; t++)
         L->workers.emplace_back([ld] {
@@ -388,6 +413,7 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c, con
     c.tid_names.reserve(nr + 16);
     c.tid_of_name.reserve(nr + 16);
     for (size_t i = 0; i < nr; i++) {
+        if (i + 8 < nr) c.tid_names.prefetch(hash[i + 8]);
         const size_t at = name_at[i], l = le32(d + at);
         const int k = c.tid_names.intern_hashed(std::string_view(reinterpret_cast<const char *>(d + at + 4), l ? l - 1 : 0), hash[i]);
         if (static_cast<size_t>(k) >= c.tid_of_name.size()) c.tid_of_name.resize(static_cast<size_t>(k) + 1);

@@ -1,10 +1,13 @@
 // BGZF members inflated on the device beside the loader's threads (palace_bgzf_inflate: one wavefront per
 // member).  Alone the device is slower than sixteen host threads (5.7 against 9 GB/s of output), but
 // it is idle while generateGraph reads its BAM: a helper thread takes batches of members off the BACK of the file (bam.hpp,
-// BackMembers), sends their compressed bytes up, and copies the inflated bytes straight into the loader's stream.  A member the
+// BackMembers), sends their compressed bytes up, and copies the inflated bytes straight into the loader's stream.  An option
+// (PALACE_BAM_DEVICE), off by default: see device_inflate_helpers below for what it measured.  A member the
 // device decoder refuses goes to the loader's own decoder (zlib behind it), as a member the CPU decoder refuses does.
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <vector>
@@ -21,6 +24,8 @@ constexpr size_t kDeviceInflateBatch = 1024;
 inline MemberHelper device_inflate_helper(int device)
 {
     return [device](BackMembers &bm) {
+        using Clock = std::chrono::steady_clock;
+        const auto t_start = Clock::now();
         palace_ctx *ctx = nullptr;
         if (palace_ctx_create(device, &ctx)) return;                           // no device: everything stays with the loader's threads
         constexpr size_t B = kDeviceInflateBatch, kMember = 65536 + 64;
@@ -33,6 +38,11 @@ inline MemberHelper device_inflate_helper(int device)
         int32_t *in_len = reinterpret_cast<int32_t *>(out_off + B), *out_len = in_len + B, *status = out_len + B;
         uint8_t *dm = static_cast<uint8_t *>(d_meta);
         size_t first = 0, n = 0;
+        const bool trace = std::getenv("PALACE_TRACE") != nullptr;          // (laps need a sync per phase: traced runs only)
+        auto ms_since = [](Clock::time_point a) { return std::chrono::duration<double, std::milli>(Clock::now() - a).count(); };
+        double t_up = 0, t_kernel = 0, t_down = 0, t_ready = ms_since(t_start);
+        size_t batches = 0, members = 0;
+        (void)t_ready;
         while (up && bm.claim(B, &first, &n)) {
             const BgzfMember &a = bm.member(first), &z = bm.member(first + n - 1);
             const uint64_t in0 = a.in_off, in1 = z.in_off + z.in_len, out0 = a.out_off, out1 = z.out_off + z.out_len;
@@ -43,24 +53,34 @@ inline MemberHelper device_inflate_helper(int device)
                 out_off[k] = static_cast<int64_t>(m.out_off - out0); out_len[k] = static_cast<int32_t>(m.out_len);
                 status[k] = -1;
             }
-            ok = ok && !palace_h2d_async(ctx, d_in, bm.file_data + in0, static_cast<size_t>(in1 - in0)) && !palace_h2d_async(ctx, d_meta, meta.data(), meta_bytes) &&
-                 !palace_bgzf_inflate(ctx, static_cast<const uint8_t *>(d_in), static_cast<int64_t>(n), reinterpret_cast<const int64_t *>(dm),
+            auto t0 = Clock::now();
+            ok = ok && !palace_h2d_async(ctx, d_in, bm.file_data + in0, static_cast<size_t>(in1 - in0)) && !palace_h2d_async(ctx, d_meta, meta.data(), meta_bytes);
+            if (trace) { palace_sync(ctx); t_up += ms_since(t0); t0 = Clock::now(); }
+            ok = ok && !palace_bgzf_inflate(ctx, static_cast<const uint8_t *>(d_in), static_cast<int64_t>(n), reinterpret_cast<const int64_t *>(dm),
                                       reinterpret_cast<const int32_t *>(dm + 16 * B), reinterpret_cast<const int64_t *>(dm + 8 * B),
-                                      reinterpret_cast<const int32_t *>(dm + 20 * B), static_cast<uint8_t *>(d_out), reinterpret_cast<int32_t *>(dm + 24 * B)) &&
-                 !palace_d2h_async(ctx, status, dm + 24 * B, 4 * n) && !palace_d2h(ctx, bm.out + out0, d_out, static_cast<size_t>(out1 - out0));
+                                      reinterpret_cast<const int32_t *>(dm + 20 * B), static_cast<uint8_t *>(d_out), reinterpret_cast<int32_t *>(dm + 24 * B));
+            if (trace) { palace_sync(ctx); t_kernel += ms_since(t0); t0 = Clock::now(); }
+            ok = ok && !palace_d2h_async(ctx, status, dm + 24 * B, 4 * n) && !palace_d2h(ctx, bm.out + out0, d_out, static_cast<size_t>(out1 - out0));
+            if (trace) { t_down += ms_since(t0); batches++; members += n; }
             for (size_t k = 0; k < n; k++) bm.finished(first + k, ok && status[k] == 0);
             if (!ok) break;                                                    // the device is out of the game; what is left goes to the threads
         }
+        if (trace)
+            std::fprintf(stderr, "[bam/device] ready at %.1f ms; %zu batches, %zu members: up %.1f ms, kernel %.1f ms, down %.1f ms; left at %.1f ms\n",
+                         t_ready, batches, members, t_up, t_kernel, t_down, ms_since(t_start));
         palace_free(ctx, d_in); palace_free(ctx, d_out); palace_free(ctx, d_meta);
         palace_ctx_destroy(ctx);
     };
 }
 
-// the helpers generateGraph and bamdepth start: PALACE_BAM_DEVICE=<n> helper threads (default 2: one's copies overlap the other's
-// kernel), 0 = the host alone
+// the helpers generateGraph starts: PALACE_BAM_DEVICE=<n> helper threads (two: one's copies overlap the other's kernel).  Default 0,
+// the host alone -- measured on the 1M-contig sample's BAM (30 590 members; tools/r04z3.sh, r04z4.sh, settings alternated on one
+// box): a helper is ready 80-100 ms into the run, a batch of 1 024 members then takes ~35 ms (up 5-10, kernel 12-25, down 5-12), so
+// one or two helpers inflate 5 000-7 000 members (20 %) before the sixteen threads have met them -- and generateGraph takes the same
+// 0.76 s (fused 0.88 s) with or without: the threads that feed the device and take its output away are taken from the inflate.
 inline std::vector<MemberHelper> device_inflate_helpers(int device)
 {
-    int n = 2;
+    int n = 0;
     if (const char *e = std::getenv("PALACE_BAM_DEVICE")) n = std::max(0, std::min(4, std::atoi(e)));
     return std::vector<MemberHelper>(static_cast<size_t>(n), device_inflate_helper(device));
 }

@@ -211,7 +211,9 @@ int main(int argc, char **argv)
         tokens.reserve(n_lines + 16);
         facts.reserve(n_lines + 16);
         for (const auto &part : rows)
-            for (const Row &r : part) {
+            for (size_t i = 0; i < part.size(); i++) {
+                const Row &r = part[i];
+                if (i + 8 < part.size()) { names.prefetch(part[i + 8].h_name); tokens.prefetch(part[i + 8].h_token); }
                 const int id = grow(names.intern_hashed(r.name, r.h_name));
                 facts[static_cast<size_t>(id)].length = r.len;
                 const int t = tokens.intern_hashed(r.token, r.h_token);
@@ -284,7 +286,9 @@ int main(int argc, char **argv)
         });
         for (size_t k = 0; k < rows.size(); k++) {
             size_t next_long = 0;
-            for (const Row &r : rows[k]) {
+            for (size_t i = 0; i < rows[k].size(); i++) {
+                const Row &r = rows[k][i];
+                if (i + 8 < rows[k].size()) names.prefetch(rows[k][i + 8].h);
                 Facts &f = facts[static_cast<size_t>(grow(names.intern_hashed(r.name, r.h)))];
                 f.score_text = r.text[0] ? std::string(r.text) : long_text[k][next_long++];
                 f.has_score = true;
@@ -389,7 +393,9 @@ int main(int argc, char **argv)
         });
         std::vector<char> hit_listed;
         for (size_t k = 0; k < recs.size(); k++)
-            for (const Rec &r : recs[k]) {
+            for (size_t i = 0; i < recs[k].size(); i++) {
+                const Rec &r = recs[k][i];
+                if (i + 8 < recs[k].size() && recs[k][i + 8].ia >= 0) __builtin_prefetch(&facts[static_cast<size_t>(recs[k][i + 8].ia)]);
                 if (!r.seg) {
                     const int l = r.ia >= 0 ? r.ia : id_of(r.a), rr = r.ib >= 0 ? r.ib : id_of(r.b);
                     ends.push_back(End{r.line, l, rr});

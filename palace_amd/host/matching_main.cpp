@@ -240,7 +240,9 @@ void load_graph_text(ConjGraph &g, const palace_host::MappedText &txt)
     g.seg_of_id.reserve(n + 16);
     g.copies.reserve(n + 16);
     for (const auto &part : recs)
-        for (const Rec &r : part) {
+        for (size_t i = 0; i < part.size(); i++) {
+            const Rec &r = part[i];
+            if (i + 8 < part.size()) { g.seg_of.prefetch(part[i + 8].ha); if (part[i + 8].junc) g.seg_of.prefetch(part[i + 8].hb); }
             if (!r.junc) { g.copies[static_cast<size_t>(g.seg(r.a, r.ha))] = r.w; continue; }
             const int32_t a = g.seg(r.a, r.ha), b = g.seg(r.b, r.hb);
             g.add(2 * a + r.minus_a, 2 * b + r.minus_b, r.w, 0);
@@ -268,7 +270,7 @@ int main(int argc, char **argv)
         if (ctx_rc) ctx_err = palace_last_error();
     });
     // one job per graph: the plain command line is a batch of one
-    struct Job { std::string graph, linear, cycle; std::unique_ptr<palace_host::MappedText> text; ConjGraph g; int32_t v0 = 0; std::string lin, cyc, selfs; std::unordered_set<std::string> lin_seen, cyc_seen; };
+    struct Job { std::string graph, linear, cycle; std::unique_ptr<palace_host::MappedText> text; ConjGraph g; int32_t v0 = 0; std::string lin, cyc, selfs; std::unordered_set<sv> lin_seen, cyc_seen; };   // (the sets hold views of the lines' part texts)
     std::vector<Job> jobs;
     std::unique_ptr<palace_host::MappedText> paths_text;
     try {
@@ -377,34 +379,58 @@ int main(int argc, char **argv)
     const uint8_t *kind = palace_match_result_kind(res);
     std::vector<int32_t> v0s;
     for (const Job &j : jobs) v0s.push_back(j.v0);
-    for (int64_t c = 0; c < n_comp; c++) {
-        const int64_t n = off[c + 1] - off[c];
-        if (n == 0) continue;
-        Job &j = jobs[static_cast<size_t>(std::upper_bound(v0s.begin(), v0s.end(), verts[off[c]]) - v0s.begin() - 1)];
-        auto line_of = [&](int64_t first) {
-            std::string s;
-            for (int64_t i = 0; i < n; i++) {
-                const int32_t v = verts[off[c] + (first + i) % n] - j.v0;
-                if (i) s += '\t';
-                s += j.g.seg_of.names[static_cast<size_t>(v >> 1)];
-                s += (v & 1) ? '-' : '+';
+    auto job_of = [&](int64_t c) -> Job & { return jobs[static_cast<size_t>(std::upper_bound(v0s.begin(), v0s.end(), verts[off[c]]) - v0s.begin() - 1)]; };
+    // the lines of the components (and, with -b, of the cycles opened at their weakest arc) are written out by parts of the
+    // component range on threads; which of them are new, and where they go, is decided in component order by this thread
+    struct PartText { std::string text; std::vector<uint64_t> at; };              // at[2k], at[2k+1]: start of component k's line / its opened line
+    const size_t n_parts = std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(n_comp), host_threads(n_comp < 4096 ? 0 : size_t{1} << 20)));   // (PALACE_HOST_THREADS forces parts: tests)
+    std::vector<PartText> part(n_parts);
+    {
+        std::vector<std::thread> pool;
+        for (size_t k = 0; k < n_parts; k++)
+            pool.emplace_back([&, k] {
+                const int64_t c0 = n_comp * static_cast<int64_t>(k) / static_cast<int64_t>(n_parts), c1 = n_comp * static_cast<int64_t>(k + 1) / static_cast<int64_t>(n_parts);
+                PartText &pt = part[k];
+                pt.at.reserve(2 * static_cast<size_t>(c1 - c0) + 1);
+                pt.text.reserve(static_cast<size_t>(off[c1] - off[c0]) * 40 + 64);
+                for (int64_t c = c0; c < c1; c++) {
+                    const int64_t n = off[c + 1] - off[c];
+                    const Job &j = n ? job_of(c) : jobs[0];
+                    for (int pass = 0; pass < 2; pass++) {
+                        pt.at.push_back(pt.text.size());
+                        if (n == 0 || (pass == 1 && !(kind[c] && opt.break_cycles))) continue;
+                        const int64_t first = pass ? open_at[c] : 0;
+                        for (int64_t i = 0; i < n; i++) {
+                            const int32_t v = verts[off[c] + (first + i) % n] - j.v0;
+                            if (i) pt.text += '\t';
+                            pt.text += j.g.seg_of.names[static_cast<size_t>(v >> 1)];
+                            pt.text += (v & 1) ? '-' : '+';
+                        }
+                        pt.text += '\n';
+                    }
+                }
+                pt.at.push_back(pt.text.size());
+            });
+        for (auto &t : pool) t.join();
+    }
+    for (size_t k = 0; k < n_parts; k++) {
+        const int64_t c0 = n_comp * static_cast<int64_t>(k) / static_cast<int64_t>(n_parts), c1 = n_comp * static_cast<int64_t>(k + 1) / static_cast<int64_t>(n_parts);
+        const PartText &pt = part[k];
+        for (int64_t c = c0; c < c1; c++) {
+            const int64_t n = off[c + 1] - off[c];
+            if (n == 0) continue;
+            Job &j = job_of(c);
+            const size_t a = 2 * static_cast<size_t>(c - c0);
+            const sv s = sv(pt.text).substr(pt.at[a], pt.at[a + 1] - pt.at[a]), open = sv(pt.text).substr(pt.at[a + 1], pt.at[a + 2] - pt.at[a + 1]);
+            if (!kind[c]) {
+                if (n == 1 && iter[c] > 0) continue;               // a bare segment is reported once, in round 0
+                if (j.lin_seen.insert(s).second) j.lin += s;
+                continue;
             }
-            s += '\n';
-            return s;
-        };
-        if (!kind[c]) {
-            if (n == 1 && iter[c] > 0) continue;               // a bare segment is reported once, in round 0
-            std::string s = line_of(0);
-            if (j.lin_seen.insert(s).second) j.lin += s;
-            continue;
-        }
-        std::string s = line_of(0);
-        if (!j.cyc_seen.insert(s).second) continue;
-        if (n == 1 && opt.self_loops) j.selfs += "self\n" + s;
-        else j.cyc += "iter " + std::to_string(iter[c]) + "\n" + s;
-        if (opt.break_cycles) {                                 // also report it opened at its weakest arc
-            std::string open = line_of(open_at[c]);
-            if (j.lin_seen.insert(open).second) j.lin += open;
+            if (!j.cyc_seen.insert(s).second) continue;
+            if (n == 1 && opt.self_loops) { j.selfs += "self\n"; j.selfs += s; }
+            else { j.cyc += "iter " + std::to_string(iter[c]) + "\n"; j.cyc += s; }
+            if (opt.break_cycles && j.lin_seen.insert(open).second) j.lin += open;   // also reported opened at its weakest arc
         }
     }
     palace_match_result_free(res);

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -159,7 +160,9 @@ inline void stage04_read_side_files(const Stage04Options &o, const BamColumns &c
         tokens.reserve(n_rows + 16);
         token_tid.reserve(n_rows + 16);
         for (const auto &part : rows)
-            for (const Row &r : part) {
+            for (size_t i = 0; i < part.size(); i++) {
+                const Row &r = part[i];
+                if (i + 8 < part.size()) tokens.prefetch(part[i + 8].h_token);
                 if (r.tid >= 0) fai_len[static_cast<size_t>(r.tid)] = r.len;
                 const int t = tokens.intern_hashed(r.token, r.h_token);
                 if (static_cast<size_t>(t) >= token_tid.size()) token_tid.resize(static_cast<size_t>(t) + 1, -1);
@@ -452,7 +455,8 @@ inline int stage04_run(palace_ctx *ctx, palace_stage04 *st, const Stage04Options
     const uint8_t *kind = palace_match_result_kind(res);
     const uint64_t *bare = palace_match_result_bare(res);
     std::string lin, cyc, selfs;
-    std::unordered_set<std::string> lin_seen, cyc_seen;
+    std::unordered_set<sv> lin_seen, cyc_seen;                            // views of the ranges' buffers (and of `opened`)
+    std::deque<std::string> opened;
     auto name_of = [&](int32_t v) -> const std::string & { return c.target_name[static_cast<size_t>(contig_of[v >> 1])]; };
     auto comp_line = [&](int64_t k, int64_t first, std::string &s) {
         const int64_t n = off[k + 1] - off[k];
@@ -502,7 +506,11 @@ inline int stage04_run(palace_ctx *ctx, palace_stage04 *st, const Stage04Options
         if (!cyc_seen.emplace(s).second) continue;
         if (n == 1 && o.self_loops) { selfs += "self\n"; selfs.append(s); }
         else { cyc += "iter " + std::to_string(iter[k]) + "\n"; cyc.append(s); }
-        if (o.break_cycles) { std::string op; comp_line(k, open_at[k], op); if (lin_seen.insert(op).second) lin += op; }
+        if (o.break_cycles) {
+            opened.emplace_back();
+            comp_line(k, open_at[k], opened.back());
+            if (lin_seen.insert(sv(opened.back())).second) lin += opened.back(); else opened.pop_back();
+        }
     }
     if (!past_round0) bare_until(n_f);
     cyc += selfs;

@@ -127,6 +127,9 @@ struct Names {
             }
         return -1;
     }
+    // the slot a look-up of hash h starts at, requested ahead of time: a table of a million names is tens of megabytes, every
+    // look-up a cache miss -- loops that know their next hashes ask for the slots a few rows early
+    void prefetch(uint64_t h) const { if (!slots.empty()) __builtin_prefetch(&slots[h & mask]); }
     int find(sv s) const { return find_hashed(s, hash_bytes(s)); }
     int intern(sv s) { return intern_hashed(s, hash_bytes(s)); }
     int intern_hashed(sv s, uint64_t h)

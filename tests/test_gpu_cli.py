@@ -2,6 +2,7 @@
 same argv, same files, byte-identical outputs vs the golden reference outputs / the oracle."""
 import hashlib
 import os
+import re
 import subprocess
 import sys
 
@@ -151,6 +152,26 @@ def test_graph_debug_lists_the_supporting_reads(tmp_path, seed, extra, opt):
         assert len(l.split(b" READS:")[1].split()) == int(t[5]) + int(t[6])
     plain, _ = graph_cli(tmp_path, targets, fai_text, recs, avg, extra)
     assert plain == b"".join(l.split(b" READS:")[0] + b"\n" for l in got.split(b"\n") if l)
+
+
+def test_graph_with_members_inflated_on_the_device(tmp_path):
+    """A BAM of thousands of small BGZF members: with device helpers (bam_device.hpp; the default) part of them is inflated by
+    palace_bgzf_inflate, the output is the one of the host alone and the oracle's.  (PALACE_BAM_HOST_SHARE holds the host threads
+    back at 30 % of the file while a helper works: a file this small would be done before the HIP runtime is up.)"""
+    targets, fai_text, recs, avg = synth.random_graph_case(synth.rng_for(9), 200, 60000)
+    bam, fai = str(tmp_path / "t.bam"), str(tmp_path / "g.fastg.fai")
+    synth.write_bam(bam, targets, recs, block=1500)
+    open(fai, "w").write(fai_text)
+    outs = {}
+    for dev in ("0", "2"):
+        out = str(tmp_path / f"graph{dev}.txt")
+        p = run([os.path.join(BIN, "generateGraph"), bam, fai, out, f"{avg:.6g}"], env=dict(os.environ, PALACE_BAM_DEVICE=dev, PALACE_TRACE="1", PALACE_BAM_HOST_SHARE="30"))
+        assert p.returncode == 0, p.stderr
+        outs[dev] = open(out, "rb").read()
+        if dev == "2":
+            m = re.search(rb"(\d+) of (\d+) members were inflated by helpers", p.stderr)
+            assert m and int(m.group(2)) > 3000 and int(m.group(1)) > 0, p.stderr[-2000:]
+    assert outs["0"] == outs["2"] == orc.graph_run(recs, targets, fai, float(f"{avg:.6g}"))
 
 
 def test_graph_long_contigs_underflow_gate(tmp_path):
