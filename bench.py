@@ -838,7 +838,7 @@ def measure(args, E, leg):
     # and counts ITS 1/W of the key space, the ">= 3" plane slices are all-gathered (the partition kernels shrink to the key
     # arithmetic plus 1/W of the sorting and the bytes); "shard_reads" -- the reads are sharded and the partial count tables
     # exchanged (two planes to their owners, merge, all-gather): 0.5-0.9 GB out per rank whatever W is, but the counting itself
-    # shards, which wins once a sample is large (5M contigs on 8 GPUs: ~11 ms against ~22 ms for the key split).  The scheme is
+    # shards, which wins once a sample is large (5M contigs on 8 GPUs: ~11 ms against ~17 ms for the key split).  The scheme is
     # picked per run from the model; PALACE_BENCH_SCHEME=replicate|key_split|shard_reads forces one (rehearsals, A/B runs).
     long_mode = args.workload == "long"
     n_reads_total = 2 * (int(5e8 * (1.0 if long_mode else args.contigs / 1_000_000)) // READ_LEN)
@@ -1321,7 +1321,8 @@ def measure(args, E, leg):
         # a line whose own cross-checks failed is still printed, but the run does not pass: wrong refs, the executables on the
         # files disagreeing with the resident step (or the leg raising), results that differ from step to step
         e2e = out.get("e2e")
-        if reported != len(sample["present"]) and args.contigs >= 1_000_000 and args.refs == 5000 and os.environ.get("PALACE_BENCH_SKIP_EREF") != "1":     # (below 1M contigs the read depth leaves a few present refs short)
+        if reported != len(sample["present"]) and args.contigs >= 1_000_000 and args.refs == 5000 and os.environ.get("PALACE_BENCH_SKIP_EREF") != "1" \
+                and not os.environ.get("PALACE_OPT_KEY_SHARE"):     # (below 1M contigs the read depth leaves a few present refs short; a tuning run that counts one rank's key share is partial by design)
             failures.append(f"refs_reported {reported} != refs_present {len(sample['present'])}")
         if out["config"]["result_digest"]["identical_over_untimed_steps"] is False:
             failures.append("result digests differ between untimed steps")

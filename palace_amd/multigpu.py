@@ -48,10 +48,11 @@ def key_buckets_of(rank: int, world: int):
 # ---- which Phase-A scheme for this many reads on this many GPUs ---------------------------------------------------------
 # Constants measured on ONE MI355X with the current kernels, 1M-contig workload = 6.67 M reads x 150 bp (DESIGN.md section 6;
 # tools/kr_diag.sh, profiles/): the count launch over all keys; the count launch of a 1/W key share of ALL reads
-# (3.35 + 5.95 / W ms: the key arithmetic over every read does not shard); the passes of the table exchange (pack the low
+# (2.35 + 5.95 / W ms at the end of round 4 -- 8.28 / 5.44 / 3.80 / 3.07 ms for W = 1 / 2 / 4 / 8, tools/r04z7.sh; round 3: 3.35 + 5.95 / W --:
+# the key arithmetic over every read does not shard); the passes of the table exchange (pack the low
 # plane, fold the parts on the owner); repacking gathered plane slices.  Everything else is interconnect arithmetic:
 # xGMI is point to point, a rank reaches each peer over its own link, `link_gbs` is what one link and direction sustains.
-MODEL = dict(reads_measured=6_666_666, count_all_ms=9.1, key_fixed_ms=3.35, key_shared_ms=5.95, three_planes_factor=1.03,
+MODEL = dict(reads_measured=6_666_666, count_all_ms=8.2, key_fixed_ms=2.35, key_shared_ms=5.95, three_planes_factor=1.03,
              exchange_passes_ms=1.1, repack_ms=0.25, collective_latency_ms=0.05, link_gbs=50.0, plane_bytes=1 << 29)
 
 
@@ -81,9 +82,9 @@ def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None) -> di
 # ---- the whole step of one rank, serial terms included ------------------------------------------------
 # One-GPU stage times of the 1M-contig workload (bench.py stage_ms, round 4) and how they scale: classify and resolve with the
 # records (= reads), Phase B with the refs (a constant DB) over the ranks, stage 04 (selection + matching, on rank 0) with the
-# contigs -- 1.4 ms alone on a device, 5.4 ms beside a count launch that saturates it (500k contigs: 2.9, 5M: 27, long: 1.6).
-STEP = dict(reset_ms=0.1, phase_b_fixed_ms=0.15, phase_b_ms=1.35, classify_ms=0.88, resolve_ms=0.37, small_collective_ms=0.1,
-            stage04_alone_ms=(0.9, 0.5), stage04_beside_count_ms=(1.0, 4.4))         # (fixed, per 1M contigs)
+# contigs -- 1.4 ms alone on a device, 4.4 ms beside a count launch that saturates it (500k contigs: 2.7, 5M: 16-18, long: 1.5).
+STEP = dict(reset_ms=0.1, phase_b_fixed_ms=0.15, phase_b_ms=1.35, classify_ms=0.45, resolve_ms=0.37, small_collective_ms=0.1,
+            stage04_alone_ms=(0.9, 0.5), stage04_beside_count_ms=(1.0, 3.4))         # (fixed, per 1M contigs)
 
 
 def step_model(n_contigs: int, n_reads: int, world: int, scheme: str | None = None, rank0_counts: bool = True, link_gbs: float | None = None) -> dict:
