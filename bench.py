@@ -61,8 +61,8 @@ def parse_args():
                          "pipeline of stream B, as a resident service would submit sample i+1 before it reads sample i's paths; with "
                          "--stage04-hold l2 the matching rounds then run beside the count kernel and Phase B only and the step is stream A's "
                          "length.  0 (default): every step collects its own result before it ends")
-    ap.add_argument("--stage04-hold", choices=("0", "l2", "1"), default="0",
-                    help="hold stage 04's matching rounds back until the count launch's partition kernels (l2) or the whole launch (1) are done")
+    ap.add_argument("--stage04-hold", choices=("0", "l1", "l2", "1"), default="0",
+                    help="hold stage 04's matching rounds back until level 1 of the count launch (l1), its partition kernels (l2) or the whole launch (1) are done")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files -> files leg (CLI chain on generated files)")
     ap.add_argument("--soak-seconds", type=float, default=2.0,
@@ -968,6 +968,8 @@ def measure(args, E, leg):
         e.eref_set_option("final_count", 1 if final_count else 0)
         if os.environ.get("PALACE_BENCH_STAGE04_LATE", args.stage04_hold) == "l2":
             e.eref_set_option("mark_before_count_kernel", 4091)
+        if os.environ.get("PALACE_BENCH_STAGE04_LATE", args.stage04_hold) == "l1":
+            e.eref_set_option("mark_before_level2", 4091)
     rows_l = [rows] + [torch.zeros_like(rows) for _ in range(depth - 1)]
     rows_host_l = [rows_host] + [torch.zeros((n_refs, 4), dtype=torch.int32).pin_memory() for _ in range(depth - 1)]
     seq = {"n": 0, "pending": None, "counted": None, "last": 0, "of_timed": {}}           # running batch number; the batch whose rows are still on their way
@@ -1091,7 +1093,7 @@ def measure(args, E, leg):
             # ("1": the rounds wait for the whole count launch; "l2": for its partition kernels -- they then run beside the count
             # kernel and Phase B only)
             if diag_skip is None:
-                stage04.match(P(e_buf), P(cn_dev), 10, False, True, after=(ctx, 4095) if late == "1" else (ctx, 4091) if late == "l2" else None)
+                stage04.match(P(e_buf), P(cn_dev), 10, False, True, after=(ctx, 4095) if late == "1" else (ctx, 4091) if late in ("l1", "l2") else None)
         if timed: ctx_s.mark(m + 3)
         th1 = time.perf_counter()
         if timed:

@@ -144,7 +144,8 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
  *                 merges or lookups until it is reset (those calls fail); popcounts report 0, 0, n.  Applies to binned
  *                 counts of one slab into a clean table, otherwise the call behaves as without the option.  0: off (default).
  *   "mark_before_count_kernel" i >= 0: a binned count call records palace_mark(ctx, i) between its partition kernels and its
- *                 count kernel (another stream can hold work back until then: palace_wait_for_mark); -1: none (default). */
+ *                 count kernel (another stream can hold work back until then: palace_wait_for_mark); -1: none (default).
+ *   "mark_before_level2" i >= 0: the same between level 1 and level 2 of the call's last part; -1: none (default). */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap);
 /* The count calls that follow take in only the keys whose top 7 bits -- one of 128 buckets of the key space -- are in the set
  * (bit b of mask128 = bucket b; default all).  For N GPUs that each hold all reads (the reference's threads share one table,

@@ -78,6 +78,7 @@ struct palace_ctx {
     const struct palace_eref_probe_index *probe_ix = nullptr;
     const struct palace_eref_probe_index *c0_hits_ix = nullptr;
     int mark_before_count = -1;     // option mark_before_count_kernel
+    int mark_before_level2 = -1;    // option mark_before_level2
     int count_mode = 0;             // 0 auto, 1 direct atomics, 2 binned
     int64_t bin_cap_override = 0;
     int64_t slab_override = 0;

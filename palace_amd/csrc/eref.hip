@@ -1914,6 +1914,11 @@ static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &
                 PALACE_HIP_TRY(hipEventRecord(ev_l1[k], ctx->side));
                 PALACE_HIP_TRY(hipStreamWaitEvent(ctx->stream, ev_l1[k], 0));
             }
+            // option mark_before_level2: level 1 of the launch's last part is done
+            if (ctx->mark_before_level2 >= 0 && slab + 1 == n_slabs && p_hi == s_hi) {
+                int rc2 = palace_mark(ctx, ctx->mark_before_level2);
+                if (rc2) return rc2;
+            }
             hipLaunchKernelGGL(eref_bin2_kernel, dim3(g2.first[kL1Buckets]), dim3(kBin2Threads), 0, ctx->stream, b.cursor1[k], b.buf1[k], pl.caps1, g2, o2);
             PALACE_HIP_TRY(hipGetLastError());
             if (overlap) PALACE_HIP_TRY(hipEventRecord(ev_l2[k], ctx->stream));
@@ -2090,6 +2095,9 @@ int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value)
     } else if (!std::strcmp(name, "final_count")) {          // the count calls that follow are each the only one between a reset and Phase B
         PALACE_REQUIRE(value == 0 || value == 1, "final_count must be 0 or 1");
         ctx->want_final = value != 0;
+    } else if (!std::strcmp(name, "mark_before_level2")) {         // -1: none; i: palace_mark(ctx, i) between level 1 and level 2 of the last part
+        PALACE_REQUIRE(value >= -1 && value < 4096, "mark index out of range");
+        ctx->mark_before_level2 = static_cast<int>(value);
     } else if (!std::strcmp(name, "mark_before_count_kernel")) {   // -1: none; i: palace_mark(ctx, i) between the partition kernels and the count kernel
         PALACE_REQUIRE(value >= -1 && value < 4096, "mark index out of range");
         ctx->mark_before_count = static_cast<int>(value);
