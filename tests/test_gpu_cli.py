@@ -254,6 +254,27 @@ def test_matching_large_random(tmp_path):
     assert got[1].count(b"iter") > 0
 
 
+def test_matching_hubs_and_ties(tmp_path):
+    """segments with thousands of junctions (long arc lists at one vertex), most weights equal (the rank is then decided by the
+    second key word), every orientation: the vertex-side search of the best arc against the oracle's sort"""
+    rng = synth.rng_for(77)
+    names, lens = synth.contig_names(rng, 6000)
+    seg = "".join(f"SEG {nm} 12.5 {int(rng.integers(1, 4))} 0 0.100 0\n" for nm in names)
+    junc = []
+    for hub in (0, 1, 2):
+        for b in rng.choice(np.arange(3, 6000), size=2500, replace=False):
+            a, b = (hub, int(b)) if rng.integers(0, 2) else (int(b), hub)
+            junc.append(f"JUNC {names[a]} {'+-'[int(rng.integers(0, 2))]} {names[b]} {'+-'[int(rng.integers(0, 2))]} {int(rng.choice([7, 7, 7, 9]))} 0\n")
+    for _ in range(4000):
+        a, b = int(rng.integers(0, 6000)), int(rng.integers(0, 6000))
+        junc.append(f"JUNC {names[a]} {'+-'[int(rng.integers(0, 2))]} {names[b]} {'+-'[int(rng.integers(0, 2))]} 7 0\n")
+    side = synth.filter_side_files(rng, names, lens)
+    for flags in (["-s", "-i", "10"], ["-i", "6", "-b", "--aggressive"]):
+        got, want = match_cli(tmp_path, seg + "".join(junc), side["contigs_paths"], flags)
+        assert got == want
+    assert got[0].count(b"\n") > 1000
+
+
 def test_matching_usage():
     p = run([os.path.join(BIN, "matching"), "-g", "x"])
     assert p.returncode == 1 and b"Usage" in p.stderr
