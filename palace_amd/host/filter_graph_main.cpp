@@ -479,20 +479,25 @@ int main(int argc, char **argv)
     FILE *out = std::fopen(out_path, "wb");
     if (!out) die(std::string("cannot write ") + out_path);
     std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &a, const Piece &b) { return a.src < b.src; });
-    for (const Piece &pc : pieces) std::fwrite(seg_block.data() + pc.at, 1, pc.len, out);
-    std::vector<int> tail;
+    {
+        std::string ordered;                                  // (one write instead of one per SEG line)
+        ordered.reserve(seg_block.size());
+        for (const Piece &pc : pieces) ordered.append(seg_block, pc.at, pc.len);
+        std::fwrite(ordered.data(), 1, ordered.size(), out);
+    }
+    std::vector<sv> tail;                                     // the rescued segments' SEG lines, in the order of the graph file
     for (int m : rescued) {
         const Facts &f = facts[static_cast<size_t>(m)];
         if (f.in_already) continue;
         if (!f.has_raw) die("contigs.paths names a contig without a SEG line: " + std::string(names.names[static_cast<size_t>(m)]));
-        tail.push_back(m);
+        tail.push_back(f.raw);
     }
-    std::sort(tail.begin(), tail.end(), [&](int a, int b) { return facts[static_cast<size_t>(a)].raw.data() < facts[static_cast<size_t>(b)].raw.data(); });
-    for (int m : tail) {
-        const Facts &f = facts[static_cast<size_t>(m)];
-        const sv raw = strip(f.raw);
-        std::fwrite(raw.data(), 1, raw.size(), out);
-        std::fputs(" 0 1.0 0\n", out);
+    std::sort(tail.begin(), tail.end(), [](sv a, sv b) { return a.data() < b.data(); });
+    {
+        std::string block;
+        block.reserve(tail.size() * 64);
+        for (sv line : tail) { block.append(strip(line)); block += " 0 1.0 0\n"; }
+        std::fwrite(block.data(), 1, block.size(), out);
     }
     {
         std::unordered_set<sv> emitted;
@@ -504,11 +509,17 @@ int main(int argc, char **argv)
 
     FILE *hits = std::fopen(hit_segs_path, "wb");
     if (!hits) die(std::string("cannot write ") + hit_segs_path);
-    for (const auto &row : hit_rows) {
-        const sv name = names.names[static_cast<size_t>(row.first)];
-        std::fputs("SAMPLE\t", hits);
-        std::fwrite(name.data(), 1, name.size(), hits);
-        std::fprintf(hits, "\t%s\n", row.second.c_str());
+    {
+        std::string block;
+        block.reserve(hit_rows.size() * 56);
+        for (const auto &row : hit_rows) {
+            block += "SAMPLE\t";
+            block.append(names.names[static_cast<size_t>(row.first)]);
+            block += '\t';
+            block += row.second;
+            block += '\n';
+        }
+        std::fwrite(block.data(), 1, block.size(), hits);
     }
     if (std::fclose(hits) != 0) die(std::string("write failed: ") + hit_segs_path);
     trace.lap("outputs");

@@ -6,7 +6,11 @@
 //   hostdump fastqpack <file.fq> <threads> <part_bytes> [keep_every]   the packed form of the sequence lines (pack_fastq_part):
 //                                      one line per part "pos0 n_words n_reads", then its words of P0, P1, U (hex, one line per stream);
 //                                      keep_every = k: read r is counted iff r % k != 0
+//   hostdump fmtg <n> <seed>           format_g6 (textio.hpp) against snprintf("%g") on n values of every kind (random bits, quotients of
+//                                      integers as SEG depths are, decimals at and next to rounding ties); prints the number of differences
 //   hostdump fasta <file.fa> [threads] one line per record (ordinal, name, length, sequence); with threads: parse_fasta_mt
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -78,6 +82,33 @@ int main(int argc, char **argv)
                     if (!nw) std::fputc('\n', stdout);
                 }
             }
+        } else if (mode == "fmtg") {
+            const long n = std::atol(argv[2]);
+            uint64_t st = argc > 3 ? static_cast<uint64_t>(std::atoll(argv[3])) * 0x9E3779B97F4A7C15ull + 1 : 1;
+            auto next = [&] { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+            long bad = 0, fast = 0;
+            char a[64], b[64];
+            auto check = [&](double v) {
+                const size_t la = format_g6(v, a);
+                const int lb = std::snprintf(b, sizeof b, "%g", v);
+                if (la != static_cast<size_t>(lb) || std::memcmp(a, b, la) != 0) { if (bad++ < 20) std::printf("differs: %.17g -> '%.*s' vs '%s'\n", v, static_cast<int>(la), a, b); }
+                fast += v >= 1e-4 && v < 1e6;
+            };
+            for (long i = 0; i < n; i++) {
+                const uint64_t r = next();
+                switch (i % 6) {
+                case 0: { double v; const uint64_t bits = (r & 0x800fffffffffffffull) | (static_cast<uint64_t>(1023 - 20 + (next() % 48)) << 52); std::memcpy(&v, &bits, 8); check(v); break; }   // random mantissa, 2^-20 .. 2^27
+                case 1: check(static_cast<double>(r % 100000000) / static_cast<double>(std::max<uint64_t>(1, next() % 200000))); break;          // sum / length
+                case 2: { const int j = static_cast<int>(next() % 10); check(static_cast<double>(r % 20000000) / std::pow(10.0, j)); break; }  // decimals with up to 8 digits: ties among them
+                case 3: check(static_cast<double>((r % 2000000) * 10 + 5) / std::pow(10.0, static_cast<int>(next() % 9))); break;                // xxxxxx5: seven digits ending in 5
+                case 4: check(std::nextafter(static_cast<double>((r % 2000000) * 10 + 5) / std::pow(10.0, static_cast<int>(next() % 9)), (next() & 1) ? 1e300 : -1e300)); break;
+                default: check(static_cast<double>(r % 3000000)); break;                                                                       // integers up to and past 1e6
+                }
+            }
+            for (double v : {0.0, -0.0, 1e-4, 9.9999949e-5, 9.9999951e-5, 0.1, 0.099999949, 0.09999995, 999999.0, 999999.4, 999999.5, 999999.6, 1e6, 1e-5, 123456.5, 1.5, 2.5, 0.5, 1e5, 1e-300, 1e300})
+                check(v);
+            std::printf("%ld differences in %ld values (%ld in the fast range)\n", bad, n + 21, fast);
+            return bad ? 1 : 0;
         } else if (mode == "fasta") {
             SeqSet db;
             const std::vector<char> txt = read_file(argv[2]);

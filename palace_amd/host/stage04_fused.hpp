@@ -455,7 +455,22 @@ inline int stage04_run(palace_ctx *ctx, palace_stage04 *st, const Stage04Options
     const uint8_t *kind = palace_match_result_kind(res);
     const uint64_t *bare = palace_match_result_bare(res);
     std::string lin, cyc, selfs;
-    std::unordered_set<sv> lin_seen, cyc_seen;                            // views of the ranges' buffers (and of `opened`)
+    // lines seen so far (views of the ranges' buffers and of `opened`): flat tables fed with the hashes the formatting threads made
+    struct LineSet {
+        std::vector<uint64_t> hash;
+        std::vector<sv> line;
+        size_t mask = 0;
+        explicit LineSet(size_t n) { size_t cap = 1024; while (cap < 2 * n + 16) cap <<= 1; hash.assign(cap, 0); line.resize(cap); mask = cap - 1; }
+        void prefetch(uint64_t h) const { __builtin_prefetch(&hash[h & mask]); }
+        bool insert(sv s, uint64_t h)                                      // true: new
+        {
+            h |= 1;                                                        // (0 = empty slot)
+            size_t at = h & mask;
+            while (hash[at]) { if (hash[at] == h && line[at] == s) return false; at = (at + 1) & mask; }
+            hash[at] = h; line[at] = s;
+            return true;
+        }
+    };
     std::deque<std::string> opened;
     auto name_of = [&](int32_t v) -> const std::string & { return c.target_name[static_cast<size_t>(contig_of[v >> 1])]; };
     auto comp_line = [&](int64_t k, int64_t first, std::string &s) {
@@ -472,17 +487,28 @@ inline int stage04_run(palace_ctx *ctx, palace_stage04 *st, const Stage04Options
     const size_t n_parts = static_cast<size_t>(std::max(1, threads)) * 2;
     std::vector<std::string> text(n_parts);
     std::vector<std::vector<uint32_t>> ends(n_parts);                     // end offset of every component's line in its range's buffer
+    std::vector<std::vector<uint64_t>> hashes(n_parts);                   // ... and the line's hash
     pool_for(n_parts, threads, [&](size_t part) {
         const int64_t k0 = n_comp * static_cast<int64_t>(part) / static_cast<int64_t>(n_parts), k1 = n_comp * static_cast<int64_t>(part + 1) / static_cast<int64_t>(n_parts);
         ends[part].reserve(static_cast<size_t>(k1 - k0));
-        for (int64_t k = k0; k < k1; k++) { comp_line(k, 0, text[part]); ends[part].push_back(static_cast<uint32_t>(text[part].size())); }
+        hashes[part].reserve(static_cast<size_t>(k1 - k0));
+        for (int64_t k = k0; k < k1; k++) {
+            const size_t a0 = text[part].size();
+            comp_line(k, 0, text[part]);
+            ends[part].push_back(static_cast<uint32_t>(text[part].size()));
+            hashes[part].push_back(hash_bytes(sv(text[part]).substr(a0)));
+        }
     });
+    LineSet lin_seen(static_cast<size_t>(n_comp) * (o.break_cycles ? 2 : 1)), cyc_seen(static_cast<size_t>(n_comp));
     size_t part_of = 0;
     int64_t part_first = 0;
+    uint64_t hash_of_line = 0;                                             // hash of the line line_of() returned last
     auto line_of = [&](int64_t k) -> sv {                                  // (k ascends)
         while (k >= n_comp * static_cast<int64_t>(part_of + 1) / static_cast<int64_t>(n_parts)) { part_of++; part_first = n_comp * static_cast<int64_t>(part_of) / static_cast<int64_t>(n_parts); }
         const size_t i = static_cast<size_t>(k - part_first);
         const uint32_t a0 = i ? ends[part_of][i - 1] : 0;
+        hash_of_line = hashes[part_of][i];
+        if (i + 8 < hashes[part_of].size()) { lin_seen.prefetch(hashes[part_of][i + 8] | 1); cyc_seen.prefetch(hashes[part_of][i + 8] | 1); }
         return sv(text[part_of]).substr(a0, ends[part_of][i] - a0);
     };
     // round 0 lists the bare segments (one-vertex paths) between the components, in first-vertex order; names are distinct,
@@ -500,16 +526,16 @@ inline int stage04_run(palace_ctx *ctx, palace_stage04 *st, const Stage04Options
         const sv s = line_of(k);
         if (!kind[k]) {
             if (n == 1 && iter[k] > 0) continue;                          // a bare segment is reported once, in round 0
-            if (lin_seen.emplace(s).second) lin.append(s);
+            if (lin_seen.insert(s, hash_of_line)) lin.append(s);
             continue;
         }
-        if (!cyc_seen.emplace(s).second) continue;
+        if (!cyc_seen.insert(s, hash_of_line)) continue;
         if (n == 1 && o.self_loops) { selfs += "self\n"; selfs.append(s); }
         else { cyc += "iter " + std::to_string(iter[k]) + "\n"; cyc.append(s); }
         if (o.break_cycles) {
             opened.emplace_back();
             comp_line(k, open_at[k], opened.back());
-            if (lin_seen.insert(sv(opened.back())).second) lin += opened.back(); else opened.pop_back();
+            if (lin_seen.insert(sv(opened.back()), hash_bytes(opened.back()))) lin += opened.back(); else opened.pop_back();
         }
     }
     if (!past_round0) bare_until(n_f);

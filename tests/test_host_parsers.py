@@ -288,3 +288,12 @@ def test_bam_loads_the_same_through_own_inflate_and_zlib(tmp_path):
     a = dump("bam", bam, "4")
     p = subprocess.run([HOSTDUMP, "bam", bam, "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, PALACE_BAM_ZLIB="1"))
     assert p.returncode == 0 and p.stdout == a and a.count(b"\n") == 40 + 6000
+
+
+def test_fast_percent_g_equals_printf():
+    """format_g6 (host/textio.hpp: the SEG lines' depth, a million per graph) gives the characters of printf("%g") -- random bit
+    patterns, quotients of integers as depths are, decimals at and next to the rounding ties, the ends of its fast range"""
+    for seed in (1, 2):
+        p = subprocess.run([HOSTDUMP, "fmtg", "1500000", str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stdout[-2000:]
+        assert p.stdout.startswith(b"0 differences in 1500021 values")
