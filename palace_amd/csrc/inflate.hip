@@ -4,8 +4,11 @@
 // them.  DEFLATE decoding is serial inside a stream -- a symbol's position in the bit stream is known only when the one
 // before it is decoded -- so the parallelism is across members: every member gets a wavefront whose 64 lanes all run the SAME
 // decode (no divergence, nothing to broadcast) and split what is parallel inside a member: building the code tables,
-// copying matches, moving finished output to HBM.  The last 32 KiB of output (DEFLATE's window) live in LDS, where a match is
-// a few LDS reads and writes instead of a round trip through L2; four such wavefronts share a CU (LDS: 4 x ~36 KiB).
+// copying matches.  DEFLATE's window (the last 32 KiB of output) is the output buffer itself: a match reads the bytes it repeats
+// back from where the wave wrote them (L2), which costs a wave a round trip per match -- and leaves a wave 4 KiB of LDS (its code
+// tables) instead of 36, so that a CU holds 32 of them instead of 4.  The decode of ONE stream is a chain of dependent steps that
+// issues an instruction every ~10 cycles; with one wave per SIMD (window in LDS: the first version, 5.7 GB/s of output for a
+// whole BAM) the chip idled behind those latencies, with eight they overlap.
 //
 // Input words reach the lanes through a register window: lane l holds dword (base + l) of the member, the decode takes dword
 // j with one v_readlane, and the following 64 dwords are always already requested -- the bit reader never waits for HBM.
@@ -19,14 +22,21 @@
 
 namespace palace {
 
-constexpr int kWinBytes = 32768, kWinMask = kWinBytes - 1;
-constexpr int kLitBits = 10, kDistBits = 8, kFlush = 1024;
+constexpr int kLitBits = 10, kDistBits = 8;
 
-__device__ const uint16_t kLenBaseD[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ const uint8_t kLenExtraD[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__device__ const uint16_t kDistBaseD[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073,
-                                            4097, 6145, 8193, 12289, 16385, 24577};
-__device__ const uint8_t kDistExtraD[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+// base value and number of extra bits of a length code (257 .. 285 -> c = 0 .. 28) and of a distance code (0 .. 29), RFC 1951 3.2.5,
+// as arithmetic (a table in memory is a dependent load per symbol)
+__device__ __forceinline__ void len_code(int c, int32_t &base, int &extra)
+{
+    if (c < 8) { base = 3 + c; extra = 0; }
+    else if (c == 28) { base = 258; extra = 0; }
+    else { extra = (c >> 2) - 1; base = 3 + ((4 + (c & 3)) << extra); }
+}
+__device__ __forceinline__ void dist_code(int c, int32_t &base, int &extra)
+{
+    if (c < 4) { base = 1 + c; extra = 0; }
+    else { extra = (c >> 1) - 1; base = 1 + ((2 + (c & 1)) << extra); }
+}
 __device__ const uint8_t kPreOrderD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 enum : int32_t { kInfOk = 0, kInfBadBlock = 1, kInfBadCode = 2, kInfBadDistance = 3, kInfOverrun = 4, kInfSize = 5, kInfInput = 6 };
@@ -176,7 +186,6 @@ struct InflateArgs {
 
 __global__ __launch_bounds__(64) void bgzf_inflate_kernel(InflateArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kWinBytes];
     __shared__ uint16_t lit_primary[1 << kLitBits], lit_sorted[288], lit_count[16];
     __shared__ uint16_t dist_primary[1 << kDistBits], dist_sorted[32], dist_count[16];
     __shared__ uint16_t pre_primary[1 << 7], pre_sorted[19], pre_count[16];
@@ -198,20 +207,11 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(InflateArgs a)
     br.seek(skip * 8);
     const int64_t end_bit = (skip + static_cast<int64_t>(in_len)) * 8;     // the member's DEFLATE data ends here
     uint8_t *const out = a.out + out_off;
-    int32_t opos = 0, flushed = 0, err = kInfOk;
-    // finished output leaves for HBM in pieces of kFlush bytes (the ring keeps the last 32 KiB; a piece is flushed long before
-    // the ring wraps onto it: kFlush + 258 < 32 KiB)
-    auto flush_to = [&](int32_t upto) {                                     // bytes [flushed, upto) -> HBM, all lanes
-        if (((reinterpret_cast<uintptr_t>(out) | static_cast<uintptr_t>(flushed)) & 3u) == 0) {
-            for (int32_t p = flushed + 4 * lane; p + 4 <= upto; p += 256)
-                *reinterpret_cast<uint32_t *>(out + p) = *reinterpret_cast<const uint32_t *>(ring + (p & kWinMask));
-            const int32_t done = flushed + ((upto - flushed) & ~3);
-            for (int32_t p = done + lane; p < upto; p += 64) out[p] = ring[p & kWinMask];
-        } else {
-            for (int32_t p = flushed + lane; p < upto; p += 64) out[p] = ring[p & kWinMask];
-        }
-        flushed = upto;
-    };
+    int32_t opos = 0, err = kInfOk;
+    // what the wave wrote so far is in memory before anything reads it back (a match's source may be a literal lane 0 stored a moment
+    // ago): a release fence of the wave's stores, then loads that are served where the stores went
+    auto written = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); };
+    auto back = [&](int32_t at) { return __hip_atomic_load(out + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     bool last_block = false;
     while (!last_block && err == kInfOk) {
         br.refill();
@@ -229,13 +229,8 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(InflateArgs a)
             const int64_t data_bit = p_bit + 32;
             if (data_bit + static_cast<int64_t>(len) * 8 > end_bit || static_cast<int32_t>(len) > out_len - opos) { err = kInfOverrun; break; }
             const uint8_t *src = reinterpret_cast<const uint8_t *>(br.base) + (data_bit >> 3);
-            for (uint32_t done = 0; done < len; done += kFlush) {             // through the ring, piece by piece (later matches may reach back into it)
-                const uint32_t n = min(len - done, static_cast<uint32_t>(kFlush));
-                for (uint32_t i = lane; i < n; i += 64) ring[(opos + i) & kWinMask] = src[done + i];
-                opos += static_cast<int32_t>(n);
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                flush_to(opos);
-            }
+            for (uint32_t i = lane; i < len; i += 64) out[opos + static_cast<int32_t>(i)] = src[i];
+            opos += static_cast<int32_t>(len);
             br.seek(data_bit + static_cast<int64_t>(len) * 8);
             continue;
         }
@@ -289,34 +284,34 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(InflateArgs a)
             if (sym < 0) { err = kInfBadCode; break; }
             if (sym < 256) {
                 if (opos >= out_len) { err = kInfOverrun; break; }
-                if (lane == 0) ring[opos & kWinMask] = static_cast<uint8_t>(sym);
+                if (lane == 0) out[opos] = static_cast<uint8_t>(sym);
                 opos++;
-                if (opos - flushed >= 2 * kFlush) { __builtin_amdgcn_s_waitcnt(0xc07f); flush_to(flushed + kFlush); }
                 continue;
             }
             if (sym == 256) break;
             if (sym > 285) { err = kInfBadCode; break; }
-            const int32_t len = static_cast<int32_t>(kLenBaseD[sym - 257] + br.take(kLenExtraD[sym - 257]));
+            int32_t lbase, dbase;
+            int lextra, dextra;
+            len_code(sym - 257, lbase, lextra);
+            const int32_t len = lbase + static_cast<int32_t>(br.take(lextra));
             br.refill();
             const int ds = decode_sym(dist, br);
             if (ds < 0 || ds > 29) { err = kInfBadDistance; break; }
             br.refill();                                                       // (a distance code may have used 15 of the 33 bits)
-            const int32_t d = static_cast<int32_t>(kDistBaseD[ds] + br.take(kDistExtraD[ds]));
+            dist_code(ds, dbase, dextra);
+            const int32_t d = dbase + static_cast<int32_t>(br.take(dextra));
             if (d > opos) { err = kInfBadDistance; break; }
             if (len > out_len - opos) { err = kInfOverrun; break; }
             // the copy: sources lie below opos, destinations at and above it; an overlapping match (d < len) repeats its d bytes
-            __builtin_amdgcn_s_waitcnt(0xc07f);                                // (lane 0's literal bytes are in the ring)
+            written();
             for (int32_t i = lane; i < len; i += 64) {
                 const int32_t s = d >= len ? i : i % d;
-                ring[(opos + i) & kWinMask] = ring[(opos - d + s) & kWinMask];
+                out[opos + i] = back(opos - d + s);
             }
             opos += len;
-            if (opos - flushed >= 2 * kFlush) { __builtin_amdgcn_s_waitcnt(0xc07f); flush_to(flushed + kFlush); }
         }
     }
     if (err == kInfOk) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        flush_to(opos);
         if (opos != out_len) err = kInfSize;
         else if (br.bit_pos() > end_bit + 7) err = kInfInput;                  // the stream ran past the member's data
     }

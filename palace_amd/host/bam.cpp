@@ -270,14 +270,16 @@ struct BamLoad : BackMembers {
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
     }
-    // A helper's batch comes back after its transfer and decode latency (a device: >= 12 ms for any batch size), in which the
-    // loader's threads get through some 1 000 members themselves: a third of what is left per claim, and nothing of the last 1 500
+    // A helper's batch comes back after its transfer and decode latency (a device: ~20 ms for the slowest member of any batch, plus
+    // the copies), in which the loader's threads get through some 1 500 members themselves: nothing of the last 1 500, and of what
+    // is left two fifths per claim -- a device with two helper threads decodes ~3 x what sixteen host threads do, so it should end
+    // up with about three quarters of what both start on (0.4 + 0.4 x 0.6 now, the same of what is left when a helper returns)
     bool claim(size_t max, size_t *first, size_t *n) override
     {
         std::lock_guard<std::mutex> g(claim_mu);
         const size_t left = next_back - next_front;
         if (bad || left < 1500) return false;
-        *n = std::min(max, left / 3);
+        *n = std::min(max, left * 2 / 5);
         next_back -= *n;
         *first = next_back;
         return true;

@@ -17,9 +17,9 @@
 
 namespace palace_host {
 
-// members per batch: the device holds ~1 000 of the decoder's wavefronts at a time (32 KiB of LDS each), and a batch takes the time
-// of its slowest member (~12 ms for 64 KiB) however small it is
-constexpr size_t kDeviceInflateBatch = 1024;
+// members per batch: the device holds ~7 000 of the decoder's wavefronts at a time (28 per CU), and a batch takes the time of its
+// slowest member (~20 ms for 64 KiB) however small it is
+constexpr size_t kDeviceInflateBatch = 8192;
 
 inline MemberHelper device_inflate_helper(int device)
 {
@@ -28,7 +28,9 @@ inline MemberHelper device_inflate_helper(int device)
         const auto t_start = Clock::now();
         palace_ctx *ctx = nullptr;
         if (palace_ctx_create(device, &ctx)) return;                           // no device: everything stays with the loader's threads
-        constexpr size_t B = kDeviceInflateBatch, kMember = 65536 + 64;
+        size_t B = kDeviceInflateBatch;
+        if (const char *e = std::getenv("PALACE_BAM_DEVICE_BATCH")) B = static_cast<size_t>(std::max(64, std::min(16384, std::atoi(e))));   // (tuning runs)
+        constexpr size_t kMember = 65536 + 64;
         void *d_in = nullptr, *d_out = nullptr, *d_meta = nullptr;
         // per member: in_off, out_off (int64), in_len, out_len, status (int32) -- one array each, one upload
         const size_t meta_bytes = B * (8 + 8 + 4 + 4 + 4);
