@@ -335,7 +335,8 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c, con
     for (size_t i = 0; i < nb; i++) L->done[i].store(0, std::memory_order_relaxed);
     BamLoad *ld = L.get();
     L->next_back = nb;
-    if (!helpers.empty()) {
+    // (a helper costs a device context and its buffers: not for files the threads are done with before the HIP runtime is even up)
+    if (!helpers.empty() && (nb >= 4096 || std::getenv("PALACE_BAM_HOST_SHARE"))) {
         L->as_members.reserve(nb);
         for (const Block &b : L->blocks) L->as_members.push_back(BgzfMember{b.in_off, b.in_len, b.out_off, b.out_len});
         L->file_data = L->file->data;

@@ -1,8 +1,8 @@
 // BGZF members inflated on the device beside the loader's threads (palace_bgzf_inflate: one wavefront per
-// member).  Alone the device is slower than sixteen host threads (5.7 against 9 GB/s of output), but
-// it is idle while generateGraph reads its BAM: a helper thread takes batches of members off the BACK of the file (bam.hpp,
-// BackMembers), sends their compressed bytes up, and copies the inflated bytes straight into the loader's stream.  An option
-// (PALACE_BAM_DEVICE), off by default: see device_inflate_helpers below for what it measured.  A member the
+// member).  The device decodes a whole BAM 2.4 x as fast as sixteen host threads (21 against 8.7 GB/s of
+// output) and is idle while generateGraph reads its BAM: a helper thread takes batches of members off the BACK of the file (bam.hpp,
+// BackMembers), sends their compressed bytes up, and copies the inflated bytes straight into the loader's stream
+// (PALACE_BAM_DEVICE=0: the host alone; see device_inflate_helpers below for what it measured).  A member the
 // device decoder refuses goes to the loader's own decoder (zlib behind it), as a member the CPU decoder refuses does.
 #pragma once
 #include <algorithm>
@@ -75,14 +75,15 @@ inline MemberHelper device_inflate_helper(int device)
     };
 }
 
-// the helpers generateGraph starts: PALACE_BAM_DEVICE=<n> helper threads (two: one's copies overlap the other's kernel).  Default 0,
-// the host alone -- measured on the 1M-contig sample's BAM (30 590 members; tools/r04z3.sh, r04z4.sh, settings alternated on one
-// box): a helper is ready 80-100 ms into the run, a batch of 1 024 members then takes ~35 ms (up 5-10, kernel 12-25, down 5-12), so
-// one or two helpers inflate 5 000-7 000 members (20 %) before the sixteen threads have met them -- and generateGraph takes the same
-// 0.76 s (fused 0.88 s) with or without: the threads that feed the device and take its output away are taken from the inflate.
+// the helpers generateGraph starts: PALACE_BAM_DEVICE=<n> helper threads (default 2: one's copies overlap the other's kernel; 0 = the
+// host alone).  Measured on the 1M-contig sample's BAM (30 590 members; tools/r04ze.sh, settings alternated on one box): a helper is
+// ready 80-100 ms into the run and takes one batch of 3 500-8 000 members (up 25-50 ms, kernel 40-65, down 35-70: the copies through
+// pageable memory are the larger part), 11 000 members (38 %) are the device's by the time the sixteen threads have met them from the
+// front; generateGraph 0.73 -> 0.68 s, with stage 04 in the process 0.86 -> 0.81 s.  (With the first version of the kernel -- window in
+// LDS, four waves per CU, 350 ms for the file -- the helpers got 20 % of the members and the wall time did not move.)
 inline std::vector<MemberHelper> device_inflate_helpers(int device)
 {
-    int n = 0;
+    int n = 2;
     if (const char *e = std::getenv("PALACE_BAM_DEVICE")) n = std::max(0, std::min(4, std::atoi(e)));
     return std::vector<MemberHelper>(static_cast<size_t>(n), device_inflate_helper(device));
 }
