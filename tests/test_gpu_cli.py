@@ -174,6 +174,34 @@ def test_graph_with_members_inflated_on_the_device(tmp_path):
     assert outs["0"] == outs["2"] == orc.graph_run(recs, targets, fai, float(f"{avg:.6g}"))
 
 
+def test_graph_damaged_member_fails_the_same_with_and_without_the_device(tmp_path):
+    """a BGZF member near the end of the file whose DEFLATE data are damaged: the device decoder refuses it (or the host's does), zlib
+    then refuses it too, and generateGraph fails with the loader's message either way -- never a graph from garbage"""
+    import struct
+    targets, fai_text, recs, avg = synth.random_graph_case(synth.rng_for(10), 100, 30000)
+    bam, fai = str(tmp_path / "t.bam"), str(tmp_path / "g.fastg.fai")
+    synth.write_bam(bam, targets, recs, block=1500)
+    open(fai, "w").write(fai_text)
+    raw = bytearray(open(bam, "rb").read())
+    starts, p = [], 0
+    while p < len(raw):
+        starts.append(p)
+        p += struct.unpack_from("<H", raw, p + 16)[0] + 1
+    assert len(starts) > 3000
+    m = starts[-40]                                             # (the last member is the empty EOF marker)
+    size = struct.unpack_from("<H", raw, m + 16)[0] + 1
+    for k in range(m + 18 + 2, m + size - 8):                   # the middle of its DEFLATE payload
+        raw[k] ^= 0x5A
+    open(bam, "wb").write(bytes(raw))
+    msgs = []
+    for dev in ("0", "2"):
+        p = run([os.path.join(BIN, "generateGraph"), bam, fai, str(tmp_path / f"o{dev}.txt"), f"{avg:.6g}"],
+                env=dict(os.environ, PALACE_BAM_DEVICE=dev, PALACE_BAM_HOST_SHARE="30"))
+        assert p.returncode == 1, (dev, p.stderr[-500:])
+        msgs.append(p.stderr.strip().splitlines()[-1])
+    assert msgs[0] == msgs[1] and b"BGZF" in msgs[0]
+
+
 def test_graph_long_contigs_underflow_gate(tmp_path):
     """N50 ~ 50 kb with a >120 kb tail: '-' orientations on long contigs underflow exp() to 0."""
     targets, fai_text, recs, avg = synth.random_graph_case(synth.rng_for(21), 25, 6000, long_mode=True)
