@@ -257,6 +257,20 @@ struct BamLoad : BackMembers {
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
     }
+    // the decode of the records into columns, pipelined behind the record walk (load_bam_finish): the walker publishes how many record
+    // starts it has found, the loader's threads -- done with the inflate -- take chunks of records as they become known
+    static constexpr size_t kChunk = 32768;
+    std::vector<uint64_t> rec_at;        // reserved to the most records the stream can hold: never reallocated while it is read
+    std::atomic<size_t> n_walked{0};
+    std::atomic<bool> walk_done{false};
+    std::atomic<int> decode_go{0};       // load_bam_finish has sized the columns: the decode may start
+    std::atomic<size_t> next_chunk{0};
+    uint64_t key_seed = 1;
+    Column<int32_t> sa_cnt;
+    std::vector<std::vector<palace_sa_item>> sa_part;      // per chunk, in record order
+    std::vector<std::vector<int32_t>> ms_part;            // (tid, pos, len) triples per chunk
+    void decode_range(size_t a, size_t b, size_t part);
+    void decode_chunks();
     std::atomic<int> helpers_running{0};
     size_t hold_at = SIZE_MAX;           // tests (PALACE_BAM_HOST_SHARE=<per cent>): the threads stop there while a helper is at work
     bool claim_front(size_t *i)
@@ -344,7 +358,7 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c, con
         L->out = c.raw.data();
         if (const char *e = std::getenv("PALACE_BAM_HOST_SHARE")) L->hold_at = nb * static_cast<size_t>(std::max(0, std::min(100, std::atoi(e)))) / 100;
         L->helpers_running = static_cast<int>(helpers.size());
-        for (const MemberHelper &h : helpers) L->workers.emplace_back([ld, h] { h(*ld); ld->helpers_running.fetch_sub(1); });
+        for (const MemberHelper &h : helpers) L->workers.emplace_back([ld, h] { h(*ld); ld->helpers_running.fetch_sub(1); ld->decode_chunks(); });
     }
     for (int t = 0; t < threads; t++)
         L->workers.emplace_back([ld] {
@@ -367,6 +381,7 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c, con
                 ld->done[i].store(1, std::memory_order_release);
             }
             inflateEnd(&zs);
+            ld->decode_chunks();
         });
     trh.lap("file mapped, members indexed, inflate threads started");
     // ---- header (BAM spec 4.2): magic, l_text, text, n_ref, then (l_name, name, l_ref) per reference ----
@@ -435,52 +450,14 @@ void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumn
     load_bam_finish(load_bam_begin(path, threads, c), key_seed);
 }
 
-void load_bam_finish(BamLoad *load, uint64_t key_seed)
+// records [a, b) of the walk into the columns (every element written exactly once, by the thread that has the chunk)
+void BamLoad::decode_range(size_t a, size_t b, size_t part)
 {
-    std::unique_ptr<BamLoad> L(load);
-    BamColumns &c = *L->c;
-    Trace tr("bam");
-    const int32_t n_ref = L->n_ref;
-    int threads = L->threads;
+    BamColumns &c = *this->c;
     const uint8_t *d = c.raw.data();
-    // ---- record boundaries, behind the inflate front ----
-    std::vector<uint64_t> rec_at;
-    rec_at.reserve(c.raw.size() / 300 + 16);
-    size_t p = L->first_record, have = L->wait_for(p + 4);
-    for (;;) {
-        if (p + 4 > have) { have = L->wait_for(p + 4); if (p + 4 > have) break; }
-        const size_t bs = le32(d + p);
-        if (bs < 32) break;                                       // truncated tail: stop like a failed sam_read1
-        if (p + 4 + bs > have) { have = L->wait_for(p + 4 + bs); if (p + 4 + bs > have) break; }
-        // the variable-length fields must fit the record (htslib's bam_read1 fails on such a record, which ends the
-        // reference's `while (sam_read1(...) >= 0)` loop at generate_graph.cpp:644): name, CIGAR, packed bases, qualities
-        const uint8_t *r = d + p + 4;
-        const size_t l_name = r[8], n_cig = le16(r + 12), l_seq = le32(r + 16);
-        if (l_name < 1 || l_seq > 0x7fffffffu || 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs) break;
-        rec_at.push_back(p + 4);
-        p += 4 + bs;
-    }
-    tr.lap("record boundaries (behind the inflate front)");
-    for (auto &t : L->workers) t.join();                          // (members behind a malformed record are still inflated)
-    tr.lap("inflate threads joined");
-    if (tr.on && !L->as_members.empty())
-        std::fprintf(stderr, "[bam] %zu of %zu members were inflated by helpers (device)\n", L->by_helpers.load(), L->blocks.size());
-    if (L->bad) throw std::runtime_error("BGZF inflate failed");
-    L->file.reset();
-    const size_t n = rec_at.size();
-    // (not zero-filled: every element is written below, by the thread that owns its record)
-    for (auto *v : {&c.tid, &c.pos, &c.mtid, &c.mpos, &c.nm, &c.ref_len, &c.read_len, &c.clip_s, &c.clip_e})
-        v->resize(n);
-    c.sa_off.resize(n + 1);
-    c.sa_off[0] = 0;
-    c.flag.resize(n); c.mapq.resize(n); c.qkey.resize(n);
-    c.qname_at.resize(n); c.qname_len.resize(n);
-    threads = std::max(1, threads);
-    std::vector<std::vector<palace_sa_item>> sa_part(static_cast<size_t>(threads));
-    std::vector<std::vector<int32_t>> ms_part(static_cast<size_t>(threads));        // (tid, pos, len) triples
-    Column<int32_t> sa_cnt(n);
-    parallel_for(n, threads, [&](size_t a, size_t b, int t) {
-        static const char opchr[] = "MIDNSHP=XB??????";
+    const int32_t n_ref = this->n_ref;
+    const uint64_t key_seed = this->key_seed;
+    static const char opchr[] = "MIDNSHP=XB??????";
         for (size_t i = a; i < b; i++) {
             const uint8_t *r = d + rec_at[i];
             const uint8_t *end = r + le32(r - 4);
@@ -525,12 +502,12 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
             }
             int32_t rl = 0, ql = 0;
             OpScan sc;
-            const bool depth_counts = !(le16(r + 14) & 0x704) && tid >= 0 && tid < n_ref && static_cast<int32_t>(le32(r + 4)) >= 0;
+            const bool depth_counts = c.want_match_segments && !(le16(r + 14) & 0x704) && tid >= 0 && tid < n_ref && static_cast<int32_t>(le32(r + 4)) >= 0;
             for (size_t k = 0; k < n_ops; k++) {
                 uint32_t v = le32(ops + 4 * k);
                 int op = v & 15, len = static_cast<int>(v >> 4);
                 if (depth_counts && len > 0 && (op == 0 || op == 7 || op == 8)) {        // a match segment at pos + (ref consumed so far)
-                    auto &m = ms_part[static_cast<size_t>(t)];
+                    auto &m = ms_part[part];
                     m.push_back(tid); m.push_back(static_cast<int32_t>(le32(r + 4)) + rl); m.push_back(len);
                 }
                 if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += len;   // bam_cigar2rlen
@@ -571,7 +548,7 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
                             const char *semi = static_cast<const char *>(std::memchr(s, ';', static_cast<size_t>(se - s)));
                             const char *ie = semi ? semi : se;
                             palace_sa_item it{};
-                            if (ie > s && parse_sa(s, ie, c, tid, it)) { sa_part[t].push_back(it); sa_cnt[i]++; }
+                            if (ie > s && parse_sa(s, ie, c, tid, it)) { sa_part[part].push_back(it); sa_cnt[i]++; }
                             s = semi ? semi + 1 : se;
                         }
                     }
@@ -579,16 +556,92 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
                 x = v + sz;
             }
         }
-    });
-    tr.lap("columns decoded");
+}
+
+void BamLoad::decode_chunks()
+{
+    while (!decode_go.load(std::memory_order_acquire)) {          // (the header is being parsed, or the loader is being torn down)
+        if (bad) return;
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    for (;;) {
+        const size_t part = next_chunk.fetch_add(1), a = part * kChunk;
+        size_t have;
+        for (;;) {
+            const bool done = walk_done.load(std::memory_order_acquire);
+            have = n_walked.load(std::memory_order_acquire);
+            if (have >= a + kChunk || done) break;
+            if (bad) return;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        if (a >= have || part >= sa_part.size()) return;
+        decode_range(a, std::min(a + kChunk, have), part);
+    }
+}
+
+void load_bam_finish(BamLoad *load, uint64_t key_seed)
+{
+    std::unique_ptr<BamLoad> L(load);
+    BamColumns &c = *L->c;
+    Trace tr("bam");
+    const uint8_t *d = c.raw.data();
+    // The columns are sized for the most records the stream can hold (36 bytes each at least; the pages behind the ones that do not
+    // exist are never touched) so that the threads can decode chunks of records while the walk below is still finding the later ones.
+    const size_t ub = (c.raw.size() > L->first_record ? (c.raw.size() - L->first_record) / 36 : 0) + 16;
+    for (auto *v : {&c.tid, &c.pos, &c.mtid, &c.mpos, &c.nm, &c.ref_len, &c.read_len, &c.clip_s, &c.clip_e})
+        v->resize(ub);
+    c.flag.resize(ub); c.mapq.resize(ub); c.qkey.resize(ub);
+    c.qname_at.resize(ub); c.qname_len.resize(ub);
+    L->sa_cnt.resize(ub);
+    const size_t max_chunks = ub / BamLoad::kChunk + 1;
+    L->sa_part.resize(max_chunks);
+    L->ms_part.resize(max_chunks);
+    L->rec_at.reserve(ub);
+    L->key_seed = key_seed;
+    L->decode_go.store(1, std::memory_order_release);
+    // ---- record boundaries, behind the inflate front ----
+    std::vector<uint64_t> &rec_at = L->rec_at;
+    size_t p = L->first_record, have = L->wait_for(p + 4);
+    for (;;) {
+        if (p + 4 > have) { have = L->wait_for(p + 4); if (p + 4 > have) break; }
+        const size_t bs = le32(d + p);
+        if (bs < 32) break;                                       // truncated tail: stop like a failed sam_read1
+        if (p + 4 + bs > have) { have = L->wait_for(p + 4 + bs); if (p + 4 + bs > have) break; }
+        // the variable-length fields must fit the record (htslib's bam_read1 fails on such a record, which ends the
+        // reference's `while (sam_read1(...) >= 0)` loop at generate_graph.cpp:644): name, CIGAR, packed bases, qualities
+        const uint8_t *r = d + p + 4;
+        const size_t l_name = r[8], n_cig = le16(r + 12), l_seq = le32(r + 16);
+        if (l_name < 1 || l_seq > 0x7fffffffu || 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs) break;
+        rec_at.push_back(p + 4);
+        if ((rec_at.size() & 4095) == 0) L->n_walked.store(rec_at.size(), std::memory_order_release);
+        p += 4 + bs;
+    }
+    L->n_walked.store(rec_at.size(), std::memory_order_release);
+    L->walk_done.store(true, std::memory_order_release);
+    tr.lap("record boundaries (behind the inflate front)");
+    L->decode_chunks();                                           // this thread helps with what is left
+    for (auto &t : L->workers) t.join();                          // (members behind a malformed record are still inflated)
+    tr.lap("inflate threads joined, columns decoded");
+    if (tr.on && !L->as_members.empty())
+        std::fprintf(stderr, "[bam] %zu of %zu members were inflated by helpers (device)\n", L->by_helpers.load(), L->blocks.size());
+    if (L->bad) throw std::runtime_error("BGZF inflate failed");
+    L->file.reset();
+    const size_t n = rec_at.size();
+    for (auto *v : {&c.tid, &c.pos, &c.mtid, &c.mpos, &c.nm, &c.ref_len, &c.read_len, &c.clip_s, &c.clip_e})
+        v->resize(n);
+    c.flag.resize(n); c.mapq.resize(n); c.qkey.resize(n);
+    c.qname_at.resize(n); c.qname_len.resize(n);
+    c.sa_off.resize(n + 1);
+    c.sa_off[0] = 0;
+    const Column<int32_t> &sa_cnt = L->sa_cnt;
     for (size_t i = 0; i < n; i++) c.sa_off[i + 1] = c.sa_off[i] + sa_cnt[i];
     c.sa.clear();
     c.sa.reserve(static_cast<size_t>(c.sa_off[n]) + 1);
-    for (auto &part : sa_part) c.sa.insert(c.sa.end(), part.begin(), part.end());   // thread ranges are in record order
+    for (auto &part : L->sa_part) c.sa.insert(c.sa.end(), part.begin(), part.end());   // chunks are in record order
     size_t n_ms = 0;
-    for (auto &part : ms_part) n_ms += part.size() / 3;
+    for (auto &part : L->ms_part) n_ms += part.size() / 3;
     c.mseg_tid.reserve(n_ms); c.mseg_pos.reserve(n_ms); c.mseg_len.reserve(n_ms);
-    for (auto &part : ms_part)
+    for (auto &part : L->ms_part)
         for (size_t k = 0; k + 2 < part.size(); k += 3) { c.mseg_tid.push_back(part[k]); c.mseg_pos.push_back(part[k + 1]); c.mseg_len.push_back(part[k + 2]); }
     tr.lap("SA items + match segments joined");
 }

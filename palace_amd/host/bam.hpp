@@ -63,6 +63,7 @@ struct BamColumns {
     // depth stage (palace:538-552): one entry per M / = / X CIGAR operation of the records `samtools depth` counts
     // (UNMAP, SECONDARY, QCFAIL, DUP clear): target, 0-based reference position, length.  Order is irrelevant.
     std::vector<int32_t> mseg_tid, mseg_pos, mseg_len;
+    bool want_match_segments = true;               // set to false before loading when the depth stage is not run (generateGraph with a numeric <avgDepth>)
     // read names stay in the inflated stream; (offset, length) per record for the exactness guard
     RawBuf raw;
     Column<uint64_t> qname_at;

@@ -79,6 +79,21 @@ int upload(palace_ctx *ctx, const std::vector<T, A> &v, T **d)
 
 void radix_sort_u64(std::vector<uint64_t> &v);
 
+// ascending order of 64-bit keys by least-significant-digit radix passes of 11 bits (only over the bits in use)
+void radix_sort_u64(std::vector<uint64_t> &v)
+{
+    uint64_t all = 0;
+    for (uint64_t x : v) all |= x;
+    std::vector<uint64_t> tmp(v.size());
+    for (int shift = 0; shift < 64 && (all >> shift) != 0; shift += 11) {
+        size_t count[2049] = {0};
+        for (uint64_t x : v) count[((x >> shift) & 2047) + 1]++;
+        for (int b = 0; b < 2048; b++) count[b + 1] += count[b];
+        for (uint64_t x : v) tmp[count[(x >> shift) & 2047]++] = x;
+        v.swap(tmp);
+    }
+}
+
 // parseFastgFile (generate_graph.cpp:119-169) reduced to the pairs whose two names are BAM targets.  The file is mapped
 // and cut into parts at line ends; every part is parsed by a thread with string views (no per-line allocation).
 std::vector<uint64_t> fastg_keys(const std::string &path, const BamColumns &c, int threads)
@@ -125,10 +140,35 @@ std::vector<uint64_t> fastg_keys(const std::string &path, const BamColumns &c, i
             }
         }
     });
+    // all keys in ascending order, each once: the parts' keys are dealt into 256 ranges of the key space (by their top bits: the left
+    // contig, evenly spread), every range is sorted and made unique by a thread, the ranges are put behind one another
+    uint64_t top = 0;
+    size_t total = 0;
+    for (auto &v : part) { total += v.size(); for (uint64_t x : v) top |= x; }
+    int shift = 0;
+    while ((top >> shift) >= 256) shift++;
+    constexpr size_t kRanges = 256;
+    std::vector<std::vector<size_t>> at(part.size(), std::vector<size_t>(kRanges + 1, 0));
+    pool_for(part.size(), threads, [&](size_t k) { for (uint64_t x : part[k]) at[k][(x >> shift) + 1]++; });
+    std::vector<size_t> first(kRanges + 1, 0);
+    for (size_t r = 0; r < kRanges; r++) {
+        size_t n = 0;
+        for (size_t k = 0; k < part.size(); k++) { const size_t c = at[k][r + 1]; at[k][r + 1] = first[r] + n; n += c; }   // at[k][r + 1]: where part k writes its keys of range r
+        first[r + 1] = first[r] + n;
+    }
+    std::vector<uint64_t> dealt(total);
+    pool_for(part.size(), threads, [&](size_t k) { for (uint64_t x : part[k]) dealt[at[k][(x >> shift) + 1]++] = x; });
+    std::vector<size_t> kept(kRanges, 0);
+    pool_for(kRanges, threads, [&](size_t r) {
+        std::vector<uint64_t> v(dealt.begin() + static_cast<std::ptrdiff_t>(first[r]), dealt.begin() + static_cast<std::ptrdiff_t>(first[r + 1]));
+        radix_sort_u64(v);
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        std::copy(v.begin(), v.end(), dealt.begin() + static_cast<std::ptrdiff_t>(first[r]));
+        kept[r] = v.size();
+    });
     std::vector<uint64_t> keys;
-    for (auto &v : part) keys.insert(keys.end(), v.begin(), v.end());
-    radix_sort_u64(keys);
-    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    keys.reserve(total);
+    for (size_t r = 0; r < kRanges; r++) keys.insert(keys.end(), dealt.begin() + static_cast<std::ptrdiff_t>(first[r]), dealt.begin() + static_cast<std::ptrdiff_t>(first[r] + kept[r]));
     return keys;
 }
 
@@ -145,12 +185,26 @@ void name_ranks(const std::vector<std::string> &names, std::vector<int32_t> &by_
         for (size_t b = 0; b < 16; b++) k[b >> 3] = (k[b >> 3] << 8) | (b < s.size() ? static_cast<unsigned char>(s[b]) : 0);
         key[static_cast<size_t>(i)] = {k[0], k[1], i};
     }
-    std::sort(key.begin(), key.end(), [&](const Key &a, const Key &b) {
+    auto before = [&](const Key &a, const Key &b) {
         if (a.hi != b.hi) return a.hi < b.hi;
         if (a.lo != b.lo) return a.lo < b.lo;
         const int c = names[static_cast<size_t>(a.id)].compare(names[static_cast<size_t>(b.id)]);   // (a NUL inside a name also lands here)
         return c != 0 ? c < 0 : a.id < b.id;
-    });
+    };
+    // eight slices sorted side by side, then merged pairwise (a strict total order: the result does not depend on the slicing)
+    const size_t parts = nt < (1 << 16) ? 1 : 8;
+    auto cut = [&](size_t k) { return key.begin() + static_cast<std::ptrdiff_t>(static_cast<size_t>(nt) * k / parts); };
+    {
+        std::vector<std::thread> pool;
+        for (size_t k = 0; k < parts; k++) pool.emplace_back([&, k] { std::sort(cut(k), cut(k + 1), before); });
+        for (auto &t : pool) t.join();
+    }
+    for (size_t width = 1; width < parts; width *= 2) {
+        std::vector<std::thread> pool;
+        for (size_t k = 0; k + width < parts; k += 2 * width)
+            pool.emplace_back([&, k] { std::inplace_merge(cut(k), cut(k + width), cut(std::min(parts, k + 2 * width)), before); });
+        for (auto &t : pool) t.join();
+    }
     by_name.resize(static_cast<size_t>(nt));
     rank.assign(static_cast<size_t>(nt), 0);
     for (int32_t k = 0, r = -1; k < nt; k++) {
@@ -160,20 +214,6 @@ void name_ranks(const std::vector<std::string> &names, std::vector<int32_t> &by_
     }
 }
 
-// ascending order of 64-bit keys by least-significant-digit radix passes of 11 bits (only over the bits in use)
-void radix_sort_u64(std::vector<uint64_t> &v)
-{
-    uint64_t all = 0;
-    for (uint64_t x : v) all |= x;
-    std::vector<uint64_t> tmp(v.size());
-    for (int shift = 0; shift < 64 && (all >> shift) != 0; shift += 11) {
-        size_t count[2049] = {0};
-        for (uint64_t x : v) count[((x >> shift) & 2047) + 1]++;
-        for (int b = 0; b < 2048; b++) count[b + 1] += count[b];
-        for (uint64_t x : v) tmp[count[(x >> shift) & 2047]++] = x;
-        v.swap(tmp);
-    }
-}
 
 }  // namespace
 
@@ -255,6 +295,7 @@ int main(int argc, char **argv)
     FastExit fast_exit = fast_exit_begin();                    // from here on this is the worker process (fast_exit.hpp)
     Trace tr("generateGraph");
     BamColumns c;
+    c.want_match_segments = auto_depth;                         // (only the depth stage reads them: 6.7 M triples at 1M contigs)
     const int threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     uint64_t seed = 1;
     BamLoad *load = nullptr;

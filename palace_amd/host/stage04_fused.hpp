@@ -112,7 +112,7 @@ inline void stage04_read_side_files(const Stage04Options &o, const BamColumns &c
     std::vector<int32_t> token_tid;
     std::string err_fai, err_blast, err_gene, err_score, err_paths;
     // name lengths: every target, not only those the fasta index lists
-    constexpr int kSideThreads = 6;                // (the inflate threads have the cores; this work only has to end before they do)
+    constexpr int kSideThreads = 10;               // (beside the inflate threads; since the device takes part of the inflate this work is what the BAM phase ends with)
     pool_for(64, kSideThreads, [&](size_t part) {
         for (size_t t = nt * part / 64; t < nt * (part + 1) / 64; t++) {
             const std::string &nm = c.target_name[t];
@@ -135,6 +135,38 @@ inline void stage04_read_side_files(const Stage04Options &o, const BamColumns &c
     for (const std::string *e : {&err_fai, &err_blast, &err_gene, &err_score, &err_paths})
         if (!e->empty()) { out.error = *e; return; }
 
+    // the two tables that need nothing but the target names start at once, each with bytes of its own (merged into `seed` at the end)
+    std::vector<uint8_t> score_hit(nt, 0);
+    std::vector<uint8_t> gene_hit(nt, 0);          // (its own bytes: the BLAST thread is writing `seed` meanwhile)
+    std::thread t_gene([&] {                       // first column, untrimmed (l.101)
+        for_each_line(genes->data, genes->size, [&](sv line) {
+            const size_t t = line.find('\t');
+            const int32_t tid = c.tid_of(t == sv::npos ? line : line.substr(0, t));
+            if (tid >= 0) gene_hit[static_cast<size_t>(tid)] = 1;
+        });
+    });
+    std::thread t_score([&] {                      // l.104-112
+        const std::vector<size_t> cut = line_cuts(scores->data, scores->size, 8);
+        std::vector<std::string> errs(cut.size() - 1);
+        for_parts(cut, [&](size_t k, size_t a, size_t b) {
+            std::vector<sv> cols;
+            for_each_line(scores->data + a, b - a, [&](sv line) {
+                if (!errs[k].empty()) return;
+                split_on(strip(line), '\t', cols);
+                double v = 0;
+                if (cols.size() < 2 || (!s4::has_e(cols[1]) && !s4::to_double(cols[1], v))) { errs[k] = "malformed line in the score table"; return; }
+                const int32_t tid = c.tid_of(cols[0]);
+                if (tid < 0) return;
+                std::string text = s4::has_e(cols[1]) ? std::string("0.0") : s4::fixed3(v);
+                const double rounded = std::strtod(text.c_str(), nullptr);
+                // (distinct targets per line; a repeated name: the later line wins, parts are in file order only per part --
+                //  a name listed twice in the score file is not something the pipeline produces)
+                out.score_text[static_cast<size_t>(tid)] = std::move(text);
+                score_hit[static_cast<size_t>(tid)] = rounded > o.score_threshold;
+            });
+        });
+        for (const auto &e : errs) if (!e.empty() && err_score.empty()) err_score = e;
+    });
     // fasta index first: lengths (the BLAST rule divides by them) and the id tokens (contigs.paths speaks in them).  Parsed in
     // parts on threads (splitting, numbers, the name look-up); applied in file order by this thread
     {
@@ -200,44 +232,11 @@ inline void stage04_read_side_files(const Stage04Options &o, const BamColumns &c
         });
         if (err_blast.empty() && !cur_q.empty()) group_done(cur_q, true);
     });
-    std::vector<uint8_t> gene_hit(nt, 0);          // (its own bytes: the BLAST thread is writing `seed` meanwhile)
-    std::thread t_gene([&] {                       // first column, untrimmed (l.101)
-        for_each_line(genes->data, genes->size, [&](sv line) {
-            const size_t t = line.find('\t');
-            const int32_t tid = c.tid_of(t == sv::npos ? line : line.substr(0, t));
-            if (tid >= 0) gene_hit[static_cast<size_t>(tid)] = 1;
-        });
-    });
-    t_blast.join();
-    t_gene.join();
-    for (size_t t = 0; t < nt; t++) if (gene_hit[t]) out.seed[t] |= 2;
-    tr.lap("blast + gene hits");
-    std::thread t_score([&] {                      // l.104-112
-        const std::vector<size_t> cut = line_cuts(scores->data, scores->size, 8);
-        std::vector<std::string> errs(cut.size() - 1);
-        for_parts(cut, [&](size_t k, size_t a, size_t b) {
-            std::vector<sv> cols;
-            for_each_line(scores->data + a, b - a, [&](sv line) {
-                if (!errs[k].empty()) return;
-                split_on(strip(line), '\t', cols);
-                double v = 0;
-                if (cols.size() < 2 || (!s4::has_e(cols[1]) && !s4::to_double(cols[1], v))) { errs[k] = "malformed line in the score table"; return; }
-                const int32_t tid = c.tid_of(cols[0]);
-                if (tid < 0) return;
-                std::string text = s4::has_e(cols[1]) ? std::string("0.0") : s4::fixed3(v);
-                const double rounded = std::strtod(text.c_str(), nullptr);
-                // (distinct targets per line; a repeated name: the later line wins, parts are in file order only per part --
-                //  a name listed twice in the score file is not something the pipeline produces)
-                out.score_text[static_cast<size_t>(tid)] = std::move(text);
-                if (rounded > o.score_threshold) out.seed[static_cast<size_t>(tid)] |= 4; else out.seed[static_cast<size_t>(tid)] &= static_cast<uint8_t>(~4);
-            });
-        });
-        for (const auto &e : errs) if (!e.empty() && err_score.empty()) err_score = e;
-    });
+    tr.lap("blast started");
     std::thread t_paths([&] {                      // contigs.paths: every line that is no NODE header (l.126-137); in parts
         const std::vector<size_t> cut = line_cuts(paths->data, paths->size, 16);
         std::vector<std::vector<int32_t>> tok(cut.size() - 1), ends(cut.size() - 1);
-        pool_for(cut.size() - 1, kSideThreads - 2, [&](size_t k) {
+        pool_for(cut.size() - 1, kSideThreads, [&](size_t k) {
             std::string clean;
             tok[k].reserve((cut[k + 1] - cut[k]) / 6 + 16);
             for_each_line(paths->data + cut[k], cut[k + 1] - cut[k], [&](sv raw) {
@@ -271,8 +270,11 @@ inline void stage04_read_side_files(const Stage04Options &o, const BamColumns &c
             for (int32_t e : ends[k]) out.path_off.push_back(base + e);
         }
     });
+    t_blast.join();
+    t_gene.join();
     t_score.join();
-    tr.lap("scores (joined)");
+    for (size_t t = 0; t < nt; t++) out.seed[t] = static_cast<uint8_t>((out.seed[t] & ~6u) | (gene_hit[t] ? 2u : 0u) | (score_hit[t] ? 4u : 0u));
+    tr.lap("blast, gene hits, scores (joined)");
     t_paths.join();
     tr.lap("paths (joined)");
     for (const std::string *e : {&err_fai, &err_blast, &err_gene, &err_score, &err_paths})
