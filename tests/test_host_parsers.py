@@ -297,3 +297,26 @@ def test_fast_percent_g_equals_printf():
         p = subprocess.run([HOSTDUMP, "fmtg", "1500000", str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert p.returncode == 0, p.stdout[-2000:]
         assert p.stdout.startswith(b"0 differences in 1500021 values")
+
+
+def test_bam_decode_in_chunks_behind_the_walk_is_thread_count_independent(tmp_path):
+    """more records than one decode chunk (32 768): the columns, SA items and their offsets are the same with 1, 3 and 8 loader threads
+    (chunks are decoded by whichever thread is free, in any order, while the record walk is still going on)"""
+    import hashlib
+    rng = synth.rng_for(8)
+    targets = [("ctg%d" % i, 5000 + 13 * i) for i in range(60)]
+    recs = []
+    for i in range(90000):
+        t = int(rng.integers(0, 60))
+        recs.append(synth.BamRecord("r%d" % (i // 2), 99 if i % 2 == 0 else 147, t, int(rng.integers(0, 4800)), int(rng.integers(0, 61)),
+                                    "30S70M" if i % 5 == 0 else "100M", mtid=int(rng.integers(0, 60)), mpos=int(rng.integers(0, 4800)), nm=int(rng.integers(0, 7)),
+                                    sa="ctg%d,%d,-,70S30M,60,1;ctg%d,%d,+,10S90M,3,0;" % (int(rng.integers(0, 60)), int(rng.integers(1, 4000)),
+                                                                                      int(rng.integers(0, 60)), int(rng.integers(1, 4000))) if i % 11 == 0 else None))
+    bam = str(tmp_path / "big.bam")
+    synth.write_bam(bam, targets, recs, block=30000)
+    digests = set()
+    for threads in ("1", "3", "8"):
+        out = dump("bam", bam, threads)
+        assert out.count(b"\n") == 60 + 90000
+        digests.add(hashlib.sha256(out).hexdigest())
+    assert len(digests) == 1
