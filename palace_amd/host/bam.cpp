@@ -241,13 +241,12 @@ struct BamLoad : BackMembers {
     std::atomic<bool> bad{false};
     BamColumns *c = nullptr;
     int threads = 1;
-    size_t ready_blocks = 0;             // members [0, ready_blocks) are inflated
     size_t first_record = 0;             // offset of the first alignment record in the inflated stream
     int32_t n_ref = 0;
 
     // bytes of the inflated stream that are final: everything in front of the first member still missing.  Blocks
     // until at least `need` bytes are there (or everything that will ever come is).
-    size_t wait_for(size_t need)
+    size_t wait_for(size_t need, size_t &ready_blocks)         // ready_blocks: the caller's own cursor (members [0, ready_blocks) seen inflated)
     {
         for (;;) {
             while (ready_blocks < blocks.size() && done[ready_blocks].load(std::memory_order_acquire)) ready_blocks++;
@@ -257,13 +256,17 @@ struct BamLoad : BackMembers {
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
     }
+    // the record walk (serial: a record's size is its first word), on a thread of its own from the moment the header's end is known
+    std::thread walker;
+    std::string walk_error;
+    void walk();
     // the decode of the records into columns, pipelined behind the record walk (load_bam_finish): the walker publishes how many record
     // starts it has found, the loader's threads -- done with the inflate -- take chunks of records as they become known
     static constexpr size_t kChunk = 32768;
     std::vector<uint64_t> rec_at;        // reserved to the most records the stream can hold: never reallocated while it is read
     std::atomic<size_t> n_walked{0};
     std::atomic<bool> walk_done{false};
-    std::atomic<int> decode_go{0};       // load_bam_finish has sized the columns: the decode may start
+    std::atomic<int> decode_go{0};       // the name index is filled (SA items can be resolved): the decode may start
     std::atomic<size_t> next_chunk{0};
     uint64_t key_seed = 1;
     Column<int32_t> sa_cnt;
@@ -308,6 +311,7 @@ struct BamLoad : BackMembers {
     ~BamLoad() override
     {
         bad = true;                          // unwinding from a header / record error: the workers stop at their next member
+        if (walker.joinable()) walker.join();
         for (auto &t : workers) if (t.joinable()) t.join();
     }
 };
@@ -386,8 +390,9 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c, con
     trh.lap("file mapped, members indexed, inflate threads started");
     // ---- header (BAM spec 4.2): magic, l_text, text, n_ref, then (l_name, name, l_ref) per reference ----
     const uint8_t *d = c.raw.data();
+    size_t header_cursor = 0;
     auto need = [&](size_t upto) {
-        if (L->wait_for(upto) < upto) throw std::runtime_error("Failed to read BAM header");
+        if (L->wait_for(upto, header_cursor) < upto) throw std::runtime_error("Failed to read BAM header");
     };
     need(12);
     if (std::memcmp(d, "BAM\1", 4) != 0) throw std::runtime_error("Failed to read BAM header");
@@ -407,6 +412,25 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c, con
         p += 8 + l;
     }
     trh.lap("name offsets walked (behind the inflate front)");
+    // The end of the header is known: the record walk starts now, on a thread of its own, beside the rest of the header work (names,
+    // hashes, the name index) -- the walk is the longest serial piece of the load (6.7 M dependent steps at 1M contigs).  The columns
+    // are sized for the most records the stream can hold (36 bytes each at least; the pages behind the ones that do not exist are never
+    // touched) so that the threads can decode chunks of records while the walk is still finding the later ones.
+    L->first_record = p;
+    L->n_ref = n_ref;
+    {
+        const size_t ub = (c.raw.size() > p ? (c.raw.size() - p) / 36 : 0) + 16;
+        for (auto *v : {&c.tid, &c.pos, &c.mtid, &c.mpos, &c.nm, &c.ref_len, &c.read_len, &c.clip_s, &c.clip_e})
+            v->resize(ub);
+        c.flag.resize(ub); c.mapq.resize(ub); c.qkey.resize(ub);
+        c.qname_at.resize(ub); c.qname_len.resize(ub);
+        L->sa_cnt.resize(ub);
+        const size_t max_chunks = ub / BamLoad::kChunk + 1;
+        L->sa_part.resize(max_chunks);
+        L->ms_part.resize(max_chunks);
+        L->rec_at.reserve(ub);
+        L->walker = std::thread([ld] { ld->walk(); });
+    }
     // names, lengths and name hashes on the threads; the index itself is filled by this thread (hashes in hand)
     const size_t nr = name_at.size();
     c.target_name.resize(nr);
@@ -438,8 +462,7 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c, con
         c.tid_of_name[static_cast<size_t>(k)] = static_cast<int32_t>(i);
     }
     trh.lap("name index filled");
-    L->first_record = p;
-    L->n_ref = n_ref;
+    L->decode_go.store(1, std::memory_order_release);            // the name index is there: SA items can be resolved
     return L.release();
 }
 
@@ -448,6 +471,35 @@ size_t load_bam_size_hint(const BamLoad *load) { return load->c->raw.size(); }
 void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumns &c)
 {
     load_bam_finish(load_bam_begin(path, threads, c), key_seed);
+}
+
+void BamLoad::walk()
+{
+    const uint8_t *d = c->raw.data();
+    size_t cursor = 0;
+    try {
+        size_t p = first_record, have = wait_for(p + 4, cursor), ahead = p & ~size_t{63};
+        for (;;) {
+            if (p + 4 > have) { have = wait_for(p + 4, cursor); if (p + 4 > have) break; }
+            const size_t bs = le32(d + p);
+            if (bs < 32) break;                                       // truncated tail: stop like a failed sam_read1
+            if (p + 4 + bs > have) { have = wait_for(p + 4 + bs, cursor); if (p + 4 + bs > have) break; }
+            // the variable-length fields must fit the record (htslib's bam_read1 fails on such a record, which ends the
+            // reference's `while (sam_read1(...) >= 0)` loop at generate_graph.cpp:644): name, CIGAR, packed bases, qualities
+            const uint8_t *r = d + p + 4;
+            const size_t l_name = r[8], n_cig = le16(r + 12), l_seq = le32(r + 16);
+            if (l_name < 1 || l_seq > 0x7fffffffu || 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs) break;
+            rec_at.push_back(p + 4);
+            if ((rec_at.size() & 4095) == 0) n_walked.store(rec_at.size(), std::memory_order_release);
+            p += 4 + bs;
+            // the next few record heads lie in the kilobyte behind this one, not at a fixed stride (the hardware does not see a
+            // stream): every line of that kilobyte is asked for as the walk exposes it
+            for (const size_t upto = std::min(have, p + 1024); ahead + 64 <= upto; ahead += 64) __builtin_prefetch(d + ahead);
+            if (ahead < p) ahead = p & ~size_t{63};
+        }
+    } catch (const std::exception &e) { walk_error = e.what(); }
+    n_walked.store(rec_at.size(), std::memory_order_release);
+    walk_done.store(true, std::memory_order_release);
 }
 
 // records [a, b) of the walk into the columns (every element written exactly once, by the thread that has the chunk)
@@ -584,40 +636,9 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
     std::unique_ptr<BamLoad> L(load);
     BamColumns &c = *L->c;
     Trace tr("bam");
-    const uint8_t *d = c.raw.data();
-    // The columns are sized for the most records the stream can hold (36 bytes each at least; the pages behind the ones that do not
-    // exist are never touched) so that the threads can decode chunks of records while the walk below is still finding the later ones.
-    const size_t ub = (c.raw.size() > L->first_record ? (c.raw.size() - L->first_record) / 36 : 0) + 16;
-    for (auto *v : {&c.tid, &c.pos, &c.mtid, &c.mpos, &c.nm, &c.ref_len, &c.read_len, &c.clip_s, &c.clip_e})
-        v->resize(ub);
-    c.flag.resize(ub); c.mapq.resize(ub); c.qkey.resize(ub);
-    c.qname_at.resize(ub); c.qname_len.resize(ub);
-    L->sa_cnt.resize(ub);
-    const size_t max_chunks = ub / BamLoad::kChunk + 1;
-    L->sa_part.resize(max_chunks);
-    L->ms_part.resize(max_chunks);
-    L->rec_at.reserve(ub);
-    L->key_seed = key_seed;
-    L->decode_go.store(1, std::memory_order_release);
-    // ---- record boundaries, behind the inflate front ----
+    L->walker.join();                                             // the record walk (started by load_bam_begin), behind the inflate front
+    if (!L->walk_error.empty()) throw std::runtime_error(L->walk_error);
     std::vector<uint64_t> &rec_at = L->rec_at;
-    size_t p = L->first_record, have = L->wait_for(p + 4);
-    for (;;) {
-        if (p + 4 > have) { have = L->wait_for(p + 4); if (p + 4 > have) break; }
-        const size_t bs = le32(d + p);
-        if (bs < 32) break;                                       // truncated tail: stop like a failed sam_read1
-        if (p + 4 + bs > have) { have = L->wait_for(p + 4 + bs); if (p + 4 + bs > have) break; }
-        // the variable-length fields must fit the record (htslib's bam_read1 fails on such a record, which ends the
-        // reference's `while (sam_read1(...) >= 0)` loop at generate_graph.cpp:644): name, CIGAR, packed bases, qualities
-        const uint8_t *r = d + p + 4;
-        const size_t l_name = r[8], n_cig = le16(r + 12), l_seq = le32(r + 16);
-        if (l_name < 1 || l_seq > 0x7fffffffu || 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs) break;
-        rec_at.push_back(p + 4);
-        if ((rec_at.size() & 4095) == 0) L->n_walked.store(rec_at.size(), std::memory_order_release);
-        p += 4 + bs;
-    }
-    L->n_walked.store(rec_at.size(), std::memory_order_release);
-    L->walk_done.store(true, std::memory_order_release);
     tr.lap("record boundaries (behind the inflate front)");
     L->decode_chunks();                                           // this thread helps with what is left
     for (auto &t : L->workers) t.join();                          // (members behind a malformed record are still inflated)
@@ -643,6 +664,7 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
     c.mseg_tid.reserve(n_ms); c.mseg_pos.reserve(n_ms); c.mseg_len.reserve(n_ms);
     for (auto &part : L->ms_part)
         for (size_t k = 0; k + 2 < part.size(); k += 3) { c.mseg_tid.push_back(part[k]); c.mseg_pos.push_back(part[k + 1]); c.mseg_len.push_back(part[k + 2]); }
+    if (key_seed != L->key_seed) rekey(c, key_seed);             // (the decode keyed the read names with the default seed)
     tr.lap("SA items + match segments joined");
 }
 

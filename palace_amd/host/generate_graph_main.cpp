@@ -319,7 +319,7 @@ int main(int argc, char **argv)
     std::thread side04;
     auto join04 = [&] { if (side04.joinable()) side04.join(); };
     std::thread side([&] { Trace t("generateGraph/names"); name_ranks(c.target_name, by_name, rank); t.lap("name ranks"); });
-    std::thread side2([&] { Trace t("generateGraph/fastg"); fkeys = fastg_keys(fai_path, c, 4); t.lap("fastg keys"); });
+    std::thread side2([&] { Trace t("generateGraph/fastg"); fkeys = fastg_keys(fai_path, c, 8); t.lap("fastg keys"); });
     std::thread hip_up([&] {
         ctx_rc = palace_ctx_create(0, &ctx);
         if (ctx_rc) ctx_err = palace_last_error();
