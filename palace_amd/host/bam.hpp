@@ -54,6 +54,11 @@ struct BamColumns {
         const int k = tid_names.find(name);
         return k < 0 ? -1 : tid_of_name[static_cast<size_t>(k)];
     }
+    int32_t tid_of_hashed(std::string_view name, uint64_t h) const       // h = hash_bytes(name)
+    {
+        const int k = tid_names.find_hashed(name, h);
+        return k < 0 ? -1 : tid_of_name[static_cast<size_t>(k)];
+    }
     // one entry per record, file order
     Column<int32_t> tid, pos, mtid, mpos, nm, ref_len, read_len, clip_s, clip_e, sa_off;
     Column<uint16_t> flag;

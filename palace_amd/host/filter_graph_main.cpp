@@ -341,8 +341,13 @@ int main(int argc, char **argv)
         const size_t a = text.find(' ');
         if (a != sv::npos) {
             const size_t b = text.find(' ', a + 1);
-            const int t = names.find(text.substr(a + 1, (b == sv::npos ? text.size() : b) - a - 1));
-            if (t >= 0) facts[static_cast<size_t>(t)].in_already = true;
+            const sv second = text.substr(a + 1, (b == sv::npos ? text.size() : b) - a - 1);
+            const size_t own = static_cast<size_t>(&f - facts.data());                 // (as a rule the text's second token is the segment's own name: no look-up)
+            if (own < names.names.size() && names.names[own] == second) f.in_already = true;
+            else {
+                const int t = names.find(second);
+                if (t >= 0) facts[static_cast<size_t>(t)].in_already = true;
+            }
         }
     };
     std::string text;

@@ -96,11 +96,12 @@ void radix_sort_u64(std::vector<uint64_t> &v)
 
 // parseFastgFile (generate_graph.cpp:119-169) reduced to the pairs whose two names are BAM targets.  The file is mapped
 // and cut into parts at line ends; every part is parsed by a thread with string views (no per-line allocation).
+constexpr size_t kLineItems = 32;
 std::vector<uint64_t> fastg_keys(const std::string &path, const BamColumns &c, int threads)
 {
     MappedText txt;
     try { txt.open(path); } catch (const std::exception &) { return {}; }     // the reference reads an unopenable file as empty
-    auto lookup = [&](std::string_view n) -> int64_t { return c.tid_of(n); };       // last duplicate wins (:624-627)
+    // (names are looked up with BamColumns::tid_of_hashed: the last duplicate of a target name wins, :624-627)
     const size_t N = txt.size;
     std::vector<size_t> cut{0};
     const size_t n_parts = static_cast<size_t>(std::max(1, threads)) * 4;
@@ -121,23 +122,40 @@ std::vector<uint64_t> fastg_keys(const std::string &path, const BamColumns &c, i
             std::string_view head = line.substr(0, line.find(';'));           // getline(ss, fullName, ';')
             const size_t colon = head.find(':');
             if (colon == std::string_view::npos) continue;                     // no linked contigs
-            std::string_view name = head.substr(0, colon);
-            const bool rev = !name.empty() && name.back() == '\'';
-            if (rev) name.remove_suffix(1);
-            const int64_t a = lookup(name);
+            // the names of the line first (hashes made, table slots asked for), then their look-ups: a table of a million names is a
+            // cache miss per look-up, and a line has four of them on average
+            struct Item { std::string_view n; uint64_t h; bool rev; };
+            Item item[kLineItems];
+            size_t n_items = 0;
+            auto add = [&](std::string_view n) {
+                const bool r = !n.empty() && n.back() == '\'';
+                if (r) n.remove_suffix(1);
+                item[n_items] = Item{n, hash_bytes(n), r};
+                c.tid_names.prefetch(item[n_items].h);
+                n_items++;
+            };
+            add(head.substr(0, colon));
+            auto flush = [&](size_t from) {                                    // links item[from ..) of the line's own contig item[0]
+                const int64_t a = c.tid_of_hashed(item[0].n, item[0].h);
+                const bool rev = item[0].rev;
+                for (size_t i = from; i < n_items; i++) {
+                    const int64_t b = c.tid_of_hashed(item[i].n, item[i].h);
+                    if (a < 0 || b < 0) continue;
+                    const uint64_t o1 = rev ? 1 : 0, o2 = (rev != item[i].rev) ? 1 : 0;  // :151-157
+                    keys.push_back((static_cast<uint64_t>(a) << 33) | (static_cast<uint64_t>(b) << 2) | (o1 << 1) | o2);
+                    keys.push_back((static_cast<uint64_t>(b) << 33) | (static_cast<uint64_t>(a) << 2) | ((o1 ^ 1) << 1) | (o2 ^ 1));
+                }
+                n_items = 1;
+            };
             for (size_t q = colon + 1; q < head.size();) {
                 const size_t comma = head.find(',', q);
                 std::string_view lk = head.substr(q, comma == std::string_view::npos ? std::string_view::npos : comma - q);
                 q = comma == std::string_view::npos ? head.size() : comma + 1;
                 if (lk.empty()) continue;
-                const bool lrev = lk.back() == '\'';
-                if (lrev) lk.remove_suffix(1);
-                const int64_t b = lookup(lk);
-                if (a < 0 || b < 0) continue;
-                const uint64_t o1 = rev ? 1 : 0, o2 = (rev != lrev) ? 1 : 0;  // :151-157
-                keys.push_back((static_cast<uint64_t>(a) << 33) | (static_cast<uint64_t>(b) << 2) | (o1 << 1) | o2);
-                keys.push_back((static_cast<uint64_t>(b) << 33) | (static_cast<uint64_t>(a) << 2) | ((o1 ^ 1) << 1) | (o2 ^ 1));
+                add(lk);
+                if (n_items == kLineItems) flush(1);
             }
+            flush(1);
         }
     });
     // all keys in ascending order, each once: the parts' keys are dealt into 256 ranges of the key space (by their top bits: the left

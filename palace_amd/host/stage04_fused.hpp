@@ -9,6 +9,8 @@
 // Line citations are to share/palace/scripts/filter_graph.py unless they name another file.
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -167,6 +169,65 @@ inline void stage04_read_side_files(const Stage04Options &o, const BamColumns &c
         });
         for (const auto &e : errs) if (!e.empty() && err_score.empty()) err_score = e;
     });
+    // contigs.paths: every line that is no NODE header (l.126-137), in parts.  Its text work (lines, the ';' removed, tokens, their
+    // hashes) needs nothing and runs beside the fasta index; the look-ups of the tokens wait for the index's id tokens.
+    std::atomic<bool> t_paths_go{false};
+    std::thread t_paths([&] {
+        const std::vector<size_t> cut = line_cuts(paths->data, paths->size, 16);
+        struct Part { std::string text; std::vector<uint32_t> at; std::vector<uint16_t> len; std::vector<uint64_t> hash; std::vector<uint8_t> kind; std::vector<int32_t> ends; };
+        std::vector<Part> part(cut.size() - 1);                           // kind: 0 empty token, 1 '<id>+' (or any other last character), 2 '<id>-'
+        pool_for(part.size(), kSideThreads / 2, [&](size_t k) {
+            Part &pt = part[k];
+            std::string clean;
+            pt.text.reserve(cut[k + 1] - cut[k]);
+            for_each_line(paths->data + cut[k], cut[k + 1] - cut[k], [&](sv raw) {
+                const sv s = strip(raw);
+                clean.clear();
+                for (char ch : s) if (ch != ';') clean += ch;
+                if (sv(clean).substr(0, 4) == "NODE") return;
+                const size_t base = pt.text.size();
+                pt.text += clean;
+                size_t p = 0;
+                while (p <= clean.size()) {
+                    const size_t comma = clean.find(',', p);
+                    const sv t = sv(clean).substr(p, comma == std::string::npos ? sv::npos : comma - p);
+                    const size_t at = base + p;
+                    p = comma == std::string::npos ? clean.size() + 1 : comma + 1;
+                    const sv id = t.empty() ? t : t.substr(0, t.size() - 1);
+                    pt.at.push_back(static_cast<uint32_t>(at));
+                    pt.len.push_back(static_cast<uint16_t>(std::min<size_t>(id.size(), 65535)));
+                    pt.hash.push_back(hash_bytes(id));
+                    pt.kind.push_back(t.empty() ? 0 : t.back() == '-' ? 2 : 1);
+                }
+                pt.ends.push_back(static_cast<int32_t>(pt.at.size()));
+            });
+        });
+        while (!t_paths_go.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        std::vector<std::vector<int32_t>> tok(part.size());
+        pool_for(part.size(), kSideThreads, [&](size_t k) {
+            const Part &pt = part[k];
+            tok[k].resize(pt.at.size());
+            for (size_t i = 0; i < pt.at.size(); i++) {
+                if (i + 8 < pt.at.size()) tokens.prefetch(pt.hash[i + 8]);
+                int32_t code = -1;
+                if (pt.kind[i] && pt.len[i] < 65535) {
+                    const int id = tokens.find_hashed(sv(pt.text).substr(pt.at[i], pt.len[i]), pt.hash[i]);
+                    const int32_t tid = id < 0 ? -1 : token_tid[static_cast<size_t>(id)];
+                    if (tid >= 0) code = 2 * tid + (pt.kind[i] == 2);
+                }
+                tok[k][i] = code;
+            }
+        });
+        size_t n_tok = 0, n_lines = 0;
+        for (size_t k = 0; k < tok.size(); k++) { n_tok += tok[k].size(); n_lines += part[k].ends.size(); }
+        out.path_tok.reserve(n_tok + 1);
+        out.path_off.reserve(n_lines + 1);
+        for (size_t k = 0; k < tok.size(); k++) {
+            const int64_t base = static_cast<int64_t>(out.path_tok.size());
+            out.path_tok.insert(out.path_tok.end(), tok[k].begin(), tok[k].end());
+            for (int32_t e : part[k].ends) out.path_off.push_back(base + e);
+        }
+    });
     // fasta index first: lengths (the BLAST rule divides by them) and the id tokens (contigs.paths speaks in them).  Parsed in
     // parts on threads (splitting, numbers, the name look-up); applied in file order by this thread
     {
@@ -233,43 +294,7 @@ inline void stage04_read_side_files(const Stage04Options &o, const BamColumns &c
         if (err_blast.empty() && !cur_q.empty()) group_done(cur_q, true);
     });
     tr.lap("blast started");
-    std::thread t_paths([&] {                      // contigs.paths: every line that is no NODE header (l.126-137); in parts
-        const std::vector<size_t> cut = line_cuts(paths->data, paths->size, 16);
-        std::vector<std::vector<int32_t>> tok(cut.size() - 1), ends(cut.size() - 1);
-        pool_for(cut.size() - 1, kSideThreads, [&](size_t k) {
-            std::string clean;
-            tok[k].reserve((cut[k + 1] - cut[k]) / 6 + 16);
-            for_each_line(paths->data + cut[k], cut[k + 1] - cut[k], [&](sv raw) {
-                const sv s = strip(raw);
-                clean.clear();
-                for (char ch : s) if (ch != ';') clean += ch;
-                if (sv(clean).substr(0, 4) == "NODE") return;
-                size_t p = 0;
-                while (p <= clean.size()) {
-                    const size_t comma = clean.find(',', p);
-                    const sv t = sv(clean).substr(p, comma == std::string::npos ? sv::npos : comma - p);
-                    p = comma == std::string::npos ? clean.size() + 1 : comma + 1;
-                    int32_t code = -1;
-                    if (!t.empty()) {
-                        const int id = tokens.find(t.substr(0, t.size() - 1));
-                        const int32_t tid = id < 0 ? -1 : token_tid[static_cast<size_t>(id)];
-                        if (tid >= 0) code = 2 * tid + (t.back() == '-');
-                    }
-                    tok[k].push_back(code);
-                }
-                ends[k].push_back(static_cast<int32_t>(tok[k].size()));
-            });
-        });
-        size_t n_tok = 0, n_lines = 0;
-        for (size_t k = 0; k < tok.size(); k++) { n_tok += tok[k].size(); n_lines += ends[k].size(); }
-        out.path_tok.reserve(n_tok + 1);
-        out.path_off.reserve(n_lines + 1);
-        for (size_t k = 0; k < tok.size(); k++) {
-            const int64_t base = static_cast<int64_t>(out.path_tok.size());
-            out.path_tok.insert(out.path_tok.end(), tok[k].begin(), tok[k].end());
-            for (int32_t e : ends[k]) out.path_off.push_back(base + e);
-        }
-    });
+    t_paths_go.store(true, std::memory_order_release);           // (the id tokens are final: the path reader may look its tokens up)
     t_blast.join();
     t_gene.join();
     t_score.join();
