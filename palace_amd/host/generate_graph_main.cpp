@@ -8,6 +8,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <charconv>
 #include <cstdio>
@@ -512,10 +514,42 @@ int main(int argc, char **argv)
     if (!out) { std::cerr << "Failed to open output " << out_path << "\n"; return 1; }
     std::vector<char> big(1 << 22);
     std::setvbuf(out, big.data(), _IOFBF, big.size());
+    // `_graph.txt` order of the edges, as an index into the device order (stage 04 flags edges in device order)
+    std::vector<uint32_t> sorted_index(edges.size());
+    std::iota(sorted_index.begin(), sorted_index.end(), 0u);
+    std::sort(sorted_index.begin(), sorted_index.end(), [&](uint32_t ia, uint32_t ib) {
+        const palace_graph_edge &a = edges[ia], &b = edges[ib];
+        if (rank[a.left] != rank[b.left]) return rank[a.left] < rank[b.left];
+        if (rank[a.right] != rank[b.right]) return rank[a.right] < rank[b.right];
+        if (a.oL != b.oL) return a.oL < b.oL;                          // '+' (43) < '-' (45)
+        return a.oR < b.oR;
+    });
     // SEG lines in name order; formatted by all threads (a slice of the order each), written in order
     std::vector<std::string> seg_text(static_cast<size_t>(threads) * 4);
     struct SegAt { int32_t tid; size_t at, len; };
     std::vector<std::vector<SegAt>> seg_at(seg_text.size());
+    std::vector<std::atomic<int>> seg_ready(seg_text.size());
+    for (auto &f : seg_ready) f.store(0, std::memory_order_relaxed);
+    // The file itself (60 MB at a million contigs) is written by a thread of its own, part by part as the formatting threads finish
+    // them (and, with stage 04 in the process, while that goes on): edges, their order and the names are final
+    bool graph_ok = false;
+    std::thread graph_writer([&] {
+        for (size_t k = 0; k < seg_text.size(); k++) {
+            while (!seg_ready[k].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            std::fwrite(seg_text[k].data(), 1, seg_text[k].size(), out);
+        }
+        for (uint32_t ei : sorted_index) {
+            const palace_graph_edge &e = edges[ei];
+            const uint32_t supp = e.counts[0], supp_nf = e.counts[1], span = e.counts[2], span_nf = e.counts[3];
+            const uint32_t total = supp + supp_nf + span + span_nf;
+            if (total == 0 || total < static_cast<uint32_t>(min_count)) continue;   // :1056-1061
+            std::fprintf(out, "JUNC %s %c %s %c %u %u", c.target_name[e.left].c_str(), e.oL ? '-' : '+',
+                         c.target_name[e.right].c_str(), e.oR ? '-' : '+', supp + span + supp_nf, span_nf);
+            if (debug) { std::fputs(" READS:", out); std::fwrite(reads_of[ei].data(), 1, reads_of[ei].size(), out); }
+            std::fputc('\n', out);
+        }
+        graph_ok = !(std::ferror(out) | std::fclose(out));   // a short write must not exit 0
+    });
     pool_for(seg_text.size(), threads, [&](size_t part) {
         std::string &txt = seg_text[part];
         char line[512];
@@ -552,33 +586,7 @@ int main(int argc, char **argv)
             txt.append(line, w);
             seg_at[part].push_back({best, at, txt.size() - at});
         }
-    });
-    // `_graph.txt` order of the edges, as an index into the device order (stage 04 flags edges in device order)
-    std::vector<uint32_t> sorted_index(edges.size());
-    std::iota(sorted_index.begin(), sorted_index.end(), 0u);
-    std::sort(sorted_index.begin(), sorted_index.end(), [&](uint32_t ia, uint32_t ib) {
-        const palace_graph_edge &a = edges[ia], &b = edges[ib];
-        if (rank[a.left] != rank[b.left]) return rank[a.left] < rank[b.left];
-        if (rank[a.right] != rank[b.right]) return rank[a.right] < rank[b.right];
-        if (a.oL != b.oL) return a.oL < b.oL;                          // '+' (43) < '-' (45)
-        return a.oR < b.oR;
-    });
-    // The file itself (60 MB at a million contigs) is written by a thread of its own while stage 04 goes on: everything it reads
-    // (SEG text, edges, their order, names) is final
-    bool graph_ok = false;
-    std::thread graph_writer([&] {
-        for (const std::string &txt : seg_text) std::fwrite(txt.data(), 1, txt.size(), out);
-        for (uint32_t ei : sorted_index) {
-            const palace_graph_edge &e = edges[ei];
-            const uint32_t supp = e.counts[0], supp_nf = e.counts[1], span = e.counts[2], span_nf = e.counts[3];
-            const uint32_t total = supp + supp_nf + span + span_nf;
-            if (total == 0 || total < static_cast<uint32_t>(min_count)) continue;   // :1056-1061
-            std::fprintf(out, "JUNC %s %c %s %c %u %u", c.target_name[e.left].c_str(), e.oL ? '-' : '+',
-                         c.target_name[e.right].c_str(), e.oR ? '-' : '+', supp + span + supp_nf, span_nf);
-            if (debug) { std::fputs(" READS:", out); std::fwrite(reads_of[ei].data(), 1, reads_of[ei].size(), out); }
-            std::fputc('\n', out);
-        }
-        graph_ok = !(std::ferror(out) | std::fclose(out));   // a short write must not exit 0
+        seg_ready[part].store(1, std::memory_order_release);               // the writer may take this part
     });
     auto graph_written = [&]() -> bool {
         if (graph_writer.joinable()) graph_writer.join();
