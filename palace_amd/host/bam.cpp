@@ -225,10 +225,14 @@ void rekey(BamColumns &c, uint64_t seed)
 // The loader as a pipeline (the reference streams the file through htslib, generate_graph.cpp:644):
 //   inflate workers   take the BGZF members one by one off the front, so the inflated stream grows from the front; helpers
 //                     (a device) take batches off the back;
+//   the walker        one thread, started by load_bam_begin the moment the header's end is known: the record boundaries behind the
+//                     inflate front (serial: a record's size is its first word), published in steps of 4 096 records;
+//   the decode        the inflate workers, as they run out of members, take chunks of 32 768 walked records and write their
+//                     columns (sized for the most records the stream can hold; pages behind the real ones are never touched);
 //   load_bam_begin    returns as soon as the members that hold the header are there and the header is parsed -- the caller
 //                     can start what depends on the target names only (name ranks, FASTG keys) beside the rest;
-//   load_bam_finish   walks the record boundaries behind the inflate front (that walk is serial: a record's size is its
-//                     first word), then decodes the records on all threads.
+//   load_bam_finish   waits for the walker, helps with the chunks that are left, cuts the columns to the records found and
+//                     puts the chunks' SA items and match segments behind one another.
 struct BamLoad : BackMembers {
     std::unique_ptr<MappedFile> file;
     std::vector<Block> blocks;

@@ -107,7 +107,10 @@ using MemberHelper = std::function<void(BackMembers &)>;
 // Reads, inflates (threads) and decodes a whole BAM file.  Throws std::runtime_error.
 void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumns &out);
 // The same in two steps: begin() returns once the header (target names and lengths, the name index) is in `out`, with the
-// inflate threads still running; finish() delivers the records.  `out` must stay where it is in between.
+// inflate threads, the record walk (a thread of its own from the moment the header's end is known) and the decode of the records
+// found so far (the inflate threads, as they run out of members) still going on; finish() waits for them and delivers the records.
+// `out` must stay where it is in between; its per-record columns are sized for the most records the stream can hold until finish()
+// cuts them to the records found.
 struct BamLoad;
 BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &out, const std::vector<MemberHelper> &helpers = {});
 void load_bam_finish(BamLoad *load, uint64_t key_seed);
