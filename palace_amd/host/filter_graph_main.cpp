@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <algorithm>
 #include <string_view>
@@ -119,19 +120,6 @@ sv field(const std::vector<sv> &cols, size_t i, const char *what)
     if (i >= cols.size()) die(std::string("short line in ") + what);
     return cols[i];
 }
-// the token between the 3rd and 4th '_' of a contig name (EDGE_<id>_length_<L>_cov_<c>)
-long long name_length(sv name)
-{
-    size_t a = 0;
-    for (int k = 0; k < 3; k++) {
-        a = name.find('_', a);
-        if (a == sv::npos) die("contig name without a length token: " + std::string(name));
-        a++;
-    }
-    const size_t b = name.find('_', a);
-    return need_int(name.substr(a, b == sv::npos ? sv::npos : b - a), "a contig name");
-}
-
 // fields written in scientific notation become plain (l.178-188)
 std::string plain_number(sv tok)
 {
@@ -299,6 +287,63 @@ int main(int argc, char **argv)
     }
     trace.lap("gene hits, scores");
     { Mapped unused(fastg_fai); }                                                 // opened like the reference does (l.114-120)
+    // contigs.paths rescue (l.126-151) needs the facts the tables above gave (BLAST / gene / score flags, name lengths) and nothing of
+    // the graph: the parts work out which lines pass and list their members on threads of their own while the graph passes below go
+    // on.  It reads snapshots (the graph passes add names and facts), and keeps its first complaint for the place the script makes it.
+    std::vector<uint8_t> backs(facts.size());
+    for (size_t i = 0; i < facts.size(); i++) backs[i] = facts[i].blast || facts[i].gene || facts[i].score_hit;
+    const std::vector<sv> names_then(names.names.begin(), names.names.end());
+    std::unique_ptr<Mapped> paths;
+    std::vector<std::vector<int>> passing;                                        // members of the passing lines of a part, in order
+    std::string rescue_err;
+    std::thread t_rescue([&] {
+        if (::access(paths_file, R_OK) != 0) { rescue_err = std::string("cannot open ") + paths_file; return; }
+        paths.reset(new Mapped(paths_file));
+        const std::vector<size_t> cut = cuts_of(*paths);
+        passing.resize(cut.size() - 1);
+        std::vector<std::string> errs(cut.size() - 1);
+        palace_host::for_parts(cut, [&](size_t k, size_t a, size_t b) {
+            std::vector<sv> cols;
+            std::string clean;
+            std::vector<int> members;
+            palace_host::for_each_line(paths->p + a, b - a, [&](sv raw_line) {
+                if (!errs[k].empty()) return;
+                const sv s = strip(raw_line);
+                clean.clear();
+                for (char c : s) if (c != ';') clean += c;
+                if (sv(clean).substr(0, 4) == "NODE") return;
+                split_on(clean, ',', cols);
+                members.clear();
+                long long total = 0, backed = 0;
+                for (sv tok : cols) {
+                    const sv key = tok.empty() ? tok : tok.substr(0, tok.size() - 1);
+                    const int t = tokens.find(key);
+                    if (t < 0) { errs[k] = "contigs.paths names an unknown contig id: '" + std::string(key) + "'"; return; }
+                    const int m = token_name[static_cast<size_t>(t)];
+                    members.push_back(m);
+                    const sv name = names_then[static_cast<size_t>(m)];
+                    size_t at = 0;                                                // name_length(), complaining instead of dying
+                    for (int u = 0; u < 3 && at != sv::npos; u++) { at = name.find('_', at); if (at != sv::npos) at++; }
+                    if (at == sv::npos) { errs[k] = "contig name without a length token: " + std::string(name); return; }
+                    const size_t e = name.find('_', at);
+                    const sv digits = strip(name.substr(at, e == sv::npos ? sv::npos : e - at));
+                    long long len = 0;
+                    size_t i = 0;
+                    bool neg = false;
+                    if (i < digits.size() && (digits[i] == '+' || digits[i] == '-')) neg = digits[i++] == '-';
+                    const size_t first = i;
+                    for (; i < digits.size() && digits[i] >= '0' && digits[i] <= '9'; i++) len = len * 10 + (digits[i] - '0');
+                    if (i == first || i != digits.size() || i - first > 18) { errs[k] = "not an integer in a contig name: '" + std::string(digits) + "'"; return; }
+                    if (neg) len = -len;
+                    total += len;
+                    if (backs[static_cast<size_t>(m)]) backed += len;
+                }
+                if (backed > 0 && (static_cast<double>(backed) / static_cast<double>(total) >= 0.5 || backed > 2000))
+                    passing[k].insert(passing[k].end(), members.begin(), members.end());
+            });
+        });
+        for (const std::string &e : errs) if (!e.empty()) { rescue_err = e; break; }
+    });
 
     Mapped graph(graph_path);
     std::string seg_block;                                                        // SEG texts as they are selected ...
@@ -441,39 +486,12 @@ int main(int argc, char **argv)
     }
     trace.lap("graph passes 2, 3");
 
-    // contigs.paths rescue (l.126-151): the parts work out which lines pass and list their members
-    Mapped paths(paths_file);
+    // contigs.paths rescue (l.126-151): worked out beside the graph passes (t_rescue, started in front of pass 1); its complaints are
+    // made here, where the script would make them
+    t_rescue.join();
+    if (!rescue_err.empty()) die(rescue_err);
     std::vector<int> rescued;
     {
-        const std::vector<size_t> cut = cuts_of(paths);
-        std::vector<std::vector<int>> passing(cut.size() - 1);            // members of the passing lines of a part, in order
-        palace_host::for_parts(cut, [&](size_t k, size_t a, size_t b) {
-            std::vector<sv> cols;
-            std::string clean;
-            std::vector<int> members;
-            palace_host::for_each_line(paths.p + a, b - a, [&](sv raw_line) {
-                const sv s = strip(raw_line);
-                clean.clear();
-                for (char c : s) if (c != ';') clean += c;
-                if (sv(clean).substr(0, 4) == "NODE") return;
-                split_on(clean, ',', cols);
-                members.clear();
-                long long total = 0, backed = 0;
-                for (sv tok : cols) {
-                    const sv key = tok.empty() ? tok : tok.substr(0, tok.size() - 1);
-                    const int t = tokens.find(key);
-                    if (t < 0) die("contigs.paths names an unknown contig id: '" + std::string(key) + "'");
-                    const int m = token_name[static_cast<size_t>(t)];
-                    members.push_back(m);
-                    const Facts &f = facts[static_cast<size_t>(m)];
-                    const long long len = name_length(names.names[static_cast<size_t>(m)]);
-                    total += len;
-                    if (f.blast || f.gene || f.score_hit) backed += len;
-                }
-                if (backed > 0 && (static_cast<double>(backed) / static_cast<double>(total) >= 0.5 || backed > 2000))
-                    passing[k].insert(passing[k].end(), members.begin(), members.end());
-            });
-        });
         std::vector<char> seen(facts.size(), 0);
         for (const auto &part : passing)
             for (int m : part)
