@@ -499,6 +499,25 @@ int main(int argc, char **argv)
     }
 
     trace.lap("paths rescue");
+    // all_hit_segs.txt is written by a thread of its own while this one writes the graph (its complaints are made behind the graph's)
+    std::string hits_err;
+    std::thread t_hits([&] {
+        FILE *hits = std::fopen(hit_segs_path, "wb");
+        if (!hits) { hits_err = std::string("cannot write ") + hit_segs_path; return; }
+        {
+            std::string block;
+            block.reserve(hit_rows.size() * 56);
+            for (const auto &row : hit_rows) {
+                block += "SAMPLE\t";
+                block.append(names.names[static_cast<size_t>(row.first)]);
+                block += '\t';
+                block += row.second;
+                block += '\n';
+            }
+            std::fwrite(block.data(), 1, block.size(), hits);
+        }
+        if (std::fclose(hits) != 0) hits_err = std::string("write failed: ") + hit_segs_path;
+    });
     FILE *out = std::fopen(out_path, "wb");
     if (!out) die(std::string("cannot write ") + out_path);
     std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &a, const Piece &b) { return a.src < b.src; });
@@ -530,21 +549,8 @@ int main(int argc, char **argv)
     }
     if (std::fclose(out) != 0) die(std::string("write failed: ") + out_path);
 
-    FILE *hits = std::fopen(hit_segs_path, "wb");
-    if (!hits) die(std::string("cannot write ") + hit_segs_path);
-    {
-        std::string block;
-        block.reserve(hit_rows.size() * 56);
-        for (const auto &row : hit_rows) {
-            block += "SAMPLE\t";
-            block.append(names.names[static_cast<size_t>(row.first)]);
-            block += '\t';
-            block += row.second;
-            block += '\n';
-        }
-        std::fwrite(block.data(), 1, block.size(), hits);
-    }
-    if (std::fclose(hits) != 0) die(std::string("write failed: ") + hit_segs_path);
+    t_hits.join();                                            // all_hit_segs.txt was written meanwhile
+    if (!hits_err.empty()) die(hits_err);
     trace.lap("outputs");
     std::fflush(nullptr);
     _exit(0);                   // both outputs are complete and closed: skip tearing down a million small host containers
