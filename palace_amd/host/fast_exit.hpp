@@ -6,14 +6,22 @@
 // address space is torn down behind the caller's back.  A child that ends any other way (an error return, a signal) reports
 // nothing: the original process then waits for it and passes its exit status on, so every failure path behaves as before.
 // PALACE_NO_FORK=1 keeps everything in one process (debuggers, sanitizers).
+// A process in which the GPU is ALREADY initialised when main() starts must not fork and go on using HIP in the child (ROCm
+// does not support that: errors, or a hung GPU): that is the case under rocprofv3 and other tools whose preloaded library
+// opens the device before main().  gpu_touched_before_main() looks for the signs -- a tool / preload variable in the
+// environment, or /dev/kfd among the open descriptors -- and the program then stays one process, as with PALACE_NO_FORK=1.
 #pragma once
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <csignal>
+#include <dirent.h>
 #include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
+
+extern char** environ;
 
 namespace palace_host {
 
@@ -34,9 +42,37 @@ struct FastExit {
     }
 };
 
+inline bool gpu_touched_before_main()
+{
+    static const char* const exact[] = {"LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCP_TOOL_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE"};
+    for (char** e = ::environ; e && *e; ++e) {
+        const char* eq = std::strchr(*e, '=');
+        if (!eq || !eq[1]) continue;                                    // unset or empty: not in force
+        const size_t n = static_cast<size_t>(eq - *e);
+        for (const char* k : exact)
+            if (std::strlen(k) == n && std::strncmp(*e, k, n) == 0) return true;
+        if (std::strncmp(*e, "ROCPROF", 7) == 0 || std::strncmp(*e, "ROCTRACER", 9) == 0) return true;     // ROCPROFILER_*, ROCPROFV3_*, ...
+    }
+    if (DIR* d = ::opendir("/proc/self/fd")) {                          // the kernel driver's node already open: a runtime is up in this process
+        bool kfd = false;
+        char link[64], path[300];
+        while (const dirent* de = ::readdir(d)) {
+            if (de->d_name[0] == '.') continue;
+            std::snprintf(path, sizeof path, "/proc/self/fd/%s", de->d_name);
+            const ssize_t k = ::readlink(path, link, sizeof link - 1);
+            if (k <= 0) continue;
+            link[k] = 0;
+            if (std::strcmp(link, "/dev/kfd") == 0 || std::strncmp(link, "/dev/dri/renderD", 16) == 0) { kfd = true; break; }
+        }
+        ::closedir(d);
+        if (kfd) return true;
+    }
+    return false;
+}
+
 inline FastExit fast_exit_begin()
 {
-    if (std::getenv("PALACE_NO_FORK")) return {};
+    if (std::getenv("PALACE_NO_FORK") || gpu_touched_before_main()) return {};
     int p[2];
     if (::pipe(p) != 0) return {};
     std::fflush(nullptr);

@@ -9,6 +9,8 @@
 //   hostdump fmtg <n> <seed>           format_g6 (textio.hpp) against snprintf("%g") on n values of every kind (random bits, quotients of
 //                                      integers as SEG depths are, decimals at and next to rounding ties); prints the number of differences
 //   hostdump fasta <file.fa> [threads] one line per record (ordinal, name, length, sequence); with threads: parse_fasta_mt
+//   hostdump forkcheck x               "1" when the executables would stay one process here (fast_exit.hpp: a profiler / preload in
+//                                      the environment, or a GPU runtime already open), else "0"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -17,6 +19,7 @@
 #include <string>
 
 #include "bam.hpp"
+#include "fast_exit.hpp"
 #include "fastx.hpp"
 
 using namespace palace_host;
@@ -26,7 +29,9 @@ int main(int argc, char **argv)
     if (argc < 3) { std::cerr << "usage: hostdump bam|fastq|fasta <file> [threads]\n"; return 2; }
     const std::string mode = argv[1];
     try {
-        if (mode == "bam") {
+        if (mode == "forkcheck") {
+            std::printf("%d\n", (std::getenv("PALACE_NO_FORK") || gpu_touched_before_main()) ? 1 : 0);
+        } else if (mode == "bam") {
             BamColumns c;
             load_bam(argv[2], argc > 3 ? std::atoi(argv[3]) : 4, 1, c);
             for (size_t i = 0; i < c.target_name.size(); i++) std::printf("@SQ\t%s\t%d\n", c.target_name[i].c_str(), c.target_len[i]);

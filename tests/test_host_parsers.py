@@ -320,3 +320,21 @@ def test_bam_decode_in_chunks_behind_the_walk_is_thread_count_independent(tmp_pa
         assert out.count(b"\n") == 60 + 90000
         digests.add(hashlib.sha256(out).hexdigest())
     assert len(digests) == 1
+
+
+def test_executables_stay_one_process_under_a_profiler_or_preload():
+    """host/fast_exit.hpp: the fork-first start-up of eref / generateGraph / matching is skipped when the GPU may already be
+    initialised before main() (rocprofv3 and other preloaded tools): a child of such a process must not use HIP"""
+    def check(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "PALACE_NO_FORK")
+             and not k.startswith(("ROCPROF", "ROCTRACER"))}
+        e.update(env)
+        p = subprocess.run([HOSTDUMP, "forkcheck", "x"], stdout=subprocess.PIPE, env=e, check=True)
+        return p.stdout.strip()
+    assert check() == b"0"
+    assert check(LD_PRELOAD="") == b"0"                                  # empty: nothing is preloaded
+    assert check(HSA_TOOLS_LIB="librocprofiler-sdk-tool.so") == b"1"
+    assert check(ROCP_TOOL_LIBRARIES="/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so") == b"1"
+    assert check(ROCPROFILER_LIBRARY_CTOR="1") == b"1"
+    assert check(ROCPROF_OUTPUT_PATH="/tmp/x") == b"1"
+    assert check(PALACE_NO_FORK="1") == b"1"
