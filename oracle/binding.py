@@ -216,6 +216,61 @@ class GraphInput:
         self.R = _OrcRecords(n, *(a.ctypes.data for a in (flag, tid, pos, mtid, mpos, mapq, nm, cigar_off, cigar, qoff,
                                                           qn, saoff, sa, has_sa)))
 
+    @classmethod
+    def from_columns(cls, col, sa_off, sa, names, lens):
+        """The same records from DECODED COLUMNS (what bench.py holds in HBM and palace_amd/bin/synthbam writes as a BAM), built with
+        numpy so that millions of records marshal in seconds: record i is qname "q<qkey & 2^48-1 in hex>", CIGAR <ref_len>M[<clip_e>S]
+        (150M when nothing is clipped), NM, and for a record with SA items the tag text "<name>,<pos>,<+|->,<clip_s>S<len-clip_s>M,
+        <mapq>,<nm>;" per item -- character for character what synthbam puts into the file (palace_amd/host/synthbam_main.cpp:98-130).
+        col: dict of arrays tid pos mtid mpos nm ref_len clip_e flag mapq qkey; sa_off: n+1; sa: rows of 8 int32
+        (tid2 pos2 mapq2 nm2 clip_s2 clip_e2 len2 rev2)."""
+        self = cls.__new__(cls)
+        n = len(col["tid"])
+        self.n, self.n_targets = n, len(names)
+        i32 = lambda k: np.ascontiguousarray(col[k], dtype=np.int32)
+        flag = np.ascontiguousarray(np.asarray(col["flag"]).view(np.uint16) if np.asarray(col["flag"]).dtype.itemsize == 2 else col["flag"], dtype=np.uint16)
+        tid, pos, mtid, mpos, nm = i32("tid"), i32("pos"), i32("mtid"), i32("mpos"), i32("nm")
+        mapq = np.ascontiguousarray(col["mapq"], dtype=np.uint8)
+        ref_len, clip_e = i32("ref_len").astype(np.uint32), i32("clip_e").astype(np.uint32)
+        clipped = clip_e != 0
+        cigar_off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(1 + clipped.astype(np.int64), out=cigar_off[1:])
+        cigar = np.zeros(int(cigar_off[-1]) + 1, dtype=np.uint32)
+        cigar[cigar_off[:-1]] = np.where(clipped, ref_len << np.uint32(4), np.uint32(150 << 4))          # M = 0
+        cigar[cigar_off[:-1][clipped] + 1] = (clip_e[clipped] << np.uint32(4)) | np.uint32(4)            # S = 4
+        # qname: "q" + hex of the low 48 bits without leading zeros ("q0" for zero), as printf("%llx")
+        q = np.asarray(col["qkey"]).view(np.uint64) & np.uint64(0xffffffffffff)
+        nib = ((q[:, None] >> (np.arange(11, -1, -1, dtype=np.uint64) * np.uint64(4))[None, :]) & np.uint64(15)).astype(np.uint8)
+        lead = np.minimum((np.cumsum(nib != 0, axis=1) == 0).sum(axis=1), 11)                            # leading zero nibbles (keep one digit)
+        qlen = 13 - lead                                                                                   # 'q' + digits
+        qoff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(qlen, out=qoff[1:])
+        qn = np.zeros(int(qoff[-1]) + 1, dtype=np.uint8)
+        qn[qoff[:-1]] = ord("q")
+        hexch = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)[nib]
+        keep = np.arange(12)[None, :] >= lead[:, None]
+        dst = (qoff[:-1] + 1 - lead)[:, None] + np.arange(12)[None, :]
+        qn[dst[keep]] = hexch[keep]
+        del nib, hexch, keep, dst
+        # SA text: only the few per cent of records that carry items take the Python loop
+        so = np.asarray(sa_off, dtype=np.int64)
+        cnt = so[1:] - so[:-1]
+        has_sa = (cnt > 0).astype(np.uint8)
+        rows = np.asarray(sa).reshape(-1, 8)
+        texts = [b""] * n
+        for i in np.flatnonzero(cnt > 0).tolist():
+            texts[i] = "".join(f"{names[it[0]]},{it[1]},{'-' if it[7] else '+'},{it[4]}S{it[6] - it[4]}M,{it[2]},{it[3]};"
+                               for it in rows[so[i]:so[i + 1]].tolist()).encode()
+        saoff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.fromiter((len(t) for t in texts), dtype=np.int64, count=n), out=saoff[1:])
+        sa_txt = np.frombuffer(b"".join(texts) + b"\0", dtype=np.uint8).copy()
+        self.tn, self.toff = _concat(names)
+        self.tlen = np.ascontiguousarray(lens, dtype=np.int32)
+        self._keep = [flag, tid, pos, mtid, mpos, mapq, nm, cigar_off, cigar, qn, qoff, sa_txt, saoff, has_sa]
+        self.R = _OrcRecords(n, *(a.ctypes.data for a in (flag, tid, pos, mtid, mpos, mapq, nm, cigar_off, cigar, qoff,
+                                                          qn, saoff, sa_txt, has_sa)))
+        return self
+
     def run(self, fastg_fai: str, avg_depth: float, opts: GraphOpts | None = None) -> bytes:
         o = opts or graph_default_opts()
         cap = 64 * 1024 * 1024 + 200 * self.n_targets

@@ -5,6 +5,13 @@
               writing other files than the five-process chain, results that differ from step to step) -- and every read of
               the workload counted through the packed entry (the bench's data path) equals the oracle's table.
   headline    the 1M-contig workload BASELINE.json's metric is quoted on: the same, plus every present ref reported.
+  configs[4]  the long-contig workload (100k contigs, N50 ~ 50 kb, 6.67 M records) through the same run.
+
+And at each of those sizes the files the EXECUTABLES wrote for the sample (`_graph.txt`, `_filtered_graph_pre.txt`, `_filtered_graph.txt`,
+all_hit_segs.txt, linear, cycle, cycle_nodup, `_all_result.txt`) against the checker's chain over ALL records of the sample
+(tests/oracle_chain.py: oracle/graph_oracle.cpp -> the golden-pinned Python filter_graph -> uniq -> oracle/match_oracle.cpp ->
+remove_cycle_dup), byte for byte; the bench itself asserts that the HBM-resident step's depth sums / copy numbers / edges read as that
+`_graph.txt` and its decomposition as that `_all_result.txt`, and that the one-process generateGraph writes the same files.
 """
 import json
 import os
@@ -19,9 +26,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(contigs):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--contigs", str(contigs), "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--soak-seconds", "0.5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=900)
+def run_bench(contigs, work=None, workload="default"):
+    """bench.py as the driver runs it (its own cross-checks decide the exit status); work: the directory its files -> files leg
+    writes the sample's files into and leaves them in"""
+    env = dict(os.environ)
+    if work is not None:
+        env.update(PALACE_BENCH_WORK_DIR=str(work), PALACE_BENCH_KEEP="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--contigs", str(contigs), "--workload", workload, "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--soak-seconds", "0.5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=900, env=env)
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
     line = json.loads(lines[0])
@@ -38,6 +50,7 @@ def check_line(line, contigs):
     e = line["e2e"]
     assert "error" not in e
     assert e["agrees_with_resident_step"] is True and e["all_result_identical_to_resident_step"] is True
+    assert e["graph_txt_identical_to_resident_step"] is True
     assert e["one_process_stage04"]["files_identical_to_the_chain"] is True
     assert e["refs_reported"] == c["refs_reported"] and e["junc_lines"] == c["graph"]["n_junc"] > 1000
     r = line["roofline"]
@@ -53,6 +66,34 @@ def check_line(line, contigs):
     assert st["classify"]["algorithmic_bytes_per_step"] >= 52 * n_reads
     assert line["value"] == pytest.approx(contigs / (line["ms_per_step"] * 1e-3))
     return c
+
+
+def files_equal_the_oracle_chain(work, line):
+    """every record of the sample through the checker's chain; each file the executables wrote must hold exactly that"""
+    import shutil
+
+    from tests import oracle_chain as oc
+    from bench import e2e
+    P = e2e.e2e_paths(str(work))
+    for k in ("fq1", "fq2", "bam"):                                    # (room: the chain below reads the decoded columns, not these)
+        os.remove(P[k])
+    want_graph, names, lens, avg, _ = oc.oracle_graph(P)
+    got_graph = open(P["graph"], "rb").read()
+    assert got_graph == want_graph, "generateGraph's _graph.txt differs from the oracle's over all records"
+    assert want_graph.count(b"\nJUNC ") == line["config"]["graph"]["n_junc"] > 1000
+    o_graph = os.path.join(str(work), "o_graph.txt")
+    open(o_graph, "wb").write(want_graph)
+    want = oc.oracle_stage04(P, o_graph, os.path.join(str(work), "o"), avg)
+    for k in ("pre", "filt", "allhit", "lin", "cyc", "nodup", "result"):
+        got = open(P[k], "rb").read()
+        if k in ("pre", "filt"):                                       # (SEG block: a set iteration in the reference script, SURVEY F4)
+            assert oc.split_graph(got) == oc.split_graph(want[k]), k
+        assert got == want[k], f"{k}: the executables' file differs from the oracle chain's"
+        assert open(P[k] + ".fused", "rb").read() == want[k], f"{k}: the one-process generateGraph's file differs from the oracle chain's"
+    n_seg, n_junc = want["filt"].count(b"SEG "), want["filt"].count(b"JUNC ")
+    assert n_seg == line["config"]["graph"]["n_segs_filtered"] and n_junc == line["config"]["graph"]["n_kept_junc"] > 100
+    assert want["result"].count(b"\n") > 1000 and want["result"].count(b"\t") > 1000
+    shutil.rmtree(str(work), ignore_errors=True)
 
 
 def count_packed_equals_oracle(contigs):
@@ -105,16 +146,26 @@ def count_packed_equals_oracle(contigs):
     assert pops[0] > pops[1] > pops[2] > 0
 
 
-def test_config2_500k_contigs_bench_checks_and_oracle_table():
-    line = run_bench(500_000)
+def test_config2_500k_contigs_bench_checks_oracle_chain_and_oracle_table(tmp_path):
+    line = run_bench(500_000, tmp_path / "w")
     c = check_line(line, 500_000)
     assert 150 <= c["refs_reported"] <= c["refs_present"] == 200        # (half the read depth of the 1M workload: a few refs fall short)
+    files_equal_the_oracle_chain(tmp_path / "w", line)
     count_packed_equals_oracle(500_000)
 
 
-def test_headline_1m_contigs_bench_checks_and_oracle_table():
-    line = run_bench(1_000_000)
+def test_headline_1m_contigs_bench_checks_oracle_chain_and_oracle_table(tmp_path):
+    line = run_bench(1_000_000, tmp_path / "w")
     c = check_line(line, 1_000_000)
     assert c["refs_reported"] == c["refs_present"] == 200
     assert line["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    files_equal_the_oracle_chain(tmp_path / "w", line)
     count_packed_equals_oracle(1_000_000)
+
+
+def test_config4_long_contigs_bench_checks_and_oracle_chain(tmp_path):
+    """100k contigs with N50 ~ 50 kb and 6.67 M records: half of the cross-contig pairs reach the exp-underflow gate (G5)"""
+    line = run_bench(100_000, tmp_path / "w", workload="long")
+    c = check_line(line, 100_000)
+    assert c["workload_kind"] == "long" and c["refs_reported"] == c["refs_present"] == 200
+    files_equal_the_oracle_chain(tmp_path / "w", line)

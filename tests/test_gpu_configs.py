@@ -300,6 +300,99 @@ def test_config4_long_contigs_full_size_and_oracle_sample(tmp_path):
     assert want.count("JUNC") > 0
 
 
+def filtered_graph_files(tmp_path, gs, contig_of, cn, edges, edge_flags):
+    """the filtered graph the device selected, as the text `matching` reads (SEG in filtered-graph id order, kept JUNCs), and contigs.paths"""
+    import bench
+    names = gs["names"]
+    gpath, ppath = str(tmp_path / "filtered_graph.txt"), str(tmp_path / "contigs.paths")
+    e = edges[(edge_flags & 6) != 0]
+    with open(gpath, "w") as f:
+        f.write("".join(f"SEG {names[c]} 1 {cn[c]} 0 0.000 0\n" for c in contig_of.tolist()))
+        f.write("".join(f"JUNC {names[l]} {'+-'[a]} {names[r_]} {'+-'[b]} {x} 0\n"
+                        for l, r_, a, b, x in zip(e["left"].tolist(), e["right"].tolist(), e["oL"].tolist(), e["oR"].tolist(),
+                                                  e["counts"].astype(np.int64).sum(axis=1).tolist())))
+    open(ppath, "w").write(bench.paths_text(names, gs["lens"], gs["side"]))
+    return gpath, ppath
+
+
+def test_config3_5m_contigs_graph_and_stage04_on_one_gpu(tmp_path):
+    """configs[3] (5M contigs, 33.3 M primary records) on ONE GPU, generateGraph's kernels and stage 04 at full size:
+      * classify + resolve + copy numbers over all records: one shot == four shards with ordinal bases; every record's reference
+        span is in the depth sums;
+      * a tenth of the records (3.3 M, from the middle of the sorted stream), exactly, against the oracle's `_graph.txt`;
+      * the stage-04 selection and the decomposition of the WHOLE graph on the device; the decomposition against
+        oracle/match_oracle.cpp on the filtered graph the device selected (2.2 M segments), with contigs.paths.
+    (The selection itself is compared with the checker's chain at the 500k / 1M / long workloads' full size in
+    tests/test_gpu_bench_workloads.py; the 8-GPU leg of this configuration needs the driver's node.)"""
+    import torch
+
+    import bench
+    from bench import e2e
+    from palace_amd import stage04_io
+    dev = torch.device("cuda", 0)
+    n_contigs, n_pairs = 5_000_000, 16_666_666
+    gs = bench.make_graph_sample(torch, dev, n_contigs, n_pairs)
+    gs["side"] = bench.make_side_inputs(gs)
+    torch.cuda.synchronize()
+    names, lens = gs["names"], gs["lens"]
+    assert gs["n"] == 2 * n_pairs
+    L, P = capi.lib(), (lambda t: t.data_ptr())
+    with capi.Ctx(0) as ctx:
+        cons1, cn1, e1, c1 = graph_on_gpu(ctx, gs, 0, gs["n"])
+        cons4, cn4, e4, _ = graph_on_gpu(ctx, gs, 0, gs["n"], shards=4)
+        assert np.array_equal(cons1, cons4) and np.array_equal(cn1, cn4) and e1.tobytes() == e4.tobytes()
+        assert len(e1) > 100_000 and len(c1) > 1_000_000
+        assert int(cons1.sum()) >= int(gs["col"]["ref_len"].sum().item())
+        del c1, cons4, cn4, e4
+        # ---- a tenth of the records against the oracle ----
+        m = gs["n"] // 10
+        lo = gs["n"] // 2 - m // 2
+        cons, cn, edges, _ = graph_on_gpu(ctx, gs, lo, lo + m)
+        col = {k: v[lo:lo + m].cpu().numpy() for k, v in gs["col"].items()}
+        so = gs["sa_off"][lo:lo + m + 1].cpu().numpy().astype(np.int64)
+        sa = gs["sa"][int(so[0]):max(int(so[-1]), int(so[0]) + 1)].cpu().numpy()
+        gin = orc.GraphInput.from_columns(col, so - so[0], sa, names, lens)
+        touched = np.zeros(n_contigs, dtype=bool)
+        touched[col["tid"]] = True
+        touched[col["mtid"][col["mtid"] >= 0]] = True
+        if so[-1] > so[0]:
+            touched[sa[: int(so[-1] - so[0]), 0]] = True
+        a, b, o1, o2 = gs["fastg_links"]
+        keep = touched[a] | touched[b]
+        q = "'"
+        fai = str(tmp_path / "g.fastg.fai")
+        with open(fai, "w") as f:
+            f.write("".join(f"{names[x]}{q if u else ''}:{names[y]}{q if (u ^ v) else ''};\t{lens[x]}\t0\t60\t61\n"
+                            for x, y, u, v in zip(a[keep].tolist(), b[keep].tolist(), o1[keep].tolist(), o2[keep].tolist())))
+        want = gin.run(fai, gs["avg_depth"])
+        del gin, col
+        got = e2e.graph_text(names, lens, cons, cn, edges, rank=gs["trank"].cpu().numpy())
+        assert got.encode() == want
+        assert want.count(b"\nJUNC ") > 1000
+        del got, want
+        # ---- stage 04 over the whole graph, on the device ----
+        side = gs["side"]
+        n_e = len(e1)
+        st = capi.Stage04(ctx, side["seed"], lens.astype(np.int32), gs["trank"].cpu().numpy(), lens.astype(np.int32), side["path_off"], side["path_tok"], 5)
+        d_e = ctx.upload(np.ascontiguousarray(e1).view(np.uint8).reshape(-1))
+        d_n = ctx.upload(np.array([n_e], np.int64))
+        d_cn = ctx.upload(cn1)
+        st.filter(d_e.ptr, d_n.ptr, n_e)
+        st.match(d_e.ptr, d_cn.ptr, 10, False, True)
+        res, contig_of = st.result()
+        got_lin, got_cyc = stage04_io.matching_text(res, contig_of, names, self_loops=True, break_cycles=False)
+        contig_of = np.asarray(contig_of).copy()
+        seg_flags, edge_flags = st.flags(n_e)
+        counts = st.counts()
+        st.close()
+    assert counts["segs_filtered"] == len(contig_of) > 1_000_000 and counts["juncs"] > 100_000
+    assert counts["kept_pass2"] + counts["kept_pass3_more"] == int(((edge_flags & 6) != 0).sum()) > 50_000
+    gpath, ppath = filtered_graph_files(tmp_path, gs, contig_of, cn1, e1, edge_flags)
+    lin, cyc = orc.match_run(gpath, ppath, 10, self_loops=True, cap=160 * len(contig_of) + (1 << 20))
+    assert got_lin.encode() == lin and got_cyc.encode() == cyc
+    assert lin.count(b"\t") > 100_000
+
+
 # ------------------------------------------------------------------------------------------------
 # E3 at its real threshold: more than 1 Gbase in fq1 switches the reference's read subsampling on
 # ------------------------------------------------------------------------------------------------

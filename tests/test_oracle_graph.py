@@ -1,6 +1,7 @@
 """oracle/graph_oracle.cpp against hand-derived expectations (no reference-run golden exists for
 generateGraph: htslib is absent, see the oracle's header)."""
 import dataclasses
+import os
 
 from oracle import binding as orc
 from tests import graph_cases as gc
@@ -94,3 +95,52 @@ def test_layout_tables_have_four_valid_rows_each():
     assert sum(gc.paired_case(*b)[1] is not None for b in BOOLS) == 4
     assert sum(gc.split_case(*b)[1] is not None for b in BOOLS) == 4
     assert sum(gc.split_case(*b, primary_first=False)[1] is not None for b in BOOLS) == 4
+
+
+def test_columns_marshalling_equals_the_record_route_and_the_chain_runs_on_cpu(tmp_path):
+    """GraphInput.from_columns (numpy, used at the bench workloads' full size) hands orc_graph_run the same records as the
+    per-record route through BamRecord texts; and the checker's chain over a work directory (tests/oracle_chain.py) gives the
+    native filter core's files on its graph (host logic only: no GPU in this test)."""
+    import subprocess
+    import sys
+
+    import torch
+
+    import bench
+    from tests import oracle_chain as oc
+    from bench import e2e
+    from palace_amd.synth import BamRecord
+    n_contigs, n_pairs = 20_000, 66_666
+    gs = bench.make_graph_sample(torch, torch.device("cpu"), n_contigs, n_pairs)
+    gs["side"] = bench.make_side_inputs(gs)
+    P = e2e.e2e_paths(str(tmp_path))
+    e2e.write_graph_inputs(gs, P, bam=False)
+    text, names, lens, avg, _ = oc.oracle_graph(P)
+    assert avg == gs["avg_depth"] and names == gs["names"]
+    c = {k: v.numpy() for k, v in gs["col"].items()}
+    so, sa = gs["sa_off"].numpy(), gs["sa"].numpy()
+    recs = []
+    for i in range(gs["n"]):
+        s_txt = None
+        if so[i + 1] > so[i]:
+            it = sa[so[i]]
+            s_txt = f"{names[it[0]]},{it[1]},{'-' if it[7] else '+'},{it[4]}S{it[6] - it[4]}M,{it[2]},{it[3]};"
+        cig = f"{c['ref_len'][i]}M{c['clip_e'][i]}S" if c["clip_e"][i] else "150M"
+        recs.append(BamRecord(f"q{int(c['qkey'][i]) & 0xffffffffffff:x}", int(c["flag"][i]) & 0xffff, int(c["tid"][i]), int(c["pos"][i]),
+                              int(c["mapq"][i]), cig, int(c["mtid"][i]), int(c["mpos"][i]), nm=int(c["nm"][i]), sa=s_txt))
+    want = orc.graph_run(recs, list(zip(names, lens.tolist())), P["fastg_fai"], avg)
+    assert text == want and text.count(b"JUNC ") > 100
+    part, *_ = oc.oracle_graph(P, 1000, 31000)                          # a record range marshals the same way
+    assert part == orc.graph_run(recs[1000:31000], list(zip(names, lens.tolist())), P["fastg_fai"], avg)
+    # the chain: Python filter (pinned to the reference script's goldens) == the native core, then matching + remove_cycle_dup
+    o_graph = str(tmp_path / "o_graph.txt")
+    open(o_graph, "wb").write(text)
+    out = oc.oracle_stage04(P, o_graph, str(tmp_path / "o"), avg)
+    core = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "palace_amd", "bin", "filter_graph")
+    if os.path.exists(core):
+        subprocess.run([sys.executable, os.path.join(oc.SCRIPTS, "filter_graph.py"), P["fastg_fai"], o_graph, str(tmp_path / "n_pre.txt"), f"{avg:.6g}", "0",
+                        P["hit"], P["score"], P["blast"], "0.7", P["fasta_fai"], str(tmp_path / "n_hits.txt"), P["paths"], "0.7"], check=True,
+                       env={k: v for k, v in os.environ.items() if k != "PALACE_FILTER_PY"})
+        assert open(tmp_path / "n_pre.txt", "rb").read() == out["pre"] and open(tmp_path / "n_hits.txt", "rb").read() == out["allhit"]
+    assert out["filt"].count(b"SEG ") > 1000 and out["filt"].count(b"JUNC ") > 50 and out["result"].count(b"\t") > 100
+    assert out["result"] == out["lin"] + out["nodup"]
