@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-from .sample import READ_LEN, paths_text
+from .sample import READ_LEN, paths_text, progress
 
 
 def fastq_to_file(torch, reads, n, tag, path):
@@ -143,6 +143,7 @@ def run_e2e(P, avg_depth, n_contigs, rows_host, n_junc_expected, result_text_exp
     import subprocess
     B = os.path.join(ROOT, "palace_amd", "bin")
     S = os.path.join(ROOT, "palace_amd", "scripts")
+    fused_cmd = None
     threads = str(min(16, os.cpu_count() or 1))
     st = {}
 
@@ -178,10 +179,11 @@ def run_e2e(P, avg_depth, n_contigs, rows_host, n_junc_expected, result_text_exp
     try:
         fp = {k: P[k] + ".fused" for k in ("graph", "pre", "filt", "allhit", "lin", "cyc", "nodup", "result")}
         t0 = time.perf_counter()
-        subprocess.run([os.path.join(B, "generateGraph"), "--hit-seqs", P["hit"], "--node-scores", P["score"], "--blast", P["blast"], "--fasta-fai", P["fasta_fai"],
-                        "--paths", P["paths"], "--filtered-pre", fp["pre"], "--filtered", fp["filt"], "--all-hit-segs", fp["allhit"], "--linear", fp["lin"],
-                        "--cycle", fp["cyc"], "--cycle-nodup", fp["nodup"], "--all-result", fp["result"], "-s", "-i", "10",
-                        P["bam"], P["fastg_fai"], fp["graph"], f"{avg_depth:.6g}"], check=True)
+        fused_cmd = [os.path.join(B, "generateGraph"), "--hit-seqs", P["hit"], "--node-scores", P["score"], "--blast", P["blast"], "--fasta-fai", P["fasta_fai"],
+                     "--paths", P["paths"], "--filtered-pre", fp["pre"], "--filtered", fp["filt"], "--all-hit-segs", fp["allhit"], "--linear", fp["lin"],
+                     "--cycle", fp["cyc"], "--cycle-nodup", fp["nodup"], "--all-result", fp["result"], "-s", "-i", "10",
+                     P["bam"], P["fastg_fai"], fp["graph"], f"{avg_depth:.6g}"]
+        subprocess.run(fused_cmd, check=True)
         t_fused = time.perf_counter() - t0
         same = all(open(fp[k], "rb").read() == open(P[k], "rb").read() for k in ("graph", "pre", "filt", "allhit", "lin", "cyc", "nodup", "result"))
         fused = dict(seconds=st["eref"] + t_fused, contigs_per_s=n_contigs / (st["eref"] + t_fused),
@@ -191,6 +193,30 @@ def run_e2e(P, avg_depth, n_contigs, rows_host, n_junc_expected, result_text_exp
                           "cycle_nodup / all_result (its --filtered-pre ... --all-result options)")
     except Exception as e:
         fused = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
+    # The executables fork first thing and the process the caller started leaves when every output is closed, while the worker's
+    # address space is torn down behind its back (host/fast_exit.hpp).  The same three programs as ONE process each
+    # (PALACE_NO_FORK=1: the wait includes the teardown, as it does for any CPU comparator), outputs to scratch names:
+    nf = {}
+    progress("e2e: chain and one-process run done; the same as single processes (PALACE_NO_FORK=1)")
+    try:
+        env1 = dict(os.environ, PALACE_NO_FORK="1")
+        time.sleep(0.5)                              # (the last worker above may still be going away)
+        with open(P["refnames"] + ".nofork", "wb") as f:
+            t0 = time.perf_counter(); subprocess.run(eref, check=True, stdout=f, env=env1); nf["eref"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        subprocess.run([os.path.join(B, "generateGraph"), P["bam"], P["fastg_fai"], P["graph"] + ".nofork", f"{avg_depth:.6g}"], check=True, env=env1)
+        nf["generateGraph"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        subprocess.run([os.path.join(B, "matching"), "-g", P["filt"], "-r", P["lin"] + ".nofork", "-c", P["cyc"] + ".nofork", "-s", "-i", "10", "-l", P["paths"]],
+                       check=True, env=env1)
+        nf["matching"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        subprocess.run([a + ".nofork" if a.endswith(".fused") else a for a in fused_cmd], check=True, env=env1)
+        nf["generateGraph_with_stage04"] = time.perf_counter() - t0
+        nf["same_outputs"] = bool(all(open(P[k] + ".nofork", "rb").read() == open(P[k], "rb").read() for k in ("refnames", "graph", "lin", "cyc"))
+                                  and open(P["result"] + ".fused.nofork", "rb").read() == open(P["result"], "rb").read())
+    except Exception as e:
+        nf = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
     # cross-check against the HBM-resident step (same coder header, same sample): reported refs and kept junctions
     r = rows_host
     want = {(i + 1, int(r[i, 0]), int(r[i, 1])) for i in range(len(r))
@@ -200,7 +226,16 @@ def run_e2e(P, avg_depth, n_contigs, rows_host, n_junc_expected, result_text_exp
     total = sum(v for k, v in st.items() if k != "eref_first_run_builds_index")
     same_result = None if result_text_expected is None else bool(open(P["result"]).read() == result_text_expected)
     same_graph = None if graph_text_expected is None else bool(open(P["graph"]).read() == graph_text_expected)
-    return dict(seconds=total, contigs_per_s=n_contigs / total, stage_s={k: round(v, 3) for k, v in st.items()},
+    no_fork = nf
+    if "error" not in nf:
+        chain_nf = total - st["eref"] - st["generateGraph"] - st["matching"] + nf["eref"] + nf["generateGraph"] + nf["matching"]
+        no_fork = dict(seconds=chain_nf, contigs_per_s=n_contigs / chain_nf, stage_s={k: round(v, 3) for k, v in nf.items() if k != "same_outputs"},
+                       one_process_stage04_seconds=nf["eref"] + nf["generateGraph_with_stage04"],
+                       one_process_stage04_contigs_per_s=n_contigs / (nf["eref"] + nf["generateGraph_with_stage04"]), same_outputs=nf["same_outputs"],
+                       note="PALACE_NO_FORK=1: eref, generateGraph and matching as one process each, so that the wait for a stage includes the "
+                            "teardown of its address space (mapped inputs, the inflated BAM stream, the HIP runtime) -- the like-for-like figure "
+                            "beside a CPU comparator timed to process exit; the other stages of the chain as timed above")
+    return dict(seconds=total, contigs_per_s=n_contigs / total, no_fork=no_fork, stage_s={k: round(v, 3) for k, v in st.items()},
                 agrees_with_resident_step=bool(got == want and n_junc == n_junc_expected and same_result is not False and same_graph is not False),
                 all_result_identical_to_resident_step=same_result, graph_txt_identical_to_resident_step=same_graph, one_process_stage04=fused,
                 refs_reported=len(got), junc_lines=n_junc, result_lines=sum(1 for _ in open(P["result"])),

@@ -5,6 +5,17 @@ import numpy as np
 SEED = 20261003
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 READ_LEN = 150
+_T0 = [None]
+
+
+def progress(msg):
+    """one line on stderr with the seconds since the first call: a run that takes minutes says where it is (and a watcher that
+    takes silence for a hang sees it alive)"""
+    import sys
+    import time
+    if _T0[0] is None:
+        _T0[0] = time.perf_counter()
+    print(f"[bench {time.perf_counter() - _T0[0]:7.1f} s] {msg}", file=sys.stderr, flush=True)
 
 
 def contig_lengths(n_contigs, long_mode):

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from .cpu_baseline import cpu_baseline
 from .e2e import graph_text, run_e2e, write_e2e_inputs
-from .sample import HBM_PEAK_GBS, READ_LEN, SEED, make_graph_sample, make_sample, make_side_inputs
+from .sample import HBM_PEAK_GBS, READ_LEN, SEED, make_graph_sample, make_sample, make_side_inputs, progress
 
 
 def roofline_stages(stages, traffic):
@@ -54,7 +54,7 @@ def measure(args, E, leg):
     sync_dist, sync_world = E.dist, E.world                               # barrier + max over ranks: always the real group
     force_exchange, force_key_split = (E.force_exchange and not solo), (E.force_key_split and not solo)
     collectives = world > 1 or force_exchange or force_key_split
-    from palace_amd import capi, coder, multigpu       # (oracle/ is imported by the cpu_baseline leg only)
+    from palace_amd import capi, coder, multigpu, stage04_io       # (oracle/ is imported by the cpu_baseline leg only)
 
     hdr = coder.header_from_picks(np.random.Generator(np.random.PCG64(SEED)).integers(0, 6, size=32))
     # Streams.  A: eref (count + scan).  B: generateGraph (classify, resolve, copy numbers) and stage 04 (selection + matching: ~150
@@ -139,6 +139,7 @@ def measure(args, E, leg):
         dist.all_reduce(tot)
         gs["avg_depth"] = float(f"{tot.item() / gs['lens'].sum():.6g}")
     torch.cuda.synchronize()
+    if rank == 0: progress(f"{leg}: sample generated on the device")
     one_min, three_min = capi.window_minimums(0.9, 0.85)
     L = capi.lib()
     P = lambda t: t.data_ptr()
@@ -441,6 +442,7 @@ def measure(args, E, leg):
             torch.cuda.synchronize()
 
     torch.cuda.synchronize()                         # every buffer torch made above is filled before a library stream touches it
+    if rank == 0: progress(f"{leg}: resident inputs ready; warm-up")
     for _ in range(args.warmup):
         step(0, False)
     barrier()
@@ -454,6 +456,7 @@ def measure(args, E, leg):
         sync_dist.all_reduce(tmax, op=sync_dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_step = 1e3 * dt / args.steps
+    if rank == 0: progress(f"{leg}: {args.steps} timed steps, {ms_step:.2f} ms each")
     # soak: the K timed steps above are what `value` is computed from; when they took less than --soak-seconds the same
     # step keeps running (untimed for `value`) so that an outside GPU-activity sampler has something to see
     soak = None
@@ -559,10 +562,11 @@ def measure(args, E, leg):
             else:
                 work = tempfile.mkdtemp(prefix="palace_e2e_", dir=os.environ.get("PALACE_BENCH_TMP", "/tmp"))
             try:
+                progress("e2e: writing the sample's files")
                 paths = write_e2e_inputs(torch, sample, gs, hdr, work)
+                progress("e2e: running the executables on them")
                 n_junc = int((h_last["edges"]["counts"].sum(axis=1) >= 5).sum())
                 # what the resident step's result reads as text: linear ++ cycles without duplicates (palace:594-600)
-                from palace_amd import stage04_io
                 lin, cyc = stage04_io.matching_text(*h_last["result"], gs["names"], self_loops=True, break_cycles=False)
                 cl = cyc.splitlines(keepends=True)
                 pairs = list(dict.fromkeys(zip(cl[0::2], cl[1::2] + (["\n"] if len(cl) % 2 else []))))      # remove_cycle_dup.py:3-30
@@ -576,11 +580,18 @@ def measure(args, E, leg):
             work = paths = None
         try:
             if world == 1 and not solo and not args.no_cpu_baseline:         # (rank 0 at N = 1 only: the contract; the other ranks would wait for it)
+                progress("cpu_baseline")
                 res_v, contig_of = h_last["result"]
                 seg_flags, edge_flags = stage04.flags(len(h_last["edges"]))
+                lin, cyc = stage04_io.matching_text(res_v, contig_of, gs["names"], self_loops=True, break_cycles=False)
+                cl = cyc.splitlines(keepends=True)
+                pairs = list(dict.fromkeys(zip(cl[0::2], cl[1::2] + (["\n"] if len(cl) % 2 else []))))
                 out["cpu_baseline"] = cpu_baseline(torch, sample, gs, hdr, args.cpu_sample_frac,
-                                                   dict(contig_of=np.asarray(contig_of).copy(), cn=h_last["cn"], edges=h_last["edges"], edge_flags=edge_flags),
-                                                   bam_path=paths["bam"] if paths else None)
+                                                   dict(contig_of=np.asarray(contig_of).copy(), cn=h_last["cn"], edges=h_last["edges"], edge_flags=edge_flags,
+                                                        result_text=lin + "".join(a + b for a, b in pairs)), paths=paths)
+                for k, v in out["cpu_baseline"].get("parity", {}).items():     # the checker beside the timing: a free parity point per stage
+                    if v is False:
+                        failures.append(f"cpu_baseline.parity.{k} is False")
         finally:
             if work and not os.environ.get("PALACE_BENCH_KEEP"):              # (tools/eref_cli_repeat.sh re-runs the executables on these files)
                 import shutil
@@ -600,6 +611,8 @@ def measure(args, E, leg):
                 for k in ("agrees_with_resident_step", "all_result_identical_to_resident_step", "graph_txt_identical_to_resident_step"):
                     if e2e.get(k) is not True:
                         failures.append(f"e2e.{k} is {e2e.get(k)}")
+                if (e2e.get("no_fork") or {}).get("same_outputs") is False:
+                    failures.append("e2e.no_fork: the one-process runs wrote other outputs than the forked ones")
                 one = e2e.get("one_process_stage04") or {}
                 if one.get("files_identical_to_the_chain") is not True:
                     failures.append("e2e.one_process_stage04: " + str(one.get("error", "files differ from the chain's")))
