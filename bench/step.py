@@ -81,7 +81,12 @@ def measure(args, E, leg):
     ctx_s = capi.Ctx(local, cu_mask=(1 << s04_cus) - 1) if 0 < s04_cus < 256 else ctx_g
     if os.environ.get("PALACE_BENCH_GRAPHS", "0") == "1":     # stage 04 as two hipGraph launches per step (measured: host enqueue 1.25 -> 0.96 ms,
         ctx_s.match_set_option("launch_graphs", 1)            # the step 10.95 -> 11.08 ms: back to back the small kernels disturb the counting kernels more)
-    for opt in ("iters_per_round", "first_group_rounds"):    # tuning runs only
+    # the decomposition's arc- and vertex-sized phases on 256 workgroups here (the library's default is 2048: stage 04 alone on the
+    # device then takes 0.8 instead of 1.4 ms, beside the counting kernels 2.75 instead of 4.4 ms -- but as a shorter, denser burst of
+    # random atomics it costs the count launch 1.05 ms instead of 0.7, and the step is stream A's length: 10.1 against 9.86 ms, A/B
+    # on one box, tools/ab.sh r05d)
+    ctx_s.match_set_option("decomp_grid", 256)
+    for opt in ("iters_per_round", "first_group_rounds", "decomp_grid"):    # tuning runs only
         if os.environ.get("PALACE_OPT_" + opt.upper()):
             ctx_s.match_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
     # one GPU: a second eref context (own stream, own count table, own scratch) so that consecutive batches overlap
@@ -89,7 +94,7 @@ def measure(args, E, leg):
     ectx = [ctx] + [capi.Ctx(local) for _ in range(depth - 1)]
     for e in ectx:
         e.eref_set_coder(hdr)
-        for opt in ("slab_bases", "bin1_ppl", "level1_parts"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
+        for opt in ("slab_bases", "bin1_ppl", "level1_parts", "scatter_bits"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
             if os.environ.get("PALACE_OPT_" + opt.upper()):
                 e.eref_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
         if os.environ.get("PALACE_OPT_KEY_SHARE"):    # tuning runs only: count the share rank 0 of N would (results are then partial)

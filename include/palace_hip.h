@@ -166,10 +166,13 @@ int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t
 
 /* E5 with a per-DB probe index -- the analogue of the index file the reference builds once per DB
  * and then only reads (<fasta>.k32.index.dat, extract_ref.cpp:676-712, 1245-1251).  The index holds
- * the channel-0 index of every valid ref position grouped by table slice (8 B/position, device
- * memory) and depends on the ref set and the coder only, not on the reads.
+ * the channel-0 index of every valid ref position grouped by table slice (6 B/position in device
+ * memory: the low 16 bits of the index and, in a second array, the position) and depends on the ref
+ * set and the coder only, not on the reads.  A DB of up to 2^32 positions.
  * palace_eref_scan_refs_indexed gives exactly the rows of palace_eref_scan_refs for the same table;
- * it replaces the per-position random probe of channel 0 by a sequential pass over the index.
+ * it replaces the per-position random probe of channel 0 by a sequential pass over 2 B/position that
+ * leaves one hit BIT per index entry, and a scatter of the few per cent of entries that hit to their
+ * positions (the position array is only read for those).
  * Meant for a resident DB scanned against many samples; a one-shot run gains nothing from it. */
 typedef struct palace_eref_probe_index palace_eref_probe_index;
 int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_refs,
@@ -183,8 +186,8 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
  * the FINAL count (option final_count, one slab, the whole key space) tests the DB's positions of every fine bucket against
  * the bucket's final ">= 3" slice while that slice is still in LDS, and the next palace_eref_scan_refs_indexed with the same
  * index starts from those hits: no probe kernel, no second read of the plane.  Results are identical either way (any other
- * count call, a merge, an attach or a reset in between makes the scan probe for itself).  The index keeps one byte per DB
- * position for the hits: attach it to ONE context at a time.  ix = NULL detaches. */
+ * count call, a merge, an attach or a reset in between makes the scan probe for itself).  The index keeps the hit bits (one per
+ * entry): attach it to ONE context at a time, and scan with it from one context at a time.  ix = NULL detaches. */
 int palace_eref_attach_probe_index(palace_ctx *ctx, const palace_eref_probe_index *ix);
 
 

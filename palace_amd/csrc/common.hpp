@@ -83,6 +83,7 @@ struct palace_ctx {
     int64_t bin_cap_override = 0;
     int64_t slab_override = 0;
     int bin1_ppl = 0;               // level 1: positions per lane (0 = by key density)
+    bool scatter_bits = false;      // indexed scan: hit positions by atomicOr into the bit words instead of a byte per position
     palace::Workspace ws;      // grow-only scratch
     bool ws_grown = false;
     palace::Workspace pin;     // grow-only pinned host staging
@@ -92,6 +93,7 @@ struct palace_ctx {
     int64_t graph_border_n = -1;    // ... and how many candidates that call left there (a buffer that was appended to is not that call's)
     bool launch_graphs = false;     // option: stage 04 replays its launch sequences as hipGraphs
     int match_first_group = 0;      // rounds enqueued before the first look at the state (0 = default)
+    int match_grid = 0;             // workgroups of the decomposition's arc- and vertex-sized phases (0 = default; decomp.hip)
     int match_iters = 0;            // matching iterations enqueued per round (0 = defaults; tests lower it to force the checked path)
     uint64_t *d_small = nullptr;   // 64 x u64 scratch for reductions
 };

@@ -411,7 +411,15 @@ int scan_u64(palace_ctx *ctx, const uint64_t *in, uint64_t *out, const int32_t *
 
 namespace {
 
-const dim3 kGrid(kDecompGrid), kBlock(kDecompBlock);
+const dim3 kBlock(kDecompBlock);
+// Grid of the arc- and vertex-sized phases.  They are chains of dependent random look-ups (done -> src / dst -> alive / next /
+// prev -> the slot words): what bounds them is how many of those chains are in flight, not bytes.  With the scans' 256 workgroups
+// (one wave per SIMD) the first iteration of a round -- every arc open, half a million arcs at the 1M-contig sample -- took
+// 0.35 + 0.43 + 0.60 ms for its three passes, as much as the 22 iterations behind it together; with one thread per arc it is a few
+// waves of latency.  Still a fixed grid (the launch sequence does not depend on a number only the device knows): workgroups
+// beyond the arcs read one count and leave.  Option "decomp_grid" (palace_match_set_option).
+constexpr int kWideGridDefault = 2048;
+inline dim3 wide_grid(const palace_ctx *ctx) { return dim3(ctx->match_grid > 0 ? ctx->match_grid : kWideGridDefault); }
 
 // `n` matching iterations of one round; `first` = the number (inside the round) of the first of them, `count` = iterations
 // enqueued since the state was initialised (the stamp), flags[flag0 ..] their `changed` words.  The first iteration of a batch
@@ -421,19 +429,19 @@ void enqueue_iterations(palace_ctx *ctx, const DecompBufs &b, int first, int n, 
     for (int k = 0; k < n; k++) {
         IterArgs a{((1ull << 21) - 1 - *count) << kStampShift, (first + k) & 1, k ? flag0 + k - 1 : -1, flag0 + k, unique_hi ? 1 : 0};
         (*count)++;
-        hipLaunchKernelGGL(dec_propose_hi_kernel, kGrid, kBlock, 0, ctx->stream, b, a);
-        if (!unique_hi) hipLaunchKernelGGL(dec_propose_lo_kernel, kGrid, kBlock, 0, ctx->stream, b, a);
-        hipLaunchKernelGGL(dec_commit_kernel, kGrid, kBlock, 0, ctx->stream, b, a);
+        hipLaunchKernelGGL(dec_propose_hi_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, a);
+        if (!unique_hi) hipLaunchKernelGGL(dec_propose_lo_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, a);
+        hipLaunchKernelGGL(dec_commit_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, a);
     }
 }
 
 int enqueue_read_off(palace_ctx *ctx, const DecompBufs &b, int round, int last_flag)
 {
-    hipLaunchKernelGGL(dec_heads_kernel, kGrid, kBlock, 0, ctx->stream, b, round, last_flag);
-    hipLaunchKernelGGL(dec_cycles_kernel, kGrid, kBlock, 0, ctx->stream, b, round);
+    hipLaunchKernelGGL(dec_heads_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, round, last_flag);
+    hipLaunchKernelGGL(dec_cycles_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, round);
     int rc = scan_u64(ctx, b.len_a, b.pos, &b.st->V, b.partials, &b.st->scan_total);
     if (rc) return rc;
-    hipLaunchKernelGGL(dec_emit_kernel, kGrid, kBlock, 0, ctx->stream, b, round);
+    hipLaunchKernelGGL(dec_emit_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, round);
     hipLaunchKernelGGL(dec_round_end_kernel, dim3(1), dim3(64), 0, ctx->stream, b);
     PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
@@ -445,7 +453,7 @@ int decomp_begin(palace_ctx *ctx, const DecompBufs &b, int rounds, int64_t comp_
 {
     PALACE_REQUIRE(rounds >= 1 && rounds <= kMaxRounds, "round count out of range");
     static_assert(kDecompGrid <= kDecompBlock, "scan_prefix_kernel scans the block sums with one workgroup");
-    hipLaunchKernelGGL(dec_init_kernel, kGrid, kBlock, 0, ctx->stream, b, comp_cap, vert_cap, rounds * kMaxIters);
+    hipLaunchKernelGGL(dec_init_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, comp_cap, vert_cap, rounds * kMaxIters);
     PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
 }
@@ -455,7 +463,7 @@ int decomp_rounds(palace_ctx *ctx, const DecompBufs &b, int t0, int t1, int roun
 {
     PALACE_REQUIRE(0 <= t0 && t0 <= t1 && t1 <= rounds && rounds <= kMaxRounds && iters >= 1 && iters <= kMaxIters, "round / iteration count out of range");
     for (int t = t0; t < t1; t++) {
-        hipLaunchKernelGGL(dec_round_begin_kernel, kGrid, kBlock, 0, ctx->stream, b, (aggressive && t == rounds - 1) ? 1 : 0);
+        hipLaunchKernelGGL(dec_round_begin_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, (aggressive && t == rounds - 1) ? 1 : 0);
         enqueue_iterations(ctx, b, 0, iters, count, t * kMaxIters, unique_hi);       // stamps descend over the whole decomposition
         int rc = enqueue_read_off(ctx, b, t, t * kMaxIters + iters - 1);
         if (rc) return rc;
@@ -472,10 +480,10 @@ int decomp_run_checked(palace_ctx *ctx, const DecompBufs &b, int rounds, int agg
 {
     PALACE_REQUIRE(rounds >= 1 && rounds <= kMaxRounds, "round count out of range");
     constexpr int kBatch = 16;                                              // even: the klo parity carries over
-    hipLaunchKernelGGL(dec_init_kernel, kGrid, kBlock, 0, ctx->stream, b, comp_cap, vert_cap, kBatch);
+    hipLaunchKernelGGL(dec_init_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, comp_cap, vert_cap, kBatch);
     uint64_t count = 0;
     for (int t = 0; t < rounds; t++) {
-        hipLaunchKernelGGL(dec_round_begin_kernel, kGrid, kBlock, 0, ctx->stream, b, (aggressive && t == rounds - 1) ? 1 : 0);
+        hipLaunchKernelGGL(dec_round_begin_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, (aggressive && t == rounds - 1) ? 1 : 0);
         for (int first = 0;; first += kBatch) {
             PALACE_HIP_TRY(hipMemsetAsync(b.changed, 0, kBatch * sizeof(uint32_t), ctx->stream));
             enqueue_iterations(ctx, b, first, kBatch, &count, 0, unique_hi);

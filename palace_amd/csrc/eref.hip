@@ -787,15 +787,23 @@ constexpr int kCountThreads = 256;
 // buckets) are tested against it and their hit bytes set: the scan that follows needs neither the probe kernel nor its read
 // of the plane (palace_eref_attach_probe_index).
 struct ProbeArgs {
-    const unsigned long long *first, *entries;             // [65537] group starts, entries (position id << 18 | index & 0x3ffff)
-    uint8_t *hit_bytes;                                     // a byte per DB position, zero before the launch
+    const unsigned long long *first;                        // [65537] start of every fine bucket's entries (multiples of 8)
+    const uint16_t *keys16;                                 // channel-0 index & 0xffff of every DB position, grouped by fine bucket
+    uint8_t *ehits;                                         // a BIT per entry, in entry order (byte i = entries 8 i .. 8 i + 7), zero before the launch
 };
-template <int THREADS, int BATCH>
-__device__ __forceinline__ void probe_first_batch(const unsigned long long *__restrict__ entries, unsigned long long e0, unsigned long long hi,
-                                                  ulonglong2 (&cur)[BATCH]);
-template <int THREADS, int BATCH, bool DOUBLE>
-__device__ __forceinline__ void probe_group(const uint32_t *l3, uint32_t key_mask, const unsigned long long *__restrict__ entries,
-                                            unsigned long long e0, unsigned long long hi, ulonglong2 (&cur)[BATCH], uint8_t *__restrict__ hit_bytes);
+// the eight 16-bit entries of one 16-byte vector against a 2^16-bit slice in LDS -> a byte of hit bits
+__device__ __forceinline__ uint32_t probe_vector(const uint32_t *__restrict__ l3, const uint4 &v)
+{
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const uint32_t k0 = d[e] & 0xffffu, k1 = d[e] >> 16;
+        m |= ((l3[k0 >> 5] >> (k0 & 31)) & 1u) << (2 * e);
+        m |= ((l3[k1 >> 5] >> (k1 & 31)) & 1u) << (2 * e + 1);
+    }
+    return m;
+}
 
 template <bool CLEAN, bool FINAL = false, bool PROBE = false>
 __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const unsigned int *__restrict__ cursor,
@@ -807,12 +815,11 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
                                                                        ProbeArgs pr)
 {
     __shared__ uint32_t l1[kFineWords], l2[kFineWords], l3[kFineWords];
-    __shared__ uint32_t hit_n;
     const uint32_t b = blockIdx.x, b1 = b / kL2Rows;
     if (!share.bucket(b1)) return;                          // a call that counts a share of the key space: not its bucket
-    constexpr int kProbeBatch = 6;                          // pair loads per thread and batch: a bucket's group (~3000 entries, ~12 per thread) is ONE batch
-    unsigned long long pe0 = 0, phi = 0;
-    if (PROBE) { pe0 = pr.first[b]; phi = pr.first[b + 1]; }
+    constexpr int kProbeBatch = 2;                          // 16-byte vectors (8 entries each) per thread and batch: a bucket's ~3000 entries are ONE batch
+    unsigned long long pe0 = 0, phi = 0;                    // the bucket's entries, in vectors of 8
+    if (PROBE) { pe0 = pr.first[b] / 8; phi = pr.first[b + 1] / 8; }
     // the bucket's keys lie in eight sub-regions (one per XCD that wrote them); as one sequence of 16-byte vectors of eight
     // keys: vector j belongs to sub-region x with first[x] <= j < first[x + 1]
     const uint32_t sub_cap = fine_sub_cap(caps, b1);
@@ -830,12 +837,11 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
             uint4 *z1 = reinterpret_cast<uint4 *>(p1 + w0), *z2 = reinterpret_cast<uint4 *>(p2 + w0);
             for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) z1[i] = z2[i] = uint4{0, 0, 0, 0};
             if (PROBE && phi > pe0) {                              // ... and is what the DB's positions of this bucket are tested against
-                ulonglong2 cur[kProbeBatch];
-                probe_first_batch<kCountThreads, kProbeBatch>(pr.entries, pe0, phi, cur);
                 const uint4 *s3 = reinterpret_cast<const uint4 *>(p3 + w0);
                 for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) reinterpret_cast<uint4 *>(l3)[i] = s3[i];
                 __syncthreads();
-                probe_group<kCountThreads, kProbeBatch, false>(l3, 0xffffu, pr.entries, pe0, phi, cur, pr.hit_bytes);
+                const uint4 *pv = reinterpret_cast<const uint4 *>(pr.keys16);
+                for (unsigned long long i = pe0 + threadIdx.x; i < phi; i += kCountThreads) pr.ehits[i] = static_cast<uint8_t>(probe_vector(l3, pv[i]));
             }
         }
         return;                                            // (no key at all: the slice is zero, no position of the DB hits)
@@ -867,9 +873,16 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
         ok[u] = 0; v[u] = uint4{0, 0, 0, 0};
         if (i < n8) v[u] = *locate(i, ok[u]);
     }
-    // PROBE: the bucket's group of the DB's probe index is requested now and is in flight during the whole count phase
-    ulonglong2 pcur[kProbeBatch];
-    if (PROBE && phi > pe0) probe_first_batch<kCountThreads, kProbeBatch>(pr.entries, pe0, phi, pcur);
+    // PROBE: the bucket's entries of the DB's probe index are requested now and are in flight during the whole count phase
+    uint4 pcur[kProbeBatch];
+    if (PROBE) {
+        const uint4 *pv = reinterpret_cast<const uint4 *>(pr.keys16);
+#pragma unroll
+        for (int u = 0; u < kProbeBatch; u++) {
+            const unsigned long long i = pe0 + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
+            pcur[u] = i < phi ? pv[i] : uint4{0, 0, 0, 0};
+        }
+    }
     const bool seed = !CLEAN || ((touched[b >> 5] >> (b & 31)) & 1u);      // uniform for the workgroup
     // (two loops, not `seed ? g[i] : zero` in one: for that the compiler selects between the global ADDRESS and the address of
     // a zero it keeps in scratch memory, and the clean case pays three flat loads per lane and round all the same)
@@ -911,43 +924,14 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
         for (int u = 0; u < kBatch; u++) { v[u] = nx[u]; ok[u] = nok[u]; }
     }
     __syncthreads();
-    // PROBE: the entries are tested against the final slice; a hit goes to a list in LDS (plane 1's slice: dead in a final count),
-    // and the bytes are stored at the very end.  No global store is issued before the last entry load has come back: a wave's
-    // vmcnt counts loads and stores together and the compiler has to wait for ALL of them once both kinds are in flight, so a
-    // second batch of entries behind the first batch's hit stores would wait for those random byte stores to be acknowledged
-    uint32_t n_hits = 0;
-    if (PROBE && phi > pe0) {
-        static_assert(!PROBE || FINAL, "the hit list lives in the slice of plane 1");
-        if (threadIdx.x == 0) hit_n = 0;
-        __syncthreads();
-        const unsigned long long lo = pe0 & ~1ull, n2 = (phi - lo + 1) / 2;
-        const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(pr.entries + lo);
-        constexpr unsigned long long kStride = static_cast<unsigned long long>(kProbeBatch) * kCountThreads;
-        auto test = [&](unsigned long long ent, unsigned long long at) {
-            if (at < pe0 || at >= phi) return;
-            const uint32_t k = static_cast<uint32_t>(ent) & 0xffffu;
-            if ((l3[k >> 5] >> (k & 31)) & 1u) {
-                const uint32_t slot = atomicAdd(&hit_n, 1u);
-                if (slot < kFineWords) l1[slot] = static_cast<uint32_t>(ent >> kBucketShift);     // (position ids fit 32 bits: checked by the host)
-                else pr.hit_bytes[ent >> kBucketShift] = 1;                                     // list full (a bucket with > 2048 hits): directly
-            }
-        };
-        for (unsigned long long i0 = threadIdx.x; i0 < n2; i0 += kStride) {
+    // PROBE: the entries are tested against the final slice, eight to a byte of hit bits IN ENTRY ORDER (what position an entry
+    // belongs to is the business of the scatter kernel of the scan).  No global store is issued before the last entry load has
+    // come back: a wave's vmcnt counts loads and stores together and the compiler has to wait for ALL of them once both kinds are
+    // in flight.  A bucket with more entries than one batch holds (> 4096) tests the rest behind the slice's write-back.
+    uint32_t pm[kProbeBatch];
+    if (PROBE) {
 #pragma unroll
-            for (int u = 0; u < kProbeBatch; u++) {
-                const unsigned long long i = i0 + static_cast<unsigned long long>(u) * kCountThreads;
-                if (i < n2) { test(pcur[u].x, lo + 2 * i); test(pcur[u].y, lo + 2 * i + 1); }
-            }
-            if (i0 - threadIdx.x + kStride < n2) {             // (uniform) a group larger than one batch
-#pragma unroll
-                for (int u = 0; u < kProbeBatch; u++) {
-                    const unsigned long long i = i0 + kStride + static_cast<unsigned long long>(u) * kCountThreads;
-                    pcur[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
-                }
-            }
-        }
-        __syncthreads();
-        n_hits = min(hit_n, static_cast<uint32_t>(kFineWords));
+        for (int u = 0; u < kProbeBatch; u++) pm[u] = probe_vector(l3, pcur[u]);
     }
     uint4 *o1 = reinterpret_cast<uint4 *>(p1 + w0), *o2 = reinterpret_cast<uint4 *>(p2 + w0),
           *o3 = reinterpret_cast<uint4 *>(p3 + w0);
@@ -960,8 +944,16 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
         }
         o3[i] = reinterpret_cast<const uint4 *>(l3)[i];
     }
-    if (PROBE)
-        for (uint32_t i = threadIdx.x; i < n_hits; i += kCountThreads) pr.hit_bytes[l1[i]] = 1;
+    if (PROBE) {
+#pragma unroll
+        for (int u = 0; u < kProbeBatch; u++) {
+            const unsigned long long i = pe0 + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
+            if (i < phi) pr.ehits[i] = static_cast<uint8_t>(pm[u]);
+        }
+        const uint4 *pv = reinterpret_cast<const uint4 *>(pr.keys16);
+        for (unsigned long long i = pe0 + threadIdx.x + static_cast<unsigned long long>(kProbeBatch) * kCountThreads; i < phi; i += kCountThreads)
+            pr.ehits[i] = static_cast<uint8_t>(probe_vector(l3, pv[i]));
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1149,11 +1141,16 @@ __device__ __forceinline__ uint32_t prefix_count(const uint64_t *__restrict__ wo
 // E5 with a probe index: the reference reads the three indices of every ref position from a file it
 // built once per DB (<fasta>.k32.index.dat, 12 B/position, extract_ref.cpp:676-712) instead of
 // recomputing them.  The analogue here is built once per DB and kept in HBM: the channel-0 index of
-// every valid ref position, grouped by fine bucket (index >> 18), 8 B per position =
-// (position id << 18) | (index & 0x3ffff), position id = 64 * (word of the ref's hit bitmap) + bit.
-// A scan then tests each group against its 32 KiB slice of plane 3 in LDS -- sequential reads of
-// 8 B/position instead of one random 64-byte sector per position -- and sets the hit bit of the few
-// positions that hit.  Channels 1 and 2 keep the pruned recompute-and-probe path.
+// every valid ref position, grouped by the count kernel's fine buckets (index >> 16), as two arrays in
+// ENTRY order: `keys16` (index & 0xffff, 2 B) and `pos` (position id = 64 * (word of the ref's hit
+// bitmap) + bit, 4 B); a bucket's entries start on a multiple of 8 (pad entries: key 0, pos ~0).
+// A scan tests each group of four buckets against its 32 KiB slice of plane 3 in LDS -- sequential
+// reads of 2 B/position instead of one random 64-byte sector per position -- and writes one hit BIT per
+// entry, in entry order (eref_probe2_kernel; or the count launch does, palace_eref_attach_probe_index);
+// eref_ehits_scatter_kernel then carries the few per cent of entries that hit to their positions
+// (`pos` is only read for those).  Channels 1 and 2 keep the pruned recompute-and-probe path.
+// Entry-order hit bits are also what ranks exchange when the key space is split between GPUs: 1 bit per
+// DB position and channel instead of the 512 MiB plane.
 // ------------------------------------------------------------------------------------------
 template <int PASS>   // 0: count positions per fine bucket, 1: place them
 __global__ __launch_bounds__(256) void eref_probe_index_kernel(const uint8_t *__restrict__ bases,
@@ -1162,7 +1159,7 @@ __global__ __launch_bounds__(256) void eref_probe_index_kernel(const uint8_t *__
                                                                const int64_t *__restrict__ word_pre, CoderMasks masks,
                                                                unsigned long long *__restrict__ count,
                                                                const unsigned long long *__restrict__ first,
-                                                               unsigned long long *__restrict__ entries)
+                                                               uint16_t *__restrict__ keys16, uint32_t *__restrict__ pos)
 {
     const int64_t tile = blockIdx.x;
     if (tile >= tile_pre[n_refs]) return;
@@ -1189,16 +1186,18 @@ __global__ __launch_bounds__(256) void eref_probe_index_kernel(const uint8_t *__
             if (key != 0) {                                   // index 0 means "none" (extract_ref.cpp:861)
                 const uint32_t b = key >> 16;                    // fine bucket of the count kernel; four of them are one probe group
                 const unsigned long long at = atomicAdd(&count[b], 1ull);
-                if (PASS == 1)
-                    entries[first[b] + at] = (static_cast<unsigned long long>((wbase + c) * 64 + lane) << kBucketShift) |
-                                             (key & ((1u << kBucketShift) - 1));
+                if (PASS == 1) {
+                    keys16[first[b] + at] = static_cast<uint16_t>(key);
+                    pos[first[b] + at] = static_cast<uint32_t>((wbase + c) * 64 + lane);
+                }
             }
         }
         lo = hi;
     }
 }
 
-// exclusive prefix of the 65536 fine-bucket counts (one workgroup, 64 buckets per thread); first[65536] = total
+// exclusive prefix of the 65536 fine-bucket counts, each rounded up to a multiple of 8 (one workgroup, 64 buckets per thread);
+// first[65536] = total (padded)
 constexpr int kIndexGroups = 1 << 16, kGroupsPerProbe = kIndexGroups / kBuckets;
 __global__ __launch_bounds__(1024) void eref_bucket_prefix_kernel(const unsigned long long *__restrict__ count,
                                                                   unsigned long long *__restrict__ first)
@@ -1206,7 +1205,7 @@ __global__ __launch_bounds__(1024) void eref_bucket_prefix_kernel(const unsigned
     __shared__ unsigned long long part[1024];
     constexpr int kPer = kIndexGroups / 1024;
     unsigned long long sum = 0;
-    for (int i = 0; i < kPer; i++) sum += count[threadIdx.x * kPer + i];
+    for (int i = 0; i < kPer; i++) sum += (count[threadIdx.x * kPer + i] + 7ull) & ~7ull;
     part[threadIdx.x] = sum;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
@@ -1216,88 +1215,131 @@ __global__ __launch_bounds__(1024) void eref_bucket_prefix_kernel(const unsigned
         __syncthreads();
     }
     unsigned long long run = part[threadIdx.x] - sum;
-    for (int i = 0; i < kPer; i++) { first[threadIdx.x * kPer + i] = run; run += count[threadIdx.x * kPer + i]; }
+    for (int i = 0; i < kPer; i++) { first[threadIdx.x * kPer + i] = run; run += (count[threadIdx.x * kPer + i] + 7ull) & ~7ull; }
     if (threadIdx.x == 1023) first[kIndexGroups] = run;
 }
 
-// the entries [e0, hi) of one group tested against a slice of plane 3 held in LDS (bit k & key_mask of the slice); a hit is a
-// BYTE store into the byte-per-position array (see eref_probe_kernel).  Entries two at a time: 16-byte loads, the group widened
-// to even entry indices and the strangers at its ends skipped (the array is padded by one entry); the next batch of loads is
-// always in flight.  `cur` must hold the first batch (probe_first_batch), which does not depend on the slice.
-template <int THREADS, int BATCH>
-__device__ __forceinline__ void probe_first_batch(const unsigned long long *__restrict__ entries, unsigned long long e0, unsigned long long hi,
-                                                  ulonglong2 (&cur)[BATCH])
+// one workgroup per group of four fine buckets: its 32 KiB slice of plane 3 in LDS, its entries (16-byte vectors of eight 16-bit
+// keys; a vector lies in ONE fine bucket, buckets start on multiples of 8) tested against it, a byte of hit bits per vector.
+// Every load of a batch is issued before the slice is waited for; the stores of a batch follow its tests.
+// `lo_group`: the first group of the launch (a rank that holds a share of the key space probes its groups only).
+constexpr int kProbeThreads = 512;
+__global__ __launch_bounds__(kProbeThreads) void eref_probe2_kernel(const unsigned long long *__restrict__ first,
+                                                                    const uint16_t *__restrict__ keys16,
+                                                                    const uint32_t *__restrict__ p3, uint8_t *__restrict__ ehits,
+                                                                    uint32_t lo_group, KeyBuckets share)
 {
-    const unsigned long long lo = e0 & ~1ull, n2 = (hi - lo + 1) / 2;
-    const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(entries + lo);
+    __shared__ uint32_t l3[kSliceWords];
+    const uint32_t g = lo_group + blockIdx.x;
+    if (!share.bucket(g * kGroupsPerProbe / kL2Rows)) return;      // not this call's share of the key space
+    const unsigned long long f0 = first[g * kGroupsPerProbe] / 8;
+    unsigned long long fk[kGroupsPerProbe];                        // start vector of each fine bucket behind the first, end of the group
 #pragma unroll
-    for (int u = 0; u < BATCH; u++) {
-        const unsigned long long i = threadIdx.x + static_cast<unsigned long long>(u) * THREADS;
-        cur[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
+    for (int k = 0; k < kGroupsPerProbe; k++) fk[k] = first[g * kGroupsPerProbe + k + 1] / 8;
+    const unsigned long long hi = fk[kGroupsPerProbe - 1];
+    if (hi == f0) return;                                          // uniform for the workgroup
+    constexpr int kBatch = 3;                                      // a group's ~12 000 entries = ~1 500 vectors: one batch of 512 x 3
+    const uint4 *pv = reinterpret_cast<const uint4 *>(keys16);
+    uint4 cur[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; u++) {
+        const unsigned long long i = f0 + threadIdx.x + static_cast<unsigned long long>(u) * kProbeThreads;
+        cur[u] = i < hi ? pv[i] : uint4{0, 0, 0, 0};
     }
-}
-template <int THREADS, int BATCH, bool DOUBLE>
-__device__ __forceinline__ void probe_group(const uint32_t *l3, uint32_t key_mask, const unsigned long long *__restrict__ entries,
-                                            unsigned long long e0, unsigned long long hi, ulonglong2 (&cur)[BATCH], uint8_t *__restrict__ hit_bytes)
-{
-    const unsigned long long lo = e0 & ~1ull, n2 = (hi - lo + 1) / 2;
-    const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(entries + lo);
-    constexpr unsigned long long kStride = static_cast<unsigned long long>(BATCH) * THREADS;
-    auto test = [&](unsigned long long ent, unsigned long long at) {  // at: global index of the entry
-        if (at < e0 || at >= hi) return;
-        const uint32_t k = static_cast<uint32_t>(ent) & key_mask;
-        if ((l3[k >> 5] >> (k & 31)) & 1u) hit_bytes[ent >> kBucketShift] = 1;
+    const uint4 *g3 = reinterpret_cast<const uint4 *>(p3 + static_cast<size_t>(g) * kSliceWords);
+    for (int i = threadIdx.x; i < kSliceWords / 4; i += kProbeThreads) reinterpret_cast<uint4 *>(l3)[i] = g3[i];
+    __syncthreads();
+    auto slice_of = [&](unsigned long long i) {                    // the fine bucket's 2^16-bit part of the slice
+        uint32_t sub = 0;
+#pragma unroll
+        for (int k = 0; k + 1 < kGroupsPerProbe; k++) sub += i >= fk[k] ? 1u : 0u;
+        return l3 + sub * kFineWords;
     };
-    for (unsigned long long i0 = threadIdx.x; i0 < n2; i0 += kStride) {
-        ulonglong2 nxt[BATCH];
-        if (DOUBLE) {                                          // the next batch of loads is in flight while this one is tested
+    for (unsigned long long i0 = f0 + threadIdx.x; i0 < hi; i0 += static_cast<unsigned long long>(kBatch) * kProbeThreads) {
+        uint32_t m[kBatch];
 #pragma unroll
-            for (int u = 0; u < BATCH; u++) {
-                const unsigned long long i = i0 + kStride + static_cast<unsigned long long>(u) * THREADS;
-                nxt[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
+        for (int u = 0; u < kBatch; u++) {
+            const unsigned long long i = i0 + static_cast<unsigned long long>(u) * kProbeThreads;
+            m[u] = i < hi ? probe_vector(slice_of(i), cur[u]) : 0u;
+        }
+        const unsigned long long n0 = i0 + static_cast<unsigned long long>(kBatch) * kProbeThreads;
+        uint4 nxt[kBatch];
+        const bool more = n0 - threadIdx.x < hi;                   // uniform: a group larger than one batch
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) {
+                const unsigned long long i = n0 + static_cast<unsigned long long>(u) * kProbeThreads;
+                nxt[u] = i < hi ? pv[i] : uint4{0, 0, 0, 0};
             }
         }
 #pragma unroll
-        for (int u = 0; u < BATCH; u++) {
-            const unsigned long long i = i0 + static_cast<unsigned long long>(u) * THREADS;
-            if (i < n2) { test(cur[u].x, lo + 2 * i); test(cur[u].y, lo + 2 * i + 1); }
+        for (int u = 0; u < kBatch; u++) {
+            const unsigned long long i = i0 + static_cast<unsigned long long>(u) * kProbeThreads;
+            if (i < hi) ehits[i] = static_cast<uint8_t>(m[u]);
         }
-        if (DOUBLE) {
+        if (more) {
 #pragma unroll
-            for (int u = 0; u < BATCH; u++) cur[u] = nxt[u];
-        } else if (i0 - threadIdx.x + kStride < n2) {          // (uniform) a group larger than one batch: rare where DOUBLE is off
-#pragma unroll
-            for (int u = 0; u < BATCH; u++) {
-                const unsigned long long i = i0 + kStride + static_cast<unsigned long long>(u) * THREADS;
-                cur[u] = i < n2 ? pairs[i] : ulonglong2{~0ull, ~0ull};
-            }
+            for (int u = 0; u < kBatch; u++) cur[u] = nxt[u];
         }
     }
 }
 
-// one workgroup per fine bucket: its slice of plane 3 in LDS, its positions tested against it.
-// 512 threads (four workgroups per CU by LDS and by waves; with 1024 there were two, each alone with its load latency between
-// its batches), the next batch of entry loads always in flight while the current one is tested.
-constexpr int kProbeThreads = 512;
-__global__ __launch_bounds__(kProbeThreads) void eref_probe_kernel(const unsigned long long *__restrict__ first,
-                                                                   const unsigned long long *__restrict__ entries,
-                                                                   const uint32_t *__restrict__ p3,
-                                                                   uint8_t *__restrict__ hit_bytes)
+// entry-order hit bits -> the byte-per-position array: the entries that hit (a few per cent) are listed per workgroup in LDS,
+// then every thread takes hits of the list -- the look-ups of `pos` and the byte stores of a thread are independent of each
+// other and issued together.  n16: 16-byte vectors of `ehits` (128 entries each).
+// BITS: a hit is an atomicOr into the bit words the window scan reads (1 bit per position: the array is small enough to live in
+// the L2s / MALL) instead of a byte store into a byte-per-position array that eref_hits_to_bits_kernel packs afterwards.
+constexpr int kScatterThreads = 256, kScatterList = 4096;
+template <bool BITS>
+__global__ __launch_bounds__(kScatterThreads) void eref_ehits_scatter_kernel(const uint4 *__restrict__ ehits, unsigned long long n16,
+                                                                             const uint32_t *__restrict__ pos, uint8_t *__restrict__ hit_bytes,
+                                                                             uint32_t *__restrict__ words32)
 {
-    __shared__ uint32_t l3[kSliceWords];
-    const uint32_t b = blockIdx.x;
-    const unsigned long long e0 = first[b * kGroupsPerProbe], hi = first[(b + 1) * kGroupsPerProbe];
-    if (hi == e0) return;                                  // uniform for the workgroup
-    // a hit is a BYTE store, not an atomicOr into the bit array: the ~8 M hits of a step are random over 200 M positions, and
-    // as 64-bit atomics they were 0.6 ms of this kernel's 1.04 (measured by leaving them out); eref_hits_to_bits_kernel packs
-    // the bytes afterwards
-    constexpr int kBatch = 4;                              // pair loads per thread and batch
-    ulonglong2 cur[kBatch];
-    probe_first_batch<kProbeThreads, kBatch>(entries, e0, hi, cur);       // requested before the slice is: it does not depend on it
-    const uint4 *g3 = reinterpret_cast<const uint4 *>(p3 + static_cast<size_t>(b) * kSliceWords);
-    for (int i = threadIdx.x; i < kSliceWords / 4; i += kProbeThreads) reinterpret_cast<uint4 *>(l3)[i] = g3[i];
-    __syncthreads();
-    probe_group<kProbeThreads, kBatch, true>(l3, (1u << kBucketShift) - 1, entries, e0, hi, cur, hit_bytes);
+    auto hit = [&](uint32_t p) {
+        if (BITS) atomicOr(&words32[p >> 5], 1u << (p & 31));
+        else hit_bytes[p] = 1;
+    };
+    __shared__ uint32_t list[kScatterList];
+    __shared__ uint32_t n_list;
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * kScatterThreads;
+    for (unsigned long long base = static_cast<unsigned long long>(blockIdx.x) * kScatterThreads; base < n16; base += stride) {   // uniform
+        if (threadIdx.x == 0) n_list = 0;
+        __syncthreads();
+        const unsigned long long i = base + threadIdx.x;
+        const uint4 v = i < n16 ? ehits[i] : uint4{0, 0, 0, 0};
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t mine = __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
+        uint32_t at = mine ? atomicAdd(&n_list, mine) : 0u;
+        const unsigned long long e0 = i * 128;                         // (entries of a launch fit 32 bits relative to the vector's start: e0 + 127)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t x = w[k];
+            while (x) {
+                const int bit = __ffs(static_cast<int>(x)) - 1;
+                x &= x - 1;
+                const uint32_t rel = static_cast<uint32_t>(threadIdx.x) * 128u + 32u * k + bit;          // entry relative to `base * 128`
+                if (at < kScatterList) list[at] = rel;
+                else { const uint32_t p = pos[e0 + 32 * k + bit]; if (p != ~0u) hit(p); }      // list full: directly
+                at++;
+            }
+        }
+        __syncthreads();
+        const uint32_t n = min(n_list, static_cast<uint32_t>(kScatterList));
+        const unsigned long long eb = base * 128;
+        constexpr int kUn = 4;
+        for (uint32_t j0 = threadIdx.x; j0 < n; j0 += kUn * kScatterThreads) {
+            uint32_t p[kUn];
+#pragma unroll
+            for (int u = 0; u < kUn; u++) {
+                const uint32_t j = j0 + u * kScatterThreads;
+                p[u] = j < n ? pos[eb + list[j]] : ~0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kUn; u++)
+                if (p[u] != ~0u) hit(p[u]);
+        }
+        __syncthreads();
+    }
 }
 
 // hit bytes of the probe kernel -> the bit words everything downstream reads: a lane packs 16 positions (bit 0 of each byte
@@ -1806,27 +1848,28 @@ static void carve_count(const CountPlan &pl, char *ws, bool with_words, CountBuf
 struct palace_eref_probe_index {
     int64_t n_refs = 0, total_bases = 0;
     palace::CoderMasks masks{};               // the coder the indices were computed with
-    unsigned long long n_entries = 0;
+    unsigned long long n_entries = 0;         // entries incl. the pads that bring every fine bucket's start to a multiple of 8
     unsigned long long *first = nullptr;      // [kIndexGroups + 1]: entries grouped by index >> 16 (the count kernel's fine buckets;
                                               //  four consecutive groups are one 2^18-key group of the stand-alone probe kernel)
-    unsigned long long *entries = nullptr;    // [n_entries] (position id << 18) | (index & 0x3ffff)
-    uint8_t *hit_bytes = nullptr;             // a byte per position id: the channel-0 hits a count launch leaves when the index is attached
-    size_t hit_bytes_size = 0;
+    uint16_t *keys16 = nullptr;               // [n_entries] index & 0xffff (pads: 0)
+    uint32_t *pos = nullptr;                  // [n_entries rounded up to 128] position id (pads and the tail: ~0)
+    uint8_t *ehits = nullptr;                 // [ehits_bytes] one hit BIT per entry, entry order: written by the probe kernel, or by a count launch
+    size_t ehits_bytes = 0;                   //  this index is attached to (multiple of 16; the tail stays zero)
+    size_t hit_bytes_size = 0;                // positions ids run over [0, hit_bytes_size): a byte per position in the scan's workspace
 };
 
 static_assert(kIndexGroups == kFine, "the probe index is grouped by the count kernel's fine buckets");
 
 static bool probe_index_usable(const palace_ctx *ctx, const palace_eref_probe_index *ix)
 {
-    // (the fused kernel keeps hit positions as 32-bit ids in LDS)
-    return ix->hit_bytes && ix->hit_bytes_size < (1ull << 32) && std::memcmp(&ix->masks, &ctx->masks, sizeof(CoderMasks)) == 0;
+    return ix->ehits && ix->keys16 && std::memcmp(&ix->masks, &ctx->masks, sizeof(CoderMasks)) == 0;
 }
 
 // the final count kernel of a launch with Phase B's channel-0 probe riding along (eref_lds_count_kernel<true, true, true>)
 static int probe_index_launch_fused(palace_ctx *ctx, const palace_eref_probe_index *ix, const CountBufs &b, const CountPlan &pl, const KeyBuckets &keys)
 {
-    PALACE_HIP_TRY(hipMemsetAsync(ix->hit_bytes, 0, ix->hit_bytes_size, ctx->stream));
-    const ProbeArgs pr{ix->first, ix->entries, ix->hit_bytes};
+    PALACE_HIP_TRY(hipMemsetAsync(ix->ehits, 0, ix->ehits_bytes, ctx->stream));      // (buckets without keys leave their bytes alone)
+    const ProbeArgs pr{ix->first, ix->keys16, ix->ehits};
     hipLaunchKernelGGL((eref_lds_count_kernel<true, true, true>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
                        ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, pr);
     PALACE_HIP_TRY(hipGetLastError());
@@ -2104,6 +2147,9 @@ int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value)
     } else if (!std::strcmp(name, "level1_parts")) {         // 0: by size; n: level 1 takes a slab in n parts beside level 2 (1: one stream)
         PALACE_REQUIRE(value >= 0 && value <= 64, "level1_parts must be 0 .. 64");
         ctx->level1_parts = static_cast<int>(value);
+    } else if (!std::strcmp(name, "scatter_bits")) {         // indexed scan: hits go to the bit words by atomicOr (1) or through a byte per position (0)
+        PALACE_REQUIRE(value == 0 || value == 1, "scatter_bits must be 0 or 1");
+        ctx->scatter_bits = value != 0;
     } else if (!std::strcmp(name, "bin1_ppl")) {              // 0: by key density, else positions per lane of level 1 (4, 5, 6, 8)
         PALACE_REQUIRE(value == 0 || value == 4 || value == 5 || value == 6 || value == 8, "bin1_ppl must be 0, 4, 5, 6 or 8");
         ctx->bin1_ppl = static_cast<int>(value);
@@ -2163,11 +2209,13 @@ struct ScanBuffers {
     uint64_t *any_w, *all_w, *good_w;
     uint32_t *any_p, *all_p;
     uint8_t *need, *active;                 // per chunk / per ref flags of eref_need_kernel
-    uint8_t *hit_bytes;                     // indexed scan: a byte per position (64 per word of any_w), see eref_probe_kernel
+    uint8_t *hit_bytes;                     // indexed scan: a byte per position (64 per word of any_w), see eref_ehits_scatter_kernel
+    uint8_t *ehits;                         // indexed scan, probing for itself: a hit bit per index entry (eref_probe2_kernel)
     int64_t max_tiles, max_words;
 };
 
-int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int64_t total_bases, ScanBuffers *b, bool with_hit_bytes = false)
+int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int64_t total_bases, ScanBuffers *b, bool with_hit_bytes = false,
+                 size_t ehits_bytes = 0)
 {
     b->max_tiles = total_bases / kTilePos + n_refs;
     b->max_words = total_bases / 64 + n_refs + 1;
@@ -2176,7 +2224,8 @@ int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int6
     const size_t w64 = align_up(b->max_words * 8, 256), w32 = align_up(b->max_words * 4, 256);
     const size_t w8 = align_up(b->max_words, 256);
     const size_t hb = with_hit_bytes ? align_up(static_cast<size_t>(b->max_words) * 64, 256) : 0;
-    int rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32 + w8 + align_up(n_refs + 1, 256) + hb);
+    const size_t eb = ehits_bytes ? align_up(ehits_bytes + 16, 256) : 0;
+    int rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32 + w8 + align_up(n_refs + 1, 256) + hb + eb);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
     b->tile_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
@@ -2188,7 +2237,8 @@ int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int6
     b->all_p = reinterpret_cast<uint32_t *>(ws); ws += w32;
     b->need = reinterpret_cast<uint8_t *>(ws); ws += w8;
     b->active = reinterpret_cast<uint8_t *>(ws); ws += align_up(n_refs + 1, 256);
-    b->hit_bytes = with_hit_bytes ? reinterpret_cast<uint8_t *>(ws) : nullptr;
+    b->hit_bytes = with_hit_bytes ? reinterpret_cast<uint8_t *>(ws) : nullptr; ws += hb;
+    b->ehits = eb ? reinterpret_cast<uint8_t *>(ws) : nullptr;
     return launch_prefix(ctx, d_offsets, n_refs, b->tile_pre, b->word_pre);
 }
 
@@ -2254,11 +2304,11 @@ int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const
     if (!ctx->coder_set) { set_error("palace_eref_probe_index_build: coder not set"); return PALACE_ESTATE; }
     PALACE_REQUIRE(n_refs == 0 || (d_bases && d_offsets), "null device pointer");
     PALACE_REQUIRE(n_refs < (1ll << 31), "too many refs for one launch");
-    PALACE_REQUIRE(total_bases + 64 * (n_refs + 1) < (1ll << 46), "position ids must fit in 46 bits");
+    PALACE_REQUIRE(total_bases + 64 * (n_refs + 1) < (1ll << 32) - 1, "position ids must fit in 32 bits");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     palace_eref_probe_index *ix = new palace_eref_probe_index();
     ix->n_refs = n_refs; ix->total_bases = total_bases; ix->masks = ctx->masks;
-    unsigned long long *count = nullptr;                  // 16384 counters, only during the build
+    unsigned long long *count = nullptr;                  // a counter per fine bucket, only during the build
     auto done = [&](int rc) {
         (void)hipStreamSynchronize(ctx->stream);
         if (count) (void)hipFree(count);
@@ -2280,17 +2330,23 @@ int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const
     TRY_OR_DONE(hipMemsetAsync(count, 0, kIndexGroups * 8, ctx->stream));
     hipLaunchKernelGGL(eref_probe_index_kernel<0>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
                        d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, count,
-                       static_cast<const unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr));
+                       static_cast<const unsigned long long *>(nullptr), static_cast<uint16_t *>(nullptr), static_cast<uint32_t *>(nullptr));
     hipLaunchKernelGGL(eref_bucket_prefix_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, ix->first);
     TRY_OR_DONE(hipGetLastError());
     TRY_OR_DONE(hipMemcpyAsync(&ix->n_entries, ix->first + kIndexGroups, 8, hipMemcpyDeviceToHost, ctx->stream));
     TRY_OR_DONE(hipStreamSynchronize(ctx->stream));
-    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->entries), (ix->n_entries + 2) * 8));      // (+ pad: the probe kernel loads pairs)
+    const unsigned long long n128 = (ix->n_entries + 127) / 128 * 128;
+    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->keys16), (n128 + 8) * 2));
+    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->pos), (n128 + 8) * 4));
+    ix->ehits_bytes = static_cast<size_t>(n128 / 8);
+    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->ehits), ix->ehits_bytes + 16));
+    TRY_OR_DONE(hipMemsetAsync(ix->keys16, 0, (n128 + 8) * 2, ctx->stream));
+    TRY_OR_DONE(hipMemsetAsync(ix->pos, 0xff, (n128 + 8) * 4, ctx->stream));
+    TRY_OR_DONE(hipMemsetAsync(ix->ehits, 0, ix->ehits_bytes + 16, ctx->stream));
     TRY_OR_DONE(hipMemsetAsync(count, 0, kIndexGroups * 8, ctx->stream));
     ix->hit_bytes_size = static_cast<size_t>(b.max_words) * 64;                                     // (position ids run over the words of the hit bitmap)
-    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->hit_bytes), ix->hit_bytes_size));
     hipLaunchKernelGGL(eref_probe_index_kernel<1>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
-                       d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, count, ix->first, ix->entries);
+                       d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, count, ix->first, ix->keys16, ix->pos);
     TRY_OR_DONE(hipGetLastError());
 #undef TRY_OR_DONE
     return done(PALACE_OK);
@@ -2303,8 +2359,9 @@ int palace_eref_probe_index_free(palace_ctx *ctx, palace_eref_probe_index *ix)
     if (ctx && ctx->probe_ix == ix) ctx->probe_ix = nullptr;
     if (ctx && ctx->c0_hits_ix == ix) ctx->c0_hits_ix = nullptr;
     if (ix->first) (void)hipFree(ix->first);
-    if (ix->entries) (void)hipFree(ix->entries);
-    if (ix->hit_bytes) (void)hipFree(ix->hit_bytes);
+    if (ix->keys16) (void)hipFree(ix->keys16);
+    if (ix->pos) (void)hipFree(ix->pos);
+    if (ix->ehits) (void)hipFree(ix->ehits);
     delete ix;
     return PALACE_OK;
 }
@@ -2331,22 +2388,35 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     rc = ensure_table(ctx);
     if (rc) return rc;
-    // channel 0: the count launch has left the hit bytes when this index was attached to it and nothing has touched the planes
-    // since; otherwise the probe kernel makes them now
-    const bool fused = ctx->c0_hits_ix == ix && ix->hit_bytes;
+    // channel 0: the count launch has left the entry-order hit bits when this index was attached to it and nothing has touched the
+    // planes since; otherwise the probe kernel makes them now.  Then the entries that hit are carried to their positions.
+    const bool fused = ctx->c0_hits_ix == ix;
     ScanBuffers b;
-    rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b, !fused);
+    rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b, true, fused ? 0 : ix->ehits_bytes);
     if (rc) return rc;
-    const uint8_t *hits = ix->hit_bytes;
-    if (!fused) {
-        PALACE_HIP_TRY(hipMemsetAsync(b.hit_bytes, 0, static_cast<size_t>(b.max_words) * 64, ctx->stream));
-        hipLaunchKernelGGL(eref_probe_kernel, dim3(kBuckets), dim3(kProbeThreads), 0, ctx->stream, ix->first, ix->entries, ctx->plane[2], b.hit_bytes);
+    PALACE_REQUIRE(static_cast<size_t>(b.max_words) * 64 == ix->hit_bytes_size, "probe index was built for another layout of the hit words");
+    const bool bits = ctx->scatter_bits;
+    if (bits) PALACE_HIP_TRY(hipMemsetAsync(b.any_w, 0, static_cast<size_t>(b.max_words) * 8, ctx->stream));
+    else PALACE_HIP_TRY(hipMemsetAsync(b.hit_bytes, 0, static_cast<size_t>(b.max_words) * 64, ctx->stream));
+    const uint8_t *eh = ix->ehits;                                  // (the attached index's own bits, left by the count launch)
+    if (!fused) {                                                   // this context's: several contexts may scan through one index
+        if (ix->ehits_bytes >= 16) PALACE_HIP_TRY(hipMemsetAsync(b.ehits + ix->ehits_bytes - 16, 0, 16, ctx->stream));   // (bytes behind the last entry)
+        hipLaunchKernelGGL(eref_probe2_kernel, dim3(kBuckets), dim3(kProbeThreads), 0, ctx->stream, ix->first, ix->keys16, ctx->plane[2], b.ehits,
+                           0u, ctx_buckets(ctx));
         PALACE_HIP_TRY(hipGetLastError());
-        hits = b.hit_bytes;
+        eh = b.ehits;
     }
-    hipLaunchKernelGGL(eref_hits_to_bits_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(hits),
-                       b.max_words * 4, reinterpret_cast<uint16_t *>(b.any_w));
-    PALACE_HIP_TRY(hipGetLastError());
+    if (bits) {
+        hipLaunchKernelGGL(eref_ehits_scatter_kernel<true>, dim3(kCUs * 8), dim3(kScatterThreads), 0, ctx->stream, reinterpret_cast<const uint4 *>(eh),
+                           static_cast<unsigned long long>(ix->ehits_bytes / 16), ix->pos, static_cast<uint8_t *>(nullptr), reinterpret_cast<uint32_t *>(b.any_w));
+        PALACE_HIP_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(eref_ehits_scatter_kernel<false>, dim3(kCUs * 8), dim3(kScatterThreads), 0, ctx->stream, reinterpret_cast<const uint4 *>(eh),
+                           static_cast<unsigned long long>(ix->ehits_bytes / 16), ix->pos, b.hit_bytes, static_cast<uint32_t *>(nullptr));
+        hipLaunchKernelGGL(eref_hits_to_bits_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(b.hit_bytes),
+                           b.max_words * 4, reinterpret_cast<uint16_t *>(b.any_w));
+        PALACE_HIP_TRY(hipGetLastError());
+    }
     return scan_tail(ctx, b, d_bases, d_offsets, n_refs, one_min, three_min, d_rows);
 }
 
