@@ -94,7 +94,7 @@ def measure(args, E, leg):
     ectx = [ctx] + [capi.Ctx(local) for _ in range(depth - 1)]
     for e in ectx:
         e.eref_set_coder(hdr)
-        for opt in ("slab_bases", "bin1_ppl", "level1_parts", "scatter_bits"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
+        for opt in ("slab_bases", "bin1_ppl", "level1_parts"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
             if os.environ.get("PALACE_OPT_" + opt.upper()):
                 e.eref_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
         if os.environ.get("PALACE_OPT_KEY_SHARE"):    # tuning runs only: count the share rank 0 of N would (results are then partial)

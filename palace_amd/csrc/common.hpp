@@ -83,7 +83,6 @@ struct palace_ctx {
     int64_t bin_cap_override = 0;
     int64_t slab_override = 0;
     int bin1_ppl = 0;               // level 1: positions per lane (0 = by key density)
-    bool scatter_bits = false;      // indexed scan: hit positions by atomicOr into the bit words instead of a byte per position
     palace::Workspace ws;      // grow-only scratch
     bool ws_grown = false;
     palace::Workspace pin;     // grow-only pinned host staging

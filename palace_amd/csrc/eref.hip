@@ -1287,18 +1287,14 @@ __global__ __launch_bounds__(kProbeThreads) void eref_probe2_kernel(const unsign
 // entry-order hit bits -> the byte-per-position array: the entries that hit (a few per cent) are listed per workgroup in LDS,
 // then every thread takes hits of the list -- the look-ups of `pos` and the byte stores of a thread are independent of each
 // other and issued together.  n16: 16-byte vectors of `ehits` (128 entries each).
-// BITS: a hit is an atomicOr into the bit words the window scan reads (1 bit per position: the array is small enough to live in
-// the L2s / MALL) instead of a byte store into a byte-per-position array that eref_hits_to_bits_kernel packs afterwards.
+// A hit is a BYTE store into a byte-per-position array that eref_hits_to_bits_kernel packs afterwards: as atomicOr into the bit
+// words themselves (25 MB instead of 200 MB, no memset of the bytes, no packing pass) the ~9 M random hits of a step cost 0.45 ms
+// MORE (scan 1.81 against 1.36 ms, round 5, tools/ab.sh r05g; round 3 had found the same inside the old probe kernel).
 constexpr int kScatterThreads = 256, kScatterList = 4096;
-template <bool BITS>
 __global__ __launch_bounds__(kScatterThreads) void eref_ehits_scatter_kernel(const uint4 *__restrict__ ehits, unsigned long long n16,
-                                                                             const uint32_t *__restrict__ pos, uint8_t *__restrict__ hit_bytes,
-                                                                             uint32_t *__restrict__ words32)
+                                                                             const uint32_t *__restrict__ pos, uint8_t *__restrict__ hit_bytes)
 {
-    auto hit = [&](uint32_t p) {
-        if (BITS) atomicOr(&words32[p >> 5], 1u << (p & 31));
-        else hit_bytes[p] = 1;
-    };
+    auto hit = [&](uint32_t p) { hit_bytes[p] = 1; };
     __shared__ uint32_t list[kScatterList];
     __shared__ uint32_t n_list;
     const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * kScatterThreads;
@@ -2147,9 +2143,6 @@ int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value)
     } else if (!std::strcmp(name, "level1_parts")) {         // 0: by size; n: level 1 takes a slab in n parts beside level 2 (1: one stream)
         PALACE_REQUIRE(value >= 0 && value <= 64, "level1_parts must be 0 .. 64");
         ctx->level1_parts = static_cast<int>(value);
-    } else if (!std::strcmp(name, "scatter_bits")) {         // indexed scan: hits go to the bit words by atomicOr (1) or through a byte per position (0)
-        PALACE_REQUIRE(value == 0 || value == 1, "scatter_bits must be 0 or 1");
-        ctx->scatter_bits = value != 0;
     } else if (!std::strcmp(name, "bin1_ppl")) {              // 0: by key density, else positions per lane of level 1 (4, 5, 6, 8)
         PALACE_REQUIRE(value == 0 || value == 4 || value == 5 || value == 6 || value == 8, "bin1_ppl must be 0, 4, 5, 6 or 8");
         ctx->bin1_ppl = static_cast<int>(value);
@@ -2395,9 +2388,7 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b, true, fused ? 0 : ix->ehits_bytes);
     if (rc) return rc;
     PALACE_REQUIRE(static_cast<size_t>(b.max_words) * 64 == ix->hit_bytes_size, "probe index was built for another layout of the hit words");
-    const bool bits = ctx->scatter_bits;
-    if (bits) PALACE_HIP_TRY(hipMemsetAsync(b.any_w, 0, static_cast<size_t>(b.max_words) * 8, ctx->stream));
-    else PALACE_HIP_TRY(hipMemsetAsync(b.hit_bytes, 0, static_cast<size_t>(b.max_words) * 64, ctx->stream));
+    PALACE_HIP_TRY(hipMemsetAsync(b.hit_bytes, 0, static_cast<size_t>(b.max_words) * 64, ctx->stream));
     const uint8_t *eh = ix->ehits;                                  // (the attached index's own bits, left by the count launch)
     if (!fused) {                                                   // this context's: several contexts may scan through one index
         if (ix->ehits_bytes >= 16) PALACE_HIP_TRY(hipMemsetAsync(b.ehits + ix->ehits_bytes - 16, 0, 16, ctx->stream));   // (bytes behind the last entry)
@@ -2406,17 +2397,11 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
         PALACE_HIP_TRY(hipGetLastError());
         eh = b.ehits;
     }
-    if (bits) {
-        hipLaunchKernelGGL(eref_ehits_scatter_kernel<true>, dim3(kCUs * 8), dim3(kScatterThreads), 0, ctx->stream, reinterpret_cast<const uint4 *>(eh),
-                           static_cast<unsigned long long>(ix->ehits_bytes / 16), ix->pos, static_cast<uint8_t *>(nullptr), reinterpret_cast<uint32_t *>(b.any_w));
-        PALACE_HIP_TRY(hipGetLastError());
-    } else {
-        hipLaunchKernelGGL(eref_ehits_scatter_kernel<false>, dim3(kCUs * 8), dim3(kScatterThreads), 0, ctx->stream, reinterpret_cast<const uint4 *>(eh),
-                           static_cast<unsigned long long>(ix->ehits_bytes / 16), ix->pos, b.hit_bytes, static_cast<uint32_t *>(nullptr));
-        hipLaunchKernelGGL(eref_hits_to_bits_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(b.hit_bytes),
-                           b.max_words * 4, reinterpret_cast<uint16_t *>(b.any_w));
-        PALACE_HIP_TRY(hipGetLastError());
-    }
+    hipLaunchKernelGGL(eref_ehits_scatter_kernel, dim3(kCUs * 8), dim3(kScatterThreads), 0, ctx->stream, reinterpret_cast<const uint4 *>(eh),
+                       static_cast<unsigned long long>(ix->ehits_bytes / 16), ix->pos, b.hit_bytes);
+    hipLaunchKernelGGL(eref_hits_to_bits_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(b.hit_bytes),
+                       b.max_words * 4, reinterpret_cast<uint16_t *>(b.any_w));
+    PALACE_HIP_TRY(hipGetLastError());
     return scan_tail(ctx, b, d_bases, d_offsets, n_refs, one_min, three_min, d_rows);
 }
 

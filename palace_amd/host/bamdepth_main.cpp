@@ -4,26 +4,43 @@
 // prints exactly what the awk line prints.
 //     bamdepth --per-contig <bam> > contig_depth.tsv
 // prints `contig <TAB> depth sum <TAB> covered positions` for every contig with coverage: the two numbers step 5 takes from
-// the tabix-indexed depth file per contig (create_sub_graph.py:186-234); palace_amd/scripts/create_sub_graph.py reads it.  (The per-base <bam>.depth.gz that step 5 reads through tabix is not written;
-// `generateGraph <bam> <fai> <out> auto` uses the same number without a second pass over the BAM.)
+// the tabix-indexed depth file per contig (create_sub_graph.py:186-234); palace_amd/scripts/create_sub_graph.py reads it.
+//     first_depth=$(bamdepth --depth-gz <bam>.depth.gz <bam>)
+// writes the per-base depth file itself -- <bam>.depth.gz (the text of `samtools depth`, BGZF) and <bam>.depth.gz.tbi (the index
+// `tabix -s 1 -b 2 -e 2` makes) -- and prints the awk number: the four commands of palace:541-545 as one, host only (depthgz.hpp).
+// (`generateGraph <bam> <fai> <out> auto` uses the same number without a second pass over the BAM.)
 #include <algorithm>
 #include <iostream>
 #include <thread>
 
 #include "bam.hpp"
 #include "depth_host.hpp"
+#include "depthgz.hpp"
 
 using namespace palace_host;
 
 int main(int argc, char **argv)
 {
     const bool per_contig = argc >= 3 && std::string(argv[1]) == "--per-contig";
-    if (argc < 2 || (per_contig && argc < 3)) { std::cerr << "Usage: " << argv[0] << " [--per-contig] <bam>\n"; return 1; }
-    const char *bam = per_contig ? argv[2] : argv[1];
+    const bool depth_gz = argc >= 4 && std::string(argv[1]) == "--depth-gz";
+    if (argc < 2 || (per_contig && argc < 3) || (std::string(argv[1]) == "--depth-gz" && argc < 4)) {
+        std::cerr << "Usage: " << argv[0] << " [--per-contig | --depth-gz <out.depth.gz>] <bam>\n";
+        return 1;
+    }
+    const char *bam = depth_gz ? argv[3] : per_contig ? argv[2] : argv[1];
+    const int threads = static_cast<int>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
     BamColumns c;
     try {
-        load_bam(bam, static_cast<int>(std::max(1u, std::min(16u, std::thread::hardware_concurrency()))), 1, c);
+        load_bam(bam, threads, 1, c);
     } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return 1; }
+    if (depth_gz) {                                  // no GPU in this mode: text and DEFLATE are host work
+        try {
+            const DepthGzResult r = write_depth_gz(c, argv[2], threads);
+            if (r.lines == 0) { std::cerr << "bamdepth: no position is covered (awk: division by zero)\n"; return 2; }
+            std::cout << awk_number(static_cast<double>(r.sum) / static_cast<double>(r.lines)) << "\n";
+            return 0;
+        } catch (const std::exception &e) { std::cerr << "bamdepth: " << e.what() << "\n"; return 1; }
+    }
     palace_ctx *ctx = nullptr;
     if (palace_ctx_create(0, &ctx)) { std::cerr << "bamdepth: " << palace_last_error() << "\n"; return 1; }
     std::string text;
