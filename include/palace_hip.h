@@ -345,12 +345,6 @@ int palace_graph_score_border(palace_ctx *ctx, palace_graph_cand *d_cands, int64
 int palace_graph_copy_numbers(palace_ctx *ctx, const uint64_t *d_consumed, const int32_t *d_tlen,
                               int32_t n_targets, double avg_depth, int32_t *d_cn);
 
-/* Diagnosis (no reference counterpart): `launches` kernels of `blocks` x 256 threads on the context's stream that together do n_ops
- * random memory operations over d_buf[0 .. n_slots) (8-byte slots): mode 0 = 8-byte loads, 1 = 64-bit atomicMin, 2 = 8-byte stores,
- * 3 = 1-byte loads.  Used to measure what a stream of such operations costs a bandwidth-bound launch on another stream
- * (tools/r04u.sh). */
-int palace_diag_disturb(palace_ctx *ctx, void *d_buf, uint64_t n_slots, uint64_t n_ops, int mode, int launches, int blocks);
-
 /* ---- N4: BGZF members inflated on the device ------------------------------------------------------------------------------ */
 
 /* What htslib's bgzf layer does inside sam_read1 (generate_graph.cpp:644), for n_members BGZF members at once, one wavefront
