@@ -85,7 +85,8 @@ def measure(args, E, leg):
     # device then takes 0.8 instead of 1.4 ms, beside the counting kernels 2.75 instead of 4.4 ms -- but as a shorter, denser burst of
     # random atomics it costs the count launch 1.05 ms instead of 0.7, and the step is stream A's length: 10.1 against 9.86 ms, A/B
     # on one box, tools/ab.sh r05d)
-    ctx_s.match_set_option("decomp_grid", 256)
+    if world == 1 or solo:                          # (N GPUs: rank 0's stream B is the longer stream once Phase A is sharded: the library's 2048)
+        ctx_s.match_set_option("decomp_grid", 256)
     for opt in ("iters_per_round", "first_group_rounds", "decomp_grid"):    # tuning runs only
         if os.environ.get("PALACE_OPT_" + opt.upper()):
             ctx_s.match_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
@@ -197,6 +198,27 @@ def measure(args, E, leg):
 
         def merge_fn(parts, n_parts, slice_off, slice_bytes, packed=False):      # stream A, behind the all-to-all issued on it
             ctx.eref_table_merge_slices(parts.data_ptr(), n_parts, slice_off, slice_bytes, packed)
+
+        # The '>= 3' plane completed on every rank in SPARSE form (palace_eref_plane_pack / _unpack: a count per fine bucket and 2 B per
+        # set bit -- 48 MB for the 1M-contig sample instead of 512 MiB of plane slices).  The room for a rank's keys is what the
+        # first step (dense gather) found, + 1/4; the counts come back with the step's results and are checked then.
+        sparse = {"on": world > 1 and 128 % world == 0 and os.environ.get("PALACE_BENCH_SPARSE_GATHER", "1") == "1", "cap": 0, "bufs": {"device": dev}, "learn": False}
+        if os.environ.get("PALACE_BENCH_SPARSE_GATHER", "1") == "1" and world == 1:
+            sparse["on"] = True                          # (one-rank rehearsals of the exchange paths: pack and count, nothing to unpack)
+        split_buckets = [multigpu.key_buckets_of(r, world) for r in range(world)] if 64 % world == 0 else None
+        slice_buckets = [list(range(r * 128 // world, (r + 1) * 128 // world)) for r in range(world)] if 128 % world == 0 else None
+        n_fine_rank = 65536 // world if 128 % world == 0 else 0
+        if sparse["on"]:
+            sparse.update(probe_counts=torch.zeros(max(1, n_fine_rank), dtype=torch.int32, device=dev), probe_keys=torch.zeros(8, dtype=torch.int16, device=dev),
+                          probe_first=torch.zeros(n_fine_rank + 1, dtype=torch.int64, device=dev),
+                          need_host=torch.zeros(1, dtype=torch.int64).pin_memory(), sums_host=torch.zeros(world, dtype=torch.int64).pin_memory())
+
+        def sparse_gather(bucket_lists):
+            counts_all = exch.gather_buckets_sparse(
+                bucket_lists, lambda c, k, f: ctx.eref_plane_pack(bucket_lists[rank], P(c), P(k), sparse["cap"], P(f)),
+                lambda r, c, k, f: ctx.eref_plane_unpack(bucket_lists[r], P(c), P(k), P(f)), sparse["cap"], sparse["bufs"])
+            sparse["sums_host"].copy_(counts_all.sum(dim=1, dtype=torch.int64), non_blocking=True)
+            sparse["steps"] = sparse.get("steps", 0) + 1
     last = {}
     seen = {"graph": set(), "rows": set(), "steps": 0}     # result digests of the untimed steps (warm-up, soak): one value each, or the step is not repeatable
     h_last = {}
@@ -274,10 +296,17 @@ def measure(args, E, leg):
         def eref_tail():
             if exch and shard_reads:                   # count-table exchange (RCCL) on stream A, then Phase B on this rank's refs
                 with on_a():
-                    exch.merge_planes(planes, merge_fn, pack_fn)
+                    exch.merge_planes(planes, merge_fn, pack_fn, final_gather=(lambda: sparse_gather(slice_buckets)) if sparse["cap"] else None)
             elif key_split:                            # every rank counted its range of the key space: gather the ">= 3" plane
                 with on_a():
-                    exch.gather_key_buckets(planes[2])
+                    if sparse["cap"]:
+                        sparse_gather(split_buckets)
+                    else:
+                        exch.gather_key_buckets(planes[2])
+            if exch and (shard_reads or key_split) and sparse["on"] and not sparse["cap"]:
+                # the first step took the dense gather: how many keys the sparse form of a rank's share holds sizes the later steps'
+                ctx.eref_plane_pack((slice_buckets if shard_reads else split_buckets)[rank], P(sparse["probe_counts"]), P(sparse["probe_keys"]), 0, P(sparse["probe_first"]))
+                sparse["learn"] = True
             if timed: ctx.mark(m + 2)
             capi._check(L.palace_eref_scan_refs_indexed(ctx.h, probe_index, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
                                                         sample["ref_total"], one_min, three_min, P(rows) + 16 * r_lo), "scan")
@@ -426,6 +455,16 @@ def measure(args, E, leg):
         if exch:
             g.mark(4093)
             g.mark_wait(4093)                          # stream B has drained on every rank (only rank 0 waited for a stage-04 result)
+            if sparse["on"] and (shard_reads or key_split):
+                ctx.mark(4090); ctx.mark_wait(4090)                 # stream A has drained (its results were waited for above; the sums travel behind them)
+                if sparse["learn"]:                                # the dense step: the largest share in sparse form, over the ranks, sizes the room
+                    need = sparse["probe_first"][-1:].clone()
+                    dist.all_reduce(need, op=dist.ReduceOp.MAX)
+                    sparse["cap"] = (int(need.item()) * 5 // 4 + 65536) // 65536 * 65536
+                    sparse["learn"] = False
+                elif sparse["cap"] and int(sparse["sums_host"].max().item()) > sparse["cap"]:
+                    sparse["cap"] = 0                              # a rank's keys were cut off: this step again with the dense gather (which sizes the room anew)
+                    return step(i, timed)
             cnt = exch.last_counts if gat["learn"] else [int(x) for x in counts_host.tolist()]
             if not gat["learn"] and max(cnt) > gat["width"]:
                 gat["width"] = 0                       # a rank had more candidates than the padded gather carried: this step again, exactly
@@ -490,6 +529,10 @@ def measure(args, E, leg):
     reported = int(((r[:, 1] > 0) & (r[:, 1].astype(np.float32) / r[:, 2].astype(np.float32) > 0.75)).sum())
 
     failures, out = [], None
+    if exch:
+        model["sparse_gather"] = dict(steps=sparse.get("steps", 0), cap_keys_per_rank=sparse["cap"],
+                                      note="steps whose '>= 3' plane was completed from counts + 16-bit keys (palace_eref_plane_pack / _unpack) "
+                                           "instead of plane slices; the first step of a run takes the dense gather and sizes the room")
     if rank == 0:
         L.palace_version.restype = ctypes.c_char_p
         version = L.palace_version().decode()

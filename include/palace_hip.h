@@ -217,6 +217,22 @@ int palace_eref_table_pack_low(palace_ctx *ctx, void *d_low);
 int palace_eref_table_merge_slices_packed(palace_ctx *ctx, const void *d_parts, int n_parts, size_t slice_off,
                                           size_t slice_bytes);
 
+/* The ">= 3" plane in sparse form, for exchanges between ranks that each hold a share of the key space (the level-1 buckets of
+ * mask128, as in palace_eref_set_key_buckets): the plane of a sample is sparse (the 1M-contig sample sets 24 M of its 2^32 bits),
+ * so a fine bucket (2^16 keys = 8 KiB of the plane) travels as the number of its set bits and their 16-bit offsets -- 48 MB for the
+ * whole plane instead of 512 MiB.
+ * pack:   d_counts[k] = set bits of the k-th fine bucket of the share (the share's level-1 buckets ascending, 512 fine buckets
+ *         each: 512 * popcount(mask128) entries), d_first[k] = their exclusive prefix (k = 0 .. n: d_first[n] = total, one more
+ *         entry than d_counts), d_keys[d_first[k] ..] = the offsets, ascending.  Keys beyond cap_keys are not written: the
+ *         caller reads d_first[n] back (at its leisure) and repeats with more room, or ships the dense slices.
+ * unpack: the reverse into THIS context's plane for the buckets of mask128 (every bit of those buckets is rewritten), from
+ *         d_counts and d_keys as pack left them; d_first is scratch of n + 1 entries.
+ * Both are enqueued on the context's stream; nothing is read back. */
+int palace_eref_plane_pack(palace_ctx *ctx, const uint32_t mask128[4], uint32_t *d_counts, uint16_t *d_keys, int64_t cap_keys,
+                           unsigned long long *d_first);
+int palace_eref_plane_unpack(palace_ctx *ctx, const uint32_t mask128[4], const uint32_t *d_counts, const uint16_t *d_keys,
+                             unsigned long long *d_first);
+
 /* Test hooks: counts (0..3) of `n` indices; population count of each plane. */
 int palace_eref_table_lookup(palace_ctx *ctx, const uint32_t *d_keys, int64_t n, uint8_t *d_counts);
 int palace_eref_table_popcounts(palace_ctx *ctx, uint64_t out3[3]);

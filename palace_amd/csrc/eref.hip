@@ -1653,6 +1653,116 @@ __global__ __launch_bounds__(256) void merge_slices_kernel(const uint4 *__restri
 }
 
 // host: E1 masks from the header (extract_ref.cpp:1104-1122 for the header layout)
+// ------------------------------------------------------------------------------------------
+// sparse form of the ">= 3" plane (what ranks exchange instead of plane slices when the key space is split between GPUs).  The
+// plane is sparse -- a 1M-contig sample sets 24 M of its 2^32 bits -- so a fine bucket (2^16 keys, 8 KiB of the plane) travels
+// as its count and the 16-bit offsets of its set bits: 2 B per key at >= 3 instead of 8 KiB per bucket.
+//   entry k of `counts` / `first` = the k-th fine bucket of the level-1 buckets in `share`, ascending (512 fine buckets each)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int share_slot(const KeyBuckets &share, uint32_t b1)         // ordinal of level-1 bucket b1 among the share's buckets
+{
+    int n = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) {
+        const uint32_t lo = 32 * w;
+        if (b1 >= lo + 32) n += __popc(share.m[w]);
+        else if (b1 > lo) n += __popc(share.m[w] & ((1u << (b1 - lo)) - 1u));
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(256) void plane_sparse_count_kernel(const uint32_t *__restrict__ p3, KeyBuckets share, uint32_t *__restrict__ counts)
+{
+    const uint32_t b = blockIdx.x, b1 = b / kL2Rows;
+    if (!share.bucket(b1)) return;
+    const uint4 *g = reinterpret_cast<const uint4 *>(p3 + static_cast<size_t>(b) * kFineWords);
+    uint32_t c = 0;
+    for (int i = threadIdx.x; i < kFineWords / 4; i += 256) { const uint4 v = g[i]; c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+    __shared__ uint32_t part[4];
+#pragma unroll
+    for (int d = 32; d; d >>= 1) c += __shfl_down(c, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[share_slot(share, b1) * kL2Rows + b % kL2Rows] = part[0] + part[1] + part[2] + part[3];
+}
+
+// exclusive prefix of n <= 65536 counts (one workgroup of 1024 threads); first[n] = total
+__global__ __launch_bounds__(1024) void plane_sparse_prefix_kernel(const uint32_t *__restrict__ counts, int n, unsigned long long *__restrict__ first)
+{
+    __shared__ unsigned long long part[1024];
+    const int per = (n + 1023) / 1024, a = min(n, static_cast<int>(threadIdx.x) * per), e = min(n, a + per);
+    unsigned long long sum = 0;
+    for (int i = a; i < e; i++) sum += counts[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned long long add = static_cast<int>(threadIdx.x) >= d ? part[threadIdx.x - d] : 0ull;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    unsigned long long run = part[threadIdx.x] - sum;
+    for (int i = a; i < e; i++) { first[i] = run; run += counts[i]; }
+    if (threadIdx.x == 1023) first[n] = part[1023];
+}
+
+// the set bits of every fine bucket of the share as ascending 16-bit offsets at first[slot] (keys beyond `cap` are not written:
+// the caller sees first[n] > cap)
+__global__ __launch_bounds__(256) void plane_sparse_pack_kernel(const uint32_t *__restrict__ p3, KeyBuckets share,
+                                                                const unsigned long long *__restrict__ first, uint16_t *__restrict__ keys,
+                                                                unsigned long long cap)
+{
+    const uint32_t b = blockIdx.x, b1 = b / kL2Rows;
+    if (!share.bucket(b1)) return;
+    const unsigned long long at0 = first[share_slot(share, b1) * kL2Rows + b % kL2Rows];
+    const uint32_t *g = p3 + static_cast<size_t>(b) * kFineWords;
+    constexpr int kPer = kFineWords / 256;                           // 8 consecutive words per thread: ascending keys overall
+    uint32_t w[kPer], c = 0;
+    const uint4 *g4 = reinterpret_cast<const uint4 *>(g + threadIdx.x * kPer);
+#pragma unroll
+    for (int k = 0; k < kPer / 4; k++) { const uint4 v = g4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+#pragma unroll
+    for (int k = 0; k < kPer; k++) c += __popc(w[k]);
+    // exclusive prefix of c over the workgroup
+    __shared__ uint32_t wave_sum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+    if (lane == 63) wave_sum[wv] = incl;
+    __syncthreads();
+    uint32_t before = incl - c;
+    for (int k = 0; k < wv; k++) before += wave_sum[k];
+    unsigned long long at = at0 + before;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+        uint32_t x = w[k];
+        while (x) {
+            const int bit = __ffs(static_cast<int>(x)) - 1;
+            x &= x - 1;
+            if (at < cap) keys[at] = static_cast<uint16_t>((threadIdx.x * kPer + k) * 32 + bit);
+            at++;
+        }
+    }
+}
+
+// the reverse: every fine bucket of the share rebuilt from its keys in LDS and written to the plane (all 8 KiB of it)
+__global__ __launch_bounds__(256) void plane_sparse_unpack_kernel(uint32_t *__restrict__ p3, KeyBuckets share,
+                                                                  const unsigned long long *__restrict__ first, const uint16_t *__restrict__ keys)
+{
+    __shared__ uint32_t l3[kFineWords];
+    const uint32_t b = blockIdx.x, b1 = b / kL2Rows;
+    if (!share.bucket(b1)) return;
+    const int slot = share_slot(share, b1) * kL2Rows + b % kL2Rows;
+    const unsigned long long a = first[slot], e = first[slot + 1];
+    for (int i = threadIdx.x; i < kFineWords; i += 256) l3[i] = 0;
+    __syncthreads();
+    for (unsigned long long i = a + threadIdx.x; i < e; i += 256) { const uint32_t k = keys[i]; atomicOr(&l3[k >> 5], 1u << (k & 31)); }
+    __syncthreads();
+    uint4 *o = reinterpret_cast<uint4 *>(p3 + static_cast<size_t>(b) * kFineWords);
+    for (int i = threadIdx.x; i < kFineWords / 4; i += 256) o[i] = reinterpret_cast<const uint4 *>(l3)[i];
+}
+
 static int masks_from_header(const uint8_t *hdr, CoderMasks *out)
 {
     std::memset(out, 0, sizeof *out);
@@ -2392,8 +2502,9 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     const uint8_t *eh = ix->ehits;                                  // (the attached index's own bits, left by the count launch)
     if (!fused) {                                                   // this context's: several contexts may scan through one index
         if (ix->ehits_bytes >= 16) PALACE_HIP_TRY(hipMemsetAsync(b.ehits + ix->ehits_bytes - 16, 0, 16, ctx->stream));   // (bytes behind the last entry)
+        // (every group: the plane a scan reads is complete, whatever share of the key space this context COUNTS)
         hipLaunchKernelGGL(eref_probe2_kernel, dim3(kBuckets), dim3(kProbeThreads), 0, ctx->stream, ix->first, ix->keys16, ctx->plane[2], b.ehits,
-                           0u, ctx_buckets(ctx));
+                           0u, KeyBuckets{{~0u, ~0u, ~0u, ~0u}});
         PALACE_HIP_TRY(hipGetLastError());
         eh = b.ehits;
     }
@@ -2496,6 +2607,50 @@ int palace_eref_table_pack_low(palace_ctx *ctx, void *d_low)
                        reinterpret_cast<const uint4 *>(ctx->plane[0]), reinterpret_cast<const uint4 *>(ctx->plane[1]),
                        reinterpret_cast<const uint4 *>(ctx->plane[2]), n16, static_cast<uint4 *>(d_low));
     PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+static int sparse_share(const uint32_t mask128[4], KeyBuckets *kb, int *n_fine)
+{
+    int n1 = 0;
+    for (int k = 0; k < 4; k++) { kb->m[k] = mask128[k]; n1 += __builtin_popcount(mask128[k]); }
+    *n_fine = n1 * kL2Rows;
+    return n1;
+}
+
+int palace_eref_plane_pack(palace_ctx *ctx, const uint32_t mask128[4], uint32_t *d_counts, uint16_t *d_keys, int64_t cap_keys,
+                           unsigned long long *d_first)
+{
+    PALACE_REQUIRE(ctx && mask128 && d_counts && d_keys && d_first && cap_keys >= 0, "bad argument");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_table(ctx);
+    if (rc) return rc;
+    KeyBuckets kb;
+    int n_fine = 0;
+    PALACE_REQUIRE(sparse_share(mask128, &kb, &n_fine) > 0, "empty share");
+    hipLaunchKernelGGL(plane_sparse_count_kernel, dim3(kFine), dim3(256), 0, ctx->stream, ctx->plane[2], kb, d_counts);
+    hipLaunchKernelGGL(plane_sparse_prefix_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_counts, n_fine, d_first);
+    hipLaunchKernelGGL(plane_sparse_pack_kernel, dim3(kFine), dim3(256), 0, ctx->stream, ctx->plane[2], kb, d_first, d_keys,
+                       static_cast<unsigned long long>(cap_keys));
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+int palace_eref_plane_unpack(palace_ctx *ctx, const uint32_t mask128[4], const uint32_t *d_counts, const uint16_t *d_keys,
+                             unsigned long long *d_first)
+{
+    PALACE_REQUIRE(ctx && mask128 && d_counts && d_keys && d_first, "bad argument");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_table(ctx);
+    if (rc) return rc;
+    KeyBuckets kb;
+    int n_fine = 0;
+    PALACE_REQUIRE(sparse_share(mask128, &kb, &n_fine) > 0, "empty share");
+    hipLaunchKernelGGL(plane_sparse_prefix_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_counts, n_fine, d_first);
+    hipLaunchKernelGGL(plane_sparse_unpack_kernel, dim3(kFine), dim3(256), 0, ctx->stream, ctx->plane[2], kb, d_first, d_keys);
+    PALACE_HIP_TRY(hipGetLastError());
+    ctx->table_clean = false;
+    ctx->c0_hits_ix = nullptr;
     return PALACE_OK;
 }
 

@@ -52,11 +52,15 @@ def key_buckets_of(rank: int, world: int):
 # the key arithmetic over every read does not shard); the passes of the table exchange (pack the low
 # plane, fold the parts on the owner); repacking gathered plane slices.  Everything else is interconnect arithmetic:
 # xGMI is point to point, a rank reaches each peer over its own link, `link_gbs` is what one link and direction sustains.
+# Round 5: the '>= 3' plane travels in SPARSE form (palace_eref_plane_pack / _unpack: a count per fine bucket + 2 B per set bit; the
+# 1M-contig sample sets 24 M of the 2^32 bits = 3.6 per read, 48 MB instead of 512 MiB); pack / unpack passes: reading a rank's
+# share twice, rewriting the other ranks' slices.
 MODEL = dict(reads_measured=6_666_666, count_all_ms=8.2, key_fixed_ms=2.35, key_shared_ms=5.95, three_planes_factor=1.03,
-             exchange_passes_ms=1.1, repack_ms=0.25, collective_latency_ms=0.05, link_gbs=50.0, plane_bytes=1 << 29)
+             exchange_passes_ms=1.1, repack_ms=0.25, collective_latency_ms=0.05, link_gbs=50.0, plane_bytes=1 << 29,
+             sparse_keys_per_read=3.6, sparse_pack_ms=0.1, sparse_unpack_ms=0.15)
 
 
-def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None) -> dict:
+def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None, sparse: bool = True) -> dict:
     """Modelled milliseconds of eref Phase A (count launch + what it takes to have the '>= 3' plane complete on every rank) per
     step for the three schemes, and the cheapest.  n_reads: reads of the whole sample (both FASTQ sides).
       replicate    every rank counts all reads, nothing moves
@@ -70,12 +74,17 @@ def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None) -> di
     out = {"replicate": m["count_all_ms"] * x}
     if W > 1:
         gather = per_link_ms(m["plane_bytes"] / W)                      # each rank pulls one slice per peer, all links at once
+        gather_ks = gather + m["repack_ms"]                             # (key split: the slices of a rank's buckets are packed / put back)
+        if sparse:                                                      # ... as counts + 16-bit keys, rebuilt on arrival
+            sparse_bytes = 2.0 * m["sparse_keys_per_read"] * n_reads + 4 * 65536
+            g_sparse = per_link_ms(sparse_bytes / W) + per_link_ms(4 * 65536 / W) + m["sparse_pack_ms"] + m["sparse_unpack_ms"] * (W - 1) / W
+            gather, gather_ks = min(gather, g_sparse), min(gather_ks, g_sparse)
         if 64 % W == 0:
-            out["key_split"] = (m["key_fixed_ms"] + m["key_shared_ms"] / W) * x + gather + m["repack_ms"]
+            out["key_split"] = (m["key_fixed_ms"] + m["key_shared_ms"] / W) * x + gather_ks
         out["shard_reads"] = (m["count_all_ms"] * m["three_planes_factor"] * x / W + per_link_ms(2 * m["plane_bytes"] / W)
                               + m["exchange_passes_ms"] + gather)
     choice = min(out, key=out.get)
-    return dict(ms={k: round(v, 2) for k, v in out.items()}, choice=choice, link_gbs=m["link_gbs"], n_reads=int(n_reads), world=W,
+    return dict(ms={k: round(v, 2) for k, v in out.items()}, choice=choice, link_gbs=m["link_gbs"], n_reads=int(n_reads), world=W, sparse_gather=bool(sparse),
                 note="modelled from 1-GPU kernel times and per-link xGMI arithmetic; no N > 1 hardware measurement behind it")
 
 
@@ -83,8 +92,11 @@ def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None) -> di
 # One-GPU stage times of the 1M-contig workload (bench.py stage_ms, round 4) and how they scale: classify and resolve with the
 # records (= reads), Phase B with the refs (a constant DB) over the ranks, stage 04 (selection + matching, on rank 0) with the
 # contigs -- 1.4 ms alone on a device, 4.4 ms beside a count launch that saturates it (500k contigs: 2.7, 5M: 16-18, long: 1.5).
+# Round 5: with the decomposition's phases on 2048 workgroups (the library's default; the one-GPU bench keeps 256, where the step is
+# stream A's length and the shorter, denser burst costs the count launch more) stage 04 takes 2.75 ms beside a count launch at 1M
+# contigs, 0.8 ms alone -- on N GPUs rank 0's stream B is the longer stream once Phase A is sharded, so it runs wide there.
 STEP = dict(reset_ms=0.1, phase_b_fixed_ms=0.15, phase_b_ms=1.35, classify_ms=0.45, resolve_ms=0.37, small_collective_ms=0.1,
-            stage04_alone_ms=(0.9, 0.5), stage04_beside_count_ms=(1.0, 3.4))         # (fixed, per 1M contigs)
+            stage04_alone_ms=(0.5, 0.3), stage04_beside_count_ms=(1.0, 3.4), stage04_beside_count_wide_ms=(0.6, 2.15))   # (fixed, per 1M contigs)
 
 
 def step_model(n_contigs: int, n_reads: int, world: int, scheme: str | None = None, rank0_counts: bool = True, link_gbs: float | None = None) -> dict:
@@ -102,7 +114,7 @@ def step_model(n_contigs: int, n_reads: int, world: int, scheme: str | None = No
     xc, xr, t = n_contigs / 1e6, n_reads / MODEL["reads_measured"], STEP
     coll = t["small_collective_ms"] if W > 1 else 0.0
     stream_a = t["reset_ms"] + a_phase + t["phase_b_fixed_ms"] + t["phase_b_ms"] / W + coll
-    s04 = t["stage04_beside_count_ms"] if (rank0_counts or W == 1) else t["stage04_alone_ms"]
+    s04 = t["stage04_beside_count_ms"] if W == 1 else t["stage04_beside_count_wide_ms"] if rank0_counts else t["stage04_alone_ms"]
     stream_b = t["classify_ms"] * xr / W + coll + t["resolve_ms"] * xr + coll + s04[0] + s04[1] * xc
     return dict(scheme=scheme, rank0_counts=bool(rank0_counts), stream_a_ms=round(stream_a, 2), stream_b_rank0_ms=round(stream_b, 2),
                 step_ms=round(max(stream_a, stream_b), 2))
@@ -122,14 +134,15 @@ class Exchange:
         self._recv = None
 
     # ---- eref count table ------------------------------------------------------------------------
-    def merge_planes(self, planes, merge_fn, pack_fn=None):
+    def merge_planes(self, planes, merge_fn, pack_fn=None, final_gather=None):
         """planes: three 1-D uint8 tensors (this rank's partial planes, equal length B with
         B % (16 * world) == 0).  merge_fn(parts, n_parts, slice_off, slice_bytes) must fold
         parts[plane][part][slice] into the planes at slice_off (the HIP library in production).
         With pack_fn (-> 1-D uint8 tensor of length B: the low bit of every key's count, p1 ^ p2 ^ p3) only TWO
         planes travel -- (low bit, count >= 2) carry everything the three unary planes do -- and merge_fn is called
         with packed=True on parts laid out [2][part][slice].
-        On return planes[2] is the global '>= 3' plane on every rank."""
+        On return planes[2] is the global '>= 3' plane on every rank: by an all_gather of the owners' slices, or by
+        final_gather() when given (the sparse form: gather_buckets_sparse with contiguous bucket ranges)."""
         torch, dist, W = self.torch, self.dist, self.world
         B = planes[0].numel()
         assert B % (16 * W) == 0 and all(p.numel() == B for p in planes)
@@ -148,6 +161,9 @@ class Exchange:
             merge_fn(self._recv, W, self.rank * S, S)
         else:
             merge_fn(self._recv, W, self.rank * S, S, packed=True)
+        if final_gather is not None:
+            final_gather()
+            return
         mine = planes[2][self.rank * S:(self.rank + 1) * S].clone()
         dist.all_gather_into_tensor(planes[2], mine)
 
@@ -166,6 +182,32 @@ class Exchange:
         for r in range(W):
             if r != self.rank:
                 rows.index_copy_(0, idx[r], allp[r])
+
+    def gather_buckets_sparse(self, bucket_lists, pack_fn, unpack_fn, cap_keys: int, bufs: dict):
+        """The '>= 3' plane completed on every rank without plane slices crossing the links: rank r holds the level-1 buckets
+        bucket_lists[r] (equal counts); pack_fn(counts, keys, first) fills this rank's sparse form (counts: int32 [512 * n_b],
+        keys: int16 [cap_keys], first: int64 [512 * n_b + 1] scratch), both are all-gathered, and unpack_fn(r, counts_r, keys_r,
+        first) rebuilds rank r's buckets here.  Nothing is read back: returns the (world, 512 * n_b) counts tensor -- the caller
+        checks, when the step's results are in, that no row sums to more than cap_keys (a rank whose keys were cut off: redo with
+        more room, or with gather_key_buckets)."""
+        torch, dist, W = self.torch, self.dist, self.world
+        n_b = len(bucket_lists[0])
+        assert all(len(b) == n_b for b in bucket_lists)
+        n_fine = 512 * n_b
+        dev = bufs["device"]
+        if bufs.get("cap") != cap_keys or bufs.get("n_fine") != n_fine:
+            bufs.update(cap=cap_keys, n_fine=n_fine,
+                        counts=torch.zeros(n_fine, dtype=torch.int32, device=dev), keys=torch.zeros(cap_keys, dtype=torch.int16, device=dev),
+                        first=torch.zeros(n_fine + 1, dtype=torch.int64, device=dev),
+                        counts_all=torch.zeros((W, n_fine), dtype=torch.int32, device=dev),
+                        keys_all=torch.zeros((W, cap_keys), dtype=torch.int16, device=dev))
+        pack_fn(bufs["counts"], bufs["keys"], bufs["first"])
+        dist.all_gather_into_tensor(bufs["counts_all"].view(-1), bufs["counts"])
+        dist.all_gather_into_tensor(bufs["keys_all"].view(torch.uint8).view(-1), bufs["keys"].view(torch.uint8))      # (as bytes: gloo has no int16)
+        for r in range(W):
+            if r != self.rank:
+                unpack_fn(r, bufs["counts_all"][r], bufs["keys_all"][r], bufs["first"])
+        return bufs["counts_all"]
 
     # ---- small tables ------------------------------------------------------------------------------
     def gather_ranges(self, table, ranges):

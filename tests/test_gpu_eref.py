@@ -734,3 +734,55 @@ def test_key_buckets_count_exactly_their_share_of_the_key_space(ctx, mode):
         ctx.eref_table_reset()
         for b in [db, do] + ds:
             b.free()
+
+
+def test_plane_sparse_pack_and_unpack_round_trip(ctx):
+    """palace_eref_plane_pack / _unpack (what ranks exchange instead of plane slices): counts per fine bucket = set bits of the
+    '>= 3' plane there, keys = their offsets, ascending; unpacked into ANOTHER context's table bucket share by bucket share they
+    give the same plane; too little room is reported by the total, and keys behind the room are not written"""
+    from palace_amd import multigpu
+    rng = synth.rng_for(77)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    cc = orc.header_to_cc(hdr)
+    src = synth.random_dna(rng, 60000)
+    rs = synth.vector_reads(rng, src, 9000, 120)                       # ~18x: many keys reach 3
+    u, c = oracle_key_counts(rs.bases, rs.offsets, cc)
+    three = np.sort(u[c >= 3])
+    assert len(three) > 20000
+    count_on_gpu(ctx, [(rs.bases, rs.offsets)], hdr)
+    other = capi.Ctx(0)
+    try:
+        other.eref_set_coder(hdr)
+        other.eref_table_reset()
+        total = 0
+        for r in range(4):
+            share = multigpu.key_buckets_of(r, 4)
+            mine = three[np.isin(three >> 25, share)]
+            n_fine = 512 * len(share)
+            d_cnt, d_first = ctx.upload(np.zeros(n_fine, np.uint32)), ctx.upload(np.zeros(n_fine + 1, np.uint64))
+            cap = len(mine) + 100
+            d_keys = ctx.upload(np.full(cap, 0xABCD, np.uint16))
+            ctx.eref_plane_pack(share, d_cnt.ptr, d_keys.ptr, cap, d_first.ptr)
+            ctx.sync()
+            cnt, first, keys = d_cnt.to_host(), d_first.to_host(), d_keys.to_host()
+            assert int(first[-1]) == len(mine) == int(cnt.sum()) and np.array_equal(first[:-1], np.concatenate([[0], np.cumsum(cnt)[:-1]]))
+            fine_of = np.concatenate([np.arange(b * 512, (b + 1) * 512) for b in sorted(share)])             # slot -> fine bucket
+            got = (np.repeat(fine_of, cnt).astype(np.uint64) << np.uint64(16)) | keys[:len(mine)].astype(np.uint64)
+            assert np.array_equal(got.astype(np.uint32), mine)                                               # ascending inside and across buckets
+            assert (keys[len(mine):] == 0xABCD).all()
+            # too little room: the total still says what is needed, nothing is written behind the room
+            small = ctx.upload(np.full(len(mine), 0xABCD, np.uint16))
+            ctx.eref_plane_pack(share, d_cnt.ptr, small.ptr, len(mine) // 2, d_first.ptr)
+            ctx.sync()
+            assert int(d_first.to_host()[-1]) == len(mine) and (small.to_host()[len(mine) // 2:] == 0xABCD).all()
+            # into the other context's table
+            o_cnt, o_keys, o_first = other.upload(cnt), other.upload(keys), other.upload(np.zeros(n_fine + 1, np.uint64))
+            other.eref_plane_unpack(share, o_cnt.ptr, o_keys.ptr, o_first.ptr)
+            other.sync()
+            total += len(mine)
+            assert other.eref_table_popcounts()[2] == total
+        assert total == len(three)
+        probe = np.unique(np.concatenate([three, rng.integers(0, 2**32, size=50000, dtype=np.uint64).astype(np.uint32)]))
+        assert np.array_equal(other.eref_table_lookup(probe) != 0, np.isin(probe, three))      # (only the ">= 3" plane travels)
+    finally:
+        other.close()

@@ -93,6 +93,8 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(world, port, scheme, rank0):
         assert pm["rank0_counts"] == (rank0 == "1") and ("rank 0 takes no reads" in b["config"]["parallelism"]) == (rank0 == "0")
     assert ("reads/records/refs sharded" in b["config"]["parallelism"]) == (scheme == "shard_reads")
     assert ("key space sharded" in b["config"]["parallelism"]) == (scheme == "key_split")
+    # the plane crossed the "links" as counts + 16-bit keys in every step but the first (which sizes the room)
+    assert (pm["sparse_gather"]["steps"] >= 2 and pm["sparse_gather"]["cap_keys_per_rank"] > 0) == (scheme in ("key_split", "shard_reads"))
     assert a["config"]["refs_reported"] == b["config"]["refs_reported"] > 0
     assert a["config"]["graph"] == b["config"]["graph"]
     assert a["config"]["result_digest"]["eref_rows"] == b["config"]["result_digest"]["eref_rows"]

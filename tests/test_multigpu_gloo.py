@@ -92,7 +92,53 @@ def worker(rank, world, port, q):
         ok_keys = bool(torch.equal(plane, full_plane))
         shares = [multigpu.key_buckets_of(r, world) for r in range(world)]
         ok_keys &= sorted(b for sh in shares for b in sh) == list(range(128)) and len({sum(255 - 2 * b for b in sh) for sh in shares}) == 1
-        q.put((rank, ok_planes, ok_rows, ok_var, ok_sum, ok_keys))
+        # ... and in sparse form: a count per fine bucket + the 16-bit offsets of its set bits (numpy stand-ins for
+        # palace_eref_plane_pack / _unpack; the "plane" here has 2^16 bits per fine bucket as the real one, 8 fine buckets per
+        # level-1 bucket instead of 512 -- the exchange does not care), with room that fits and room that does not
+        FINE = 8
+        dense = (rng.random((128, FINE, 1 << 16)) < 0.004)                   # every rank draws the same plane
+        mine_b = multigpu.key_buckets_of(rank, world)
+
+        def np_pack(buckets, cap):
+            cnt = np.array([dense[b, f].sum() for b in buckets for f in range(FINE)], dtype=np.int32)
+            keys = np.concatenate([np.flatnonzero(dense[b, f]) for b in buckets for f in range(FINE)]).astype(np.uint16)
+            out = np.zeros(cap, dtype=np.uint16)
+            out[:min(cap, len(keys))] = keys[:cap]
+            return cnt, out.view(np.int16)
+        got_plane = np.zeros_like(dense)
+        for b in mine_b:
+            got_plane[b] = dense[b]
+
+        def pack_fn(counts, keys, first, cap):
+            c, k = np_pack(mine_b, cap)
+            counts.copy_(torch.from_numpy(c)); keys.copy_(torch.from_numpy(k))
+
+        def unpack_fn(r, counts, keys, first):
+            c, k = counts.numpy(), keys.numpy().view(np.uint16)
+            off = np.concatenate([[0], np.cumsum(c)])
+            for j, b in enumerate(multigpu.key_buckets_of(r, world)):
+                for f in range(FINE):
+                    row = np.zeros(1 << 16, dtype=bool)
+                    row[k[off[j * FINE + f]:off[j * FINE + f + 1]]] = True
+                    got_plane[b, f] = row
+        orig_gather = multigpu.Exchange.gather_buckets_sparse
+
+        def gather(cap):
+            bufs = {"device": "cpu"}
+            # (the method sizes its buffers for 512 fine buckets per level-1 bucket: give it lists of FINE / 512 "buckets" worth)
+            bl = [multigpu.key_buckets_of(r, world) for r in range(world)]
+            n_fine = FINE * len(bl[0])
+            bufs.update(cap=cap, n_fine=512 * len(bl[0]))            # pre-sized below instead
+            bufs.update(counts=torch.zeros(n_fine, dtype=torch.int32), keys=torch.zeros(cap, dtype=torch.int16), first=torch.zeros(n_fine + 1, dtype=torch.int64),
+                        counts_all=torch.zeros((world, n_fine), dtype=torch.int32), keys_all=torch.zeros((world, cap), dtype=torch.int16))
+            return ex.gather_buckets_sparse(bl, lambda c, k, f: pack_fn(c, k, f, cap), unpack_fn, cap, bufs)
+        need = int(dense.sum(axis=(1, 2)).reshape(128)[mine_b].sum())
+        roomy = max(int(dense.sum(axis=(1, 2))[multigpu.key_buckets_of(r, world)].sum()) for r in range(world)) + 64
+        sums = gather(roomy).sum(dim=1)
+        ok_sparse = bool(np.array_equal(got_plane, dense)) and int(sums[rank]) == need and int(sums.max()) <= roomy
+        tight = gather(roomy // 2).sum(dim=1)                                # too little room: the counts say so (the caller redoes the step)
+        ok_sparse &= int(tight.max()) > roomy // 2
+        q.put((rank, ok_planes, ok_rows, ok_var, ok_sum, ok_keys and ok_sparse))
     finally:
         dist.destroy_process_group()
 
@@ -123,12 +169,16 @@ def test_phase_a_scheme_model_picks_by_size():
     on 8 -> read-sharded exchange, two GPUs -> every rank counts everything (a half plane would cross ONE link)"""
     m = multigpu.phase_a_model
     assert m(6_666_666, 8)["choice"] == "key_split" and m(6_666_666, 4)["choice"] == "key_split"
-    assert m(33_333_333, 8)["choice"] == "shard_reads" and m(33_333_333, 4)["choice"] == "shard_reads"
-    assert m(6_666_666, 2)["choice"] == "replicate" and m(6_666_666, 1)["choice"] == "replicate" and set(m(6_666_666, 1)["ms"]) == {"replicate"}
+    assert m(33_333_333, 8)["choice"] == "shard_reads" and m(33_333_333, 4, sparse=False)["choice"] == "shard_reads"
+    assert m(6_666_666, 1)["choice"] == "replicate" and set(m(6_666_666, 1)["ms"]) == {"replicate"}
+    assert m(6_666_666, 2, sparse=False)["choice"] == "replicate"                     # dense slices: half a plane would cross ONE link
+    # the plane in sparse form (48 MB instead of 512 MiB at 1M contigs): the key split pays from two GPUs on
+    assert m(6_666_666, 2)["choice"] == "key_split" and m(6_666_666, 8)["ms"]["key_split"] < m(6_666_666, 8, sparse=False)["ms"]["key_split"] - 1.0
     assert "key_split" not in m(6_666_666, 3)["ms"]                                   # shares are mirrored bucket pairs: W must divide 64
-    slow = m(6_666_666, 8, link_gbs=5.0)                                               # a slow interconnect: nothing beats counting everything
+    slow = m(6_666_666, 8, link_gbs=5.0, sparse=False)                                 # a slow interconnect, dense slices: nothing beats counting everything
     assert slow["choice"] == "replicate" and slow["link_gbs"] == 5.0
-    assert m(33_333_333, 8, link_gbs=5.0)["choice"] == "key_split"                     # ... until the sample is large: the one gather pays
+    assert m(33_333_333, 8, link_gbs=5.0, sparse=False)["choice"] == "key_split"       # ... until the sample is large: the one gather pays
+    assert m(6_666_666, 8, link_gbs=5.0)["choice"] == "key_split"                      # (in sparse form the gather is small even then)
     for w in (2, 4, 8):
         r = m(6_666_666, w)
         assert r["ms"][r["choice"]] == min(r["ms"].values()) and r["world"] == w
