@@ -75,6 +75,9 @@ int palace_timer_end(palace_ctx *ctx, float *ms_out);
 int palace_mark(palace_ctx *ctx, int i);
 int palace_mark_elapsed(palace_ctx *ctx, int a, int b, float *ms_out);
 int palace_mark_wait(palace_ctx *ctx, int i);
+/* the same with a deadline: polls the mark and gives up after `seconds` (PALACE_ESTATE; the work is still enqueued -- a caller
+ * that cannot wait any longer for a device has to leave without touching what that work writes) */
+int palace_mark_wait_for(palace_ctx *ctx, int i, double seconds);
 /* Orders two contexts on the device without the host: work enqueued on `ctx` after this call starts only when mark i of
  * `other` (recorded before this call) has been reached on other's stream. */
 int palace_wait_for_mark(palace_ctx *ctx, palace_ctx *other, int i);

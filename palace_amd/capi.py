@@ -80,6 +80,7 @@ _SIGS = {
     "palace_d2h_async": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "palace_h2d_async": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "palace_mark_wait": [C.c_void_p, C.c_int],
+    "palace_mark_wait_for": [C.c_void_p, C.c_int, C.c_double],
     "palace_wait_for_mark": [C.c_void_p, C.c_void_p, C.c_int],
     "palace_timer_begin": [C.c_void_p],
     "palace_timer_end": [C.c_void_p, C.POINTER(C.c_float)],

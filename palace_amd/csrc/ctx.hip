@@ -1,6 +1,9 @@
 // Context, memory and timing plumbing of the C ABI (include/palace_hip.h).
 #include "common.hpp"
 
+#include <chrono>
+#include <thread>
+
 namespace palace {
 
 static thread_local char g_err[512] = "";
@@ -275,6 +278,22 @@ int palace_mark_wait(palace_ctx *ctx, int i)
     PALACE_REQUIRE(ctx && i >= 0 && static_cast<size_t>(i) < ctx->marks.size() && ctx->marks[i], "mark not recorded");
     PALACE_HIP_TRY(hipEventSynchronize(ctx->marks[i]));
     return PALACE_OK;
+}
+
+int palace_mark_wait_for(palace_ctx *ctx, int i, double seconds)
+{
+    PALACE_REQUIRE(ctx && i >= 0 && static_cast<size_t>(i) < ctx->marks.size() && ctx->marks[i], "mark not recorded");
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ctx->marks[i]);
+        if (e == hipSuccess) return PALACE_OK;
+        if (e != hipErrorNotReady) { set_error("hipEventQuery failed: %s", hipGetErrorString(e)); return PALACE_EHIP; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) {
+            set_error("palace_mark_wait_for: mark %d not reached after %.1f s", i, seconds);
+            return PALACE_ESTATE;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
 }
 
 int palace_d2h(palace_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)

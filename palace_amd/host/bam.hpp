@@ -3,6 +3,7 @@
 // does inside sam_open / sam_hdr_read / sam_read1 / bam_aux_get for the reference
 // (generate_graph.cpp:611-698); written against the SAM/BAM specification, not against htslib.
 #pragma once
+#include <sys/mman.h>
 #include <cstdint>
 #include <functional>
 #include <memory>
@@ -33,13 +34,35 @@ struct RawBuf {
 
 // A vector whose resize() leaves its (trivial) elements uninitialised.  The per-record columns are written exactly once, in full,
 // by the decode threads; zero-filling 350 MB of them on one thread first was ~0.1 s of generateGraph at 6.7 M records.
+// Large columns are RESERVED, not committed (mmap with MAP_NORESERVE, as RawBuf): they are sized for the most records the inflated
+// stream can hold (bytes / 36) before the record walk has counted them -- 3.7 GB of address space for a 2 GB stream, of which only
+// the pages of the records that exist are ever touched -- and that must not fail under vm.overcommit_memory = 2 or an address-space
+// limit that the exact sizing of earlier versions fitted.
 template <class T>
-struct NoInit : std::allocator<T> {
+struct NoInit {
+    using value_type = T;
     template <class U> struct rebind { using other = NoInit<U>; };
     NoInit() = default;
     template <class U> NoInit(const NoInit<U> &) {}
+    static constexpr size_t kMapFrom = size_t{1} << 20;                   // bytes from which an allocation is a mapping of its own
+    T *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(T);
+        if (bytes < kMapFrom) return static_cast<T *>(::operator new(bytes));
+        void *m = ::mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (m == MAP_FAILED) throw std::bad_alloc();
+        return static_cast<T *>(m);
+    }
+    void deallocate(T *p, size_t n) noexcept
+    {
+        const size_t bytes = n * sizeof(T);
+        if (bytes < kMapFrom) ::operator delete(p);
+        else ::munmap(p, bytes);
+    }
     template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
     template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const NoInit<U> &) const { return true; }
+    template <class U> bool operator!=(const NoInit<U> &) const { return false; }
 };
 template <class T> using Column = std::vector<T, NoInit<T>>;
 

@@ -20,6 +20,7 @@ namespace palace_host {
 // members per batch: the device holds ~7 000 of the decoder's wavefronts at a time (28 per CU), and a batch takes the time of its
 // slowest member (~20 ms for 64 KiB) however small it is
 constexpr size_t kDeviceInflateBatch = 8192;
+constexpr double kDeviceBatchDeadlineS = 20.0;          // a batch takes ~0.1 s; behind this the device is taken to be hung
 
 inline MemberHelper device_inflate_helper(int device)
 {
@@ -30,11 +31,19 @@ inline MemberHelper device_inflate_helper(int device)
         if (palace_ctx_create(device, &ctx)) return;                           // no device: everything stays with the loader's threads
         size_t B = kDeviceInflateBatch;
         if (const char *e = std::getenv("PALACE_BAM_DEVICE_BATCH")) B = static_cast<size_t>(std::max(64, std::min(16384, std::atoi(e))));   // (tuning runs)
-        constexpr size_t kMember = 65536 + 64;
         void *d_in = nullptr, *d_out = nullptr, *d_meta = nullptr;
+        size_t in_cap = 0, out_cap = 0;                                        // sized by the batches claimed, not by the largest batch there could be
         // per member: in_off, out_off (int64), in_len, out_len, status (int32) -- one array each, one upload
         const size_t meta_bytes = B * (8 + 8 + 4 + 4 + 4);
-        bool up = !palace_malloc(ctx, B * kMember + 64, &d_in) && !palace_malloc(ctx, B * kMember + 64, &d_out) && !palace_malloc(ctx, meta_bytes, &d_meta);
+        bool up = !palace_malloc(ctx, meta_bytes, &d_meta);
+        auto room = [&](void *&p, size_t &cap, size_t need) {
+            if (need + 64 <= cap) return true;
+            if (p) palace_free(ctx, p);
+            p = nullptr; cap = 0;
+            if (palace_malloc(ctx, need + need / 8 + 64, &p)) return false;
+            cap = need + need / 8 + 64;
+            return true;
+        };
         std::vector<uint8_t> meta(meta_bytes);
         int64_t *in_off = reinterpret_cast<int64_t *>(meta.data()), *out_off = in_off + B;
         int32_t *in_len = reinterpret_cast<int32_t *>(out_off + B), *out_len = in_len + B, *status = out_len + B;
@@ -48,7 +57,7 @@ inline MemberHelper device_inflate_helper(int device)
         while (up && bm.claim(B, &first, &n)) {
             const BgzfMember &a = bm.member(first), &z = bm.member(first + n - 1);
             const uint64_t in0 = a.in_off, in1 = z.in_off + z.in_len, out0 = a.out_off, out1 = z.out_off + z.out_len;
-            bool ok = in1 - in0 <= B * kMember && out1 - out0 <= B * kMember;
+            bool ok = room(d_in, in_cap, static_cast<size_t>(in1 - in0)) && room(d_out, out_cap, static_cast<size_t>(out1 - out0));
             for (size_t k = 0; k < n; k++) {
                 const BgzfMember &m = bm.member(first + k);
                 in_off[k] = static_cast<int64_t>(m.in_off - in0); in_len[k] = static_cast<int32_t>(m.in_len);
@@ -62,7 +71,17 @@ inline MemberHelper device_inflate_helper(int device)
                                       reinterpret_cast<const int32_t *>(dm + 16 * B), reinterpret_cast<const int64_t *>(dm + 8 * B),
                                       reinterpret_cast<const int32_t *>(dm + 20 * B), static_cast<uint8_t *>(d_out), reinterpret_cast<int32_t *>(dm + 24 * B));
             if (trace) { palace_sync(ctx); t_kernel += ms_since(t0); t0 = Clock::now(); }
-            ok = ok && !palace_d2h_async(ctx, status, dm + 24 * B, 4 * n) && !palace_d2h(ctx, bm.out + out0, d_out, static_cast<size_t>(out1 - out0));
+            ok = ok && !palace_d2h_async(ctx, status, dm + 24 * B, 4 * n) && !palace_d2h_async(ctx, bm.out + out0, d_out, static_cast<size_t>(out1 - out0)) &&
+                 !palace_mark(ctx, 0);
+            if (ok && palace_mark_wait_for(ctx, 0, kDeviceBatchDeadlineS)) {
+                // the batch never came back (a kernel or a copy that does not return): its members' bytes may still be written behind
+                // our back, so nothing of this process can be trusted to finish -- say so and leave, instead of letting the loader's
+                // walker and decode threads wait for done[] forever
+                std::fprintf(stderr, "generateGraph: the device did not return a batch of BGZF members within %.0f s (%s); "
+                                     "run with PALACE_BAM_DEVICE=0 to inflate on the host alone\n", kDeviceBatchDeadlineS, palace_last_error());
+                std::fflush(stderr);
+                std::_Exit(1);
+            }
             if (trace) { t_down += ms_since(t0); batches++; members += n; }
             for (size_t k = 0; k < n; k++) bm.finished(first + k, ok && status[k] == 0);
             if (!ok) break;                                                    // the device is out of the game; what is left goes to the threads
