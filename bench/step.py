@@ -87,7 +87,7 @@ def measure(args, E, leg):
     # on one box, tools/ab.sh r05d)
     if world == 1 or solo:                          # (N GPUs: rank 0's stream B is the longer stream once Phase A is sharded: the library's 2048)
         ctx_s.match_set_option("decomp_grid", 256)
-    for opt in ("iters_per_round", "first_group_rounds", "decomp_grid"):    # tuning runs only
+    for opt in ("iters_per_round", "first_group_rounds", "decomp_grid", "one_word_keys"):    # tuning runs only
         if os.environ.get("PALACE_OPT_" + opt.upper()):
             ctx_s.match_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
     # one GPU: a second eref context (own stream, own count table, own scratch) so that consecutive batches overlap

@@ -439,6 +439,11 @@ typedef struct palace_match_result palace_match_result;
  * that read their counts from device memory) as hipGraphs at the first call with a set of arguments and replay them while the
  * arguments -- edge array, copy numbers, iterations, flags -- stay the same: for a resident caller that runs sample after
  * sample through the same buffers.  0 (default): plain launches (a one-shot process would only pay for the capture).
+ * "decomp_grid" workgroups of the decomposition's arc- and vertex-sized phases (0 = default 2048: chains of dependent random
+ * look-ups, bounded by how many are in flight; 256 costs a saturating kernel on another stream less, see bench/step.py).
+ * "one_word_keys" 0: palace_stage04_match ranks its arcs by the two-word key in every case (default 1: by a one-word form of
+ * the same order -- weight | path-backed | class of (tail, head) -- whenever the sample's arcs fit it, which saves the second
+ * proposal pass of every matching iteration: half of the atomics and a third of the look-ups).
  * "first_group_rounds" the rounds enqueued before the first look at the state (0 = default 5; fewer launches beside other
  * work, one host round trip more when a second round is needed: no effect on the step time where measured). */
 int palace_match_set_option(palace_ctx *ctx, const char *name, int64_t value);

@@ -93,6 +93,7 @@ struct palace_ctx {
     bool launch_graphs = false;     // option: stage 04 replays its launch sequences as hipGraphs
     int match_first_group = 0;      // rounds enqueued before the first look at the state (0 = default)
     int match_grid = 0;             // workgroups of the decomposition's arc- and vertex-sized phases (0 = default; decomp.hip)
+    bool match_two_word_keys = false; // option: the decomposition never uses the one-word form of the arc keys (A/B runs, tests)
     int match_iters = 0;            // matching iterations enqueued per round (0 = defaults; tests lower it to force the checked path)
     uint64_t *d_small = nullptr;   // 64 x u64 scratch for reductions
 };

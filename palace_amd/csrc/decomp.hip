@@ -28,6 +28,7 @@ namespace {
 
 constexpr uint64_t kNoKey = ~0ull;
 constexpr int kStampShift = 42;                        // khi < 2^42; the iteration stamp lives above
+constexpr int kPackedShift = 52, kPackedStamps = 1 << (64 - kPackedShift);      // one-word keys < 2^52: 12 bits of stamp
 constexpr uint64_t kLenMask = (1ull << 40) - 1;
 
 
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(kDecompBlock) void scan_apply_kernel(const uint64_t
 struct Span { int tid, n; };
 __device__ __forceinline__ Span whole_grid() { return Span{static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x), static_cast<int>(gridDim.x * blockDim.x)}; }
 
-__device__ void ph_init(const DecompBufs &b, Span T, int64_t comp_cap, int64_t vert_cap, int n_flags)
+__device__ void ph_init(const DecompBufs &b, Span T, int64_t comp_cap, int64_t vert_cap, int n_flags, int allow_packed)
 {
     DecompState *st = b.st;
     const int V = st->V;
@@ -131,6 +132,7 @@ __device__ void ph_init(const DecompBufs &b, Span T, int64_t comp_cap, int64_t v
     if (T.tid == 0) {
         st->n_comp = 0; st->n_vert = 0; st->comp_cap = comp_cap; st->vert_cap = vert_cap;
         st->unsettled = 0; st->overflow = 0; st->bad = 0; st->dead = 0; st->scan_total = 0; st->alive_after = 0;
+        st->packed = (allow_packed && b.kc && b.pack_bad && *b.pack_bad == 0) ? 1u : 0u;
         if (comp_cap >= 0) b.o_off[0] = 0;
     }
 }
@@ -142,19 +144,21 @@ __device__ void ph_round_begin(const DecompBufs &b, Span T, int reset_left)
     if (T.tid == 0) { b.st->alive_after = 0; if (reset_left) b.st->dead = 0; }
     const int64_t E = b.st->E;
     for (int64_t e = T.tid; e < E; e += T.n) b.done[e] = 0;    // every arc is looked at afresh in the round's first iteration
+    const bool packed = b.st->packed != 0;                     // (the klo slot arrays are not used then)
     for (int i = T.tid; i < V; i += T.n) {
         const int s = i >> 1;
         const int64_t l = reset_left ? 1 : b.left[s];          // the aggressive round: every segment gets one more copy
         if (reset_left && !(i & 1)) b.left[s] = 1;
         b.alive[i] = l > 0;
         b.next[i] = -1; b.prev[i] = -1;
-        b.bo_lo[i] = kNoKey; b.bo_lo[V + i] = kNoKey; b.bi_lo[i] = kNoKey; b.bi_lo[V + i] = kNoKey;
+        if (!packed) { b.bo_lo[i] = kNoKey; b.bo_lo[V + i] = kNoKey; b.bi_lo[i] = kNoKey; b.bi_lo[V + i] = kNoKey; }
         b.len_a[i] = 0;
     }
 }
 
 struct IterArgs {
     uint64_t stamp;           // (descending iteration stamp) << kStampShift
+    uint64_t stamp_p;         // the same for one-word keys: << kPackedShift
     int parity;               // which half of the klo slot arrays this iteration uses
     int prev_flag, flag;      // index of the previous iteration's `changed` word in this round (-1: first) / of this one's
     int unique_hi;
@@ -182,12 +186,13 @@ __device__ void ph_propose_hi(const DecompBufs &b, Span T, const IterArgs &a)
     const int64_t E = b.st->E;
     const int V = b.st->V;
     const int other = (a.parity ^ 1) * V;
+    const bool packed = b.st->packed != 0;
     for (int64_t e = T.tid; e < E; e += T.n) {
         PALACE_OPEN_ARC_OR_CONTINUE(b, e, u, v)
-        const uint64_t k = a.stamp | b.khi[e];
+        const uint64_t k = packed ? (a.stamp_p | b.kc[e]) : (a.stamp | b.khi[e]);
         atomicMin(reinterpret_cast<unsigned long long *>(&b.bo_hi[u]), static_cast<unsigned long long>(k));
         atomicMin(reinterpret_cast<unsigned long long *>(&b.bi_hi[v]), static_cast<unsigned long long>(k));
-        if (!a.unique_hi) { b.bo_lo[other + u] = kNoKey; b.bi_lo[other + v] = kNoKey; }
+        if (!a.unique_hi && !packed) { b.bo_lo[other + u] = kNoKey; b.bi_lo[other + v] = kNoKey; }
     }
 }
 
@@ -196,6 +201,7 @@ __device__ void ph_propose_lo(const DecompBufs &b, Span T, const IterArgs &a)
 {
     if (b.st->dead) return;
     if (a.prev_flag >= 0 && !b.changed[a.prev_flag]) return;
+    if (b.st->packed) return;                                          // one-word keys: the first pass has decided every slot
     const int64_t E = b.st->E;
     const int mine = a.parity * b.st->V;
     for (int64_t e = T.tid; e < E; e += T.n) {
@@ -219,11 +225,13 @@ __device__ void ph_commit_flag(const DecompBufs &b, Span T, const IterArgs &a, v
     bool any = false;
     const int64_t E = b.st->E;
     const int mine = a.parity * b.st->V;
+    const bool packed = b.st->packed != 0;
     for (int64_t e = T.tid; e < E; e += T.n) {
         PALACE_OPEN_ARC_OR_CONTINUE(b, e, u, v)      // (a slot taken a moment ago by another arc of this pass reads as closed: that arc held the slot's best key, not this one)
-        const uint64_t k = a.stamp | b.khi[e], lo = b.klo[e];
+        const uint64_t k = packed ? (a.stamp_p | b.kc[e]) : (a.stamp | b.khi[e]);
         if (b.bo_hi[u] != k || b.bi_hi[v] != k) continue;
-        if (!a.unique_hi && (b.bo_lo[mine + u] != lo || b.bi_lo[mine + v] != lo)) continue;
+        const uint64_t lo = b.klo[e];
+        if (!a.unique_hi && !packed && (b.bo_lo[mine + u] != lo || b.bi_lo[mine + v] != lo)) continue;
         b.next[u] = v; b.prev[v] = u;
         b.nhi[u] = b.khi[e]; b.nlo[u] = lo;
         b.done[e] = 1;                               // (taken: both its slots are closed now)
@@ -328,7 +336,7 @@ __device__ void ph_emit(const DecompBufs &b, Span T, int round, int64_t c0, int6
 
 
 // one kernel per phase
-__global__ void dec_init_kernel(DecompBufs b, int64_t comp_cap, int64_t vert_cap, int n_flags) { ph_init(b, whole_grid(), comp_cap, vert_cap, n_flags); }
+__global__ void dec_init_kernel(DecompBufs b, int64_t comp_cap, int64_t vert_cap, int n_flags, int allow_packed) { ph_init(b, whole_grid(), comp_cap, vert_cap, n_flags, allow_packed); }
 __global__ void dec_round_begin_kernel(DecompBufs b, int reset_left) { ph_round_begin(b, whole_grid(), reset_left); }
 __global__ void dec_propose_hi_kernel(DecompBufs b, IterArgs a) { ph_propose_hi(b, whole_grid(), a); }
 __global__ void dec_propose_lo_kernel(DecompBufs b, IterArgs a) { ph_propose_lo(b, whole_grid(), a); }
@@ -369,6 +377,7 @@ size_t carve_all(DecompBufs &b, char *base, int64_t s_cap, int64_t e_cap, int64_
     b.src = c.take<int32_t>(E); b.dst = c.take<int32_t>(E);
     b.khi = c.take<uint64_t>(E); b.klo = c.take<uint64_t>(E);
     b.done = c.take<uint8_t>(E);
+    b.kc = c.take<uint64_t>(E);
     b.left = c.take<int64_t>(S); b.orig = c.take<int32_t>(S);
     b.next = c.take<int32_t>(V); b.prev = c.take<int32_t>(V); b.on_path = c.take<int32_t>(V); b.open_at = c.take<int32_t>(V);
     b.nhi = c.take<uint64_t>(V); b.nlo = c.take<uint64_t>(V);
@@ -427,7 +436,8 @@ inline dim3 wide_grid(const palace_ctx *ctx) { return dim3(ctx->match_grid > 0 ?
 void enqueue_iterations(palace_ctx *ctx, const DecompBufs &b, int first, int n, uint64_t *count, int flag0, bool unique_hi)
 {
     for (int k = 0; k < n; k++) {
-        IterArgs a{((1ull << 21) - 1 - *count) << kStampShift, (first + k) & 1, k ? flag0 + k - 1 : -1, flag0 + k, unique_hi ? 1 : 0};
+        IterArgs a{((1ull << 21) - 1 - *count) << kStampShift, static_cast<uint64_t>((kPackedStamps - 1 - *count) & (kPackedStamps - 1)) << kPackedShift,
+                   (first + k) & 1, k ? flag0 + k - 1 : -1, flag0 + k, unique_hi ? 1 : 0};
         (*count)++;
         hipLaunchKernelGGL(dec_propose_hi_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, a);
         if (!unique_hi) hipLaunchKernelGGL(dec_propose_lo_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, a);
@@ -453,7 +463,9 @@ int decomp_begin(palace_ctx *ctx, const DecompBufs &b, int rounds, int64_t comp_
 {
     PALACE_REQUIRE(rounds >= 1 && rounds <= kMaxRounds, "round count out of range");
     static_assert(kDecompGrid <= kDecompBlock, "scan_prefix_kernel scans the block sums with one workgroup");
-    hipLaunchKernelGGL(dec_init_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, comp_cap, vert_cap, rounds * kMaxIters);
+    // one-word keys carry 12 bits of stamp: only when every iteration this decomposition can enqueue has a stamp of its own
+    const int allow_packed = !ctx->match_two_word_keys && static_cast<int64_t>(rounds) * kMaxIters < kPackedStamps ? 1 : 0;
+    hipLaunchKernelGGL(dec_init_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, comp_cap, vert_cap, rounds * kMaxIters, allow_packed);
     PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
 }
@@ -480,7 +492,7 @@ int decomp_run_checked(palace_ctx *ctx, const DecompBufs &b, int rounds, int agg
 {
     PALACE_REQUIRE(rounds >= 1 && rounds <= kMaxRounds, "round count out of range");
     constexpr int kBatch = 16;                                              // even: the klo parity carries over
-    hipLaunchKernelGGL(dec_init_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, comp_cap, vert_cap, kBatch);
+    hipLaunchKernelGGL(dec_init_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, comp_cap, vert_cap, kBatch, 0);      // (any number of iterations: two-word keys)
     uint64_t count = 0;
     for (int t = 0; t < rounds; t++) {
         hipLaunchKernelGGL(dec_round_begin_kernel, wide_grid(ctx), kBlock, 0, ctx->stream, b, (aggressive && t == rounds - 1) ? 1 : 0);

@@ -36,6 +36,7 @@ struct DecompState {
     uint32_t overflow;                     // output arrays too small
     uint32_t bad;                          // (unused)
     uint32_t dead;                         // no segment kept a copy in the last round: the kernels of further ordinary rounds return at once
+    uint32_t packed;                       // the arcs' one-word keys (DecompBufs::kc) rank them: the second proposal pass has nothing to do
     uint64_t scan_total;                   // last scan: sum of all inputs
     int64_t alive_after;                   // vertices reported in the last round whose segment still has copies (0: later rounds are empty)
 };
@@ -46,6 +47,13 @@ struct DecompBufs {
     int32_t *src = nullptr, *dst = nullptr;
     uint64_t *khi = nullptr, *klo = nullptr;
     uint8_t *done = nullptr;                            // the arc was seen closed in this round (it stays closed until the round ends)
+    // Optional one-word form of the rank key (round 5): kc[e] < 2^52 orders the arcs of every slot exactly as (khi, klo) does,
+    // so one 64-bit atomicMin per slot settles a proposal and the klo pass, its slot arrays and their resets fall away.  Whoever
+    // builds the arcs fills kc and counts in *pack_bad the arcs that do not fit (filter.hip: weight | backed | class of (u, v)
+    // in sub-graph ids); dec_init turns the mode on when none was counted and the decomposition enqueues fewer than 4096
+    // iterations (12 bits of stamp above the key).  nullptr: keys are (khi, klo) or, with unique_hi, khi alone.
+    uint64_t *kc = nullptr;
+    const uint32_t *pack_bad = nullptr;
     // segments [S]: copies left, id of the segment in the caller's graph (vertices are reported as 2 * orig + orientation)
     int64_t *left = nullptr;
     int32_t *orig = nullptr;

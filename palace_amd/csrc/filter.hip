@@ -31,7 +31,7 @@ struct FilterState {                                  // device scalars
     int64_t n_edges, n_junc, n_kept2, n_kept3, n_arcs;
     int64_t n_static, n_dyn;                          // arcs backed by contigs.paths / junction arcs beside them
     int64_t n_path_arcs;                              // (create) distinct arcs of contigs.paths
-    uint32_t bad, pad;
+    uint32_t bad, pack_bad;                           // pack_bad: arcs whose rank key does not fit the decomposition's one-word form (decomp.hpp)
     uint64_t scan_total;
 };
 enum : uint32_t { kBadPathToken = 1, kBadNoSeg = 2, kBadEdgeBound = 4, kBadArcTable = 8 };
@@ -101,6 +101,7 @@ __global__ void st4_begin_kernel(F f, const int64_t *__restrict__ d_n_edges, int
         fs->n_edges = n < 0 ? 0 : (n > bound ? bound : n);
         fs->n_junc = 0; fs->n_kept2 = 0; fs->n_kept3 = 0; fs->n_arcs = 0; fs->n_static = 0; fs->n_dyn = 0;
         fs->bad = n > bound ? kBadEdgeBound : 0u;
+        fs->pack_bad = 0;
         fs->scan_total = 0;
     }
 }
@@ -394,10 +395,24 @@ __global__ void st4_sub_kernel(F f, DecompBufs b, const int32_t *__restrict__ cn
         b.left[sub] = max(1, cn[f.contig_of[i]]);
     }
     const int64_t n_arcs = min(fs->n_arcs, f.arc_cap);
+    // The rank key of an arc in one word, where it fits (decomp.hpp, DecompBufs::kc): [weight term | not backed | class of (u, v)] with
+    // the sub-graph's vertex ids -- the renumbering is monotone, so classes compare as they do in st4_arc_keys_kernel's two words, and
+    // the bit that tells an arc from its conjugate there is not needed to rank the arcs of ONE slot (the two never share one).
+    const int vbits = 32 - __clz(max(1, 2 * n_sub - 1)), wbits = min(40, 51 - 2 * vbits);
+    const uint64_t wmax = wbits > 0 ? (1ull << wbits) - 1 : 0;
+    if (gtid() == 0 && wbits <= 0) fs->pack_bad = 1;
     for (int64_t a = gtid(); a < n_arcs; a += gsize()) {
         const int32_t u = f.arc_u[a], v = f.arc_v[a];
-        b.src[a] = 2 * static_cast<int32_t>(f.scan_out[u >> 1]) + (u & 1);
-        b.dst[a] = 2 * static_cast<int32_t>(f.scan_out[v >> 1]) + (v & 1);
+        const int32_t su = 2 * static_cast<int32_t>(f.scan_out[u >> 1]) + (u & 1), sv = 2 * static_cast<int32_t>(f.scan_out[v >> 1]) + (v & 1);
+        b.src[a] = su;
+        b.dst[a] = sv;
+        if (wbits > 0) {
+            const uint64_t w = f.arc_w[a];
+            if (w > wmax) atomicOr(&fs->pack_bad, 1u);
+            const uint64_t key = (static_cast<uint64_t>(su) << vbits) | static_cast<uint32_t>(sv);
+            const uint64_t twin = (static_cast<uint64_t>(sv ^ 1) << vbits) | static_cast<uint32_t>(su ^ 1);
+            b.kc[a] = ((wmax - min(w, wmax)) << (2 * vbits + 1)) | (static_cast<uint64_t>(f.arc_backed[a] ? 0u : 1u) << (2 * vbits)) | min(key, twin);
+        }
     }
     if (gtid() == 0) { b.st->S = n_sub; b.st->V = 2 * n_sub; b.st->E = n_arcs; }
 }
@@ -534,6 +549,7 @@ int grow_device(palace_ctx *ctx, palace_stage04 *s, int64_t edge_bound, int roun
         s->f.arc_backed = carve<uint8_t>(p, static_cast<size_t>(e_cap));
         s->f.arc_cap = e_cap;
         decomp_carve(s->b, p, s_cap, e_cap, comp_cap, vert_cap, rounds, kMaxIters);
+        s->b.pack_bad = &s->f.fs->pack_bad;
         PALACE_HIP_TRY(hipMemsetAsync(s->f.t.key, 0xff, slots * 8, ctx->stream));       // empty; every use leaves it empty again
         PALACE_HIP_TRY(hipMemsetAsync(s->f.t.w, 0, slots * 8, ctx->stream));
         s->edge_bound = edge_bound; s->s_cap = s_cap; s->e_cap = e_cap; s->comp_cap = comp_cap; s->vert_cap = vert_cap; s->rounds = rounds;

@@ -390,6 +390,9 @@ int palace_match_set_option(palace_ctx *ctx, const char *name, int64_t value)
     } else if (!std::strcmp(name, "launch_graphs")) {
         PALACE_REQUIRE(value == 0 || value == 1, "launch_graphs must be 0 or 1");
         ctx->launch_graphs = value != 0;
+    } else if (!std::strcmp(name, "one_word_keys")) {
+        PALACE_REQUIRE(value == 0 || value == 1, "one_word_keys must be 0 or 1");
+        ctx->match_two_word_keys = value == 0;
     } else if (!std::strcmp(name, "decomp_grid")) {
         PALACE_REQUIRE(value >= 0 && value <= 65536, "decomp_grid out of range");
         ctx->match_grid = static_cast<int>(value);
