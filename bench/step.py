@@ -59,7 +59,7 @@ def measure(args, E, leg):
     hdr = coder.header_from_picks(np.random.Generator(np.random.PCG64(SEED)).integers(0, 6, size=32))
     # Streams.  A: eref (count + scan).  B: generateGraph (classify, resolve, copy numbers) and stage 04 (selection + matching: ~150
     # small latency-bound launches), high priority.  Stage 04 beside the saturating counting kernels takes 5.4 ms instead of the
-    # 1.4 ms it takes alone and costs the count launch ~1 ms.  Measured in round 4 (tools/cu_mask_ab.sh, tools/r04c-e.sh; DESIGN.md
+    # 1.4 ms it takes alone and costs the count launch ~1 ms.  Measured in round 4 (tools/cu_mask_ab.sh, tools/archive/r04c-e.sh; DESIGN.md
     # section 4): confining stage 04 to a CU subset (hipExtStreamCreateWithCUMask; PALACE_BENCH_STAGE04_CUS=n puts it on a stream S
     # of its own on the first n CUs, and keeps stream A off them) does not help -- on 32 CUs of its own it still takes 7.2 ms
     # (it is slowed by the memory system the counting kernels saturate, not by the CUs they occupy), the step is 10.9 ms either

@@ -95,7 +95,7 @@ inline MemberHelper device_inflate_helper(int device)
 }
 
 // the helpers generateGraph starts: PALACE_BAM_DEVICE=<n> helper threads (default 2: one's copies overlap the other's kernel; 0 = the
-// host alone).  Measured on the 1M-contig sample's BAM (30 590 members; tools/r04ze.sh, settings alternated on one box): a helper is
+// host alone).  Measured on the 1M-contig sample's BAM (30 590 members; tools/archive/r04ze.sh, settings alternated on one box): a helper is
 // ready 80-100 ms into the run and takes one batch of 3 500-8 000 members (up 25-50 ms, kernel 40-65, down 35-70: the copies through
 // pageable memory are the larger part), 11 000 members (38 %) are the device's by the time the sixteen threads have met them from the
 // front; generateGraph 0.73 -> 0.68 s, with stage 04 in the process 0.86 -> 0.81 s.  (With the first version of the kernel -- window in

@@ -48,7 +48,7 @@ def key_buckets_of(rank: int, world: int):
 # ---- which Phase-A scheme for this many reads on this many GPUs ---------------------------------------------------------
 # Constants measured on ONE MI355X with the current kernels, 1M-contig workload = 6.67 M reads x 150 bp (DESIGN.md section 6;
 # tools/kr_diag.sh, profiles/): the count launch over all keys; the count launch of a 1/W key share of ALL reads
-# (2.35 + 5.95 / W ms at the end of round 4 -- 8.28 / 5.44 / 3.80 / 3.07 ms for W = 1 / 2 / 4 / 8, tools/r04z7.sh; round 3: 3.35 + 5.95 / W --:
+# (2.35 + 5.95 / W ms at the end of round 4 -- 8.28 / 5.44 / 3.80 / 3.07 ms for W = 1 / 2 / 4 / 8, tools/archive/r04z7.sh; round 3: 3.35 + 5.95 / W --:
 # the key arithmetic over every read does not shard); the passes of the table exchange (pack the low
 # plane, fold the parts on the owner); repacking gathered plane slices.  Everything else is interconnect arithmetic:
 # xGMI is point to point, a rank reaches each peer over its own link, `link_gbs` is what one link and direction sustains.
