@@ -216,7 +216,7 @@ def measure(args, E, leg):
         def sparse_gather(bucket_lists):
             counts_all = exch.gather_buckets_sparse(
                 bucket_lists, lambda c, k, f: ctx.eref_plane_pack(bucket_lists[rank], P(c), P(k), sparse["cap"], P(f)),
-                lambda r, c, k, f: ctx.eref_plane_unpack(bucket_lists[r], P(c), P(k), P(f)), sparse["cap"], sparse["bufs"])
+                lambda r, c, k, f: ctx.eref_plane_unpack(bucket_lists[r], P(c), P(k), sparse["cap"], P(f)), sparse["cap"], sparse["bufs"])
             sparse["sums_host"].copy_(counts_all.sum(dim=1, dtype=torch.int64), non_blocking=True)
             sparse["steps"] = sparse.get("steps", 0) + 1
     last = {}

@@ -229,11 +229,12 @@ int palace_eref_table_merge_slices_packed(palace_ctx *ctx, const void *d_parts, 
  *         entry than d_counts), d_keys[d_first[k] ..] = the offsets, ascending.  Keys beyond cap_keys are not written: the
  *         caller reads d_first[n] back (at its leisure) and repeats with more room, or ships the dense slices.
  * unpack: the reverse into THIS context's plane for the buckets of mask128 (every bit of those buckets is rewritten), from
- *         d_counts and d_keys as pack left them; d_first is scratch of n + 1 entries.
+ *         d_counts and d_keys as pack left them; cap_keys = the room d_keys has (keys the sender could not fit are not looked
+ *         for: the caller, who sees the counts, discards such a result); d_first is scratch of n + 1 entries.
  * Both are enqueued on the context's stream; nothing is read back. */
 int palace_eref_plane_pack(palace_ctx *ctx, const uint32_t mask128[4], uint32_t *d_counts, uint16_t *d_keys, int64_t cap_keys,
                            unsigned long long *d_first);
-int palace_eref_plane_unpack(palace_ctx *ctx, const uint32_t mask128[4], const uint32_t *d_counts, const uint16_t *d_keys,
+int palace_eref_plane_unpack(palace_ctx *ctx, const uint32_t mask128[4], const uint32_t *d_counts, const uint16_t *d_keys, int64_t cap_keys,
                              unsigned long long *d_first);
 
 /* Test hooks: counts (0..3) of `n` indices; population count of each plane. */

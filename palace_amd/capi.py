@@ -110,7 +110,7 @@ _SIGS = {
     "palace_eref_table_merge_slices_packed": [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t],
     "palace_eref_table_pack_low": [C.c_void_p, C.c_void_p],
     "palace_eref_plane_pack": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
-    "palace_eref_plane_unpack": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "palace_eref_plane_unpack": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "palace_eref_table_lookup": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "palace_eref_table_popcounts": [C.c_void_p, C.POINTER(C.c_uint64)],
     "palace_graph_classify": [C.c_void_p, C.POINTER(BamCols), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
@@ -400,8 +400,8 @@ class Ctx:
         512 * len(buckets) uint32 counts, cap_keys uint16 keys, 512 * len(buckets) + 1 uint64 prefix entries"""
         _check(lib().palace_eref_plane_pack(self.h, self._bucket_mask(buckets), counts_ptr, keys_ptr, cap_keys, first_ptr), "palace_eref_plane_pack")
 
-    def eref_plane_unpack(self, buckets, counts_ptr: int, keys_ptr: int, first_ptr: int):
-        _check(lib().palace_eref_plane_unpack(self.h, self._bucket_mask(buckets), counts_ptr, keys_ptr, first_ptr), "palace_eref_plane_unpack")
+    def eref_plane_unpack(self, buckets, counts_ptr: int, keys_ptr: int, cap_keys: int, first_ptr: int):
+        _check(lib().palace_eref_plane_unpack(self.h, self._bucket_mask(buckets), counts_ptr, keys_ptr, cap_keys, first_ptr), "palace_eref_plane_unpack")
 
 
 _ARC_BUFFERS = {}

@@ -1748,13 +1748,14 @@ __global__ __launch_bounds__(256) void plane_sparse_pack_kernel(const uint32_t *
 
 // the reverse: every fine bucket of the share rebuilt from its keys in LDS and written to the plane (all 8 KiB of it)
 __global__ __launch_bounds__(256) void plane_sparse_unpack_kernel(uint32_t *__restrict__ p3, KeyBuckets share,
-                                                                  const unsigned long long *__restrict__ first, const uint16_t *__restrict__ keys)
+                                                                  const unsigned long long *__restrict__ first, const uint16_t *__restrict__ keys,
+                                                                  unsigned long long cap)
 {
     __shared__ uint32_t l3[kFineWords];
     const uint32_t b = blockIdx.x, b1 = b / kL2Rows;
     if (!share.bucket(b1)) return;
     const int slot = share_slot(share, b1) * kL2Rows + b % kL2Rows;
-    const unsigned long long a = first[slot], e = first[slot + 1];
+    const unsigned long long a = min(first[slot], cap), e = min(first[slot + 1], cap);      // (a sender whose keys did not fit its room: what is there)
     for (int i = threadIdx.x; i < kFineWords; i += 256) l3[i] = 0;
     __syncthreads();
     for (unsigned long long i = a + threadIdx.x; i < e; i += 256) { const uint32_t k = keys[i]; atomicOr(&l3[k >> 5], 1u << (k & 31)); }
@@ -2636,10 +2637,10 @@ int palace_eref_plane_pack(palace_ctx *ctx, const uint32_t mask128[4], uint32_t 
     return PALACE_OK;
 }
 
-int palace_eref_plane_unpack(palace_ctx *ctx, const uint32_t mask128[4], const uint32_t *d_counts, const uint16_t *d_keys,
+int palace_eref_plane_unpack(palace_ctx *ctx, const uint32_t mask128[4], const uint32_t *d_counts, const uint16_t *d_keys, int64_t cap_keys,
                              unsigned long long *d_first)
 {
-    PALACE_REQUIRE(ctx && mask128 && d_counts && d_keys && d_first, "bad argument");
+    PALACE_REQUIRE(ctx && mask128 && d_counts && d_keys && d_first && cap_keys >= 0, "bad argument");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
@@ -2647,7 +2648,8 @@ int palace_eref_plane_unpack(palace_ctx *ctx, const uint32_t mask128[4], const u
     int n_fine = 0;
     PALACE_REQUIRE(sparse_share(mask128, &kb, &n_fine) > 0, "empty share");
     hipLaunchKernelGGL(plane_sparse_prefix_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_counts, n_fine, d_first);
-    hipLaunchKernelGGL(plane_sparse_unpack_kernel, dim3(kFine), dim3(256), 0, ctx->stream, ctx->plane[2], kb, d_first, d_keys);
+    hipLaunchKernelGGL(plane_sparse_unpack_kernel, dim3(kFine), dim3(256), 0, ctx->stream, ctx->plane[2], kb, d_first, d_keys,
+                       static_cast<unsigned long long>(cap_keys));
     PALACE_HIP_TRY(hipGetLastError());
     ctx->table_clean = false;
     ctx->c0_hits_ix = nullptr;

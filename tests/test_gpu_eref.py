@@ -775,9 +775,15 @@ def test_plane_sparse_pack_and_unpack_round_trip(ctx):
             ctx.eref_plane_pack(share, d_cnt.ptr, small.ptr, len(mine) // 2, d_first.ptr)
             ctx.sync()
             assert int(d_first.to_host()[-1]) == len(mine) and (small.to_host()[len(mine) // 2:] == 0xABCD).all()
-            # into the other context's table
-            o_cnt, o_keys, o_first = other.upload(cnt), other.upload(keys), other.upload(np.zeros(n_fine + 1, np.uint64))
-            other.eref_plane_unpack(share, o_cnt.ptr, o_keys.ptr, o_first.ptr)
+            # into the other context's table -- first from a key buffer that was too small for the sender (the counts say more
+            # keys than the room holds): only what is there is looked at, nothing beyond the room is read
+            o_cnt, o_first = other.upload(cnt), other.upload(np.zeros(n_fine + 1, np.uint64))
+            o_small = other.upload(keys[:len(mine) // 2].copy())
+            other.eref_plane_unpack(share, o_cnt.ptr, o_small.ptr, len(mine) // 2, o_first.ptr)
+            other.sync()
+            assert other.eref_table_popcounts()[2] == total + len(mine) // 2
+            o_keys = other.upload(keys)
+            other.eref_plane_unpack(share, o_cnt.ptr, o_keys.ptr, cap, o_first.ptr)
             other.sync()
             total += len(mine)
             assert other.eref_table_popcounts()[2] == total
