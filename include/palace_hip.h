@@ -169,13 +169,14 @@ int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t
 
 /* E5 with a per-DB probe index -- the analogue of the index file the reference builds once per DB
  * and then only reads (<fasta>.k32.index.dat, extract_ref.cpp:676-712, 1245-1251).  The index holds
- * the channel-0 index of every valid ref position grouped by table slice (6 B/position in device
- * memory: the low 16 bits of the index and, in a second array, the position) and depends on the ref
- * set and the coder only, not on the reads.  A DB of up to 2^32 positions.
+ * the three channel indices of every valid ref position as 16-bit entries grouped by table slice, the
+ * maps from a position to its entries, and a quarter of channel 0 once more as "sentinels" with their
+ * positions: 19.5 B/position in device memory (3.9 GB for a 200 Mb DB); it depends on the ref set and
+ * the coder only, not on the reads.  A DB of up to 2^32 positions.
  * palace_eref_scan_refs_indexed gives exactly the rows of palace_eref_scan_refs for the same table;
- * it replaces the per-position random probe of channel 0 by a sequential pass over 2 B/position that
- * leaves one hit BIT per index entry, and a scatter of the few per cent of entries that hit to their
- * positions (the position array is only read for those).
+ * it replaces the per-position random probes by one sequential pass over 6.5 B/position that leaves a
+ * hit BIT per entry (the plane slices in LDS), a scatter of the sentinels that hit, the exact pruning
+ * of refs and 64-position chunks on those, and a gather of the three channels' bits for what is left.
  * Meant for a resident DB scanned against many samples; a one-shot run gains nothing from it. */
 typedef struct palace_eref_probe_index palace_eref_probe_index;
 int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_refs,

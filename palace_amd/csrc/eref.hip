@@ -1140,26 +1140,43 @@ __device__ __forceinline__ uint32_t prefix_count(const uint64_t *__restrict__ wo
 // ------------------------------------------------------------------------------------------
 // E5 with a probe index: the reference reads the three indices of every ref position from a file it
 // built once per DB (<fasta>.k32.index.dat, 12 B/position, extract_ref.cpp:676-712) instead of
-// recomputing them.  The analogue here is built once per DB and kept in HBM: the channel-0 index of
-// every valid ref position, grouped by the count kernel's fine buckets (index >> 16), as two arrays in
-// ENTRY order: `keys16` (index & 0xffff, 2 B) and `pos` (position id = 64 * (word of the ref's hit
-// bitmap) + bit, 4 B); a bucket's entries start on a multiple of 8 (pad entries: key 0, pos ~0).
-// A scan tests each group of four buckets against its 32 KiB slice of plane 3 in LDS -- sequential
-// reads of 2 B/position instead of one random 64-byte sector per position -- and writes one hit BIT per
-// entry, in entry order (eref_probe2_kernel; or the count launch does, palace_eref_attach_probe_index);
-// eref_ehits_scatter_kernel then carries the few per cent of entries that hit to their positions
-// (`pos` is only read for those).  Channels 1 and 2 keep the pruned recompute-and-probe path.
-// Entry-order hit bits are also what ranks exchange when the key space is split between GPUs: 1 bit per
-// DB position and channel instead of the 512 MiB plane.
+// recomputing them.  The analogue here is built once per DB and kept in HBM, and is laid out for what
+// the scan does with it -- test EVERY position's index against the ">= 3" plane, then look at the few
+// refs that can pass:
+//   entry sets   four lists of 16-bit entries (index & 0xffff) grouped by the count kernel's fine buckets
+//                (index >> 16; a bucket's entries start on a multiple of 8): channel 0, 1 and 2 of every
+//                valid position, and the SENTINELS -- channel 0 of the positions = 0 (mod 4) of every ref.
+//                A probe tests each group of four buckets against its 32 KiB slice of plane 3 in LDS --
+//                2 B per position and channel read sequentially instead of one random 128-byte line each --
+//                and leaves one hit BIT per entry, in entry order (eref_probe_sets_kernel; for channel 0
+//                the count launch can do it, palace_eref_attach_probe_index).
+//   sentinels    `pos_s` (entry -> sentinel ordinal = position id / 4): the sentinels' hits (a quarter of
+//                channel 0's, 2.3 M at the 1M-contig sample) are scattered to position order.  A window
+//                passes only with >= three_min of its 500 positions hit in ALL channels, so it misses at most
+//                500 - three_min channel-0 hits, so of its >= 124 sentinels at least three_min - 376 hit:
+//                eref_need_kernel with that threshold on the sentinel bits marks, exactly as before, the refs
+//                and 64-position chunks that can lie in a passing window (96 % of the refs have none).
+//   entry maps   `eix[c]` (position id -> entry of channel c, ~0 = none): for the needed chunks only, the hit
+//                bits of the three channels are GATHERED from the entry-order bit arrays (25 MB each:
+//                cache resident) -- eref_gather_hits_kernel -- where round 4 / early round 5 scattered all
+//                9 M channel-0 hits into a byte per position (0.45 ms) and probed channels 1 and 2 of the needed
+//                chunks at random in the 512 MB plane (0.47 ms).
+// Entry-order hit bits are also what ranks could exchange when the key space is split between GPUs.
 // ------------------------------------------------------------------------------------------
-template <int PASS>   // 0: count positions per fine bucket, 1: place them
+constexpr int kIndexGroups = 1 << 16, kGroupsPerProbe = kIndexGroups / kBuckets;
+constexpr int kSets = 4, kSentinelSet = 3, kSentinelStride = 4;
+struct IndexBuild {
+    unsigned long long *count;                  // [kSets][65536]
+    const unsigned long long *first;            // [kSets][65537] (PASS 1)
+    uint16_t *keys16[kSets];
+    uint32_t *eix[3];                           // position id -> entry of the channel
+    uint32_t *pos_s;                            // sentinel entry -> position id / 4
+};
+template <int PASS>   // 0: count positions per set and fine bucket, 1: place them
 __global__ __launch_bounds__(256) void eref_probe_index_kernel(const uint8_t *__restrict__ bases,
                                                                const int64_t *__restrict__ offsets, int64_t n_refs,
                                                                const int64_t *__restrict__ tile_pre,
-                                                               const int64_t *__restrict__ word_pre, CoderMasks masks,
-                                                               unsigned long long *__restrict__ count,
-                                                               const unsigned long long *__restrict__ first,
-                                                               uint16_t *__restrict__ keys16, uint32_t *__restrict__ pos)
+                                                               const int64_t *__restrict__ word_pre, CoderMasks masks, IndexBuild ib)
 {
     const int64_t tile = blockIdx.x;
     if (tile >= tile_pre[n_refs]) return;
@@ -1180,15 +1197,21 @@ __global__ __launch_bounds__(256) void eref_probe_index_kernel(const uint8_t *__
         const int64_t j = c * 64 + lane;
         const uint32_t ok = window32(lo.ok, hi.ok, lane);
         if (j < npos && ok == 0xffffffffu) {
-            const uint32_t w0 = window32(lo.p0, hi.p0, lane), w1 = window32(lo.p1, hi.p1, lane),
-                           w2 = window32(lo.p2, hi.p2, lane);
-            const uint32_t key = canonical(masks, 0, w0, w1, w2, __brev(w0), __brev(w1), __brev(w2));
-            if (key != 0) {                                   // index 0 means "none" (extract_ref.cpp:861)
-                const uint32_t b = key >> 16;                    // fine bucket of the count kernel; four of them are one probe group
-                const unsigned long long at = atomicAdd(&count[b], 1ull);
+            uint32_t key[3];
+            kmer_keys(masks, window32(lo.p0, hi.p0, lane), window32(lo.p1, hi.p1, lane), window32(lo.p2, hi.p2, lane), key);
+            const uint32_t posid = static_cast<uint32_t>((wbase + c) * 64 + lane);
+#pragma unroll
+            for (int set = 0; set < kSets; set++) {
+                const uint32_t k = key[set == kSentinelSet ? 0 : set];
+                if (k == 0) continue;                             // index 0 means "none" (extract_ref.cpp:861)
+                if (set == kSentinelSet && (lane & (kSentinelStride - 1))) continue;      // (refs start on word boundaries: lane = position mod 64)
+                const uint32_t b = k >> 16;                       // fine bucket of the count kernel; four of them are one probe group
+                const unsigned long long at = atomicAdd(&ib.count[static_cast<size_t>(set) * kIndexGroups + b], 1ull);
                 if (PASS == 1) {
-                    keys16[first[b] + at] = static_cast<uint16_t>(key);
-                    pos[first[b] + at] = static_cast<uint32_t>((wbase + c) * 64 + lane);
+                    const unsigned long long e = ib.first[static_cast<size_t>(set) * (kIndexGroups + 1) + b] + at;
+                    ib.keys16[set][e] = static_cast<uint16_t>(k);
+                    if (set == kSentinelSet) ib.pos_s[e] = posid / kSentinelStride;
+                    else ib.eix[set][posid] = static_cast<uint32_t>(e);
                 }
             }
         }
@@ -1198,10 +1221,11 @@ __global__ __launch_bounds__(256) void eref_probe_index_kernel(const uint8_t *__
 
 // exclusive prefix of the 65536 fine-bucket counts, each rounded up to a multiple of 8 (one workgroup, 64 buckets per thread);
 // first[65536] = total (padded)
-constexpr int kIndexGroups = 1 << 16, kGroupsPerProbe = kIndexGroups / kBuckets;
-__global__ __launch_bounds__(1024) void eref_bucket_prefix_kernel(const unsigned long long *__restrict__ count,
-                                                                  unsigned long long *__restrict__ first)
+__global__ __launch_bounds__(1024) void eref_bucket_prefix_kernel(const unsigned long long *__restrict__ count_all,
+                                                                  unsigned long long *__restrict__ first_all)
 {
+    const unsigned long long *count = count_all + static_cast<size_t>(blockIdx.x) * kIndexGroups;       // one workgroup per entry set
+    unsigned long long *first = first_all + static_cast<size_t>(blockIdx.x) * (kIndexGroups + 1);
     __shared__ unsigned long long part[1024];
     constexpr int kPer = kIndexGroups / 1024;
     unsigned long long sum = 0;
@@ -1219,77 +1243,123 @@ __global__ __launch_bounds__(1024) void eref_bucket_prefix_kernel(const unsigned
     if (threadIdx.x == 1023) first[kIndexGroups] = run;
 }
 
-// one workgroup per group of four fine buckets: its 32 KiB slice of plane 3 in LDS, its entries (16-byte vectors of eight 16-bit
-// keys; a vector lies in ONE fine bucket, buckets start on multiples of 8) tested against it, a byte of hit bits per vector.
-// Every load of a batch is issued before the slice is waited for; the stores of a batch follow its tests.
-// `lo_group`: the first group of the launch (a rank that holds a share of the key space probes its groups only).
+// one workgroup per group of four fine buckets: its 32 KiB slice of plane 3 in LDS, the group's entries of every entry set in
+// `sets.mask` (16-byte vectors of eight 16-bit keys; a vector lies in ONE fine bucket, buckets start on multiples of 8) tested
+// against it, a byte of hit bits per vector.  The plane is read ONCE for all sets.  The first set's first batch of loads is
+// issued before the slice is waited for; the stores of a batch follow its tests.
+struct ProbeSet { const unsigned long long *first; const uint16_t *keys16; uint8_t *ehits; };
+struct ProbeSets { ProbeSet s[kSets]; uint32_t mask; };
 constexpr int kProbeThreads = 512;
-__global__ __launch_bounds__(kProbeThreads) void eref_probe2_kernel(const unsigned long long *__restrict__ first,
-                                                                    const uint16_t *__restrict__ keys16,
-                                                                    const uint32_t *__restrict__ p3, uint8_t *__restrict__ ehits,
-                                                                    uint32_t lo_group, KeyBuckets share)
+__global__ __launch_bounds__(kProbeThreads) void eref_probe_sets_kernel(ProbeSets sets, const uint32_t *__restrict__ p3)
 {
     __shared__ uint32_t l3[kSliceWords];
-    const uint32_t g = lo_group + blockIdx.x;
-    if (!share.bucket(g * kGroupsPerProbe / kL2Rows)) return;      // not this call's share of the key space
-    const unsigned long long f0 = first[g * kGroupsPerProbe] / 8;
-    unsigned long long fk[kGroupsPerProbe];                        // start vector of each fine bucket behind the first, end of the group
-#pragma unroll
-    for (int k = 0; k < kGroupsPerProbe; k++) fk[k] = first[g * kGroupsPerProbe + k + 1] / 8;
-    const unsigned long long hi = fk[kGroupsPerProbe - 1];
-    if (hi == f0) return;                                          // uniform for the workgroup
-    constexpr int kBatch = 3;                                      // a group's ~12 000 entries = ~1 500 vectors: one batch of 512 x 3
-    const uint4 *pv = reinterpret_cast<const uint4 *>(keys16);
-    uint4 cur[kBatch];
-#pragma unroll
-    for (int u = 0; u < kBatch; u++) {
-        const unsigned long long i = f0 + threadIdx.x + static_cast<unsigned long long>(u) * kProbeThreads;
-        cur[u] = i < hi ? pv[i] : uint4{0, 0, 0, 0};
-    }
+    const uint32_t g = blockIdx.x;
     const uint4 *g3 = reinterpret_cast<const uint4 *>(p3 + static_cast<size_t>(g) * kSliceWords);
     for (int i = threadIdx.x; i < kSliceWords / 4; i += kProbeThreads) reinterpret_cast<uint4 *>(l3)[i] = g3[i];
     __syncthreads();
-    auto slice_of = [&](unsigned long long i) {                    // the fine bucket's 2^16-bit part of the slice
-        uint32_t sub = 0;
+    for (int set = 0; set < kSets; set++) {                            // uniform
+        if (!((sets.mask >> set) & 1u)) continue;
+        const ProbeSet &ps = sets.s[set];
+        const unsigned long long f0 = ps.first[g * kGroupsPerProbe] / 8;
+        unsigned long long fk[kGroupsPerProbe];                        // start vector of each fine bucket behind the first, end of the group
 #pragma unroll
-        for (int k = 0; k + 1 < kGroupsPerProbe; k++) sub += i >= fk[k] ? 1u : 0u;
-        return l3 + sub * kFineWords;
-    };
-    for (unsigned long long i0 = f0 + threadIdx.x; i0 < hi; i0 += static_cast<unsigned long long>(kBatch) * kProbeThreads) {
-        uint32_t m[kBatch];
-#pragma unroll
-        for (int u = 0; u < kBatch; u++) {
-            const unsigned long long i = i0 + static_cast<unsigned long long>(u) * kProbeThreads;
-            m[u] = i < hi ? probe_vector(slice_of(i), cur[u]) : 0u;
-        }
-        const unsigned long long n0 = i0 + static_cast<unsigned long long>(kBatch) * kProbeThreads;
-        uint4 nxt[kBatch];
-        const bool more = n0 - threadIdx.x < hi;                   // uniform: a group larger than one batch
-        if (more) {
+        for (int k = 0; k < kGroupsPerProbe; k++) fk[k] = ps.first[g * kGroupsPerProbe + k + 1] / 8;
+        const unsigned long long hi = fk[kGroupsPerProbe - 1];
+        constexpr int kBatch = 3;                                      // a group's ~12 000 entries of a channel = ~1 500 vectors: one batch of 512 x 3
+        const uint4 *pv = reinterpret_cast<const uint4 *>(ps.keys16);
+        for (unsigned long long b0 = f0; b0 < hi; b0 += static_cast<unsigned long long>(kBatch) * kProbeThreads) {     // uniform
+            uint4 cur[kBatch];
 #pragma unroll
             for (int u = 0; u < kBatch; u++) {
-                const unsigned long long i = n0 + static_cast<unsigned long long>(u) * kProbeThreads;
-                nxt[u] = i < hi ? pv[i] : uint4{0, 0, 0, 0};
+                const unsigned long long i = b0 + threadIdx.x + static_cast<unsigned long long>(u) * kProbeThreads;
+                cur[u] = i < hi ? pv[i] : uint4{0, 0, 0, 0};
             }
-        }
+            uint32_t m[kBatch];
 #pragma unroll
-        for (int u = 0; u < kBatch; u++) {
-            const unsigned long long i = i0 + static_cast<unsigned long long>(u) * kProbeThreads;
-            if (i < hi) ehits[i] = static_cast<uint8_t>(m[u]);
-        }
-        if (more) {
+            for (int u = 0; u < kBatch; u++) {
+                const unsigned long long i = b0 + threadIdx.x + static_cast<unsigned long long>(u) * kProbeThreads;
+                uint32_t sub = 0;                                      // the fine bucket's 2^16-bit part of the slice
 #pragma unroll
-            for (int u = 0; u < kBatch; u++) cur[u] = nxt[u];
+                for (int k = 0; k + 1 < kGroupsPerProbe; k++) sub += i >= fk[k] ? 1u : 0u;
+                m[u] = i < hi ? probe_vector(l3 + sub * kFineWords, cur[u]) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) {
+                const unsigned long long i = b0 + threadIdx.x + static_cast<unsigned long long>(u) * kProbeThreads;
+                if (i < hi) ps.ehits[i] = static_cast<uint8_t>(m[u]);
+            }
         }
     }
 }
 
-// entry-order hit bits -> the byte-per-position array: the entries that hit (a few per cent) are listed per workgroup in LDS,
+// the sentinels' hit bytes (one per sentinel = per 4 positions, in position order) -> a bit word per 64 positions with the bits
+// of the sentinel positions (0, 4, ..., 60) set: what eref_need_kernel reads as "channel-0 hits" with the sentinel threshold
+__global__ __launch_bounds__(256) void eref_sentinel_words_kernel(const uint4 *__restrict__ sent_bytes, int64_t n_words, uint64_t *__restrict__ words)
+{
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t w = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+        const uint4 v = sent_bytes[w];                                 // 16 sentinels = 64 positions
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+        uint64_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) out |= static_cast<uint64_t>((d[k >> 2] >> (8 * (k & 3))) & 1u) << (kSentinelStride * k);
+        words[w] = out;
+    }
+}
+
+// the three channels' hit bits of the needed chunks of the active refs, gathered from the entry-order bit arrays through the
+// entry maps: any / all words as eref_ref_kernel<0> writes them; chunks that are not needed get zeros (no window that can pass
+// touches them: eref_need_kernel), the words of inactive refs are nobody's to read.  Tiling as eref_ref_kernel.
+struct GatherArgs { const uint32_t *eix[3]; const uint8_t *ehits[3]; };
+__global__ __launch_bounds__(256) void eref_gather_hits_kernel(const int64_t *__restrict__ offsets, int64_t n_refs,
+                                                               const int64_t *__restrict__ tile_pre, const int64_t *__restrict__ word_pre,
+                                                               GatherArgs ga, const uint8_t *__restrict__ need, const uint8_t *__restrict__ active,
+                                                               uint64_t *__restrict__ any_words, uint64_t *__restrict__ all_words)
+{
+    const int64_t tile = blockIdx.x;
+    if (tile >= tile_pre[n_refs]) return;
+    const int64_t r = find_seq(tile_pre, n_refs, tile);
+    if (!active[r]) return;
+    const int64_t len = offsets[r + 1] - offsets[r];
+    const int64_t npos = len - 31;
+    const int64_t n_chunks = (len + 63) / 64;
+    const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
+    constexpr int per_wave = kTileChunks / 4;
+    const int64_t c0 = (tile - tile_pre[r]) * kTileChunks + static_cast<int64_t>(wv_id) * per_wave;
+    if (c0 >= n_chunks) return;
+    const int64_t c1 = min(n_chunks, c0 + per_wave), wbase = word_pre[r];
+    uint32_t e[per_wave][3];
+    bool todo[per_wave];
+#pragma unroll
+    for (int q = 0; q < per_wave; q++) {                                  // every entry look-up of the wave's chunks, then every bit look-up
+        todo[q] = c0 + q < c1 && need[wbase + c0 + q];
+        const int64_t j = (c0 + q) * 64 + lane;
+        const int64_t posid = (wbase + c0 + q) * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < 3; c++) e[q][c] = (todo[q] && j < npos) ? ga.eix[c][posid] : ~0u;
+    }
+    uint32_t byte_of[per_wave][3];
+#pragma unroll
+    for (int q = 0; q < per_wave; q++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) byte_of[q][c] = e[q][c] != ~0u ? ga.ehits[c][e[q][c] >> 3] : 0u;
+#pragma unroll
+    for (int q = 0; q < per_wave; q++) {
+        if (c0 + q >= c1) continue;                                       // uniform
+        int h = 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) h += (byte_of[q][c] >> (e[q][c] & 7u)) & 1u;
+        const uint64_t any = __ballot(h > 0), all = __ballot(h == 3);
+        if (lane == 0) { any_words[wbase + c0 + q] = todo[q] ? any : 0ull; all_words[wbase + c0 + q] = todo[q] ? all : 0ull; }
+    }
+}
+
+// entry-order hit bits of the SENTINEL set -> a byte per sentinel in position order: the entries that hit (a few per cent) are listed per workgroup in LDS,
 // then every thread takes hits of the list -- the look-ups of `pos` and the byte stores of a thread are independent of each
 // other and issued together.  n16: 16-byte vectors of `ehits` (128 entries each).
-// A hit is a BYTE store into a byte-per-position array that eref_hits_to_bits_kernel packs afterwards: as atomicOr into the bit
-// words themselves (25 MB instead of 200 MB, no memset of the bytes, no packing pass) the ~9 M random hits of a step cost 0.45 ms
-// MORE (scan 1.81 against 1.36 ms, round 5, tools/ab.sh r05g; round 3 had found the same inside the old probe kernel).
+// A hit is a BYTE store into a byte array that eref_sentinel_words_kernel packs afterwards: as atomicOr into the bit words
+// themselves (no memset of the bytes, no packing pass) the ~9 M random hits of a step -- when ALL of channel 0 was scattered, before
+// the sentinels -- cost 0.45 ms MORE (scan 1.81 against 1.36 ms, round 5, tools/ab.sh r05g; round 3 had found the same).
 constexpr int kScatterThreads = 256, kScatterList = 4096;
 __global__ __launch_bounds__(kScatterThreads) void eref_ehits_scatter_kernel(const uint4 *__restrict__ ehits, unsigned long long n16,
                                                                              const uint32_t *__restrict__ pos, uint8_t *__restrict__ hit_bytes)
@@ -1335,19 +1405,6 @@ __global__ __launch_bounds__(kScatterThreads) void eref_ehits_scatter_kernel(con
                 if (p[u] != ~0u) hit(p[u]);
         }
         __syncthreads();
-    }
-}
-
-// hit bytes of the probe kernel -> the bit words everything downstream reads: a lane packs 16 positions (bit 0 of each byte
-// gathered by a multiply, 8 at a time) into a 16-bit piece of the word array
-__global__ __launch_bounds__(256) void eref_hits_to_bits_kernel(const uint4 *__restrict__ hit_bytes, int64_t n16, uint16_t *__restrict__ words16)
-{
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride) {
-        const uint4 v = hit_bytes[i];
-        const unsigned long long a = v.x | (static_cast<unsigned long long>(v.y) << 32), b = v.z | (static_cast<unsigned long long>(v.w) << 32);
-        const unsigned long long m = 0x0101010101010101ull, g = 0x0102040810204080ull;
-        words16[i] = static_cast<uint16_t>((((a & m) * g) >> 56) | ((((b & m) * g) >> 56) << 8));
     }
 }
 
@@ -1955,28 +2012,30 @@ static void carve_count(const CountPlan &pl, char *ws, bool with_words, CountBuf
 struct palace_eref_probe_index {
     int64_t n_refs = 0, total_bases = 0;
     palace::CoderMasks masks{};               // the coder the indices were computed with
-    unsigned long long n_entries = 0;         // entries incl. the pads that bring every fine bucket's start to a multiple of 8
-    unsigned long long *first = nullptr;      // [kIndexGroups + 1]: entries grouped by index >> 16 (the count kernel's fine buckets;
-                                              //  four consecutive groups are one 2^18-key group of the stand-alone probe kernel)
-    uint16_t *keys16 = nullptr;               // [n_entries] index & 0xffff (pads: 0)
-    uint32_t *pos = nullptr;                  // [n_entries rounded up to 128] position id (pads and the tail: ~0)
-    uint8_t *ehits = nullptr;                 // [ehits_bytes] one hit BIT per entry, entry order: written by the probe kernel, or by a count launch
-    size_t ehits_bytes = 0;                   //  this index is attached to (multiple of 16; the tail stays zero)
-    size_t hit_bytes_size = 0;                // positions ids run over [0, hit_bytes_size): a byte per position in the scan's workspace
+    // entry sets 0..2 = channels 0..2 of every valid position, 3 = the sentinels (channel 0 at positions = 0 mod 4)
+    unsigned long long n_entries[palace::kSets] = {0, 0, 0, 0};      // incl. the pads that bring every fine bucket's start to a multiple of 8
+    unsigned long long *first = nullptr;      // [kSets][kIndexGroups + 1]: entries grouped by index >> 16 (the count kernel's fine buckets;
+                                              //  four consecutive groups are one 2^18-key group of the probe kernel)
+    uint16_t *keys16[palace::kSets] = {nullptr, nullptr, nullptr, nullptr};       // [n_entries rounded up to 128 (+ 8)] index & 0xffff (pads: 0)
+    uint32_t *eix[3] = {nullptr, nullptr, nullptr};                    // [hit_bytes_size] position id -> entry of channel c (~0: none)
+    uint32_t *pos_s = nullptr;                // sentinel entry -> position id / 4 (pads and the tail: ~0)
+    uint8_t *ehits0 = nullptr;                // channel 0's hit bits (one per entry) when a count launch this index is attached to leaves them
+    size_t ehits_bytes[palace::kSets] = {0, 0, 0, 0};                  // bytes of a set's hit bits (multiple of 16; the tail stays zero)
+    size_t hit_bytes_size = 0;                // position ids run over [0, hit_bytes_size)
 };
 
 static_assert(kIndexGroups == kFine, "the probe index is grouped by the count kernel's fine buckets");
 
 static bool probe_index_usable(const palace_ctx *ctx, const palace_eref_probe_index *ix)
 {
-    return ix->ehits && ix->keys16 && std::memcmp(&ix->masks, &ctx->masks, sizeof(CoderMasks)) == 0;
+    return ix->ehits0 && ix->keys16[0] && std::memcmp(&ix->masks, &ctx->masks, sizeof(CoderMasks)) == 0;
 }
 
 // the final count kernel of a launch with Phase B's channel-0 probe riding along (eref_lds_count_kernel<true, true, true>)
 static int probe_index_launch_fused(palace_ctx *ctx, const palace_eref_probe_index *ix, const CountBufs &b, const CountPlan &pl, const KeyBuckets &keys)
 {
-    PALACE_HIP_TRY(hipMemsetAsync(ix->ehits, 0, ix->ehits_bytes, ctx->stream));      // (buckets without keys leave their bytes alone)
-    const ProbeArgs pr{ix->first, ix->keys16, ix->ehits};
+    PALACE_HIP_TRY(hipMemsetAsync(ix->ehits0, 0, ix->ehits_bytes[0], ctx->stream));      // (buckets without keys leave their bytes alone)
+    const ProbeArgs pr{ix->first, ix->keys16[0], ix->ehits0};
     hipLaunchKernelGGL((eref_lds_count_kernel<true, true, true>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
                        ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, pr);
     PALACE_HIP_TRY(hipGetLastError());
@@ -2313,13 +2372,13 @@ struct ScanBuffers {
     uint64_t *any_w, *all_w, *good_w;
     uint32_t *any_p, *all_p;
     uint8_t *need, *active;                 // per chunk / per ref flags of eref_need_kernel
-    uint8_t *hit_bytes;                     // indexed scan: a byte per position (64 per word of any_w), see eref_ehits_scatter_kernel
-    uint8_t *ehits;                         // indexed scan, probing for itself: a hit bit per index entry (eref_probe2_kernel)
+    uint8_t *hit_bytes;                     // indexed scan: a byte per SENTINEL (16 per word of any_w), see eref_ehits_scatter_kernel
+    uint8_t *ehits[kSets];                  // indexed scan: a hit bit per index entry and entry set (eref_probe_sets_kernel)
     int64_t max_tiles, max_words;
 };
 
 int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int64_t total_bases, ScanBuffers *b, bool with_hit_bytes = false,
-                 size_t ehits_bytes = 0)
+                 const size_t *ehits_bytes = nullptr)
 {
     b->max_tiles = total_bases / kTilePos + n_refs;
     b->max_words = total_bases / 64 + n_refs + 1;
@@ -2327,9 +2386,10 @@ int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int6
     const size_t pre_bytes = align_up((n_refs + 1) * 8, 256);
     const size_t w64 = align_up(b->max_words * 8, 256), w32 = align_up(b->max_words * 4, 256);
     const size_t w8 = align_up(b->max_words, 256);
-    const size_t hb = with_hit_bytes ? align_up(static_cast<size_t>(b->max_words) * 64, 256) : 0;
-    const size_t eb = ehits_bytes ? align_up(ehits_bytes + 16, 256) : 0;
-    int rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32 + w8 + align_up(n_refs + 1, 256) + hb + eb);
+    const size_t hb = with_hit_bytes ? align_up(static_cast<size_t>(b->max_words) * (64 / kSentinelStride), 256) : 0;
+    size_t eb[kSets] = {0, 0, 0, 0}, eb_all = 0;
+    for (int k = 0; k < kSets; k++) { eb[k] = ehits_bytes && ehits_bytes[k] ? align_up(ehits_bytes[k] + 16, 256) : 0; eb_all += eb[k]; }
+    int rc = ensure_workspace(ctx, 2 * pre_bytes + 3 * w64 + 2 * w32 + w8 + align_up(n_refs + 1, 256) + hb + eb_all);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws.ptr);
     b->tile_pre = reinterpret_cast<int64_t *>(ws); ws += pre_bytes;
@@ -2342,7 +2402,7 @@ int scan_buffers(palace_ctx *ctx, const int64_t *d_offsets, int64_t n_refs, int6
     b->need = reinterpret_cast<uint8_t *>(ws); ws += w8;
     b->active = reinterpret_cast<uint8_t *>(ws); ws += align_up(n_refs + 1, 256);
     b->hit_bytes = with_hit_bytes ? reinterpret_cast<uint8_t *>(ws) : nullptr; ws += hb;
-    b->ehits = eb ? reinterpret_cast<uint8_t *>(ws) : nullptr;
+    for (int k = 0; k < kSets; k++) { b->ehits[k] = eb[k] ? reinterpret_cast<uint8_t *>(ws) : nullptr; ws += eb[k]; }
     return launch_prefix(ctx, d_offsets, n_refs, b->tile_pre, b->word_pre);
 }
 
@@ -2424,33 +2484,50 @@ int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const
         hipError_t e__ = (expr);                                                                            \
         if (e__ != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(e__)); return done(PALACE_EHIP); } \
     } while (0)
-    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->first), (kIndexGroups + 1) * 8));
-    TRY_OR_DONE(hipMemsetAsync(ix->first, 0, (kIndexGroups + 1) * 8, ctx->stream));
+    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->first), static_cast<size_t>(kSets) * (kIndexGroups + 1) * 8));
+    TRY_OR_DONE(hipMemsetAsync(ix->first, 0, static_cast<size_t>(kSets) * (kIndexGroups + 1) * 8, ctx->stream));
     if (n_refs == 0) return done(PALACE_OK);
     ScanBuffers b;
     int rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b);     // tile_pre / word_pre exactly as the scans lay them out
     if (rc) return done(rc);
-    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&count), kIndexGroups * 8));
-    TRY_OR_DONE(hipMemsetAsync(count, 0, kIndexGroups * 8, ctx->stream));
+    const size_t count_bytes = static_cast<size_t>(kSets) * kIndexGroups * 8;
+    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&count), count_bytes));
+    TRY_OR_DONE(hipMemsetAsync(count, 0, count_bytes, ctx->stream));
+    IndexBuild ib{};
+    ib.count = count;
     hipLaunchKernelGGL(eref_probe_index_kernel<0>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
-                       d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, count,
-                       static_cast<const unsigned long long *>(nullptr), static_cast<uint16_t *>(nullptr), static_cast<uint32_t *>(nullptr));
-    hipLaunchKernelGGL(eref_bucket_prefix_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, ix->first);
+                       d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, ib);
+    hipLaunchKernelGGL(eref_bucket_prefix_kernel, dim3(kSets), dim3(1024), 0, ctx->stream, count, ix->first);
     TRY_OR_DONE(hipGetLastError());
-    TRY_OR_DONE(hipMemcpyAsync(&ix->n_entries, ix->first + kIndexGroups, 8, hipMemcpyDeviceToHost, ctx->stream));
+    for (int k = 0; k < kSets; k++)
+        TRY_OR_DONE(hipMemcpyAsync(&ix->n_entries[k], ix->first + static_cast<size_t>(k) * (kIndexGroups + 1) + kIndexGroups, 8, hipMemcpyDeviceToHost, ctx->stream));
     TRY_OR_DONE(hipStreamSynchronize(ctx->stream));
-    const unsigned long long n128 = (ix->n_entries + 127) / 128 * 128;
-    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->keys16), (n128 + 8) * 2));
-    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->pos), (n128 + 8) * 4));
-    ix->ehits_bytes = static_cast<size_t>(n128 / 8);
-    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->ehits), ix->ehits_bytes + 16));
-    TRY_OR_DONE(hipMemsetAsync(ix->keys16, 0, (n128 + 8) * 2, ctx->stream));
-    TRY_OR_DONE(hipMemsetAsync(ix->pos, 0xff, (n128 + 8) * 4, ctx->stream));
-    TRY_OR_DONE(hipMemsetAsync(ix->ehits, 0, ix->ehits_bytes + 16, ctx->stream));
-    TRY_OR_DONE(hipMemsetAsync(count, 0, kIndexGroups * 8, ctx->stream));
     ix->hit_bytes_size = static_cast<size_t>(b.max_words) * 64;                                     // (position ids run over the words of the hit bitmap)
+    for (int k = 0; k < kSets; k++) {
+        if (ix->n_entries[k] >= (1ull << 32) - 256) { set_error("palace_eref_probe_index_build: too many entries for 32-bit entry ids"); return done(PALACE_EINVAL); }
+        const unsigned long long n128 = (ix->n_entries[k] + 127) / 128 * 128;
+        TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->keys16[k]), (n128 + 8) * 2));
+        TRY_OR_DONE(hipMemsetAsync(ix->keys16[k], 0, (n128 + 8) * 2, ctx->stream));
+        ix->ehits_bytes[k] = static_cast<size_t>(n128 / 8);
+        ib.keys16[k] = ix->keys16[k];
+    }
+    for (int c = 0; c < 3; c++) {
+        TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->eix[c]), ix->hit_bytes_size * 4 + 64));
+        TRY_OR_DONE(hipMemsetAsync(ix->eix[c], 0xff, ix->hit_bytes_size * 4 + 64, ctx->stream));
+        ib.eix[c] = ix->eix[c];
+    }
+    {
+        const unsigned long long n128 = (ix->n_entries[kSentinelSet] + 127) / 128 * 128;
+        TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->pos_s), (n128 + 8) * 4));
+        TRY_OR_DONE(hipMemsetAsync(ix->pos_s, 0xff, (n128 + 8) * 4, ctx->stream));
+        ib.pos_s = ix->pos_s;
+    }
+    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->ehits0), ix->ehits_bytes[0] + 16));
+    TRY_OR_DONE(hipMemsetAsync(ix->ehits0, 0, ix->ehits_bytes[0] + 16, ctx->stream));
+    TRY_OR_DONE(hipMemsetAsync(count, 0, count_bytes, ctx->stream));
+    ib.first = ix->first;
     hipLaunchKernelGGL(eref_probe_index_kernel<1>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
-                       d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, count, ix->first, ix->keys16, ix->pos);
+                       d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, ib);
     TRY_OR_DONE(hipGetLastError());
 #undef TRY_OR_DONE
     return done(PALACE_OK);
@@ -2463,9 +2540,10 @@ int palace_eref_probe_index_free(palace_ctx *ctx, palace_eref_probe_index *ix)
     if (ctx && ctx->probe_ix == ix) ctx->probe_ix = nullptr;
     if (ctx && ctx->c0_hits_ix == ix) ctx->c0_hits_ix = nullptr;
     if (ix->first) (void)hipFree(ix->first);
-    if (ix->keys16) (void)hipFree(ix->keys16);
-    if (ix->pos) (void)hipFree(ix->pos);
-    if (ix->ehits) (void)hipFree(ix->ehits);
+    for (int k = 0; k < palace::kSets; k++) if (ix->keys16[k]) (void)hipFree(ix->keys16[k]);
+    for (int c = 0; c < 3; c++) if (ix->eix[c]) (void)hipFree(ix->eix[c]);
+    if (ix->pos_s) (void)hipFree(ix->pos_s);
+    if (ix->ehits0) (void)hipFree(ix->ehits0);
     delete ix;
     return PALACE_OK;
 }
@@ -2492,29 +2570,48 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     rc = ensure_table(ctx);
     if (rc) return rc;
-    // channel 0: the count launch has left the entry-order hit bits when this index was attached to it and nothing has touched the
-    // planes since; otherwise the probe kernel makes them now.  Then the entries that hit are carried to their positions.
+    // channel 0's hit bits: the count launch has left them when this index was attached to it and nothing has touched the planes
+    // since; every other entry set (and channel 0 otherwise) is probed now, the plane read once for all of them
     const bool fused = ctx->c0_hits_ix == ix;
+    size_t eb[kSets];
+    for (int k = 0; k < kSets; k++) eb[k] = (k == 0 && fused) ? 0 : ix->ehits_bytes[k];
     ScanBuffers b;
-    rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b, true, fused ? 0 : ix->ehits_bytes);
+    rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b, true, eb);
     if (rc) return rc;
     PALACE_REQUIRE(static_cast<size_t>(b.max_words) * 64 == ix->hit_bytes_size, "probe index was built for another layout of the hit words");
-    PALACE_HIP_TRY(hipMemsetAsync(b.hit_bytes, 0, static_cast<size_t>(b.max_words) * 64, ctx->stream));
-    const uint8_t *eh = ix->ehits;                                  // (the attached index's own bits, left by the count launch)
-    if (!fused) {                                                   // this context's: several contexts may scan through one index
-        if (ix->ehits_bytes >= 16) PALACE_HIP_TRY(hipMemsetAsync(b.ehits + ix->ehits_bytes - 16, 0, 16, ctx->stream));   // (bytes behind the last entry)
-        // (every group: the plane a scan reads is complete, whatever share of the key space this context COUNTS)
-        hipLaunchKernelGGL(eref_probe2_kernel, dim3(kBuckets), dim3(kProbeThreads), 0, ctx->stream, ix->first, ix->keys16, ctx->plane[2], b.ehits,
-                           0u, KeyBuckets{{~0u, ~0u, ~0u, ~0u}});
-        PALACE_HIP_TRY(hipGetLastError());
-        eh = b.ehits;
+    PALACE_HIP_TRY(hipMemsetAsync(b.hit_bytes, 0, static_cast<size_t>(b.max_words) * (64 / kSentinelStride), ctx->stream));
+    ProbeSets sets{};
+    for (int k = 0; k < kSets; k++) {
+        uint8_t *eh = (k == 0 && fused) ? ix->ehits0 : b.ehits[k];   // (this context's: several contexts may scan through one index)
+        sets.s[k] = ProbeSet{ix->first + static_cast<size_t>(k) * (kIndexGroups + 1), ix->keys16[k], eh};
+        if (!(k == 0 && fused)) {
+            sets.mask |= 1u << k;
+            if (ix->ehits_bytes[k] >= 16) PALACE_HIP_TRY(hipMemsetAsync(eh + ix->ehits_bytes[k] - 16, 0, 16, ctx->stream));     // (bytes behind the last entry)
+        }
     }
-    hipLaunchKernelGGL(eref_ehits_scatter_kernel, dim3(kCUs * 8), dim3(kScatterThreads), 0, ctx->stream, reinterpret_cast<const uint4 *>(eh),
-                       static_cast<unsigned long long>(ix->ehits_bytes / 16), ix->pos, b.hit_bytes);
-    hipLaunchKernelGGL(eref_hits_to_bits_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(b.hit_bytes),
-                       b.max_words * 4, reinterpret_cast<uint16_t *>(b.any_w));
+    hipLaunchKernelGGL(eref_probe_sets_kernel, dim3(kBuckets), dim3(kProbeThreads), 0, ctx->stream, sets, ctx->plane[2]);
+    // the sentinels that hit -> position order -> the bit words eref_need_kernel reads
+    hipLaunchKernelGGL(eref_ehits_scatter_kernel, dim3(kCUs * 8), dim3(kScatterThreads), 0, ctx->stream,
+                       reinterpret_cast<const uint4 *>(sets.s[kSentinelSet].ehits), static_cast<unsigned long long>(ix->ehits_bytes[kSentinelSet] / 16),
+                       ix->pos_s, b.hit_bytes);
+    hipLaunchKernelGGL(eref_sentinel_words_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(b.hit_bytes),
+                       b.max_words, b.any_w);
     PALACE_HIP_TRY(hipGetLastError());
-    return scan_tail(ctx, b, d_bases, d_offsets, n_refs, one_min, three_min, d_rows);
+    // A window that passes holds >= three_min positions hit in all channels, i.e. misses at most 500 - three_min channel-0 hits;
+    // it holds at least 500 / 4 - 1 sentinels (the cumulative windows at a ref's start, which must hold three_min positions
+    // to pass at all, hold more in proportion), so at least this many of its sentinels hit:
+    const int sentinel_min = std::max(0, 500 / kSentinelStride - 1 - (500 - three_min));
+    hipLaunchKernelGGL(eref_need_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(kRefThreads), 0, ctx->stream, d_offsets,
+                       n_refs, b.word_pre, b.any_w, b.any_p, b.good_w, b.all_p, sentinel_min, b.need, b.active);
+    GatherArgs ga{};
+    for (int c = 0; c < 3; c++) { ga.eix[c] = ix->eix[c]; ga.ehits[c] = sets.s[c].ehits; }
+    hipLaunchKernelGGL(eref_gather_hits_kernel, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream, d_offsets, n_refs,
+                       b.tile_pre, b.word_pre, ga, static_cast<const uint8_t *>(b.need), static_cast<const uint8_t *>(b.active), b.any_w, b.all_w);
+    hipLaunchKernelGGL(eref_window_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(kRefThreads), 0, ctx->stream,
+                       d_offsets, n_refs, b.word_pre, b.any_w, b.all_w, b.any_p, b.all_p, b.good_w, one_min, three_min,
+                       static_cast<const uint8_t *>(b.active), d_rows);
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
 }
 
 int palace_eref_table_planes(palace_ctx *ctx, void **d_planes3, size_t *bytes_per_plane)
