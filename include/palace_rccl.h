@@ -36,6 +36,13 @@ int palace_eref_table_exchange(palace_ctx *ctx, void *comm, int rank, int world)
  * place, stream-ordered).  No partial tables, no merge.  world must divide 64. */
 int palace_eref_key_share(int rank, int world, uint32_t mask128[4]);
 int palace_eref_key_share_gather(palace_ctx *ctx, void *comm, int rank, int world);
+/* The same gather with the plane in SPARSE form (palace_eref_plane_pack / _unpack of palace_hip.h): every rank sends the number of
+ * set bits of each of its fine buckets and their 16-bit offsets -- 48 MB for the whole plane of a 1M-contig sample instead of
+ * 512 MiB of slices.  cap_keys = room for ONE rank's keys (the same on every rank).  h_max_keys, when not NULL, receives the
+ * number of keys the largest share holds (the call then waits for the stream): a value above cap_keys means keys were cut off
+ * -- call palace_eref_key_share_gather instead (the counting is not repeated: the rank's own slices are untouched), and give
+ * the next sample that much room + a margin.  A first call with cap_keys = 0 only sizes. */
+int palace_eref_key_share_gather_sparse(palace_ctx *ctx, void *comm, int rank, int world, int64_t cap_keys, unsigned long long *h_max_keys);
 
 /* Phase B rows: every rank scanned the refs [ref_lo[r], ref_hi[r]) and holds their rows (4 x int32 per ref) in d_rows;
  * afterwards every rank holds all n_refs rows.  ref_lo / ref_hi: host arrays of `world` entries, the same on every rank. */

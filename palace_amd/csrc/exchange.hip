@@ -85,6 +85,55 @@ int palace_eref_key_share_gather(palace_ctx *ctx, void *comm_, int rank, int wor
     return PALACE_OK;
 }
 
+// The same gather with the plane in sparse form (palace_eref_plane_pack / _unpack): counts + 16-bit keys instead of slices.
+int palace_eref_key_share_gather_sparse(palace_ctx *ctx, void *comm_, int rank, int world, int64_t cap_keys, unsigned long long *h_max_keys)
+{
+    PALACE_REQUIRE(ctx && comm_ && world >= 1 && rank >= 0 && rank < world && 64 % world == 0 && cap_keys >= 0, "world must divide 64");
+    ncclComm_t comm = static_cast<ncclComm_t>(comm_);
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n_fine = 65536 / static_cast<size_t>(world);
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t counts_b = up(n_fine * 4), keys_b = up(static_cast<size_t>(cap_keys) * 2 + 16), first_b = up((n_fine + 1) * 8);
+    int rc = ensure_workspace(ctx, world * (counts_b + keys_b) + first_b);
+    if (rc) return rc;
+    char *ws = static_cast<char *>(ctx->ws.ptr);
+    char *counts = ws, *keys = ws + world * counts_b, *first = keys + world * keys_b;
+    uint32_t mine[4];
+    rc = palace_eref_key_share(rank, world, mine);
+    if (rc) return rc;
+    // this rank's share packed straight into its slot of the gathered arrays, then both arrays gathered in place
+    rc = palace_eref_plane_pack(ctx, mine, reinterpret_cast<uint32_t *>(counts + rank * counts_b), reinterpret_cast<uint16_t *>(keys + rank * keys_b),
+                                cap_keys, reinterpret_cast<unsigned long long *>(first));
+    if (rc) return rc;
+    PALACE_NCCL_TRY(ncclGroupStart());
+    PALACE_NCCL_TRY(ncclAllGather(counts + rank * counts_b, counts, counts_b, ncclUint8, comm, ctx->stream));
+    PALACE_NCCL_TRY(ncclAllGather(keys + rank * keys_b, keys, keys_b, ncclUint8, comm, ctx->stream));
+    PALACE_NCCL_TRY(ncclGroupEnd());
+    for (int r = 0; r < world; r++) {
+        if (r == rank) continue;
+        uint32_t theirs[4];
+        rc = palace_eref_key_share(r, world, theirs);
+        if (rc) return rc;
+        rc = palace_eref_plane_unpack(ctx, theirs, reinterpret_cast<const uint32_t *>(counts + r * counts_b), reinterpret_cast<const uint16_t *>(keys + r * keys_b),
+                                      cap_keys, reinterpret_cast<unsigned long long *>(first));
+        if (rc) return rc;
+    }
+    if (h_max_keys) {                                        // what the largest share needed: more than cap_keys means keys were cut off
+        std::vector<uint32_t> h(world * n_fine);
+        for (int r = 0; r < world; r++)
+            PALACE_HIP_TRY(hipMemcpyAsync(h.data() + r * n_fine, counts + r * counts_b, n_fine * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        unsigned long long mx = 0;
+        for (int r = 0; r < world; r++) {
+            unsigned long long t = 0;
+            for (size_t k = 0; k < n_fine; k++) t += h[r * n_fine + k];
+            mx = std::max(mx, t);
+        }
+        *h_max_keys = mx;
+    }
+    return PALACE_OK;
+}
+
 int palace_eref_rows_allgather(palace_ctx *ctx, void *comm_, int rank, int world, int32_t *d_rows, int64_t n_refs,
                                const int64_t *ref_lo, const int64_t *ref_hi)
 {

@@ -65,6 +65,13 @@ int main(int argc, char **argv)
     CK(palace_sync(ctx));
     CK(palace_eref_table_popcounts(ctx, after));
     if (std::memcmp(before, after, sizeof before) != 0) { std::fprintf(stderr, "exchange_selftest: the share gather changed the planes\n"); return 1; }
+    // ... and in sparse form: sized first (room 0: nothing is written, the total is reported), then with room
+    unsigned long long need = 0, again = 0;
+    CK(palace_eref_key_share_gather_sparse(ctx, comm, 0, 1, 0, &need));
+    if (need != before[2]) { std::fprintf(stderr, "exchange_selftest: sparse gather sized %llu keys, plane 3 has %llu\n", need, (unsigned long long)before[2]); return 1; }
+    CK(palace_eref_key_share_gather_sparse(ctx, comm, 0, 1, static_cast<int64_t>(need + 64), &again));
+    CK(palace_eref_table_popcounts(ctx, after));
+    if (again != need || std::memcmp(before, after, sizeof before) != 0) { std::fprintf(stderr, "exchange_selftest: the sparse share gather changed the planes\n"); return 1; }
     // rows: 5 refs, all owned by rank 0
     std::vector<int32_t> rows(20);
     for (int i = 0; i < 20; i++) rows[static_cast<size_t>(i)] = i * 3 + 1;

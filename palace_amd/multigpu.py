@@ -89,13 +89,13 @@ def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None, spars
 
 
 # ---- the whole step of one rank, serial terms included ------------------------------------------------
-# One-GPU stage times of the 1M-contig workload (bench.py stage_ms, round 4) and how they scale: classify and resolve with the
+# One-GPU stage times of the 1M-contig workload (bench.py stage_ms, round 5: Phase B 1.07 ms probing for itself) and how they scale: classify and resolve with the
 # records (= reads), Phase B with the refs (a constant DB) over the ranks, stage 04 (selection + matching, on rank 0) with the
 # contigs -- 1.4 ms alone on a device, 4.4 ms beside a count launch that saturates it (500k contigs: 2.7, 5M: 16-18, long: 1.5).
 # Round 5: with the decomposition's phases on 2048 workgroups (the library's default; the one-GPU bench keeps 256, where the step is
 # stream A's length and the shorter, denser burst costs the count launch more) stage 04 takes 2.75 ms beside a count launch at 1M
 # contigs, 0.8 ms alone -- on N GPUs rank 0's stream B is the longer stream once Phase A is sharded, so it runs wide there.
-STEP = dict(reset_ms=0.1, phase_b_fixed_ms=0.15, phase_b_ms=1.35, classify_ms=0.45, resolve_ms=0.37, small_collective_ms=0.1,
+STEP = dict(reset_ms=0.1, phase_b_fixed_ms=0.15, phase_b_ms=0.92, classify_ms=0.45, resolve_ms=0.37, small_collective_ms=0.1,
             stage04_alone_ms=(0.5, 0.3), stage04_beside_count_ms=(1.0, 3.4), stage04_beside_count_wide_ms=(0.6, 2.15))   # (fixed, per 1M contigs)
 
 
