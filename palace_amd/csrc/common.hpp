@@ -73,6 +73,7 @@ struct palace_ctx {
     bool want_final = false;        // option final_count: a count into a clean table may keep only the ">= 3" plane
     bool final_only = false;        // ... and did: planes ">= 1" and ">= 2" are all zero, the table cannot take further counts
     bool table_clean = false;       // every plane bit is zero (set by reset, cleared by whatever writes the planes)
+    int64_t keys_counted = 0;       // key instances counted into the table since the last reset (an upper bound; -1: unknown -- planes merged or written from outside)
     // Phase B's channel-0 probe fused into the count launch (palace_eref_attach_probe_index): the attached per-DB index, and the
     // index whose hit bytes the last count launch left complete (cleared by whatever changes the planes afterwards)
     const struct palace_eref_probe_index *probe_ix = nullptr;

@@ -1311,6 +1311,10 @@ __global__ __launch_bounds__(256) void eref_sentinel_words_kernel(const uint4 *_
 // entry maps: any / all words as eref_ref_kernel<0> writes them; chunks that are not needed get zeros (no window that can pass
 // touches them: eref_need_kernel), the words of inactive refs are nobody's to read.  Tiling as eref_ref_kernel.
 struct GatherArgs { const uint32_t *eix[3]; const uint8_t *ehits[3]; };
+// MODE 0: all three channels (the pruning on the sentinels is the only one);
+// MODE 1: channel 0 alone into any_words -- on which eref_need_kernel prunes a SECOND time, with the exact threshold;
+// MODE 2: channels 1 and 2, joined with the channel-0 bits MODE 1 left in any_words (chunks not needed any more: zeros).
+template <int MODE>
 __global__ __launch_bounds__(256) void eref_gather_hits_kernel(const int64_t *__restrict__ offsets, int64_t n_refs,
                                                                const int64_t *__restrict__ tile_pre, const int64_t *__restrict__ word_pre,
                                                                GatherArgs ga, const uint8_t *__restrict__ need, const uint8_t *__restrict__ active,
@@ -1328,6 +1332,7 @@ __global__ __launch_bounds__(256) void eref_gather_hits_kernel(const int64_t *__
     const int64_t c0 = (tile - tile_pre[r]) * kTileChunks + static_cast<int64_t>(wv_id) * per_wave;
     if (c0 >= n_chunks) return;
     const int64_t c1 = min(n_chunks, c0 + per_wave), wbase = word_pre[r];
+    constexpr int C0 = MODE == 2 ? 1 : 0, C1 = MODE == 1 ? 1 : 3;         // channels [C0, C1) are gathered
     uint32_t e[per_wave][3];
     bool todo[per_wave];
 #pragma unroll
@@ -1336,21 +1341,25 @@ __global__ __launch_bounds__(256) void eref_gather_hits_kernel(const int64_t *__
         const int64_t j = (c0 + q) * 64 + lane;
         const int64_t posid = (wbase + c0 + q) * 64 + lane;
 #pragma unroll
-        for (int c = 0; c < 3; c++) e[q][c] = (todo[q] && j < npos) ? ga.eix[c][posid] : ~0u;
+        for (int c = C0; c < C1; c++) e[q][c] = (todo[q] && j < npos) ? ga.eix[c][posid] : ~0u;
     }
     uint32_t byte_of[per_wave][3];
 #pragma unroll
     for (int q = 0; q < per_wave; q++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) byte_of[q][c] = e[q][c] != ~0u ? ga.ehits[c][e[q][c] >> 3] : 0u;
+        for (int c = C0; c < C1; c++) byte_of[q][c] = e[q][c] != ~0u ? ga.ehits[c][e[q][c] >> 3] : 0u;
 #pragma unroll
     for (int q = 0; q < per_wave; q++) {
         if (c0 + q >= c1) continue;                                       // uniform
         int h = 0;
 #pragma unroll
-        for (int c = 0; c < 3; c++) h += (byte_of[q][c] >> (e[q][c] & 7u)) & 1u;
+        for (int c = C0; c < C1; c++) h += (byte_of[q][c] >> (e[q][c] & 7u)) & 1u;
+        if (MODE == 2) h += todo[q] ? static_cast<int>((any_words[wbase + c0 + q] >> lane) & 1ull) : 0;
         const uint64_t any = __ballot(h > 0), all = __ballot(h == 3);
-        if (lane == 0) { any_words[wbase + c0 + q] = todo[q] ? any : 0ull; all_words[wbase + c0 + q] = todo[q] ? all : 0ull; }
+        if (lane == 0) {
+            any_words[wbase + c0 + q] = todo[q] ? any : 0ull;
+            if (MODE != 1) all_words[wbase + c0 + q] = todo[q] ? all : 0ull;
+        }
     }
 }
 
@@ -1867,6 +1876,7 @@ int palace_eref_table_reset(palace_ctx *ctx)
         for (int p = ctx->final_only ? 2 : 0; p < 3; p++)       // (after a final count the two lower planes are zero already)
             PALACE_HIP_TRY(hipMemsetAsync(ctx->plane[p], 0, kPlaneBytes, ctx->stream));
     ctx->table_clean = true;
+    ctx->keys_counted = 0;
     ctx->final_only = false;
     ctx->c0_hits_ix = nullptr;
     return PALACE_OK;
@@ -2177,6 +2187,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
+    if (ctx->keys_counted >= 0) ctx->keys_counted += 3 * total_bases;
     // total bases bound the number of keys; tiny inputs keep the direct path (a 16 Ki-workgroup launch
     // per call would dominate them), everything else is binned
     if (total_bases < 0) {                                  // caller does not know: read the two end offsets back
@@ -2256,6 +2267,7 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
+    if (ctx->keys_counted >= 0) ctx->keys_counted += 3 * n_positions;
     const bool binned = ctx->count_mode == 2 || (ctx->count_mode == 0 && n_positions >= (1ll << 22));
     if (!binned) {
         const int64_t blocks = std::min<int64_t>((n_positions + 255) / 256, static_cast<int64_t>(kCUs) * 8 * 8);
@@ -2605,8 +2617,25 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
                        n_refs, b.word_pre, b.any_w, b.any_p, b.good_w, b.all_p, sentinel_min, b.need, b.active);
     GatherArgs ga{};
     for (int c = 0; c < 3; c++) { ga.eix[c] = ix->eix[c]; ga.ehits[c] = sets.s[c].ehits; }
-    hipLaunchKernelGGL(eref_gather_hits_kernel, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream, d_offsets, n_refs,
-                       b.tile_pre, b.word_pre, ga, static_cast<const uint8_t *>(b.need), static_cast<const uint8_t *>(b.active), b.any_w, b.all_w);
+    const dim3 tiles(static_cast<unsigned>(b.max_tiles));
+    const uint8_t *need = b.need, *active = b.active;
+    // How sharp the sentinel pruning is depends on how full the table is: a passing window needs 39 % of its sentinels hit where the
+    // exact rule needs 85 % of its positions, and in a table that many reads have filled (5M contigs: 12 G key instances for 4.3 G
+    // slots, half of all keys at >= 3) chance alone gives that -- every ref would be gathered in full.  So unless the table is known
+    // to be sparse (fewer key instances counted since the reset than 0.9 x 2^32: the 1M-contig sample has 2.4 G), channel 0 is
+    // gathered first, the exact rule prunes once more, and channels 1 and 2 are gathered for what is left.
+    const bool sparse_table = ctx->keys_counted >= 0 && ctx->keys_counted < static_cast<int64_t>(0.9 * 4294967296.0);
+    if (sparse_table) {
+        hipLaunchKernelGGL(eref_gather_hits_kernel<0>, tiles, dim3(256), 0, ctx->stream, d_offsets, n_refs, b.tile_pre, b.word_pre, ga, need, active,
+                           b.any_w, b.all_w);
+    } else {
+        hipLaunchKernelGGL(eref_gather_hits_kernel<1>, tiles, dim3(256), 0, ctx->stream, d_offsets, n_refs, b.tile_pre, b.word_pre, ga, need, active,
+                           b.any_w, b.all_w);
+        hipLaunchKernelGGL(eref_need_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(kRefThreads), 0, ctx->stream, d_offsets,
+                           n_refs, b.word_pre, b.any_w, b.any_p, b.good_w, b.all_p, three_min, b.need, b.active);
+        hipLaunchKernelGGL(eref_gather_hits_kernel<2>, tiles, dim3(256), 0, ctx->stream, d_offsets, n_refs, b.tile_pre, b.word_pre, ga, need, active,
+                           b.any_w, b.all_w);
+    }
     hipLaunchKernelGGL(eref_window_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(kRefThreads), 0, ctx->stream,
                        d_offsets, n_refs, b.word_pre, b.any_w, b.all_w, b.any_p, b.all_p, b.good_w, one_min, three_min,
                        static_cast<const uint8_t *>(b.active), d_rows);
@@ -2638,6 +2667,7 @@ int palace_eref_table_attach(palace_ctx *ctx, void *const d_planes3[3])
     }
     ctx->planes_external = true;
     ctx->table_clean = false;                              // caller-owned memory: contents unknown
+    ctx->keys_counted = -1;
     ctx->final_only = false;
     ctx->c0_hits_ix = nullptr;
     return PALACE_OK;
@@ -2647,6 +2677,7 @@ int palace_eref_table_invalidate(palace_ctx *ctx)
 {
     PALACE_REQUIRE(ctx, "ctx is null");
     ctx->table_clean = false;
+    ctx->keys_counted = -1;
     ctx->final_only = false;
     ctx->c0_hits_ix = nullptr;
     return PALACE_OK;
@@ -2664,6 +2695,7 @@ static int merge_slices_impl(palace_ctx *ctx, const void *d_parts, int n_parts, 
     size_t n16 = slice_bytes / 16;
     if (n16 == 0) return PALACE_OK;
     ctx->table_clean = false;
+    ctx->keys_counted = -1;                                // (partial tables of other ranks folded in: how many keys stand behind the planes is not known here)
     char *b1 = reinterpret_cast<char *>(ctx->plane[0]) + slice_off;
     char *b2 = reinterpret_cast<char *>(ctx->plane[1]) + slice_off;
     char *b3 = reinterpret_cast<char *>(ctx->plane[2]) + slice_off;

@@ -281,6 +281,24 @@ def test_probe_fused_into_the_final_count_equals_the_probe_kernel_and_the_oracle
             ctx.eref_count_reads(rb, ro, rr.n)
             ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), one_min, three_min, rows_p)
             assert np.array_equal(rows_p.to_host(), got_f), which
+            # a table whose fill is not known (here: declared so; really: planes merged from other ranks, or more reads counted than
+            # the table has slots) takes the scan's two-stage pruning -- sentinels, then channel 0 exactly: same rows; with other
+            # thresholds too (a low perfect_ratio makes every ref active in both stages)
+            ctx.eref_table_invalidate()
+            ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), one_min, three_min, rows_p)
+            assert np.array_equal(rows_p.to_host(), got_f), which
+            for hr, pr in ((0.5, 0.2), (0.9, 0.76), (0.05, 0.0)):
+                o2, t2 = capi.window_minimums(hr, pr)
+                ctx.eref_scan_refs(db, do, rs_refs.n, len(rs_refs.bases), o2, t2, rows_f)             # (the unindexed scan: recomputed keys, random probes)
+                ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), o2, t2, rows_p)
+                assert np.array_equal(rows_p.to_host(), rows_f.to_host()), (which, hr, pr, "dense")
+            ctx.eref_table_reset()
+            ctx.eref_count_reads(rb, ro, rr.n)
+            for hr, pr in ((0.5, 0.2), (0.9, 0.76), (0.05, 0.0)):
+                o2, t2 = capi.window_minimums(hr, pr)
+                ctx.eref_scan_refs(db, do, rs_refs.n, len(rs_refs.bases), o2, t2, rows_f)
+                ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), o2, t2, rows_p)
+                assert np.array_equal(rows_p.to_host(), rows_f.to_host()), (which, hr, pr, "sparse")
             rb.free(); ro.free()
             positives += sum(1 for a, b in want if b > 0)
         assert positives >= 4                                   # (the deep samples report their refs, the shallow third one none)
