@@ -18,7 +18,7 @@ import sys
 SETUP = ("mark_read_ends_kernel", "mark_dropped_kernel", "eref_streams_kernel")
 STAGES = {
     "phase_a": SETUP + ("eref_usable_kernel", "eref_bin1_sort_kernel", "eref_bin2_kernel", "eref_lds_count_kernel"),
-    "phase_b": ("eref_probe2_kernel", "eref_ehits_scatter_kernel", "eref_hits_to_bits_kernel", "eref_need_kernel", "eref_ref_kernel", "eref_window_kernel", "seq_prefix_kernel"),
+    "phase_b": ("eref_probe_sets_kernel", "eref_ehits_scatter_kernel", "eref_sentinel_words_kernel", "eref_gather_hits_kernel", "eref_need_kernel", "eref_ref_kernel", "eref_window_kernel", "seq_prefix_kernel"),
     "classify": ("graph_depth_select_kernel", "graph_classify_kernel"),
     "resolve": ("resolve_split_kernel", "resolve_pair_insert_kernel", "resolve_pair_apply_kernel", "compact_edges_kernel", "copy_number_kernel"),
     "stage04": ("st4_", "dec_", "scan_apply_kernel", "scan_partials_kernel", "scan_prefix_kernel"),
