@@ -264,8 +264,15 @@ def measure(args, E, leg):
     rows_host_l = [rows_host] + [torch.zeros((n_refs, 4), dtype=torch.int32).pin_memory() for _ in range(depth - 1)]
     seq = {"n": 0, "pending": None, "counted": None, "last": 0, "of_timed": {}}           # running batch number; the batch whose rows are still on their way
 
+    # Timing marks.  One GPU, one batch in flight: the marks of a step are read at the step's end -- every stream has drained by then, the
+    # reads do not wait -- and the next step but one reuses them: 16 marks per context in all.  (With a mark of its own per step and
+    # stream the enqueueing thread's turn-around between two steps grew with the number of events alive: 0.36 ms at 30 steps, 0.88 at
+    # 100 -- time the instrumentation cost the steps it measures.)  Everything else keeps a mark per step, read after the timed region.
+    harvest = depth == 1 and not args.graph_lag and not collectives and not os.environ.get("PALACE_BENCH_DIAG_SKIP") and not os.environ.get("PALACE_BENCH_SKIP_EREF")
+    acc = {k: [] for k in ("count", "merge", "scan", "between", "classify", "resolve", "stage04")}
+
     def step(i, timed):
-        m = 8 * i
+        m = 8 * (i & 1) if harvest else 8 * i
         tot_b = n_side * READ_LEN
         slot = seq["n"] % depth                        # which eref context / rows buffers this batch uses
         seq["n"] += 1
@@ -444,6 +451,11 @@ def measure(args, E, leg):
         ctx.mark(4094)
         if depth == 1:
             ctx.mark_wait(4094)
+            if timed and harvest:
+                acc["count"].append(ctx.mark_elapsed(m, m + 1)); acc["merge"].append(ctx.mark_elapsed(m + 1, m + 2)); acc["scan"].append(ctx.mark_elapsed(m + 2, m + 3))
+                if i > 0: acc["between"].append(ctx.mark_elapsed(8 * ((i - 1) & 1) + 3, m))
+                acc["classify"].append(ctx_g.mark_elapsed(m, m + 1)); acc["resolve"].append(ctx_g.mark_elapsed(m + 1, m + 2))
+                acc["stage04"].append(ctx_s.mark_elapsed(m + 2, m + 3))
             if not timed:
                 seen["rows"].add(hashlib.sha256(rows_host.numpy().tobytes()).hexdigest()[:16])
                 seen["steps"] += 1
@@ -490,11 +502,17 @@ def measure(args, E, leg):
     for _ in range(args.warmup):
         step(0, False)
     barrier()
+    # The sample's host side is millions of Python objects (a name and a score text per contig): a full collection of the cyclic
+    # garbage collector walks them all -- one 60 ms pause somewhere in a 100-step run, 0.6 ms on the mean step.  They are long-lived:
+    # frozen out of the collector's sight, and no collection inside the timed region.
+    import gc
+    gc.collect(); gc.freeze(); gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, True)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if sync_world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         sync_dist.all_reduce(tmax, op=sync_dist.ReduceOp.MAX)
@@ -514,17 +532,23 @@ def measure(args, E, leg):
         soak = dict(steps=n_soak, seconds=time.perf_counter() - t1, ms_per_step=1e3 * (time.perf_counter() - t1) / max(1, n_soak),
                     note="untimed steps also lexsort and sha256 the results for `result_digest` (bookkeeping): not comparable with ms_per_step")
     K = range(args.steps)
-    if os.environ.get("PALACE_BENCH_SKIP_EREF") == "1":
-        count_each, count_ms, merge_ms, scan_ms = [1.0], 1.0, 0.0, 0.0
+    if harvest:
+        count_each, between_ms = acc["count"], (float(np.mean(acc["between"])) if acc["between"] else None)
+        count_ms, merge_ms, scan_ms = np.mean(acc["count"]), np.mean(acc["merge"]), np.mean(acc["scan"])
+        classify_ms, resolve_ms, stage04_ms = np.mean(acc["classify"]), np.mean(acc["resolve"]), np.mean(acc["stage04"])
     else:
-        E = lambda i: ectx[seq["of_timed"][i]]                                      # the context timed step i ran on
-        count_each = [E(i).mark_elapsed(8 * i, 8 * i + 1) for i in K]
-        count_ms = np.mean(count_each)                                              # one launch per step (both FASTQ sides)
-        merge_ms = np.mean([E(i).mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
-        scan_ms = np.mean([E(i).mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
-    classify_ms = np.mean([ctx_g.mark_elapsed(8 * i, 8 * i + 1) for i in K])
-    resolve_ms = np.mean([ctx_g.mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
-    stage04_ms = np.mean([ctx_s.mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
+        if os.environ.get("PALACE_BENCH_SKIP_EREF") == "1":
+            count_each, count_ms, merge_ms, scan_ms, between_ms = [1.0], 1.0, 0.0, 0.0, None
+        else:
+            E = lambda i: ectx[seq["of_timed"][i]]                                      # the context timed step i ran on
+            count_each = [E(i).mark_elapsed(8 * i, 8 * i + 1) for i in K]
+            count_ms = np.mean(count_each)                                              # one launch per step (both FASTQ sides)
+            merge_ms = np.mean([E(i).mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
+            scan_ms = np.mean([E(i).mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
+            between_ms = float(np.mean([E(i).mark_elapsed(8 * i + 3, 8 * (i + 1)) for i in range(args.steps - 1)])) if depth == 1 and args.steps > 1 else None
+        classify_ms = np.mean([ctx_g.mark_elapsed(8 * i, 8 * i + 1) for i in K])
+        resolve_ms = np.mean([ctx_g.mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
+        stage04_ms = np.mean([ctx_s.mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
     r = rows_host_l[seq["last"]].numpy()
     reported = int(((r[:, 1] > 0) & (r[:, 1].astype(np.float32) / r[:, 2].astype(np.float32) > 0.75)).sum())
 
@@ -594,7 +618,8 @@ def measure(args, E, leg):
             # eref's unit is a read, generateGraph's a BAM record -- the same step in those units
             "rates": {"reads_per_s": 2 * sample["n_pairs_total"] / (ms_step * 1e-3), "bam_records_per_s": gs["n_total"] / (ms_step * 1e-3),
                       "read_bases_per_s": 2 * sample["n_pairs_total"] * READ_LEN / (ms_step * 1e-3)},
-            "stage_ms": {"eref_count_each_step": [round(float(x), 3) for x in count_each], "eref_count_both_sides": count_ms, "eref_table_merge": merge_ms, "eref_scan_refs": scan_ms,
+            "stage_ms": {"eref_count_each_step": [round(float(x), 3) for x in count_each], "eref_count_both_sides": count_ms, "eref_table_merge": merge_ms, "eref_scan_refs": scan_ms, "eref_stream_between_steps": between_ms, "eref_stream_between_steps_median": (float(np.median(acc["between"])) if harvest and acc["between"] else None),
+                         "eref_stream_between_steps_max": (float(np.max(acc["between"])) if harvest and acc["between"] else None),
                          "graph_classify": classify_ms, "graph_resolve": resolve_ms, "graph_filter_and_matching_on_device": stage04_ms,
                          **{"host_" + k: v for k, v in host_ms.items()},
                          "note": "eref runs on one HIP stream, generateGraph + matching on another; they overlap"},
