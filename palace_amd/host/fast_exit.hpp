@@ -8,8 +8,9 @@
 // PALACE_NO_FORK=1 keeps everything in one process (debuggers, sanitizers).
 // A process in which the GPU is ALREADY initialised when main() starts must not fork and go on using HIP in the child (ROCm
 // does not support that: errors, or a hung GPU): that is the case under rocprofv3 and other tools whose preloaded library
-// opens the device before main().  gpu_touched_before_main() looks for the signs -- a tool / preload variable in the
-// environment, or /dev/kfd among the open descriptors -- and the program then stays one process, as with PALACE_NO_FORK=1.
+// opens the device before main().  gpu_touched_before_main() looks for the signs -- a tool variable in the environment, a
+// preload that names a GPU tool or the runtime, or /dev/kfd among the open descriptors -- and the program then stays one
+// process, as with PALACE_NO_FORK=1.
 #pragma once
 #include <cerrno>
 #include <cstdio>
@@ -20,6 +21,7 @@
 #include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
+#include "trace.hpp"
 
 extern char** environ;
 
@@ -30,6 +32,7 @@ struct FastExit {
     // every output is written, flushed and closed: tell the caller's process, then leave (no destructors, no unmapping in user space)
     [[noreturn]] void done(int status = 0)
     {
+        trace_since_launch("exit", "outputs complete");
         std::fflush(nullptr);
         if (fd >= 0) {
             ::close(1);                // a caller reading our stdout through a pipe must see its end now, not after the teardown
@@ -44,11 +47,20 @@ struct FastExit {
 
 inline bool gpu_touched_before_main()
 {
-    static const char* const exact[] = {"LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCP_TOOL_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE"};
+    static const char* const exact[] = {"HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCP_TOOL_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE"};
+    // A preloaded library as such says nothing (the GPU boxes of this project preload a guard into EVERY process: with a bare
+    // "LD_PRELOAD is set" rule, round 5's first form, no run there ever took the forked start): it counts when it names a GPU tool
+    // or the runtime itself; whatever else a preload does before main() shows in the descriptor scan below.
+    static const char* const preload_marks[] = {"rocprof", "roctracer", "roctx", "rocsys", "omnitrace", "omniperf", "libamdhip", "libhsa-runtime", "librccl"};
     for (char** e = ::environ; e && *e; ++e) {
         const char* eq = std::strchr(*e, '=');
         if (!eq || !eq[1]) continue;                                    // unset or empty: not in force
         const size_t n = static_cast<size_t>(eq - *e);
+        if (n == 10 && std::strncmp(*e, "LD_PRELOAD", 10) == 0) {
+            for (const char* m : preload_marks)
+                if (std::strstr(eq + 1, m)) return true;
+            continue;
+        }
         for (const char* k : exact)
             if (std::strlen(k) == n && std::strncmp(*e, k, n) == 0) return true;
         if (std::strncmp(*e, "ROCPROF", 7) == 0 || std::strncmp(*e, "ROCTRACER", 9) == 0) return true;     // ROCPROFILER_*, ROCPROFV3_*, ...
@@ -72,6 +84,7 @@ inline bool gpu_touched_before_main()
 
 inline FastExit fast_exit_begin()
 {
+    trace_since_launch("start", "main reached");
     if (std::getenv("PALACE_NO_FORK") || gpu_touched_before_main()) return {};
     int p[2];
     if (::pipe(p) != 0) return {};
@@ -87,7 +100,7 @@ inline FastExit fast_exit_begin()
     unsigned char st = 0;
     ssize_t n;
     do n = ::read(p[0], &st, 1); while (n < 0 && errno == EINTR);
-    if (n == 1) ::_exit(st);           // outputs complete: the worker's teardown is nobody's wait
+    if (n == 1) { trace_since_launch("exit", "status byte read"); ::_exit(st); }           // outputs complete: the worker's teardown is nobody's wait
     int ws = 0;
     pid_t w;
     do w = ::waitpid(child, &ws, 0); while (w < 0 && errno == EINTR);

@@ -20,4 +20,13 @@ struct Trace {
         last = now;
     }
 };
+// PALACE_TRACE=1 with PALACE_TRACE_T0=<ns since the epoch, taken by the caller just before it started the program> (tools/e2e_trace.sh):
+// where the caller's wait goes that the laps do not see -- loading the program, the forked start, the way out.
+inline void trace_since_launch(const char *who, const char *what)
+{
+    const char *t0 = std::getenv("PALACE_TRACE_T0");
+    if (!t0 || !std::getenv("PALACE_TRACE")) return;
+    const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+    std::fprintf(stderr, "[%s] %-28s           (+%8.1f ms after the caller's launch)\n", who, what, static_cast<double>(now - std::atoll(t0)) / 1e6);
+}
 }  // namespace palace_host

@@ -333,6 +333,9 @@ def test_executables_stay_one_process_under_a_profiler_or_preload():
         return p.stdout.strip()
     assert check() == b"0"
     assert check(LD_PRELOAD="") == b"0"                                  # empty: nothing is preloaded
+    assert check(LD_PRELOAD="/usr/local/lib/some_guard.so") == b"0"      # a preload as such is no sign (the GPU boxes preload a guard everywhere)
+    assert check(LD_PRELOAD="/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so") == b"1"
+    assert check(LD_PRELOAD="/x/guard.so:/opt/rocm/lib/libamdhip64.so") == b"1"
     assert check(HSA_TOOLS_LIB="librocprofiler-sdk-tool.so") == b"1"
     assert check(ROCP_TOOL_LIBRARIES="/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so") == b"1"
     assert check(ROCPROFILER_LIBRARY_CTOR="1") == b"1"

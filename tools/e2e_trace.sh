@@ -15,7 +15,8 @@ e = d["e2e"]
 print("bench e2e:", round(e["seconds"], 3), e["stage_s"], "fused", e["one_process_stage04"].get("seconds"), e["one_process_stage04"].get("stage_s"))
 PY
 B=palace_amd/bin; S=palace_amd/scripts
-t() { s=$(date +%s%N); "$@"; e=$(date +%s%N); echo "$(( (e - s) / 1000000 )) ms"; }
+exec 3>&1          # (walls go to the script's stdout whatever a command's own stdout is redirected to)
+t() { s=$(date +%s%N); PALACE_TRACE_T0=$s "$@"; e=$(date +%s%N); echo "$(( (e - s) / 1000000 )) ms" >&3; }
 for i in 1 2; do
   echo "== run $i"
   echo -n "eref "; PALACE_TRACE=1 t $B/eref $W/reads_1.fq $W/reads_2.fq $W/phagedb.fa $W/s_tmp.txt 0.9 0.85 16 > $W/refs.txt 2> gpurun_out/${tag}_eref_$i.err; tail -1 $W/refs.txt > /dev/null
