@@ -37,8 +37,8 @@ def profiled_traffic(args, world, version, fused):
         return None, None, {}
     if world != 1 or t.get("contigs") != args.contigs or t.get("workload", "default") != args.workload or t.get("reads", "ascii") != args.reads:
         return None, "profiles/phase_a_traffic.json is of another workload", {}
-    if bool(t.get("fused_probe", False)) != bool(fused):
-        return None, "profiles/phase_a_traffic.json was measured with" + ("out" if fused else "") + " the fused probe", {}
+    if int(t.get("fused_probe", 0)) != int(fused):
+        return None, f"profiles/phase_a_traffic.json was measured with --fused-probe {int(t.get('fused_probe', 0))}; this run is --fused-probe {int(fused)}", {}
     if t.get("build") != version:
         return None, f"profiles/phase_a_traffic.json was measured on another build ({t.get('build')}); this is {version}", {}
     return t.get("bytes_per_launch"), t.get("source"), {k: v.get("bytes") for k, v in (t.get("stages") or {}).items()}
@@ -232,9 +232,14 @@ def measure(args, E, leg):
                                                 sample["ref_total"], ctypes.byref(probe_index)), "probe index")
     # the count launch of a step is its final count (below): with --fused-probe 1 (or PALACE_BENCH_FUSED_PROBE=1) channel 0 of Phase B
     # rides along in the count kernel while each fine bucket's ">= 3" slice is in LDS (palace_eref_attach_probe_index)
-    fused_probe = depth == 1 and os.environ.get("PALACE_BENCH_FUSED_PROBE", str(args.fused_probe)) == "1"
+    # --fused-probe 2 (round 5): ALL of Phase B's look-ups ride along (the index's four entry sets) and the '>= 3' plane is never written
+    # -- no slice write-back, no probe kernel, no reset of the plane before the next step (option probe_all_sets)
+    fused_mode = int(os.environ.get("PALACE_BENCH_FUSED_PROBE", str(args.fused_probe))) if depth == 1 else 0
+    fused_probe, fused_all = fused_mode >= 1, fused_mode == 2
     if fused_probe:
         capi._check(L.palace_eref_attach_probe_index(ctx.h, probe_index), "attach probe index")
+    if fused_all:
+        capi._check(L.palace_eref_set_option(ctx.h, b"probe_all_sets", 1), "probe_all_sets")
 
     # the reads in the form the step counts them from (resident before the timed region, like every other input)
     packed = None
@@ -561,10 +566,11 @@ def measure(args, E, leg):
         L.palace_version.restype = ctypes.c_char_p
         version = L.palace_version().decode()
         fused_now = fused_probe and final_count and not key_split
-        traffic, traffic_src, stage_traffic = profiled_traffic(args, world, version, fused_now)
+        traffic, traffic_src, stage_traffic = profiled_traffic(args, world, version, (2 if fused_all else 1) if fused_now else 0)
         alg_bytes = (READ_LEN + 6 * (READ_LEN - 31)) * 2 * n_side        # per launch (both FASTQ sides of this rank)
         # when Phase B's channel-0 probe rides along in the count kernel, its look-ups (1 B per ref position) are work of this launch
-        probe_bytes = sum(int(l) - 31 for l in sample["ref_lens"][r_lo:r_hi]) if fused_now else 0
+        fused_sets = 0 if not fused_now else (3 if fused_all else 1)         # channels of Phase B's look-ups the count launch does
+        probe_bytes = fused_sets * sum(int(l) - 31 for l in sample["ref_lens"][r_lo:r_hi])
         achieved = (alg_bytes + probe_bytes) / (max(count_ms, 1e-6) * 1e-3) / 1e9          # (a rank 0 that takes no reads reports 0)
         out = {
             "metric": "contigs/sec eref+generate_graph+matching, 1M-contig synth, 1/2/4/8 GPU",       # BASELINE.json, verbatim
@@ -583,7 +589,8 @@ def measure(args, E, leg):
                                                                    f"records/refs sharded over {world} GPUs (RCCL), reads counted on every GPU"),
                        "parallelism_model": model,
                        "ref_index": "per-DB probe index prebuilt, as the reference's cached <fasta>.k32.index.dat (8 B/position in HBM)"
-                                    + ("; its channel-0 probe rides along in the count kernel" if fused_probe and final_count and not key_split else ""),
+                                    + (("; all of its look-ups ride along in the count kernel, the '>= 3' plane is never written" if fused_all else
+                                        "; its channel-0 probe rides along in the count kernel") if fused_probe and final_count and not key_split else ""),
                        "refs_reported": reported, "refs_present": int(len(sample["present"])),
                        "result_digest": {"eref_rows": hashlib.sha256(np.ascontiguousarray(r).tobytes()).hexdigest()[:16],
                                          "graph_and_components": last.get("digest_graph"),
@@ -594,21 +601,21 @@ def measure(args, E, leg):
                                                           "n_comp", "n_cycles", "n_multi")},
                        "stage04": "filter_graph.py's selection (seeds, 1- and 2-hop junctions, contigs.paths rescue) and matching -i 10 -l contigs.paths "
                                   "on the filtered graph, both on the device (palace_stage04_*), as palace:566-591 runs them on files"},
-            "roofline": {"bound": "hbm", "kernel": ("eref count_reads_packed (bin1 + bin2 + lds_count kernels of one launch" + (", Phase B's channel-0 probe fused into lds_count)" if fused_now else ")")) if packed else
+            "roofline": {"bound": "hbm", "kernel": ("eref count_reads_packed (bin1 + bin2 + lds_count kernels of one launch" + ((", Phase B's look-ups of all three channels fused into lds_count, no plane written)" if fused_all else ", Phase B's channel-0 probe fused into lds_count)") if fused_now else ")")) if packed else
                                    "eref count_reads (streams + bin1 + bin2 + lds_count kernels of one launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # PMC (separate rocprofv3 passes, profiles/r01q_end_state_fused_launch.md): FETCH_SIZE x2 + WRITE_SIZE of
                          # bin1 + bin2 + lds_count per launch; only valid for the default workload on one GPU
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "avg_launch_ms": count_ms, "algorithmic_bytes_per_launch": alg_bytes + probe_bytes,
-                         "algorithmic_bytes_note": f"864 B per 150-bp read x {2 * n_side} reads" + (f" + {probe_bytes} B: the channel-0 look-ups of Phase B (1 B per ref "
-                                                   "position), which this launch's count kernel does while a bucket's slice is in LDS" if probe_bytes else "")},
+                         "algorithmic_bytes_note": f"864 B per 150-bp read x {2 * n_side} reads" + (f" + {probe_bytes} B: the look-ups of Phase B ({fused_sets} B per ref "
+                                                   "position: " + ("all three channels" if fused_sets == 3 else "channel 0") + "), which this launch's count kernel does while a bucket's slice is in LDS" if probe_bytes else "")},
             # the other stages of the step against the same roofline (SURVEY.md section 8(d) algorithmic bytes; live event times of
             # this run; PMC traffic of the committed profile when it is of this build and workload)
             "roofline_stages": roofline_stages(dict(
-                phase_b=(sum(int(l) + (2 if fused_now else 3) * (int(l) - 31) for l in sample["ref_lens"][r_lo:r_hi]), scan_ms,
+                phase_b=(sum(int(l) + (3 - fused_sets) * (int(l) - 31) for l in sample["ref_lens"][r_lo:r_hi]), scan_ms,
                          "l + 3(l - 31) B per ref: a byte per base, three 1-byte look-ups per position" +
-                         (" -- minus the channel-0 look-ups, which the count launch did" if fused_now else "")),
+                         (" -- minus the look-ups the count launch did (" + ("all three channels" if fused_sets == 3 else "channel 0") + ")" if fused_now else "")),
                 classify=(52 * gs["n"] + 64 * gs["n_sa"], classify_ms, "52 B per primary record + 64 B per SA item"),
                 resolve=(64 * int(last.get("n_cands", 0)) + 16 * int(last.get("n_cands", 0)), resolve_ms,
                          "64 B per candidate read + 16 B per evidence written"),

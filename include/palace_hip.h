@@ -146,6 +146,13 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
  *                 the next reset clears one plane instead of three.  Afterwards the table cannot take further counts,
  *                 merges or lookups until it is reset (those calls fail); popcounts report 0, 0, n.  Applies to binned
  *                 counts of one slab into a clean table, otherwise the call behaves as without the option.  0: off (default).
+ *   "probe_all_sets" 1: a final count (see "final_count") with a probe index attached (palace_eref_attach_probe_index) tests ALL of the
+ *                 index's entries -- the three channels of every DB position and the sentinels -- against each fine bucket's ">= 3"
+ *                 slice while it is in LDS, and does not write the slice: the table's planes stay all zero (slices the overflow path of
+ *                 the partition kernels had written into are zeroed again), so Phase B of that sample is the index's hit bits alone
+ *                 (read_index's table look-ups, extract_ref.cpp:858-870, done where the counts are) and the next reset costs nothing.
+ *                 Until that reset the table holds NOTHING: only palace_eref_scan_refs_indexed with the attached index works, every
+ *                 other call that reads or extends the table fails.  0: off (default).
  *   "mark_before_count_kernel" i >= 0: a binned count call records palace_mark(ctx, i) between its partition kernels and its
  *                 count kernel (another stream can hold work back until then: palace_wait_for_mark); -1: none (default).
  *   "mark_before_level2" i >= 0: the same between level 1 and level 2 of the call's last part; -1: none (default). */

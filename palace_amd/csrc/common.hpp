@@ -78,6 +78,10 @@ struct palace_ctx {
     // index whose hit bytes the last count launch left complete (cleared by whatever changes the planes afterwards)
     const struct palace_eref_probe_index *probe_ix = nullptr;
     const struct palace_eref_probe_index *c0_hits_ix = nullptr;
+    uint32_t hits_mask = 0;         // ... which of its entry sets' hit bits that launch left (bit 0: channel 0; 0xf: all four, option probe_all_sets)
+    bool probe_all_sets = false;    // option: a final count with an attached index tests every entry set and writes no plane
+    bool planeless = false;         // ... and did: the table holds NOTHING (all three planes are zero, as after a reset); Phase B is the attached
+                                    // index's hit bits alone, and whatever else reads the table is refused until the next reset
     int mark_before_count = -1;     // option mark_before_count_kernel
     int mark_before_level2 = -1;    // option mark_before_level2
     int count_mode = 0;             // 0 auto, 1 direct atomics, 2 binned

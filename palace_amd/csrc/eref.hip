@@ -786,10 +786,16 @@ constexpr int kCountThreads = 256;
 // is in LDS, the DB positions whose channel-0 index falls into the bucket (the per-DB probe index, grouped by these very
 // buckets) are tested against it and their hit bytes set: the scan that follows needs neither the probe kernel nor its read
 // of the plane (palace_eref_attach_probe_index).
+// PROBE = 2 (round 5, with FINAL, whole key space; option probe_all_sets): ALL FOUR entry sets of the DB's probe index (channels 0, 1, 2
+// and the sentinels) are tested here, so nothing reads the ">= 3" plane afterwards -- and the slice is not written: the plane never
+// exists in HBM (0.54 GB of write-back, the 0.5 GB reset of the next step and the probe kernel's 0.5 GB read of it fall away).  Where
+// the overflow path of the partition kernels put bits into the global planes (touched buckets) all three slices are zeroed again:
+// after the launch the table is all zero, as after a reset, and holds nothing (palace_ctx::planeless).
+constexpr int kProbeSetsMax = 4;
 struct ProbeArgs {
-    const unsigned long long *first;                        // [65537] start of every fine bucket's entries (multiples of 8)
-    const uint16_t *keys16;                                 // channel-0 index & 0xffff of every DB position, grouped by fine bucket
-    uint8_t *ehits;                                         // a BIT per entry, in entry order (byte i = entries 8 i .. 8 i + 7), zero before the launch
+    const unsigned long long *first[kProbeSetsMax];         // [65537] start of every fine bucket's entries of the set (multiples of 8)
+    const uint16_t *keys16[kProbeSetsMax];                  // index & 0xffff of the set's entries, grouped by fine bucket
+    uint8_t *ehits[kProbeSetsMax];                          // a BIT per entry, in entry order (byte i = entries 8 i .. 8 i + 7), zero before the launch
 };
 // the eight 16-bit entries of one 16-byte vector against a 2^16-bit slice in LDS -> a byte of hit bits
 __device__ __forceinline__ uint32_t probe_vector(const uint32_t *__restrict__ l3, const uint4 &v)
@@ -805,7 +811,7 @@ __device__ __forceinline__ uint32_t probe_vector(const uint32_t *__restrict__ l3
     return m;
 }
 
-template <bool CLEAN, bool FINAL = false, bool PROBE = false>
+template <bool CLEAN, bool FINAL = false, int PROBE = 0>
 __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const unsigned int *__restrict__ cursor,
                                                                        const uint16_t *__restrict__ binned,
                                                                        DensityCaps caps, uint32_t *__restrict__ p1,
@@ -819,7 +825,19 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
     if (!share.bucket(b1)) return;                          // a call that counts a share of the key space: not its bucket
     constexpr int kProbeBatch = 2;                          // 16-byte vectors (8 entries each) per thread and batch: a bucket's ~3000 entries are ONE batch
     unsigned long long pe0 = 0, phi = 0;                    // the bucket's entries, in vectors of 8
-    if (PROBE) { pe0 = pr.first[b] / 8; phi = pr.first[b + 1] / 8; }
+    if (PROBE) { pe0 = pr.first[0][b] / 8; phi = pr.first[0][b + 1] / 8; }
+    // PROBE == 2: the other three sets' entries of the bucket (vectors [q0, q1) of each); channels 1 and 2 take up to kLateCh vectors per
+    // thread in one batch (the densest buckets hold twice the mean of ~380), the sentinels one
+    constexpr int kLateCh = 3, kLateSent = 1;
+#ifndef PALACE_PROBE_GROUP
+#define PALACE_PROBE_GROUP 1
+#endif
+    constexpr int kProbeGroup = PALACE_PROBE_GROUP;
+    unsigned long long q0[kProbeSetsMax - 1] = {0, 0, 0}, q1[kProbeSetsMax - 1] = {0, 0, 0};
+    if (PROBE == 2) {
+#pragma unroll
+        for (int k = 1; k < kProbeSetsMax; k++) { q0[k - 1] = pr.first[k][b] / 8; q1[k - 1] = pr.first[k][b + 1] / 8; }
+    }
     // the bucket's keys lie in eight sub-regions (one per XCD that wrote them); as one sequence of 16-byte vectors of eight
     // keys: vector j belongs to sub-region x with first[x] <= j < first[x + 1]
     const uint32_t sub_cap = fine_sub_cap(caps, b1);
@@ -836,12 +854,22 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
         if (FINAL && ((touched[b >> 5] >> (b & 31)) & 1u)) {       // only overflow keys: plane 3 is right as it is, the lower two go back to zero
             uint4 *z1 = reinterpret_cast<uint4 *>(p1 + w0), *z2 = reinterpret_cast<uint4 *>(p2 + w0);
             for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) z1[i] = z2[i] = uint4{0, 0, 0, 0};
-            if (PROBE && phi > pe0) {                              // ... and is what the DB's positions of this bucket are tested against
+            if (PROBE == 2 || (PROBE && phi > pe0)) {              // ... and is what the DB's positions of this bucket are tested against
                 const uint4 *s3 = reinterpret_cast<const uint4 *>(p3 + w0);
                 for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) reinterpret_cast<uint4 *>(l3)[i] = s3[i];
                 __syncthreads();
-                const uint4 *pv = reinterpret_cast<const uint4 *>(pr.keys16);
-                for (unsigned long long i = pe0 + threadIdx.x; i < phi; i += kCountThreads) pr.ehits[i] = static_cast<uint8_t>(probe_vector(l3, pv[i]));
+                const uint4 *pv = reinterpret_cast<const uint4 *>(pr.keys16[0]);
+                for (unsigned long long i = pe0 + threadIdx.x; i < phi; i += kCountThreads) pr.ehits[0][i] = static_cast<uint8_t>(probe_vector(l3, pv[i]));
+                if (PROBE == 2) {
+#pragma unroll
+                    for (int k = 1; k < kProbeSetsMax; k++) {
+                        const uint4 *qv = reinterpret_cast<const uint4 *>(pr.keys16[k]);
+                        for (unsigned long long i = q0[k - 1] + threadIdx.x; i < q1[k - 1]; i += kCountThreads)
+                            pr.ehits[k][i] = static_cast<uint8_t>(probe_vector(l3, qv[i]));
+                    }
+                    uint4 *z3 = reinterpret_cast<uint4 *>(p3 + w0);        // the plane goes back to zero as well: nothing reads it any more
+                    for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) z3[i] = uint4{0, 0, 0, 0};
+                }
             }
         }
         return;                                            // (no key at all: the slice is zero, no position of the DB hits)
@@ -876,7 +904,7 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
     // PROBE: the bucket's entries of the DB's probe index are requested now and are in flight during the whole count phase
     uint4 pcur[kProbeBatch];
     if (PROBE) {
-        const uint4 *pv = reinterpret_cast<const uint4 *>(pr.keys16);
+        const uint4 *pv = reinterpret_cast<const uint4 *>(pr.keys16[0]);
 #pragma unroll
         for (int u = 0; u < kProbeBatch; u++) {
             const unsigned long long i = pe0 + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
@@ -923,36 +951,103 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
 #pragma unroll
         for (int u = 0; u < kBatch; u++) { v[u] = nx[u]; ok[u] = nok[u]; }
     }
+    // PROBE == 2: the entries of the other three sets are requested now, in the registers the key vectors have left (behind the count
+    // phase, not in flight during it like set 0's: seven more vectors per lane then would cost the kernel a workgroup per CU)
+    uint4 lch[2][kLateCh], lsn[kLateSent];
+    if (PROBE == 2) {
+        asm volatile("" ::: "memory");                     // (not hoisted above the count loop: 28 registers live through it would halve the occupancy)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint4 *qv = reinterpret_cast<const uint4 *>(pr.keys16[1 + c]);
+#pragma unroll
+            for (int u = 0; u < kLateCh; u++) {
+                const unsigned long long i = q0[c] + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
+                lch[c][u] = i < q1[c] ? qv[i] : uint4{0, 0, 0, 0};
+            }
+        }
+        const uint4 *qs = reinterpret_cast<const uint4 *>(pr.keys16[3]);
+#pragma unroll
+        for (int u = 0; u < kLateSent; u++) {
+            const unsigned long long i = q0[2] + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
+            lsn[u] = i < q1[2] ? qs[i] : uint4{0, 0, 0, 0};
+        }
+    }
     __syncthreads();
     // PROBE: the entries are tested against the final slice, eight to a byte of hit bits IN ENTRY ORDER (what position an entry
     // belongs to is the business of the scatter kernel of the scan).  No global store is issued before the last entry load has
     // come back: a wave's vmcnt counts loads and stores together and the compiler has to wait for ALL of them once both kinds are
     // in flight.  A bucket with more entries than one batch holds (> 4096) tests the rest behind the slice's write-back.
-    uint32_t pm[kProbeBatch];
+    uint32_t pm[kProbeBatch], lm[2][kLateCh], sm[kLateSent];
     if (PROBE) {
 #pragma unroll
-        for (int u = 0; u < kProbeBatch; u++) pm[u] = probe_vector(l3, pcur[u]);
+        for (int u = 0; u < kProbeBatch; u++) {
+            pm[u] = probe_vector(l3, pcur[u]);
+            if (PROBE == 2) asm volatile("" : "+v"(pm[u]) : : "memory");
+        }
+    }
+    if (PROBE == 2) {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int u = 0; u < kLateCh; u++) {
+                lm[c][u] = probe_vector(l3, lch[c][u]);
+                // (kProbeGroup vectors at a time: left alone the compiler issues the LDS reads of all nine vectors first -- 72 registers
+                // of results, 136 in all, three workgroups per CU instead of six)
+                if ((c * kLateCh + u) % kProbeGroup == kProbeGroup - 1) asm volatile("" : "+v"(lm[c][u]) : : "memory");
+            }
+#pragma unroll
+        for (int u = 0; u < kLateSent; u++) { sm[u] = probe_vector(l3, lsn[u]); asm volatile("" : "+v"(sm[u]) : : "memory"); }
     }
     uint4 *o1 = reinterpret_cast<uint4 *>(p1 + w0), *o2 = reinterpret_cast<uint4 *>(p2 + w0),
           *o3 = reinterpret_cast<uint4 *>(p3 + w0);
-    for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) {
-        if (!FINAL) {
-            o1[i] = reinterpret_cast<const uint4 *>(l1)[i];
-            o2[i] = reinterpret_cast<const uint4 *>(l2)[i];
-        } else if (seed) {
-            o1[i] = o2[i] = uint4{0, 0, 0, 0};
+    if (PROBE == 2) {                                      // the slice stays in LDS; a seeded one (overflow keys) goes back to zero in all planes
+        if (seed)
+            for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) o1[i] = o2[i] = o3[i] = uint4{0, 0, 0, 0};
+    } else {
+        for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) {
+            if (!FINAL) {
+                o1[i] = reinterpret_cast<const uint4 *>(l1)[i];
+                o2[i] = reinterpret_cast<const uint4 *>(l2)[i];
+            } else if (seed) {
+                o1[i] = o2[i] = uint4{0, 0, 0, 0};
+            }
+            o3[i] = reinterpret_cast<const uint4 *>(l3)[i];
         }
-        o3[i] = reinterpret_cast<const uint4 *>(l3)[i];
     }
     if (PROBE) {
 #pragma unroll
         for (int u = 0; u < kProbeBatch; u++) {
             const unsigned long long i = pe0 + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
-            if (i < phi) pr.ehits[i] = static_cast<uint8_t>(pm[u]);
+            if (i < phi) pr.ehits[0][i] = static_cast<uint8_t>(pm[u]);
         }
-        const uint4 *pv = reinterpret_cast<const uint4 *>(pr.keys16);
+    }
+    if (PROBE == 2) {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int u = 0; u < kLateCh; u++) {
+                const unsigned long long i = q0[c] + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
+                if (i < q1[c]) pr.ehits[1 + c][i] = static_cast<uint8_t>(lm[c][u]);
+            }
+#pragma unroll
+        for (int u = 0; u < kLateSent; u++) {
+            const unsigned long long i = q0[2] + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
+            if (i < q1[2]) pr.ehits[3][i] = static_cast<uint8_t>(sm[u]);
+        }
+    }
+    if (PROBE) {                                           // buckets with more entries than the batches hold (another DB's density): the rest, one by one
+        const uint4 *pv = reinterpret_cast<const uint4 *>(pr.keys16[0]);
         for (unsigned long long i = pe0 + threadIdx.x + static_cast<unsigned long long>(kProbeBatch) * kCountThreads; i < phi; i += kCountThreads)
-            pr.ehits[i] = static_cast<uint8_t>(probe_vector(l3, pv[i]));
+            pr.ehits[0][i] = static_cast<uint8_t>(probe_vector(l3, pv[i]));
+    }
+    if (PROBE == 2) {
+#pragma unroll
+        for (int k = 1; k < kProbeSetsMax; k++) {
+            const uint4 *qv = reinterpret_cast<const uint4 *>(pr.keys16[k]);
+            const int held = k == 3 ? kLateSent : kLateCh;
+            for (unsigned long long i = q0[k - 1] + threadIdx.x + static_cast<unsigned long long>(held) * kCountThreads; i < q1[k - 1]; i += kCountThreads)
+                pr.ehits[k][i] = static_cast<uint8_t>(probe_vector(l3, qv[i]));
+        }
     }
 }
 
@@ -1872,9 +1967,10 @@ int palace_eref_table_reset(palace_ctx *ctx)
     bool fresh = ctx->plane[0] == nullptr;
     int rc = ensure_table(ctx);
     if (rc) return rc;
-    if (!fresh)
+    if (!fresh && !ctx->planeless)                             // (a count that probed every entry set itself left all three planes zero)
         for (int p = ctx->final_only ? 2 : 0; p < 3; p++)       // (after a final count the two lower planes are zero already)
             PALACE_HIP_TRY(hipMemsetAsync(ctx->plane[p], 0, kPlaneBytes, ctx->stream));
+    ctx->planeless = false;
     ctx->table_clean = true;
     ctx->keys_counted = 0;
     ctx->final_only = false;
@@ -2029,25 +2125,40 @@ struct palace_eref_probe_index {
     uint16_t *keys16[palace::kSets] = {nullptr, nullptr, nullptr, nullptr};       // [n_entries rounded up to 128 (+ 8)] index & 0xffff (pads: 0)
     uint32_t *eix[3] = {nullptr, nullptr, nullptr};                    // [hit_bytes_size] position id -> entry of channel c (~0: none)
     uint32_t *pos_s = nullptr;                // sentinel entry -> position id / 4 (pads and the tail: ~0)
-    uint8_t *ehits0 = nullptr;                // channel 0's hit bits (one per entry) when a count launch this index is attached to leaves them
+    uint8_t *ehits_own[palace::kSets] = {nullptr, nullptr, nullptr, nullptr};    // the sets' hit bits (one per entry) when a count launch this index is
+                                              //  attached to leaves them: channel 0's, or (option probe_all_sets) all four; ONE allocation, [0] heads it
+    size_t ehits_own_bytes = 0;
     size_t ehits_bytes[palace::kSets] = {0, 0, 0, 0};                  // bytes of a set's hit bits (multiple of 16; the tail stays zero)
     size_t hit_bytes_size = 0;                // position ids run over [0, hit_bytes_size)
 };
 
 static_assert(kIndexGroups == kFine, "the probe index is grouped by the count kernel's fine buckets");
+static_assert(kSets == kProbeSetsMax, "the count kernel's probe arguments hold every entry set");
 
 static bool probe_index_usable(const palace_ctx *ctx, const palace_eref_probe_index *ix)
 {
-    return ix->ehits0 && ix->keys16[0] && std::memcmp(&ix->masks, &ctx->masks, sizeof(CoderMasks)) == 0;
+    return ix->ehits_own[0] && ix->keys16[0] && std::memcmp(&ix->masks, &ctx->masks, sizeof(CoderMasks)) == 0;
 }
 
 // the final count kernel of a launch with Phase B's channel-0 probe riding along (eref_lds_count_kernel<true, true, true>)
-static int probe_index_launch_fused(palace_ctx *ctx, const palace_eref_probe_index *ix, const CountBufs &b, const CountPlan &pl, const KeyBuckets &keys)
+// (all_sets: eref_lds_count_kernel<true, true, 2> -- every entry set is tested and the ">= 3" plane is not written at all)
+static int probe_index_launch_fused(palace_ctx *ctx, const palace_eref_probe_index *ix, const CountBufs &b, const CountPlan &pl, const KeyBuckets &keys,
+                                    bool all_sets)
 {
-    PALACE_HIP_TRY(hipMemsetAsync(ix->ehits0, 0, ix->ehits_bytes[0], ctx->stream));      // (buckets without keys leave their bytes alone)
-    const ProbeArgs pr{ix->first, ix->keys16[0], ix->ehits0};
-    hipLaunchKernelGGL((eref_lds_count_kernel<true, true, true>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
-                       ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, pr);
+    // (buckets without keys leave their bytes alone)
+    PALACE_HIP_TRY(hipMemsetAsync(ix->ehits_own[0], 0, all_sets ? ix->ehits_own_bytes : ix->ehits_bytes[0], ctx->stream));
+    ProbeArgs pr{};
+    for (int k = 0; k < kSets; k++) {
+        pr.first[k] = ix->first + static_cast<size_t>(k) * (kIndexGroups + 1);
+        pr.keys16[k] = ix->keys16[k];
+        pr.ehits[k] = ix->ehits_own[k];
+    }
+    if (all_sets)
+        hipLaunchKernelGGL((eref_lds_count_kernel<true, true, 2>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
+                           ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, pr);
+    else
+        hipLaunchKernelGGL((eref_lds_count_kernel<true, true, 1>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
+                           ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, pr);
     PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
 }
@@ -2148,15 +2259,18 @@ static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &
             int rc = palace_mark(ctx, ctx->mark_before_count);
             if (rc) return rc;
         }
-        const ProbeArgs no_probe{nullptr, nullptr, nullptr};
+        const ProbeArgs no_probe{};
         if (clean && n_slabs == 1 && ctx->want_final) {
             const palace_eref_probe_index *ix = ctx->probe_ix;
             const bool whole = (ctx->key_buckets[0] & ctx->key_buckets[1] & ctx->key_buckets[2] & ctx->key_buckets[3]) == ~0u;
             if (ix && whole && probe_index_usable(ctx, ix)) {
-                // the final count of a whole key space with a probe index attached: channel 0 of Phase B rides along
-                int rc = probe_index_launch_fused(ctx, ix, b, pl, keys);
+                // the final count of a whole key space with a probe index attached: channel 0 of Phase B rides along -- or (option
+                // probe_all_sets) all of Phase B's look-ups, and the ">= 3" plane is never written
+                int rc = probe_index_launch_fused(ctx, ix, b, pl, keys, ctx->probe_all_sets);
                 if (rc) return rc;
                 ctx->c0_hits_ix = ix;
+                ctx->hits_mask = ctx->probe_all_sets ? (1u << kSets) - 1 : 1u;
+                ctx->planeless = ctx->probe_all_sets;
             } else {
                 hipLaunchKernelGGL((eref_lds_count_kernel<true, true>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
                                    ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, no_probe);
@@ -2316,6 +2430,9 @@ int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value)
     } else if (!std::strcmp(name, "final_count")) {          // the count calls that follow are each the only one between a reset and Phase B
         PALACE_REQUIRE(value == 0 || value == 1, "final_count must be 0 or 1");
         ctx->want_final = value != 0;
+    } else if (!std::strcmp(name, "probe_all_sets")) {       // with final_count and an attached probe index: the final count tests ALL of the
+        PALACE_REQUIRE(value == 0 || value == 1, "probe_all_sets must be 0 or 1");      // index's entry sets and writes no plane (see ProbeArgs)
+        ctx->probe_all_sets = value != 0;
     } else if (!std::strcmp(name, "mark_before_level2")) {         // -1: none; i: palace_mark(ctx, i) between level 1 and level 2 of the last part
         PALACE_REQUIRE(value >= -1 && value < 4096, "mark index out of range");
         ctx->mark_before_level2 = static_cast<int>(value);
@@ -2458,6 +2575,7 @@ int palace_eref_scan_refs(palace_ctx *ctx, const uint8_t *d_bases, const int64_t
 {
     int rc = scan_args_ok(ctx, d_bases, d_offsets, n_refs, total_bases, d_rows);
     if (rc || n_refs == 0) return rc;
+    PALACE_REQUIRE(!ctx->planeless, "the table holds nothing (option probe_all_sets: its last count tested the attached index and wrote no plane): reset it first");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     rc = ensure_table(ctx);
     if (rc) return rc;
@@ -2534,8 +2652,15 @@ int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const
         TRY_OR_DONE(hipMemsetAsync(ix->pos_s, 0xff, (n128 + 8) * 4, ctx->stream));
         ib.pos_s = ix->pos_s;
     }
-    TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&ix->ehits0), ix->ehits_bytes[0] + 16));
-    TRY_OR_DONE(hipMemsetAsync(ix->ehits0, 0, ix->ehits_bytes[0] + 16, ctx->stream));
+    {   // the hit bits a count launch leaves (channel 0's, or every set's): one block, each set's part 256-byte aligned with 16 spare bytes
+        size_t at[kSets], total = 0;
+        for (int k = 0; k < kSets; k++) { at[k] = total; total += align_up(ix->ehits_bytes[k] + 16, 256); }
+        uint8_t *blk = nullptr;
+        TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&blk), total));
+        TRY_OR_DONE(hipMemsetAsync(blk, 0, total, ctx->stream));
+        for (int k = 0; k < kSets; k++) ix->ehits_own[k] = blk + at[k];
+        ix->ehits_own_bytes = total;
+    }
     TRY_OR_DONE(hipMemsetAsync(count, 0, count_bytes, ctx->stream));
     ib.first = ix->first;
     hipLaunchKernelGGL(eref_probe_index_kernel<1>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
@@ -2555,7 +2680,7 @@ int palace_eref_probe_index_free(palace_ctx *ctx, palace_eref_probe_index *ix)
     for (int k = 0; k < palace::kSets; k++) if (ix->keys16[k]) (void)hipFree(ix->keys16[k]);
     for (int c = 0; c < 3; c++) if (ix->eix[c]) (void)hipFree(ix->eix[c]);
     if (ix->pos_s) (void)hipFree(ix->pos_s);
-    if (ix->ehits0) (void)hipFree(ix->ehits0);
+    if (ix->ehits_own[0]) (void)hipFree(ix->ehits_own[0]);
     delete ix;
     return PALACE_OK;
 }
@@ -2584,9 +2709,11 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     if (rc) return rc;
     // channel 0's hit bits: the count launch has left them when this index was attached to it and nothing has touched the planes
     // since; every other entry set (and channel 0 otherwise) is probed now, the plane read once for all of them
-    const bool fused = ctx->c0_hits_ix == ix;
+    const uint32_t fused = ctx->c0_hits_ix == ix ? ctx->hits_mask : 0u;      // bit k: set k's hit bits are the count launch's
+    PALACE_REQUIRE(!ctx->planeless || fused == (1u << kSets) - 1,
+                   "the table holds nothing (option probe_all_sets): only the index that rode along in the count can be scanned through; reset the table first");
     size_t eb[kSets];
-    for (int k = 0; k < kSets; k++) eb[k] = (k == 0 && fused) ? 0 : ix->ehits_bytes[k];
+    for (int k = 0; k < kSets; k++) eb[k] = ((fused >> k) & 1u) ? 0 : ix->ehits_bytes[k];
     ScanBuffers b;
     rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b, true, eb);
     if (rc) return rc;
@@ -2594,14 +2721,15 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     PALACE_HIP_TRY(hipMemsetAsync(b.hit_bytes, 0, static_cast<size_t>(b.max_words) * (64 / kSentinelStride), ctx->stream));
     ProbeSets sets{};
     for (int k = 0; k < kSets; k++) {
-        uint8_t *eh = (k == 0 && fused) ? ix->ehits0 : b.ehits[k];   // (this context's: several contexts may scan through one index)
+        const bool have = (fused >> k) & 1u;
+        uint8_t *eh = have ? ix->ehits_own[k] : b.ehits[k];          // (this context's: several contexts may scan through one index)
         sets.s[k] = ProbeSet{ix->first + static_cast<size_t>(k) * (kIndexGroups + 1), ix->keys16[k], eh};
-        if (!(k == 0 && fused)) {
+        if (!have) {
             sets.mask |= 1u << k;
             if (ix->ehits_bytes[k] >= 16) PALACE_HIP_TRY(hipMemsetAsync(eh + ix->ehits_bytes[k] - 16, 0, 16, ctx->stream));     // (bytes behind the last entry)
         }
     }
-    hipLaunchKernelGGL(eref_probe_sets_kernel, dim3(kBuckets), dim3(kProbeThreads), 0, ctx->stream, sets, ctx->plane[2]);
+    if (sets.mask) hipLaunchKernelGGL(eref_probe_sets_kernel, dim3(kBuckets), dim3(kProbeThreads), 0, ctx->stream, sets, ctx->plane[2]);
     // the sentinels that hit -> position order -> the bit words eref_need_kernel reads
     hipLaunchKernelGGL(eref_ehits_scatter_kernel, dim3(kCUs * 8), dim3(kScatterThreads), 0, ctx->stream,
                        reinterpret_cast<const uint4 *>(sets.s[kSentinelSet].ehits), static_cast<unsigned long long>(ix->ehits_bytes[kSentinelSet] / 16),
@@ -2646,6 +2774,7 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
 int palace_eref_table_planes(palace_ctx *ctx, void **d_planes3, size_t *bytes_per_plane)
 {
     PALACE_REQUIRE(ctx && d_planes3 && bytes_per_plane, "null argument");
+    PALACE_REQUIRE(!ctx->planeless, "the table holds nothing (option probe_all_sets: its last count tested the attached index and wrote no plane): reset it first");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
@@ -2666,6 +2795,7 @@ int palace_eref_table_attach(palace_ctx *ctx, void *const d_planes3[3])
         ctx->plane[p] = static_cast<uint32_t *>(d_planes3[p]);
     }
     ctx->planes_external = true;
+    ctx->planeless = false;
     ctx->table_clean = false;                              // caller-owned memory: contents unknown
     ctx->keys_counted = -1;
     ctx->final_only = false;
@@ -2677,6 +2807,7 @@ int palace_eref_table_invalidate(palace_ctx *ctx)
 {
     PALACE_REQUIRE(ctx, "ctx is null");
     ctx->table_clean = false;
+    ctx->planeless = false;
     ctx->keys_counted = -1;
     ctx->final_only = false;
     ctx->c0_hits_ix = nullptr;
@@ -2752,6 +2883,7 @@ int palace_eref_plane_pack(palace_ctx *ctx, const uint32_t mask128[4], uint32_t 
                            unsigned long long *d_first)
 {
     PALACE_REQUIRE(ctx && mask128 && d_counts && d_keys && d_first && cap_keys >= 0, "bad argument");
+    PALACE_REQUIRE(!ctx->planeless, "the table holds nothing (option probe_all_sets: its last count tested the attached index and wrote no plane): reset it first");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
@@ -2770,6 +2902,7 @@ int palace_eref_plane_unpack(palace_ctx *ctx, const uint32_t mask128[4], const u
                              unsigned long long *d_first)
 {
     PALACE_REQUIRE(ctx && mask128 && d_counts && d_keys && d_first && cap_keys >= 0, "bad argument");
+    PALACE_REQUIRE(!ctx->planeless, "the table holds nothing (option probe_all_sets: its last count tested the attached index and wrote no plane): reset it first");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
@@ -2803,6 +2936,7 @@ int palace_eref_table_lookup(palace_ctx *ctx, const uint32_t *d_keys, int64_t n,
 int palace_eref_table_popcounts(palace_ctx *ctx, uint64_t out3[3])
 {
     PALACE_REQUIRE(ctx && out3, "null argument");
+    PALACE_REQUIRE(!ctx->planeless, "the table holds nothing (option probe_all_sets: its last count tested the attached index and wrote no plane): reset it first");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;

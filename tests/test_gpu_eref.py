@@ -274,6 +274,37 @@ def test_probe_fused_into_the_final_count_equals_the_probe_kernel_and_the_oracle
             got_p = rows_p.to_host()
             assert np.array_equal(got_f, got_p), which
             assert [(int(a), int(b)) for a, b in got_f[:, :2]] == [(int(a), int(b)) for a, b in want], which
+            # every entry set rides along and no plane is written (option probe_all_sets): same rows, from the hit bits alone; other
+            # thresholds scan off the same bits; whatever else would read the table is refused; after the (free) reset the planes are
+            # all zero -- a plain count then gives the table a fresh context's count gives (touched buckets were zeroed again)
+            ctx.eref_attach_probe_index(ix)
+            ctx.eref_set_option("final_count", 1)
+            ctx.eref_set_option("probe_all_sets", 1)
+            ctx.eref_table_reset()
+            ctx.eref_count_reads(rb, ro, rr.n)
+            ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), one_min, three_min, rows_p)
+            assert np.array_equal(rows_p.to_host(), got_f), (which, "all sets fused")
+            o2, t2 = capi.window_minimums(0.5, 0.2)
+            ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), o2, t2, rows_p)
+            rows_all_02 = rows_p.to_host().copy()
+            with pytest.raises(capi.PalaceError):
+                ctx.eref_scan_refs(db, do, rs_refs.n, len(rs_refs.bases), one_min, three_min, rows_p)
+            with pytest.raises(capi.PalaceError):
+                ctx.eref_table_popcounts()
+            with pytest.raises(capi.PalaceError):
+                ctx.eref_count_reads(rb, ro, rr.n)
+            ctx.eref_set_option("probe_all_sets", 0)
+            ctx.eref_set_option("final_count", 0)
+            ctx.eref_attach_probe_index(None)
+            ctx.eref_table_reset()                                   # (no memset: the planes are known to be zero)
+            ctx.eref_count_reads(rb, ro, rr.n)
+            pops_after = ctx.eref_table_popcounts()
+            ctx.eref_scan_refs(db, do, rs_refs.n, len(rs_refs.bases), o2, t2, rows_p)
+            assert np.array_equal(rows_p.to_host(), rows_all_02), (which, "all sets fused, other thresholds")
+            ctx.eref_table_invalidate()                              # contents declared unknown: this reset clears the planes for real
+            ctx.eref_table_reset()
+            ctx.eref_count_reads(rb, ro, rr.n)
+            assert ctx.eref_table_popcounts() == pops_after, (which, "planes were not all zero after the plane-less count")
             # attached, but the count is not a final one (three planes): nothing rides along, same rows
             ctx.eref_attach_probe_index(ix)
             ctx.eref_set_option("final_count", 0)
@@ -305,6 +336,7 @@ def test_probe_fused_into_the_final_count_equals_the_probe_kernel_and_the_oracle
     finally:
         ctx.eref_attach_probe_index(None)
         ctx.eref_set_option("final_count", 0)
+        ctx.eref_set_option("probe_all_sets", 0)
         ctx.eref_set_count_mode(0, 0)
         if ix is not None:
             ctx.eref_probe_index_free(ix)

@@ -9,6 +9,7 @@ With packed reads (bench.py --reads packed, the default) the kernels that make t
 launch: they are listed but left out of the sum.
 usage: traffic_json.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <source tag> [contigs] [workload] [reads]"""
 import collections
+import re
 import csv
 import ctypes
 import json
@@ -33,15 +34,16 @@ def kernel_of(name):
     return None
 
 
-FUSED = {"seen": False}                                     # the count kernel ran with Phase B's probe in it (its third template flag)
+FUSED = {"seen": 0}                                     # the count kernel ran with Phase B's probe in it (its third template flag)
 
 
 def sums(path, counter):
     """kernel -> (sum over dispatches in bytes, dispatches)"""
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(path)):
-        if "eref_lds_count_kernel<true, true, true>" in r["Kernel_Name"].replace("(bool)1", "true"):
-            FUSED["seen"] = True
+        m = re.search(r"eref_lds_count_kernel<true, true, (?:\(int\))?([12])>", r["Kernel_Name"].replace("(bool)1", "true"))
+        if m:                                                   # 1: channel 0 rode along; 2: every entry set did and no plane was written
+            FUSED["seen"] = max(int(FUSED["seen"]), int(m.group(1)))
         if r["Counter_Name"] == counter:
             k = kernel_of(r["Kernel_Name"])
             if k:
