@@ -796,7 +796,21 @@ struct ProbeArgs {
     const unsigned long long *first[kProbeSetsMax];         // [65537] start of every fine bucket's entries of the set (multiples of 8)
     const uint16_t *keys16[kProbeSetsMax];                  // index & 0xffff of the set's entries, grouped by fine bucket
     uint8_t *ehits[kProbeSetsMax];                          // a BIT per entry, in entry order (byte i = entries 8 i .. 8 i + 7), zero before the launch
+    // PROBE == 2: the sentinels that hit are carried to position order right here (entry -> sentinel ordinal, a byte per sentinel, zero
+    // before the launch) -- what eref_ehits_scatter_kernel does for a scan that probes for itself; their entry-order bits are not stored
+    const uint32_t *pos_s;
+    uint8_t *sent_bytes;
 };
+// the sentinels of one 16-byte vector (entries 8 i .. 8 i + 7) that hit: every look-up of `pos_s` first, then the byte stores
+__device__ __forceinline__ void scatter_sentinels(const ProbeArgs &pr, unsigned long long i, uint32_t m)
+{
+    uint32_t p[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) p[e] = ((m >> e) & 1u) ? pr.pos_s[i * 8 + e] : ~0u;
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+        if (p[e] != ~0u) pr.sent_bytes[p[e]] = 1;
+}
 // the eight 16-bit entries of one 16-byte vector against a 2^16-bit slice in LDS -> a byte of hit bits
 __device__ __forceinline__ uint32_t probe_vector(const uint32_t *__restrict__ l3, const uint4 &v)
 {
@@ -830,7 +844,7 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
     // thread in one batch (the densest buckets hold twice the mean of ~380), the sentinels one
     constexpr int kLateCh = 3, kLateSent = 1;
 #ifndef PALACE_PROBE_GROUP
-#define PALACE_PROBE_GROUP 1
+#define PALACE_PROBE_GROUP 2
 #endif
     constexpr int kProbeGroup = PALACE_PROBE_GROUP;
     unsigned long long q0[kProbeSetsMax - 1] = {0, 0, 0}, q1[kProbeSetsMax - 1] = {0, 0, 0};
@@ -864,8 +878,11 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
 #pragma unroll
                     for (int k = 1; k < kProbeSetsMax; k++) {
                         const uint4 *qv = reinterpret_cast<const uint4 *>(pr.keys16[k]);
-                        for (unsigned long long i = q0[k - 1] + threadIdx.x; i < q1[k - 1]; i += kCountThreads)
-                            pr.ehits[k][i] = static_cast<uint8_t>(probe_vector(l3, qv[i]));
+                        for (unsigned long long i = q0[k - 1] + threadIdx.x; i < q1[k - 1]; i += kCountThreads) {
+                            const uint32_t m = probe_vector(l3, qv[i]);
+                            if (k == 3) scatter_sentinels(pr, i, m);
+                            else pr.ehits[k][i] = static_cast<uint8_t>(m);
+                        }
                     }
                     uint4 *z3 = reinterpret_cast<uint4 *>(p3 + w0);        // the plane goes back to zero as well: nothing reads it any more
                     for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) z3[i] = uint4{0, 0, 0, 0};
@@ -998,6 +1015,13 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
 #pragma unroll
         for (int u = 0; u < kLateSent; u++) { sm[u] = probe_vector(l3, lsn[u]); asm volatile("" : "+v"(sm[u]) : : "memory"); }
     }
+    if (PROBE == 2) {                                      // (the position look-ups of the sentinels that hit: before any store of this wave is in flight)
+#pragma unroll
+        for (int u = 0; u < kLateSent; u++) {
+            const unsigned long long i = q0[2] + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
+            if (i < q1[2] && sm[u]) scatter_sentinels(pr, i, sm[u]);
+        }
+    }
     uint4 *o1 = reinterpret_cast<uint4 *>(p1 + w0), *o2 = reinterpret_cast<uint4 *>(p2 + w0),
           *o3 = reinterpret_cast<uint4 *>(p3 + w0);
     if (PROBE == 2) {                                      // the slice stays in LDS; a seeded one (overflow keys) goes back to zero in all planes
@@ -1029,11 +1053,6 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
                 const unsigned long long i = q0[c] + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
                 if (i < q1[c]) pr.ehits[1 + c][i] = static_cast<uint8_t>(lm[c][u]);
             }
-#pragma unroll
-        for (int u = 0; u < kLateSent; u++) {
-            const unsigned long long i = q0[2] + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
-            if (i < q1[2]) pr.ehits[3][i] = static_cast<uint8_t>(sm[u]);
-        }
     }
     if (PROBE) {                                           // buckets with more entries than the batches hold (another DB's density): the rest, one by one
         const uint4 *pv = reinterpret_cast<const uint4 *>(pr.keys16[0]);
@@ -1045,8 +1064,11 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
         for (int k = 1; k < kProbeSetsMax; k++) {
             const uint4 *qv = reinterpret_cast<const uint4 *>(pr.keys16[k]);
             const int held = k == 3 ? kLateSent : kLateCh;
-            for (unsigned long long i = q0[k - 1] + threadIdx.x + static_cast<unsigned long long>(held) * kCountThreads; i < q1[k - 1]; i += kCountThreads)
-                pr.ehits[k][i] = static_cast<uint8_t>(probe_vector(l3, qv[i]));
+            for (unsigned long long i = q0[k - 1] + threadIdx.x + static_cast<unsigned long long>(held) * kCountThreads; i < q1[k - 1]; i += kCountThreads) {
+                const uint32_t m = probe_vector(l3, qv[i]);
+                if (k == 3) scatter_sentinels(pr, i, m);
+                else pr.ehits[k][i] = static_cast<uint8_t>(m);
+            }
         }
     }
 }
@@ -2128,6 +2150,7 @@ struct palace_eref_probe_index {
     uint8_t *ehits_own[palace::kSets] = {nullptr, nullptr, nullptr, nullptr};    // the sets' hit bits (one per entry) when a count launch this index is
                                               //  attached to leaves them: channel 0's, or (option probe_all_sets) all four; ONE allocation, [0] heads it
     size_t ehits_own_bytes = 0;
+    uint8_t *sent_bytes_own = nullptr;        // ... and, behind them in the same block, the byte per sentinel in position order that launch sets for the hits
     size_t ehits_bytes[palace::kSets] = {0, 0, 0, 0};                  // bytes of a set's hit bits (multiple of 16; the tail stays zero)
     size_t hit_bytes_size = 0;                // position ids run over [0, hit_bytes_size)
 };
@@ -2153,6 +2176,8 @@ static int probe_index_launch_fused(palace_ctx *ctx, const palace_eref_probe_ind
         pr.keys16[k] = ix->keys16[k];
         pr.ehits[k] = ix->ehits_own[k];
     }
+    pr.pos_s = ix->pos_s;
+    pr.sent_bytes = ix->sent_bytes_own;
     if (all_sets)
         hipLaunchKernelGGL((eref_lds_count_kernel<true, true, 2>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
                            ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, pr);
@@ -2655,10 +2680,13 @@ int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const
     {   // the hit bits a count launch leaves (channel 0's, or every set's): one block, each set's part 256-byte aligned with 16 spare bytes
         size_t at[kSets], total = 0;
         for (int k = 0; k < kSets; k++) { at[k] = total; total += align_up(ix->ehits_bytes[k] + 16, 256); }
+        const size_t at_sent = total;
+        total += align_up(ix->hit_bytes_size / kSentinelStride + 16, 256);
         uint8_t *blk = nullptr;
         TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&blk), total));
         TRY_OR_DONE(hipMemsetAsync(blk, 0, total, ctx->stream));
         for (int k = 0; k < kSets; k++) ix->ehits_own[k] = blk + at[k];
+        ix->sent_bytes_own = blk + at_sent;
         ix->ehits_own_bytes = total;
     }
     TRY_OR_DONE(hipMemsetAsync(count, 0, count_bytes, ctx->stream));
@@ -2718,7 +2746,8 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b, true, eb);
     if (rc) return rc;
     PALACE_REQUIRE(static_cast<size_t>(b.max_words) * 64 == ix->hit_bytes_size, "probe index was built for another layout of the hit words");
-    PALACE_HIP_TRY(hipMemsetAsync(b.hit_bytes, 0, static_cast<size_t>(b.max_words) * (64 / kSentinelStride), ctx->stream));
+    const bool sent_done = fused == (1u << kSets) - 1;          // the count launch carried the sentinels' hits to position order as well
+    if (!sent_done) PALACE_HIP_TRY(hipMemsetAsync(b.hit_bytes, 0, static_cast<size_t>(b.max_words) * (64 / kSentinelStride), ctx->stream));
     ProbeSets sets{};
     for (int k = 0; k < kSets; k++) {
         const bool have = (fused >> k) & 1u;
@@ -2731,11 +2760,12 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     }
     if (sets.mask) hipLaunchKernelGGL(eref_probe_sets_kernel, dim3(kBuckets), dim3(kProbeThreads), 0, ctx->stream, sets, ctx->plane[2]);
     // the sentinels that hit -> position order -> the bit words eref_need_kernel reads
-    hipLaunchKernelGGL(eref_ehits_scatter_kernel, dim3(kCUs * 8), dim3(kScatterThreads), 0, ctx->stream,
-                       reinterpret_cast<const uint4 *>(sets.s[kSentinelSet].ehits), static_cast<unsigned long long>(ix->ehits_bytes[kSentinelSet] / 16),
-                       ix->pos_s, b.hit_bytes);
-    hipLaunchKernelGGL(eref_sentinel_words_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(b.hit_bytes),
-                       b.max_words, b.any_w);
+    if (!sent_done)
+        hipLaunchKernelGGL(eref_ehits_scatter_kernel, dim3(kCUs * 8), dim3(kScatterThreads), 0, ctx->stream,
+                           reinterpret_cast<const uint4 *>(sets.s[kSentinelSet].ehits), static_cast<unsigned long long>(ix->ehits_bytes[kSentinelSet] / 16),
+                           ix->pos_s, b.hit_bytes);
+    hipLaunchKernelGGL(eref_sentinel_words_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const uint4 *>(sent_done ? ix->sent_bytes_own : b.hit_bytes), b.max_words, b.any_w);
     PALACE_HIP_TRY(hipGetLastError());
     // A window that passes holds >= three_min positions hit in all channels, i.e. misses at most 500 - three_min channel-0 hits;
     // it holds at least 500 / 4 - 1 sentinels (the cumulative windows at a ref's start, which must hold three_min positions
