@@ -608,6 +608,12 @@ def measure(args, E, leg):
                          # bin1 + bin2 + lds_count per launch; only valid for the default workload on one GPU
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "avg_launch_ms": count_ms, "algorithmic_bytes_per_launch": alg_bytes + probe_bytes,
+                         # the same launch priced on Phase A's bytes alone (the look-ups it also does counted as nothing), and the whole of
+                         # eref -- Phase A + Phase B's SURVEY bytes -- over the launch + the scan behind it: the two figures that do not
+                         # depend on which kernel Phase B's look-ups are done in
+                         "frac_phase_a_bytes_only": alg_bytes / (max(count_ms, 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_eref_count_plus_scan": (alg_bytes + sum(int(l) + 3 * (int(l) - 31) for l in sample["ref_lens"][r_lo:r_hi]))
+                                                      / (max(count_ms + scan_ms, 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_note": f"864 B per 150-bp read x {2 * n_side} reads" + (f" + {probe_bytes} B: the look-ups of Phase B ({fused_sets} B per ref "
                                                    "position: " + ("all three channels" if fused_sets == 3 else "channel 0") + "), which this launch's count kernel does while a bucket's slice is in LDS" if probe_bytes else "")},
             # the other stages of the step against the same roofline (SURVEY.md section 8(d) algorithmic bytes; live event times of

@@ -14,6 +14,7 @@
 #include <thread>
 
 #include "bam.hpp"
+#include "device_pick.hpp"
 #include "depth_host.hpp"
 #include "depthgz.hpp"
 
@@ -42,7 +43,7 @@ int main(int argc, char **argv)
         } catch (const std::exception &e) { std::cerr << "bamdepth: " << e.what() << "\n"; return 1; }
     }
     palace_ctx *ctx = nullptr;
-    if (palace_ctx_create(0, &ctx)) { std::cerr << "bamdepth: " << palace_last_error() << "\n"; return 1; }
+    if (palace_ctx_create(pick_device(), &ctx)) { std::cerr << "bamdepth: " << palace_last_error() << "\n"; return 1; }
     std::string text;
     std::vector<uint64_t> cs, cc;
     const int rc = per_contig ? first_depth(ctx, c, text, nullptr, nullptr, &cs, &cc) : first_depth(ctx, c, text);

@@ -28,6 +28,7 @@
 #include "fastx.hpp"
 #include "trace.hpp"
 #include "fast_exit.hpp"
+#include "device_pick.hpp"
 
 using namespace palace_host;
 
@@ -123,6 +124,7 @@ int main(int argc, char **argv)
         return 1;
     }
     palace_host::FastExit fast_exit = palace_host::fast_exit_begin();   // from here on this is the worker process (fast_exit.hpp)
+    const int device = palace_host::pick_device();                       // PALACE_DEVICE (device_pick.hpp): before anything touches HIP
     const std::string fq1 = argv[1], fq2 = argv[2], fasta = argv[3], interval_name = argv[4];
     const float hit_ratio = static_cast<float>(std::stod(argv[5]));            // :1228-1229
     const float perfect_ratio = static_cast<float>(std::stod(argv[6]));
@@ -148,7 +150,7 @@ int main(int argc, char **argv)
     }).share();
     std::thread hip_up([&] {
         Trace th("eref/hip");
-        ctx_rc = palace_ctx_create(0, &ctx);
+        ctx_rc = palace_ctx_create(device, &ctx);
         th.lap("context");
         if (!ctx_rc) ctx_rc = palace_eref_table_reset(ctx);
         th.lap("table");

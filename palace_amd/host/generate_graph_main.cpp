@@ -32,6 +32,7 @@
 #include "stage04_fused.hpp"
 #include "trace.hpp"
 #include "fast_exit.hpp"
+#include "device_pick.hpp"
 
 using namespace palace_host;
 
@@ -313,6 +314,7 @@ int main(int argc, char **argv)
     double avg_depth = auto_depth ? 0.0 : std::atof(argv[optind + 3]);
 
     FastExit fast_exit = fast_exit_begin();                    // from here on this is the worker process (fast_exit.hpp)
+    const int device = pick_device();                          // PALACE_DEVICE (device_pick.hpp): before anything touches HIP
     Trace tr("generateGraph");
     BamColumns c;
     c.want_match_segments = auto_depth;                         // (only the depth stage reads them: 6.7 M triples at 1M contigs)
@@ -321,7 +323,7 @@ int main(int argc, char **argv)
     BamLoad *load = nullptr;
     try {
         // header parsed, the rest of the file is being inflated -- by the threads, and by the device once its runtime is up (bam_device.hpp)
-        load = load_bam_begin(bam_path, threads, c, device_inflate_helpers(0));
+        load = load_bam_begin(bam_path, threads, c, device_inflate_helpers(device));
     } catch (const std::exception &e) {
         std::cerr << e.what() << "\n";
         return 1;
@@ -341,7 +343,7 @@ int main(int argc, char **argv)
     std::thread side([&] { Trace t("generateGraph/names"); name_ranks(c.target_name, by_name, rank); t.lap("name ranks"); });
     std::thread side2([&] { Trace t("generateGraph/fastg"); fkeys = fastg_keys(fai_path, c, 8); t.lap("fastg keys"); });
     std::thread hip_up([&] {
-        ctx_rc = palace_ctx_create(0, &ctx);
+        ctx_rc = palace_ctx_create(device, &ctx);
         if (ctx_rc) ctx_err = palace_last_error();
     });
     palace_stage04 *s4obj = nullptr;

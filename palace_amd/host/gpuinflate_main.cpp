@@ -16,6 +16,7 @@
 
 #include "../../include/palace_hip.h"
 #include "bam.hpp"
+#include "device_pick.hpp"
 
 using namespace palace_host;
 using Clock = std::chrono::steady_clock;
@@ -52,7 +53,7 @@ int main(int argc, char **argv)
     const auto h1 = Clock::now();
     // ---- device ----
     palace_ctx *ctx = nullptr;
-    CK(palace_ctx_create(0, &ctx));
+    CK(palace_ctx_create(pick_device(), &ctx));
     std::vector<int64_t> in_off(static_cast<size_t>(n)), out_off(static_cast<size_t>(n));
     std::vector<int32_t> in_len(static_cast<size_t>(n)), out_len(static_cast<size_t>(n)), status(static_cast<size_t>(n), -1);
     for (int64_t i = 0; i < n; i++) {

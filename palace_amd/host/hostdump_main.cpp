@@ -9,6 +9,7 @@
 //   hostdump fmtg <n> <seed>           format_g6 (textio.hpp) against snprintf("%g") on n values of every kind (random bits, quotients of
 //                                      integers as SEG depths are, decimals at and next to rounding ties); prints the number of differences
 //   hostdump fasta <file.fa> [threads] one line per record (ordinal, name, length, sequence); with threads: parse_fasta_mt
+//   hostdump devicepick x              "<ordinal handed to palace_ctx_create> <ROCR_VISIBLE_DEVICES afterwards>" (device_pick.hpp)
 //   hostdump forkcheck x               "1" when the executables would stay one process here (fast_exit.hpp: a profiler / preload in
 //                                      the environment, or a GPU runtime already open), else "0"
 #include <algorithm>
@@ -20,6 +21,7 @@
 
 #include "bam.hpp"
 #include "fast_exit.hpp"
+#include "device_pick.hpp"
 #include "fastx.hpp"
 
 using namespace palace_host;
@@ -31,6 +33,10 @@ int main(int argc, char **argv)
     try {
         if (mode == "forkcheck") {
             std::printf("%d\n", (std::getenv("PALACE_NO_FORK") || gpu_touched_before_main()) ? 1 : 0);
+        } else if (mode == "devicepick") {
+            const int ord = pick_device();
+            const char *v = std::getenv("ROCR_VISIBLE_DEVICES");
+            std::printf("%d %s\n", ord, v ? v : "-");
         } else if (mode == "bam") {
             BamColumns c;
             load_bam(argv[2], argc > 3 ? std::atoi(argv[3]) : 4, 1, c);

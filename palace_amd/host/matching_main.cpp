@@ -28,6 +28,7 @@
 #include "textio.hpp"
 #include "trace.hpp"
 #include "fast_exit.hpp"
+#include "device_pick.hpp"
 
 namespace {
 
@@ -261,12 +262,13 @@ int main(int argc, char **argv)
         return 1;
     }
     palace_host::FastExit fast_exit = palace_host::fast_exit_begin();   // from here on this is the worker process (fast_exit.hpp)
+    const int device = palace_host::pick_device();                       // PALACE_DEVICE (device_pick.hpp): before anything touches HIP
     palace_host::Trace tr("matching");
     palace_ctx *ctx = nullptr;                                // the HIP runtime comes up while the graph text is read
     int ctx_rc = 0;
     std::string ctx_err;
     std::thread hip_up([&] {
-        ctx_rc = palace_ctx_create(0, &ctx);
+        ctx_rc = palace_ctx_create(device, &ctx);
         if (ctx_rc) ctx_err = palace_last_error();
     });
     // one job per graph: the plain command line is a batch of one

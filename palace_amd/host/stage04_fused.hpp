@@ -24,6 +24,7 @@
 
 #include "../../include/palace_hip.h"
 #include "bam.hpp"
+#include "device_pick.hpp"
 #include "fastx.hpp"
 #include "textio.hpp"
 #include "trace.hpp"
@@ -357,7 +358,7 @@ inline palace_stage04 *stage04_prepare(const Stage04Options &o, const BamColumns
     if (!side.error.empty()) { err = side.error; return nullptr; }
     Trace tr("generateGraph/prepare");
     palace_ctx *ctx = nullptr;
-    if (palace_ctx_create(0, &ctx)) { err = palace_last_error(); return nullptr; }
+    if (palace_ctx_create(pick_device(), &ctx)) { err = palace_last_error(); return nullptr; }
     tr.lap("context");
     palace_stage04_inputs in{};
     in.n_segs = static_cast<int32_t>(c.target_name.size()); in.min_count = min_count;

@@ -57,8 +57,9 @@ def check_line(line, contigs):
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
     n_reads = int(c["workload"].split(", ")[1].split(" reads")[0])
     ref_bp = int(c["workload"].split("phage refs (")[1].split(" bp")[0])
-    # 864 B per 150-bp read; with Phase B's channel-0 probe fused into the count kernel, its 1 B per ref position too
-    assert r["algorithmic_bytes_per_launch"] in (864 * n_reads, 864 * n_reads + ref_bp - 31 * 5000)
+    # 864 B per 150-bp read; with Phase B's look-ups fused into the count kernel, their 1 B per ref position and channel too
+    # (channel 0, or -- the default since round 5 -- all three: --fused-probe 2)
+    assert r["algorithmic_bytes_per_launch"] in (864 * n_reads, 864 * n_reads + ref_bp - 31 * 5000, 864 * n_reads + 3 * (ref_bp - 31 * 5000))
     st = line["roofline_stages"]
     assert set(st) == {"phase_b", "classify", "resolve", "stage04"}
     for v in st.values():

@@ -341,3 +341,20 @@ def test_executables_stay_one_process_under_a_profiler_or_preload():
     assert check(ROCPROFILER_LIBRARY_CTOR="1") == b"1"
     assert check(ROCPROF_OUTPUT_PATH="/tmp/x") == b"1"
     assert check(PALACE_NO_FORK="1") == b"1"
+
+
+def test_device_pick_of_the_executables():
+    """host/device_pick.hpp: PALACE_DEVICE chooses the GPU of an executable; when nothing else restricts the visible devices the
+    choice is made through ROCR_VISIBLE_DEVICES (one device comes up instead of the node's eight) and the ordinal is 0"""
+    def pick(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "PALACE_DEVICE", "ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES",
+                                                              "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES")
+             and not k.startswith(("ROCPROF", "ROCTRACER"))}
+        e.update(env)
+        return subprocess.run([HOSTDUMP, "devicepick", "x"], stdout=subprocess.PIPE, env=e, check=True).stdout.strip()
+    assert pick() == b"0 0"
+    assert pick(PALACE_DEVICE="5") == b"0 5"
+    assert pick(PALACE_DEVICE="-3") == b"0 0"
+    assert pick(PALACE_DEVICE="2", HIP_VISIBLE_DEVICES="4,5,6") == b"2 -"          # an ordinal within somebody else's choice
+    assert pick(PALACE_DEVICE="1", ROCR_VISIBLE_DEVICES="3,7") == b"1 3,7"
+    assert pick(PALACE_DEVICE="3", HSA_TOOLS_LIB="librocprofiler-sdk-tool.so") == b"3 -"   # a runtime may be up already: too late for the variable
