@@ -238,8 +238,6 @@ def measure(args, E, leg):
     fused_probe, fused_all = fused_mode >= 1, fused_mode == 2
     if fused_probe:
         capi._check(L.palace_eref_attach_probe_index(ctx.h, probe_index), "attach probe index")
-    if fused_all:
-        capi._check(L.palace_eref_set_option(ctx.h, b"probe_all_sets", 1), "probe_all_sets")
 
     # the reads in the form the step counts them from (resident before the timed region, like every other input)
     packed = None
@@ -257,6 +255,9 @@ def measure(args, E, leg):
     # kernels move 1/W of the bytes, the key arithmetic stays) and the ">= 3" plane slices are all-gathered -- one collective of
     # 512 MiB / W per rank instead of the table exchange
     key_split = bool(exch) and scheme == "key_split"
+    fused_all = fused_all and final_count and not key_split and not shard_reads     # (whoever exchanges plane slices afterwards needs the plane)
+    if fused_all:
+        capi._check(L.palace_eref_set_option(ctx.h, b"probe_all_sets", 1), "probe_all_sets")
     if key_split:
         ctx.eref_set_key_buckets(multigpu.key_buckets_of(rank, world))       # mirrored pairs of buckets: equal key mass per rank
     for e in ectx:
