@@ -51,10 +51,10 @@ def parse_args():
                          "device and its own duration -- the roofline figure -- grows from 9.2 to 10.3 ms; 1 (default) = every step drains "
                          "before the next, the count launch is timed with only this step's generateGraph stream beside it")
     ap.add_argument("--fused-probe", type=int, choices=(0, 1, 2), default=2,
-                    help="1 (default): Phase B's channel-0 probe rides along in the count kernel (palace_eref_attach_probe_index: 2 B per DB position "
+                    help="1: Phase B's channel-0 probe rides along in the count kernel (palace_eref_attach_probe_index: 2 B per DB position "
                          "tested against each fine bucket's '>= 3' slice while it is in LDS): the count launch 0.1 ms longer, Phase B 0.2 ms shorter "
                          "(1.16 against 1.36 ms), and `roofline` counts those look-ups (1 B per ref position) as work of the launch; 0: the count "
-                         "launch is Phase A alone and the scan probes for itself; 2: ALL of Phase B's look-ups ride along (the index's four entry sets) and "
+                         "launch is Phase A alone and the scan probes for itself; 2 (default): ALL of Phase B's look-ups ride along (the index's four entry sets) and "
                          "the '>= 3' plane is never written -- no slice write-back, no probe kernel, no reset before the next step (option probe_all_sets)")
     ap.add_argument("--graph-lag", type=int, choices=(0, 1), default=0,
                     help="1: the graph result of a step (stage 04's decomposition) is collected at the START of the next step -- a two-deep "
