@@ -286,6 +286,24 @@ class GraphInput:
         return buf.raw[:got]
 
 
+def graph_trace(records, targets, fastg_fai: str, avg_depth: float, opts: GraphOpts | None = None):
+    """-> (graph text, the text `generateGraph --debug` writes to stderr on the way: generate_graph.cpp:454-458, :607-609, :711-853)"""
+    gin = GraphInput(records, targets)
+    o = opts or graph_default_opts()
+    cap = 64 * 1024 * 1024 + 200 * gin.n_targets
+    buf, tbuf = C.create_string_buffer(cap), C.create_string_buffer(cap)
+    tlen = C.c_long()
+    L = lib()
+    L.orc_graph_run_trace.restype = C.c_long
+    L.orc_graph_run_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_double,
+                                      C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_long)]
+    got = L.orc_graph_run_trace(C.byref(gin.R), gin.n_targets, gin.tn.ctypes.data, gin.toff.ctypes.data, gin.tlen.ctypes.data,
+                                fastg_fai.encode(), avg_depth, C.byref(o), buf, cap, tbuf, cap, C.byref(tlen))
+    if got < 0:
+        raise OSError("orc_graph_run_trace: output buffer too small")
+    return buf.raw[:got], tbuf.raw[:tlen.value]
+
+
 def depth_mean(records, targets):
     """-> (text awk would print, sum, NR) for `samtools depth | awk '{sum+=$3} END {print sum/NR}'` (palace:538-552)."""
     gin = GraphInput(records, targets)

@@ -111,8 +111,9 @@ bool paired_layout_ok(const Side &l, const Side &r, char oL, char oR, const Opts
 }
 
 // generate_graph.cpp:432-461 with :255-260 and :310-318.  `oL`/`oR` are the *_eval orientations.
+// dbg: --debug's line of :454-458 (ostream's default formatting of the four doubles); score_out: the value :852 prints
 bool score_positive(const Side &l, int mapqL, int nmL, char oL, const Side &r, int mapqR, int nmR, char oR,
-                    const Opts &o)
+                    const Opts &o, std::ostream *dbg = nullptr, double *score_out = nullptr)
 {
     Region gl = (oL == '-') ? flipped(l.reg) : l.reg, gr = (oR == '-') ? flipped(r.reg) : r.reg;
     int dL = (gl == R_START) ? to_start(l.pos) : to_end(l.pos, l.len);
@@ -123,6 +124,8 @@ bool score_positive(const Side &l, int mapqL, int nmL, char oL, const Side &r, i
     double qL = std::min(1.0, (double)mapqL / 60.0) * (1.0 / (1.0 + 0.2 * std::max(0, nmL)));
     double qR = std::min(1.0, (double)mapqR / 60.0) * (1.0 / (1.0 + 0.2 * std::max(0, nmR)));
     double score = w_end * qL * qR;
+    if (dbg) *dbg << "Score calculation: w_end=" << w_end << " w_qualL=" << qL << " w_qualR=" << qR << " total=" << score << "\n";
+    if (score_out) *score_out = score;
     return score > 0.0;
 }
 
@@ -211,10 +214,14 @@ void orc_graph_default_opts(OrcGraphOpts *o)
 }
 
 // generate_graph.cpp:644-1076.  Writes the SEG/JUNC text into out; returns its size or -1.
-long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const int64_t *tname_off,
-                   const int32_t *tlen, const char *fastg_fai, double avg_depth, const OrcGraphOpts *oo,
-                   char *out, size_t cap)
+// trace (may be null): what --debug writes to stderr on the way (:454-458, :607-609, :711-717, :746-750, :758-767, :789-797, :851-853)
+static long graph_run(const OrcRecords *R, int n_targets, const char *tnames, const int64_t *tname_off,
+                      const int32_t *tlen, const char *fastg_fai, double avg_depth, const OrcGraphOpts *oo,
+                      char *out, size_t cap, std::string *trace)
 {
+    std::ostringstream dbg_text;
+    std::ostream *dbg = trace ? &dbg_text : nullptr;
+    auto region_name = [](Region r) { return r == R_START ? "START" : r == R_END ? "END" : "MIDDLE"; };
     Opts o;
     o.max_end = oo->max_end; o.min_mapq = oo->min_mapq; o.max_nm = oo->max_nm; o.enable_paired = oo->enable_paired;
     o.both_order = oo->both_order; o.min_count = oo->min_count; o.max_span_frac = oo->max_span_frac;
@@ -225,6 +232,7 @@ long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const
         name_to_tid[tname[i]] = i;                              // :624-627 (last duplicate wins)
     }
     std::set<PairKey> fastg = parse_fastg_fai(fastg_fai);
+    if (dbg) *dbg << "Loaded " << fastg.size() << " expected connections from FastG\n";      // :607-609
     std::unordered_map<std::string, double> consumed;           // :631
     std::map<PairKey, Agg> agg;                                 // :632 (same ordering as LayoutKey)
     std::unordered_set<std::string> seen_pairs;                 // :635
@@ -268,6 +276,10 @@ long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const
             std::string cigar1;
             for (int k = 0; k < ncg; k++) cigar1 += std::to_string(cg[k] >> 4) + opchr[std::min<int>(cg[k] & 15, 9)];
             Interval iv1 = read_interval(cigar1, s1.rev, read_len);
+            if (dbg)                                                           // :711-717
+                *dbg << "\n=== Split-read: " << qname << " (len=" << read_len << ") ===\n"
+                     << "Primary: " << r1 << " pos=" << s1.pos << " rev=" << s1.rev << " region=" << region_name(s1.reg)
+                     << " read[" << iv1.start << "-" << iv1.end << "]" << " CIGAR=" << cigar1 << "\n";
             std::stringstream ss(std::string(R->sa + R->sa_off[i], R->sa + R->sa_off[i + 1]));
             std::string item;
             while (std::getline(ss, item, ';')) {                              // :719
@@ -281,8 +293,15 @@ long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const
                 s2.reg = region_of(s2.pos, s2.len, o);
                 if (s1.reg == R_MIDDLE || s2.reg == R_MIDDLE) continue;        // :742
                 Interval iv2 = read_interval(it.cigar, it.rev, read_len);
+                if (dbg)                                                       // :746-750
+                    *dbg << "SA: " << it.rname << " pos=" << s2.pos << " rev=" << s2.rev << " region=" << region_name(s2.reg)
+                         << " read[" << iv2.start << "-" << iv2.end << "]" << " CIGAR=" << it.cigar << "\n";
                 bool first1 = false;
-                if (!stitchable(iv1, iv2, 150, 150, first1)) continue;         // :757
+                if (!stitchable(iv1, iv2, 150, 150, first1)) {                 // :757
+                    if (dbg) *dbg << "  -> Cannot stitch: intervals too far apart or too much overlap\n";
+                    continue;
+                }
+                if (dbg) *dbg << "  -> Can stitch! " << (first1 ? "Primary first" : "SA first") << "\n";
                 const Side &l = first1 ? s1 : s2, &r = first1 ? s2 : s1;
                 char oL = 0, oR = 0;
                 for (char a : {'+', '-'}) {
@@ -290,12 +309,18 @@ long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const
                         if (split_layout_ok(l, r, a, b)) { oL = a; oR = b; break; }
                     if (oL) break;
                 }
-                if (!oL) continue;
+                if (!oL) {
+                    if (dbg) *dbg << "  -> No valid layout found\n";           // :789-791
+                    continue;
+                }
                 const std::string &cL = first1 ? r1 : it.rname, &cR = first1 ? it.rname : r1;
+                if (dbg) *dbg << "  -> Found valid layout: " << cL << "(" << oL << ") -> " << cR << "(" << oR << ")\n";   // :795-797
                 int mqL = first1 ? mapq : it.mapq, nmL = first1 ? nm : it.nm;
                 int mqR = first1 ? it.mapq : mapq, nmR = first1 ? it.nm : nm;
                 bool left_is_a = cL <= cR;                                      // :802, :846
-                if (score_positive(l, mqL, nmL, left_is_a ? oL : oR, r, mqR, nmR, left_is_a ? oR : oL, o)) {
+                double score = 0.0;
+                if (score_positive(l, mqL, nmL, left_is_a ? oL : oR, r, mqR, nmR, left_is_a ? oR : oL, o, dbg, &score)) {
+                    if (dbg) *dbg << "  -> Passed eval with score=" << score << "\n";      // :851-853
                     add_edge(cL, oL, cR, oR, true, qname, f);
                     has_supp = true;
                 }
@@ -329,7 +354,7 @@ long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const
             const Side &l = first1 ? s1 : s2, &r = first1 ? s2 : s1;
             const std::string &cL = first1 ? tname[tid] : tname[mtid], &cR = first1 ? tname[mtid] : tname[tid];
             bool left_is_a = cL <= cR;
-            if (score_positive(l, mapq, nm, left_is_a ? oL : oR, r, mapq, nm, left_is_a ? oR : oL, o))   // :950-951, :990
+            if (score_positive(l, mapq, nm, left_is_a ? oL : oR, r, mapq, nm, left_is_a ? oR : oL, o, dbg))   // :950-951, :990 (its debug line: :454-458)
                 add_edge(cL, oL, cR, oR, false, qname, f);
         }
     }
@@ -359,10 +384,32 @@ long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const
         }
         os << "\n";
     }
+    if (trace) *trace = dbg_text.str();
     std::string s = os.str();
     if (s.size() > cap) return -1;
     std::memcpy(out, s.data(), s.size());
     return (long)s.size();
+}
+
+long orc_graph_run(const OrcRecords *R, int n_targets, const char *tnames, const int64_t *tname_off,
+                   const int32_t *tlen, const char *fastg_fai, double avg_depth, const OrcGraphOpts *oo,
+                   char *out, size_t cap)
+{
+    return graph_run(R, n_targets, tnames, tname_off, tlen, fastg_fai, avg_depth, oo, out, cap, nullptr);
+}
+
+// The graph text as orc_graph_run, and what --debug writes to stderr meanwhile into trace_out; returns the graph text's size, -1 when
+// either buffer is too small.
+long orc_graph_run_trace(const OrcRecords *R, int n_targets, const char *tnames, const int64_t *tname_off,
+                         const int32_t *tlen, const char *fastg_fai, double avg_depth, const OrcGraphOpts *oo,
+                         char *out, size_t cap, char *trace_out, size_t trace_cap, long *trace_len)
+{
+    std::string trace;
+    long n = graph_run(R, n_targets, tnames, tname_off, tlen, fastg_fai, avg_depth, oo, out, cap, &trace);
+    if (n < 0 || trace.size() > trace_cap) return -1;
+    std::memcpy(trace_out, trace.data(), trace.size());
+    *trace_len = (long)trace.size();
+    return n;
 }
 
 }  // extern "C"

@@ -33,6 +33,7 @@
 #include "trace.hpp"
 #include "fast_exit.hpp"
 #include "device_pick.hpp"
+#include "debug_trace.hpp"
 
 using namespace palace_host;
 
@@ -52,8 +53,8 @@ void usage(const char *prog)            // same option surface as generate_graph
               << "  --lib <FR|RF|FF>          Library type (accepted, unused as in the reference)\n"
               << "  --min-count <int>         Minimum supporting reads (default: 5)\n"
               << "  --min-score <double>      (accepted, unused as in the reference)\n"
-              << "  --debug                   JUNC lines carry their supporting reads (' READS: name(flag) ...'); the per-read\n"
-              << "                            traces on stderr are not produced\n"
+              << "  --debug                   JUNC lines carry their supporting reads (' READS: name(flag) ...') and the per-read\n"
+              << "                            text of the reference's debug mode goes to stderr\n"
               << "Stage 04 in this process (optional; every file of palace:566-600, none read back):\n"
               << "  --hit-seqs F --node-scores F --blast F --fasta-fai F --paths F   inputs of filter_graph.py (+ --blast-ratio, --score-threshold: 0.7)\n"
               << "  --filtered-pre F --filtered F --all-hit-segs F                  its outputs (F after uniq)\n"
@@ -365,6 +366,13 @@ int main(int argc, char **argv)
         return 1;
     }
     tr.lap("bam records");
+    if (debug) {
+        // the per-read text of the reference's --debug (:454-458, :607-609, :711-853): a diagnostic the host writes from the decoded
+        // records (debug_trace.hpp); the graph below is the device's as without the option
+        const std::string text = debug_trace(c, fai_path, prm);
+        std::fwrite(text.data(), 1, text.size(), stderr);
+        tr.lap("--debug: per-read text");
+    }
     join04();                                                     // (it joined `side`)
     if (side.joinable()) side.join();
     side2.join();

@@ -9,6 +9,7 @@
 //   hostdump fmtg <n> <seed>           format_g6 (textio.hpp) against snprintf("%g") on n values of every kind (random bits, quotients of
 //                                      integers as SEG depths are, decimals at and next to rounding ties); prints the number of differences
 //   hostdump fasta <file.fa> [threads] one line per record (ordinal, name, length, sequence); with threads: parse_fasta_mt
+//   hostdump bamtrace <bam> <fai> [..] what `generateGraph --debug` writes to stderr for the file's records (debug_trace.hpp), on stdout
 //   hostdump devicepick x              "<ordinal handed to palace_ctx_create> <ROCR_VISIBLE_DEVICES afterwards>" (device_pick.hpp)
 //   hostdump forkcheck x               "1" when the executables would stay one process here (fast_exit.hpp: a profiler / preload in
 //                                      the environment, or a GPU runtime already open), else "0"
@@ -22,6 +23,7 @@
 #include "bam.hpp"
 #include "fast_exit.hpp"
 #include "device_pick.hpp"
+#include "debug_trace.hpp"
 #include "fastx.hpp"
 
 using namespace palace_host;
@@ -33,6 +35,19 @@ int main(int argc, char **argv)
     try {
         if (mode == "forkcheck") {
             std::printf("%d\n", (std::getenv("PALACE_NO_FORK") || gpu_touched_before_main()) ? 1 : 0);
+        } else if (mode == "bamtrace") {                  // hostdump bamtrace <bam> <fastg.fai> [max_end min_mapq max_nm enable_paired max_span_frac]
+            if (argc < 4) { std::cerr << "usage: hostdump bamtrace <bam> <fastg.fai> [max_end min_mapq max_nm enable_paired max_span_frac]\n"; return 2; }
+            BamColumns c;
+            c.want_match_segments = false;
+            load_bam(argv[2], 4, 1, c);
+            palace_graph_params prm{300, 0, 5, 1, 0, 0, 0.80};
+            if (argc > 4) prm.max_end = std::atoi(argv[4]);
+            if (argc > 5) prm.min_mapq = std::atoi(argv[5]);
+            if (argc > 6) prm.max_nm = std::atoi(argv[6]);
+            if (argc > 7) prm.enable_paired = std::atoi(argv[7]);
+            if (argc > 8) prm.max_span_frac = std::atof(argv[8]);
+            const std::string t = debug_trace(c, argv[3], prm);
+            std::fwrite(t.data(), 1, t.size(), stdout);
         } else if (mode == "devicepick") {
             const int ord = pick_device();
             const char *v = std::getenv("ROCR_VISIBLE_DEVICES");

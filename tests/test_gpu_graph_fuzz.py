@@ -88,3 +88,26 @@ def test_adversarial_records_cli_equals_oracle(case):
         for k, v in OPTS[extra].items():
             setattr(o, k, v)
         assert open(out, "rb").read() == orc.graph_run(recs, targets, fai, 1.0, o)
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(cases())
+def test_adversarial_records_debug_text_and_read_lists(case):
+    """--debug: the JUNC lines' read lists (:1068-1073) and the per-read text on stderr (:454-458, :607-609, :711-853) against the oracle's"""
+    targets, fai_text, recs, extra = case
+    with tempfile.TemporaryDirectory(prefix="palace_fuzz_") as d:
+        bam, fai, out = os.path.join(d, "t.bam"), os.path.join(d, "g.fastg.fai"), os.path.join(d, "graph.txt")
+        synth.write_bam(bam, targets, recs, block=700)
+        open(fai, "w").write(fai_text)
+        p = subprocess.run([os.path.join(BIN, "generateGraph"), "--debug", "--min-count", "1", *extra, bam, fai, out, "1"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr
+        o = orc.graph_default_opts()
+        o.min_count, o.debug = 1, 1
+        for k, v in OPTS[extra].items():
+            setattr(o, k, v)
+        graph, trace = orc.graph_trace(recs, targets, fai, 1.0, o)
+        assert open(out, "rb").read() == graph
+        # (the GPU boxes' libdrm writes a line of its own to stderr when its ids file is missing)
+        got = b"".join(l for l in p.stderr.splitlines(keepends=True) if not l.startswith(b"/opt/amdgpu/"))
+        assert got == trace
