@@ -152,7 +152,10 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
  *                 the partition kernels had written into are zeroed again), so Phase B of that sample is the index's hit bits alone
  *                 (read_index's table look-ups, extract_ref.cpp:858-870, done where the counts are) and the next reset costs nothing.
  *                 Until that reset the table holds NOTHING: only palace_eref_scan_refs_indexed with the attached index works, every
- *                 other call that reads or extends the table fails.  0: off (default).
+ *                 other call that reads or extends the table fails.  2: the same, but what is left per entry is its partial COUNT (a rank
+ *                 that counted a share of the reads: see palace_eref_entry_layout).  0: off (default).
+ *   "scan_ref_lo", "scan_ref_hi"  palace_eref_scan_refs_indexed works on the refs [lo, hi) only (hi = 0: all); the rows of the others
+ *                 read n_intervals = el = 0.
  *   "mark_before_count_kernel" i >= 0: a binned count call records palace_mark(ctx, i) between its partition kernels and its
  *                 count kernel (another stream can hold work back until then: palace_wait_for_mark); -1: none (default).
  *   "mark_before_level2" i >= 0: the same between level 1 and level 2 of the call's last part; -1: none (default). */
@@ -200,6 +203,25 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
  * count call, a merge, an attach or a reset in between makes the scan probe for itself).  The index keeps the hit bits (one per
  * entry): attach it to ONE context at a time, and scan with it from one context at a time.  ix = NULL detaches. */
 int palace_eref_attach_probe_index(palace_ctx *ctx, const palace_eref_probe_index *ix);
+
+/* N GPUs that each counted a SHARE OF THE READS of one sample (no reference counterpart: its threads share one table,
+ * extract_ref.cpp:1269-1291).  Phase B reads the table at the DB's keys only (read_index, :858-870), so what the ranks owe each other
+ * is not their partial tables but their partial COUNTS of the DB's entries: with option "probe_all_sets" 2 the final count of a rank
+ * leaves, for every entry of the attached index (built over the WHOLE DB on every rank), its count 0..3 in two bits -- 16 bits per
+ * vector of eight entries, the four entry sets in one block of `counts_bytes` = 2 x `hits_bytes` (multiples of 256 x 840, so that 1 .. 8
+ * ranks own equal, aligned shares).  The ranks exchange the block by shares (an all-to-all of counts_bytes / W per peer), each sums the
+ * W parts of ITS share -- entry_hits_from_counts(d_parts, n_parts, part_stride, off, bytes): part p's counts of the block's bytes
+ * [off, off + bytes) lie at d_parts + p * part_stride (the receive buffer of the all-to-all as it is); bit set iff the counts add up
+ * to >= 3, exact because min(3, sum of min(3, c_r)) =
+ * min(3, sum of c_r) -- into its share of the hit-bit block, the shares are all-gathered, and entry_hits_complete declares the block
+ * whole: palace_eref_scan_refs_indexed then starts from it as from a count that tested every entry itself (options "scan_ref_lo" /
+ * "scan_ref_hi": a rank scans its range of the refs).  No plane crosses a link: 162 + 81 MB per 200 Mb of DB instead of 2 x 512 MiB.
+ * buffers_attach: the caller's device buffers (what its collectives address; NULL = the index's own) stand in for the two blocks. */
+int palace_eref_entry_layout(const palace_eref_probe_index *ix, size_t *counts_bytes, size_t *hits_bytes);
+int palace_eref_entry_buffers_attach(palace_ctx *ctx, palace_eref_probe_index *ix, void *d_counts, void *d_hits);
+int palace_eref_entry_hits_from_counts(palace_ctx *ctx, const palace_eref_probe_index *ix, const void *d_parts, int n_parts, size_t part_stride,
+                                       size_t off, size_t bytes);
+int palace_eref_entry_hits_complete(palace_ctx *ctx, const palace_eref_probe_index *ix, int64_t keys_counted);
 
 
 /* Multi-GPU exchange of the count table (no reference counterpart: the reference shares one

@@ -100,6 +100,10 @@ _SIGS = {
                               C.c_void_p],
     "palace_eref_probe_index_build": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)],
     "palace_eref_attach_probe_index": [C.c_void_p, C.c_void_p],
+    "palace_eref_entry_layout": [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
+    "palace_eref_entry_buffers_attach": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "palace_eref_entry_hits_from_counts": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t],
+    "palace_eref_entry_hits_complete": [C.c_void_p, C.c_void_p, C.c_int64],
     "palace_eref_probe_index_free": [C.c_void_p, C.c_void_p],
     "palace_eref_scan_refs_indexed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                       C.c_void_p],
@@ -338,6 +342,24 @@ class Ctx:
     def eref_attach_probe_index(self, index):
         """count calls that run as the final count also probe channel 0 of this DB (palace_eref_attach_probe_index); None detaches"""
         _check(lib().palace_eref_attach_probe_index(self.h, index), "palace_eref_attach_probe_index")
+
+    def eref_entry_layout(self, index):
+        """-> (bytes of the partial-count block, bytes of the hit-bit block) of a probe index (palace_eref_entry_layout)"""
+        cb, hb = C.c_size_t(), C.c_size_t()
+        _check(lib().palace_eref_entry_layout(index, C.byref(cb), C.byref(hb)), "palace_eref_entry_layout")
+        return int(cb.value), int(hb.value)
+
+    def eref_entry_buffers_attach(self, index, counts_ptr: int | None, hits_ptr: int | None):
+        """the caller's device buffers stand in for the index's count / hit-bit blocks (None: the index's own)"""
+        _check(lib().palace_eref_entry_buffers_attach(self.h, index, counts_ptr, hits_ptr), "palace_eref_entry_buffers_attach")
+
+    def eref_entry_hits_from_counts(self, index, parts_ptr: int, n_parts: int, part_stride: int, off: int, nbytes: int):
+        """sum n_parts partial-count arrays over the count block's bytes [off, off + nbytes) into the hit bits of that entry range"""
+        _check(lib().palace_eref_entry_hits_from_counts(self.h, index, parts_ptr, n_parts, part_stride, off, nbytes), "palace_eref_entry_hits_from_counts")
+
+    def eref_entry_hits_complete(self, index, keys_counted: int = -1):
+        """the hit-bit block of the attached index is whole: the next indexed scan starts from it"""
+        _check(lib().palace_eref_entry_hits_complete(self.h, index, keys_counted), "palace_eref_entry_hits_complete")
 
     def eref_probe_index_free(self, index: C.c_void_p):
         _check(lib().palace_eref_probe_index_free(self.h, index), "palace_eref_probe_index_free")

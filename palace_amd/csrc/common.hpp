@@ -79,7 +79,9 @@ struct palace_ctx {
     const struct palace_eref_probe_index *probe_ix = nullptr;
     const struct palace_eref_probe_index *c0_hits_ix = nullptr;
     uint32_t hits_mask = 0;         // ... which of its entry sets' hit bits that launch left (bit 0: channel 0; 0xf: all four, option probe_all_sets)
-    bool probe_all_sets = false;    // option: a final count with an attached index tests every entry set and writes no plane
+    int probe_all_sets = 0;         // option: a final count with an attached index tests every entry set and writes no plane (2: leaves partial counts)
+    bool sent_scattered = false;    // ... and that launch carried the sentinels' hits to position order itself
+    int64_t scan_ref_lo = 0, scan_ref_hi = 0;   // options scan_ref_lo / _hi: the indexed scan works on refs [lo, hi) (hi = 0: all)
     bool planeless = false;         // ... and did: the table holds NOTHING (all three planes are zero, as after a reset); Phase B is the attached
                                     // index's hit bits alone, and whatever else reads the table is refused until the next reset
     int mark_before_count = -1;     // option mark_before_count_kernel

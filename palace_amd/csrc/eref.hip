@@ -811,7 +811,26 @@ __device__ __forceinline__ void scatter_sentinels(const ProbeArgs &pr, unsigned 
     for (int e = 0; e < 8; e++)
         if (p[e] != ~0u) pr.sent_bytes[p[e]] = 1;
 }
+// PROBE = 3 (option probe_all_sets 2: a rank that counted a SHARE OF THE READS of a sample): as PROBE = 2, but what is left per
+// entry is not the hit bit but the partial COUNT, 0..3 in two bits (the three unary slices added up; 16 bits per vector of eight
+// entries, in `ehits`, which then points at the index's count block) -- ranks sum the counts of an entry range
+// (palace_eref_entry_hits_from_counts: min(3, sum of min(3, c_r)) = min(3, sum of c_r), exact) and gather the hit bits, so that no
+// plane crosses a link; the sentinels' hits are carried to position order by the scan (their counts are partial here).
 // the eight 16-bit entries of one 16-byte vector against a 2^16-bit slice in LDS -> a byte of hit bits
+__device__ __forceinline__ uint32_t count_vector(const uint32_t *__restrict__ l1, const uint32_t *__restrict__ l2, const uint32_t *__restrict__ l3, const uint4 &v)
+{
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const uint32_t k0 = d[e] & 0xffffu, k1 = d[e] >> 16;
+        const uint32_t c0 = ((l1[k0 >> 5] >> (k0 & 31)) & 1u) + ((l2[k0 >> 5] >> (k0 & 31)) & 1u) + ((l3[k0 >> 5] >> (k0 & 31)) & 1u);
+        const uint32_t c1 = ((l1[k1 >> 5] >> (k1 & 31)) & 1u) + ((l2[k1 >> 5] >> (k1 & 31)) & 1u) + ((l3[k1 >> 5] >> (k1 & 31)) & 1u);
+        m |= c0 << (4 * e);
+        m |= c1 << (4 * e + 2);
+    }
+    return m;
+}
 __device__ __forceinline__ uint32_t probe_vector(const uint32_t *__restrict__ l3, const uint4 &v)
 {
     const uint32_t d[4] = {v.x, v.y, v.z, v.w};
@@ -847,8 +866,14 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
 #define PALACE_PROBE_GROUP 2
 #endif
     constexpr int kProbeGroup = PALACE_PROBE_GROUP;
+    constexpr bool ALL = PROBE >= 2, COUNTS = PROBE == 3;   // every entry set is tested here / what is left per entry is its partial count
+    auto code = [&](const uint4 &vec) -> uint32_t { return COUNTS ? count_vector(l1, l2, l3, vec) : probe_vector(l3, vec); };
+    auto put_code = [&](int k, unsigned long long i, uint32_t m) {
+        if (COUNTS) reinterpret_cast<uint16_t *>(pr.ehits[k])[i] = static_cast<uint16_t>(m);
+        else pr.ehits[k][i] = static_cast<uint8_t>(m);
+    };
     unsigned long long q0[kProbeSetsMax - 1] = {0, 0, 0}, q1[kProbeSetsMax - 1] = {0, 0, 0};
-    if (PROBE == 2) {
+    if (ALL) {
 #pragma unroll
         for (int k = 1; k < kProbeSetsMax; k++) { q0[k - 1] = pr.first[k][b] / 8; q1[k - 1] = pr.first[k][b + 1] / 8; }
     }
@@ -867,21 +892,27 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
     if (n8 == 0) {                                         // uniform for the whole workgroup
         if (FINAL && ((touched[b >> 5] >> (b & 31)) & 1u)) {       // only overflow keys: plane 3 is right as it is, the lower two go back to zero
             uint4 *z1 = reinterpret_cast<uint4 *>(p1 + w0), *z2 = reinterpret_cast<uint4 *>(p2 + w0);
+            if (COUNTS) {                                          // (partial counts need the lower slices as well: read before they are zeroed)
+                for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) {
+                    reinterpret_cast<uint4 *>(l1)[i] = z1[i];
+                    reinterpret_cast<uint4 *>(l2)[i] = z2[i];
+                }
+            }
             for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) z1[i] = z2[i] = uint4{0, 0, 0, 0};
-            if (PROBE == 2 || (PROBE && phi > pe0)) {              // ... and is what the DB's positions of this bucket are tested against
+            if (ALL || (PROBE && phi > pe0)) {                     // ... and is what the DB's positions of this bucket are tested against
                 const uint4 *s3 = reinterpret_cast<const uint4 *>(p3 + w0);
                 for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) reinterpret_cast<uint4 *>(l3)[i] = s3[i];
                 __syncthreads();
                 const uint4 *pv = reinterpret_cast<const uint4 *>(pr.keys16[0]);
-                for (unsigned long long i = pe0 + threadIdx.x; i < phi; i += kCountThreads) pr.ehits[0][i] = static_cast<uint8_t>(probe_vector(l3, pv[i]));
-                if (PROBE == 2) {
+                for (unsigned long long i = pe0 + threadIdx.x; i < phi; i += kCountThreads) put_code(0, i, code(pv[i]));
+                if (ALL) {
 #pragma unroll
                     for (int k = 1; k < kProbeSetsMax; k++) {
                         const uint4 *qv = reinterpret_cast<const uint4 *>(pr.keys16[k]);
                         for (unsigned long long i = q0[k - 1] + threadIdx.x; i < q1[k - 1]; i += kCountThreads) {
-                            const uint32_t m = probe_vector(l3, qv[i]);
-                            if (k == 3) scatter_sentinels(pr, i, m);
-                            else pr.ehits[k][i] = static_cast<uint8_t>(m);
+                            const uint32_t m = code(qv[i]);
+                            if (k == 3 && !COUNTS) scatter_sentinels(pr, i, m);
+                            else put_code(k, i, m);
                         }
                     }
                     uint4 *z3 = reinterpret_cast<uint4 *>(p3 + w0);        // the plane goes back to zero as well: nothing reads it any more
@@ -971,7 +1002,7 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
     // PROBE == 2: the entries of the other three sets are requested now, in the registers the key vectors have left (behind the count
     // phase, not in flight during it like set 0's: seven more vectors per lane then would cost the kernel a workgroup per CU)
     uint4 lch[2][kLateCh], lsn[kLateSent];
-    if (PROBE == 2) {
+    if (ALL) {
         asm volatile("" ::: "memory");                     // (not hoisted above the count loop: 28 registers live through it would halve the occupancy)
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -998,24 +1029,24 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
     if (PROBE) {
 #pragma unroll
         for (int u = 0; u < kProbeBatch; u++) {
-            pm[u] = probe_vector(l3, pcur[u]);
-            if (PROBE == 2) asm volatile("" : "+v"(pm[u]) : : "memory");
+            pm[u] = code(pcur[u]);
+            if (ALL) asm volatile("" : "+v"(pm[u]) : : "memory");
         }
     }
-    if (PROBE == 2) {
+    if (ALL) {
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int u = 0; u < kLateCh; u++) {
-                lm[c][u] = probe_vector(l3, lch[c][u]);
+                lm[c][u] = code(lch[c][u]);
                 // (kProbeGroup vectors at a time: left alone the compiler issues the LDS reads of all nine vectors first -- 72 registers
                 // of results, 136 in all, three workgroups per CU instead of six)
-                if ((c * kLateCh + u) % kProbeGroup == kProbeGroup - 1) asm volatile("" : "+v"(lm[c][u]) : : "memory");
+                if (COUNTS || (c * kLateCh + u) % kProbeGroup == kProbeGroup - 1) asm volatile("" : "+v"(lm[c][u]) : : "memory");
             }
 #pragma unroll
-        for (int u = 0; u < kLateSent; u++) { sm[u] = probe_vector(l3, lsn[u]); asm volatile("" : "+v"(sm[u]) : : "memory"); }
+        for (int u = 0; u < kLateSent; u++) { sm[u] = code(lsn[u]); asm volatile("" : "+v"(sm[u]) : : "memory"); }
     }
-    if (PROBE == 2) {                                      // (the position look-ups of the sentinels that hit: before any store of this wave is in flight)
+    if (ALL && !COUNTS) {                                  // (the position look-ups of the sentinels that hit: before any store of this wave is in flight)
 #pragma unroll
         for (int u = 0; u < kLateSent; u++) {
             const unsigned long long i = q0[2] + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
@@ -1024,7 +1055,7 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
     }
     uint4 *o1 = reinterpret_cast<uint4 *>(p1 + w0), *o2 = reinterpret_cast<uint4 *>(p2 + w0),
           *o3 = reinterpret_cast<uint4 *>(p3 + w0);
-    if (PROBE == 2) {                                      // the slice stays in LDS; a seeded one (overflow keys) goes back to zero in all planes
+    if (ALL) {                                             // the slice stays in LDS; a seeded one (overflow keys) goes back to zero in all planes
         if (seed)
             for (int i = threadIdx.x; i < kFineWords / 4; i += kCountThreads) o1[i] = o2[i] = o3[i] = uint4{0, 0, 0, 0};
     } else {
@@ -1042,32 +1073,39 @@ __global__ __launch_bounds__(kCountThreads) void eref_lds_count_kernel(const uns
 #pragma unroll
         for (int u = 0; u < kProbeBatch; u++) {
             const unsigned long long i = pe0 + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
-            if (i < phi) pr.ehits[0][i] = static_cast<uint8_t>(pm[u]);
+            if (i < phi) put_code(0, i, pm[u]);
         }
     }
-    if (PROBE == 2) {
+    if (ALL) {
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int u = 0; u < kLateCh; u++) {
                 const unsigned long long i = q0[c] + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
-                if (i < q1[c]) pr.ehits[1 + c][i] = static_cast<uint8_t>(lm[c][u]);
+                if (i < q1[c]) put_code(1 + c, i, lm[c][u]);
             }
+        if (COUNTS) {
+#pragma unroll
+            for (int u = 0; u < kLateSent; u++) {
+                const unsigned long long i = q0[2] + threadIdx.x + static_cast<unsigned long long>(u) * kCountThreads;
+                if (i < q1[2]) put_code(3, i, sm[u]);
+            }
+        }
     }
     if (PROBE) {                                           // buckets with more entries than the batches hold (another DB's density): the rest, one by one
         const uint4 *pv = reinterpret_cast<const uint4 *>(pr.keys16[0]);
         for (unsigned long long i = pe0 + threadIdx.x + static_cast<unsigned long long>(kProbeBatch) * kCountThreads; i < phi; i += kCountThreads)
-            pr.ehits[0][i] = static_cast<uint8_t>(probe_vector(l3, pv[i]));
+            put_code(0, i, code(pv[i]));
     }
-    if (PROBE == 2) {
+    if (ALL) {
 #pragma unroll
         for (int k = 1; k < kProbeSetsMax; k++) {
             const uint4 *qv = reinterpret_cast<const uint4 *>(pr.keys16[k]);
             const int held = k == 3 ? kLateSent : kLateCh;
             for (unsigned long long i = q0[k - 1] + threadIdx.x + static_cast<unsigned long long>(held) * kCountThreads; i < q1[k - 1]; i += kCountThreads) {
-                const uint32_t m = probe_vector(l3, qv[i]);
-                if (k == 3) scatter_sentinels(pr, i, m);
-                else pr.ehits[k][i] = static_cast<uint8_t>(m);
+                const uint32_t m = code(qv[i]);
+                if (k == 3 && !COUNTS) scatter_sentinels(pr, i, m);
+                else put_code(k, i, m);
             }
         }
     }
@@ -1546,10 +1584,12 @@ __global__ __launch_bounds__(kRefThreads) void eref_need_kernel(const int64_t *_
                                                         const uint64_t *__restrict__ c0_words,
                                                         uint32_t *__restrict__ c0_pre, uint64_t *__restrict__ cand_words,
                                                         uint32_t *__restrict__ cand_pre, int three_min,
-                                                        uint8_t *__restrict__ need, uint8_t *__restrict__ active)
+                                                        uint8_t *__restrict__ need, uint8_t *__restrict__ active,
+                                                        int64_t r_lo, int64_t r_hi)       // refs outside [r_lo, r_hi) are not this call's: inactive
 {
     const int64_t r = blockIdx.x;
     if (r >= n_refs) return;
+    if (r < r_lo || r >= r_hi) { if (threadIdx.x == 0) active[r] = 0; return; }
     const int64_t len = offsets[r + 1] - offsets[r];
     const int64_t n_words = (len + 63) / 64, w0 = word_pre[r];
     const uint64_t *A = c0_words + w0;
@@ -2151,10 +2191,16 @@ struct palace_eref_probe_index {
                                               //  attached to leaves them: channel 0's, or (option probe_all_sets) all four; ONE allocation, [0] heads it
     size_t ehits_own_bytes = 0;
     uint8_t *sent_bytes_own = nullptr;        // ... and, behind them in the same block, the byte per sentinel in position order that launch sets for the hits
+    // (option probe_all_sets 2) the sets' partial COUNTS, 16 bits per vector of eight entries: same layout as the hit bits, twice the bytes
+    uint8_t *ecnt_own[palace::kSets] = {nullptr, nullptr, nullptr, nullptr};
+    size_t entry_hits_bytes = 0;              // bytes of the four sets' hit-bit parts together (without the sentinel bytes); counts: twice that
+    size_t set_at[palace::kSets] = {0, 0, 0, 0};    // where a set's part starts in the hit-bit block
+    uint8_t *hits_block = nullptr, *counts_block = nullptr;       // the index's own allocations (the pointers above may be re-pointed at a caller's)
     size_t ehits_bytes[palace::kSets] = {0, 0, 0, 0};                  // bytes of a set's hit bits (multiple of 16; the tail stays zero)
     size_t hit_bytes_size = 0;                // position ids run over [0, hit_bytes_size)
 };
 
+constexpr size_t kEntryBlockAlign = 256 * 840;          // 840 = lcm(1 .. 8)
 static_assert(kIndexGroups == kFine, "the probe index is grouped by the count kernel's fine buckets");
 static_assert(kSets == kProbeSetsMax, "the count kernel's probe arguments hold every entry set");
 
@@ -2166,19 +2212,31 @@ static bool probe_index_usable(const palace_ctx *ctx, const palace_eref_probe_in
 // the final count kernel of a launch with Phase B's channel-0 probe riding along (eref_lds_count_kernel<true, true, true>)
 // (all_sets: eref_lds_count_kernel<true, true, 2> -- every entry set is tested and the ">= 3" plane is not written at all)
 static int probe_index_launch_fused(palace_ctx *ctx, const palace_eref_probe_index *ix, const CountBufs &b, const CountPlan &pl, const KeyBuckets &keys,
-                                    bool all_sets)
+                                    int mode)                  // 0: channel 0; 1: every entry set, hit bits; 2: every entry set, partial counts
 {
+    const bool all_sets = mode >= 1;
     // (buckets without keys leave their bytes alone)
-    PALACE_HIP_TRY(hipMemsetAsync(ix->ehits_own[0], 0, all_sets ? ix->ehits_own_bytes : ix->ehits_bytes[0], ctx->stream));
+    if (mode == 2) {
+        PALACE_REQUIRE(ix->ecnt_own[0], "the probe index has no count block (palace_eref_entry_layout / _buffers_attach)");
+        PALACE_HIP_TRY(hipMemsetAsync(ix->ecnt_own[0], 0, 2 * ix->entry_hits_bytes, ctx->stream));
+    } else if (all_sets && ix->ehits_own[0] == ix->hits_block) {
+        PALACE_HIP_TRY(hipMemsetAsync(ix->hits_block, 0, ix->ehits_own_bytes, ctx->stream));     // hit bits and sentinel bytes: one block
+    } else {
+        PALACE_HIP_TRY(hipMemsetAsync(ix->ehits_own[0], 0, all_sets ? ix->entry_hits_bytes : ix->ehits_bytes[0], ctx->stream));
+        if (all_sets) PALACE_HIP_TRY(hipMemsetAsync(ix->sent_bytes_own, 0, ix->hit_bytes_size / kSentinelStride, ctx->stream));
+    }
     ProbeArgs pr{};
     for (int k = 0; k < kSets; k++) {
         pr.first[k] = ix->first + static_cast<size_t>(k) * (kIndexGroups + 1);
         pr.keys16[k] = ix->keys16[k];
-        pr.ehits[k] = ix->ehits_own[k];
+        pr.ehits[k] = mode == 2 ? ix->ecnt_own[k] : ix->ehits_own[k];
     }
     pr.pos_s = ix->pos_s;
     pr.sent_bytes = ix->sent_bytes_own;
-    if (all_sets)
+    if (mode == 2)
+        hipLaunchKernelGGL((eref_lds_count_kernel<true, true, 3>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
+                           ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, pr);
+    else if (all_sets)
         hipLaunchKernelGGL((eref_lds_count_kernel<true, true, 2>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
                            ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, pr);
     else
@@ -2293,9 +2351,15 @@ static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &
                 // probe_all_sets) all of Phase B's look-ups, and the ">= 3" plane is never written
                 int rc = probe_index_launch_fused(ctx, ix, b, pl, keys, ctx->probe_all_sets);
                 if (rc) return rc;
-                ctx->c0_hits_ix = ix;
-                ctx->hits_mask = ctx->probe_all_sets ? (1u << kSets) - 1 : 1u;
-                ctx->planeless = ctx->probe_all_sets;
+                if (ctx->probe_all_sets == 2) {              // partial counts: nothing to scan from until the ranks' counts are summed
+                    ctx->c0_hits_ix = nullptr;
+                    ctx->hits_mask = 0;
+                } else {
+                    ctx->c0_hits_ix = ix;
+                    ctx->hits_mask = ctx->probe_all_sets ? (1u << kSets) - 1 : 1u;
+                }
+                ctx->sent_scattered = ctx->probe_all_sets == 1;
+                ctx->planeless = ctx->probe_all_sets != 0;
             } else {
                 hipLaunchKernelGGL((eref_lds_count_kernel<true, true>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
                                    ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, no_probe);
@@ -2456,8 +2520,11 @@ int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value)
         PALACE_REQUIRE(value == 0 || value == 1, "final_count must be 0 or 1");
         ctx->want_final = value != 0;
     } else if (!std::strcmp(name, "probe_all_sets")) {       // with final_count and an attached probe index: the final count tests ALL of the
-        PALACE_REQUIRE(value == 0 || value == 1, "probe_all_sets must be 0 or 1");      // index's entry sets and writes no plane (see ProbeArgs)
-        ctx->probe_all_sets = value != 0;
+        PALACE_REQUIRE(value >= 0 && value <= 2, "probe_all_sets must be 0, 1 or 2");   // index's entry sets and writes no plane (see ProbeArgs);
+        ctx->probe_all_sets = static_cast<int>(value);                                   // 2: leaves partial counts (a share of the reads)
+    } else if (!std::strcmp(name, "scan_ref_lo") || !std::strcmp(name, "scan_ref_hi")) {   // palace_eref_scan_refs_indexed works on refs [lo, hi) only
+        PALACE_REQUIRE(value >= 0, "a ref ordinal");                                       // (hi = 0: all); rows of other refs: n_intervals = el = 0
+        (name[9] == 'l' ? ctx->scan_ref_lo : ctx->scan_ref_hi) = value;
     } else if (!std::strcmp(name, "mark_before_level2")) {         // -1: none; i: palace_mark(ctx, i) between level 1 and level 2 of the last part
         PALACE_REQUIRE(value >= -1 && value < 4096, "mark index out of range");
         ctx->mark_before_level2 = static_cast<int>(value);
@@ -2566,7 +2633,7 @@ int scan_tail(palace_ctx *ctx, const ScanBuffers &b, const uint8_t *d_bases, con
               int one_min, int three_min, int32_t *d_rows)
 {
     hipLaunchKernelGGL(eref_need_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(kRefThreads), 0, ctx->stream, d_offsets,
-                       n_refs, b.word_pre, b.any_w, b.any_p, b.good_w, b.all_p, three_min, b.need, b.active);
+                       n_refs, b.word_pre, b.any_w, b.any_p, b.good_w, b.all_p, three_min, b.need, b.active, static_cast<int64_t>(0), n_refs);
     PALACE_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(eref_ref_kernel<0>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
                        d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, ctx->plane[2], b.any_w,
@@ -2680,14 +2747,17 @@ int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const
     {   // the hit bits a count launch leaves (channel 0's, or every set's): one block, each set's part 256-byte aligned with 16 spare bytes
         size_t at[kSets], total = 0;
         for (int k = 0; k < kSets; k++) { at[k] = total; total += align_up(ix->ehits_bytes[k] + 16, 256); }
+        total = align_up(total, kEntryBlockAlign);          // (so that 1 .. 8 ranks can each own an equal, 256-byte aligned share of the block)
+        ix->entry_hits_bytes = total;
         const size_t at_sent = total;
         total += align_up(ix->hit_bytes_size / kSentinelStride + 16, 256);
         uint8_t *blk = nullptr;
         TRY_OR_DONE(hipMalloc(reinterpret_cast<void **>(&blk), total));
         TRY_OR_DONE(hipMemsetAsync(blk, 0, total, ctx->stream));
-        for (int k = 0; k < kSets; k++) ix->ehits_own[k] = blk + at[k];
+        for (int k = 0; k < kSets; k++) { ix->ehits_own[k] = blk + at[k]; ix->set_at[k] = at[k]; }
         ix->sent_bytes_own = blk + at_sent;
         ix->ehits_own_bytes = total;
+        ix->hits_block = blk;
     }
     TRY_OR_DONE(hipMemsetAsync(count, 0, count_bytes, ctx->stream));
     ib.first = ix->first;
@@ -2708,7 +2778,8 @@ int palace_eref_probe_index_free(palace_ctx *ctx, palace_eref_probe_index *ix)
     for (int k = 0; k < palace::kSets; k++) if (ix->keys16[k]) (void)hipFree(ix->keys16[k]);
     for (int c = 0; c < 3; c++) if (ix->eix[c]) (void)hipFree(ix->eix[c]);
     if (ix->pos_s) (void)hipFree(ix->pos_s);
-    if (ix->ehits_own[0]) (void)hipFree(ix->ehits_own[0]);
+    if (ix->hits_block) (void)hipFree(ix->hits_block);
+    if (ix->counts_block) (void)hipFree(ix->counts_block);
     delete ix;
     return PALACE_OK;
 }
@@ -2746,7 +2817,7 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     rc = scan_buffers(ctx, d_offsets, n_refs, total_bases, &b, true, eb);
     if (rc) return rc;
     PALACE_REQUIRE(static_cast<size_t>(b.max_words) * 64 == ix->hit_bytes_size, "probe index was built for another layout of the hit words");
-    const bool sent_done = fused == (1u << kSets) - 1;          // the count launch carried the sentinels' hits to position order as well
+    const bool sent_done = fused == (1u << kSets) - 1 && ctx->sent_scattered;   // the count launch carried the sentinels' hits to position order as well
     if (!sent_done) PALACE_HIP_TRY(hipMemsetAsync(b.hit_bytes, 0, static_cast<size_t>(b.max_words) * (64 / kSentinelStride), ctx->stream));
     ProbeSets sets{};
     for (int k = 0; k < kSets; k++) {
@@ -2771,8 +2842,9 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     // it holds at least 500 / 4 - 1 sentinels (the cumulative windows at a ref's start, which must hold three_min positions
     // to pass at all, hold more in proportion), so at least this many of its sentinels hit:
     const int sentinel_min = std::max(0, 500 / kSentinelStride - 1 - (500 - three_min));
+    const int64_t r_lo = std::min(ctx->scan_ref_lo, n_refs), r_hi = ctx->scan_ref_hi > 0 ? std::min(ctx->scan_ref_hi, n_refs) : n_refs;   // options scan_ref_lo / _hi
     hipLaunchKernelGGL(eref_need_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(kRefThreads), 0, ctx->stream, d_offsets,
-                       n_refs, b.word_pre, b.any_w, b.any_p, b.good_w, b.all_p, sentinel_min, b.need, b.active);
+                       n_refs, b.word_pre, b.any_w, b.any_p, b.good_w, b.all_p, sentinel_min, b.need, b.active, r_lo, r_hi);
     GatherArgs ga{};
     for (int c = 0; c < 3; c++) { ga.eix[c] = ix->eix[c]; ga.ehits[c] = sets.s[c].ehits; }
     const dim3 tiles(static_cast<unsigned>(b.max_tiles));
@@ -2790,7 +2862,7 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
         hipLaunchKernelGGL(eref_gather_hits_kernel<1>, tiles, dim3(256), 0, ctx->stream, d_offsets, n_refs, b.tile_pre, b.word_pre, ga, need, active,
                            b.any_w, b.all_w);
         hipLaunchKernelGGL(eref_need_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(kRefThreads), 0, ctx->stream, d_offsets,
-                           n_refs, b.word_pre, b.any_w, b.any_p, b.good_w, b.all_p, three_min, b.need, b.active);
+                           n_refs, b.word_pre, b.any_w, b.any_p, b.good_w, b.all_p, three_min, b.need, b.active, r_lo, r_hi);
         hipLaunchKernelGGL(eref_gather_hits_kernel<2>, tiles, dim3(256), 0, ctx->stream, d_offsets, n_refs, b.tile_pre, b.word_pre, ga, need, active,
                            b.any_w, b.all_w);
     }
@@ -2798,6 +2870,93 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
                        d_offsets, n_refs, b.word_pre, b.any_w, b.all_w, b.any_p, b.all_p, b.good_w, one_min, three_min,
                        static_cast<const uint8_t *>(b.active), d_rows);
     PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+/* ---- N GPUs that each counted a share of the READS: partial counts of the DB's entries instead of partial planes ---- */
+namespace {
+// parts[p][j] (u16 = eight 2-bit partial counts of the entries 8 j .. 8 j + 7), p < n_parts -> hit byte j: bit e set iff the counts of
+// entry e add up to 3 or more.  Eight u16 (16 bytes) per thread and part.
+__global__ __launch_bounds__(256) void entry_sum_kernel(const uint4 *__restrict__ parts, int n_parts, size_t part_stride16, size_t n16,
+                                                        unsigned long long *__restrict__ hits)
+{
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        uint32_t sum[8][8];                                              // [u16 of the vector][entry]
+#pragma unroll
+        for (int h = 0; h < 8; h++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) sum[h][e] = 0;
+        for (int p = 0; p < n_parts; p++) {
+            const uint4 v = parts[static_cast<size_t>(p) * part_stride16 + i];
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int h = 0; h < 8; h++) {
+                const uint32_t w = (d[h >> 1] >> (16 * (h & 1))) & 0xffffu;
+#pragma unroll
+                for (int e = 0; e < 8; e++) sum[h][e] += (w >> (2 * e)) & 3u;
+            }
+        }
+        unsigned long long out = 0;
+#pragma unroll
+        for (int h = 0; h < 8; h++) {
+            uint32_t byte = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) byte |= (sum[h][e] >= 3u ? 1u : 0u) << e;
+            out |= static_cast<unsigned long long>(byte) << (8 * h);
+        }
+        hits[i] = out;
+    }
+}
+}  // namespace
+
+int palace_eref_entry_layout(const palace_eref_probe_index *ix, size_t *counts_bytes, size_t *hits_bytes)
+{
+    PALACE_REQUIRE(ix && counts_bytes && hits_bytes, "null argument");
+    *hits_bytes = ix->entry_hits_bytes;
+    *counts_bytes = 2 * ix->entry_hits_bytes;
+    return PALACE_OK;
+}
+
+int palace_eref_entry_buffers_attach(palace_ctx *ctx, palace_eref_probe_index *ix, void *d_counts, void *d_hits)
+{
+    PALACE_REQUIRE(ctx && ix, "null argument");
+    PALACE_REQUIRE((reinterpret_cast<uintptr_t>(d_counts) | reinterpret_cast<uintptr_t>(d_hits)) % 256 == 0, "buffers must be 256-byte aligned");
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->c0_hits_ix == ix) ctx->c0_hits_ix = nullptr;
+    uint8_t *counts = static_cast<uint8_t *>(d_counts);
+    if (!counts) {                                                     // the index's own count block (made on first use: 2 x the hit bits)
+        if (!ix->counts_block) PALACE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ix->counts_block), 2 * ix->entry_hits_bytes));
+        counts = ix->counts_block;
+    }
+    uint8_t *hits = d_hits ? static_cast<uint8_t *>(d_hits) : ix->hits_block;
+    for (int k = 0; k < kSets; k++) { ix->ecnt_own[k] = counts + 2 * ix->set_at[k]; ix->ehits_own[k] = hits + ix->set_at[k]; }
+    return PALACE_OK;
+}
+
+int palace_eref_entry_hits_from_counts(palace_ctx *ctx, const palace_eref_probe_index *ix, const void *d_parts, int n_parts, size_t part_stride,
+                                       size_t off, size_t bytes)
+{
+    PALACE_REQUIRE(ctx && ix && d_parts && n_parts > 0, "bad argument");
+    PALACE_REQUIRE(off % 16 == 0 && bytes % 16 == 0 && part_stride % 16 == 0 && reinterpret_cast<uintptr_t>(d_parts) % 16 == 0, "16-byte granules");
+    PALACE_REQUIRE(off + bytes <= 2 * ix->entry_hits_bytes && bytes <= part_stride, "range outside the count block");
+    if (bytes == 0) return PALACE_OK;
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(entry_sum_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream, static_cast<const uint4 *>(d_parts), n_parts, part_stride / 16,
+                       bytes / 16, reinterpret_cast<unsigned long long *>(ix->ehits_own[0] + off / 2));
+    PALACE_HIP_TRY(hipGetLastError());
+    return PALACE_OK;
+}
+
+int palace_eref_entry_hits_complete(palace_ctx *ctx, const palace_eref_probe_index *ix, int64_t keys_counted)
+{
+    PALACE_REQUIRE(ctx && ix, "null argument");
+    PALACE_REQUIRE(ctx->probe_ix == ix && ctx->probe_all_sets == 2, "the index is not attached to this context with option probe_all_sets 2");
+    ctx->c0_hits_ix = ix;
+    ctx->hits_mask = (1u << kSets) - 1;
+    ctx->sent_scattered = false;                                       // (the scan carries the sentinels' hits to position order)
+    ctx->keys_counted = keys_counted;                                  // key instances of ALL ranks (what the scan's pruning goes by); -1: unknown
     return PALACE_OK;
 }
 

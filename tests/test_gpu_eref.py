@@ -344,6 +344,99 @@ def test_probe_fused_into_the_final_count_equals_the_probe_kernel_and_the_oracle
         db.free(); do.free()
 
 
+@pytest.mark.parametrize("cap", [0, 64])                                       # 64: most keys take the overflow path (touched buckets are seeded)
+def test_partial_entry_counts_of_read_shares_sum_to_the_hits_of_the_whole_sample(ctx, cap):
+    """Option probe_all_sets 2 + palace_eref_entry_*: W shares of a sample's reads counted one after another (what W ranks do side by
+    side), each leaving its partial counts of the DB's entries; the parts summed by entry range; the hit bits declared whole -- the
+    indexed scan must then give the rows of ONE count over all reads (and the oracle's), also restricted to a range of the refs, with
+    the blocks in caller-owned buffers as the collectives of a multi-GPU host need them, and for W that does not divide the block evenly."""
+    import ctypes
+    rng = synth.rng_for(91)
+    hdr = orc.header_from_picks(rng.integers(0, 6, size=32))
+    cc = orc.header_to_cc(hdr)
+    refs = [synth.random_dna(rng, L) for L in (30000, 4000, 33, 2500, 9000, 700)]
+    reads = []
+    for i, depth in ((0, 9), (3, 14), (4, 7), (1, 2)):
+        s_ = refs[i]
+        for st in rng.integers(0, len(s_) - 120, size=int(depth * len(s_) / 120)):
+            reads.append(synth.mutate(rng, s_[st:st + 120], 0.005))
+    order = rng.permutation(len(reads))
+    reads = [reads[k] for k in order]
+    rs_refs = synth.reads_from_list(refs)
+    db, do = ctx.upload(rs_refs.bases), ctx.upload(rs_refs.offsets)
+    rr = synth.reads_from_list(reads)
+    t = orc.CountTable()
+    t.count(rr.bases, rr.offsets, cc)
+    want = [orc.scan_ref(orc.index_ref(s_, cc), len(s_), t, 0.9, 0.85)[1:3] for s_ in refs]
+    t.free()
+    assert sum(1 for a, b in want if b > 0) >= 2
+    ix = None
+    L = capi.lib()
+    try:
+        ctx.eref_set_coder(hdr)
+        ix = ctx.eref_probe_index_build(db, do, rs_refs.n, len(rs_refs.bases))
+        ctx.eref_set_count_mode(2, cap)
+        one_min, three_min = capi.window_minimums(0.9, 0.85)
+        rows = ctx.empty((rs_refs.n, 4), np.int32)
+        cb, hb = ctx.eref_entry_layout(ix)
+        assert cb == 2 * hb and hb % (256 * 840) == 0
+        for W, own_hits in ((1, False), (3, True), (8, False)):
+            counts_buf = ctx.empty((cb,), np.uint8)                      # (caller-owned, as a host's collectives need it: read out below)
+            hits_buf = ctx.empty((hb,), np.uint8) if own_hits else None
+            ctx.eref_entry_buffers_attach(ix, counts_buf.ptr, hits_buf.ptr if own_hits else None)
+            parts = ctx.empty((W, cb), np.uint8)
+            ctx.eref_attach_probe_index(ix)
+            ctx.eref_set_option("final_count", 1)
+            ctx.eref_set_option("probe_all_sets", 2)
+            n_counting = max(1, W - 1)                                   # W > 1: the last "rank" takes no reads (rank 0 of a large sample does not)
+            for r in range(W):
+                share = synth.reads_from_list(reads[r * len(reads) // n_counting:(r + 1) * len(reads) // n_counting]) if r < n_counting else None
+                ctx.eref_table_reset()
+                if share is None:
+                    capi._check(L.palace_memset(ctx.h, ctypes.c_void_p(parts.ptr + r * cb), 0, cb), "memset")
+                    continue
+                sb, so = ctx.upload(share.bases), ctx.upload(share.offsets)
+                ctx.eref_count_reads(sb, so, share.n)
+                with pytest.raises(capi.PalaceError):                    # partial counts are nothing to scan from
+                    ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), one_min, three_min, rows)
+                ctx.d2d(parts.ptr + r * cb, counts_buf.ptr, cb)
+                ctx.sync()
+                sb.free(); so.free()
+            # every "rank" sums its share of the block: cb / W bytes each (a multiple of 512)
+            S = cb // W
+            assert S * W == cb and S % 512 == 0
+            for r in range(W):
+                ctx.eref_entry_hits_from_counts(ix, parts.ptr + r * S, W, cb, r * S, S)      # (part p's counts OF THE RANGE lie at ptr + p * stride)
+            ctx.eref_entry_hits_complete(ix, 3 * len(rr.bases))
+            ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), one_min, three_min, rows)
+            got = rows.to_host()
+            assert [(int(a), int(b)) for a, b in got[:, :2]] == [(int(a), int(b)) for a, b in want], (W, own_hits)
+            # a rank's range of the refs: the same rows inside, zero rows outside
+            ctx.eref_set_option("scan_ref_lo", 1)
+            ctx.eref_set_option("scan_ref_hi", 4)
+            ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), one_min, three_min, rows)
+            part = rows.to_host()
+            assert np.array_equal(part[1:4], got[1:4]) and not part[[0, 4, 5], :2].any(), (W, "range")
+            ctx.eref_set_option("scan_ref_lo", 0)
+            ctx.eref_set_option("scan_ref_hi", 0)
+            ctx.eref_table_reset()
+            ctx.eref_entry_buffers_attach(ix, None, None)
+            parts.free(); counts_buf.free()
+            if own_hits:
+                hits_buf.free()
+    finally:
+        ctx.eref_attach_probe_index(None)
+        ctx.eref_set_option("final_count", 0)
+        ctx.eref_set_option("probe_all_sets", 0)
+        ctx.eref_set_option("scan_ref_lo", 0)
+        ctx.eref_set_option("scan_ref_hi", 0)
+        ctx.eref_set_count_mode(0, 0)
+        if ix is not None:
+            ctx.eref_probe_index_free(ix)
+        ctx.eref_table_reset()
+        db.free(); do.free()
+
+
 def test_properties_full_size(ctx):
     """Size-independent properties at bench scale (2M reads): order independence, idempotence at
     saturation (x3 == x4), and the saturating merge of partial tables equals one-shot counting."""
