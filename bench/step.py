@@ -118,27 +118,32 @@ def measure(args, E, leg):
         forced = "key_split"
     elif world > 1 and os.environ.get("PALACE_BENCH_SCHEME", "auto") != "auto":
         forced = os.environ["PALACE_BENCH_SCHEME"]
-        if forced not in ("replicate", "key_split", "shard_reads") or (forced == "key_split" and 64 % world):
+        if forced not in ("replicate", "key_split", "shard_reads", "shard_counts") or (forced == "key_split" and 64 % world):
             raise SystemExit(f"PALACE_BENCH_SCHEME={forced}: not a scheme for {world} ranks")
     if forced:
         scheme = forced
     if not collectives:
         scheme = "replicate"
-    shard_reads = scheme == "shard_reads"
+    # "shard_counts" (end of round 5, PALACE_BENCH_SCHEME=shard_counts: opt-in until an N-GPU run has checked it): the reads are sharded
+    # as under shard_reads, but what the ranks exchange is their partial COUNTS of the DB's probe-index entries (two bits per entry,
+    # summed by entry range, hit bits all-gathered: include/palace_hip.h, palace_eref_entry_layout) -- no plane crosses a link
+    shard_counts = scheme == "shard_counts"
+    shard_reads = scheme == "shard_reads"                   # (the plane exchange)
+    reads_sharded = shard_reads or shard_counts
     # Stage 04 runs on rank 0.  Beside a count launch that saturates the device it takes 4-5x what it takes alone and grows with
     # the sample (5M contigs: 27 ms), so for large samples under the read-sharded scheme rank 0 takes NO reads: ranks 1 .. W-1
     # count 1/(W-1) each, rank 0's device has stage 04 (and its share of everything else) to itself.  PALACE_BENCH_RANK0_READS=0|1 forces.
     rank0_counts = True
-    if shard_reads and world > 2:
+    if reads_sharded and world > 2:
         env0 = os.environ.get("PALACE_BENCH_RANK0_READS", "auto")
         rank0_counts = (env0 == "1") if env0 in ("0", "1") else (best["rank0_counts"] if scheme == best["scheme"] else
                                                                   multigpu.step_model(args.contigs, n_reads_total, world, scheme, False)["step_ms"] >=
                                                                   multigpu.step_model(args.contigs, n_reads_total, world, scheme, True)["step_ms"])
-    read_weights = None if (rank0_counts or not shard_reads) else [0.0] + [1.0] * (world - 1)
+    read_weights = None if (rank0_counts or not reads_sharded) else [0.0] + [1.0] * (world - 1)
     model.update(choice_in_force=scheme, forced=bool(forced), rank0_counts=bool(rank0_counts), choice=best["scheme"],
                  step=multigpu.step_model(args.contigs, n_reads_total, world, scheme, rank0_counts),
                  step_alternatives=[multigpu.step_model(args.contigs, n_reads_total, world, sch, True) for sch in model["ms"]])
-    sample = make_sample(torch, dev, args.contigs, args.refs, rank if shard_reads else 0, world if shard_reads else 1, long_mode, read_weights)
+    sample = make_sample(torch, dev, args.contigs, args.refs, rank if reads_sharded else 0, world if reads_sharded else 1, long_mode, read_weights)
     gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world, long_mode)
     if collectives:                                 # avgDepth is a pipeline input: computed once from all shards
         tot = torch.tensor([float(gs["col"]["ref_len"].sum().item())], device=dev, dtype=torch.float64)
@@ -228,14 +233,19 @@ def measure(args, E, leg):
     # DB through the index file it built on first use (<fasta>.k32.index.dat), and the CPU baseline below is
     # timed with its index prebuilt as well.
     probe_index = ctypes.c_void_p()
-    capi._check(L.palace_eref_probe_index_build(ctx.h, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
-                                                sample["ref_total"], ctypes.byref(probe_index)), "probe index")
+    if shard_counts:                                # every rank probes the WHOLE DB's entries (the ranks' partial counts line up entry by entry)
+        ref_off_local = sample["ref_off"].contiguous()
+        capi._check(L.palace_eref_probe_index_build(ctx.h, P(sample["ref_bases"]), P(ref_off_local), n_refs,
+                                                    sample["ref_total"], ctypes.byref(probe_index)), "probe index")
+    else:
+        capi._check(L.palace_eref_probe_index_build(ctx.h, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
+                                                    sample["ref_total"], ctypes.byref(probe_index)), "probe index")
     # the count launch of a step is its final count (below): with --fused-probe 1 (or PALACE_BENCH_FUSED_PROBE=1) channel 0 of Phase B
     # rides along in the count kernel while each fine bucket's ">= 3" slice is in LDS (palace_eref_attach_probe_index)
     # --fused-probe 2 (round 5): ALL of Phase B's look-ups ride along (the index's four entry sets) and the '>= 3' plane is never written
     # -- no slice write-back, no probe kernel, no reset of the plane before the next step (option probe_all_sets)
     fused_mode = int(os.environ.get("PALACE_BENCH_FUSED_PROBE", str(args.fused_probe))) if depth == 1 else 0
-    fused_probe, fused_all = fused_mode >= 1, fused_mode == 2
+    fused_probe, fused_all = fused_mode >= 1 or shard_counts, fused_mode == 2 and not shard_counts
     if fused_probe:
         capi._check(L.palace_eref_attach_probe_index(ctx.h, probe_index), "attach probe index")
 
@@ -258,6 +268,17 @@ def measure(args, E, leg):
     fused_all = fused_all and final_count and not key_split and not shard_reads     # (whoever exchanges plane slices afterwards needs the plane)
     if fused_all:
         capi._check(L.palace_eref_set_option(ctx.h, b"probe_all_sets", 1), "probe_all_sets")
+    ec = None
+    if shard_counts:                                # the two blocks in torch-owned memory (what the collectives address); an idle rank's counts stay zero
+        cb, hb = ctx.eref_entry_layout(probe_index)
+        assert cb % (512 * world) == 0, "the count block does not split evenly over this many ranks"
+        ec = {"counts": torch.zeros(cb, dtype=torch.uint8, device=dev), "hits": torch.zeros(hb, dtype=torch.uint8, device=dev),
+              "keys_total": 3 * 2 * sample["n_pairs_total"] * READ_LEN}
+        torch.cuda.synchronize()
+        ctx.eref_entry_buffers_attach(probe_index, P(ec["counts"]), P(ec["hits"]))
+        capi._check(L.palace_eref_set_option(ctx.h, b"probe_all_sets", 2), "probe_all_sets")
+        capi._check(L.palace_eref_set_option(ctx.h, b"scan_ref_lo", r_lo), "scan_ref_lo")
+        capi._check(L.palace_eref_set_option(ctx.h, b"scan_ref_hi", r_hi), "scan_ref_hi")
     if key_split:
         ctx.eref_set_key_buckets(multigpu.key_buckets_of(rank, world))       # mirrored pairs of buckets: equal key mass per rank
     for e in ectx:
@@ -307,6 +328,14 @@ def measure(args, E, leg):
                                                        # RCCL's high-priority stream) overlap the counting kernels
 
         def eref_tail():
+            if exch and shard_counts:                  # the ranks' partial entry counts: all-to-all by entry range, sum, all-gather of the hit bits
+                with on_a():
+                    exch.merge_entry_counts(ec["counts"], ec["hits"],
+                                            lambda parts, n, stride, off, nb: ctx.eref_entry_hits_from_counts(probe_index, P(parts), n, stride, off, nb))
+                ctx.eref_entry_hits_complete(probe_index, ec["keys_total"])
+            elif shard_counts:                         # (one rank, rehearsal: its counts are the sample's)
+                ctx.eref_entry_hits_from_counts(probe_index, P(ec["counts"]), 1, ec["counts"].numel(), 0, ec["counts"].numel())
+                ctx.eref_entry_hits_complete(probe_index, ec["keys_total"])
             if exch and shard_reads:                   # count-table exchange (RCCL) on stream A, then Phase B on this rank's refs
                 with on_a():
                     exch.merge_planes(planes, merge_fn, pack_fn, final_gather=(lambda: sparse_gather(slice_buckets)) if sparse["cap"] else None)
@@ -321,8 +350,13 @@ def measure(args, E, leg):
                 ctx.eref_plane_pack((slice_buckets if shard_reads else split_buckets)[rank], P(sparse["probe_counts"]), P(sparse["probe_keys"]), 0, P(sparse["probe_first"]))
                 sparse["learn"] = True
             if timed: ctx.mark(m + 2)
-            capi._check(L.palace_eref_scan_refs_indexed(ctx.h, probe_index, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
-                                                        sample["ref_total"], one_min, three_min, P(rows) + 16 * r_lo), "scan")
+            if shard_counts:                           # the whole DB's index, this rank's range of the refs (options scan_ref_lo / _hi)
+                # (the rows of the other ranks' refs come out as zero rows here and are overwritten by the row gather below)
+                capi._check(L.palace_eref_scan_refs_indexed(ctx.h, probe_index, P(sample["ref_bases"]), P(ref_off_local), n_refs,
+                                                            sample["ref_total"], one_min, three_min, P(rows)), "scan")
+            else:
+                capi._check(L.palace_eref_scan_refs_indexed(ctx.h, probe_index, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
+                                                            sample["ref_total"], one_min, three_min, P(rows) + 16 * r_lo), "scan")
             if timed: ctx.mark(m + 3)
             if exch:
                 with on_a():
@@ -585,7 +619,8 @@ def measure(args, E, leg):
                        "batches_in_flight": depth, "graph_lag": args.graph_lag, "stage04_hold": args.stage04_hold,
                        "reads": ("packed in HBM: two bits per base + 32-mer start mask, 0.375 B/base (palace_eref_count_reads_packed)" if packed else
                                  "ASCII in HBM, 1 B/base (palace_eref_count_reads)") + ("; count keeps only the '>= 3' plane (final_count)" if final_count else ""),
-                       "parallelism": "1 GPU" if world == 1 else (f"reads/records/refs sharded over {world} GPUs (RCCL)" + ("" if rank0_counts else f"; rank 0 takes no reads: stage 04 has its device to itself, ranks 1-{world - 1} count") if shard_reads else
+                       "parallelism": "1 GPU" if world == 1 else (f"reads/records/refs sharded over {world} GPUs (RCCL)" + ("; the ranks exchange partial counts of the DB's probe-index entries, no plane crosses a link" if shard_counts else "")
+                                                                   + ("" if rank0_counts else f"; rank 0 takes no reads: stage 04 has its device to itself, ranks 1-{world - 1} count") if reads_sharded else
                                                                    f"records/refs and the key space sharded over {world} GPUs (RCCL): every GPU counts its 1/{world} of the keys of all reads, the '>= 3' plane is all-gathered" if key_split else
                                                                    f"records/refs sharded over {world} GPUs (RCCL), reads counted on every GPU"),
                        "parallelism_model": model,

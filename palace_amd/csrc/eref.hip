@@ -1326,6 +1326,7 @@ struct IndexBuild {
     uint16_t *keys16[kSets];
     uint32_t *eix[3];                           // position id -> entry of the channel
     uint32_t *pos_s;                            // sentinel entry -> position id / 4
+    uint32_t *epos[kSets];                      // (build only) entry -> position id: what eref_probe_index_canon_kernel orders a bucket's entries by
 };
 template <int PASS>   // 0: count positions per set and fine bucket, 1: place them
 __global__ __launch_bounds__(256) void eref_probe_index_kernel(const uint8_t *__restrict__ bases,
@@ -1365,12 +1366,54 @@ __global__ __launch_bounds__(256) void eref_probe_index_kernel(const uint8_t *__
                 if (PASS == 1) {
                     const unsigned long long e = ib.first[static_cast<size_t>(set) * (kIndexGroups + 1) + b] + at;
                     ib.keys16[set][e] = static_cast<uint16_t>(k);
+                    if (ib.epos[set]) ib.epos[set][e] = posid;
                     if (set == kSentinelSet) ib.pos_s[e] = posid / kSentinelStride;
                     else ib.eix[set][posid] = static_cast<uint32_t>(e);
                 }
             }
         }
         lo = hi;
+    }
+}
+
+// The placement above hands out a bucket's slots by atomicAdd: WHICH slot a position gets depends on the order its thread got there,
+// i.e. two builds of one DB agree on the buckets and disagree inside them.  For everything one GPU does that is immaterial; ranks that
+// sum partial counts entry by entry (palace_eref_entry_hits_from_counts) need the same entry to mean the same DB position everywhere.
+// So every bucket's entries are put into position order afterwards: one workgroup per (set, bucket), a bitonic sort of
+// (position id << 16 | key) in LDS, keys / maps rewritten.  Buckets of more than kCanonMax entries (a DB of gigabases) are left as
+// they are and counted: the index then refuses the partial-count mode.
+constexpr int kCanonMax = 8192, kCanonThreads = 1024;
+__global__ __launch_bounds__(kCanonThreads) void eref_probe_index_canon_kernel(IndexBuild ib, const unsigned long long *__restrict__ count,
+                                                                                 unsigned int *__restrict__ not_canon)
+{
+    __shared__ unsigned long long e[kCanonMax];
+    const uint32_t set = blockIdx.y, b = blockIdx.x;
+    const unsigned long long n = count[static_cast<size_t>(set) * kIndexGroups + b];
+    if (n <= 1) return;
+    if (n > kCanonMax) { if (threadIdx.x == 0) atomicAdd(not_canon, 1u); return; }
+    const unsigned long long f0 = ib.first[static_cast<size_t>(set) * (kIndexGroups + 1) + b];
+    uint32_t N = 2;
+    while (N < n) N <<= 1;
+    for (uint32_t i = threadIdx.x; i < N; i += kCanonThreads)
+        e[i] = i < n ? (static_cast<unsigned long long>(ib.epos[set][f0 + i]) << 16) | ib.keys16[set][f0 + i] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < N; i += kCanonThreads) {
+                const uint32_t p = i ^ j;
+                if (p > i) {
+                    const unsigned long long a = e[i], c = e[p];
+                    if (((i & k) == 0) == (a > c)) { e[i] = c; e[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < n; i += kCanonThreads) {
+        const unsigned long long v = e[i];
+        const uint32_t posid = static_cast<uint32_t>(v >> 16);
+        ib.keys16[set][f0 + i] = static_cast<uint16_t>(v);
+        if (set == kSentinelSet) ib.pos_s[f0 + i] = posid / kSentinelStride;
+        else ib.eix[set][posid] = static_cast<uint32_t>(f0 + i);
     }
 }
 
@@ -2196,6 +2239,7 @@ struct palace_eref_probe_index {
     size_t entry_hits_bytes = 0;              // bytes of the four sets' hit-bit parts together (without the sentinel bytes); counts: twice that
     size_t set_at[palace::kSets] = {0, 0, 0, 0};    // where a set's part starts in the hit-bit block
     uint8_t *hits_block = nullptr, *counts_block = nullptr;       // the index's own allocations (the pointers above may be re-pointed at a caller's)
+    bool canonical = false;                   // every bucket's entries are in position order: two builds of one DB are the same index (eref_probe_index_canon_kernel)
     size_t ehits_bytes[palace::kSets] = {0, 0, 0, 0};                  // bytes of a set's hit bits (multiple of 16; the tail stays zero)
     size_t hit_bytes_size = 0;                // position ids run over [0, hit_bytes_size)
 };
@@ -2218,6 +2262,8 @@ static int probe_index_launch_fused(palace_ctx *ctx, const palace_eref_probe_ind
     // (buckets without keys leave their bytes alone)
     if (mode == 2) {
         PALACE_REQUIRE(ix->ecnt_own[0], "the probe index has no count block (palace_eref_entry_layout / _buffers_attach)");
+        PALACE_REQUIRE(ix->canonical, "the probe index's entries are not in position order (a bucket of more than 8192 entries, or no room for the ordering pass): "
+                                      "ranks could not add their partial counts entry by entry");
         PALACE_HIP_TRY(hipMemsetAsync(ix->ecnt_own[0], 0, 2 * ix->entry_hits_bytes, ctx->stream));
     } else if (all_sets && ix->ehits_own[0] == ix->hits_block) {
         PALACE_HIP_TRY(hipMemsetAsync(ix->hits_block, 0, ix->ehits_own_bytes, ctx->stream));     // hit bits and sentinel bytes: one block
@@ -2695,9 +2741,11 @@ int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const
     palace_eref_probe_index *ix = new palace_eref_probe_index();
     ix->n_refs = n_refs; ix->total_bases = total_bases; ix->masks = ctx->masks;
     unsigned long long *count = nullptr;                  // a counter per fine bucket, only during the build
+    uint32_t *epos[kSets] = {nullptr, nullptr, nullptr, nullptr};
     auto done = [&](int rc) {
         (void)hipStreamSynchronize(ctx->stream);
         if (count) (void)hipFree(count);
+        for (uint32_t *p : epos) if (p) (void)hipFree(p);
         if (rc) palace_eref_probe_index_free(ctx, ix); else *out = ix;
         return rc;
     };
@@ -2761,9 +2809,25 @@ int palace_eref_probe_index_build(palace_ctx *ctx, const uint8_t *d_bases, const
     }
     TRY_OR_DONE(hipMemsetAsync(count, 0, count_bytes, ctx->stream));
     ib.first = ix->first;
+    for (int k = 0; k < kSets; k++) {                      // entry -> position id, for the ordering pass only (4 B per entry: 2.6 GB for a 200 Mb DB)
+        if (hipMalloc(reinterpret_cast<void **>(&epos[k]), (ix->n_entries[k] + 8) * 4) != hipSuccess) { epos[k] = nullptr; (void)hipGetLastError(); }
+        ib.epos[k] = epos[k];
+    }
+    const bool can_order = epos[0] && epos[1] && epos[2] && epos[3];
+    if (!can_order) for (int k = 0; k < kSets; k++) ib.epos[k] = nullptr;
     hipLaunchKernelGGL(eref_probe_index_kernel<1>, dim3(static_cast<unsigned>(b.max_tiles)), dim3(256), 0, ctx->stream,
                        d_bases, d_offsets, n_refs, b.tile_pre, b.word_pre, ctx->masks, ib);
     TRY_OR_DONE(hipGetLastError());
+    if (can_order) {
+        TRY_OR_DONE(hipMemsetAsync(ctx->d_small, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(eref_probe_index_canon_kernel, dim3(kIndexGroups, kSets), dim3(kCanonThreads), 0, ctx->stream, ib, count,
+                           reinterpret_cast<unsigned int *>(ctx->d_small));
+        TRY_OR_DONE(hipGetLastError());
+        unsigned int not_canon = 1;
+        TRY_OR_DONE(hipMemcpyAsync(&not_canon, ctx->d_small, 4, hipMemcpyDeviceToHost, ctx->stream));
+        TRY_OR_DONE(hipStreamSynchronize(ctx->stream));
+        ix->canonical = not_canon == 0;
+    }
 #undef TRY_OR_DONE
     return done(PALACE_OK);
 }

@@ -57,10 +57,13 @@ def key_buckets_of(rank: int, world: int):
 # share twice, rewriting the other ranks' slices.
 MODEL = dict(reads_measured=6_666_666, count_all_ms=8.2, key_fixed_ms=2.35, key_shared_ms=5.95, three_planes_factor=1.03,
              exchange_passes_ms=1.1, repack_ms=0.25, collective_latency_ms=0.05, link_gbs=50.0, plane_bytes=1 << 29,
-             sparse_keys_per_read=3.6, sparse_pack_ms=0.1, sparse_unpack_ms=0.15)
+             sparse_keys_per_read=3.6, sparse_pack_ms=0.1, sparse_unpack_ms=0.15,
+             # end of round 5 (shard_counts): the count launch with every entry set probed inside (8.3 ms, of which ~0.25 ms is the DB's
+             # 1.3 GB of entries -- read by every rank whatever its share of the reads), the hit-bit block of the 200 Mb DB, the sum pass
+             count_fused_ms=8.05, entry_probe_fixed_ms=0.25, entry_hits_bytes=81.5e6, entry_sum_ms=0.05)
 
 
-def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None, sparse: bool = True) -> dict:
+def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None, sparse: bool = True, entry_counts: bool = False) -> dict:
     """Modelled milliseconds of eref Phase A (count launch + what it takes to have the '>= 3' plane complete on every rank) per
     step for the three schemes, and the cheapest.  n_reads: reads of the whole sample (both FASTQ sides).
       replicate    every rank counts all reads, nothing moves
@@ -83,6 +86,12 @@ def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None, spars
             out["key_split"] = (m["key_fixed_ms"] + m["key_shared_ms"] / W) * x + gather_ks
         out["shard_reads"] = (m["count_all_ms"] * m["three_planes_factor"] * x / W + per_link_ms(2 * m["plane_bytes"] / W)
                               + m["exchange_passes_ms"] + gather)
+        if entry_counts:
+            # reads sharded, partial counts of the DB's entries exchanged instead of planes: every rank probes the whole DB's entries
+            # (fixed), sends (W - 1) / W of its count block -- one share per link --, sums its share, gathers the hit bits
+            cb = 2.0 * m["entry_hits_bytes"]
+            out["shard_counts"] = (m["count_fused_ms"] * x / W + m["entry_probe_fixed_ms"] + per_link_ms(cb / W) + m["entry_sum_ms"]
+                                   + per_link_ms(m["entry_hits_bytes"] / W))
     choice = min(out, key=out.get)
     return dict(ms={k: round(v, 2) for k, v in out.items()}, choice=choice, link_gbs=m["link_gbs"], n_reads=int(n_reads), world=W, sparse_gather=bool(sparse),
                 note="modelled from 1-GPU kernel times and per-link xGMI arithmetic; no N > 1 hardware measurement behind it")
@@ -95,8 +104,13 @@ def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None, spars
 # Round 5: with the decomposition's phases on 2048 workgroups (the library's default; the one-GPU bench keeps 256, where the step is
 # stream A's length and the shorter, denser burst costs the count launch more) stage 04 takes 2.75 ms beside a count launch at 1M
 # contigs, 0.8 ms alone -- on N GPUs rank 0's stream B is the longer stream once Phase A is sharded, so it runs wide there.
-STEP = dict(reset_ms=0.1, phase_b_fixed_ms=0.15, phase_b_ms=0.92, classify_ms=0.45, resolve_ms=0.37, small_collective_ms=0.1,
+STEP = dict(reset_ms=0.1, phase_b_fixed_ms=0.15, phase_b_ms=0.92, phase_b_counts_fixed_ms=0.2, phase_b_counts_ms=0.55, phase_b_counts_dense_fixed_ms=1.3, phase_b_counts_dense_ms=2.8, classify_ms=0.45, resolve_ms=0.37, small_collective_ms=0.1,
             stage04_alone_ms=(0.5, 0.3), stage04_beside_count_ms=(1.0, 3.4), stage04_beside_count_wide_ms=(0.6, 2.15))   # (fixed, per 1M contigs)
+
+
+def xr_dense(n_reads: int) -> bool:
+    """more key instances than 0.9 x 2^32 table slots: the scan takes its two-stage pruning (eref.hip, palace_eref_scan_refs_indexed)"""
+    return 3.0 * n_reads * 119 > 0.9 * 4294967296.0
 
 
 def step_model(n_contigs: int, n_reads: int, world: int, scheme: str | None = None, rank0_counts: bool = True, link_gbs: float | None = None) -> dict:
@@ -105,15 +119,22 @@ def step_model(n_contigs: int, n_reads: int, world: int, scheme: str | None = No
     gather, resolve, depth reduce, stage 04); the step is the longer of the two.  rank0_counts=False: the reads are sharded over
     ranks 1 .. W-1 only (scheme shard_reads), so that stage 04 has rank 0's device to itself."""
     W = max(1, world)
-    pa = phase_a_model(n_reads, W, link_gbs)
+    pa = phase_a_model(n_reads, W, link_gbs, entry_counts=scheme == "shard_counts")
     scheme = scheme or pa["choice"]
     a_phase = pa["ms"].get(scheme, pa["ms"]["replicate"])            # (a scheme forced where the model has none for it: one rank, W not dividing 64)
     if not rank0_counts and scheme == "shard_reads" and W > 2:
         m, x = MODEL, n_reads / MODEL["reads_measured"]
         a_phase += m["count_all_ms"] * m["three_planes_factor"] * x * (1.0 / (W - 1) - 1.0 / W)
+    if not rank0_counts and scheme == "shard_counts" and W > 2:
+        m, x = MODEL, n_reads / MODEL["reads_measured"]
+        a_phase += m["count_fused_ms"] * x * (1.0 / (W - 1) - 1.0 / W)
     xc, xr, t = n_contigs / 1e6, n_reads / MODEL["reads_measured"], STEP
     coll = t["small_collective_ms"] if W > 1 else 0.0
-    stream_a = t["reset_ms"] + a_phase + t["phase_b_fixed_ms"] + t["phase_b_ms"] / W + coll
+    if scheme == "shard_counts":     # no reset (no plane is written), no probe kernel: the sentinel scatter over the whole DB + need / gather / window on 1 / W of the refs
+        dense = xr_dense(n_reads)        # (a table most of whose slots are taken: half of the DB's sentinels hit and are scattered on EVERY rank, every ref is gathered)
+        stream_a = a_phase + t["phase_b_counts_dense_fixed_ms" if dense else "phase_b_counts_fixed_ms"] + t["phase_b_counts_dense_ms" if dense else "phase_b_counts_ms"] / W + coll
+    else:
+        stream_a = t["reset_ms"] + a_phase + t["phase_b_fixed_ms"] + t["phase_b_ms"] / W + coll
     s04 = t["stage04_beside_count_ms"] if W == 1 else t["stage04_beside_count_wide_ms"] if rank0_counts else t["stage04_alone_ms"]
     stream_b = t["classify_ms"] * xr / W + coll + t["resolve_ms"] * xr + coll + s04[0] + s04[1] * xc
     return dict(scheme=scheme, rank0_counts=bool(rank0_counts), stream_a_ms=round(stream_a, 2), stream_b_rank0_ms=round(stream_b, 2),
@@ -132,6 +153,7 @@ class Exchange:
     def __init__(self, torch, dist, rank: int, world: int):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
         self._recv = None
+        self._recv_counts = None
 
     # ---- eref count table ------------------------------------------------------------------------
     def merge_planes(self, planes, merge_fn, pack_fn=None, final_gather=None):
@@ -166,6 +188,24 @@ class Exchange:
             return
         mine = planes[2][self.rank * S:(self.rank + 1) * S].clone()
         dist.all_gather_into_tensor(planes[2], mine)
+
+    def merge_entry_counts(self, counts, hits, sum_fn):
+        """The ranks counted shares of the READS and hold partial counts of the DB's probe-index entries (include/palace_hip.h,
+        palace_eref_entry_layout): counts = this rank's block, 1-D uint8 of B bytes (16 bits per vector of eight entries, two bits
+        per entry; B % (512 * world) == 0), hits = the hit-bit block, 1-D uint8 of B / 2 bytes.  One all_to_all of B / world per
+        peer; sum_fn(parts, n_parts, part_stride, off, nbytes) sums the world parts of THIS rank's share of the block (bytes
+        [off, off + nbytes); part p at parts + p * part_stride) into its share of `hits` (the HIP library in production); one
+        all_gather of the shares.  On return `hits` is whole on every rank.  No plane crosses a link."""
+        torch, dist, W = self.torch, self.dist, self.world
+        B = counts.numel()
+        assert B % (512 * W) == 0 and hits.numel() * 2 == B
+        S = B // W
+        if self._recv_counts is None or self._recv_counts.numel() != B:
+            self._recv_counts = torch.empty(B, dtype=torch.uint8, device=counts.device)
+        dist.all_to_all_single(self._recv_counts, counts)
+        sum_fn(self._recv_counts, W, S, self.rank * S, S)
+        mine = hits[self.rank * S // 2:(self.rank + 1) * S // 2].clone()
+        dist.all_gather_into_tensor(hits, mine)
 
     def gather_key_buckets(self, plane):
         """plane: 1-D uint8 tensor of 2^29 bytes (the '>= 3' plane) of which this rank holds the 4 MiB slices of its buckets

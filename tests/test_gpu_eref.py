@@ -370,22 +370,24 @@ def test_partial_entry_counts_of_read_shares_sum_to_the_hits_of_the_whole_sample
     want = [orc.scan_ref(orc.index_ref(s_, cc), len(s_), t, 0.9, 0.85)[1:3] for s_ in refs]
     t.free()
     assert sum(1 for a, b in want if b > 0) >= 2
-    ix = None
+    ix = ix2 = None
     L = capi.lib()
     try:
         ctx.eref_set_coder(hdr)
         ix = ctx.eref_probe_index_build(db, do, rs_refs.n, len(rs_refs.bases))
+        ix2 = ctx.eref_probe_index_build(db, do, rs_refs.n, len(rs_refs.bases))   # a second build of the same DB (another rank's): the same entries in the same order
         ctx.eref_set_count_mode(2, cap)
         one_min, three_min = capi.window_minimums(0.9, 0.85)
         rows = ctx.empty((rs_refs.n, 4), np.int32)
         cb, hb = ctx.eref_entry_layout(ix)
+        assert ctx.eref_entry_layout(ix2) == (cb, hb)
         assert cb == 2 * hb and hb % (256 * 840) == 0
         for W, own_hits in ((1, False), (3, True), (8, False)):
             counts_buf = ctx.empty((cb,), np.uint8)                      # (caller-owned, as a host's collectives need it: read out below)
             hits_buf = ctx.empty((hb,), np.uint8) if own_hits else None
             ctx.eref_entry_buffers_attach(ix, counts_buf.ptr, hits_buf.ptr if own_hits else None)
+            ctx.eref_entry_buffers_attach(ix2, counts_buf.ptr, None)
             parts = ctx.empty((W, cb), np.uint8)
-            ctx.eref_attach_probe_index(ix)
             ctx.eref_set_option("final_count", 1)
             ctx.eref_set_option("probe_all_sets", 2)
             n_counting = max(1, W - 1)                                   # W > 1: the last "rank" takes no reads (rank 0 of a large sample does not)
@@ -396,7 +398,9 @@ def test_partial_entry_counts_of_read_shares_sum_to_the_hits_of_the_whole_sample
                     capi._check(L.palace_memset(ctx.h, ctypes.c_void_p(parts.ptr + r * cb), 0, cb), "memset")
                     continue
                 sb, so = ctx.upload(share.bases), ctx.upload(share.offsets)
+                ctx.eref_attach_probe_index(ix2 if r % 2 else ix)        # (odd "ranks" count through their own build of the index)
                 ctx.eref_count_reads(sb, so, share.n)
+                ctx.eref_attach_probe_index(ix)
                 with pytest.raises(capi.PalaceError):                    # partial counts are nothing to scan from
                     ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), one_min, three_min, rows)
                 ctx.d2d(parts.ptr + r * cb, counts_buf.ptr, cb)
@@ -421,6 +425,7 @@ def test_partial_entry_counts_of_read_shares_sum_to_the_hits_of_the_whole_sample
             ctx.eref_set_option("scan_ref_hi", 0)
             ctx.eref_table_reset()
             ctx.eref_entry_buffers_attach(ix, None, None)
+            ctx.eref_entry_buffers_attach(ix2, None, None)
             parts.free(); counts_buf.free()
             if own_hits:
                 hits_buf.free()
@@ -433,6 +438,8 @@ def test_partial_entry_counts_of_read_shares_sum_to_the_hits_of_the_whole_sample
         ctx.eref_set_count_mode(0, 0)
         if ix is not None:
             ctx.eref_probe_index_free(ix)
+        if ix2 is not None:
+            ctx.eref_probe_index_free(ix2)
         ctx.eref_table_reset()
         db.free(); do.free()
 

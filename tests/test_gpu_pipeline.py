@@ -68,11 +68,13 @@ def test_bench_exchange_path_rehearsal():
 
 
 @pytest.mark.parametrize("world,port,scheme,rank0", [(2, 29521, "replicate", "auto"), (4, 29522, "shard_reads", "1"), (4, 29525, "shard_reads", "0"),
-                                                    (4, 29523, "key_split", "auto"), (2, 29524, "auto", "auto")])
+                                                    (4, 29523, "key_split", "auto"), (2, 29524, "auto", "auto"),
+                                                    (4, 29526, "shard_counts", "0"), (2, 29527, "shard_counts", "auto")])
 def test_bench_multi_rank_rehearsal_on_one_gpu(world, port, scheme, rank0):
     """The N-rank step with all ranks on GPU 0 and the collectives over gloo (RCCL refuses two ranks on one device), under each
     Phase-A scheme (replicate: every rank counts all reads; shard_reads: reads sharded, count-table exchange + merge; key_split:
-    the key space split, all-gather of the plane slices; auto: whatever the cost model picks for this size): the same refs and
+    the key space split, all-gather of the plane slices; shard_counts: reads sharded, partial counts of the DB's probe-index
+    entries exchanged and summed, no plane moved; auto: whatever the cost model picks for this size): the same refs and
     the same graph as the single-process run, from the exact candidate gather (first step) and from the padded one (later
     steps); and the weak record (every rank the whole one-GPU step) carries the same digest."""
     size = ["--contigs", "20000", "--refs", "200", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--soak-seconds", "0"]
@@ -91,7 +93,8 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(world, port, scheme, rank0):
     assert pm["choice_in_force"] == scheme and pm["step"]["scheme"] == scheme and pm["step"]["step_ms"] > 0
     if rank0 in ("0", "1"):
         assert pm["rank0_counts"] == (rank0 == "1") and ("rank 0 takes no reads" in b["config"]["parallelism"]) == (rank0 == "0")
-    assert ("reads/records/refs sharded" in b["config"]["parallelism"]) == (scheme == "shard_reads")
+    assert ("reads/records/refs sharded" in b["config"]["parallelism"]) == (scheme in ("shard_reads", "shard_counts"))
+    assert ("partial counts of the DB's probe-index entries" in b["config"]["parallelism"]) == (scheme == "shard_counts")
     assert ("key space sharded" in b["config"]["parallelism"]) == (scheme == "key_split")
     # the plane crossed the "links" as counts + 16-bit keys in every step but the first (which sizes the room)
     assert (pm["sparse_gather"]["steps"] >= 2 and pm["sparse_gather"]["cap_keys_per_rank"] > 0) == (scheme in ("key_split", "shard_reads"))

@@ -138,7 +138,26 @@ def worker(rank, world, port, q):
         ok_sparse = bool(np.array_equal(got_plane, dense)) and int(sums[rank]) == need and int(sums.max()) <= roomy
         tight = gather(roomy // 2).sum(dim=1)                                # too little room: the counts say so (the caller redoes the step)
         ok_sparse &= int(tight.max()) > roomy // 2
-        q.put((rank, ok_planes, ok_rows, ok_var, ok_sum, ok_keys and ok_sparse))
+        # reads sharded, partial COUNTS of the DB's probe-index entries exchanged instead of planes (merge_entry_counts): two bits per
+        # entry, 16 bits per vector of eight; a numpy statement of palace_eref_entry_hits_from_counts stands in for the library's sum
+        n_vec = 256 * world * 3                                             # u16 per vector: the block is 2 * n_vec bytes, a multiple of 512 * world
+        per_rank = [rng.integers(0, 4, size=(n_vec, 8)) * (rng.random((n_vec, 8)) < 0.4) for _ in range(world)]    # every rank draws every rank's counts
+        if world > 2:
+            per_rank[0][:] = 0                                              # (a rank that takes no reads)
+        def pack16(c):
+            return (c.astype(np.uint16) << (2 * np.arange(8, dtype=np.uint16))).sum(axis=1).astype("<u2")
+        counts_t = torch.from_numpy(pack16(per_rank[rank]).view(np.uint8).copy())
+        hits_t = torch.zeros(n_vec, dtype=torch.uint8)
+        def np_sum(parts, n_parts, stride, off, nbytes):
+            a = parts.numpy().view("<u2").reshape(n_parts, stride // 2)[:, :nbytes // 2].astype(np.uint32)
+            byte = np.zeros(nbytes // 2, dtype=np.uint8)
+            for e in range(8):
+                byte |= ((((a >> (2 * e)) & 3).sum(axis=0) >= 3).astype(np.uint8) << e)
+            hits_t[off // 2:off // 2 + nbytes // 2] = torch.from_numpy(byte)
+        ex.merge_entry_counts(counts_t, hits_t, np_sum)
+        want_hits = np.packbits((np.minimum(3, sum(per_rank)) >= 3).astype(np.uint8), axis=1, bitorder="little").reshape(-1)
+        ok_counts = bool(np.array_equal(hits_t.numpy(), want_hits)) and int(want_hits.sum()) > 0
+        q.put((rank, ok_planes, ok_rows, ok_var, ok_sum, ok_keys and ok_sparse and ok_counts))
     finally:
         dist.destroy_process_group()
 
@@ -196,6 +215,20 @@ def test_step_model_gives_rank_0_to_stage_04_for_large_samples():
     one = multigpu.best_step(1_000_000, 6_666_666, 1)
     assert one["scheme"] == "replicate" and 9 < one["step_ms"] < 12
     assert multigpu.best_step(5_000_000, 33_333_333, 8)["step_ms"] < multigpu.best_step(5_000_000, 33_333_333, 4)["step_ms"] < one["step_ms"] * 5
+
+
+def test_entry_count_scheme_in_the_step_model():
+    """shard_counts (reads sharded, partial counts of the DB's entries exchanged): opt-in -- best_step never picks it -- and, by the
+    model, shorter than the plane exchange on 8 GPUs for both sample sizes, with rank 0 left to stage 04"""
+    for nc, nr in ((1_000_000, 6_666_666), (5_000_000, 33_333_333)):
+        assert multigpu.best_step(nc, nr, 8)["scheme"] != "shard_counts"
+        new = min((multigpu.step_model(nc, nr, 8, "shard_counts", r0) for r0 in (True, False)), key=lambda c: c["step_ms"])
+        old = multigpu.best_step(nc, nr, 8)
+        assert new["rank0_counts"] is False and new["step_ms"] < old["step_ms"]
+        one = multigpu.step_model(nc, nr, 1)["step_ms"]
+        assert 3.0 < one / new["step_ms"] < 6.5
+    assert "shard_counts" in multigpu.phase_a_model(6_666_666, 8, entry_counts=True)["ms"]
+    assert "shard_counts" not in multigpu.phase_a_model(6_666_666, 8)["ms"]
 
 
 def test_split_by_weight_properties():
