@@ -25,3 +25,13 @@ for name, nc, nr in samples + [("long contigs (100k, reads of the 1M config)", 1
         b = mg.best_step(nc, nr, W) if W > 1 else dict(one, scheme="—")
         sch = b["scheme"] + ("" if b.get("rank0_counts", True) or W == 1 else ", rank 0 idle in Phase A")
         print(f"| {name if W == 1 else ''} | {W} | {sch} | {b['stream_a_ms']:.1f} | {b['stream_b_rank0_ms']:.1f} | {b['step_ms']:.1f} | {one['step_ms'] / b['step_ms']:.2f} × |")
+print()
+print("opt-in scheme shard_counts (reads sharded, partial counts of the DB's probe-index entries exchanged, no plane moved):")
+print("| sample | W | rank 0 | stream A | stream B (rank 0) | step | vs one GPU | the picked scheme above |\n|---|---|---|---|---|---|---|---|")
+for name, nc, nr in samples + [("long contigs (100k, reads of the 1M config)", 100_000, reads_of(1_000_000))]:
+    one = mg.step_model(nc, nr, 1)
+    for W in (2, 4, 8):
+        b = min((mg.step_model(nc, nr, W, "shard_counts", r0) for r0 in (True, False)), key=lambda c: c["step_ms"])
+        old = mg.best_step(nc, nr, W)
+        print(f"| {name if W == 2 else ''} | {W} | {'counts' if b['rank0_counts'] else 'idle in Phase A'} | {b['stream_a_ms']:.1f} | {b['stream_b_rank0_ms']:.1f} | {b['step_ms']:.1f} | "
+              f"{one['step_ms'] / b['step_ms']:.2f} × | {one['step_ms'] / old['step_ms']:.2f} × |")
