@@ -219,6 +219,7 @@ int palace_eref_attach_probe_index(palace_ctx *ctx, const palace_eref_probe_inde
  * buffers_attach: the caller's device buffers (what its collectives address; NULL = the index's own) stand in for the two blocks. */
 int palace_eref_entry_layout(const palace_eref_probe_index *ix, size_t *counts_bytes, size_t *hits_bytes);
 int palace_eref_entry_buffers_attach(palace_ctx *ctx, palace_eref_probe_index *ix, void *d_counts, void *d_hits);
+int palace_eref_entry_buffers(const palace_eref_probe_index *ix, void **d_counts, void **d_hits);     /* where the two blocks lie now (counts: NULL before a first attach) */
 int palace_eref_entry_hits_from_counts(palace_ctx *ctx, const palace_eref_probe_index *ix, const void *d_parts, int n_parts, size_t part_stride,
                                        size_t off, size_t bytes);
 int palace_eref_entry_hits_complete(palace_ctx *ctx, const palace_eref_probe_index *ix, int64_t keys_counted);

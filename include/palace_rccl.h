@@ -44,6 +44,15 @@ int palace_eref_key_share_gather(palace_ctx *ctx, void *comm, int rank, int worl
  * the next sample that much room + a margin.  A first call with cap_keys = 0 only sizes. */
 int palace_eref_key_share_gather_sparse(palace_ctx *ctx, void *comm, int rank, int world, int64_t cap_keys, unsigned long long *h_max_keys);
 
+/* The reads sharded, partial COUNTS of the DB's probe-index entries exchanged instead of planes (palace_hip.h: palace_eref_entry_layout):
+ * after a final count with option "probe_all_sets" 2 and the whole DB's index attached (a rank without reads: no count, its block zero),
+ * every rank sends each peer that peer's share of its count block, sums the `world` parts of its own share into hit bits, and the
+ * shares of the hit-bit block are all-gathered; the block is then declared whole (keys_counted: key instances of ALL ranks, -1 =
+ * unknown), and palace_eref_scan_refs_indexed starts from it (options "scan_ref_lo" / "scan_ref_hi": this rank's refs).  The blocks are
+ * the index's own unless palace_eref_entry_buffers_attach put the caller's in their place; world must divide the count block into
+ * 512-byte multiples (1 .. 8 always do). */
+int palace_eref_entry_counts_exchange(palace_ctx *ctx, palace_eref_probe_index *ix, void *comm, int rank, int world, int64_t keys_counted);
+
 /* Phase B rows: every rank scanned the refs [ref_lo[r], ref_hi[r]) and holds their rows (4 x int32 per ref) in d_rows;
  * afterwards every rank holds all n_refs rows.  ref_lo / ref_hi: host arrays of `world` entries, the same on every rank. */
 int palace_eref_rows_allgather(palace_ctx *ctx, void *comm, int rank, int world, int32_t *d_rows, int64_t n_refs,

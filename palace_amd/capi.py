@@ -102,6 +102,7 @@ _SIGS = {
     "palace_eref_attach_probe_index": [C.c_void_p, C.c_void_p],
     "palace_eref_entry_layout": [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "palace_eref_entry_buffers_attach": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "palace_eref_entry_buffers": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
     "palace_eref_entry_hits_from_counts": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t],
     "palace_eref_entry_hits_complete": [C.c_void_p, C.c_void_p, C.c_int64],
     "palace_eref_probe_index_free": [C.c_void_p, C.c_void_p],

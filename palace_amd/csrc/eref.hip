@@ -2999,6 +2999,14 @@ int palace_eref_entry_buffers_attach(palace_ctx *ctx, palace_eref_probe_index *i
     return PALACE_OK;
 }
 
+int palace_eref_entry_buffers(const palace_eref_probe_index *ix, void **d_counts, void **d_hits)
+{
+    PALACE_REQUIRE(ix && d_counts && d_hits, "null argument");
+    *d_counts = ix->ecnt_own[0];
+    *d_hits = ix->ehits_own[0];
+    return PALACE_OK;
+}
+
 int palace_eref_entry_hits_from_counts(palace_ctx *ctx, const palace_eref_probe_index *ix, const void *d_parts, int n_parts, size_t part_stride,
                                        size_t off, size_t bytes)
 {

@@ -134,6 +134,38 @@ int palace_eref_key_share_gather_sparse(palace_ctx *ctx, void *comm_, int rank, 
     return PALACE_OK;
 }
 
+// ---- the reads sharded, partial counts of the DB's entries exchanged (no plane moves) ----
+int palace_eref_entry_counts_exchange(palace_ctx *ctx, palace_eref_probe_index *ix, void *comm_, int rank, int world, int64_t keys_counted)
+{
+    PALACE_REQUIRE(ctx && ix && comm_ && world >= 1 && rank >= 0 && rank < world, "bad argument");
+    ncclComm_t comm = static_cast<ncclComm_t>(comm_);
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    size_t cb = 0, hb = 0;
+    int rc = palace_eref_entry_layout(ix, &cb, &hb);
+    if (rc) return rc;
+    PALACE_REQUIRE(cb % (512 * static_cast<size_t>(world)) == 0, "world must divide the count block into 512-byte multiples");
+    void *cnt = nullptr, *hits = nullptr;
+    rc = palace_eref_entry_buffers(ix, &cnt, &hits);
+    if (rc) return rc;
+    PALACE_REQUIRE(cnt && hits, "the index has no count block yet (palace_eref_entry_buffers_attach before the count)");
+    const size_t S = cb / static_cast<size_t>(world);
+    rc = ensure_workspace(ctx, cb);                          // [world][S]: every peer's counts of this rank's share
+    if (rc) return rc;
+    char *recv = static_cast<char *>(ctx->ws.ptr);
+    const char *send = static_cast<const char *>(cnt);
+    PALACE_NCCL_TRY(ncclGroupStart());
+    for (int peer = 0; peer < world; peer++) {
+        PALACE_NCCL_TRY(ncclSend(send + static_cast<size_t>(peer) * S, S, ncclUint8, peer, comm, ctx->stream));
+        PALACE_NCCL_TRY(ncclRecv(recv + static_cast<size_t>(peer) * S, S, ncclUint8, peer, comm, ctx->stream));
+    }
+    PALACE_NCCL_TRY(ncclGroupEnd());
+    rc = palace_eref_entry_hits_from_counts(ctx, ix, recv, world, S, static_cast<size_t>(rank) * S, S);
+    if (rc) return rc;
+    char *h = static_cast<char *>(hits);
+    PALACE_NCCL_TRY(ncclAllGather(h + static_cast<size_t>(rank) * (S / 2), h, S / 2, ncclUint8, comm, ctx->stream));
+    return palace_eref_entry_hits_complete(ctx, ix, keys_counted);
+}
+
 int palace_eref_rows_allgather(palace_ctx *ctx, void *comm_, int rank, int world, int32_t *d_rows, int64_t n_refs,
                                const int64_t *ref_lo, const int64_t *ref_hi)
 {

@@ -82,6 +82,40 @@ int main(int argc, char **argv)
     std::vector<int32_t> back(20);
     CK(palace_d2h(ctx, back.data(), d_rows, 80));
     if (back != rows) { std::fprintf(stderr, "exchange_selftest: rows changed\n"); return 1; }
+    // the reads sharded, partial counts of the DB's entries exchanged: the pool as a one-ref DB, the reads counted with every entry of
+    // its probe index tested (option probe_all_sets 2), a one-rank exchange (the sum of one part), the indexed scan -- against the
+    // plain count and scan of the same reads
+    {
+        void *d_ref = nullptr, *d_roff = nullptr, *d_r1 = nullptr, *d_r2 = nullptr;
+        const int64_t roff[2] = {0, static_cast<int64_t>(pool.size())};
+        CK(palace_malloc(ctx, pool.size(), &d_ref)); CK(palace_malloc(ctx, 16, &d_roff)); CK(palace_malloc(ctx, 16, &d_r1)); CK(palace_malloc(ctx, 16, &d_r2));
+        CK(palace_h2d(ctx, d_ref, pool.data(), pool.size())); CK(palace_h2d(ctx, d_roff, roff, 16));
+        CK(palace_eref_set_count_mode(ctx, 2, 0));                                      // (the binned path, although the input is small)
+        CK(palace_eref_table_reset(ctx));
+        CK(palace_eref_count_reads(ctx, static_cast<const uint8_t *>(d_bases), static_cast<const int64_t *>(d_off), n_reads, nullptr, n_reads * read_len));
+        CK(palace_eref_scan_refs(ctx, static_cast<const uint8_t *>(d_ref), static_cast<const int64_t *>(d_roff), 1, roff[1], 450, 425, static_cast<int32_t *>(d_r1)));
+        palace_eref_probe_index *ix = nullptr;
+        CK(palace_eref_probe_index_build(ctx, static_cast<const uint8_t *>(d_ref), static_cast<const int64_t *>(d_roff), 1, roff[1], &ix));
+        CK(palace_eref_entry_buffers_attach(ctx, ix, nullptr, nullptr));                // the index's own blocks
+        CK(palace_eref_attach_probe_index(ctx, ix));
+        CK(palace_eref_set_option(ctx, "final_count", 1));
+        CK(palace_eref_set_option(ctx, "probe_all_sets", 2));
+        CK(palace_eref_table_reset(ctx));
+        CK(palace_eref_count_reads(ctx, static_cast<const uint8_t *>(d_bases), static_cast<const int64_t *>(d_off), n_reads, nullptr, n_reads * read_len));
+        CK(palace_eref_entry_counts_exchange(ctx, ix, comm, 0, 1, 3 * n_reads * read_len));
+        CK(palace_eref_scan_refs_indexed(ctx, ix, static_cast<const uint8_t *>(d_ref), static_cast<const int64_t *>(d_roff), 1, roff[1], 450, 425, static_cast<int32_t *>(d_r2)));
+        int32_t r1[4], r2[4];
+        CK(palace_d2h(ctx, r1, d_r1, 16)); CK(palace_d2h(ctx, r2, d_r2, 16));
+        if (std::memcmp(r1, r2, 16) != 0 || r1[1] <= 0) {
+            std::fprintf(stderr, "exchange_selftest: entry-count exchange: rows %d %d %d, plain scan %d %d %d\n", r2[0], r2[1], r2[2], r1[0], r1[1], r1[2]);
+            return 1;
+        }
+        CK(palace_eref_set_option(ctx, "probe_all_sets", 0));
+        CK(palace_eref_set_option(ctx, "final_count", 0));
+        CK(palace_eref_attach_probe_index(ctx, nullptr));
+        CK(palace_eref_probe_index_free(ctx, ix));
+        CK(palace_eref_table_reset(ctx));
+    }
     ncclCommDestroy(comm);
     palace_ctx_destroy(ctx);
     std::printf("ok: planes %llu >= %llu >= %llu unchanged by a one-rank exchange\n", (unsigned long long)before[0], (unsigned long long)before[1],

@@ -48,8 +48,8 @@ def test_rccl_library_exports_what_its_header_declares():
     text = open(os.path.join(root, "include", "palace_rccl.h")).read()
     names = sorted(set(re.findall(r"\b(palace_[a-z0-9_]+)\s*\(", text)) - {"palace_eref_table_pack_low", "palace_eref_table_merge_slices_packed"})
     names = [n for n in names if n != "palace_eref_set_key_buckets"]                  # (libpalace_hip.so's, named in a comment)
-    assert names == ["palace_eref_key_share", "palace_eref_key_share_gather", "palace_eref_key_share_gather_sparse", "palace_eref_rows_allgather",
-                     "palace_eref_table_exchange"]
+    assert names == ["palace_eref_entry_counts_exchange", "palace_eref_key_share", "palace_eref_key_share_gather", "palace_eref_key_share_gather_sparse",
+                     "palace_eref_rows_allgather", "palace_eref_table_exchange"]
     capi.lib()                                                   # libpalace_hip.so first: the rccl library links it by name
     lib = ctypes.CDLL(os.path.join(root, "palace_amd", "libpalace_rccl.so"), mode=ctypes.RTLD_GLOBAL)
     for n in names:
