@@ -4,7 +4,6 @@ import ctypes
 import hashlib
 import json
 import os
-import sys
 import time
 
 import numpy as np
