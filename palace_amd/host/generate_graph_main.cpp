@@ -567,6 +567,16 @@ int main(int argc, char **argv)
         const int32_t k1 = static_cast<int32_t>(static_cast<int64_t>(nt) * (part + 1) / seg_text.size());
         txt.reserve(static_cast<size_t>(k1 - k0) * 48);
         for (int32_t k = k0; k < k1; k++) {
+            // (name order is not target order: every line's name, sums and lengths are cache misses in tables of a million entries --
+            // the ones of the line sixteen ahead are asked for now, its name's characters eight ahead)
+            if (k + 16 < k1) {
+                const int32_t t = by_name[k + 16];
+                __builtin_prefetch(&c.target_name[static_cast<size_t>(t)]);
+                __builtin_prefetch(&consumed[static_cast<size_t>(t)]);
+                __builtin_prefetch(&c.target_len[static_cast<size_t>(t)]);
+                __builtin_prefetch(&cn_dev[static_cast<size_t>(t)]);
+            }
+            if (k + 8 < k1) __builtin_prefetch(c.target_name[static_cast<size_t>(by_name[k + 8])].data());
             // std::map keeps one entry per distinct name; a later duplicate overwrites an earlier one (:1033)
             if (k + 1 < nt && rank[by_name[k + 1]] == rank[by_name[k]]) continue;
             int32_t best = -1;
