@@ -623,7 +623,7 @@ def measure(args, E, leg):
                                                                    f"records/refs and the key space sharded over {world} GPUs (RCCL): every GPU counts its 1/{world} of the keys of all reads, the '>= 3' plane is all-gathered" if key_split else
                                                                    f"records/refs sharded over {world} GPUs (RCCL), reads counted on every GPU"),
                        "parallelism_model": model,
-                       "ref_index": "per-DB probe index prebuilt, as the reference's cached <fasta>.k32.index.dat (8 B/position in HBM)"
+                       "ref_index": "per-DB probe index prebuilt, as the reference's cached <fasta>.k32.index.dat (19.5 B/position in HBM: four entry sets of 2-byte entries, three position -> entry maps, sentinel positions)"
                                     + (("; all of its look-ups ride along in the count kernel, the '>= 3' plane is never written" if fused_all else
                                         "; its channel-0 probe rides along in the count kernel") if fused_probe and final_count and not key_split else ""),
                        "refs_reported": reported, "refs_present": int(len(sample["present"])),

@@ -216,13 +216,18 @@ int palace_eref_attach_probe_index(palace_ctx *ctx, const palace_eref_probe_inde
  * min(3, sum of c_r) -- into its share of the hit-bit block, the shares are all-gathered, and entry_hits_complete declares the block
  * whole: palace_eref_scan_refs_indexed then starts from it as from a count that tested every entry itself (options "scan_ref_lo" /
  * "scan_ref_hi": a rank scans its range of the refs).  No plane crosses a link: 162 + 81 MB per 200 Mb of DB instead of 2 x 512 MiB.
- * buffers_attach: the caller's device buffers (what its collectives address; NULL = the index's own) stand in for the two blocks. */
+ * buffers_attach: the caller's device buffers (what its collectives address; NULL = the index's own, zeroed) stand in for the two blocks.
+ * Under option "probe_all_sets" 2 a count call has no other form of result: it takes the binned, fused path whatever the size of the
+ * share (one call per reset, one slab, whole key space, clean table) or fails with PALACE_ESTATE; with n = 0 (a rank without reads) it
+ * zeroes the block.  entry_counts_valid: 1 when such a call of this context stands behind the block `ix` points at, else 0;
+ * entry_hits_complete fails (PALACE_ESTATE) otherwise -- stale counts are never summed silently. */
 int palace_eref_entry_layout(const palace_eref_probe_index *ix, size_t *counts_bytes, size_t *hits_bytes);
 int palace_eref_entry_buffers_attach(palace_ctx *ctx, palace_eref_probe_index *ix, void *d_counts, void *d_hits);
 int palace_eref_entry_buffers(const palace_eref_probe_index *ix, void **d_counts, void **d_hits);     /* where the two blocks lie now (counts: NULL before a first attach) */
 int palace_eref_entry_hits_from_counts(palace_ctx *ctx, const palace_eref_probe_index *ix, const void *d_parts, int n_parts, size_t part_stride,
                                        size_t off, size_t bytes);
 int palace_eref_entry_hits_complete(palace_ctx *ctx, const palace_eref_probe_index *ix, int64_t keys_counted);
+int palace_eref_entry_counts_valid(const palace_ctx *ctx, const palace_eref_probe_index *ix);
 
 
 /* Multi-GPU exchange of the count table (no reference counterpart: the reference shares one

@@ -45,7 +45,8 @@ int palace_eref_key_share_gather(palace_ctx *ctx, void *comm, int rank, int worl
 int palace_eref_key_share_gather_sparse(palace_ctx *ctx, void *comm, int rank, int world, int64_t cap_keys, unsigned long long *h_max_keys);
 
 /* The reads sharded, partial COUNTS of the DB's probe-index entries exchanged instead of planes (palace_hip.h: palace_eref_entry_layout):
- * after a final count with option "probe_all_sets" 2 and the whole DB's index attached (a rank without reads: no count, its block zero),
+ * after a final count with option "probe_all_sets" 2 and the whole DB's index attached (a rank without reads makes the same call with
+ * n = 0, which zeroes its block; a context that made no such call since its last reset is refused: PALACE_ESTATE, before anything is sent),
  * every rank sends each peer that peer's share of its count block, sums the `world` parts of its own share into hit bits, and the
  * shares of the hit-bit block are all-gathered; the block is then declared whole (keys_counted: key instances of ALL ranks, -1 =
  * unknown), and palace_eref_scan_refs_indexed starts from it (options "scan_ref_lo" / "scan_ref_hi": this rank's refs).  The blocks are

@@ -105,6 +105,7 @@ _SIGS = {
     "palace_eref_entry_buffers": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
     "palace_eref_entry_hits_from_counts": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t],
     "palace_eref_entry_hits_complete": [C.c_void_p, C.c_void_p, C.c_int64],
+    "palace_eref_entry_counts_valid": [C.c_void_p, C.c_void_p],
     "palace_eref_probe_index_free": [C.c_void_p, C.c_void_p],
     "palace_eref_scan_refs_indexed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                       C.c_void_p],
@@ -357,6 +358,10 @@ class Ctx:
     def eref_entry_hits_from_counts(self, index, parts_ptr: int, n_parts: int, part_stride: int, off: int, nbytes: int):
         """sum n_parts partial-count arrays over the count block's bytes [off, off + nbytes) into the hit bits of that entry range"""
         _check(lib().palace_eref_entry_hits_from_counts(self.h, index, parts_ptr, n_parts, part_stride, off, nbytes), "palace_eref_entry_hits_from_counts")
+
+    def eref_entry_counts_valid(self, index) -> bool:
+        """a count call of this context (option probe_all_sets 2) stands behind the count block `index` points at"""
+        return bool(lib().palace_eref_entry_counts_valid(self.h, index))
 
     def eref_entry_hits_complete(self, index, keys_counted: int = -1):
         """the hit-bit block of the attached index is whole: the next indexed scan starts from it"""

@@ -82,6 +82,8 @@ struct palace_ctx {
     int probe_all_sets = 0;         // option: a final count with an attached index tests every entry set and writes no plane (2: leaves partial counts)
     bool sent_scattered = false;    // ... and that launch carried the sentinels' hits to position order itself
     int64_t scan_ref_lo = 0, scan_ref_hi = 0;   // options scan_ref_lo / _hi: the indexed scan works on refs [lo, hi) (hi = 0: all)
+    const void *counts_ptr = nullptr;   // probe_all_sets 2: the count block (an index's, or the caller's) that holds this context's partial counts of
+                                    // the sample counted since the last reset -- a fused count wrote them, or a call without reads zeroed them
     bool planeless = false;         // ... and did: the table holds NOTHING (all three planes are zero, as after a reset); Phase B is the attached
                                     // index's hit bits alone, and whatever else reads the table is refused until the next reset
     int mark_before_count = -1;     // option mark_before_count_kernel

@@ -2080,6 +2080,7 @@ int palace_eref_table_reset(palace_ctx *ctx)
     ctx->keys_counted = 0;
     ctx->final_only = false;
     ctx->c0_hits_ix = nullptr;
+    ctx->counts_ptr = nullptr;
     return PALACE_OK;
 }
 
@@ -2159,7 +2160,7 @@ int palace_eref_reserve(palace_ctx *ctx, int64_t total_bases)
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
-    const bool binned = ctx->count_mode == 2 || (ctx->count_mode == 0 && total_bases >= (1ll << 22));
+    const bool binned = ctx->probe_all_sets == 2 || ctx->count_mode == 2 || (ctx->count_mode == 0 && total_bases >= (1ll << 22));
     if (!binned) return PALACE_OK;
     CountPlan pl;
     rc = plan_count(ctx, total_bases, &pl);
@@ -2292,6 +2293,33 @@ static int probe_index_launch_fused(palace_ctx *ctx, const palace_eref_probe_ind
     return PALACE_OK;
 }
 
+// Option probe_all_sets 2 (a rank that counts a share of a sample's reads): a count call has ONE form of result, the partial counts of
+// the attached index's entries in its count block, and only the fused count kernel writes it -- so the call must take the binned path
+// into a clean table, in one slab, over the whole key space, or fail; what it must never do is succeed some other way and leave the
+// block as it was (ADVICE of round 5: the exchange would then add stale counts, and rows come out wrong without an error).
+static int partial_counts_ready(palace_ctx *ctx)
+{
+    const palace_eref_probe_index *ix = ctx->probe_ix;
+    if (!ix || !ctx->want_final) { set_error("option probe_all_sets 2 needs option final_count and an attached probe index"); return PALACE_ESTATE; }
+    if (!probe_index_usable(ctx, ix)) { set_error("probe_all_sets 2: the attached probe index was built with another coder or holds no entries"); return PALACE_ESTATE; }
+    if (!ix->ecnt_own[0]) { set_error("probe_all_sets 2: the probe index has no count block (palace_eref_entry_buffers_attach)"); return PALACE_ESTATE; }
+    const bool whole = (ctx->key_buckets[0] & ctx->key_buckets[1] & ctx->key_buckets[2] & ctx->key_buckets[3]) == ~0u;
+    if (!whole) { set_error("probe_all_sets 2: a share of the reads is counted over the whole key space (palace_eref_set_key_buckets is set)"); return PALACE_ESTATE; }
+    if (!ctx->table_clean || ctx->counts_ptr) { set_error("probe_all_sets 2: one count call per reset (the table is not clean)"); return PALACE_ESTATE; }
+    return PALACE_OK;
+}
+// ... a rank without reads: its counts are zero
+static int partial_counts_zero(palace_ctx *ctx)
+{
+    const palace_eref_probe_index *ix = ctx->probe_ix;
+    PALACE_HIP_TRY(hipSetDevice(ctx->device));
+    PALACE_HIP_TRY(hipMemsetAsync(ix->ecnt_own[0], 0, 2 * ix->entry_hits_bytes, ctx->stream));
+    ctx->counts_ptr = ix->ecnt_own[0];
+    ctx->c0_hits_ix = nullptr;
+    ctx->hits_mask = 0;
+    return PALACE_OK;
+}
+
 static int launch_bin1(palace_ctx *ctx, hipStream_t stream, int ppl, const uint32_t *w0, const uint32_t *w1, const uint32_t *wu, int64_t p_lo,
                        int64_t p_hi, const BinOut &o1)
 {
@@ -2400,6 +2428,7 @@ static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &
                 if (ctx->probe_all_sets == 2) {              // partial counts: nothing to scan from until the ranks' counts are summed
                     ctx->c0_hits_ix = nullptr;
                     ctx->hits_mask = 0;
+                    ctx->counts_ptr = ix->ecnt_own[0];
                 } else {
                     ctx->c0_hits_ix = ix;
                     ctx->hits_mask = ctx->probe_all_sets ? (1u << kSets) - 1 : 1u;
@@ -2407,6 +2436,7 @@ static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &
                 ctx->sent_scattered = ctx->probe_all_sets == 1;
                 ctx->planeless = ctx->probe_all_sets != 0;
             } else {
+                if (ctx->probe_all_sets == 2) { set_error("probe_all_sets 2: the count could not be fused with the probe index"); return PALACE_ESTATE; }
                 hipLaunchKernelGGL((eref_lds_count_kernel<true, true>), dim3(kFine), dim3(kCountThreads), 0, ctx->stream, b.cursor2, b.buf2, pl.caps2,
                                    ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys, no_probe);
             }
@@ -2430,13 +2460,14 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
 {
     PALACE_REQUIRE(ctx && n_reads >= 0, "bad argument");
     if (!ctx->coder_set) { set_error("palace_eref_count_reads: coder not set"); return PALACE_ESTATE; }
-    if (n_reads == 0) return PALACE_OK;
+    const bool partial = ctx->probe_all_sets == 2;       // the call leaves partial entry counts or fails (partial_counts_ready)
+    if (partial) { int rc0 = partial_counts_ready(ctx); if (rc0) return rc0; }
+    if (n_reads == 0) return partial ? partial_counts_zero(ctx) : PALACE_OK;
     PALACE_REQUIRE(d_bases && d_offsets, "null device pointer");
     PALACE_REQUIRE(!ctx->final_only, "the table holds only its \">= 3\" plane (option final_count): reset it first");
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_table(ctx);
     if (rc) return rc;
-    if (ctx->keys_counted >= 0) ctx->keys_counted += 3 * total_bases;
     // total bases bound the number of keys; tiny inputs keep the direct path (a 16 Ki-workgroup launch
     // per call would dominate them), everything else is binned
     if (total_bases < 0) {                                  // caller does not know: read the two end offsets back
@@ -2447,7 +2478,8 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
         total_bases = h_off[1] - h_off[0];
         PALACE_REQUIRE(total_bases >= 0, "offsets not ascending");
     }
-    const bool binned = ctx->count_mode == 2 || (ctx->count_mode == 0 && total_bases >= (1ll << 22));
+    if (ctx->keys_counted >= 0) ctx->keys_counted += 3 * total_bases;
+    const bool binned = partial || ctx->count_mode == 2 || (ctx->count_mode == 0 && total_bases >= (1ll << 22));
     if (!binned) {
         int64_t blocks = (n_reads + 3) / 4;                 // 4 waves (reads) per 256-thread block
         int64_t cap = static_cast<int64_t>(kCUs) * 8 * 8;   // grid-stride beyond 16 Ki blocks
@@ -2463,6 +2495,7 @@ int palace_eref_count_reads(palace_ctx *ctx, const uint8_t *d_bases, const int64
     CountPlan pl;
     rc = plan_count(ctx, total_bases, &pl);
     if (rc) return rc;
+    if (partial && pl.n_slabs != 1) { set_error("probe_all_sets 2: the read share does not fit one slab (%lld positions)", static_cast<long long>(total_bases)); return PALACE_ESTATE; }
     const size_t words_bytes = pl.words_bytes;
     rc = ensure_workspace(ctx, pl.total());
     if (rc) return rc;
@@ -2508,7 +2541,9 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
 {
     PALACE_REQUIRE(ctx && n_positions >= 0 && n_reads_hint >= 0, "bad argument");
     if (!ctx->coder_set) { set_error("palace_eref_count_reads_packed: coder not set"); return PALACE_ESTATE; }
-    if (n_positions == 0) return PALACE_OK;
+    const bool partial = ctx->probe_all_sets == 2;       // the call leaves partial entry counts or fails (partial_counts_ready)
+    if (partial) { int rc0 = partial_counts_ready(ctx); if (rc0) return rc0; }
+    if (n_positions == 0) return partial ? partial_counts_zero(ctx) : PALACE_OK;
     PALACE_REQUIRE(d_p0 && d_p1 && d_u, "null device pointer");
     PALACE_REQUIRE(((reinterpret_cast<uintptr_t>(d_p0) | reinterpret_cast<uintptr_t>(d_p1) | reinterpret_cast<uintptr_t>(d_u)) & 7) == 0,
                    "the streams must be 8-byte aligned");
@@ -2517,7 +2552,7 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
     int rc = ensure_table(ctx);
     if (rc) return rc;
     if (ctx->keys_counted >= 0) ctx->keys_counted += 3 * n_positions;
-    const bool binned = ctx->count_mode == 2 || (ctx->count_mode == 0 && n_positions >= (1ll << 22));
+    const bool binned = partial || ctx->count_mode == 2 || (ctx->count_mode == 0 && n_positions >= (1ll << 22));
     if (!binned) {
         const int64_t blocks = std::min<int64_t>((n_positions + 255) / 256, static_cast<int64_t>(kCUs) * 8 * 8);
         ctx->c0_hits_ix = nullptr;
@@ -2530,6 +2565,7 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
     CountPlan pl;
     rc = plan_count(ctx, n_positions, &pl);
     if (rc) return rc;
+    if (partial && pl.n_slabs != 1) { set_error("probe_all_sets 2: the read share does not fit one slab (%lld positions)", static_cast<long long>(n_positions)); return PALACE_ESTATE; }
     // (palace_eref_packed_bytes covers what plan_count checks the look-ahead of the last tile against: (n >> 5) + 3 words of 4 bytes)
     rc = ensure_workspace(ctx, pl.total() - 5 * pl.words_bytes);
     if (rc) return rc;
@@ -2990,10 +3026,12 @@ int palace_eref_entry_buffers_attach(palace_ctx *ctx, palace_eref_probe_index *i
     PALACE_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->c0_hits_ix == ix) ctx->c0_hits_ix = nullptr;
     uint8_t *counts = static_cast<uint8_t *>(d_counts);
-    if (!counts) {                                                     // the index's own count block (made on first use: 2 x the hit bits)
+    if (!counts) {                                                     // the index's own count block (made on first use: 2 x the hit bits), zero
         if (!ix->counts_block) PALACE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ix->counts_block), 2 * ix->entry_hits_bytes));
         counts = ix->counts_block;
+        PALACE_HIP_TRY(hipMemsetAsync(counts, 0, 2 * ix->entry_hits_bytes, ctx->stream));
     }
+    ctx->counts_ptr = nullptr;                                         // (whatever this context counted lies in the blocks attached before)
     uint8_t *hits = d_hits ? static_cast<uint8_t *>(d_hits) : ix->hits_block;
     for (int k = 0; k < kSets; k++) { ix->ecnt_own[k] = counts + 2 * ix->set_at[k]; ix->ehits_own[k] = hits + ix->set_at[k]; }
     return PALACE_OK;
@@ -3025,11 +3063,20 @@ int palace_eref_entry_hits_complete(palace_ctx *ctx, const palace_eref_probe_ind
 {
     PALACE_REQUIRE(ctx && ix, "null argument");
     PALACE_REQUIRE(ctx->probe_ix == ix && ctx->probe_all_sets == 2, "the index is not attached to this context with option probe_all_sets 2");
+    if (!ctx->counts_ptr || ctx->counts_ptr != ix->ecnt_own[0]) {
+        set_error("palace_eref_entry_hits_complete: no count call of this context has left its partial counts in the index's count block since the last reset");
+        return PALACE_ESTATE;
+    }
     ctx->c0_hits_ix = ix;
     ctx->hits_mask = (1u << kSets) - 1;
     ctx->sent_scattered = false;                                       // (the scan carries the sentinels' hits to position order)
     ctx->keys_counted = keys_counted;                                  // key instances of ALL ranks (what the scan's pruning goes by); -1: unknown
     return PALACE_OK;
+}
+
+int palace_eref_entry_counts_valid(const palace_ctx *ctx, const palace_eref_probe_index *ix)
+{
+    return ctx && ix && ctx->counts_ptr && ctx->counts_ptr == ix->ecnt_own[0] ? 1 : 0;
 }
 
 int palace_eref_table_planes(palace_ctx *ctx, void **d_planes3, size_t *bytes_per_plane)
@@ -3061,6 +3108,7 @@ int palace_eref_table_attach(palace_ctx *ctx, void *const d_planes3[3])
     ctx->keys_counted = -1;
     ctx->final_only = false;
     ctx->c0_hits_ix = nullptr;
+    ctx->counts_ptr = nullptr;
     return PALACE_OK;
 }
 
@@ -3072,6 +3120,7 @@ int palace_eref_table_invalidate(palace_ctx *ctx)
     ctx->keys_counted = -1;
     ctx->final_only = false;
     ctx->c0_hits_ix = nullptr;
+    ctx->counts_ptr = nullptr;
     return PALACE_OK;
 }
 

@@ -148,6 +148,11 @@ int palace_eref_entry_counts_exchange(palace_ctx *ctx, palace_eref_probe_index *
     rc = palace_eref_entry_buffers(ix, &cnt, &hits);
     if (rc) return rc;
     PALACE_REQUIRE(cnt && hits, "the index has no count block yet (palace_eref_entry_buffers_attach before the count)");
+    if (!palace_eref_entry_counts_valid(ctx, ix)) {          // (before anything is sent: stale or foreign counts must not reach the peers)
+        set_error("palace_eref_entry_counts_exchange: no count call (option probe_all_sets 2; n = 0 for a rank without reads) of this context "
+                  "has written the index's count block since the last reset");
+        return PALACE_ESTATE;
+    }
     const size_t S = cb / static_cast<size_t>(world);
     rc = ensure_workspace(ctx, cb);                          // [world][S]: every peer's counts of this rank's share
     if (rc) return rc;

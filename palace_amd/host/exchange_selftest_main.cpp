@@ -101,6 +101,11 @@ int main(int argc, char **argv)
         CK(palace_eref_set_option(ctx, "final_count", 1));
         CK(palace_eref_set_option(ctx, "probe_all_sets", 2));
         CK(palace_eref_table_reset(ctx));
+        if (palace_eref_entry_counts_exchange(ctx, ix, comm, 0, 1, 0) != PALACE_ESTATE) {     // no count since the reset: refused before anything is sent
+            std::fprintf(stderr, "exchange_selftest: an exchange without a count was not refused\n");
+            return 1;
+        }
+        CK(palace_eref_set_count_mode(ctx, 0, 0));                                      // (auto: a small share must still take the fused path)
         CK(palace_eref_count_reads(ctx, static_cast<const uint8_t *>(d_bases), static_cast<const int64_t *>(d_off), n_reads, nullptr, n_reads * read_len));
         CK(palace_eref_entry_counts_exchange(ctx, ix, comm, 0, 1, 3 * n_reads * read_len));
         CK(palace_eref_scan_refs_indexed(ctx, ix, static_cast<const uint8_t *>(d_ref), static_cast<const int64_t *>(d_roff), 1, roff[1], 450, 425, static_cast<int32_t *>(d_r2)));

@@ -394,13 +394,28 @@ def test_partial_entry_counts_of_read_shares_sum_to_the_hits_of_the_whole_sample
             for r in range(W):
                 share = synth.reads_from_list(reads[r * len(reads) // n_counting:(r + 1) * len(reads) // n_counting]) if r < n_counting else None
                 ctx.eref_table_reset()
-                if share is None:
-                    capi._check(L.palace_memset(ctx.h, ctypes.c_void_p(parts.ptr + r * cb), 0, cb), "memset")
+                assert not ctx.eref_entry_counts_valid(ix)                # nothing counted since the reset ...
+                with pytest.raises(capi.PalaceError):                    # ... so the hit bits cannot be declared whole
+                    ctx.eref_entry_hits_complete(ix, 0)
+                if share is None:                                        # a rank without reads: the same call with n = 0 zeroes its block
+                    capi._check(L.palace_memset(ctx.h, ctypes.c_void_p(counts_buf.ptr), 0x55, cb), "memset")
+                    ctx.eref_attach_probe_index(ix)
+                    capi._check(L.palace_eref_count_reads(ctx.h, None, None, 0, None, 0), "count of no reads")
+                    assert ctx.eref_entry_counts_valid(ix)
+                    ctx.d2d(parts.ptr + r * cb, counts_buf.ptr, cb)
+                    ctx.sync()
+                    assert not counts_buf.to_host().any()
                     continue
                 sb, so = ctx.upload(share.bases), ctx.upload(share.offsets)
                 ctx.eref_attach_probe_index(ix2 if r % 2 else ix)        # (odd "ranks" count through their own build of the index)
+                if r == 0 and W > 1:
+                    ctx.eref_set_count_mode(0, 0)                        # auto mode, a share far below 2^22 bases: still the fused, binned count
                 ctx.eref_count_reads(sb, so, share.n)
+                ctx.eref_set_count_mode(2, cap)
+                with pytest.raises(capi.PalaceError):                    # one count call per reset: a second one could not be fused, and is refused
+                    ctx.eref_count_reads(sb, so, share.n)
                 ctx.eref_attach_probe_index(ix)
+                assert ctx.eref_entry_counts_valid(ix)
                 with pytest.raises(capi.PalaceError):                    # partial counts are nothing to scan from
                     ctx.eref_scan_refs_indexed(ix, db, do, rs_refs.n, len(rs_refs.bases), one_min, three_min, rows)
                 ctx.d2d(parts.ptr + r * cb, counts_buf.ptr, cb)
