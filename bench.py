@@ -88,10 +88,118 @@ def launch_ranks(args) -> int:
     return subprocess.run(cmd).returncode
 
 
+def scheme_plan(world):
+    """The N-rank configurations one `--gpus N` run measures (palace_amd/multigpu.py): the weak leg (every rank the whole one-GPU step
+    on a full sample: its digests are what every scheme's result must equal), then every Phase-A scheme that exists for this many
+    ranks, the read-sharded ones also with rank 0 taking no reads (stage 04 then has rank 0's device to itself)."""
+    plan = [("weak", {"PALACE_BENCH_LEG": "weak"})]
+    strong = lambda scheme, r0: (scheme + ("" if r0 else ", rank 0 idle in Phase A"), {"PALACE_BENCH_LEG": "strong", "PALACE_BENCH_SCHEME": scheme,
+                                                                                      "PALACE_BENCH_RANK0_READS": "1" if r0 else "0"})
+    plan.append(strong("replicate", True))
+    if 64 % world == 0:
+        plan.append(strong("key_split", True))
+    for scheme in ("shard_reads", "shard_counts"):
+        plan.append(strong(scheme, True))
+        if world > 2:
+            plan.append(strong(scheme, False))
+    only = os.environ.get("PALACE_BENCH_ONLY_SCHEMES")                 # rehearsals: a comma-separated subset of the labels' schemes
+    if only:
+        keep = set(only.split(","))
+        plan = [pl for pl in plan if pl[0] == "weak" or pl[1]["PALACE_BENCH_SCHEME"] in keep]
+    return plan
+
+
+def run_all_schemes(args) -> int:
+    """One rank of a `--gpus N` run (N > 1) that was not told which scheme to use: this process never touches a GPU.  It starts one
+    CHILD process per configuration of scheme_plan() -- the same bench.py, the same rank, a rendezvous port of its own, the scheme
+    forced -- and waits for it with a time limit: a configuration that hangs in a collective, faults or exits non-zero is killed and
+    reported under its name, and the others are still measured.  Every child times exactly --steps steps.  Rank 0 prints ONE line:
+    the line of the fastest configuration whose results equal the one-GPU step's (`value` is that child's), with every configuration's
+    time and verdict under `parallelism_measured`; a configuration that failed is a failed check (exit status 3), never a silent skip."""
+    import signal
+    import subprocess
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"])
+    base = int(os.environ.get("MASTER_PORT", "29500"))
+    limit = float(os.environ.get("PALACE_BENCH_SCHEME_TIMEOUT", "240"))
+    plan, res = scheme_plan(world), {}
+    for k, (label, env_add) in enumerate(plan):
+        port = base + 1 + k if base + 1 + len(plan) < 65536 else base - 1 - k
+        env = dict(os.environ, PALACE_BENCH_CHILD="1", MASTER_PORT=str(port), **env_add)
+        for v in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID"):      # the child's rank 0 hosts the store of ITS group on ITS port
+            env.pop(v, None)
+        t0 = time.perf_counter()
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL,
+                             start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=limit)
+            status = "ok" if p.returncode == 0 else f"exit status {p.returncode}"
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            out, _ = p.communicate()
+            status = f"no result within {limit:.0f} s (killed)"
+        line = None
+        if rank == 0:
+            for l in (out or b"").decode(errors="replace").splitlines():
+                if l.startswith("{"):
+                    line = json.loads(l)
+        res[label] = dict(status=status, seconds=round(time.perf_counter() - t0, 1), line=line)
+        print(f"[bench rank {rank}] {label}: {status} in {res[label]['seconds']} s", file=sys.stderr, flush=True)
+    if rank != 0:
+        return 0                                           # (the verdict is rank 0's to print: a launcher that sees another rank fail first tears rank 0 down)
+    weak = res["weak"]["line"]
+    want = (weak or {}).get("result_digest") or {}
+    measured, failures, best = {}, [], None
+    if weak is None:
+        failures.append(f"weak leg: {res['weak']['status']}")
+    for label, r in res.items():
+        if label == "weak":
+            continue
+        line = r["line"]
+        if line is None:
+            measured[label] = dict(status=r["status"], valid=False)
+            failures.append(f"scheme '{label}': {r['status']}")
+            continue
+        d = line["config"]["result_digest"]
+        same = bool(want) and d.get("eref_rows") == want.get("eref_rows") and d.get("graph_and_components") == want.get("graph_and_components")
+        bad = list(line.get("failed_checks") or []) + ([] if same else ["results differ from the one-GPU step's (digests)" if want else "no one-GPU digest to compare with"])
+        measured[label] = dict(status=r["status"], valid=not bad, ms_per_step=line["ms_per_step"], contigs_per_s=line["value"],
+                               eref_count_ms=(line.get("stage_ms") or {}).get("eref_count_both_sides"), **({"failed": bad} if bad else {}))
+        if bad:
+            failures.append(f"scheme '{label}': " + "; ".join(bad))
+        elif best is None or line["ms_per_step"] < res[best]["line"]["ms_per_step"]:
+            best = label
+    if best is None:
+        out = dict(metric=json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"], value=None, unit="contigs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   higher_is_better=True, scaling="strong", vs_baseline=None, data="synthetic", config={"workload": "no configuration of the N-GPU step produced a valid result"})
+    else:
+        out = res[best]["line"]
+        out.pop("failed_checks", None)
+        out["config"]["parallelism"] = f"{world} GPUs, one sample: {best} (the fastest valid one of the configurations measured in this run)"
+    out["parallelism_measured"] = measured
+    out["parallelism_measured_note"] = ("every configuration is a child process per rank (own process group, the scheme forced) timing exactly --steps steps of the SAME sample; "
+                                        "valid = its eref rows and graph / component digests equal the one-GPU step's (the weak leg's); `value` is the fastest valid one's")
+    if weak is not None:
+        out["weak"] = weak
+    if failures:
+        out["failed_checks"] = failures
+    sys.stdout.flush()
+    os.write(1, (json.dumps(out) + "\n").encode())
+    if failures:
+        print("bench.py: FAILED CHECKS: " + "; ".join(failures), file=sys.stderr)
+        return 3
+    return 0
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 and not os.environ.get("PALACE_BENCH_CHILD") and os.environ.get("PALACE_BENCH_SCHEME", "auto") == "auto"
+            and os.environ.get("PALACE_BENCH_ALL_SCHEMES", "1") == "1"):
+        raise SystemExit(run_all_schemes(args))
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 when a process group
     # initialises, so everything written to fd 1 before the final line is routed to stderr.
     sys.stdout.flush()
@@ -128,8 +236,11 @@ def main():
     E = SimpleNamespace(torch=torch, dev=dev, local=local, dist=dist, rank=rank, world=world,
                         force_exchange=force_exchange, force_key_split=force_key_split)
     from bench.step import measure
-    out, failures = measure(args, E, "strong" if world > 1 else "single")
-    if world > 1 and os.environ.get("PALACE_BENCH_WEAK", "1") == "1":
+    if os.environ.get("PALACE_BENCH_LEG") == "weak" and world > 1:        # a child of run_all_schemes: the weak leg alone
+        out, failures = measure(args, E, "weak")
+    else:
+        out, failures = measure(args, E, "strong" if world > 1 else "single")
+    if world > 1 and os.environ.get("PALACE_BENCH_WEAK", "1") == "1" and not os.environ.get("PALACE_BENCH_LEG"):
         # the other reading of "N GPUs": one independent sample per GPU, no collective in the data path.  Every rank runs the
         # whole 1-GPU step on the (same) full sample; aggregate = N samples per max-over-ranks time.
         weak, _ = measure(args, E, "weak")

@@ -683,6 +683,11 @@ def measure(args, E, leg):
             else:
                 work = tempfile.mkdtemp(prefix="palace_e2e_", dir=os.environ.get("PALACE_BENCH_TMP", "/tmp"))
             try:
+                # the eref rows (ordinal, n_intervals, el, ref_len per ref) of the resident step as it was timed -- tests/test_gpu_bench_workloads.py
+                # holds them against the oracle's scan of every ref on the oracle's table of every read
+                np.save(os.path.join(work, "eref_rows_resident_step.npy"), r.copy())
+                with open(os.path.join(work, "eref_rows_resident_step.json"), "w") as fh:
+                    json.dump({"fused_probe_mode": int(fused_mode), "probe_all_sets": bool(fused_all), "reads": args.reads, "final_count": bool(final_count)}, fh)
                 progress("e2e: writing the sample's files")
                 paths = write_e2e_inputs(torch, sample, gs, hdr, work)
                 progress("e2e: running the executables on them")

@@ -12,7 +12,10 @@
 //                scheduling).  Rank = 128-bit key (khi, klo), lower is better: per iteration a pass of 64-bit atomicMin on
 //                the stamped khi, a pass of atomicMin on klo among the arcs that tie on khi, and the commit pass.  The
 //                stamp (iteration number, descending) in the top bits of khi lets newer proposals displace older ones, so
-//                the slot arrays are never cleared inside a round.
+//                the slot arrays are never cleared inside a round.  The slot word IS the slot's state (round 6): 0 = closed
+//                (the vertex is dead, or the slot has been given to an arc) -- below every stamped key, so no proposal
+//                displaces it and no key ever equals it; an iteration therefore reads one word per end of an arc instead
+//                of alive / next / prev beside it.
 //   read-off     a vertex without predecessor walks its path; what no walk reaches lies on cycles, and the smallest vertex
 //                of a cycle walks it.  Of a component and its conjugate twin exactly one walker -- the one with the smaller
 //                first vertex -- reports (make_final_fa.py:20-34 for the conjugate rule).  Reported lengths are scanned over
@@ -27,6 +30,8 @@ namespace palace {
 namespace {
 
 constexpr uint64_t kNoKey = ~0ull;
+constexpr uint64_t kClosed = 0;                        // slot word of a closed slot: stamps are >= 1 in every key that is proposed (decomp_begin,
+                                                       // decomp_run_checked bound the iteration count), so a stamped key is never 0
 constexpr int kStampShift = 42;                        // khi < 2^42; the iteration stamp lives above
 constexpr int kPackedShift = 52, kPackedStamps = 1 << (64 - kPackedShift);      // one-word keys < 2^52: 12 bits of stamp
 constexpr uint64_t kLenMask = (1ull << 40) - 1;
@@ -151,6 +156,7 @@ __device__ void ph_round_begin(const DecompBufs &b, Span T, int reset_left)
         if (reset_left && !(i & 1)) b.left[s] = 1;
         b.alive[i] = l > 0;
         b.next[i] = -1; b.prev[i] = -1;
+        b.bo_hi[i] = b.bi_hi[i] = l > 0 ? kNoKey : kClosed;      // both slots of a live vertex are open
         if (!packed) { b.bo_lo[i] = kNoKey; b.bo_lo[V + i] = kNoKey; b.bi_lo[i] = kNoKey; b.bi_lo[V + i] = kNoKey; }
         b.len_a[i] = 0;
     }
@@ -164,18 +170,12 @@ struct IterArgs {
     int unique_hi;
 };
 
-__device__ __forceinline__ bool arc_open(const DecompBufs &b, int u, int v)
-{
-    return b.alive[u] && b.alive[v] && b.next[u] < 0 && b.prev[v] < 0;
-}
-// An arc that is closed stays closed until the round ends (vertices do not come back to life and slots are not given up inside
-// a round), so whoever sees it closed says so in `done`: from then on an iteration spends one sequential byte on it instead of
-// four random look-ups.  After the first iteration of a round most arcs are closed, and the decomposition's ~140 launches were
-// mostly such look-ups -- beside the counting kernels, which pay for every one of them.
-#define PALACE_OPEN_ARC_OR_CONTINUE(b, e, u, v)                 \
-    if ((b).done[e]) continue;                                  \
-    const int u = (b).src[e], v = (b).dst[e];                   \
-    if (!arc_open((b), u, v)) { (b).done[e] = 1; continue; }
+// An arc is open while both its slots are: the out slot of its tail and the in slot of its head.  A closed slot stays closed until
+// the round ends (vertices do not come back to life and slots are not given up inside a round), so whoever sees an arc closed says so
+// in `done`: from then on an iteration spends one sequential byte on it.  After the first iteration of a round most arcs are closed.
+// Per open arc and iteration the three passes do five random accesses to the two slot words (a load and two atomicMin, one of them
+// returning, in the proposal pass; two loads in the commit pass) -- until round 6 they looked up alive[u], alive[v], next[u], prev[v] in
+// every pass on top of the slot words (twelve), and the counting kernels beside them pay for every one.
 
 // pass 1: stamped khi into both slots; the klo halves of the OTHER parity (written one iteration ago, needed again in the
 // next one) are reset here, where nothing writes next / prev and "open" is the same for every thread that looks
@@ -188,15 +188,20 @@ __device__ void ph_propose_hi(const DecompBufs &b, Span T, const IterArgs &a)
     const int other = (a.parity ^ 1) * V;
     const bool packed = b.st->packed != 0;
     for (int64_t e = T.tid; e < E; e += T.n) {
-        PALACE_OPEN_ARC_OR_CONTINUE(b, e, u, v)
+        if (b.done[e]) continue;
+        const int u = b.src[e], v = b.dst[e];
+        // the head's slot is looked at BEFORE the tail's takes the proposal: an arc that is closed must leave its key nowhere (a key
+        // left in the tail's slot by an arc whose head is closed could keep the slot's best open arc from being taken in this
+        // iteration, and an iteration that takes no arc ends the round).  Nothing closes a slot during this pass.
+        if (b.bi_hi[v] == kClosed) { b.done[e] = 1; continue; }
         const uint64_t k = packed ? (a.stamp_p | b.kc[e]) : (a.stamp | b.khi[e]);
-        atomicMin(reinterpret_cast<unsigned long long *>(&b.bo_hi[u]), static_cast<unsigned long long>(k));
+        if (atomicMin(reinterpret_cast<unsigned long long *>(&b.bo_hi[u]), static_cast<unsigned long long>(k)) == kClosed) { b.done[e] = 1; continue; }
         atomicMin(reinterpret_cast<unsigned long long *>(&b.bi_hi[v]), static_cast<unsigned long long>(k));
         if (!a.unique_hi && !packed) { b.bo_lo[other + u] = kNoKey; b.bi_lo[other + v] = kNoKey; }
     }
 }
 
-// pass 2: among the arcs that tie on khi in a slot, the smallest klo
+// pass 2: among the arcs that tie on khi in a slot, the smallest klo (a closed arc's key stands in no slot)
 __device__ void ph_propose_lo(const DecompBufs &b, Span T, const IterArgs &a)
 {
     if (b.st->dead) return;
@@ -205,14 +210,15 @@ __device__ void ph_propose_lo(const DecompBufs &b, Span T, const IterArgs &a)
     const int64_t E = b.st->E;
     const int mine = a.parity * b.st->V;
     for (int64_t e = T.tid; e < E; e += T.n) {
-        PALACE_OPEN_ARC_OR_CONTINUE(b, e, u, v)
+        if (b.done[e]) continue;
+        const int u = b.src[e], v = b.dst[e];
         const uint64_t k = a.stamp | b.khi[e], lo = b.klo[e];
         if (b.bo_hi[u] == k) atomicMin(reinterpret_cast<unsigned long long *>(&b.bo_lo[mine + u]), static_cast<unsigned long long>(lo));
         if (b.bi_hi[v] == k) atomicMin(reinterpret_cast<unsigned long long *>(&b.bi_lo[mine + v]), static_cast<unsigned long long>(lo));
     }
 }
 
-// pass 3: an arc that is the best of both its slots is taken (slot owners are unique: keys are distinct)
+// pass 3: an arc that is the best of both its slots is taken (slot owners are unique: keys are distinct) and closes them
 __device__ void ph_commit_flag(const DecompBufs &b, Span T, const IterArgs &a, volatile unsigned int *took);
 __device__ void ph_commit(const DecompBufs &b, Span T, const IterArgs &a)
 {
@@ -227,13 +233,15 @@ __device__ void ph_commit_flag(const DecompBufs &b, Span T, const IterArgs &a, v
     const int mine = a.parity * b.st->V;
     const bool packed = b.st->packed != 0;
     for (int64_t e = T.tid; e < E; e += T.n) {
-        PALACE_OPEN_ARC_OR_CONTINUE(b, e, u, v)      // (a slot taken a moment ago by another arc of this pass reads as closed: that arc held the slot's best key, not this one)
+        if (b.done[e]) continue;
+        const int u = b.src[e], v = b.dst[e];
         const uint64_t k = packed ? (a.stamp_p | b.kc[e]) : (a.stamp | b.khi[e]);
-        if (b.bo_hi[u] != k || b.bi_hi[v] != k) continue;
+        if (b.bo_hi[u] != k || b.bi_hi[v] != k) continue;      // (a slot closed a moment ago by another arc of this pass held that arc's key, not this one)
         const uint64_t lo = b.klo[e];
         if (!a.unique_hi && !packed && (b.bo_lo[mine + u] != lo || b.bi_lo[mine + v] != lo)) continue;
         b.next[u] = v; b.prev[v] = u;
         b.nhi[u] = b.khi[e]; b.nlo[u] = lo;
+        b.bo_hi[u] = kClosed; b.bi_hi[v] = kClosed;
         b.done[e] = 1;                               // (taken: both its slots are closed now)
         any = true;
     }

@@ -60,7 +60,7 @@ struct DecompBufs {
     // vertices [V]
     int32_t *next = nullptr, *prev = nullptr, *on_path = nullptr, *open_at = nullptr;
     uint64_t *nhi = nullptr, *nlo = nullptr;            // key of the arc leaving the vertex
-    uint64_t *bo_hi = nullptr, *bi_hi = nullptr;        // best proposal per out / in slot (stamped)
+    uint64_t *bo_hi = nullptr, *bi_hi = nullptr;        // per out / in slot: its best proposal (stamped), or 0 = the slot is closed (decomp.hip)
     uint64_t *bo_lo = nullptr, *bi_lo = nullptr;        // [2][V], by iteration parity
     uint64_t *len_a = nullptr, *pos = nullptr;          // scan input / output: (1 << 40 | length) at emitting first vertices
     int64_t *pay = nullptr;

@@ -1568,10 +1568,15 @@ __global__ __launch_bounds__(256) void eref_gather_hits_kernel(const int64_t *__
 // themselves (no memset of the bytes, no packing pass) the ~9 M random hits of a step -- when ALL of channel 0 was scattered, before
 // the sentinels -- cost 0.45 ms MORE (scan 1.81 against 1.36 ms, round 5, tools/ab.sh r05g; round 3 had found the same).
 constexpr int kScatterThreads = 256, kScatterList = 4096;
+// word_pre / r_lo / r_hi (options scan_ref_lo / _hi: a rank of N scans its range of the refs): only the sentinels of those refs are
+// carried over -- the byte stores, the expensive half of a hit (a random 64-byte granule each), shrink with the rank's share of the DB.
 __global__ __launch_bounds__(kScatterThreads) void eref_ehits_scatter_kernel(const uint4 *__restrict__ ehits, unsigned long long n16,
-                                                                             const uint32_t *__restrict__ pos, uint8_t *__restrict__ hit_bytes)
+                                                                             const uint32_t *__restrict__ pos, uint8_t *__restrict__ hit_bytes,
+                                                                             const int64_t *__restrict__ word_pre, int64_t r_lo, int64_t r_hi)
 {
-    auto hit = [&](uint32_t p) { hit_bytes[p] = 1; };
+    // sentinel ordinals of the refs [r_lo, r_hi): 64 / kSentinelStride per word of the hit bitmap
+    const uint32_t s_lo = static_cast<uint32_t>(word_pre[r_lo] * (64 / kSentinelStride)), s_n = static_cast<uint32_t>(word_pre[r_hi] * (64 / kSentinelStride)) - s_lo;
+    auto hit = [&](uint32_t p) { if (p - s_lo < s_n) hit_bytes[p] = 1; };
     __shared__ uint32_t list[kScatterList];
     __shared__ uint32_t n_list;
     const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * kScatterThreads;
@@ -2931,10 +2936,11 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     }
     if (sets.mask) hipLaunchKernelGGL(eref_probe_sets_kernel, dim3(kBuckets), dim3(kProbeThreads), 0, ctx->stream, sets, ctx->plane[2]);
     // the sentinels that hit -> position order -> the bit words eref_need_kernel reads
+    const int64_t r_lo = std::min(ctx->scan_ref_lo, n_refs), r_hi = ctx->scan_ref_hi > 0 ? std::max(r_lo, std::min(ctx->scan_ref_hi, n_refs)) : n_refs;   // options scan_ref_lo / _hi
     if (!sent_done)
         hipLaunchKernelGGL(eref_ehits_scatter_kernel, dim3(kCUs * 8), dim3(kScatterThreads), 0, ctx->stream,
                            reinterpret_cast<const uint4 *>(sets.s[kSentinelSet].ehits), static_cast<unsigned long long>(ix->ehits_bytes[kSentinelSet] / 16),
-                           ix->pos_s, b.hit_bytes);
+                           ix->pos_s, b.hit_bytes, static_cast<const int64_t *>(b.word_pre), r_lo, r_hi);
     hipLaunchKernelGGL(eref_sentinel_words_kernel, dim3(kCUs * 8), dim3(256), 0, ctx->stream,
                        reinterpret_cast<const uint4 *>(sent_done ? ix->sent_bytes_own : b.hit_bytes), b.max_words, b.any_w);
     PALACE_HIP_TRY(hipGetLastError());
@@ -2942,7 +2948,6 @@ int palace_eref_scan_refs_indexed(palace_ctx *ctx, const palace_eref_probe_index
     // it holds at least 500 / 4 - 1 sentinels (the cumulative windows at a ref's start, which must hold three_min positions
     // to pass at all, hold more in proportion), so at least this many of its sentinels hit:
     const int sentinel_min = std::max(0, 500 / kSentinelStride - 1 - (500 - three_min));
-    const int64_t r_lo = std::min(ctx->scan_ref_lo, n_refs), r_hi = ctx->scan_ref_hi > 0 ? std::min(ctx->scan_ref_hi, n_refs) : n_refs;   // options scan_ref_lo / _hi
     hipLaunchKernelGGL(eref_need_kernel, dim3(static_cast<unsigned>(n_refs)), dim3(kRefThreads), 0, ctx->stream, d_offsets,
                        n_refs, b.word_pre, b.any_w, b.any_p, b.good_w, b.all_p, sentinel_min, b.need, b.active, r_lo, r_hi);
     GatherArgs ga{};

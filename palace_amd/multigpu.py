@@ -143,9 +143,9 @@ def step_model(n_contigs: int, n_reads: int, world: int, scheme: str | None = No
 
 def best_step(n_contigs: int, n_reads: int, world: int, link_gbs: float | None = None) -> dict:
     """scheme and rank-0 read share with the shortest modelled step"""
-    cands = [step_model(n_contigs, n_reads, world, s, True, link_gbs) for s in phase_a_model(n_reads, world, link_gbs)["ms"]]
-    if world > 2:
-        cands.append(step_model(n_contigs, n_reads, world, "shard_reads", False, link_gbs))
+    cands = [step_model(n_contigs, n_reads, world, s, True, link_gbs) for s in phase_a_model(n_reads, world, link_gbs, entry_counts=True)["ms"]]
+    if world > 2:                                  # the read-sharded schemes with rank 0 taking no reads
+        cands += [step_model(n_contigs, n_reads, world, s, False, link_gbs) for s in ("shard_reads", "shard_counts")]
     return min(cands, key=lambda c: c["step_ms"])
 
 

@@ -97,9 +97,19 @@ def files_equal_the_oracle_chain(work, line):
     shutil.rmtree(str(work), ignore_errors=True)
 
 
-def count_packed_equals_oracle(contigs):
+def resident_rows(work):
+    """the eref rows (n_intervals, el, ref_len, 0 per ref) of the bench's HBM-resident step as it was timed, and how that step counted"""
+    rows = np.load(os.path.join(str(work), "eref_rows_resident_step.npy"))
+    how = json.load(open(os.path.join(str(work), "eref_rows_resident_step.json")))
+    return rows, how
+
+
+def count_packed_equals_oracle(contigs, timed_rows=None):
     """every read of the workload through palace_eref_pack_reads + palace_eref_count_reads_packed (three planes) against the
-    oracle's byte table: plane populations over the whole key space, and look-ups at random keys and at the keys of a present ref"""
+    oracle's byte table: plane populations over the whole key space, and look-ups at random keys and at the keys of a present ref.
+    timed_rows: the rows of the bench's resident step (the path the headline number times: every look-up of Phase B inside the
+    count launch, no plane written) -- held, for ALL refs, against the oracle's scan (extract_ref.cpp:813-903, 504-617) on the
+    oracle's table of ALL reads; and the same rows once more through the C ABI in this process (fused count, indexed scan)."""
     import torch
 
     import bench
@@ -127,8 +137,33 @@ def count_packed_equals_oracle(contigs):
         capi._check(L.palace_eref_count_reads_packed(ctx.h, *(P(t) for t in packed), tot, 2 * n_side), "count")
         ctx.sync()
         pops, got = ctx.eref_table_popcounts(), ctx.eref_table_lookup(probe)
+        fused_rows = None
+        if timed_rows is not None:                                     # the timed path itself, once more through the C ABI (bench/step.py:245-278, 300-358)
+            import ctypes
+            n_refs = sample["n_refs"]
+            ix = ctypes.c_void_p()
+            capi._check(L.palace_eref_probe_index_build(ctx.h, P(sample["ref_bases"]), P(sample["ref_off"]), n_refs, sample["ref_total"], ctypes.byref(ix)), "probe index")
+            capi._check(L.palace_eref_attach_probe_index(ctx.h, ix), "attach")
+            ctx.eref_set_option("final_count", 1)
+            ctx.eref_set_option("probe_all_sets", 1)
+            rows_d = torch.zeros((n_refs, 4), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            one_min, three_min = capi.window_minimums(0.9, 0.85)
+            ctx.eref_table_reset()
+            capi._check(L.palace_eref_count_reads_packed(ctx.h, *(P(t) for t in packed), tot, 2 * n_side), "fused count")
+            capi._check(L.palace_eref_scan_refs_indexed(ctx.h, ix, P(sample["ref_bases"]), P(sample["ref_off"]), n_refs, sample["ref_total"],
+                                                        one_min, three_min, P(rows_d)), "indexed scan")
+            ctx.sync()
+            fused_rows = rows_d.cpu().numpy()
+            ctx.eref_set_option("probe_all_sets", 0)
+            ctx.eref_set_option("final_count", 0)
+            capi._check(L.palace_eref_attach_probe_index(ctx.h, None), "detach")
+            ctx.eref_probe_index_free(ix)
+            ctx.eref_table_reset()
     b12 = sample["r12"].cpu().numpy()
     off = sample["read_off"].cpu().numpy()
+    ref_b = sample["ref_bases"].cpu().numpy() if timed_rows is not None else None
+    ref_o = sample["ref_off"].cpu().numpy() if timed_rows is not None else None
     del sample, packed
     torch.cuda.empty_cache()
     table = orc.CountTable()
@@ -140,7 +175,23 @@ def count_packed_equals_oracle(contigs):
         v = table.view[lo:lo + (1 << 28)]
         for k in range(3):
             want_pops[k] += int(np.count_nonzero(v > k))
+    if timed_rows is not None:
+        # the oracle's Phase B over every ref of the DB on that table: index (extract_ref.cpp:711-738), look-ups (:858-870), windows (:504-617)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def scan(i):
+            s_ = ref_b[int(ref_o[i]):int(ref_o[i + 1])]
+            _, n_int, el, _ = orc.scan_ref(orc.index_ref(s_, cc), len(s_), table, 0.9, 0.85)
+            return n_int, el, len(s_)
+        with ThreadPoolExecutor(max(1, min(os.cpu_count() or 1, 16))) as ex:           # (ctypes calls release the interpreter lock)
+            want_rows = np.array(list(ex.map(scan, range(len(ref_o) - 1))), dtype=np.int64)
     table.free()
+    if timed_rows is not None:
+        assert timed_rows.shape == (len(want_rows), 4)
+        assert np.array_equal(timed_rows[:, :3].astype(np.int64), want_rows), "the bench's timed eref rows differ from the oracle's scan of every ref"
+        assert np.array_equal(fused_rows[:, :3].astype(np.int64), want_rows), "fused count + indexed scan through the C ABI differ from the oracle"
+        printed = (want_rows[:, 1] > 0) & (want_rows[:, 1].astype(np.float32) / want_rows[:, 2].astype(np.float32) > np.float32(0.75))
+        assert printed.sum() >= 150 and (want_rows[:, 0] > 0).sum() >= printed.sum()
     assert np.array_equal(got, want)
     assert (want == 3).sum() > 10000 and (want == 1).sum() > 10000 and (want == 0).sum() > 10000
     assert list(pops) == want_pops
@@ -151,8 +202,10 @@ def test_config2_500k_contigs_bench_checks_oracle_chain_and_oracle_table(tmp_pat
     line = run_bench(500_000, tmp_path / "w")
     c = check_line(line, 500_000)
     assert 150 <= c["refs_reported"] <= c["refs_present"] == 200        # (half the read depth of the 1M workload: a few refs fall short)
+    rows, how = resident_rows(tmp_path / "w")
+    assert how["probe_all_sets"] is True and how["reads"] == "packed"   # the default step: Phase B's look-ups inside the count launch
     files_equal_the_oracle_chain(tmp_path / "w", line)
-    count_packed_equals_oracle(500_000)
+    count_packed_equals_oracle(500_000, rows)
 
 
 def test_headline_1m_contigs_bench_checks_oracle_chain_and_oracle_table(tmp_path):
@@ -160,8 +213,10 @@ def test_headline_1m_contigs_bench_checks_oracle_chain_and_oracle_table(tmp_path
     c = check_line(line, 1_000_000)
     assert c["refs_reported"] == c["refs_present"] == 200
     assert line["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    rows, how = resident_rows(tmp_path / "w")
+    assert how["probe_all_sets"] is True and how["reads"] == "packed"   # the configuration the headline number is timed in
     files_equal_the_oracle_chain(tmp_path / "w", line)
-    count_packed_equals_oracle(1_000_000)
+    count_packed_equals_oracle(1_000_000, rows)
 
 
 def test_config4_long_contigs_bench_checks_and_oracle_chain(tmp_path):

@@ -104,6 +104,73 @@ def test_config1_c_abi_equals_reference(cfg1):
 
 
 # ------------------------------------------------------------------------------------------------
+# the headline configuration's size (1M contigs: 5 000 refs, 3 333 333 read pairs) against the COMPILED REFERENCE
+# ------------------------------------------------------------------------------------------------
+def test_headline_size_eref_cli_and_timed_path_equal_reference(tmp_path):
+    """tests/golden/eref_1m.npz: stdout of the unmodified extract_ref.cpp (threads=1) on an eref input of the 1M-contig configuration's
+    size, made in the build container by tests/golden/make_eref_1m_golden.py.  The inputs are regenerated from the seed and proven to be
+    the same bytes; then (a) the executable on the files, building its index with the coder the reference drew, and (b) the path
+    bench.py times -- reads packed in HBM, every look-up of Phase B inside the count launch (options final_count + probe_all_sets), the
+    indexed scan on the hit bits -- must give the reference's lines byte for byte, for both ratio pairs (the second pair off the same
+    hit bits).  extract_ref.cpp:504-617, 813-903, 905-1008."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "eref_1m.npz"))
+    seed, n_refs, n_pairs, n_present, pool = (int(x) for x in g["params"])
+    assert (n_refs, n_pairs) == (5000, 3_333_333)                       # 6.67 M reads x 150 bp: the 1M-contig configuration (SURVEY 8(d))
+    fa, fq1, fq2, refs, r1, r2 = synth.eref_config_inputs(seed, n_refs, n_pairs, pool_bases=pool, n_present=n_present, n_phage_pairs=n_pairs // 10, arrays=True)
+    for key, b in (("sha256_db_fa", fa), ("sha256_fq1", fq1), ("sha256_fq2", fq2)):
+        assert hashlib.sha256(b).hexdigest() == str(g[key]), f"regenerated input differs from the one the reference ran on ({key})"
+    d = tmp_path
+    for name, b in (("db.fa", fa), ("r_1.fq", fq1), ("r_2.fq", fq2)):
+        open(d / name, "wb").write(b)
+    del fa, fq1, fq2
+    open(d / "coder.hdr", "wb").write(g["index_header"].tobytes())
+    # (a) the executable
+    args = [os.path.join(BIN, "eref"), str(d / "r_1.fq"), str(d / "r_2.fq"), str(d / "db.fa"), str(d / "tmp.txt")]
+    p = subprocess.run(args + ["0.9", "0.85", "16"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, PALACE_CODER_HEADER=str(d / "coder.hdr")))
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == g["stdout_090_085"].tobytes() and p.stdout.count(b"\n") >= 150
+    p = subprocess.run(args + ["0.8", "0.5", "16"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == g["stdout_080_050"].tobytes()
+    for name in ("r_1.fq", "r_2.fq", "db.fa.k32.index.dat"):
+        os.remove(d / name)
+    # (b) the timed path through the C ABI
+    ref_off = np.zeros(len(refs) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in refs], out=ref_off[1:])
+    ref_bases = np.concatenate(refs)
+    n, rl = r1.shape
+    r12 = np.concatenate([np.ascontiguousarray(r1).reshape(-1), np.ascontiguousarray(r2).reshape(-1)])
+    del r1, r2
+    off = np.arange(2 * n + 1, dtype=np.int64) * rl
+    L = capi.lib()
+    with capi.Ctx(0) as ctx:
+        ctx.eref_set_coder(g["index_header"])
+        db, do = ctx.upload(r12), ctx.upload(off)
+        nb = int(L.palace_eref_packed_bytes(len(r12)))
+        packed = [ctx.empty((nb,), np.uint8) for _ in range(3)]
+        ctx.eref_pack_reads(db, do, 2 * n, None, len(r12), *packed)
+        ctx.sync()
+        db.free(); do.free()
+        rb, ro = ctx.upload(ref_bases), ctx.upload(ref_off)
+        ix = ctx.eref_probe_index_build(rb, ro, len(refs), len(ref_bases))
+        ctx.eref_attach_probe_index(ix)
+        ctx.eref_set_option("final_count", 1)
+        ctx.eref_set_option("probe_all_sets", 1)
+        ctx.eref_table_reset()
+        ctx.eref_count_reads_packed(*packed, len(r12), 2 * n)
+        rows = ctx.empty((len(refs), 4), np.int32)
+        for key, hr, pr in (("stdout_090_085", 0.9, 0.85), ("stdout_080_050", 0.8, 0.5)):
+            one_min, three_min = capi.window_minimums(hr, pr)
+            ctx.eref_scan_refs_indexed(ix, rb, ro, len(refs), len(ref_bases), one_min, three_min, rows)
+            assert lines_from_rows(rows.to_host()) == g[key].tobytes(), key
+        ctx.eref_set_option("probe_all_sets", 0)
+        ctx.eref_set_option("final_count", 0)
+        ctx.eref_attach_probe_index(None)
+        ctx.eref_probe_index_free(ix)
+        ctx.eref_table_reset()
+
+
+# ------------------------------------------------------------------------------------------------
 # configs[3]: 5M-contig scale on one GPU
 # ------------------------------------------------------------------------------------------------
 def test_config3_5m_contig_scale_slab_path():
