@@ -123,7 +123,7 @@ def run_all_schemes(args) -> int:
     limit = float(os.environ.get("PALACE_BENCH_SCHEME_TIMEOUT", "240"))
     plan, res = scheme_plan(world), {}
     for k, (label, env_add) in enumerate(plan):
-        port = base + 1 + k if base + 1 + len(plan) < 65536 else base - 1 - k
+        port = base + 64 * (k + 1) if base + 64 * (len(plan) + 1) < 65536 else base - 64 * (k + 1)      # (a rendezvous port of its own, away from the launcher's)
         env = dict(os.environ, PALACE_BENCH_CHILD="1", MASTER_PORT=str(port), **env_add)
         for v in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID"):      # the child's rank 0 hosts the store of ITS group on ITS port
             env.pop(v, None)
@@ -236,6 +236,8 @@ def main():
     E = SimpleNamespace(torch=torch, dev=dev, local=local, dist=dist, rank=rank, world=world,
                         force_exchange=force_exchange, force_key_split=force_key_split)
     from bench.step import measure
+    if os.environ.get("PALACE_BENCH_TEST_HANG") and os.environ.get("PALACE_BENCH_TEST_HANG") == os.environ.get("PALACE_BENCH_SCHEME") and rank == world - 1:
+        time.sleep(1e6)                                    # tests only: the last rank of this scheme's child never joins a collective
     if os.environ.get("PALACE_BENCH_LEG") == "weak" and world > 1:        # a child of run_all_schemes: the weak leg alone
         out, failures = measure(args, E, "weak")
     else:

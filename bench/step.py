@@ -123,6 +123,11 @@ def measure(args, E, leg):
         scheme = forced
     if not collectives:
         scheme = "replicate"
+    # tuning runs only (one GPU): PALACE_OPT_COUNTS_SHARE=W -- the step of rank 1 of W under shard_counts: 1 / W of the reads counted (partial
+    # entry counts), 1 / W of the refs scanned, no peer; results are partial by design (what the model's constants are measured with)
+    counts_share = int(os.environ.get("PALACE_OPT_COUNTS_SHARE", "0")) if (world == 1 and not solo and not collectives) else 0
+    if counts_share > 1:
+        scheme = "shard_counts"
     # "shard_counts" (end of round 5, PALACE_BENCH_SCHEME=shard_counts: opt-in until an N-GPU run has checked it): the reads are sharded
     # as under shard_reads, but what the ranks exchange is their partial COUNTS of the DB's probe-index entries (two bits per entry,
     # summed by entry range, hit bits all-gathered: include/palace_hip.h, palace_eref_entry_layout) -- no plane crosses a link
@@ -142,7 +147,10 @@ def measure(args, E, leg):
     model.update(choice_in_force=scheme, forced=bool(forced), rank0_counts=bool(rank0_counts), choice=best["scheme"],
                  step=multigpu.step_model(args.contigs, n_reads_total, world, scheme, rank0_counts),
                  step_alternatives=[multigpu.step_model(args.contigs, n_reads_total, world, sch, True) for sch in model["ms"]])
-    sample = make_sample(torch, dev, args.contigs, args.refs, rank if reads_sharded else 0, world if reads_sharded else 1, long_mode, read_weights)
+    if counts_share > 1:
+        sample = make_sample(torch, dev, args.contigs, args.refs, 1, counts_share, long_mode, None)
+    else:
+        sample = make_sample(torch, dev, args.contigs, args.refs, rank if reads_sharded else 0, world if reads_sharded else 1, long_mode, read_weights)
     gs = make_graph_sample(torch, dev, args.contigs, sample["n_pairs_total"], rank, world, long_mode)
     if collectives:                                 # avgDepth is a pipeline input: computed once from all shards
         tot = torch.tensor([float(gs["col"]["ref_len"].sum().item())], device=dev, dtype=torch.float64)
@@ -155,7 +163,7 @@ def measure(args, E, leg):
     P = lambda t: t.data_ptr()
     n_side, n_refs, nt = sample["n_reads_side"], sample["n_refs"], args.contigs
     # refs shard by cumulative length across ranks (eref Phase B); every rank holds the whole (small) DB
-    r_lo, r_hi = multigpu.split_by_weight(sample["ref_lens"], rank, world)
+    r_lo, r_hi = multigpu.split_by_weight(sample["ref_lens"], rank, world) if counts_share <= 1 else multigpu.split_by_weight(sample["ref_lens"], 1, counts_share)
     rows = torch.zeros((n_refs, 4), dtype=torch.int32, device=dev)
     rows_host = torch.zeros((n_refs, 4), dtype=torch.int32).pin_memory()
     cn_host = torch.zeros(args.contigs, dtype=torch.int32).pin_memory()
@@ -726,7 +734,7 @@ def measure(args, E, leg):
         # files disagreeing with the resident step (or the leg raising), results that differ from step to step
         e2e = out.get("e2e")
         if reported != len(sample["present"]) and args.contigs >= 1_000_000 and args.refs == 5000 and os.environ.get("PALACE_BENCH_SKIP_EREF") != "1" \
-                and not os.environ.get("PALACE_OPT_KEY_SHARE"):     # (below 1M contigs the read depth leaves a few present refs short; a tuning run that counts one rank's key share is partial by design)
+                and not os.environ.get("PALACE_OPT_KEY_SHARE") and not os.environ.get("PALACE_OPT_COUNTS_SHARE"):     # (below 1M contigs the read depth leaves a few present refs short; a tuning run that counts one rank's key share is partial by design)
             failures.append(f"refs_reported {reported} != refs_present {len(sample['present'])}")
         if out["config"]["result_digest"]["identical_over_untimed_steps"] is False:
             failures.append("result digests differ between untimed steps")

@@ -226,7 +226,12 @@ void rekey(BamColumns &c, uint64_t seed)
 //   inflate workers   take the BGZF members one by one off the front, so the inflated stream grows from the front; helpers
 //                     (a device) take batches off the back;
 //   the walker        one thread, started by load_bam_begin the moment the header's end is known: the record boundaries behind the
-//                     inflate front (serial: a record's size is its first word), published in steps of 4 096 records;
+//                     inflate front (serial: a record's size is its first word), published in steps of 4 096 records.  Round 6: the
+//                     inflate workers walk the stream SPECULATIVELY in segments of 1 MiB as the inflate front passes them (entry =
+//                     the first offset from which four plausible records chain; from there the walker's own rules), and the walker
+//                     adopts a segment's list from the moment its true position IS one of the list's record starts -- from the same
+//                     start the walk is the same function of the stream, so the result is the serial walk's, record for record; a
+//                     segment whose list the true walk never meets is walked serially as before;
 //   the decode        the inflate workers, as they run out of members, take chunks of 32 768 walked records and write their
 //                     columns (sized for the most records the stream can hold; pages behind the real ones are never touched);
 //   load_bam_begin    returns as soon as the members that hold the header are there and the header is parsed -- the caller
@@ -264,6 +269,48 @@ struct BamLoad : BackMembers {
     std::thread walker;
     std::string walk_error;
     void walk();
+    // ... and ahead of it, by the inflate workers: segment s = bytes [first_record + s * kSeg, + kSeg) of the inflated stream
+    static constexpr size_t kSeg = size_t{1} << 20, kSegSlack = size_t{1} << 16;
+    struct SpecSeg {
+        std::vector<uint64_t> rec;       // record starts (offset of the byte behind block_size) found from the guessed entry on, ascending
+        size_t exit = 0;                 // offset of the block_size word the walk of this segment ended in front of
+        bool stopped = false;            // ... because the stream ends or is malformed THERE (the serial walk stops there too)
+        std::atomic<int> state{0};       // 2: the list is complete
+    };
+    std::unique_ptr<SpecSeg[]> segs;
+    std::atomic<size_t> n_segs_pub{SIZE_MAX};      // SIZE_MAX: the header's end (where the records begin) is not known yet
+    std::atomic<size_t> next_seg{0};
+    std::atomic<int> spec_drainers{0};
+    size_t n_adopted = 0;                // records the walker took over from the segments' lists (the rest it walked itself)
+    bool speculate = true;
+    // bytes of the inflated stream that are final right now (never blocks)
+    size_t ready_prefix(size_t &ready_blocks) const
+    {
+        while (ready_blocks < blocks.size() && done[ready_blocks].load(std::memory_order_acquire)) ready_blocks++;
+        return ready_blocks < blocks.size() ? blocks[ready_blocks].out_off : c->raw.size();
+    }
+    // one step of THE walk at offset p, on the bytes [0, limit) of a stream of `total` bytes: 1 = a record (its start appended by
+    // the caller, *next = the offset behind it), 0 = the stream ends or is malformed here (the walk is over), -1 = not decidable
+    // on `limit` bytes yet.  The only place the record rules live: the walker and the speculation share it.
+    static int walk_step(const uint8_t *d, size_t p, size_t limit, size_t total, size_t *next)
+    {
+        if (p + 4 > total) return 0;
+        if (p + 4 > limit) return -1;
+        const size_t bs = le32(d + p);
+        if (bs < 32) return 0;                                        // truncated tail: stop like a failed sam_read1
+        if (p + 4 + bs > total) return 0;
+        if (p + 4 + bs > limit) return -1;
+        // the variable-length fields must fit the record (htslib's bam_read1 fails on such a record, which ends the
+        // reference's `while (sam_read1(...) >= 0)` loop at generate_graph.cpp:644): name, CIGAR, packed bases, qualities
+        const uint8_t *r = d + p + 4;
+        const size_t l_name = r[8], n_cig = le16(r + 12), l_seq = le32(r + 16);
+        if (l_name < 1 || l_seq > 0x7fffffffu || 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs) return 0;
+        *next = p + 4 + bs;
+        return 1;
+    }
+    bool plausible_chain(size_t p, size_t limit) const;
+    void spec_segment(size_t s, size_t limit);
+    void spec_some(size_t &cursor, bool drain);
     // the decode of the records into columns, pipelined behind the record walk (load_bam_finish): the walker publishes how many record
     // starts it has found, the loader's threads -- done with the inflate -- take chunks of records as they become known
     static constexpr size_t kChunk = 32768;
@@ -373,6 +420,7 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c, con
             z_stream zs{};
             if (inflateInit2(&zs, -15) != Z_OK) { ld->bad = true; return; }
             uint8_t *out = ld->c->raw.data();
+            size_t spec_cursor = 0;
             const bool use_fast = std::getenv("PALACE_BAM_ZLIB") == nullptr;          // PALACE_BAM_ZLIB=1: zlib for every member (A/B, tests)
             for (size_t i = 0; !ld->bad && ld->claim_front(&i);) {
                 const Block &k = ld->blocks[i];
@@ -387,8 +435,12 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c, con
                     if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) { ld->bad = true; break; }
                 }
                 ld->done[i].store(1, std::memory_order_release);
+                ld->spec_some(spec_cursor, false);                  // a segment the inflate front has passed, if nobody has taken it
             }
             inflateEnd(&zs);
+            // what is left of the segments, as the members of the helpers arrive: two of the threads (a segment is ~0.1 ms of walking; the
+            // others decode columns behind the walker meanwhile)
+            if (ld->spec_drainers.fetch_add(1) < 2) ld->spec_some(spec_cursor, true);
             ld->decode_chunks();
         });
     trh.lap("file mapped, members indexed, inflate threads started");
@@ -433,6 +485,11 @@ BamLoad *load_bam_begin(const std::string &path, int threads, BamColumns &c, con
         L->sa_part.resize(max_chunks);
         L->ms_part.resize(max_chunks);
         L->rec_at.reserve(ub);
+        L->speculate = std::getenv("PALACE_BAM_SERIAL_WALK") == nullptr;      // PALACE_BAM_SERIAL_WALK=1: the walker alone (A/B, tests)
+        const size_t n_segs = L->speculate && c.raw.size() > p ? (c.raw.size() - p + BamLoad::kSeg - 1) / BamLoad::kSeg : 0;
+        L->segs.reset(new BamLoad::SpecSeg[n_segs ? n_segs : 1]);
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        L->n_segs_pub.store(n_segs, std::memory_order_release);     // (the workers have been running since before the header was parsed)
         L->walker = std::thread([ld] { ld->walk(); });
     }
     // names, lengths and name hashes on the threads; the index itself is filled by this thread (hashes in hand)
@@ -477,25 +534,120 @@ void load_bam(const std::string &path, int threads, uint64_t key_seed, BamColumn
     load_bam_finish(load_bam_begin(path, threads, c), key_seed);
 }
 
+// a record could start at p: the fixed fields of four records in a row are what a record's are (stricter than the walk's own rules,
+// which decide nothing here: a wrong guess only costs its segment the speculation)
+bool BamLoad::plausible_chain(size_t p, size_t limit) const
+{
+    const uint8_t *d = c->raw.data();
+    for (int k = 0; k < 4; k++) {
+        if (p + 36 > limit) return false;
+        const size_t bs = le32(d + p);
+        if (bs < 32 || bs > (size_t{1} << 24) || p + 4 + bs > limit) return false;
+        const uint8_t *r = d + p + 4;
+        const int32_t tid = static_cast<int32_t>(le32(r)), pos = static_cast<int32_t>(le32(r + 4)), mtid = static_cast<int32_t>(le32(r + 20)),
+                      mpos = static_cast<int32_t>(le32(r + 24));
+        const size_t l_name = r[8], n_cig = le16(r + 12), l_seq = le32(r + 16);
+        if (tid < -1 || tid >= n_ref || mtid < -1 || mtid >= n_ref || pos < -1 || mpos < -1) return false;
+        if (l_name < 1 || l_seq > (size_t{1} << 28) || 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs) return false;
+        if (r[32 + l_name - 1] != 0) return false;                    // the read name is NUL-terminated
+        p += 4 + bs;
+    }
+    return true;
+}
+
+// the walk of segment s from a guessed entry, on the first `limit` bytes of the stream (final when the segment was taken)
+void BamLoad::spec_segment(size_t s, size_t limit)
+{
+    const uint8_t *d = c->raw.data();
+    const size_t total = c->raw.size(), seg_lo = first_record + s * kSeg, seg_hi = std::min(total, seg_lo + kSeg);
+    SpecSeg &sg = segs[s];
+    size_t p = seg_lo;
+    if (s > 0) {                                                      // (the first segment starts where the records do)
+        while (p < seg_hi && !plausible_chain(p, limit)) p++;
+    }
+    sg.exit = p;
+    if (p < seg_hi) {
+        sg.rec.reserve(kSeg / 160);
+        for (;;) {
+            size_t next = 0;
+            const int st = p < seg_hi ? walk_step(d, p, limit, total, &next) : -1;
+            if (st <= 0) { sg.stopped = st == 0; break; }
+            sg.rec.push_back(p + 4);
+            p = next;
+        }
+        sg.exit = p;
+    }
+    sg.state.store(2, std::memory_order_release);
+}
+
+// an inflate worker between two members (drain = false: at most one segment, only if the inflate front has passed it) or out of
+// members (drain = true: every segment nobody has taken, as the members of the helpers arrive)
+void BamLoad::spec_some(size_t &cursor, bool drain)
+{
+    for (;;) {
+        const size_t n = n_segs_pub.load(std::memory_order_acquire);
+        if (n == SIZE_MAX) {                                          // the header is still being read
+            if (!drain || bad) return;
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+            continue;
+        }
+        size_t s = next_seg.load(std::memory_order_relaxed);
+        if (s >= n) return;
+        const size_t need = std::min(c->raw.size(), first_record + (s + 1) * kSeg + kSegSlack);
+        const size_t have = ready_prefix(cursor);
+        if (have < need) {
+            if (!drain || bad) return;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+            continue;
+        }
+        if (!next_seg.compare_exchange_strong(s, s + 1)) continue;
+        spec_segment(s, have);
+        if (!drain) return;
+    }
+}
+
 void BamLoad::walk()
 {
     const uint8_t *d = c->raw.data();
+    const size_t total = c->raw.size();
     size_t cursor = 0;
     try {
-        size_t p = first_record, have = wait_for(p + 4, cursor), ahead = p & ~size_t{63};
+        size_t p = first_record, have = wait_for(std::min(total, p + 4), cursor), ahead = p & ~size_t{63};
+        const size_t n = n_segs_pub.load(std::memory_order_acquire) == SIZE_MAX ? 0 : n_segs_pub.load(std::memory_order_acquire);
+        size_t seg = 0;                                               // the segment p lies in (speculation on)
+        int misses = 0;                                               // serial steps in this segment that did not meet its list
         for (;;) {
-            if (p + 4 > have) { have = wait_for(p + 4, cursor); if (p + 4 > have) break; }
-            const size_t bs = le32(d + p);
-            if (bs < 32) break;                                       // truncated tail: stop like a failed sam_read1
-            if (p + 4 + bs > have) { have = wait_for(p + 4 + bs, cursor); if (p + 4 + bs > have) break; }
-            // the variable-length fields must fit the record (htslib's bam_read1 fails on such a record, which ends the
-            // reference's `while (sam_read1(...) >= 0)` loop at generate_graph.cpp:644): name, CIGAR, packed bases, qualities
-            const uint8_t *r = d + p + 4;
-            const size_t l_name = r[8], n_cig = le16(r + 12), l_seq = le32(r + 16);
-            if (l_name < 1 || l_seq > 0x7fffffffu || 32 + l_name + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs) break;
+            if (n) {
+                const size_t in = (p - first_record) / kSeg;
+                if (in != seg) { seg = in; misses = 0; }
+                // the true position is a record start of the segment's list: from here the list IS the walk
+                if (seg < n && misses < 64 && segs[seg].state.load(std::memory_order_acquire) == 2) {
+                    const SpecSeg &sg = segs[seg];
+                    const auto it = std::lower_bound(sg.rec.begin(), sg.rec.end(), static_cast<uint64_t>(p + 4));
+                    if (it != sg.rec.end() && *it == p + 4) {
+                        rec_at.insert(rec_at.end(), it, sg.rec.end());
+                        n_adopted += static_cast<size_t>(sg.rec.end() - it);
+                        n_walked.store(rec_at.size(), std::memory_order_release);
+                        p = sg.exit;
+                        if (sg.stopped) break;
+                        ahead = p & ~size_t{63};
+                        continue;
+                    }
+                    misses++;
+                }
+            }
+            size_t next = 0;
+            int st = walk_step(d, p, have, total, &next);
+            if (st < 0) {                                             // behind the inflate front: wait for the bytes the step needs
+                have = wait_for(std::min(total, p + 4), cursor);
+                if (p + 4 <= have) have = wait_for(std::min(total, p + 4 + static_cast<size_t>(le32(d + p))), cursor);
+                st = walk_step(d, p, have, total, &next);
+                if (st < 0) break;                                    // (everything that will ever come is there, and it is not enough)
+            }
+            if (st == 0) break;
             rec_at.push_back(p + 4);
             if ((rec_at.size() & 4095) == 0) n_walked.store(rec_at.size(), std::memory_order_release);
-            p += 4 + bs;
+            p = next;
             // the next few record heads lie in the kilobyte behind this one, not at a fixed stride (the hardware does not see a
             // stream): every line of that kilobyte is asked for as the walk exposes it
             for (const size_t upto = std::min(have, p + 1024); ahead + 64 <= upto; ahead += 64) __builtin_prefetch(d + ahead);
@@ -647,6 +799,8 @@ void load_bam_finish(BamLoad *load, uint64_t key_seed)
     L->decode_chunks();                                           // this thread helps with what is left
     for (auto &t : L->workers) t.join();                          // (members behind a malformed record are still inflated)
     tr.lap("inflate threads joined, columns decoded");
+    if (tr.on && L->speculate)
+        std::fprintf(stderr, "[bam] %zu of %zu record boundaries came from the segments walked ahead by the inflate threads\n", L->n_adopted, rec_at.size());
     if (tr.on && !L->as_members.empty())
         std::fprintf(stderr, "[bam] %zu of %zu members were inflated by helpers (device)\n", L->by_helpers.load(), L->blocks.size());
     if (L->bad) throw std::runtime_error("BGZF inflate failed");

@@ -58,9 +58,12 @@ def key_buckets_of(rank: int, world: int):
 MODEL = dict(reads_measured=6_666_666, count_all_ms=8.2, key_fixed_ms=2.35, key_shared_ms=5.95, three_planes_factor=1.03,
              exchange_passes_ms=1.1, repack_ms=0.25, collective_latency_ms=0.05, link_gbs=50.0, plane_bytes=1 << 29,
              sparse_keys_per_read=3.6, sparse_pack_ms=0.1, sparse_unpack_ms=0.15,
-             # end of round 5 (shard_counts): the count launch with every entry set probed inside (8.3 ms, of which ~0.25 ms is the DB's
-             # 1.3 GB of entries -- read by every rank whatever its share of the reads), the hit-bit block of the 200 Mb DB, the sum pass
-             count_fused_ms=8.05, entry_probe_fixed_ms=0.25, entry_hits_bytes=81.5e6, entry_sum_ms=0.05)
+             # shard_counts, MEASURED in round 6 on one GPU as rank 1 of W (tools/counts_share_diag.sh, profiles/r06b_counts_share.log: the count
+             # launch of a 1/W share of the reads with every entry of the WHOLE DB's index probed inside, stage 04 beside it): 5.01 / 3.15 /
+             # 2.28 / 2.13 ms for W = 2 / 4 / 7 / 8 = 1.25 + 7.3 / W -- the fixed part is what every rank does whatever its share (the DB's
+             # 1.3 GB of entries read and tested against every fine bucket's slice, 65 536 workgroups, the partition kernels' tails); round
+             # 5 had modelled it as 0.25 + 8.05 / W.  The sum pass over a rank's share of the W count blocks: 0.12 ms.
+             count_fused_ms=7.3, entry_probe_fixed_ms=1.25, entry_hits_bytes=81.5e6, entry_sum_ms=0.12)
 
 
 def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None, sparse: bool = True, entry_counts: bool = False) -> dict:
@@ -104,7 +107,7 @@ def phase_a_model(n_reads: int, world: int, link_gbs: float | None = None, spars
 # Round 5: with the decomposition's phases on 2048 workgroups (the library's default; the one-GPU bench keeps 256, where the step is
 # stream A's length and the shorter, denser burst costs the count launch more) stage 04 takes 2.75 ms beside a count launch at 1M
 # contigs, 0.8 ms alone -- on N GPUs rank 0's stream B is the longer stream once Phase A is sharded, so it runs wide there.
-STEP = dict(reset_ms=0.1, phase_b_fixed_ms=0.15, phase_b_ms=0.92, phase_b_counts_fixed_ms=0.2, phase_b_counts_ms=0.55, phase_b_counts_dense_fixed_ms=1.3, phase_b_counts_dense_ms=2.8, classify_ms=0.45, resolve_ms=0.37, small_collective_ms=0.1,
+STEP = dict(reset_ms=0.1, phase_b_fixed_ms=0.15, phase_b_ms=0.92, phase_b_counts_fixed_ms=0.25, phase_b_counts_ms=0.58, phase_b_counts_dense_fixed_ms=1.3, phase_b_counts_dense_ms=2.8, classify_ms=0.45, resolve_ms=0.37, small_collective_ms=0.1,
             stage04_alone_ms=(0.5, 0.3), stage04_beside_count_ms=(1.0, 3.4), stage04_beside_count_wide_ms=(0.6, 2.15))   # (fixed, per 1M contigs)
 
 
