@@ -45,24 +45,6 @@ def parse_args():
     ap.add_argument("--reads", choices=("packed", "ascii"), default="packed",
                     help="form of the reads resident in HBM: packed = two bits per base + 32-mer start mask (what the eref executable's "
                          "parser threads produce; palace_eref_count_reads_packed), ascii = a byte per base (palace_eref_count_reads)")
-    ap.add_argument("--batches-in-flight", type=int, choices=(1, 2), default=1,
-                    help="one GPU: 2 = the k-mer table is double-buffered and the counting kernels of a step run beside Phase B of the step "
-                         "before (its rows are fetched one step later): 10.4 instead of 11.1 ms per step, but the count launch then shares the "
-                         "device and its own duration -- the roofline figure -- grows from 9.2 to 10.3 ms; 1 (default) = every step drains "
-                         "before the next, the count launch is timed with only this step's generateGraph stream beside it")
-    ap.add_argument("--fused-probe", type=int, choices=(0, 1, 2), default=2,
-                    help="1: Phase B's channel-0 probe rides along in the count kernel (palace_eref_attach_probe_index: 2 B per DB position "
-                         "tested against each fine bucket's '>= 3' slice while it is in LDS): the count launch 0.1 ms longer, Phase B 0.2 ms shorter "
-                         "(1.16 against 1.36 ms), and `roofline` counts those look-ups (1 B per ref position) as work of the launch; 0: the count "
-                         "launch is Phase A alone and the scan probes for itself; 2 (default): ALL of Phase B's look-ups ride along (the index's four entry sets) and "
-                         "the '>= 3' plane is never written -- no slice write-back, no probe kernel, no reset before the next step (option probe_all_sets)")
-    ap.add_argument("--graph-lag", type=int, choices=(0, 1), default=0,
-                    help="1: the graph result of a step (stage 04's decomposition) is collected at the START of the next step -- a two-deep "
-                         "pipeline of stream B, as a resident service would submit sample i+1 before it reads sample i's paths; with "
-                         "--stage04-hold l2 the matching rounds then run beside the count kernel and Phase B only and the step is stream A's "
-                         "length.  0 (default): every step collects its own result before it ends")
-    ap.add_argument("--stage04-hold", choices=("0", "l1", "l2", "1"), default="0",
-                    help="hold stage 04's matching rounds back until level 1 of the count launch (l1), its partition kernels (l2) or the whole launch (1) are done")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files -> files leg (CLI chain on generated files)")
     ap.add_argument("--soak-seconds", type=float, default=2.0,

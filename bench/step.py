@@ -57,46 +57,34 @@ def measure(args, E, leg):
 
     hdr = coder.header_from_picks(np.random.Generator(np.random.PCG64(SEED)).integers(0, 6, size=32))
     # Streams.  A: eref (count + scan).  B: generateGraph (classify, resolve, copy numbers) and stage 04 (selection + matching: ~150
-    # small latency-bound launches), high priority.  Stage 04 beside the saturating counting kernels takes 5.4 ms instead of the
-    # 1.4 ms it takes alone and costs the count launch ~1 ms.  Measured in round 4 (tools/cu_mask_ab.sh, tools/archive/r04c-e.sh; DESIGN.md
-    # section 4): confining stage 04 to a CU subset (hipExtStreamCreateWithCUMask; PALACE_BENCH_STAGE04_CUS=n puts it on a stream S
-    # of its own on the first n CUs, and keeps stream A off them) does not help -- on 32 CUs of its own it still takes 7.2 ms
-    # (it is slowed by the memory system the counting kernels saturate, not by the CUs they occupy), the step is 10.9 ms either
-    # way; holding it back behind the partition kernels or the whole count launch (PALACE_BENCH_STAGE04_LATE=l2|1) puts it on the
-    # critical path (11.3 / 11.7 ms).  Default: stage 04 on stream B.
+    # small latency-bound launches), high priority.  Stage 04 beside the saturating counting kernels takes ~3.5 ms instead of the ~1.1 ms
+    # it takes alone and costs the count launch ~0.6 ms; confining it to CUs of its own, holding its rounds back behind the partition
+    # kernels or the count launch, capturing it as hipGraphs and a two-deep pipeline of stream B were all measured in rounds 3-5 and
+    # none shortened the step (profiles/HISTORY.md); the knobs went in round 6.
     # With collectives (N GPUs) A and B are torch streams the contexts run on (palace_ctx_create_on_stream), so that
     # torch.distributed's collectives are stream-ordered with the library's kernels and nothing waits on the host.
-    mask_of = lambda k: int(os.environ[k], 16) if os.environ.get(k) else None      # tuning runs: PALACE_BENCH_CU_MASK_A / _B (hex)
-    s04_cus = int(os.environ.get("PALACE_BENCH_STAGE04_CUS", "0"))
     if collectives:
         sA, sB = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1)
         ctx, ctx_g = capi.Ctx(local, stream=sA.cuda_stream), capi.Ctx(local, stream=sB.cuda_stream)
     else:
-        mask_a = mask_of("PALACE_BENCH_CU_MASK_A")
-        if mask_a is None and 0 < s04_cus < 256 and os.environ.get("PALACE_BENCH_EXCLUDE_A", "1") == "1":
-            mask_a = ((1 << 256) - 1) ^ ((1 << s04_cus) - 1)         # the eref stream keeps off stage 04's compute units
-        ctx = capi.Ctx(local, cu_mask=mask_a)
-        ctx_g = capi.Ctx(local, high_priority=os.environ.get("PALACE_BENCH_PRIO", "1") == "1", cu_mask=mask_of("PALACE_BENCH_CU_MASK_B"))
-    ctx_s = capi.Ctx(local, cu_mask=(1 << s04_cus) - 1) if 0 < s04_cus < 256 else ctx_g
-    if os.environ.get("PALACE_BENCH_GRAPHS", "0") == "1":     # stage 04 as two hipGraph launches per step (measured: host enqueue 1.25 -> 0.96 ms,
-        ctx_s.match_set_option("launch_graphs", 1)            # the step 10.95 -> 11.08 ms: back to back the small kernels disturb the counting kernels more)
+        ctx, ctx_g = capi.Ctx(local), capi.Ctx(local, high_priority=True)
+    ctx_s = ctx_g
     # the decomposition's arc- and vertex-sized phases on 256 workgroups here (the library's default is 2048: stage 04 alone on the
     # device then takes 0.8 instead of 1.4 ms, beside the counting kernels 2.75 instead of 4.4 ms -- but as a shorter, denser burst of
     # random atomics it costs the count launch 1.05 ms instead of 0.7, and the step is stream A's length: 10.1 against 9.86 ms, A/B
     # on one box, tools/ab.sh r05d)
     if world == 1 or solo:                          # (N GPUs: rank 0's stream B is the longer stream once Phase A is sharded: the library's 2048)
         ctx_s.match_set_option("decomp_grid", 256)
-    for opt in ("iters_per_round", "first_group_rounds", "decomp_grid", "one_word_keys"):    # tuning runs only
+    for opt in ("iters_per_round", "decomp_grid", "one_word_keys"):    # tuning runs only
         if os.environ.get("PALACE_OPT_" + opt.upper()):
             ctx_s.match_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
-    # one GPU: a second eref context (own stream, own count table, own scratch) so that consecutive batches overlap
-    depth = args.batches_in_flight if not collectives else 1
-    ectx = [ctx] + [capi.Ctx(local) for _ in range(depth - 1)]
-    for e in ectx:
+    # (a second eref context with a count table of its own, so that a step's counting kernels run beside the step before's Phase B --
+    # --batches-in-flight 2 of rounds 3-5 -- bought 6 % while Phase B was 1.5 ms and distorted the count launch's own duration; with Phase B
+    # inside the count launch there is 0.6 ms left to hide.  Removed in round 6.)
+    for e in (ctx,):
         e.eref_set_coder(hdr)
-        for opt in ("slab_bases", "bin1_ppl", "level1_parts"):        # tuning runs only (tools/): PALACE_OPT_BIN1_PPL=5 python bench.py
-            if os.environ.get("PALACE_OPT_" + opt.upper()):
-                e.eref_set_option(opt, int(os.environ["PALACE_OPT_" + opt.upper()]))
+        if os.environ.get("PALACE_OPT_SLAB_BASES"):       # tuning runs only
+            e.eref_set_option("slab_bases", int(os.environ["PALACE_OPT_SLAB_BASES"]))
         if os.environ.get("PALACE_OPT_KEY_SHARE"):    # tuning runs only: count the share rank 0 of N would (results are then partial)
             e.eref_set_key_buckets(multigpu.key_buckets_of(0, int(os.environ["PALACE_OPT_KEY_SHARE"])))
     # Phase A across ranks, three schemes (palace_amd/multigpu.py phase_a_model; none measured on more than
@@ -247,15 +235,6 @@ def measure(args, E, leg):
     else:
         capi._check(L.palace_eref_probe_index_build(ctx.h, P(sample["ref_bases"]), P(ref_off_local), r_hi - r_lo,
                                                     sample["ref_total"], ctypes.byref(probe_index)), "probe index")
-    # the count launch of a step is its final count (below): with --fused-probe 1 (or PALACE_BENCH_FUSED_PROBE=1) channel 0 of Phase B
-    # rides along in the count kernel while each fine bucket's ">= 3" slice is in LDS (palace_eref_attach_probe_index)
-    # --fused-probe 2 (round 5): ALL of Phase B's look-ups ride along (the index's four entry sets) and the '>= 3' plane is never written
-    # -- no slice write-back, no probe kernel, no reset of the plane before the next step (option probe_all_sets)
-    fused_mode = int(os.environ.get("PALACE_BENCH_FUSED_PROBE", str(args.fused_probe))) if depth == 1 else 0
-    fused_probe, fused_all = fused_mode >= 1 or shard_counts, fused_mode == 2 and not shard_counts
-    if fused_probe:
-        capi._check(L.palace_eref_attach_probe_index(ctx.h, probe_index), "attach probe index")
-
     # the reads in the form the step counts them from (resident before the timed region, like every other input)
     packed = None
     if args.reads == "packed":
@@ -267,12 +246,20 @@ def measure(args, E, leg):
         ctx.sync()
     # one GPU (and N GPUs that each count all reads): the count of a step is the only one between its reset and its scan, so the
     # two lower planes of the table need not leave the LDS (include/palace_hip.h, option final_count)
-    final_count = not shard_reads and os.environ.get("PALACE_BENCH_FINAL", "1") == "1"      # (=0: A/B runs)
+    final_count = not shard_reads
     # key split: rank r counts only the keys of ITS 1/W of the key space (they are dropped where they are made: the partition
     # kernels move 1/W of the bytes, the key arithmetic stays) and the ">= 3" plane slices are all-gathered -- one collective of
     # 512 MiB / W per rank instead of the table exchange
     key_split = bool(exch) and scheme == "key_split"
-    fused_all = fused_all and final_count and not key_split and not shard_reads     # (whoever exchanges plane slices afterwards needs the plane)
+    # The count launch of a step is its final count, so ALL of Phase B's look-ups ride along in the count kernel (the index's four entry
+    # sets tested against each fine bucket's ">= 3" slice while it is in LDS: palace_eref_attach_probe_index + option probe_all_sets) and
+    # the plane is never written -- no slice write-back, no probe kernel, no reset before the next step.  Not for the ranks of a key
+    # split or a plane exchange: whoever exchanges plane slices afterwards needs the plane, and probes it in the scan.
+    fused_all = final_count and not key_split and not shard_reads and not shard_counts
+    fused_probe = fused_all or shard_counts
+    fused_mode = 2 if fused_all else 0                     # (the field profiles/phase_a_traffic.json is keyed by)
+    if fused_probe:
+        capi._check(L.palace_eref_attach_probe_index(ctx.h, probe_index), "attach probe index")
     if fused_all:
         capi._check(L.palace_eref_set_option(ctx.h, b"probe_all_sets", 1), "probe_all_sets")
     ec = None
@@ -288,37 +275,22 @@ def measure(args, E, leg):
         capi._check(L.palace_eref_set_option(ctx.h, b"scan_ref_hi", r_hi), "scan_ref_hi")
     if key_split:
         ctx.eref_set_key_buckets(multigpu.key_buckets_of(rank, world))       # mirrored pairs of buckets: equal key mass per rank
-    for e in ectx:
-        e.eref_set_option("final_count", 1 if final_count else 0)
-        if os.environ.get("PALACE_BENCH_STAGE04_LATE", args.stage04_hold) == "l2":
-            e.eref_set_option("mark_before_count_kernel", 4091)
-        if os.environ.get("PALACE_BENCH_STAGE04_LATE", args.stage04_hold) == "l1":
-            e.eref_set_option("mark_before_level2", 4091)
-    rows_l = [rows] + [torch.zeros_like(rows) for _ in range(depth - 1)]
-    rows_host_l = [rows_host] + [torch.zeros((n_refs, 4), dtype=torch.int32).pin_memory() for _ in range(depth - 1)]
-    seq = {"n": 0, "pending": None, "counted": None, "last": 0, "of_timed": {}}           # running batch number; the batch whose rows are still on their way
+    ctx.eref_set_option("final_count", 1 if final_count else 0)
+    seq = {}
 
     # Timing marks.  One GPU, one batch in flight: the marks of a step are read at the step's end -- every stream has drained by then, the
     # reads do not wait -- and the next step but one reuses them: 16 marks per context in all.  (With a mark of its own per step and
     # stream the enqueueing thread's turn-around between two steps grew with the number of events alive: 0.36 ms at 30 steps, 0.88 at
     # 100 -- time the instrumentation cost the steps it measures.)  Everything else keeps a mark per step, read after the timed region.
-    harvest = depth == 1 and not args.graph_lag and not collectives and not os.environ.get("PALACE_BENCH_DIAG_SKIP") and not os.environ.get("PALACE_BENCH_SKIP_EREF")
+    harvest = not collectives and not os.environ.get("PALACE_BENCH_DIAG_SKIP") and not os.environ.get("PALACE_BENCH_SKIP_EREF")
     acc = {k: [] for k in ("count", "merge", "scan", "between", "classify", "resolve", "stage04")}
 
     def step(i, timed):
         m = 8 * (i & 1) if harvest else 8 * i
         tot_b = n_side * READ_LEN
-        slot = seq["n"] % depth                        # which eref context / rows buffers this batch uses
-        seq["n"] += 1
-        ctx, rows, rows_host = ectx[slot], rows_l[slot], rows_host_l[slot]
-        if timed: seq["of_timed"][i] = slot
         # ---------------- eref: runs asynchronously on its own stream ----------------
         def eref_head():
             capi._check(L.palace_eref_table_reset(ctx.h), "reset")
-            if depth > 1 and seq["counted"] is not None:
-                # this batch's counting kernels start when the previous batch's are done (two count launches side by side would
-                # only share the device); what then runs beside them is the previous batch's Phase B
-                ctx.wait_for_mark(ectx[seq["counted"]], 4095)
             if timed: ctx.mark(m)
             # both FASTQ sides as one read set: one binning pass, the plane slices are loaded and stored once
             if packed:
@@ -326,8 +298,6 @@ def measure(args, E, leg):
             else:
                 capi._check(L.palace_eref_count_reads(ctx.h, P(sample["r12"]), P(sample["read_off"]), 2 * n_side, None, 2 * tot_b), "count")
             if timed: ctx.mark(m + 1)
-            ctx.mark(4095)                             # "the counting kernels are done" (the next batch's, and a held-back stage 04, wait for it)
-            seq["counted"] = slot
 
         skip_eref = os.environ.get("PALACE_BENCH_SKIP_EREF") == "1"      # tuning runs only: stream B alone on the device
         if not skip_eref:
@@ -376,8 +346,6 @@ def measure(args, E, leg):
         # enqueued: classify -> resolve (edge count stays on the device) -> copy numbers -> filter_graph.py's selection ->
         # matching on the filtered graph, all in HBM.
         g = ctx_g
-        if seq.get("graph_pending"):                   # --graph-lag 1: the step before's decomposition is collected now, with this step's
-            seq.pop("graph_pending")()                 # counting kernels already enqueued (stage 04's buffers are then free for this step)
         th0 = time.perf_counter()
         if timed: g.mark(m)
         capi._check(L.palace_memset(g.h, P(consumed), 0, nt * 8), "memset")
@@ -420,31 +388,15 @@ def measure(args, E, leg):
             with on_b():
                 exch.reduce_sum(consumed)
         capi._check(L.palace_graph_copy_numbers(g.h, P(consumed), P(gs["tlen"]), nt, gs["avg_depth"], P(cn_dev)), "cn")
-        if ctx_s is not g and stage04 is not None:  # stage 04 has a stream of its own: it starts when the copy numbers are there
-            g.mark(4092)
-            ctx_s.wait_for_mark(g, 4092)
         if timed: g.mark(m + 2); ctx_s.mark(m + 2)
         if stage04 is not None:                     # rank 0 owns the (small) stage; its result is what the sample's all_result holds
-            # Stage 04 is ~150 small latency-bound launches beside the bandwidth-bound counting kernels; each costs those kernels a
-            # few microseconds (kernel boundaries write back the L2 lines the partition kernels combine their stores in): about
-            # 1 ms per step, measured.  Holding the rounds back until the counting kernels are done (PALACE_BENCH_STAGE04_LATE=1:
-            # palace_stage04_match_after) leaves those undisturbed but puts the rounds on the critical path -- 14.8 against 12.8 ms.
-            late = os.environ.get("PALACE_BENCH_STAGE04_LATE", args.stage04_hold) if not exch and not skip_eref else "0"
             # (diagnosis only, timed steps only -- the line then fails its own checks on purpose: PALACE_BENCH_DIAG_SKIP=stage04|match
             # leaves stage 04 / its matching rounds out, to see what they cost the counting kernels beside them)
             diag_skip = os.environ.get("PALACE_BENCH_DIAG_SKIP") if timed else None
             if diag_skip != "stage04":
                 stage04.filter(P(e_buf), P(n_edges_dev), max(1, n_cands))
-            if diag_skip and os.environ.get("PALACE_BENCH_DISTURB"):                  # "mode:ops:launches:slots:blocks"
-                dm, dops, dl, dslots, dblk = (int(x) for x in os.environ["PALACE_BENCH_DISTURB"].split(":"))
-                if "disturb_buf" not in seq:
-                    seq["disturb_buf"] = torch.full((dslots,), -1, dtype=torch.int64, device=dev)
-                    torch.cuda.synchronize()
-                capi._check(L.palace_diag_disturb(ctx_s.h, P(seq["disturb_buf"]), dslots, dops, dm, dl, dblk), "disturb")
-            # ("1": the rounds wait for the whole count launch; "l2": for its partition kernels -- they then run beside the count
-            # kernel and Phase B only)
             if diag_skip is None:
-                stage04.match(P(e_buf), P(cn_dev), 10, False, True, after=(ctx, 4095) if late == "1" else (ctx, 4091) if late in ("l1", "l2") else None)
+                stage04.match(P(e_buf), P(cn_dev), 10, False, True)
         if timed: ctx_s.mark(m + 3)
         th1 = time.perf_counter()
         if timed:
@@ -487,30 +439,19 @@ def measure(args, E, leg):
 
         if exch and not skip_eref:
             eref_tail()                                # the plane exchange / gather, Phase B and the row gather, all enqueued on stream A
-        if args.graph_lag and not exch:
-            seq["graph_pending"] = finish_graph
-        else:
-            finish_graph()
+        finish_graph()
         # ---------------- join: eref results to the host ----------------
-        # the rows of THIS batch are requested; with two batches in flight the ones waited for are the previous batch's (whose
-        # Phase B ran beside this batch's counting kernels), with one they are this batch's
         capi._check(L.palace_d2h_async(ctx.h, rows_host.data_ptr(), P(rows), rows.numel() * 4), "d2h")
         ctx.mark(4094)
-        if depth == 1:
-            ctx.mark_wait(4094)
-            if timed and harvest:
-                acc["count"].append(ctx.mark_elapsed(m, m + 1)); acc["merge"].append(ctx.mark_elapsed(m + 1, m + 2)); acc["scan"].append(ctx.mark_elapsed(m + 2, m + 3))
-                if i > 0: acc["between"].append(ctx.mark_elapsed(8 * ((i - 1) & 1) + 3, m))
-                acc["classify"].append(ctx_g.mark_elapsed(m, m + 1)); acc["resolve"].append(ctx_g.mark_elapsed(m + 1, m + 2))
-                acc["stage04"].append(ctx_s.mark_elapsed(m + 2, m + 3))
-            if not timed:
-                seen["rows"].add(hashlib.sha256(rows_host.numpy().tobytes()).hexdigest()[:16])
-                seen["steps"] += 1
-        else:
-            if seq["pending"] is not None:
-                ectx[seq["pending"]].mark_wait(4094)
-            seq["pending"] = slot
-        seq["last"] = slot
+        ctx.mark_wait(4094)
+        if timed and harvest:
+            acc["count"].append(ctx.mark_elapsed(m, m + 1)); acc["merge"].append(ctx.mark_elapsed(m + 1, m + 2)); acc["scan"].append(ctx.mark_elapsed(m + 2, m + 3))
+            if i > 0: acc["between"].append(ctx.mark_elapsed(8 * ((i - 1) & 1) + 3, m))
+            acc["classify"].append(ctx_g.mark_elapsed(m, m + 1)); acc["resolve"].append(ctx_g.mark_elapsed(m + 1, m + 2))
+            acc["stage04"].append(ctx_s.mark_elapsed(m + 2, m + 3))
+        if not timed:
+            seen["rows"].add(hashlib.sha256(rows_host.numpy().tobytes()).hexdigest()[:16])
+            seen["steps"] += 1
         if exch:
             g.mark(4093)
             g.mark_wait(4093)                          # stream B has drained on every rank (only rank 0 waited for a stage-04 result)
@@ -532,11 +473,7 @@ def measure(args, E, leg):
             gat["width"] = max(gat["width"], (max(cnt) + max(cnt) // 8 + 256) // 256 * 256)
 
     def barrier():
-        if seq.get("graph_pending"):
-            seq.pop("graph_pending")()
-        for e in ectx:
-            e.sync()
-        seq["pending"] = None
+        ctx.sync()
         ctx_g.sync()
         ctx_s.sync()
         torch.cuda.synchronize()
@@ -587,16 +524,16 @@ def measure(args, E, leg):
         if os.environ.get("PALACE_BENCH_SKIP_EREF") == "1":
             count_each, count_ms, merge_ms, scan_ms, between_ms = [1.0], 1.0, 0.0, 0.0, None
         else:
-            E = lambda i: ectx[seq["of_timed"][i]]                                      # the context timed step i ran on
+            E = lambda i: ctx
             count_each = [E(i).mark_elapsed(8 * i, 8 * i + 1) for i in K]
             count_ms = np.mean(count_each)                                              # one launch per step (both FASTQ sides)
             merge_ms = np.mean([E(i).mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
             scan_ms = np.mean([E(i).mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
-            between_ms = float(np.mean([E(i).mark_elapsed(8 * i + 3, 8 * (i + 1)) for i in range(args.steps - 1)])) if depth == 1 and args.steps > 1 else None
+            between_ms = float(np.mean([E(i).mark_elapsed(8 * i + 3, 8 * (i + 1)) for i in range(args.steps - 1)])) if args.steps > 1 else None
         classify_ms = np.mean([ctx_g.mark_elapsed(8 * i, 8 * i + 1) for i in K])
         resolve_ms = np.mean([ctx_g.mark_elapsed(8 * i + 1, 8 * i + 2) for i in K])
         stage04_ms = np.mean([ctx_s.mark_elapsed(8 * i + 2, 8 * i + 3) for i in K])
-    r = rows_host_l[seq["last"]].numpy()
+    r = rows_host.numpy()
     reported = int(((r[:, 1] > 0) & (r[:, 1].astype(np.float32) / r[:, 2].astype(np.float32) > 0.75)).sum())
 
     failures, out = [], None
@@ -607,8 +544,8 @@ def measure(args, E, leg):
     if rank == 0:
         L.palace_version.restype = ctypes.c_char_p
         version = L.palace_version().decode()
-        fused_now = fused_probe and final_count and not key_split
-        traffic, traffic_src, stage_traffic = profiled_traffic(args, world, version, (2 if fused_all else 1) if fused_now else 0)
+        fused_now = fused_all
+        traffic, traffic_src, stage_traffic = profiled_traffic(args, world, version, fused_mode)
         alg_bytes = (READ_LEN + 6 * (READ_LEN - 31)) * 2 * n_side        # per launch (both FASTQ sides of this rank)
         # when Phase B's channel-0 probe rides along in the count kernel, its look-ups (1 B per ref position) are work of this launch
         fused_sets = 0 if not fused_now else (3 if fused_all else 1)         # channels of Phase B's look-ups the count launch does
@@ -623,7 +560,6 @@ def measure(args, E, leg):
                                    f"{2 * sample['n_pairs_total']} reads x {READ_LEN} bp, {gs['n_total']} primary BAM records, "
                                    f"{gs['n_fastg']} FASTG links",
                        "stages": ["eref", "generateGraph", "matching"], "seed": SEED, "workload_kind": args.workload,
-                       "batches_in_flight": depth, "graph_lag": args.graph_lag, "stage04_hold": args.stage04_hold,
                        "reads": ("packed in HBM: two bits per base + 32-mer start mask, 0.375 B/base (palace_eref_count_reads_packed)" if packed else
                                  "ASCII in HBM, 1 B/base (palace_eref_count_reads)") + ("; count keeps only the '>= 3' plane (final_count)" if final_count else ""),
                        "parallelism": "1 GPU" if world == 1 else (f"reads/records/refs sharded over {world} GPUs (RCCL)" + ("; the ranks exchange partial counts of the DB's probe-index entries, no plane crosses a link" if shard_counts else "")
@@ -753,10 +689,6 @@ def measure(args, E, leg):
     capi._check(L.palace_eref_probe_index_free(ctx.h, probe_index), "probe index free")
     if stage04 is not None:
         stage04.close()
-    for e in ectx[1:]:
-        e.close()
-    if ctx_s is not ctx_g:
-        ctx_s.close()
     ctx.close()
     ctx_g.close()
     if solo:

@@ -40,9 +40,6 @@ int palace_ctx_create(int device, palace_ctx **out);
 /* same, with the context's stream at the device's highest priority when high_priority != 0 (for
  * small latency-bound work that runs beside bulk kernels of another context) */
 int palace_ctx_create_prio(int device, int high_priority, palace_ctx **out);
-/* The same with the stream confined to the compute units whose bit is set in cu_mask (n_words x 32 bits; NULL / 0 = no mask):
- * a stream of many small latency-bound launches beside a saturating launch on another stream keeps CUs of its own. */
-int palace_ctx_create_masked(int device, int high_priority, const uint32_t *cu_mask, int n_words, palace_ctx **out);
 /* A context on the CALLER's stream (a hipStream_t): every call of the context enqueues there, so the caller's own work on that
  * stream -- collectives, copies -- is ordered with the library's kernels without events or waits.  The stream is not
  * destroyed with the context. */
@@ -135,10 +132,6 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
  * atomics for tiny ones), 1 = always direct, 2 = always partitioned; bucket_cap > 0 overrides the per-bucket capacity
  * of the partitioned path (keys beyond it take the direct path).  set_option(name, value):
  *   "slab_bases"  positions per slab that large read sets are processed in (multiple of 64; 0 = default 2^30 / 2^31)
- *   "bin1_ppl"    read positions per lane of the first partition kernel (4, 5, 6 or 8; 0 = by key density)
- *   "level1_parts" parts per slab in which the first partition kernel works, on a second stream, beside the second partition
- *                 kernel of the part before (0 or 1 = one part, everything on the context's stream: the default, and the faster
- *                 choice where measured).  The call stays stream-ordered: what follows it on the context's stream sees the finished table.
  *   "final_count" 1: every count call from now on is the ONLY one between palace_eref_table_reset and the scan.  Phase B
  *                 reads nothing but the "count >= 3" plane (the slide tests `== least_depth`, extract_ref.cpp:23, :531, of a count that
  *                 saturates there, :995), so such a
@@ -155,10 +148,7 @@ int palace_eref_count_reads_packed(palace_ctx *ctx, const uint32_t *d_p0, const 
  *                 other call that reads or extends the table fails.  2: the same, but what is left per entry is its partial COUNT (a rank
  *                 that counted a share of the reads: see palace_eref_entry_layout).  0: off (default).
  *   "scan_ref_lo", "scan_ref_hi"  palace_eref_scan_refs_indexed works on the refs [lo, hi) only (hi = 0: all); the rows of the others
- *                 read n_intervals = el = 0.
- *   "mark_before_count_kernel" i >= 0: a binned count call records palace_mark(ctx, i) between its partition kernels and its
- *                 count kernel (another stream can hold work back until then: palace_wait_for_mark); -1: none (default).
- *   "mark_before_level2" i >= 0: the same between level 1 and level 2 of the call's last part; -1: none (default). */
+ *                 read n_intervals = el = 0. */
 int palace_eref_set_count_mode(palace_ctx *ctx, int mode, int64_t bucket_cap);
 /* The count calls that follow take in only the keys whose top 7 bits -- one of 128 buckets of the key space -- are in the set
  * (bit b of mask128 = bucket b; default all).  For N GPUs that each hold all reads (the reference's threads share one table,
@@ -472,17 +462,11 @@ typedef struct palace_match_result palace_match_result;
  * iterations behind a round's fixed point return at once); the host looks at the state after each group, stops as soon as no
  * segment keeps a copy, and redoes the decomposition with a check after every batch of iterations should a round not have
  * settled.  "iters_per_round" overrides the number of iterations (0 = defaults, at most 64; 1 forces the checked path);
- * "launch_graphs" 1: palace_stage04_filter / _match capture their launch sequences (about 10 and 160 kernels with fixed grids
- * that read their counts from device memory) as hipGraphs at the first call with a set of arguments and replay them while the
- * arguments -- edge array, copy numbers, iterations, flags -- stay the same: for a resident caller that runs sample after
- * sample through the same buffers.  0 (default): plain launches (a one-shot process would only pay for the capture).
  * "decomp_grid" workgroups of the decomposition's arc- and vertex-sized phases (0 = default 2048: chains of dependent random
  * look-ups, bounded by how many are in flight; 256 costs a saturating kernel on another stream less, see bench/step.py).
  * "one_word_keys" 0: palace_stage04_match ranks its arcs by the two-word key in every case (default 1: by a one-word form of
  * the same order -- weight | path-backed | class of (tail, head) -- whenever the sample's arcs fit it, which saves the second
- * proposal pass of every matching iteration: half of the atomics and a third of the look-ups).
- * "first_group_rounds" the rounds enqueued before the first look at the state (0 = default 5; fewer launches beside other
- * work, one host round trip more when a second round is needed: no effect on the step time where measured). */
+ * proposal pass of every matching iteration: half of the atomics and a third of the look-ups). */
 int palace_match_set_option(palace_ctx *ctx, const char *name, int64_t value);
 int palace_match_decompose(palace_ctx *ctx, int32_t n_segs, const int64_t *copies, int64_t n_arcs,
                            const int32_t *src, const int32_t *dst, int32_t iterations, int32_t aggressive,
@@ -555,12 +539,6 @@ int palace_stage04_counts(palace_ctx *ctx, palace_stage04 *s, int64_t counts[8])
  * aggressive per filter call's reservation). */
 int palace_stage04_match(palace_ctx *ctx, palace_stage04 *s, const palace_graph_edge *d_edges, const int32_t *d_cn,
                          int32_t iterations, int32_t aggressive, int32_t use_paths);
-/* The same, with the rounds of the decomposition -- a few hundred small, latency-bound launches -- starting only when mark
- * `mark` of context `other` has been reached on the device (palace_wait_for_mark); the arcs are built at once.  For a caller
- * that runs bandwidth-bound kernels on another stream (eref's counting kernels): every kernel boundary beside them costs
- * them microseconds, beside small kernels it costs nothing. */
-int palace_stage04_match_after(palace_ctx *ctx, palace_stage04 *s, const palace_graph_edge *d_edges, const int32_t *d_cn,
-                               int32_t iterations, int32_t aggressive, int32_t use_paths, palace_ctx *other, int32_t mark);
 /* Waits and hands out the result in the compact form of palace_match_decompose_ex (vertices 2 * segment + orientation,
  * segments = ids of the filtered graph; bare segments as bits), owned by `s` (valid until the next match call or destroy;
  * palace_match_result_free on it does nothing), and contig_of[filtered segment] -> contig (n_segs_filtered entries). */

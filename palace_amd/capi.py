@@ -65,7 +65,6 @@ assert CAND_DTYPE.itemsize == 64 and EDGE_DTYPE.itemsize == 32 and SA_ITEM_DTYPE
 _SIGS = {
     "palace_ctx_create": [C.c_int, C.POINTER(C.c_void_p)],
     "palace_ctx_create_prio": [C.c_int, C.c_int, C.POINTER(C.c_void_p)],
-    "palace_ctx_create_masked": [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)],
     "palace_ctx_create_on_stream": [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)],
     "palace_ctx_destroy": [C.c_void_p],
     "palace_sync": [C.c_void_p],
@@ -144,7 +143,6 @@ _SIGS = {
                                  C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(GraphParams), C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "palace_graph_fastg_offsets": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
-    "palace_diag_disturb": [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int],
     "palace_bgzf_inflate": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "palace_graph_score_border": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(GraphParams)],
     "palace_graph_resolve_ex": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(GraphParams), C.c_void_p,
@@ -156,7 +154,6 @@ _SIGS = {
     "palace_stage04_flags": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64],
     "palace_stage04_counts": [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],
     "palace_stage04_match": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32],
-    "palace_stage04_match_after": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32],
     "palace_stage04_result": [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)],
 }
 
@@ -224,15 +221,11 @@ class DevBuf:
 class Ctx:
     """One device context (one HIP stream).  `calls` go straight to the C ABI."""
 
-    def __init__(self, device: int = 0, high_priority: bool = False, cu_mask: int | None = None, stream: int | None = None):
-        """cu_mask: an integer whose bit i admits compute unit i to the context's stream (palace_ctx_create_masked);
-        stream: a hipStream_t of the caller's to run on instead of a stream of the context's own (palace_ctx_create_on_stream)"""
+    def __init__(self, device: int = 0, high_priority: bool = False, stream: int | None = None):
+        """stream: a hipStream_t of the caller's to run on instead of a stream of the context's own (palace_ctx_create_on_stream)"""
         h = C.c_void_p()
         if stream:
             _check(lib().palace_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(h)), "palace_ctx_create_on_stream")
-        elif cu_mask:
-            words = (C.c_uint32 * 8)(*[(cu_mask >> (32 * k)) & 0xFFFFFFFF for k in range(8)])
-            _check(lib().palace_ctx_create_masked(device, int(high_priority), words, 8, C.byref(h)), "palace_ctx_create_masked")
         else:
             _check(lib().palace_ctx_create_prio(device, int(high_priority), C.byref(h)), "palace_ctx_create_prio")
         self.h = h
@@ -540,12 +533,8 @@ class Stage04:
                "palace_stage04_flags")
         return seg, edge
 
-    def match(self, d_edges_ptr: int, d_cn_ptr: int, iterations: int = 10, aggressive: bool = False, use_paths: bool = True,
-              after: "tuple[Ctx, int] | None" = None):
-        """after = (other context, mark): the decomposition's rounds start when that mark is reached on the device"""
-        other, mark = (after[0].h, after[1]) if after else (None, 0)
-        _check(lib().palace_stage04_match_after(self.ctx.h, self.h, d_edges_ptr, d_cn_ptr, iterations, int(aggressive), int(use_paths),
-                                                other, mark), "palace_stage04_match")
+    def match(self, d_edges_ptr: int, d_cn_ptr: int, iterations: int = 10, aggressive: bool = False, use_paths: bool = True):
+        _check(lib().palace_stage04_match(self.ctx.h, self.h, d_edges_ptr, d_cn_ptr, iterations, int(aggressive), int(use_paths)), "palace_stage04_match")
 
     def result(self):
         """-> (MatchResult view with .bare / .n_bare, contig_of array view); valid until the next match() / close()"""

@@ -59,11 +59,7 @@ struct palace_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = true;        // false: the caller's stream (palace_ctx_create_on_stream)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // eref count_reads: level 1 of the next part of a slab runs on `side` beside level 2 of the current one (eref.hip, bin_and_count)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_part[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // start, level 1 done [2], level 2 done [2]
     uint32_t key_buckets[4] = {~0u, ~0u, ~0u, ~0u};   // palace_eref_set_key_buckets: the level-1 buckets (key >> 25) count calls take in
-    int level1_parts = 0;           // option: parts per slab (0 = by size, 1 = no overlap)
     std::vector<hipEvent_t> marks;   // lazily created
     // eref
     bool coder_set = false;
@@ -86,12 +82,9 @@ struct palace_ctx {
                                     // the sample counted since the last reset -- a fused count wrote them, or a call without reads zeroed them
     bool planeless = false;         // ... and did: the table holds NOTHING (all three planes are zero, as after a reset); Phase B is the attached
                                     // index's hit bits alone, and whatever else reads the table is refused until the next reset
-    int mark_before_count = -1;     // option mark_before_count_kernel
-    int mark_before_level2 = -1;    // option mark_before_level2
     int count_mode = 0;             // 0 auto, 1 direct atomics, 2 binned
     int64_t bin_cap_override = 0;
     int64_t slab_override = 0;
-    int bin1_ppl = 0;               // level 1: positions per lane (0 = by key density)
     palace::Workspace ws;      // grow-only scratch
     bool ws_grown = false;
     palace::Workspace pin;     // grow-only pinned host staging
@@ -99,8 +92,6 @@ struct palace_ctx {
     int64_t graph_border = -1;      // candidates of the last classify call that the host's libm has to score, and whose they are
     const void *graph_border_cands = nullptr;
     int64_t graph_border_n = -1;    // ... and how many candidates that call left there (a buffer that was appended to is not that call's)
-    bool launch_graphs = false;     // option: stage 04 replays its launch sequences as hipGraphs
-    int match_first_group = 0;      // rounds enqueued before the first look at the state (0 = default)
     int match_grid = 0;             // workgroups of the decomposition's arc- and vertex-sized phases (0 = default; decomp.hip)
     bool match_two_word_keys = false; // option: the decomposition never uses the one-word form of the arc keys (A/B runs, tests)
     int match_iters = 0;            // matching iterations enqueued per round (0 = defaults; tests lower it to force the checked path)

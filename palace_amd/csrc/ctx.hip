@@ -85,25 +85,22 @@ const char *palace_version(void) { return "palace_hip 0.2 (gfx950) build " PALAC
 
 int palace_ctx_create(int device, palace_ctx **out) { return palace_ctx_create_prio(device, 0, out); }
 
+static int ctx_create(int device, int high_priority, hipStream_t given, palace_ctx **out);
+
 int palace_ctx_create_prio(int device, int high_priority, palace_ctx **out)
 {
-    return palace_ctx_create_masked(device, high_priority, nullptr, 0, out);
-}
-
-static int ctx_create(int device, int high_priority, const uint32_t *cu_mask, int n_words, hipStream_t given, palace_ctx **out);
-
-int palace_ctx_create_masked(int device, int high_priority, const uint32_t *cu_mask, int n_words, palace_ctx **out)
-{
-    return ctx_create(device, high_priority, cu_mask, n_words, nullptr, out);
+    return ctx_create(device, high_priority, nullptr, out);
 }
 
 int palace_ctx_create_on_stream(int device, void *hip_stream, palace_ctx **out)
 {
     PALACE_REQUIRE(hip_stream != nullptr, "stream is null");
-    return ctx_create(device, 0, nullptr, 0, static_cast<hipStream_t>(hip_stream), out);
+    return ctx_create(device, 0, static_cast<hipStream_t>(hip_stream), out);
 }
 
-static int ctx_create(int device, int high_priority, const uint32_t *cu_mask, int n_words, hipStream_t given, palace_ctx **out)
+// (A stream confined to a set of compute units -- hipExtStreamCreateWithCUMask, palace_ctx_create_masked in rounds 4-5 -- was measured for
+// stage 04 beside the counting kernels and never helped: what slows the small kernels is the memory system, not the CUs.  Removed in round 6.)
+static int ctx_create(int device, int high_priority, hipStream_t given, palace_ctx **out)
 {
     PALACE_REQUIRE(out != nullptr, "out is null");
     int n = 0;
@@ -124,8 +121,6 @@ static int ctx_create(int device, int high_priority, const uint32_t *cu_mask, in
     if (given) {                                           // the caller's stream: used, never destroyed
         ctx->stream = given;
         ctx->owns_stream = false;
-    } else if (cu_mask && n_words > 0) {                   // the stream's kernels only run on the CUs whose bit is set (no priority with it)
-        if ((e = hipExtStreamCreateWithCUMask(&ctx->stream, static_cast<uint32_t>(n_words), cu_mask)) != hipSuccess) return fail("hipExtStreamCreateWithCUMask", e);
     } else if (high_priority) {
         int least = 0, greatest = 0;                       // numerically lower = more urgent
         if ((e = hipDeviceGetStreamPriorityRange(&least, &greatest)) != hipSuccess) return fail("hipDeviceGetStreamPriorityRange", e);
@@ -153,41 +148,10 @@ int palace_ctx_destroy(palace_ctx *ctx)
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     for (hipEvent_t e : ctx->marks)
         if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ctx->ev_part)
-        if (e) (void)hipEventDestroy(e);
-    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream && ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
-    return PALACE_OK;
-}
-
-// ---- diagnosis: a stream of random memory operations of one kind, to see what they cost a kernel on another stream ----
-namespace {
-__global__ void diag_disturb_kernel(unsigned long long *buf, unsigned long long n_slots, unsigned long long n_ops, int mode, unsigned long long salt)
-{
-    unsigned long long acc = 0;
-    for (unsigned long long i = blockIdx.x * static_cast<unsigned long long>(blockDim.x) + threadIdx.x; i < n_ops; i += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
-        unsigned long long x = (i + salt) * 0x9E3779B97F4A7C15ull;
-        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
-        const unsigned long long idx = x % n_slots;
-        if (mode == 0) acc += buf[idx];                                        // gather, 8 bytes
-        else if (mode == 1) atomicMin(&buf[idx], x | (1ull << 63));            // 64-bit atomic, result unused
-        else if (mode == 2) buf[idx] = x;                                       // scattered store
-        else if (mode == 3) acc += reinterpret_cast<unsigned char *>(buf)[idx]; // gather, 1 byte
-    }
-    if (acc == 0x123456789abcdefull) buf[0] = acc;                             // (keeps the loads)
-}
-}  // namespace
-
-extern "C" int palace_diag_disturb(palace_ctx *ctx, void *d_buf, uint64_t n_slots, uint64_t n_ops, int mode, int launches, int blocks)
-{
-    PALACE_REQUIRE(ctx && d_buf && n_slots > 0 && launches > 0 && blocks > 0, "bad argument");
-    for (int l = 0; l < launches; l++)
-        hipLaunchKernelGGL(diag_disturb_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<unsigned long long *>(d_buf), n_slots, n_ops / launches, mode,
-                           static_cast<unsigned long long>(l) << 40);
-    PALACE_HIP_TRY(hipGetLastError());
     return PALACE_OK;
 }
 

@@ -525,7 +525,7 @@ int decomp_run_checked(palace_ctx *ctx, const DecompBufs &b, int rounds, int agg
 
 int decomp_group(palace_ctx *ctx, const DecompBufs &b, DecompRun &run, int rounds, int aggressive, bool unique_hi)
 {
-    const int first = ctx->match_first_group > 0 ? ctx->match_first_group : kFirstGroupRounds;
+    const int first = kFirstGroupRounds;
     const int t0 = run.next_round, t1 = std::min(rounds, t0 + (t0 == 0 ? first : kRoundsPerGroup));
     for (int t = t0; t < t1; t++) {
         const int iters = ctx->match_iters > 0 ? std::min(ctx->match_iters, kMaxIters) : (t == 0 ? kFirstRoundIters : kLaterRoundIters);

@@ -675,7 +675,8 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
     // per key before this form, 77 % of the kernel's time at full issue rate), and every `if` around an LDS operation costs an
     // exec-mask round.  A slot of a group that holds no key (only a run's last group has such) adds 0 to a row; a key
     // that finds no room, and a slot that is none, write to the spare slot behind the rows.
-    uint32_t homeless = 0;                                 // bit 5 * it + e: that key found its row full
+    using Homeless = std::conditional_t<(kGroups2PerThread * kGroupKeys > 32), unsigned long long, uint32_t>;
+    Homeless homeless = 0;                                 // bit 5 * it + e: that key found its row full
 #pragma unroll
     for (int it = 0; it < kGroups2PerThread; it++) {
         uint32_t k[kGroupKeys];
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
             const uint32_t row = k[e] >> kFineBits;
             const bool is_key = e < n, fits = at[e] < (row + 1) * kRowSlots;
             st.slot[is_key && fits ? at[e] : kStage2Slots] = static_cast<uint16_t>(k[e]);
-            homeless |= (is_key && !fits ? 1u : 0u) << (kGroupKeys * it + e);
+            homeless |= static_cast<Homeless>(is_key && !fits ? 1u : 0u) << (kGroupKeys * it + e);
         }
     }
     if (homeless) {
@@ -769,7 +770,8 @@ __global__ __launch_bounds__(kBin2Threads) void eref_bin2_kernel(const unsigned 
             }
             continue;
         }
-        if (lane + 64 < cj) dst[lane + 64] = row_slots[lane + 64];
+        for (uint32_t q = 64; q < cj; q += 64)
+            if (lane + q < cj) dst[lane + q] = row_slots[lane + q];
     }
 }
 
@@ -2094,11 +2096,9 @@ namespace {
 constexpr size_t kTouchedBytes = 8192 + 256;             // one bit per fine bucket (2^16 bits), padded
 struct CountPlan {
     int64_t slab_bases_max = 0, n_slabs = 0, n_chunks = 0;
-    int64_t part_bases = 0;              // level 1 works through a slab in parts of this many positions (level-1 regions hold one part)
-    int n_buf1 = 1;                      // 2: parts alternate between two sets of level-1 regions
     DensityCaps caps1{}, caps2{};
     size_t cur1_bytes = 0, cur2_bytes = 0, buf1_bytes = 0, buf2_bytes = 0, words_bytes = 0;
-    size_t total() const { return n_buf1 * (cur1_bytes + buf1_bytes) + cur2_bytes + kTouchedBytes + 5 * words_bytes + buf2_bytes; }
+    size_t total() const { return cur1_bytes + buf1_bytes + cur2_bytes + kTouchedBytes + 5 * words_bytes + buf2_bytes; }
 };
 constexpr int64_t kRegions = static_cast<int64_t>(kL1Buckets) * kL1Replicas;
 
@@ -2118,16 +2118,10 @@ int plan_count(palace_ctx *ctx, int64_t total_bases, CountPlan *pl)
     const int64_t slab_bases = std::min(total_bases, pl->slab_bases_max);
     // capacities: the key upper bound of one slab (a position range) shared out by the key density with 20 % head
     // room, plus a flat pad of 1/8 of the mean and a constant
-    // Option level1_parts: level 1 takes a slab in parts, level 2 follows part by part on the other stream (bin_and_count); the
-    // level-1 regions then hold one part, twice.  Default: one part, one stream -- the overlap was measured and LOSES (1M-contig
-    // step, count launch: 1 part 9.24 ms, 2 parts 9.49, 4 parts 9.87, 8 parts 13.1): the two kernels do load different units,
-    // but side by side they split the CUs' LDS (a level-2 workgroup needs the room of two level-1 workgroups) and each part
-    // adds a kernel tail.
-    int parts = ctx->level1_parts > 0 ? ctx->level1_parts : 1;
-    pl->part_bases = ((slab_bases + parts - 1) / parts + 63) / 64 * 64;
-    if (pl->part_bases >= slab_bases) { pl->part_bases = slab_bases; parts = 1; }
-    pl->n_buf1 = parts > 1 ? 2 : 1;
-    const int64_t max_keys = 3 * slab_bases, max_keys1 = 3 * pl->part_bases;
+    // (Level 1 of a slab in parts on a second stream beside level 2 of the part before -- two sets of level-1 regions -- was an option in
+    // rounds 3-5 and always lost, 9.24 ms for one part against 9.49 / 9.87 / 13.1 for 2 / 4 / 8: side by side the two kernels split the CUs'
+    // LDS and every part adds a kernel tail.  Removed in round 6.)
+    const int64_t max_keys = 3 * slab_bases, max_keys1 = max_keys;
     // (level-1 runs are padded to 4 keys: on average 1.5 pad keys per run of ~48)
     // (level-1 regions hold GROUPS of five keys; a run's last group is partly filled: ~2 pad slots per run of ~72)
     const int64_t mean1 = max_keys1 / kRegions / kGroupKeys * 26 / 25 + 1, mean2 = max_keys / kFine / 2;    // mean1: groups; mean2: pairs of 16-bit keys
@@ -2154,7 +2148,7 @@ int plan_count(palace_ctx *ctx, int64_t total_bases, CountPlan *pl)
     PALACE_REQUIRE(pl->caps1.prefix(kL1Buckets) * kL1Replicas < (1ull << 32), "level-1 regions exceed 2^32 groups of 16 bytes");
     //  (c) a region cursor keeps counting when its region is full (the excess takes the exact path): it must not wrap even
     //      if every key of the slab's tiles of one replica lands in one bucket.
-    PALACE_REQUIRE(3ull * static_cast<uint64_t>(pl->part_bases) / kL1Replicas + (1ull << 20) < (1ull << 32), "slab too large for 32-bit region cursors");
+    PALACE_REQUIRE(3ull * static_cast<uint64_t>(slab_bases) / kL1Replicas + (1ull << 20) < (1ull << 32), "slab too large for 32-bit region cursors");
     return PALACE_OK;
 }
 }  // namespace
@@ -2211,18 +2205,18 @@ static KeyBuckets ctx_buckets(const palace_ctx *ctx)
 
 // Scratch of one count call, carved out of the context's workspace (sizes: CountPlan).
 struct CountBufs {
-    unsigned int *cursor2 = nullptr, *touched = nullptr, *cursor1[2] = {nullptr, nullptr};
+    unsigned int *cursor2 = nullptr, *touched = nullptr, *cursor1 = nullptr;
     unsigned long long *words = nullptr;                 // 5 x words_bytes (ASCII entry: read ends, dropped, three streams) or nothing
-    uint32_t *buf1[2] = {nullptr, nullptr};
+    uint32_t *buf1 = nullptr;
     uint16_t *buf2 = nullptr;
 };
 static void carve_count(const CountPlan &pl, char *ws, bool with_words, CountBufs *b)
 {
     b->cursor2 = reinterpret_cast<unsigned int *>(ws); ws += pl.cur2_bytes;
     b->touched = reinterpret_cast<unsigned int *>(ws); ws += kTouchedBytes;
-    for (int k = 0; k < pl.n_buf1; k++) { b->cursor1[k] = reinterpret_cast<unsigned int *>(ws); ws += pl.cur1_bytes; }
+    b->cursor1 = reinterpret_cast<unsigned int *>(ws); ws += pl.cur1_bytes;
     if (with_words) { b->words = reinterpret_cast<unsigned long long *>(ws); ws += 5 * pl.words_bytes; }
-    for (int k = 0; k < pl.n_buf1; k++) { b->buf1[k] = reinterpret_cast<uint32_t *>(ws); ws += pl.buf1_bytes; }
+    b->buf1 = reinterpret_cast<uint32_t *>(ws); ws += pl.buf1_bytes;
     b->buf2 = reinterpret_cast<uint16_t *>(ws);
 }
 
@@ -2338,19 +2332,9 @@ static int launch_bin1(palace_ctx *ctx, hipStream_t stream, int ppl, const uint3
     const dim3 grid(static_cast<unsigned>(tiles)), block(kBinThreads);
 #define PALACE_BIN1(P_, SHARE_) hipLaunchKernelGGL((eref_bin1_sort_kernel<P_, kBinThreads, SHARE_>), grid, block, 0, stream, w0, w1, wu, p_lo, p_hi, ctx->masks, o1)
     if (o1.keys.all()) {
-        switch (ppl) {
-        case 4: PALACE_BIN1(4, false); break;
-        case 5: PALACE_BIN1(5, false); break;
-        case 6: PALACE_BIN1(6, false); break;
-        default: PALACE_BIN1(8, false); break;
-        }
+        if (ppl == 6) PALACE_BIN1(6, false); else PALACE_BIN1(8, false);
     } else {
-        switch (ppl) {
-        case 4: PALACE_BIN1(4, true); break;
-        case 5: PALACE_BIN1(5, true); break;
-        case 6: PALACE_BIN1(6, true); break;
-        default: PALACE_BIN1(8, true); break;
-        }
+        if (ppl == 6) PALACE_BIN1(6, true); else PALACE_BIN1(8, true);
     }
 #undef PALACE_BIN1
     PALACE_HIP_TRY(hipGetLastError());
@@ -2360,9 +2344,6 @@ static int launch_bin1(palace_ctx *ctx, hipStream_t stream, int ppl, const uint3
 // The read set as bit streams (P0, P1, U: see eref_streams_kernel) -> level-1 partition -> level-2 partition -> count in LDS,
 // slab by slab.  Shared by the ASCII entry (which builds the streams first) and the packed entry (whose caller did).
 //
-// With the option level1_parts > 1 level 1 works through a slab in PARTS, on a second stream: level 1 of part p + 1 runs beside
-// level 2 of part p (two sets of level-1 regions), all parts append to the same fine regions, one count kernel per slab.
-// (Measured slower than one part on one stream, see plan_count; kept as an option, exact either way.)
 static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &b, const uint32_t *w0, const uint32_t *w1,
                          const uint32_t *wu, int64_t total_bases, double keys_per_pos)
 {
@@ -2371,56 +2352,23 @@ static int bin_and_count(palace_ctx *ctx, const CountPlan &pl, const CountBufs &
     // positions per lane of the level-1 kernel.  Its throughput is (key slots the CU's LDS holds) / (latency of a tile,
     // ~11 us whatever the tile size): 6 positions x 3 keys x 512 lanes + pads = 39.8 KiB, the most that still fits four
     // times into 160 KiB (5: +4 %, 4: +8 %, 8 -- three workgroups per CU --: +2 %).  Sparse sets (short reads) take 8.
-    const int ppl = ctx->bin1_ppl ? ctx->bin1_ppl : keys_per_pos > 1.6 ? 6 : 8;
-    const bool overlap = pl.n_buf1 > 1;
-    if (overlap && !ctx->side) {
-        PALACE_HIP_TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-        for (hipEvent_t &e : ctx->ev_part) PALACE_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    hipEvent_t ev_start = ctx->ev_part[0], *ev_l1 = ctx->ev_part + 1, *ev_l2 = ctx->ev_part + 3;
+    const int ppl = keys_per_pos > 1.6 ? 6 : 8;
     const KeyBuckets keys = ctx_buckets(ctx);
     Bin2Grid g2;
     g2.first[0] = 0;
     for (uint32_t bk = 0; bk < kL1Buckets; bk++)                                                 // (level 2 only where level 1 wrote)
         g2.first[bk + 1] = g2.first[bk] + (keys.bucket(bk) ? tiles_of_bucket(pl.caps1, bk) * kL1Replicas : 0);
     const Bin2Out o2{b.cursor2, b.buf2, pl.caps2, ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched};
+    const BinOut o1{b.cursor1, b.buf1, pl.caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys};
     for (int64_t slab = 0; slab < n_slabs; slab++) {
         PALACE_HIP_TRY(hipMemsetAsync(b.cursor2, 0, pl.cur2_bytes + kTouchedBytes, ctx->stream));
+        PALACE_HIP_TRY(hipMemsetAsync(b.cursor1, 0, pl.cur1_bytes, ctx->stream));
         const bool clean = ctx->table_clean && slab == 0;        // every plane bit is still zero: slices need no reading
         const int64_t s_lo = slab * kSlabBases, s_hi = std::min(total_bases, (slab + 1) * kSlabBases);
-        hipStream_t l1 = overlap ? ctx->side : ctx->stream;
-        if (overlap) {                                           // level 1 starts behind whatever the stream holds so far
-            PALACE_HIP_TRY(hipEventRecord(ev_start, ctx->stream));
-            PALACE_HIP_TRY(hipStreamWaitEvent(ctx->side, ev_start, 0));
-        }
-        int part = 0;
-        for (int64_t p_lo = s_lo; p_lo < s_hi; p_lo += pl.part_bases, part++) {
-            const int64_t p_hi = std::min(s_hi, p_lo + pl.part_bases);
-            const int k = overlap ? part & 1 : 0;
-            if (overlap && part >= 2) PALACE_HIP_TRY(hipStreamWaitEvent(ctx->side, ev_l2[k], 0));   // level 2 has read this set of regions
-            PALACE_HIP_TRY(hipMemsetAsync(b.cursor1[k], 0, pl.cur1_bytes, l1));
-            const BinOut o1{b.cursor1[k], b.buf1[k], pl.caps1, ctx->plane[0], ctx->plane[1], ctx->plane[2], b.touched, keys};
-            int rc = launch_bin1(ctx, l1, ppl, w0, w1, wu, p_lo, p_hi, o1);
-            if (rc) return rc;
-            if (overlap) {
-                PALACE_HIP_TRY(hipEventRecord(ev_l1[k], ctx->side));
-                PALACE_HIP_TRY(hipStreamWaitEvent(ctx->stream, ev_l1[k], 0));
-            }
-            // option mark_before_level2: level 1 of the launch's last part is done
-            if (ctx->mark_before_level2 >= 0 && slab + 1 == n_slabs && p_hi == s_hi) {
-                int rc2 = palace_mark(ctx, ctx->mark_before_level2);
-                if (rc2) return rc2;
-            }
-            hipLaunchKernelGGL(eref_bin2_kernel, dim3(g2.first[kL1Buckets]), dim3(kBin2Threads), 0, ctx->stream, b.cursor1[k], b.buf1[k], pl.caps1, g2, o2);
-            PALACE_HIP_TRY(hipGetLastError());
-            if (overlap) PALACE_HIP_TRY(hipEventRecord(ev_l2[k], ctx->stream));
-        }
-        // option mark_before_count_kernel: the partition kernels of the launch are done (what may run beside the count kernel
-        // and Phase B without slowing the partition kernels can be made to wait for this mark: palace_wait_for_mark)
-        if (ctx->mark_before_count >= 0 && slab + 1 == n_slabs) {
-            int rc = palace_mark(ctx, ctx->mark_before_count);
-            if (rc) return rc;
-        }
+        int rc1 = launch_bin1(ctx, ctx->stream, ppl, w0, w1, wu, s_lo, s_hi, o1);
+        if (rc1) return rc1;
+        hipLaunchKernelGGL(eref_bin2_kernel, dim3(g2.first[kL1Buckets]), dim3(kBin2Threads), 0, ctx->stream, b.cursor1, b.buf1, pl.caps1, g2, o2);
+        PALACE_HIP_TRY(hipGetLastError());
         const ProbeArgs no_probe{};
         if (clean && n_slabs == 1 && ctx->want_final) {
             const palace_eref_probe_index *ix = ctx->probe_ix;
@@ -2612,18 +2560,6 @@ int palace_eref_set_option(palace_ctx *ctx, const char *name, int64_t value)
     } else if (!std::strcmp(name, "scan_ref_lo") || !std::strcmp(name, "scan_ref_hi")) {   // palace_eref_scan_refs_indexed works on refs [lo, hi) only
         PALACE_REQUIRE(value >= 0, "a ref ordinal");                                       // (hi = 0: all); rows of other refs: n_intervals = el = 0
         (name[9] == 'l' ? ctx->scan_ref_lo : ctx->scan_ref_hi) = value;
-    } else if (!std::strcmp(name, "mark_before_level2")) {         // -1: none; i: palace_mark(ctx, i) between level 1 and level 2 of the last part
-        PALACE_REQUIRE(value >= -1 && value < 4096, "mark index out of range");
-        ctx->mark_before_level2 = static_cast<int>(value);
-    } else if (!std::strcmp(name, "mark_before_count_kernel")) {   // -1: none; i: palace_mark(ctx, i) between the partition kernels and the count kernel
-        PALACE_REQUIRE(value >= -1 && value < 4096, "mark index out of range");
-        ctx->mark_before_count = static_cast<int>(value);
-    } else if (!std::strcmp(name, "level1_parts")) {         // 0: by size; n: level 1 takes a slab in n parts beside level 2 (1: one stream)
-        PALACE_REQUIRE(value >= 0 && value <= 64, "level1_parts must be 0 .. 64");
-        ctx->level1_parts = static_cast<int>(value);
-    } else if (!std::strcmp(name, "bin1_ppl")) {              // 0: by key density, else positions per lane of level 1 (4, 5, 6, 8)
-        PALACE_REQUIRE(value == 0 || value == 4 || value == 5 || value == 6 || value == 8, "bin1_ppl must be 0, 4, 5, 6 or 8");
-        ctx->bin1_ppl = static_cast<int>(value);
     } else {
         set_error("palace_eref_set_option: unknown option '%s'", name);
         return PALACE_EINVAL;

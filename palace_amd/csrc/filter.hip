@@ -467,10 +467,6 @@ struct palace_stage04 {
     palace::DecompState *h_ds = nullptr;
     palace_match_result res;
     int32_t *h_contig_of = nullptr;
-    // option launch_graphs: the launch sequences of filter / match as hipGraphs, captured at the first call with a set of
-    // arguments and replayed while they stay the same (kernels have fixed grids and read their counts from device memory)
-    struct Captured { hipGraphExec_t exec = nullptr; uint64_t key = 0; palace::DecompRun run_after; } g_filter, g_match;
-    uint64_t generation = 0;          // bumped whenever a device block moves: graphs of an older generation are stale
 };
 
 using namespace palace;
@@ -479,35 +475,8 @@ namespace {
 
 const dim3 kG(1024), kB(kDecompBlock);           // fixed grid of the grid-stride kernels over contigs / edges / path lines
 
-uint64_t mix_key(uint64_t h, uint64_t v) { return (h ^ v) * 0x9E3779B97F4A7C15ull + (h >> 29); }
-
-// Runs `enqueue` (asynchronous launches on ctx->stream only) -- directly, or, with the option launch_graphs, as a hipGraph
-// captured once per `key` and replayed: ~10 / ~160 kernel launches become one graph launch per call.
-template <class Fn>
-int run_maybe_captured(palace_ctx *ctx, palace_stage04::Captured &g, uint64_t key, Fn &&enqueue)
-{
-    if (!ctx->launch_graphs) return enqueue();
-    if (g.exec && g.key != key) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-    if (!g.exec) {
-        PALACE_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue();
-        hipGraph_t graph = nullptr;
-        const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);            // (always: the stream must leave capture mode)
-        if (rc || e != hipSuccess) {
-            if (graph) (void)hipGraphDestroy(graph);
-            if (rc) return rc;
-            set_error("stage04: hipStreamEndCapture failed: %s", hipGetErrorString(e));
-            return PALACE_EHIP;
-        }
-        const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (ei != hipSuccess) { g.exec = nullptr; set_error("stage04: hipGraphInstantiate failed: %s", hipGetErrorString(ei)); return PALACE_EHIP; }
-        g.key = key;
-    }
-    PALACE_HIP_TRY(hipGraphLaunch(g.exec, ctx->stream));
-    return PALACE_OK;
-}
-
+// (The launch sequences of filter / match as hipGraphs, captured once and replayed -- option launch_graphs of rounds 3-5 -- saved the host
+// 0.3 ms of enqueueing per step and never shortened the step: the kernels run back to back either way.  Removed in round 6.)
 int grow_pinned(palace_ctx *ctx, palace_stage04 *s, size_t bytes)
 {
     if (s->pin_bytes >= bytes) return PALACE_OK;
@@ -553,7 +522,6 @@ int grow_device(palace_ctx *ctx, palace_stage04 *s, int64_t edge_bound, int roun
         PALACE_HIP_TRY(hipMemsetAsync(s->f.t.key, 0xff, slots * 8, ctx->stream));       // empty; every use leaves it empty again
         PALACE_HIP_TRY(hipMemsetAsync(s->f.t.w, 0, slots * 8, ctx->stream));
         s->edge_bound = edge_bound; s->s_cap = s_cap; s->e_cap = e_cap; s->comp_cap = comp_cap; s->vert_cap = vert_cap; s->rounds = rounds;
-        s->generation++;                                                               // captured launch sequences point into the old block
     }
     s->f.edge_bound = s->edge_bound;
     return PALACE_OK;
@@ -647,8 +615,6 @@ int palace_stage04_destroy(palace_ctx *ctx, palace_stage04 *s)
 {
     if (!s) return PALACE_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
-    if (s->g_filter.exec) (void)hipGraphExecDestroy(s->g_filter.exec);
-    if (s->g_match.exec) (void)hipGraphExecDestroy(s->g_match.exec);
     if (s->fixed) (void)hipFree(s->fixed);
     if (s->grown) (void)hipFree(s->grown);
     if (s->pin) (void)hipHostFree(s->pin);
@@ -672,9 +638,7 @@ int palace_stage04_filter(palace_ctx *ctx, palace_stage04 *s, const palace_graph
     PALACE_HIP_TRY(hipSetDevice(ctx->device));
     int rc = grow_device(ctx, s, std::max<int64_t>(edge_bound, s->edge_bound), std::max(s->rounds, 11));
     if (rc) return rc;
-    uint64_t key = mix_key(mix_key(mix_key(s->generation, reinterpret_cast<uint64_t>(d_edges)), reinterpret_cast<uint64_t>(d_n_edges)), 1);
-    key = mix_key(key, static_cast<uint64_t>(edge_bound));
-    rc = run_maybe_captured(ctx, s->g_filter, key, [&]() -> int {
+    rc = [&]() -> int {
         const F &f = s->f;
         hipStream_t st = ctx->stream;
         hipLaunchKernelGGL(st4_begin_kernel, kG, kB, 0, st, f, d_n_edges, edge_bound);
@@ -688,7 +652,7 @@ int palace_stage04_filter(palace_ctx *ctx, palace_stage04 *s, const palace_graph
         hipLaunchKernelGGL(st4_ids_kernel, kG, kB, 0, st, f);
         PALACE_HIP_TRY(hipGetLastError());
         return PALACE_OK;
-    });
+    }();
     if (rc) return rc;
     s->filtered = true;
     s->matched = false;
@@ -714,14 +678,10 @@ static int enqueue_match(palace_ctx *ctx, palace_stage04 *s, const palace_graph_
     return PALACE_OK;
 }
 
+// (palace_stage04_match_after -- the rounds held back until a mark of another context's stream, so that they would not run beside its
+// counting kernels -- put them on the critical path wherever it was tried (rounds 3-5).  Removed in round 6.)
 int palace_stage04_match(palace_ctx *ctx, palace_stage04 *s, const palace_graph_edge *d_edges, const int32_t *d_cn,
                          int32_t iterations, int32_t aggressive, int32_t use_paths)
-{
-    return palace_stage04_match_after(ctx, s, d_edges, d_cn, iterations, aggressive, use_paths, nullptr, 0);
-}
-
-int palace_stage04_match_after(palace_ctx *ctx, palace_stage04 *s, const palace_graph_edge *d_edges, const int32_t *d_cn,
-                               int32_t iterations, int32_t aggressive, int32_t use_paths, palace_ctx *other, int32_t mark)
 {
     PALACE_REQUIRE(ctx && s && d_cn && iterations >= 1, "bad argument");
     PALACE_REQUIRE(s->filtered, "palace_stage04_filter has not run");
@@ -732,37 +692,13 @@ int palace_stage04_match_after(palace_ctx *ctx, palace_stage04 *s, const palace_
     s->d_cn = d_cn; s->aggressive = aggressive ? 1 : 0;
     // the first group of rounds goes out now; palace_stage04_result looks at the state after it and continues while segments
     // keep copies (a typical sample is done after the first group)
-    s->run = DecompRun{};
     s->f.use_paths = use_paths ? 1 : 0;
-    auto enqueue = [&]() -> int {
-        int rc2 = enqueue_match(ctx, s, d_edges, use_paths != 0);
-        if (rc2) return rc2;
-        if (other) {                                         // the arcs are built; the rounds wait for the other stream's mark
-            rc2 = palace_wait_for_mark(ctx, other, mark);
-            if (rc2) return rc2;
-        }
-        s->run = DecompRun{};
-        if ((rc2 = decomp_begin(ctx, s->b, rounds, s->comp_cap, s->vert_cap))) return rc2;
-        if ((rc2 = decomp_group(ctx, s->b, s->run, rounds, s->aggressive, false))) return rc2;
-        PALACE_HIP_TRY(hipMemcpyAsync(s->h_fs, s->f.fs, sizeof(FilterState), hipMemcpyDeviceToHost, ctx->stream));
-        return PALACE_OK;
-    };
-    int rc;
-    if (other) rc = enqueue();                               // (a wait for another stream's event is not captured)
-    else {
-        uint64_t key = mix_key(mix_key(mix_key(s->generation, reinterpret_cast<uint64_t>(d_edges)), reinterpret_cast<uint64_t>(d_cn)), 2);
-        key = mix_key(key, (static_cast<uint64_t>(rounds) << 32) | (s->aggressive << 2) | (use_paths ? 2 : 0));
-        key = mix_key(key, (static_cast<uint64_t>(ctx->match_iters) << 32) | static_cast<uint32_t>(ctx->match_first_group));
-        const bool replay = ctx->launch_graphs && s->g_match.exec && s->g_match.key == key;
-        rc = run_maybe_captured(ctx, s->g_match, key, enqueue);
-        if (!rc && ctx->launch_graphs) {
-            // a replay does not run the host side of decomp_group: the state that enqueue left when it was captured (rounds
-            // enqueued, iteration stamp) is kept with the graph and put back
-            if (replay) s->run = s->g_match.run_after;
-            else s->g_match.run_after = s->run;
-        }
-    }
+    int rc = enqueue_match(ctx, s, d_edges, use_paths != 0);
     if (rc) return rc;
+    s->run = DecompRun{};
+    if ((rc = decomp_begin(ctx, s->b, rounds, s->comp_cap, s->vert_cap))) return rc;
+    if ((rc = decomp_group(ctx, s->b, s->run, rounds, s->aggressive, false))) return rc;
+    PALACE_HIP_TRY(hipMemcpyAsync(s->h_fs, s->f.fs, sizeof(FilterState), hipMemcpyDeviceToHost, ctx->stream));
     s->rounds = std::max(s->rounds, rounds);
     s->matched = true;
     s->last_rounds = rounds;

@@ -387,18 +387,12 @@ int palace_match_set_option(palace_ctx *ctx, const char *name, int64_t value)
     if (!std::strcmp(name, "iters_per_round")) {
         PALACE_REQUIRE(value >= 0 && value <= palace::kMaxIters, "iters_per_round out of range");
         ctx->match_iters = static_cast<int>(value);
-    } else if (!std::strcmp(name, "launch_graphs")) {
-        PALACE_REQUIRE(value == 0 || value == 1, "launch_graphs must be 0 or 1");
-        ctx->launch_graphs = value != 0;
     } else if (!std::strcmp(name, "one_word_keys")) {
         PALACE_REQUIRE(value == 0 || value == 1, "one_word_keys must be 0 or 1");
         ctx->match_two_word_keys = value == 0;
     } else if (!std::strcmp(name, "decomp_grid")) {
         PALACE_REQUIRE(value >= 0 && value <= 65536, "decomp_grid out of range");
         ctx->match_grid = static_cast<int>(value);
-    } else if (!std::strcmp(name, "first_group_rounds")) {
-        PALACE_REQUIRE(value >= 0 && value <= palace::kMaxRounds, "first_group_rounds out of range");
-        ctx->match_first_group = static_cast<int>(value);
     } else {
         palace::set_error("palace_match_set_option: unknown option '%s'", name);
         return PALACE_EINVAL;

@@ -660,9 +660,8 @@ def test_binned_flat_stream_with_offset_base_and_ragged_reads(ctx):
     assert_table_equals(ctx, u, c)
 
 
-@pytest.mark.parametrize("parts", [1, 3])
 @pytest.mark.parametrize("with_keep", [False, True])
-def test_binned_slabs(ctx, with_keep, parts):
+def test_binned_slabs(ctx, with_keep):
     """large read sets are processed in slabs, a slab's level 1 in parts on a second stream beside level 2 of the part before;
     force tiny slabs (and three parts per slab) and compare with the oracle"""
     rng = synth.rng_for(29)
@@ -673,10 +672,8 @@ def test_binned_slabs(ctx, with_keep, parts):
     try:
         ctx.eref_set_count_mode(2, 0)
         ctx.eref_set_option("slab_bases", 64 * 1024)                                # 64 Ki-base slabs -> 10 slabs
-        ctx.eref_set_option("level1_parts", parts)
         count_on_gpu(ctx, [(rs.bases, rs.offsets)], hdr, keep=[keep] if with_keep else None)
     finally:
-        ctx.eref_set_option("level1_parts", 0)
         ctx.eref_set_option("slab_bases", 0)
         ctx.eref_set_count_mode(0, 0)
     kept = synth.reads_from_list([rs.read(i) for i in range(rs.n) if keep is None or keep[i]])
@@ -742,7 +739,6 @@ def test_packed_entry_equals_ascii_entry(ctx, mode, with_keep, gap_every):
         ctx.eref_set_count_mode(mode, 0)
         if mode == 2:
             ctx.eref_set_option("slab_bases", 64 * 1024)
-            ctx.eref_set_option("level1_parts", 2 + int(with_keep))
         ctx.eref_set_coder(hdr)
         ctx.eref_table_reset()
         d = [ctx.upload(s) for s in streams]
@@ -754,7 +750,6 @@ def test_packed_entry_equals_ascii_entry(ctx, mode, with_keep, gap_every):
         count_on_gpu(ctx, [(rs.bases, rs.offsets)], hdr, keep=[keep] if with_keep else None)
         assert_table_equals(ctx, u, c)
     finally:
-        ctx.eref_set_option("level1_parts", 0)
         ctx.eref_set_option("slab_bases", 0)
         ctx.eref_set_count_mode(0, 0)
 

@@ -319,44 +319,3 @@ def test_stage04_paths_with_empty_lines_bad_offsets_and_the_call_s_own_edge_boun
         bad = off.copy(); bad[50] = 7                                           # 0 ... 7 0 ...: descends
         with pytest.raises(capi.PalaceError, match="ascend"):
             capi.Stage04(ctx, np.ones(n, np.uint8), np.full(n, 500, np.int32), stage04_io.name_ranks(names), stage04_io.name_lengths(names), bad, long_line)
-
-
-def test_launch_graphs_replay_gives_what_plain_launches_give(tmp_path):
-    """option launch_graphs: filter / match captured as hipGraphs at the first call and replayed -- on NEW contents of the same
-    buffers (the kernels read counts and data from device memory) the replay must give what plain launches give"""
-    from oracle import binding as orc
-    rng = synth.rng_for(21)
-    targets, fai_text, recs, avg = synth.random_graph_case(rng, 400, 30000)
-    names, lens = [t[0] for t in targets], [t[1] for t in targets]
-    open(tmp_path / "g.fastg.fai", "w").write(fai_text)
-    o = orc.graph_default_opts()
-    o.min_count = 2
-    graph = orc.graph_run(recs, targets, str(tmp_path / "g.fastg.fai"), avg, o).decode()
-    files = dict(graph=graph, fastg_fai=fai_text, **synth.filter_side_files(rng, names, lens))
-    case = _load_case(files, tmp_path)
-    e_full = case["edges"]
-    e_thin = e_full.copy()
-    e_thin["counts"][::3] = 0                                   # every third junction falls below MIN_COUNT: another selection, another graph
-    assert len(e_full) > 30
-
-    def run(graphs, edge_sets):
-        out = []
-        with capi.Ctx(0) as ctx:
-            ctx.match_set_option("launch_graphs", 1 if graphs else 0)
-            st = capi.Stage04(ctx, case["seed"], case["tlen"], case["rank"], case["name_len"], case["path_off"], case["path_tok"], 5)
-            d_e = ctx.upload(e_full.view(np.uint8).reshape(-1))
-            d_n = ctx.upload(np.array([len(e_full)], np.int64))
-            d_cn = ctx.upload(case["cn"])
-            for e in edge_sets:
-                capi._check(capi.lib().palace_h2d(ctx.h, d_e.ptr, e.ctypes.data, e.nbytes), "h2d")
-                st.filter(d_e.ptr, d_n.ptr, len(e_full))
-                st.match(d_e.ptr, d_cn.ptr, 10, False, True)
-                res, contig_of = st.result()
-                out.append((stage04_io.matching_text(res, contig_of, names, self_loops=True, break_cycles=False), list(contig_of), st.counts()))
-            st.close()
-        return out
-
-    plain = run(False, [e_full, e_thin, e_full])
-    replay = run(True, [e_full, e_thin, e_full])                # call 1 captures, calls 2 and 3 replay
-    assert plain == replay
-    assert plain[0] == plain[2] and plain[0] != plain[1] and plain[0][2]["arcs"] > 10
