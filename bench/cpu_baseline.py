@@ -57,6 +57,32 @@ def reference_eref(b1, b2, off, refs, tmp, small_div=10):
             times[2 * m] = time.perf_counter() - t0
             ours = subprocess.run(cmd(eref_bin, m, hit, perfect, str(min(16, os.cpu_count() or 1))), stdout=subprocess.PIPE, check=True, timeout=600)
             parity[f"{2 * m} reads, thresholds {hit} {perfect}"] = dict(identical=bool(ours.stdout == r.stdout), lines=r.stdout.count(b"\n"))
+        # one more parity point, untimed, at the PIPELINE's thresholds with refs that pass them: the sampled reads above are a twentieth (and
+        # a two-hundredth) of the depth, so nothing of them passes 0.9 / 0.85 and equal empty outputs say little; here two refs of the DB are
+        # tiled at 12x (both strands, a few substitutions) on top of a slice of the sample
+        try:
+            rng = np.random.Generator(np.random.PCG64(7))
+            comp = np.zeros(256, dtype=np.uint8)
+            comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+            tiles = []
+            for r in refs[:2]:
+                st = np.arange(0, max(1, len(r) - READ_LEN), max(1, READ_LEN // 12))
+                tiles.append(r[st[:, None] + np.arange(READ_LEN)[None, :]])
+            t1 = np.concatenate(tiles)
+            sub = rng.random(t1.shape) < 0.003
+            t1 = np.where(sub, np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=t1.shape)], t1)
+            k = min(2000, n)
+            both = (np.concatenate([t1, b1[: k * READ_LEN].reshape(k, READ_LEN)]), np.concatenate([comp[t1[:, ::-1]], b2[: k * READ_LEN].reshape(k, READ_LEN)]))
+            for tag, arr in zip(("1", "2"), both):
+                with open(fq(tag, "tiled"), "wb") as f:
+                    q = b"I" * READ_LEN
+                    f.write(b"".join(b"@t%d\n" % i + arr[i].tobytes() + b"\n+\n" + q + b"\n" for i in range(len(arr))))
+            r = subprocess.run(cmd(ref_bin, "tiled", "0.9", "0.85", "1"), stdout=subprocess.PIPE, check=True, timeout=600)
+            ours = subprocess.run(cmd(eref_bin, "tiled", "0.9", "0.85", str(min(16, os.cpu_count() or 1))), stdout=subprocess.PIPE, check=True, timeout=600)
+            parity[f"two refs tiled at 12x + {2 * k} sampled reads, thresholds 0.9 0.85"] = dict(identical=bool(ours.stdout == r.stdout and r.stdout.count(b"\n") >= 1),
+                                                                                               lines=r.stdout.count(b"\n"))
+        except Exception as e:
+            parity["two refs tiled at 12x"] = dict(identical=False, lines=0, error=f"{type(e).__name__}: {str(e)[:200]}")
         (ra, ta), (rbn, tb) = min(times.items()), max(times.items())
         marginal = (rbn - ra) / max(1e-9, tb - ta) if rbn > ra else None
         return dict(binary="oracle/_ref/eref_ref (unmodified extract_ref.cpp, g++ -O2, threads=1, index cached by an untimed first run)",

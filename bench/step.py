@@ -662,6 +662,17 @@ def measure(args, E, leg):
                 for k, v in out["cpu_baseline"].get("parity", {}).items():     # the checker beside the timing: a free parity point per stage
                     if v is False:
                         failures.append(f"cpu_baseline.parity.{k} is False")
+                # files -> files against the CPU path timed the same way (files in, process exit): the like-for-like ratio, stated
+                e2e, cb = out.get("e2e") or {}, out["cpu_baseline"]
+                if cb.get("value") and "error" not in e2e and e2e.get("contigs_per_s"):
+                    one, nf = e2e.get("one_process_stage04") or {}, e2e.get("no_fork") or {}
+                    ratio = lambda x: None if not x else round(x / cb["value"], 1)
+                    e2e["vs_cpu_baseline"] = dict(chain=ratio(e2e["contigs_per_s"]), fused=ratio(one.get("contigs_per_s")),
+                                                  no_fork_chain=ratio(nf.get("contigs_per_s")), no_fork_fused=ratio(nf.get("one_process_stage04_contigs_per_s")),
+                                                  cores=cb.get("cores"), multi_thread_chain=ratio(e2e["contigs_per_s"]) and cb.get("multi_thread", {}).get("value") and
+                                                  round(e2e["contigs_per_s"] / cb["multi_thread"]["value"], 1),
+                                                  note="executables on files (wall clock to the caller's return) / cpu_baseline.value (one thread, files in, to process exit); "
+                                                       "`value` / cpu_baseline.value is NOT like for like: the headline step starts from inputs resident in HBM")
         finally:
             if work and not os.environ.get("PALACE_BENCH_KEEP"):              # (tools/eref_cli_repeat.sh re-runs the executables on these files)
                 import shutil

@@ -2,7 +2,7 @@
 cd "$(dirname "$0")/.." || exit 1
 name=$1; shift
 mkdir -p tools/ab /tmp/var_$name
-for f in ctx eref graph match decomp filter depth inflate; do
+for f in ctx eref eref_scan eref_index eref_table graph match decomp filter depth inflate; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 "$@" -c palace_amd/csrc/$f.hip -o /tmp/var_$name/$f.o &
 done
 wait
