@@ -112,7 +112,7 @@ STEP = dict(reset_ms=0.1, phase_b_fixed_ms=0.15, phase_b_ms=0.92, phase_b_counts
 
 
 def xr_dense(n_reads: int) -> bool:
-    """more key instances than 0.9 x 2^32 table slots: the scan takes its two-stage pruning (eref.hip, palace_eref_scan_refs_indexed)"""
+    """more key instances than 0.9 x 2^32 table slots: the scan takes its two-stage pruning (eref_scan.hip, palace_eref_scan_refs_indexed)"""
     return 3.0 * n_reads * 119 > 0.9 * 4294967296.0
 
 
