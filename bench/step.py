@@ -37,7 +37,7 @@ def profiled_traffic(args, world, version, fused):
     if world != 1 or t.get("contigs") != args.contigs or t.get("workload", "default") != args.workload or t.get("reads", "ascii") != args.reads:
         return None, "profiles/phase_a_traffic.json is of another workload", {}
     if int(t.get("fused_probe", 0)) != int(fused):
-        return None, f"profiles/phase_a_traffic.json was measured with --fused-probe {int(t.get('fused_probe', 0))}; this run is --fused-probe {int(fused)}", {}
+        return None, f"profiles/phase_a_traffic.json was measured with Phase B's look-ups {'inside' if int(t.get('fused_probe', 0)) else 'outside'} the count launch; this run has them {'inside' if int(fused) else 'outside'}", {}
     if t.get("build") != version:
         return None, f"profiles/phase_a_traffic.json was measured on another build ({t.get('build')}); this is {version}", {}
     return t.get("bytes_per_launch"), t.get("source"), {k: v.get("bytes") for k, v in (t.get("stages") or {}).items()}

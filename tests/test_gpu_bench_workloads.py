@@ -58,7 +58,7 @@ def check_line(line, contigs):
     n_reads = int(c["workload"].split(", ")[1].split(" reads")[0])
     ref_bp = int(c["workload"].split("phage refs (")[1].split(" bp")[0])
     # 864 B per 150-bp read; with Phase B's look-ups fused into the count kernel, their 1 B per ref position and channel too
-    # (channel 0, or -- the default since round 5 -- all three: --fused-probe 2)
+    # (all three channels on one GPU; none for a rank that exchanges plane slices)
     assert r["algorithmic_bytes_per_launch"] in (864 * n_reads, 864 * n_reads + ref_bp - 31 * 5000, 864 * n_reads + 3 * (ref_bp - 31 * 5000))
     st = line["roofline_stages"]
     assert set(st) == {"phase_b", "classify", "resolve", "stage04"}

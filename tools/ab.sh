@@ -1,7 +1,7 @@
 # A/B runs of bench.py on ONE GPU box (box-to-box spread, +-0.15 ms, is larger than most effects compared), variants alternated.
 #   usage (GPU box):  bash tools/ab.sh <tag> <reps> <variant> [<variant> ...]
 #   variant = label[,ENV=VALUE ...][@extra bench.py arguments]        e.g.
-#     bash tools/ab.sh r05d 3 default grid256,PALACE_OPT_DECOMP_GRID=256 hold,PALACE_OPT_DECOMP_GRID=2048@--stage04-hold\ 1
+#     bash tools/ab.sh r06x 3 default grid2048,PALACE_OPT_DECOMP_GRID=2048 "long@--workload long"
 # One line per run on stdout (tools/bench_brief.py: ms per step, M contigs/s, stage times); full JSON lines in gpurun_out/<tag>_ab.jsonl.
 : "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it)}"
 cd "$GRAFT_REPO_ROOT" || exit 1
