@@ -247,3 +247,63 @@ def test_malformed_records_end_the_stream_like_sam_read1(tmp_path):
     assert n_records(big_b) == 5
     bad_sub = record("b", 0, 0, 5, 60, "50M", aux=b"ZBB?" + struct.pack("<i", 1) + b"\0" * 4)
     assert n_records(bad_sub) == 5
+
+
+# ---- the record walk ahead of the walker (round 6: the inflate threads walk 1 MiB segments speculatively) ----------------------
+def run_mode(path, threads, serial):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1")
+    if serial:
+        env["PALACE_BAM_SERIAL_WALK"] = "1"
+    p = subprocess.run([HOSTDUMP, "bam", path, str(threads)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    return p.returncode, p.stdout, p.stderr.decode()[-300:]
+
+
+def test_the_walk_ahead_gives_the_serial_walk_on_streams_full_of_fake_record_chains(tmp_path):
+    """A ~9 MB stream (nine segments) in which most records carry an auxiliary byte array that READS like five well-formed records in a
+    row -- what the speculation's entry search takes for a record start --, two records larger than a segment, records of every size in
+    between; the same file cut short at member boundaries and inside a record.  The loader with the segments walked ahead must print what
+    the walker alone prints (same records, same columns, same SA items, same exit status), for 1, 3 and 8 threads."""
+    import random
+    rnd = random.Random(11)
+    fake_one = lambda i: (lambda body: struct.pack("<I", len(body)) + body)(
+        struct.pack("<iiBBHHHIiii", i % 3, 10 * i, 2, 30, 4680, 0, 0, 0, -1, -1, 0) + b"x\0")
+    fake = b"".join(fake_one(i) for i in range(5))
+    recs = []
+    pos = 0
+    for i in range(21000):
+        tid = 0 if i < 9000 else 1 if i < 12000 else 2
+        if i in (9000, 12000):
+            pos = 0
+        pos += rnd.randrange(0, 3)
+        L = rnd.choice((36, 100, 150, 150, 150, 251, 1000))
+        if i in (4000, 15000):
+            L = 800_000                                                  # 1.2 MB records: longer than a segment
+        aux = aux_C("NM", i % 7)
+        if i % 4:
+            aux += aux_B("ZF", "C", list(fake))
+        if i % 50 == 0:
+            aux += aux_Z("SA", f"{TARGETS[2][0]},{100 + i},+,40M{L - 40}S,60,1;")
+        recs.append(record(f"r{i}", 99 if i % 2 else 147, tid, min(pos, TARGETS[tid][1] - 1), 60, f"{L}M", mtid=(tid + i % 2) % 3, mpos=5, aux=aux))
+    raw = header(TARGETS) + b"".join(recs)
+    assert len(raw) > 8 * (1 << 20)
+    members = [bgzf_member(raw[i:i + 60000], level=1) for i in range(0, len(raw), 60000)]
+    full = str(tmp_path / "fake_chains.bam")
+    write(full, members + [EOF_MEMBER])
+    want = run_mode(full, 3, True)
+    assert want[0] == 0 and want[1].count(b"\n") == len(recs) + len(TARGETS)
+    for threads in (1, 3, 8):
+        assert run_mode(full, threads, False) == want, threads
+    tr = subprocess.run([HOSTDUMP, "bamtime", full, "8"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, PALACE_TRACE="1"), timeout=300)
+    import re
+    m = re.search(r"(\d+) of (\d+) record boundaries came from the segments walked ahead", tr.stderr.decode())
+    assert m and int(m.group(2)) == len(recs) and int(m.group(1)) > 0, tr.stderr.decode()[-500:]      # (the speculation did take part)
+    asan = run(HOSTDUMP_ASAN, full, "4")                                    # (and under AddressSanitizer + UBSan)
+    assert asan[0] == 0 and asan[1].encode() == want[1]
+    # cut short: whole members missing (no EOF block), and the stream ending inside a record
+    for k, cut in enumerate((len(members) // 3, len(members) - 2)):
+        part = str(tmp_path / f"cut{k}.bam")
+        write(part, members[:cut])
+        a = run_mode(part, 3, True)
+        assert a[1].count(b"\n") < want[1].count(b"\n")
+        for threads in (2, 8):
+            assert run_mode(part, threads, False) == a, (k, threads)
